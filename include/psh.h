@@ -1,0 +1,148 @@
+/*
+ * psh.h -- C ABI of libpsh_hip.so: the MI355X (gfx950) k-nearest-path scan.
+ *
+ * This is the drop-in boundary for ONE hot path of RudyMorel/shadowing:
+ * PathShadowing.shadow() with the Identity embedding, the RelativeMSE distance
+ * and a PredictionContext -- the sliding-window distance scan over an ensemble
+ * of R trajectories followed by the top-k selection.  The reference has no FFI
+ * of its own (it is pure Python on torch); the seam these entry points sit
+ * under is PathShadowing.batched_distance (reference
+ * shadowing/path_shadowing/path_shadowing.py:97-179) and the path gather of
+ * shadow() (path_shadowing.py:211-216).  INTEGRATION.md shows the ctypes stub
+ * a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; every pointer marked "device" is HBM on `device`.
+ *   - the caller owns every buffer (torch tensors -> data_ptr()); the library
+ *     allocates nothing persistent and keeps no global state.
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t, NULL = the
+ *     default stream) and returns; the caller synchronises.
+ *   - return value: PSH_OK or a negative PSH_ERR_*; nothing throws or aborts.
+ *   - re-entrant and thread-safe given distinct workspaces.
+ *   - results are bit-exact with the reference's CPU run (cuda=False): float32
+ *     distances d = fl(fl(sqrt(acc))/||x||) with acc the sequential fp32 FMA
+ *     chain over the window, indices (r_global, t) int32, rows sorted by
+ *     (d, r, t) ascending -- the canonical order among the reference's
+ *     arbitrarily ordered exact ties.
+ */
+#ifndef PSH_H
+#define PSH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSH_VERSION 1
+
+#define PSH_OK                 0
+#define PSH_ERR_ARG           -1   /* NULL pointer / non-positive size / k > number of windows */
+#define PSH_ERR_UNSUPPORTED   -2   /* W > PSH_MAX_W, k > PSH_MAX_K, index would overflow int32 */
+#define PSH_ERR_WORKSPACE     -3   /* workspace too small (see psh_workspace_bytes) */
+#define PSH_ERR_HIP           -4   /* a HIP runtime call failed (psh_last_hip_error) */
+
+#define PSH_MAX_W      256         /* longest query window handled natively */
+#define PSH_MAX_K      16384       /* largest k handled natively */
+
+/* per-query status words written to `out_status` (device) by psh_scan_topk */
+#define PSH_STATUS_OK        0
+#define PSH_STATUS_OVERFLOW  1     /* candidate buffer overflowed: results of that query are
+                                      INVALID, rerun it with psh_scan_topk_exhaustive */
+
+/* Stage timings (milliseconds, HIP events on `stream`) filled when a non-NULL
+ * psh_profile is passed; doing so makes the call synchronise the stream. */
+typedef struct psh_profile {
+    float prep_ms;        /* query norms + state reset                      */
+    float sample_ms;      /* sample-rows scan -> histogram of lane minima   */
+    float threshold_ms;   /* histogram -> admission threshold               */
+    float scan_ms;        /* the full sliding-window scan + filter (HBM-bound kernel) */
+    float select_ms;      /* radix select + bitonic sort of the survivors   */
+    float total_ms;
+    int   path;           /* 0 = sampled threshold path, 1 = exhaustive path */
+    int   n_sample_rows;
+    int   grid_blocks;    /* blocks of the scan kernel */
+    int   reserved;
+} psh_profile;
+
+int         psh_version(void);
+const char* psh_strerror(int code);
+const char* psh_last_hip_error(void);   /* text of the last failing HIP call on this thread */
+
+/*
+ * Bytes of device workspace psh_scan_topk / psh_scan_topk_exhaustive want for
+ * this problem (a larger workspace is used as a larger candidate buffer).
+ */
+int psh_workspace_bytes(int64_t R, int64_t T, int B, int W, int h, int k, size_t* out_bytes);
+
+/*
+ * ||x||_2 of each query in the reduction order of the reference's
+ * x.norm(dim=-1) (path_distance.py:65).  queries: device B x W.  out: device B.
+ */
+int psh_query_norm(int device, void* stream, const float* queries, int B, int W, float* out_qnorm);
+
+/*
+ * The scan: k nearest windows of every query.  Replaces the loop body of
+ * PathShadowing.batched_distance (path_shadowing.py:149-173: embed, distance,
+ * topk, index decode, running merge) for Identity + RelativeMSE +
+ * PredictionContext(horizon = h).
+ *
+ *   dataset   device, R x T row-major float32 (single channel), resident in HBM
+ *   r_offset  added to the row index in out_idx (shard -> global row)
+ *   queries   device, B x W float32
+ *   qnorm     device, B floats, or NULL: computed as psh_query_norm does
+ *   h         PredictionContext.horizon (0 for None): windows t in [0, T-W-h]
+ *   out_d     device, B x k float32, ascending
+ *   out_idx   device, B x k x 2 int32 = [r_offset + r, t]
+ *   out_status device, B int32 (PSH_STATUS_*)
+ *
+ * Requires R*(T-W-h+1) >= k (the reference raises for k larger than a split,
+ * path_shadowing.py:165) and r_offset + R, T < 2^31.
+ */
+int psh_scan_topk(int device, void* stream,
+                  const float* dataset, int64_t R, int64_t T, int64_t r_offset,
+                  const float* queries, const float* qnorm, int B, int W, int h, int k,
+                  float* out_d, int32_t* out_idx, int32_t* out_status,
+                  void* workspace, size_t workspace_bytes, psh_profile* profile);
+
+/*
+ * Same contract, no sampling and no admission threshold: the dataset is
+ * processed in row chunks whose every window fits the candidate buffer.
+ * Always exact (any amount of ties), several times slower.  out_status is
+ * always PSH_STATUS_OK.
+ */
+int psh_scan_topk_exhaustive(int device, void* stream,
+                             const float* dataset, int64_t R, int64_t T, int64_t r_offset,
+                             const float* queries, const float* qnorm, int B, int W, int h, int k,
+                             float* out_d, int32_t* out_idx, int32_t* out_status,
+                             void* workspace, size_t workspace_bytes, psh_profile* profile);
+
+/*
+ * Merge G sorted-or-not candidate lists per query into the k best by (d, r, t):
+ * the running merge of path_shadowing.py:170-173 and the cross-GPU merge after
+ * the all-gather of per-shard results.
+ *   d_lists   device, B x n_in float32   (n_in = G * k_in, lists concatenated)
+ *   idx_lists device, B x n_in x 2 int32 (entries with r < 0 are padding)
+ *   workspace device, >= psh_merge_workspace_bytes(B, k)
+ */
+int psh_merge_workspace_bytes(int B, int k, size_t* out_bytes);
+int psh_merge_topk(int device, void* stream,
+                   const float* d_lists, const int32_t* idx_lists, int B, int n_in, int k,
+                   float* out_d, int32_t* out_idx, void* workspace, size_t workspace_bytes);
+
+/*
+ * Path gather of shadow() (path_shadowing.py:211-216):
+ *   out[i, c, :] = dataset[idx[i,0] - r_offset, c, idx[i,1] : idx[i,1] + len]
+ * dataset: device R x C x T;  idx: device n x 2;  out: device n x C x len.
+ * Entries whose row is outside [0, R) (other shards' rows, padding) are left
+ * untouched.
+ */
+int psh_gather_paths(int device, void* stream,
+                     const float* dataset, int64_t R, int64_t C, int64_t T, int64_t r_offset,
+                     const int32_t* idx, int64_t n, int len, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSH_H */

@@ -1,0 +1,125 @@
+"""ctypes front-end of oracle/libpsh_oracle.so (test infrastructure only)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_SO = _HERE / "libpsh_oracle.so"
+_lib = None
+
+
+def build(force: bool = False) -> Path:
+    """Compile psh_oracle.c with the committed Makefile (gcc, a second or two)."""
+    src = _HERE / "psh_oracle.c"
+    if force or not _SO.exists() or _SO.stat().st_mtime < src.stat().st_mtime:
+        subprocess.run(["make", "-C", str(_HERE), "-B"], check=True, capture_output=True)
+    return _SO
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not _SO.exists():
+            build()
+        L = C.CDLL(str(_SO))
+        f32p, i32p = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        L.psh_oracle_qnorm.restype = C.c_float
+        L.psh_oracle_qnorm.argtypes = [f32p, C.c_int]
+        L.psh_oracle_scan_topk.restype = C.c_int
+        L.psh_oracle_scan_topk.argtypes = [f32p, C.c_int64, C.c_int64, C.c_int64, f32p, f32p,
+                                           C.c_int, C.c_int, C.c_int, C.c_int, f32p, i32p, C.c_int]
+        L.psh_oracle_all_distances.restype = C.c_int
+        L.psh_oracle_all_distances.argtypes = [f32p, C.c_int64, C.c_int64, f32p, C.c_float,
+                                               C.c_int, C.c_int, f32p]
+        L.psh_oracle_gather_paths.restype = C.c_int
+        L.psh_oracle_gather_paths.argtypes = [f32p, C.c_int64, C.c_int64, C.c_int64, i32p,
+                                              C.c_int64, C.c_int, f32p]
+        _lib = L
+    return _lib
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+
+
+def _p(a: np.ndarray, ty):
+    return a.ctypes.data_as(C.POINTER(ty))
+
+
+def _rows(dataset) -> np.ndarray:
+    ds = _f32(dataset)
+    if ds.ndim == 3:
+        if ds.shape[1] != 1:
+            raise ValueError("oracle covers the single-channel path only")
+        ds = ds[:, 0, :]
+    elif ds.ndim == 1:
+        ds = ds[None, :]
+    return np.ascontiguousarray(ds)
+
+
+def qnorm(queries) -> np.ndarray:
+    """||x|| per query in the reference's reduction order (path_distance.py:65)."""
+    q = np.atleast_2d(_f32(queries))
+    return np.array([lib().psh_oracle_qnorm(_p(np.ascontiguousarray(r), C.c_float), q.shape[1])
+                     for r in q], dtype=np.float32)
+
+
+def scan_topk(dataset, queries, k: int, h: int = 0, r_offset: int = 0, qn=None,
+              nthreads: int = 0):
+    """(d (B,k) f32, idx (B,k,2) i32), canonical order (d, r, t) ascending."""
+    ds = _rows(dataset)
+    q = np.atleast_2d(_f32(queries))
+    B, W = q.shape
+    R, T = ds.shape
+    d = np.empty((B, k), np.float32)
+    idx = np.empty((B, k, 2), np.int32)
+    qn_arr = None if qn is None else _f32(qn).reshape(B)
+    rc = lib().psh_oracle_scan_topk(_p(ds, C.c_float), R, T, r_offset, _p(q, C.c_float),
+                                    None if qn_arr is None else _p(qn_arr, C.c_float),
+                                    B, W, h, k, _p(d, C.c_float), _p(idx, C.c_int32), nthreads)
+    if rc != 0:
+        raise RuntimeError(f"psh_oracle_scan_topk failed: {rc}")
+    return d, idx
+
+
+def all_distances(dataset, query, h: int = 0, qn=None) -> np.ndarray:
+    ds = _rows(dataset)
+    x = _f32(query).reshape(-1)
+    R, T = ds.shape
+    W = x.shape[0]
+    Tp = T - W - h + 1
+    out = np.empty((R, Tp), np.float32)
+    xn = float(qnorm(x)[0]) if qn is None else float(qn)
+    rc = lib().psh_oracle_all_distances(_p(ds, C.c_float), R, T, _p(x, C.c_float), xn, W, h,
+                                        _p(out, C.c_float))
+    if rc != 0:
+        raise RuntimeError("psh_oracle_all_distances failed")
+    return out
+
+
+def gather_paths(dataset, idx, length: int, r_offset: int = 0) -> np.ndarray:
+    ds = _rows(dataset)
+    ix = np.ascontiguousarray(idx, dtype=np.int32)
+    n = ix.size // 2
+    out = np.empty(ix.shape[:-1] + (length,), np.float32)
+    rc = lib().psh_oracle_gather_paths(_p(ds, C.c_float), ds.shape[0], ds.shape[1], r_offset,
+                                       _p(ix, C.c_int32), n, length, _p(out, C.c_float))
+    if rc != 0:
+        raise RuntimeError("psh_oracle_gather_paths: index out of range")
+    return out
+
+
+def shadow(dataset, x_context, k: int, horizon=None, nthreads: int = 0):
+    """Whole shadow() result of path_shadowing.py:181-218 for the Identity +
+    RelativeMSE + PredictionContext(horizon) configuration:
+    (d (B,k), paths (B,k,1,W+h), idx (B,k,2))."""
+    h = 0 if horizon is None else int(horizon)
+    q = np.atleast_2d(_f32(x_context).reshape(-1, np.asarray(x_context).shape[-1]))
+    d, idx = scan_topk(dataset, q, k, h=h, nthreads=nthreads)
+    paths = gather_paths(dataset, idx, q.shape[1] + h)[:, :, None, :]
+    return d, paths, idx

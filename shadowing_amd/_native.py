@@ -1,0 +1,210 @@
+"""ctypes binding of libpsh_hip.so (include/psh.h) on PyTorch-ROCm tensors.
+
+PyTorch is plumbing here: device memory, streams, the caching allocator.  All
+compute goes through the C ABI.  There is NO CPU fallback in this module: if the
+library cannot be loaded, or a tensor is not on a HIP device, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import torch
+
+from . import _build
+
+PSH_OK = 0
+PSH_STATUS_OK, PSH_STATUS_OVERFLOW = 0, 1
+PSH_MAX_W, PSH_MAX_K = 256, 16384
+
+
+class NativeLibraryError(RuntimeError):
+    """The HIP extension is missing or failed."""
+
+
+class PshProfile(C.Structure):
+    _fields_ = [("prep_ms", C.c_float), ("sample_ms", C.c_float), ("threshold_ms", C.c_float),
+                ("scan_ms", C.c_float), ("select_ms", C.c_float), ("total_ms", C.c_float),
+                ("path", C.c_int), ("n_sample_rows", C.c_int), ("grid_blocks", C.c_int),
+                ("reserved", C.c_int)]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
+
+
+EXPORTS = ("psh_version", "psh_strerror", "psh_last_hip_error", "psh_workspace_bytes", "psh_query_norm",
+           "psh_scan_topk", "psh_scan_topk_exhaustive", "psh_merge_workspace_bytes", "psh_merge_topk",
+           "psh_gather_paths")
+
+_lib = None
+
+
+def library_path() -> Path:
+    return _build.LIB
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library (never builds implicitly on a GPU box: the built
+    .so travels with the tree; __graft_entry__.build() / `python -m shadowing_amd._build`
+    produce it)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not path.exists():
+        raise NativeLibraryError(
+            f"{path} is missing: build it with `python -m shadowing_amd._build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for cuda=True.")
+    try:
+        L = C.CDLL(str(path))
+    except OSError as e:  # pragma: no cover
+        raise NativeLibraryError(f"cannot load {path}: {e}") from e
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+    L.psh_version.restype = i32
+    L.psh_strerror.restype = C.c_char_p
+    L.psh_strerror.argtypes = [i32]
+    L.psh_last_hip_error.restype = C.c_char_p
+    L.psh_workspace_bytes.restype = i32
+    L.psh_workspace_bytes.argtypes = [i64, i64, i32, i32, i32, i32, C.POINTER(C.c_size_t)]
+    L.psh_query_norm.restype = i32
+    L.psh_query_norm.argtypes = [i32, vp, vp, i32, i32, vp]
+    scan_args = [i32, vp, vp, i64, i64, i64, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, C.c_size_t,
+                 C.POINTER(PshProfile)]
+    L.psh_scan_topk.restype = i32
+    L.psh_scan_topk.argtypes = scan_args
+    L.psh_scan_topk_exhaustive.restype = i32
+    L.psh_scan_topk_exhaustive.argtypes = scan_args
+    L.psh_merge_workspace_bytes.restype = i32
+    L.psh_merge_workspace_bytes.argtypes = [i32, i32, C.POINTER(C.c_size_t)]
+    L.psh_merge_topk.restype = i32
+    L.psh_merge_topk.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, C.c_size_t]
+    L.psh_gather_paths.restype = i32
+    L.psh_gather_paths.argtypes = [i32, vp, vp, i64, i64, i64, i64, vp, i64, i32, vp]
+    _lib = L
+    return L
+
+
+def _check(rc: int, what: str):
+    if rc == PSH_OK:
+        return
+    L = load()
+    msg = L.psh_strerror(rc).decode()
+    if rc == -4:
+        msg += ": " + L.psh_last_hip_error().decode()
+    if rc == -1:
+        raise ValueError(f"{what}: {msg}")
+    raise NativeLibraryError(f"{what}: {msg} (code {rc})")
+
+
+def _dev_tensor(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise NativeLibraryError(f"{name} must be a tensor on a HIP device (got {type(t).__name__} "
+                                 f"on {getattr(t, 'device', '?')}); there is no CPU path here")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+def _stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def workspace_bytes(R: int, T: int, B: int, W: int, h: int, k: int) -> int:
+    out = C.c_size_t(0)
+    _check(load().psh_workspace_bytes(R, T, B, W, h, k, C.byref(out)), "psh_workspace_bytes")
+    return int(out.value)
+
+
+class Workspace:
+    """Caller-owned scratch of the scan (a torch uint8 tensor), grown on demand."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.buf = None
+
+    def get(self, nbytes: int) -> torch.Tensor:
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+def query_norm(queries: torch.Tensor) -> torch.Tensor:
+    q = _dev_tensor(queries, torch.float32, "queries")
+    B, W = q.shape
+    out = torch.empty(B, dtype=torch.float32, device=q.device)
+    _check(load().psh_query_norm(q.device.index, _stream_ptr(q.device), q.data_ptr(), B, W, out.data_ptr()),
+           "psh_query_norm")
+    return out
+
+
+def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, r_offset: int = 0,
+              qnorm: torch.Tensor | None = None, workspace: Workspace | None = None,
+              exhaustive: bool = False, profile: bool = False, extra_workspace_factor: float = 1.0):
+    """Enqueue the scan on the current stream.
+
+    dataset (R, T) float32 device, queries (B, W) float32 device.  Returns
+    (d (B,k) f32, idx (B,k,2) i32, status (B,) i32[, profile dict]) -- device tensors,
+    NOT synchronised; status must be inspected (after a sync) unless exhaustive=True.
+    """
+    ds = _dev_tensor(dataset, torch.float32, "dataset")
+    q = _dev_tensor(queries, torch.float32, "queries")
+    if ds.dim() != 2 or q.dim() != 2:
+        raise ValueError("dataset must be (R, T) and queries (B, W)")
+    if q.device != ds.device:
+        raise ValueError("dataset and queries must live on the same device")
+    R, T = ds.shape
+    B, W = q.shape
+    dev = ds.device
+    if qnorm is not None:
+        qnorm = _dev_tensor(qnorm, torch.float32, "qnorm")
+    nbytes = int(workspace_bytes(R, T, B, W, h, k) * extra_workspace_factor)
+    ws = (workspace or Workspace(dev)).get(nbytes)
+    out_d = torch.empty((B, k), dtype=torch.float32, device=dev)
+    out_idx = torch.empty((B, k, 2), dtype=torch.int32, device=dev)
+    status = torch.empty((B,), dtype=torch.int32, device=dev)
+    prof = PshProfile() if profile else None
+    fn = load().psh_scan_topk_exhaustive if exhaustive else load().psh_scan_topk
+    rc = fn(dev.index, _stream_ptr(dev), ds.data_ptr(), R, T, r_offset, q.data_ptr(),
+            None if qnorm is None else qnorm.data_ptr(), B, W, h, k,
+            out_d.data_ptr(), out_idx.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(),
+            C.byref(prof) if prof is not None else None)
+    _check(rc, "psh_scan_topk_exhaustive" if exhaustive else "psh_scan_topk")
+    if profile:
+        return out_d, out_idx, status, prof.as_dict()
+    return out_d, out_idx, status
+
+
+def merge_topk(d_lists: torch.Tensor, idx_lists: torch.Tensor, k: int):
+    """k best by (d, r, t) out of (B, n) candidates; entries with r < 0 are padding."""
+    d = _dev_tensor(d_lists, torch.float32, "d_lists")
+    ix = _dev_tensor(idx_lists, torch.int32, "idx_lists")
+    B, n = d.shape
+    if tuple(ix.shape) != (B, n, 2):
+        raise ValueError("idx_lists must be (B, n, 2)")
+    need = C.c_size_t(0)
+    _check(load().psh_merge_workspace_bytes(B, k, C.byref(need)), "psh_merge_workspace_bytes")
+    ws = torch.empty(int(need.value), dtype=torch.uint8, device=d.device)
+    out_d = torch.empty((B, k), dtype=torch.float32, device=d.device)
+    out_idx = torch.empty((B, k, 2), dtype=torch.int32, device=d.device)
+    _check(load().psh_merge_topk(d.device.index, _stream_ptr(d.device), d.data_ptr(), ix.data_ptr(), B, n, k,
+                                 out_d.data_ptr(), out_idx.data_ptr(), ws.data_ptr(), ws.numel()),
+           "psh_merge_topk")
+    return out_d, out_idx
+
+
+def gather_paths(dataset: torch.Tensor, idx: torch.Tensor, length: int, r_offset: int = 0,
+                 out: torch.Tensor | None = None) -> torch.Tensor:
+    """out[b, i, c, :] = dataset[idx[b,i,0] - r_offset, c, idx[b,i,1] : +length]; dataset (R, C, T)."""
+    ds = _dev_tensor(dataset, torch.float32, "dataset")
+    ix = _dev_tensor(idx, torch.int32, "idx")
+    if ds.dim() != 3:
+        raise ValueError("dataset must be (R, C, T)")
+    R, Cc, T = ds.shape
+    n = ix.numel() // 2
+    if out is None:
+        out = torch.zeros(tuple(ix.shape[:-1]) + (Cc, length), dtype=torch.float32, device=ds.device)
+    _check(load().psh_gather_paths(ds.device.index, _stream_ptr(ds.device), ds.data_ptr(), R, Cc, T, r_offset,
+                                   ix.data_ptr(), n, length, out.data_ptr()), "psh_gather_paths")
+    return out

@@ -1,0 +1,431 @@
+// psh_capi.hip -- the C ABI declared in include/psh.h: argument checking, workspace
+// carving, launch planning.  Everything is enqueued on the caller's stream; no
+// allocation, no global state (a thread-local string holds the last HIP error text).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "psh.h"
+#include "psh_kernels.h"
+
+using namespace psh;
+
+namespace {
+
+thread_local char g_hip_err[256] = "";
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess) {                                                             \
+            snprintf(g_hip_err, sizeof(g_hip_err), "%s -> %s (%s:%d)", #expr,                \
+                     hipGetErrorString(e__), __FILE__, __LINE__);                            \
+            return PSH_ERR_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+
+struct DeviceGuard {   // launch on the caller's device, restore the previous one
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != device && hipSetDevice(device) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline int next_pow2(int x) { int p = 2; while (p < x) p <<= 1; return p; }
+inline int tile_floats_for(int W) {
+    const int logical = PSH_SEG + W + 32;               // SEG + W - 1 used, slack for the sliding refills
+    return (logical + ((logical >> 6) << 2) + 8 + 3) & ~3;
+}
+
+struct Workspace {
+    QueryState* qstate;
+    int* counts;
+    unsigned* hist;
+    int2* sel_rt;
+    float* cand_d;
+    int2* cand_rt;
+    int cap;
+    int kpad;
+};
+
+// fixed part + cap * 12 bytes per query
+size_t fixed_bytes(int B, int kpad) {
+    size_t o = 0;
+    o += align_up(sizeof(QueryState) * (size_t)B, 256);
+    o += align_up(sizeof(int) * (size_t)B, 256);
+    o += align_up(sizeof(unsigned) * (size_t)B * PSH_NBINS, 256);
+    o += align_up(sizeof(int2) * (size_t)B * kpad, 256);
+    return o + 512;  // alignment slack for the two candidate arrays
+}
+
+int carve(void* ws, size_t bytes, int B, int k, Workspace* out) {
+    const int kpad = next_pow2(k);
+    const size_t fixed = fixed_bytes(B, kpad);
+    if (!ws || bytes <= fixed) return PSH_ERR_WORKSPACE;
+    int64_t cap = (int64_t)((bytes - fixed) / (12 * (size_t)B));
+    cap &= ~(int64_t)63;
+    if (cap > (1 << 30)) cap = 1 << 30;
+    if (cap <= 0) return PSH_ERR_WORKSPACE;
+    char* p = (char*)ws;
+    if (((uintptr_t)p & 255u) != 0) return PSH_ERR_ARG;   // torch allocations are >= 512-byte aligned
+    out->qstate = (QueryState*)p; p += align_up(sizeof(QueryState) * (size_t)B, 256);
+    out->counts = (int*)p;        p += align_up(sizeof(int) * (size_t)B, 256);
+    out->hist = (unsigned*)p;     p += align_up(sizeof(unsigned) * (size_t)B * PSH_NBINS, 256);
+    out->sel_rt = (int2*)p;       p += align_up(sizeof(int2) * (size_t)B * kpad, 256);
+    out->cand_d = (float*)p;      p += align_up(sizeof(float) * (size_t)B * cap, 256);
+    out->cand_rt = (int2*)p;
+    out->cap = (int)cap;
+    out->kpad = kpad;
+    return PSH_OK;
+}
+
+int recommended_cap(int64_t Tp, int k) {
+    int64_t cap = 64 * (int64_t)k;
+    if (cap < 65536) cap = 65536;
+    if (cap < k + 4 * Tp) cap = k + 4 * Tp;   // exhaustive path: >= 4 rows per chunk
+    return (int)((cap + 63) & ~(int64_t)63);
+}
+
+struct Problem {
+    int64_t R, T, r_offset, Tp, N;
+    int B, W, h, k;
+    bool aligned;
+};
+
+int check_problem(const float* dataset, int64_t R, int64_t T, int64_t r_offset, const float* queries,
+                  int B, int W, int h, int k, float* out_d, int32_t* out_idx, Problem* p) {
+    if (!dataset || !queries || !out_d || !out_idx) return PSH_ERR_ARG;
+    if (R <= 0 || T <= 0 || B <= 0 || W <= 0 || h < 0 || k <= 0 || r_offset < 0) return PSH_ERR_ARG;
+    if (W > PSH_MAX_W || k > PSH_MAX_K) return PSH_ERR_UNSUPPORTED;
+    const int64_t Tp = T - W - h + 1;
+    if (Tp <= 0) return PSH_ERR_ARG;
+    if (T >= (1ll << 31) - PSH_SEG - 1024 || r_offset + R >= (1ll << 31)) return PSH_ERR_UNSUPPORTED;
+    const int64_t N = R * Tp;
+    if ((int64_t)k > N) return PSH_ERR_ARG;   // the reference raises too (topk: k out of range)
+    p->R = R; p->T = T; p->r_offset = r_offset; p->Tp = Tp; p->N = N;
+    p->B = B; p->W = W; p->h = h; p->k = k;
+    p->aligned = (((uintptr_t)dataset & 15u) == 0) && (T % 4 == 0);
+    return PSH_OK;
+}
+
+struct Plan { int grid; int n_qgroups; int q_per_group; int tile_floats; };
+
+int plan_scan(int device, const Problem& p, int64_t n_rows, Plan* plan) {
+    const int tile_floats = tile_floats_for(p.W);
+    const size_t shmem = (size_t)tile_floats * (PSH_SCAN_THREADS / 64) * sizeof(float);
+    int bpc = 0, ncu = 0;
+    HIP_TRY(scan_blocks_per_cu(p.W, p.aligned, shmem, &bpc));
+    HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+    if (bpc < 1) bpc = 1;
+    if (bpc > 8) bpc = 8;
+    const int nseg = (int)((p.Tp + PSH_SEG - 1) / PSH_SEG);
+    const int64_t n_rs = n_rows * nseg;
+    const int64_t waves = (int64_t)bpc * ncu * (PSH_SCAN_THREADS / 64);
+    // not enough (row, segment) units to fill the chip: also split the queries
+    int n_qgroups = 1;
+    if (n_rs < waves && p.B > 1) {
+        int64_t g = (waves + n_rs - 1) / n_rs;
+        n_qgroups = (int)(g < p.B ? g : p.B);
+    }
+    const int q_per_group = (p.B + n_qgroups - 1) / n_qgroups;
+    n_qgroups = (p.B + q_per_group - 1) / q_per_group;
+    const int64_t units = n_rs * n_qgroups;
+    int64_t grid = (units + (PSH_SCAN_THREADS / 64) - 1) / (PSH_SCAN_THREADS / 64);
+    if (grid > (int64_t)bpc * ncu) grid = (int64_t)bpc * ncu;
+    if (grid < 1) grid = 1;
+    plan->grid = (int)grid;
+    plan->n_qgroups = n_qgroups;
+    plan->q_per_group = q_per_group;
+    plan->tile_floats = tile_floats;
+    return PSH_OK;
+}
+
+ScanArgs make_scan_args(const float* dataset, const float* queries, const Problem& p, const Workspace& w,
+                        const Plan& plan, int64_t row0, int64_t row_stride, int64_t n_rows) {
+    ScanArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dataset = dataset;
+    a.T = p.T;
+    a.Tp = (int)p.Tp;
+    a.nseg = (int)((p.Tp + PSH_SEG - 1) / PSH_SEG);
+    a.W = p.W;
+    a.row0 = row0;
+    a.row_stride = row_stride;
+    a.n_rows = (int)n_rows;
+    a.r_offset = p.r_offset;
+    a.queries = queries;
+    a.B = p.B;
+    a.n_qgroups = plan.n_qgroups;
+    a.q_per_group = plan.q_per_group;
+    a.tile_floats = plan.tile_floats;
+    a.qstate = w.qstate;
+    a.hist = w.hist;
+    a.cand_d = w.cand_d;
+    a.cand_rt = w.cand_rt;
+    a.counts = w.counts;
+    a.cap = w.cap;
+    return a;
+}
+
+SelectArgs make_select_args(const Problem& p, const Workspace& w, float* out_d, int32_t* out_idx, int* status) {
+    SelectArgs s;
+    memset(&s, 0, sizeof(s));
+    s.cand_d = w.cand_d;
+    s.cand_rt = w.cand_rt;
+    s.cand_stride = w.cap;
+    s.counts = w.counts;
+    s.n_fixed = 0;
+    s.cap = w.cap;
+    s.k = p.k;
+    s.kpad = w.kpad;
+    s.skip_negative_rows = 0;
+    s.out_d = out_d;
+    s.out_idx = out_idx;
+    s.sel_rt = w.sel_rt;
+    s.status = status;
+    s.qstate = w.qstate;
+    return s;
+}
+
+struct Timer {   // optional per-stage HIP events
+    bool on;
+    hipStream_t s;
+    hipEvent_t ev[8];
+    int n = 0;
+    Timer(bool enable, hipStream_t stream) : on(enable), s(stream) {}
+    int init() {
+        if (!on) return PSH_OK;
+        for (int i = 0; i < 8; ++i) HIP_TRY(hipEventCreate(&ev[i]));
+        return PSH_OK;
+    }
+    int mark() {
+        if (!on) return PSH_OK;
+        HIP_TRY(hipEventRecord(ev[n++], s));
+        return PSH_OK;
+    }
+    int elapsed(int i, int j, float* ms) {
+        *ms = 0.f;
+        if (!on) return PSH_OK;
+        HIP_TRY(hipEventElapsedTime(ms, ev[i], ev[j]));
+        return PSH_OK;
+    }
+    ~Timer() { if (on) for (int i = 0; i < 8; ++i) (void)hipEventDestroy(ev[i]); }
+};
+
+int run_exhaustive(int device, hipStream_t s, const float* dataset, const float* queries, const float* qnorm,
+                   const Problem& p, const Workspace& w, float* out_d, int32_t* out_idx, int32_t* out_status,
+                   psh_profile* prof) {
+    if ((int64_t)w.cap < (int64_t)p.k + p.Tp) return PSH_ERR_WORKSPACE;
+    Timer tm(prof != nullptr, s);
+    int rc = tm.init(); if (rc) return rc;
+    rc = tm.mark(); if (rc) return rc;
+    PrepArgs pa{queries, qnorm, p.B, p.W, w.qstate, w.counts, out_status};
+    HIP_TRY(launch_prep(pa, s));
+    rc = tm.mark(); if (rc) return rc;
+    int64_t rows_per_chunk = ((int64_t)w.cap - p.k) / p.Tp;
+    if (rows_per_chunk > p.R) rows_per_chunk = p.R;
+    int grid_used = 0;
+    for (int64_t r0 = 0; r0 < p.R; r0 += rows_per_chunk) {
+        const int64_t nr = (r0 + rows_per_chunk <= p.R) ? rows_per_chunk : (p.R - r0);
+        Plan plan;
+        rc = plan_scan(device, p, nr, &plan); if (rc) return rc;
+        grid_used = plan.grid;
+        if (r0 > 0) {
+            ReseedArgs ra{out_d, out_idx, w.qstate, w.cand_d, w.cand_rt, w.counts, w.cap, p.k};
+            HIP_TRY(launch_reseed(ra, p.B, s));
+        }
+        ScanArgs sa = make_scan_args(dataset, queries, p, w, plan, r0, 1, nr);
+        HIP_TRY(launch_scan(sa, PSH_MODE_ALL, p.aligned, plan.grid, s));
+        SelectArgs se = make_select_args(p, w, out_d, out_idx, nullptr);   // cannot overflow by construction
+        HIP_TRY(launch_select(se, p.B, s));
+    }
+    rc = tm.mark(); if (rc) return rc;
+    if (prof) {
+        HIP_TRY(hipStreamSynchronize(s));
+        memset(prof, 0, sizeof(*prof));
+        tm.elapsed(0, 1, &prof->prep_ms);
+        tm.elapsed(1, 2, &prof->scan_ms);
+        tm.elapsed(0, 2, &prof->total_ms);
+        prof->path = 1;
+        prof->grid_blocks = grid_used;
+    }
+    return PSH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int psh_version(void) { return PSH_VERSION; }
+
+const char* psh_strerror(int code) {
+    switch (code) {
+        case PSH_OK: return "ok";
+        case PSH_ERR_ARG: return "invalid argument (null pointer, non-positive size, k larger than the number of windows, misaligned workspace)";
+        case PSH_ERR_UNSUPPORTED: return "unsupported size (W > PSH_MAX_W, k > PSH_MAX_K, or int32 index overflow)";
+        case PSH_ERR_WORKSPACE: return "workspace too small (see psh_workspace_bytes)";
+        case PSH_ERR_HIP: return "HIP runtime error (see psh_last_hip_error)";
+        default: return "unknown error";
+    }
+}
+
+const char* psh_last_hip_error(void) { return g_hip_err; }
+
+int psh_workspace_bytes(int64_t R, int64_t T, int B, int W, int h, int k, size_t* out_bytes) {
+    if (!out_bytes || R <= 0 || T <= 0 || B <= 0 || W <= 0 || h < 0 || k <= 0) return PSH_ERR_ARG;
+    if (W > PSH_MAX_W || k > PSH_MAX_K) return PSH_ERR_UNSUPPORTED;
+    const int64_t Tp = T - W - h + 1;
+    if (Tp <= 0) return PSH_ERR_ARG;
+    const int cap = recommended_cap(Tp, k);
+    *out_bytes = fixed_bytes(B, next_pow2(k)) + (size_t)12 * (size_t)B * (size_t)cap + 64 * 12 * (size_t)B;
+    return PSH_OK;
+}
+
+int psh_query_norm(int device, void* stream, const float* queries, int B, int W, float* out_qnorm) {
+    if (!queries || !out_qnorm || B <= 0 || W <= 0) return PSH_ERR_ARG;
+    DeviceGuard g(device);
+    if (!g.ok) { snprintf(g_hip_err, sizeof(g_hip_err), "hipSetDevice(%d) failed", device); return PSH_ERR_HIP; }
+    HIP_TRY(launch_qnorm(queries, B, W, out_qnorm, (hipStream_t)stream));
+    return PSH_OK;
+}
+
+int psh_scan_topk_exhaustive(int device, void* stream, const float* dataset, int64_t R, int64_t T, int64_t r_offset,
+                             const float* queries, const float* qnorm, int B, int W, int h, int k,
+                             float* out_d, int32_t* out_idx, int32_t* out_status,
+                             void* workspace, size_t workspace_bytes, psh_profile* profile) {
+    Problem p;
+    int rc = check_problem(dataset, R, T, r_offset, queries, B, W, h, k, out_d, out_idx, &p);
+    if (rc) return rc;
+    Workspace w;
+    rc = carve(workspace, workspace_bytes, B, k, &w);
+    if (rc) return rc;
+    DeviceGuard g(device);
+    if (!g.ok) { snprintf(g_hip_err, sizeof(g_hip_err), "hipSetDevice(%d) failed", device); return PSH_ERR_HIP; }
+    return run_exhaustive(device, (hipStream_t)stream, dataset, queries, qnorm, p, w, out_d, out_idx, out_status, profile);
+}
+
+int psh_scan_topk(int device, void* stream, const float* dataset, int64_t R, int64_t T, int64_t r_offset,
+                  const float* queries, const float* qnorm, int B, int W, int h, int k,
+                  float* out_d, int32_t* out_idx, int32_t* out_status,
+                  void* workspace, size_t workspace_bytes, psh_profile* profile) {
+    Problem p;
+    int rc = check_problem(dataset, R, T, r_offset, queries, B, W, h, k, out_d, out_idx, &p);
+    if (rc) return rc;
+    if (!out_status) return PSH_ERR_ARG;
+    Workspace w;
+    rc = carve(workspace, workspace_bytes, B, k, &w);
+    if (rc) return rc;
+    if ((int64_t)w.cap < (int64_t)k + p.Tp) return PSH_ERR_WORKSPACE;
+    DeviceGuard g(device);
+    if (!g.ok) { snprintf(g_hip_err, sizeof(g_hip_err), "hipSetDevice(%d) failed", device); return PSH_ERR_HIP; }
+    hipStream_t s = (hipStream_t)stream;
+
+    // ---- plan the sample: expected survivors ~ k * R / n_sample_rows <= cap / 4, and the
+    // sample must hold >= 4k lane minima for the bound to be tight.
+    const int64_t lanes_per_row = (p.Tp + PSH_L - 1) / PSH_L;
+    int64_t ns_a = (4 * (int64_t)k * p.R + w.cap - 1) / w.cap;
+    int64_t ns_b = (4 * (int64_t)k + lanes_per_row - 1) / lanes_per_row;
+    int64_t n_sample = ns_a > ns_b ? ns_a : ns_b;
+    if (n_sample < 1) n_sample = 1;
+    // small problems (everything fits the candidate buffer) or an unhelpful sample: exhaustive
+    if (p.N + k <= (int64_t)w.cap || 2 * n_sample > p.R)
+        return run_exhaustive(device, s, dataset, queries, qnorm, p, w, out_d, out_idx, out_status, profile);
+    const int64_t stride = p.R / n_sample;
+    const int64_t row0 = stride / 2;
+
+    Timer tm(profile != nullptr, s);
+    rc = tm.init(); if (rc) return rc;
+    rc = tm.mark(); if (rc) return rc;                                       // 0
+    PrepArgs pa{queries, qnorm, B, W, w.qstate, w.counts, out_status};
+    HIP_TRY(launch_prep(pa, s));
+    HIP_TRY(hipMemsetAsync(w.hist, 0, sizeof(unsigned) * (size_t)B * PSH_NBINS, s));
+    rc = tm.mark(); if (rc) return rc;                                       // 1
+
+    Plan plan_s;
+    rc = plan_scan(device, p, n_sample, &plan_s); if (rc) return rc;
+    ScanArgs sa = make_scan_args(dataset, queries, p, w, plan_s, row0, stride, n_sample);
+    HIP_TRY(launch_scan(sa, PSH_MODE_SAMPLE, p.aligned, plan_s.grid, s));
+    rc = tm.mark(); if (rc) return rc;                                       // 2
+
+    ThresholdArgs ta{w.hist, w.qstate, k};
+    HIP_TRY(launch_threshold(ta, B, s));
+    rc = tm.mark(); if (rc) return rc;                                       // 3
+
+    Plan plan_f;
+    rc = plan_scan(device, p, p.R, &plan_f); if (rc) return rc;
+    ScanArgs fa = make_scan_args(dataset, queries, p, w, plan_f, 0, 1, p.R);
+    HIP_TRY(launch_scan(fa, PSH_MODE_FILTER, p.aligned, plan_f.grid, s));
+    rc = tm.mark(); if (rc) return rc;                                       // 4
+
+    SelectArgs se = make_select_args(p, w, out_d, out_idx, out_status);
+    HIP_TRY(launch_select(se, B, s));
+    rc = tm.mark(); if (rc) return rc;                                       // 5
+
+    if (profile) {
+        HIP_TRY(hipStreamSynchronize(s));
+        memset(profile, 0, sizeof(*profile));
+        tm.elapsed(0, 1, &profile->prep_ms);
+        tm.elapsed(1, 2, &profile->sample_ms);
+        tm.elapsed(2, 3, &profile->threshold_ms);
+        tm.elapsed(3, 4, &profile->scan_ms);
+        tm.elapsed(4, 5, &profile->select_ms);
+        tm.elapsed(0, 5, &profile->total_ms);
+        profile->path = 0;
+        profile->n_sample_rows = (int)n_sample;
+        profile->grid_blocks = plan_f.grid;
+    }
+    return PSH_OK;
+}
+
+int psh_merge_workspace_bytes(int B, int k, size_t* out_bytes) {
+    if (!out_bytes || B <= 0 || k <= 0) return PSH_ERR_ARG;
+    if (k > PSH_MAX_K) return PSH_ERR_UNSUPPORTED;
+    *out_bytes = align_up(sizeof(int2) * (size_t)B * next_pow2(k), 256);
+    return PSH_OK;
+}
+
+int psh_merge_topk(int device, void* stream, const float* d_lists, const int32_t* idx_lists, int B, int n_in, int k,
+                   float* out_d, int32_t* out_idx, void* workspace, size_t workspace_bytes) {
+    if (!d_lists || !idx_lists || !out_d || !out_idx || !workspace || B <= 0 || n_in <= 0 || k <= 0) return PSH_ERR_ARG;
+    if (k > PSH_MAX_K) return PSH_ERR_UNSUPPORTED;
+    if (((uintptr_t)idx_lists & 7u) != 0 || ((uintptr_t)workspace & 7u) != 0) return PSH_ERR_ARG;
+    const int kpad = next_pow2(k);
+    if (workspace_bytes < sizeof(int2) * (size_t)B * kpad) return PSH_ERR_WORKSPACE;
+    DeviceGuard g(device);
+    if (!g.ok) { snprintf(g_hip_err, sizeof(g_hip_err), "hipSetDevice(%d) failed", device); return PSH_ERR_HIP; }
+    SelectArgs s;
+    memset(&s, 0, sizeof(s));
+    s.cand_d = d_lists;
+    s.cand_rt = (const int2*)idx_lists;
+    s.cand_stride = n_in;
+    s.counts = nullptr;
+    s.n_fixed = n_in;
+    s.cap = n_in;
+    s.k = k;
+    s.kpad = kpad;
+    s.skip_negative_rows = 1;
+    s.out_d = out_d;
+    s.out_idx = out_idx;
+    s.sel_rt = (int2*)workspace;
+    s.status = nullptr;
+    s.qstate = nullptr;
+    HIP_TRY(launch_select(s, B, (hipStream_t)stream));
+    return PSH_OK;
+}
+
+int psh_gather_paths(int device, void* stream, const float* dataset, int64_t R, int64_t C, int64_t T, int64_t r_offset,
+                     const int32_t* idx, int64_t n, int len, float* out) {
+    if (!dataset || !idx || !out || R <= 0 || C <= 0 || T <= 0 || n < 0 || len <= 0) return PSH_ERR_ARG;
+    DeviceGuard g(device);
+    if (!g.ok) { snprintf(g_hip_err, sizeof(g_hip_err), "hipSetDevice(%d) failed", device); return PSH_ERR_HIP; }
+    GatherArgs a{dataset, R, C, T, r_offset, idx, n, (int64_t)len, out};
+    HIP_TRY(launch_gather(a, (hipStream_t)stream));
+    return PSH_OK;
+}
+
+}  // extern "C"

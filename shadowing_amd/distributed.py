@@ -1,0 +1,148 @@
+"""R-sharded scan across the GPUs of one node (new work -- the
+reference has no multi-GPU path).
+
+Windows never cross trajectories, so the ensemble shards by rows: rank g keeps
+rows [lo_g, hi_g) resident in its own HBM, runs the same scan with
+`r_offset = lo_g`, and produces a local top-k of (d, r_global, t).  The only
+exchange is ONE all-gather of B*k*12 bytes per rank (RCCL over xGMI when the
+process group's backend is "nccl"); every rank then merges the G*k candidates
+with the same (d, r, t) order, so the result is identical to the single-GPU and
+to the reference CPU result for any G.  The payload is 12 KiB per query per rank:
+latency-bound, nowhere near the xGMI link rate -- there is nothing to tune in the
+collective, and there is no collective on the data path itself.
+"""
+from __future__ import annotations
+
+from typing import Callable
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _native
+from .path_distance import RelativeMSE
+from .path_embedding import Identity, PredictionContext
+
+
+def shard_rows(R: int, world_size: int, rank: int) -> tuple[int, int]:
+    """Contiguous, balanced row block of `rank`: [lo, hi)."""
+    base, extra = divmod(R, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def _native_local_topk(ds2d: torch.Tensor, q: torch.Tensor, k: int, h: int, r_offset: int, workspace):
+    d, idx, status = _native.scan_topk(ds2d, q, k, h=h, r_offset=r_offset, workspace=workspace)
+    bad = torch.nonzero(status != _native.PSH_STATUS_OK).flatten()
+    if bad.numel():
+        d2, idx2, _ = _native.scan_topk(ds2d, q[bad].contiguous(), k, h=h, r_offset=r_offset,
+                                        workspace=workspace, exhaustive=True)
+        d[bad] = d2
+        idx[bad] = idx2
+    return d, idx
+
+
+class ShardedPathShadowing:
+    """The Identity + RelativeMSE + PredictionContext scan over a row-sharded ensemble.
+
+    Every rank constructs it with ITS OWN rows (`local_dataset`, (R_local, 1, T) or
+    (R_local, T)) and the global index of its first row.  `shadow()` is collective
+    and returns the same global result on every rank.
+
+    `local_topk` / `merge` are injection points for the CPU (gloo) tests of the
+    exchange logic; production leaves them None and runs the HIP kernels.
+    """
+
+    def __init__(self, embedding: Identity, distance: RelativeMSE, local_dataset, row_offset: int,
+                 context: PredictionContext | None = None, group=None, device: torch.device | None = None,
+                 local_topk: Callable | None = None, merge: Callable | None = None):
+        if type(embedding) is not Identity or type(distance) is not RelativeMSE:
+            raise TypeError("the sharded scan implements Identity + RelativeMSE only")
+        self.embedding, self.distance = embedding, distance
+        self.context = context or PredictionContext(horizon=None)
+        if type(self.context) is not PredictionContext:
+            raise TypeError("the sharded scan implements PredictionContext only")
+        self.group = group
+        self.row_offset = int(row_offset)
+        self._local_topk = local_topk
+        self._merge = merge
+        ds = local_dataset if isinstance(local_dataset, torch.Tensor) else torch.as_tensor(
+            np.ascontiguousarray(local_dataset), dtype=torch.float32)
+        if ds.dim() == 2:
+            ds = ds[:, None, :]
+        if ds.dim() != 3 or ds.shape[1] != 1:
+            raise ValueError("local_dataset must be (R_local, 1, T) or (R_local, T)")
+        if local_topk is None:   # production: resident in this rank's HBM
+            if device is None:
+                if not torch.cuda.is_available():
+                    raise _native.NativeLibraryError("ShardedPathShadowing needs a HIP device")
+                device = torch.device("cuda", torch.cuda.current_device())
+            _native.load()
+            ds = ds.to(device)
+            self._workspace = _native.Workspace(device)
+        else:
+            self._workspace = None
+        self.dataset = ds.contiguous()
+        self.device = self.dataset.device
+
+    @property
+    def world_size(self) -> int:
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def local_scan(self, q: torch.Tensor, k: int):
+        """This rank's candidates: (d (B,k), idx (B,k,2)) with global row numbers,
+        padded with (+inf, -1) when the shard holds fewer than k windows."""
+        h = self.context.get_out_times()
+        R_local, _, T = self.dataset.shape
+        n_local = R_local * (T - q.shape[-1] - h + 1)
+        k_local = min(k, n_local)
+        fn = self._local_topk or (lambda ds, qq, kk, hh, off: _native_local_topk(ds, qq, kk, hh, off, self._workspace))
+        d, idx = fn(self.dataset[:, 0, :], q, k_local, h, self.row_offset)
+        if k_local < k:
+            B = q.shape[0]
+            d = torch.cat([d, d.new_full((B, k - k_local), float("inf"))], dim=1)
+            idx = torch.cat([idx, idx.new_full((B, k - k_local, 2), -1)], dim=1)
+        return d.contiguous(), idx.contiguous()
+
+    def scan(self, queries: torch.Tensor, k: int):
+        """Collective.  queries (B, W) float32 (same on every rank).  Returns device
+        tensors (d (B,k), idx (B,k,2)) -- the global k best, identical on all ranks."""
+        q = queries.to(self.device, dtype=torch.float32).contiguous()
+        d, idx = self.local_scan(q, k)
+        G = self.world_size
+        if G == 1:
+            return d, idx
+        # ONE exchange: pack (d, r, t) as 3 x int32 so a single all-gather moves everything
+        packed = torch.cat([d.view(torch.int32).unsqueeze(-1), idx], dim=-1).contiguous()   # (B, k, 3)
+        B = q.shape[0]
+        gathered = torch.empty((G * B, k, 3), dtype=torch.int32, device=self.device)   # rank-major concat
+        dist.all_gather_into_tensor(gathered, packed, group=self.group)
+        allc = gathered.view(G, B, k, 3).permute(1, 0, 2, 3).reshape(B, G * k, 3)
+        d_all = allc[..., 0].contiguous().view(torch.float32)
+        i_all = allc[..., 1:].contiguous()
+        merge = self._merge or _native.merge_topk
+        return merge(d_all, i_all, k)
+
+    def shadow(self, x_context, k: int = 1):
+        """Collective counterpart of PathShadowing.shadow(): numpy (d (B,k),
+        paths (B,k,1,W+h), idx (B,k,2)), the same on every rank.  Paths are collected
+        from their owner ranks with one sum all-reduce (each entry has exactly one
+        non-zero contributor, so the sum is exact)."""
+        x = x_context if isinstance(x_context, torch.Tensor) else torch.as_tensor(np.asarray(x_context), dtype=torch.float32)
+        x = x.reshape(-1, x.shape[-1]) if x.dim() != 2 else x
+        if x.shape[-1] != self.embedding.kernel.shape[-1]:
+            raise Exception("The embedding kernel should be of the same size as the context.")
+        d, idx = self.scan(x, k)
+        length = x.shape[-1] + self.context.get_out_times()
+        if self._local_topk is None:
+            paths = _native.gather_paths(self.dataset, idx, length, r_offset=self.row_offset)
+        else:   # CPU test path of the exchange logic
+            paths = torch.zeros(tuple(idx.shape[:-1]) + (1, length), dtype=torch.float32, device=self.device)
+            r = idx[..., 0].long() - self.row_offset
+            mine = (r >= 0) & (r < self.dataset.shape[0])
+            t = idx[..., 1].long()
+            for b, i in zip(*torch.nonzero(mine, as_tuple=True)):
+                paths[b, i, 0] = self.dataset[r[b, i], 0, t[b, i]:t[b, i] + length]
+        if self.world_size > 1:
+            dist.all_reduce(paths, op=dist.ReduceOp.SUM, group=self.group)
+        return d.cpu().numpy(), paths.cpu().numpy(), idx.cpu().numpy()

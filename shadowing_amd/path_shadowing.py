@@ -1,0 +1,257 @@
+"""PathShadowing: the k-nearest-path scan, MI355X-native behind the reference's API.
+
+Mirror of RudyMorel/shadowing shadowing/path_shadowing/path_shadowing.py
+(`PathShadowing` :61-301, helpers :16-58).  The object, its methods, their
+arguments, return types and error behaviour are the reference's; what happens
+inside `batched_distance(..., cuda=True)` is new:
+
+  * Identity embedding + RelativeMSE distance + PredictionContext, single channel
+    -> the hand-written HIP kernels of libpsh_hip.so (include/psh.h), with the
+    trajectory ensemble RESIDENT in HBM (uploaded once per dataset, not once per
+    split per call as path_shadowing.py:154-155 does), exact fp32 distances in
+    the reference CPU path's arithmetic order, rows ordered by (d, r, t).
+  * any other plugin combination (Foveal, user subclasses, other contexts,
+    several channels) -> a generic torch path with the reference's semantics, on
+    the HIP device when cuda=True.
+
+`cuda=True` never falls back to the CPU: if the HIP library is missing or no
+device is present it raises.  `cuda=False` is the reference's own meaning: run
+the generic torch formulation on the host.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Callable
+
+import numpy as np
+import torch
+from tqdm import tqdm
+
+from . import _native
+from .averaging import DiscreteProba, Softmax, Uniform
+from .path_distance import PathDistance, RelativeMSE
+from .path_embedding import (ArrayType, ContextManagerBase, Identity, PathEmbedding,
+                             PredictionContext)
+
+
+def _dim_array(x: ArrayType) -> ArrayType:
+    """(T,) -> (1,1,T);  (B,T) -> (B,1,T);  (B,C,T) unchanged  (ref :16-26)."""
+    if x is None:
+        return x
+    if x.ndim == 1:
+        return x[None, None, :]
+    if x.ndim == 2:
+        return x[:, None, :]
+    if x.ndim == 3:
+        return x
+    raise Exception("Array cannot be formatted to (B, C, T) shape.")
+
+
+def _torch(x: ArrayType) -> torch.Tensor:
+    """float32 torch tensor (a tensor is returned as is)  (ref :29-33)."""
+    return x if isinstance(x, torch.Tensor) else torch.tensor(x, dtype=torch.float32)
+
+
+def _numpy(x: ArrayType) -> np.ndarray:
+    return x if isinstance(x, np.ndarray) else x.cpu().numpy()
+
+
+def select_cartesian_product(indices: torch.Tensor, tensors: list[torch.Tensor]) -> torch.Tensor:
+    """Rows `indices` of torch.cartesian_prod(*tensors) without building the product
+    (ref :43-58): mixed-radix decode of the flat index, most significant factor first."""
+    sizes = [int(t.shape[0]) for t in tensors]
+    columns = []
+    rest = indices
+    weight = 1
+    for s in sizes:
+        weight *= s
+    for t, s in zip(tensors, sizes):
+        weight //= s
+        columns.append(t[(rest // weight) % s])
+    return torch.stack(columns, dim=-1)
+
+
+class PathShadowing:
+    """Scan a dataset of generated paths for the ones closest to an observed context.
+
+    Attributes (as in the reference): `embedding`, `distance`, `dataset`, `context`.
+    """
+
+    def __init__(self, embedding: PathEmbedding, distance: PathDistance,
+                 dataset, context: ContextManagerBase | None = None):
+        if isinstance(dataset, Path) or hasattr(dataset, "load"):
+            dataset = self._load_with_scatspectra(dataset)
+        self.dataset = dataset
+        self.embedding = embedding
+        self.distance = distance
+        self.context = context or PredictionContext(horizon=None)
+        self._resident = None       # (key, device tensor (R, C, T)) -- the ensemble in HBM
+        self._workspace = None
+        self.last_profile = None
+
+    @staticmethod
+    def _load_with_scatspectra(dataset):
+        # ref :84-88 -- Path / TimeSeriesDataset inputs go through the un-vendored scatspectra
+        try:
+            from scatspectra import TimeSeriesDataset  # type: ignore
+        except Exception as e:  # noqa: BLE001
+            raise ImportError("loading a dataset from a path needs the `scatspectra` package "
+                              "(pass the array itself instead)") from e
+        if isinstance(dataset, Path):
+            dataset = TimeSeriesDataset(dpath=dataset, R=None).load()
+        if isinstance(dataset, TimeSeriesDataset):
+            dataset = dataset.load()
+        return dataset
+
+    # ------------------------------------------------------------------ native path
+    def _native_ok(self, x: torch.Tensor, y: torch.Tensor, k: int) -> bool:
+        """Exactly the configuration the HIP kernels implement (types compared with
+        `is`, so user subclasses keep their own behaviour on the generic path)."""
+        return (type(self.embedding) is Identity and type(self.distance) is RelativeMSE
+                and type(self.context) is PredictionContext
+                and x.shape[1] == 1 and y.shape[1] == 1 and y.ndim == 3
+                and x.shape[-1] == self.embedding.kernel.shape[0]
+                and x.dtype == torch.float32 and y.dtype == torch.float32
+                and x.shape[-1] <= _native.PSH_MAX_W and k <= _native.PSH_MAX_K)
+
+    @staticmethod
+    def _hip_device() -> torch.device:
+        if not torch.cuda.is_available():
+            raise _native.NativeLibraryError(
+                "cuda=True needs a HIP device (torch.cuda.is_available() is False); "
+                "there is no CPU fallback on this path -- use cuda=False for the host path")
+        return torch.device("cuda", torch.cuda.current_device())
+
+    def _resident_dataset(self, y: torch.Tensor, device: torch.device) -> torch.Tensor:
+        """The (R, C, T) ensemble in HBM, uploaded once and kept while `y` is the same
+        host storage (the reference re-uploads every split on every call, ref :154-155)."""
+        if y.is_cuda:
+            return y.contiguous()
+        key = (y.data_ptr(), tuple(y.shape), y._version, device)
+        if self._resident is None or self._resident[0] != key:
+            self._resident = (key, y.contiguous().to(device, non_blocking=False))
+        return self._resident[1]
+
+    def _native_scan(self, x: torch.Tensor, y: torch.Tensor, k: int):
+        dev = self._hip_device()
+        _native.load()
+        ds = self._resident_dataset(y, dev)
+        q = x[:, 0, :].contiguous().to(dev)
+        h = self.context.get_out_times()
+        if self._workspace is None or self._workspace.device != dev:
+            self._workspace = _native.Workspace(dev)
+        n_windows = ds.shape[0] * (ds.shape[-1] - q.shape[-1] - h + 1)
+        if k > n_windows:
+            # the reference fails inside torch.topk (ref :165) with the same exception type
+            raise RuntimeError("selected index k out of range")
+        d, idx, status = _native.scan_topk(ds[:, 0, :], q, k, h=h, workspace=self._workspace)
+        bad = torch.nonzero(status != _native.PSH_STATUS_OK).flatten()
+        if bad.numel():
+            # candidate buffer overflowed (massive ties / adversarial data): exact slow path
+            d2, idx2, _ = _native.scan_topk(ds[:, 0, :], q[bad].contiguous(), k, h=h,
+                                            workspace=self._workspace, exhaustive=True)
+            d[bad] = d2
+            idx[bad] = idx2
+        return d, idx, ds
+
+    # ------------------------------------------------------------------ generic path
+    def _generic_scan(self, x: torch.Tensor, y: torch.Tensor, k: int, n_splits: int, cuda: bool):
+        """The reference's formulation with stock torch ops (ref :129-177): embed the
+        query, pad the kernel by the context, then per dataset split: embed, broadcast
+        distance, top-k, decode, merge with the running best."""
+        embedding, distance = self.embedding, self.distance
+        dev = self._hip_device() if cuda else torch.device("cpu")
+        x = x.to(dev)
+        embedding = embedding.to(dev)
+        distance = distance.to(dev)
+        n_query, n_paths = x.shape[0], y.shape[0]
+        dim = embedding.kernel.shape[0] or x.shape[-1]
+        hx = embedding(x)[:, 0, :]
+        scanner = embedding.adjust_to_context(self.context)
+        best_d = hx.new_full((n_query, k), float("inf"))
+        best_i = torch.full((n_query, k, y.ndim - 1), -1, dtype=torch.int32, device=dev)
+        hx = hx.view((n_query,) + (1,) * (y.ndim - 1) + (dim,))
+        for rows in torch.arange(n_paths, dtype=torch.int32).split(n_paths // n_splits):
+            hy = scanner(y[rows.long(), ...].to(dev))
+            rows = rows.to(dev)
+            dist = distance(hx, hy[None, ...]).view(n_query, -1)
+            d_new, flat = torch.topk(dist, k=k, dim=-1, largest=False)
+            axes = [rows] + [torch.arange(s, dtype=torch.int32, device=dev) for s in hy.shape[1:-1]]
+            i_new = select_cartesian_product(flat.to(torch.int32), axes)
+            pool_d = torch.cat([best_d, d_new], dim=1)
+            pool_i = torch.cat([best_i, i_new], dim=1)
+            best_d, pos = torch.topk(pool_d, k=k, dim=-1, largest=False)
+            best_i = torch.gather(pool_i, 1, pos.unsqueeze(-1).expand(-1, -1, pool_i.shape[-1]))
+        return best_d.cpu(), best_i.cpu()
+
+    # ------------------------------------------------------------------ public API
+    def batched_distance(self, x: torch.Tensor, y: torch.Tensor, k: int, n_splits: int, cuda: bool
+                         ) -> tuple[torch.Tensor, torch.Tensor]:
+        """k smallest distances d(h(x), h(y)) and where they are (ref :97-179).
+
+        x (B, C, T_x) queries, y (S, C, T) dataset.  Returns CPU tensors:
+        distances (B, k) float32 ascending and indices (B, k, 2) int32 = [path, time].
+        `n_splits` only bounds memory on the generic path; the HIP path streams the
+        dataset once and ignores it.
+        """
+        if cuda and self._native_ok(x, y, k):
+            d, idx, _ = self._native_scan(x, y, k)
+            return d.cpu(), idx.cpu()
+        return self._generic_scan(x, y, k, n_splits, cuda)
+
+    def shadow(self, x_context: ArrayType, k: int = 1, n_splits: int = 1, cuda: bool = False
+               ) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """Distances (B,k), shadowing paths with their out-context (B,k,C,T_x+h) and
+        indices (B,k,2) of the k closest windows of the dataset (ref :181-218)."""
+        ksize = self.embedding.kernel.shape[-1]
+        if ksize != 0 and ksize != x_context.shape[-1]:
+            raise Exception("The embedding kernel should be of the same size as the context.")
+        x = _torch(_dim_array(x_context))
+        y = _torch(_dim_array(self.dataset))
+        length = x.shape[-1] + self.context.get_out_times()
+
+        if cuda and self._native_ok(x, y, k):
+            d, idx, ds = self._native_scan(x, y, k)
+            paths = _native.gather_paths(ds, idx, length)           # (B, k, C, len) on device
+            self.last_path = "hip"
+            return d.cpu().numpy(), paths.cpu().numpy(), idx.cpu().numpy()
+
+        d, idx = self._generic_scan(x, y, k, n_splits, cuda)
+        self.last_path = "torch"
+        # gather dataset[r, :, t : t+len] for every (r, t)  (ref :211-216)
+        offs = torch.arange(length, dtype=torch.int64)
+        r = idx[..., 0].long()
+        t = idx[..., 1].long()[..., None] + offs                     # (B, k, len)
+        paths = y[r[..., None], :, t]                                # (B, k, len, C)
+        return _numpy(d), _numpy(paths.permute(0, 1, 3, 2).contiguous()), _numpy(idx)
+
+    @staticmethod
+    def init_averaging_proba(proba_name: str, distances: np.ndarray, eta: float | None) -> DiscreteProba:
+        """"uniform" or "softmax" averaging over the shadowing paths (ref :220-232)."""
+        if proba_name == "uniform":
+            return Uniform()
+        if proba_name == "softmax":
+            return Softmax(distances, eta)
+        raise ValueError("Unrecognized averaging proba")
+
+    def predict_from_paths(self, distances: np.ndarray, paths: np.ndarray, to_predict: Callable,
+                           proba_name: str, eta: float | None) -> tuple[np.ndarray, np.ndarray]:
+        """Weighted mean / std over the k paths of `to_predict(out-context)` (ref :234-254)."""
+        future = self.context.select_out_context(paths)
+        proba = self.init_averaging_proba(proba_name, distances[:, :, None], eta)
+        values = to_predict(future)
+        return proba.avg(values, axis=1), proba.std(values, axis=1)
+
+    def predict(self, x_context: ArrayType, k: int, to_predict: Callable, eta: float | None = None,
+                proba_name: str = "softmax", n_dataset_splits: int = 1, n_context_splits: int = 1,
+                cuda: bool = False) -> tuple[np.ndarray, np.ndarray]:
+        """shadow() + predict_from_paths() over `n_context_splits` batches of queries (ref :256-301)."""
+        x = _torch(_dim_array(x_context))
+        n = x.shape[0]
+        means, stds = [], []
+        for rows in tqdm(torch.arange(n).split(n // n_context_splits)):
+            d, paths, _ = self.shadow(x[rows, ...], k, n_dataset_splits, cuda)
+            m, s = self.predict_from_paths(d, paths, to_predict, proba_name, eta)
+            means.append(m)
+            stds.append(s)
+        return np.concatenate(means), np.concatenate(stds)

@@ -1,0 +1,115 @@
+#!/usr/bin/env python
+"""Generate the golden vectors in this directory by running the READ-ONLY
+reference (/root/reference, RudyMorel/shadowing @ 2024-12-20) on CPU.
+
+Run in the build container only (the reference does not travel):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [--big]
+
+`scatspectra` (an un-vendored dependency the scan never touches when the
+dataset is an array) is replaced by a names-only stub so that
+`import shadowing` succeeds.  Every fixture stores the inputs (or, for large
+datasets, the generator seed + SHA-256 of the bytes), the query norms torch
+computed, and the reference's raw outputs of
+PathShadowing.shadow(..., cuda=False): distances, indices and gathered paths.
+Nothing but data is written: no reference source is copied.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import sys
+import time
+import types
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+sys.dont_write_bytecode = True
+
+
+def load_reference():
+    stub = types.ModuleType("scatspectra")
+    for name in ("TimeSeriesDataset", "Softmax", "Uniform", "DiscreteProba", "PriceData", "windows"):
+        setattr(stub, name, type(name, (), {}))
+    sys.modules["scatspectra"] = stub
+    sys.path.insert(0, "/root/reference")
+    import shadowing  # noqa: F401  (the reference)
+    sys.path.pop(0)
+    return sys.modules["shadowing"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--big", action="store_true", help="also the cfg-2 / cfg-3 sized cases (~2 min)")
+    args = ap.parse_args()
+
+    ref = load_reference()
+    import torch
+    # synthetic generator of the build (pure numpy), loaded by path so that the
+    # build's own `shadowing` alias package never shadows the reference here
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("psh_synthetic", REPO / "shadowing_amd" / "synthetic.py")
+    syn = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(syn)
+
+    def run(name, ds, q, W, h, k, n_splits, store_dataset, meta=None):
+        obj = ref.PathShadowing(ref.Identity(W), ref.RelativeMSE(), ds, ref.PredictionContext(horizon=h))
+        t0 = time.time()
+        d, paths, idx = obj.shadow(q, k=k, n_splits=n_splits, cuda=False)
+        dt = time.time() - t0
+        q2 = np.atleast_2d(q).astype(np.float32)
+        xn = torch.tensor(q2).norm(dim=-1).numpy()
+        out = dict(queries=q2, xn=xn, d=d, idx=idx, paths=paths,
+                   W=W, h=-1 if h is None else h, k=k, n_splits=n_splits,
+                   dataset_sha256=syn.sha256(ds), dataset_shape=np.array(ds.shape))
+        if store_dataset:
+            out["dataset"] = ds
+        m = dict(meta or {})
+        m.update(reference_seconds=round(dt, 3), numpy=np.__version__, torch=torch.__version__)
+        out["meta"] = json.dumps(m)
+        np.savez_compressed(HERE / f"{name}.npz", **out)
+        print(f"{name}: d{d.shape} idx{idx.shape} paths{paths.shape} ref {dt:.2f}s")
+
+    # --- BASELINE.json configs[0]: the reference's own CPU-runnable case ----------------
+    ds = syn.dataset(256, 1024, 0)
+    q = syn.single_query(20, 1)
+    run("cfg1_h20", ds, q, 20, 20, 64, 1, False, dict(gen="dataset(256,1024,0)", qgen="single_query(20,1)"))
+    run("cfg1_hNone", ds, q, 20, None, 64, 1, False, dict(gen="dataset(256,1024,0)", qgen="single_query(20,1)"))
+
+    # --- multi-query, multi-split ------------------------------------------------------
+    ds = syn.dataset(96, 512, 10)
+    run("multiquery_splits", ds, syn.rolling_queries(5, 20, 11), 20, 20, 48, 4, True)
+    # --- remainder split (S % n_splits != 0), odd W -------------------------------------
+    ds = syn.dataset(100, 384, 12)
+    run("remainder_split_W12", ds, syn.gbm_log_returns((2, 12), 13), 12, 7, 32, 3, True)
+    run("oddW33_h11", syn.dataset(64, 300, 14), syn.gbm_log_returns((2, 33), 15), 33, 11, 50, 2, True)
+    run("W7_h0", syn.dataset(64, 300, 16), syn.gbm_log_returns((3, 7), 17), 7, 0, 16, 1, True)
+    # --- exact ties: every path appears twice --------------------------------------------
+    half = syn.dataset(48, 256, 18)
+    run("duplicated_paths", np.concatenate([half, half], 0), syn.gbm_log_returns((2, 20), 19), 20, 20, 33, 1, True)
+    # --- zero query: every distance is +inf ----------------------------------------------
+    run("zero_query", syn.dataset(16, 128, 20), np.zeros((1, 20), np.float32), 20, 20, 8, 1, True)
+    # --- query cut out of the dataset: an exact 0 distance --------------------------------
+    ds = syn.dataset(32, 256, 21)
+    run("self_match", ds, ds[3, 0, 100:120].copy(), 20, 20, 8, 1, True)
+    # --- one window per row (T == W + h): the numerator's reduction order changes ---------
+    run("single_window_rows", syn.dataset(300, 25, 22), syn.gbm_log_returns((2, 20), 23), 20, 5, 40, 1, True)
+    # --- 2-D dataset (R, T) and 1-D query, k = 1 -----------------------------------------
+    run("k1_2d_dataset", syn.dataset(40, 200, 24)[:, 0, :], syn.single_query(20, 25), 20, 20, 1, 1, True)
+
+    if args.big:
+        # BASELINE.json configs[1] size: R=32768, T=4096, W=20, k=1024, single query
+        ds = syn.dataset(32768, 4096, 0)
+        run("cfg2_R32768", ds, syn.single_query(20, 1), 20, 20, 1024, 64, False,
+            dict(gen="dataset(32768,4096,0)", qgen="single_query(20,1)"))
+        # configs[2] shape at a CPU-tractable size: rolling-window queries
+        ds = syn.dataset(2048, 4096, 2)
+        run("cfg3_rolling_R2048", ds, syn.rolling_queries(4, 20, 3), 20, 20, 1024, 32, False,
+            dict(gen="dataset(2048,4096,2)", qgen="rolling_queries(4,20,3)"))
+
+
+if __name__ == "__main__":
+    main()

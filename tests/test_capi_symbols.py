@@ -1,0 +1,89 @@
+"""The C-ABI library loads and exports every symbol include/psh.h declares; its
+host-only entry points (no GPU needed) behave as documented."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from shadowing_amd import _build, _native
+    _build.build()                       # hipcc cross-compiles gfx950 without a GPU
+    return _native.load()
+
+
+def declared_symbols():
+    text = (REPO / "include" / "psh.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(psh_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    from shadowing_amd import _native
+    syms = declared_symbols()
+    assert len(syms) >= 10
+    assert set(syms) == set(_native.EXPORTS)
+
+
+def test_every_declared_symbol_is_exported(lib):
+    for name in declared_symbols():
+        assert hasattr(lib, name), f"{name} declared in include/psh.h but not exported"
+
+
+def test_version_and_strerror(lib):
+    assert lib.psh_version() == 1
+    assert lib.psh_strerror(0) == b"ok"
+    for code in (-1, -2, -3, -4):
+        assert len(lib.psh_strerror(code)) > 5
+    assert lib.psh_strerror(-99) == b"unknown error"
+
+
+def test_workspace_bytes(lib):
+    out = C.c_size_t(0)
+    assert lib.psh_workspace_bytes(32768, 4096, 1, 20, 20, 1024, C.byref(out)) == 0
+    one = out.value
+    assert 65536 * 12 <= one < 64 << 20
+    assert lib.psh_workspace_bytes(32768, 4096, 8, 20, 20, 1024, C.byref(out)) == 0
+    assert out.value > 7 * one * 0.9
+    assert lib.psh_workspace_bytes(32768, 4096, 1, 20, 20, 1024, None) == -1          # PSH_ERR_ARG
+    assert lib.psh_workspace_bytes(0, 4096, 1, 20, 20, 1024, C.byref(out)) == -1
+    assert lib.psh_workspace_bytes(16, 30, 1, 20, 20, 4, C.byref(out)) == -1           # no admissible window
+    assert lib.psh_workspace_bytes(16, 4096, 1, 257, 0, 4, C.byref(out)) == -2         # W > PSH_MAX_W
+    assert lib.psh_workspace_bytes(16, 4096, 1, 20, 0, 16385, C.byref(out)) == -2      # k > PSH_MAX_K
+    assert lib.psh_merge_workspace_bytes(4, 1000, C.byref(out)) == 0 and out.value >= 4 * 1024 * 8
+
+
+def test_null_arguments_are_rejected_not_crashing(lib):
+    st = C.c_int(0)
+    rc = lib.psh_scan_topk(0, None, None, 16, 128, 0, None, None, 1, 20, 0, 4, None, None, None, None, 0, None)
+    assert rc == -1
+    assert lib.psh_query_norm(0, None, None, 1, 20, None) == -1
+    assert lib.psh_gather_paths(0, None, None, 1, 1, 8, 0, None, 0, 4, None) == -1
+    assert lib.psh_merge_topk(0, None, None, None, 1, 8, 4, None, None, None, 0) == -1
+
+
+def test_cuda_true_fails_loudly_without_a_device():
+    """No silent CPU fallback: cuda=True without a HIP device raises."""
+    import numpy as np
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    import shadowing_amd as sa
+    from shadowing_amd import _native, synthetic as syn
+    obj = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), syn.dataset(8, 128, 0), sa.PredictionContext(20))
+    with pytest.raises(_native.NativeLibraryError):
+        obj.shadow(syn.single_query(20), k=4, cuda=True)
+    with pytest.raises(_native.NativeLibraryError):
+        _native.scan_topk(torch.zeros(8, 128), torch.zeros(1, 20), 4)
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under shadowing_amd/ (or bench's
+    product leg) may reference it."""
+    for p in (REPO / "shadowing_amd").rglob("*"):
+        if p.suffix in (".py", ".hip", ".h", ".cpp"):
+            assert not re.search(r"^\s*(from|import)\s+oracle\b|libpsh_oracle|#include\s*[<\"][^\n]*oracle|psh_oracle_\w+\s*\(", p.read_text(), flags=re.M), p

@@ -1,0 +1,80 @@
+"""The N>1 path on CPU: two processes over gloo run ShardedPathShadowing with the
+oracle injected as the per-shard scan and a torch lexsort as the merge; the collective
+result must equal the single-process result on the whole ensemble, on every rank."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+def _oracle_local(ds2d, q, k, h, r_offset):
+    import oracle
+    d, idx = oracle.scan_topk(ds2d.numpy(), q.numpy(), k, h=h, r_offset=r_offset, nthreads=2)
+    return torch.from_numpy(d), torch.from_numpy(idx)
+
+
+def _torch_merge(d_all, i_all, k):
+    d_all, i_all = d_all.numpy(), i_all.numpy()
+    B = d_all.shape[0]
+    out_d = np.empty((B, k), np.float32)
+    out_i = np.empty((B, k, 2), np.int32)
+    for b in range(B):
+        real = i_all[b, :, 0] >= 0
+        dd, ii = d_all[b][real], i_all[b][real]
+        o = np.lexsort((ii[:, 1], ii[:, 0], dd))[:k]
+        out_d[b], out_i[b] = dd[o], ii[o]
+    return torch.from_numpy(out_d), torch.from_numpy(out_i)
+
+
+def _worker(rank, world, port, R, T, W, h, k, B, tmp):
+    sys.path.insert(0, str(REPO))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import shadowing_amd as sa
+        from shadowing_amd import synthetic as syn
+        from shadowing_amd.distributed import ShardedPathShadowing, shard_rows
+        lo, hi = shard_rows(R, world, rank)
+        local = syn.dataset_rows(R, T, 5, lo, hi)
+        obj = ShardedPathShadowing(sa.Identity(W), sa.RelativeMSE(), local, lo, sa.PredictionContext(h),
+                                   local_topk=_oracle_local, merge=_torch_merge)
+        q = syn.rolling_queries(B, W, 6)
+        d, paths, idx = obj.shadow(q, k)
+        np.savez(os.path.join(tmp, f"rank{rank}.npz"), d=d, paths=paths, idx=idx)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("R,k", [(37, 50), (5, 300)])   # uneven shards; a shard with fewer than k windows
+def test_two_rank_gloo_matches_single_process(tmp_path, oracle_mod, R, k):
+    T, W, h, B = 160, 20, 20, 3
+    port = 29500 + (os.getpid() % 2000) + (R % 7)
+    mp.spawn(_worker, args=(2, port, R, T, W, h, k, B, str(tmp_path)), nprocs=2, join=True)
+    from shadowing_amd import synthetic as syn
+    ds = syn.dataset(R, T, 5)
+    q = syn.rolling_queries(B, W, 6)
+    d, paths, idx = oracle_mod.shadow(ds, q, k, h)
+    for rank in range(2):
+        z = np.load(tmp_path / f"rank{rank}.npz")
+        assert np.array_equal(z["d"].view(np.uint32), d.view(np.uint32))
+        assert np.array_equal(z["idx"], idx)
+        assert np.array_equal(z["paths"], paths)
+
+
+def test_shard_rows_partition():
+    from shadowing_amd.distributed import shard_rows
+    for R in (1, 7, 8, 262144, 1000003):
+        for G in (1, 2, 3, 8):
+            blocks = [shard_rows(R, G, g) for g in range(G)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == R
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(G - 1))
+            sizes = [hi - lo for lo, hi in blocks]
+            assert max(sizes) - min(sizes) <= 1

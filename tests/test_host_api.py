@@ -1,0 +1,145 @@
+"""Host-side mirror of the reference's plugin surface: names,
+signatures, return types, error behaviour -- and the reference's own three test cells
+(testing.ipynb: forward_topk prefix consistency, shadow() self-consistency)."""
+import numpy as np
+import pytest
+import torch
+
+import shadowing_amd as sa
+from _util import SMALL_GOLDENS, assert_exact, load_golden
+from shadowing_amd import synthetic as syn
+from shadowing_amd.path_shadowing import _dim_array, _numpy, _torch
+
+
+def test_drop_in_import_paths():
+    import shadowing
+    from shadowing import (Foveal, Identity, PathShadowing, PredictionContext, RelativeMSE, Softmax,  # noqa: F401
+                           realized_variance, select_cartesian_product)
+    from shadowing.path_shadowing import PathDistance, PathEmbedding  # noqa: F401
+    assert shadowing.PathShadowing is sa.PathShadowing
+
+
+@pytest.mark.parametrize("name", SMALL_GOLDENS)
+def test_generic_torch_path_reproduces_reference(name):
+    """cuda=False runs the same torch formulation as the reference: same bits, same
+    (even tie) order as the stored reference outputs."""
+    g = load_golden(name)
+    obj = sa.PathShadowing(sa.Identity(g["W"]), sa.RelativeMSE(), g["dataset"], sa.PredictionContext(g["h"]))
+    q = g["queries"] if name != "k1_2d_dataset" else g["queries"][0]
+    d, paths, idx = obj.shadow(q, k=g["k"], n_splits=g["n_splits"], cuda=False)
+    assert d.dtype == np.float32 and paths.dtype == np.float32 and idx.dtype == np.int32
+    assert np.array_equal(paths, g["paths"])
+    assert_exact(d, idx, g["d"], g["idx"], name)
+
+
+def test_forward_topk_prefix_consistency():
+    """testing.ipynb cell 1: top-32 with 32 splits == first 32 of top-64 with 64 splits."""
+    torch.manual_seed(0)
+    dist = sa.RelativeMSE()
+    x, y = torch.randn(8, 34), torch.randn(128, 96, 34)
+    d32, i32 = dist.forward_topk(x, y, 32, 32)
+    d64, i64 = dist.forward_topk(x, y, 64, 64)
+    assert torch.equal(d32, d64[:, :32]) and torch.equal(i32, i64[:, :32])
+    assert i32.dtype == torch.int64 and i32.shape == (8, 32, 2)
+    # indices point at the distances they claim
+    for b in range(8):
+        r, t = i32[b, :, 0], i32[b, :, 1]
+        assert torch.equal(dist(x[b][None, :], y[r, t]), d32[b])
+
+
+def test_shadow_self_consistency_foveal():
+    """testing.ipynb cell 2 (smaller): re-embedding the returned paths' in-context part
+    reproduces the returned distances."""
+    torch.manual_seed(1)
+    emb = sa.Foveal(alpha=1.15, beta=0.9, max_context=126)
+    ctx = sa.PredictionContext(horizon=50)
+    ds = torch.randn(16, 1, 1024).numpy()
+    x = torch.randn(4, 1, 126).numpy()
+    obj = sa.PathShadowing(emb, sa.RelativeMSE(), ds, ctx)
+    d, paths, idx = obj.shadow(x, k=64, cuda=False)
+    assert paths.shape == (4, 64, 1, 176) and idx.shape == (4, 64, 2)
+    hx = emb(torch.tensor(x))[:, 0, :]
+    hp = emb(torch.tensor(ctx.select_in_context(paths)).reshape(-1, 1, 126))[:, 0, :].reshape(4, 64, -1)
+    again = sa.RelativeMSE()(hx[:, None, :], hp).numpy()
+    assert np.allclose(again, d, rtol=1e-4)
+    assert np.all(np.diff(d, axis=1) >= 0)
+    assert emb.dim == 34 and len(emb.slices) == 34 and emb.kernel.shape == (34, 1, 126)
+
+
+def test_error_behaviour():
+    obj = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), syn.dataset(4, 64, 0), sa.PredictionContext(20))
+    with pytest.raises(Exception, match="same size as the context"):
+        obj.shadow(np.zeros(19, np.float32), k=1)
+    with pytest.raises(RuntimeError):          # k larger than the number of windows, as torch.topk in the reference
+        obj.shadow(syn.single_query(20), k=1000)
+    with pytest.raises(ValueError, match="Unrecognized averaging proba"):
+        sa.PathShadowing.init_averaging_proba("median", np.zeros((1, 2, 1)), None)
+    with pytest.raises(Exception, match="cannot be formatted"):
+        _dim_array(np.zeros((1, 1, 1, 1)))
+    assert isinstance(obj.context, sa.PredictionContext)
+    assert sa.PathShadowing(sa.Identity(4), sa.RelativeMSE(), np.zeros((2, 16))).context.horizon is None
+
+
+def test_helpers_and_contexts():
+    assert _dim_array(np.zeros(5)).shape == (1, 1, 5) and _dim_array(np.zeros((3, 5))).shape == (3, 1, 5)
+    assert _torch(np.zeros(3, np.float64)).dtype == torch.float32
+    t = torch.ones(2)
+    assert _torch(t) is t and isinstance(_numpy(t), np.ndarray)
+    a, b, c = torch.arange(3), torch.arange(10, 14), torch.arange(20, 22)
+    flat = torch.tensor([0, 5, 23, 7])
+    assert torch.equal(sa.select_cartesian_product(flat, [a, b, c]), torch.cartesian_prod(a, b, c)[flat])
+    x = np.arange(10.0)[None, :]
+    p = sa.PredictionContext(3)
+    assert p.get_out_times() == 3 and p.select_in_context(x).shape[-1] == 7 and np.array_equal(p.select_out_context(x)[0], [7, 8, 9])
+    assert p.pad_context(torch.ones(2, 1, 4)).shape[-1] == 7
+    none = sa.PredictionContext()
+    assert none.get_out_times() == 0 and none.select_out_context(x) is x and none.pad_context(t) is t
+    im = sa.ImputationContext((2, 3, 4))
+    assert im.get_out_times() == 3 and np.array_equal(im.select_in_context(x)[0], [0, 1, 6, 7, 8, 9])
+    assert np.array_equal(im.select_out_context(x)[0], [2, 3, 4, 5]) and im.slect_out_context(x).shape == (1, 4)
+    assert torch.equal(im.pad_context(torch.arange(6.0)[None]), torch.tensor([[0, 1, 0, 0, 0, 2, 3, 4, 5.]]))
+    cc = sa.CrossChannelContext(1)
+    y = np.zeros((2, 3, 8))
+    assert cc.select_in_context(y).shape == (2, 2, 8) and cc.select_out_context(y).shape == (2, 1, 8)
+    assert cc.pad_context(torch.zeros(4, 2, 5)).shape == (4, 3, 5) and cc.get_out_times() == 0
+    e = sa.Identity(6)
+    assert e.d == 6 and e.kernel.shape == (6, 1, 6) and e(torch.randn(2, 1, 9)).shape == (2, 4, 6)
+    assert e.adjust_to_context(p).kernel.shape == (6, 1, 9)
+    xx = torch.randn(2, 1, 9)
+    assert torch.equal(e(xx)[:, 1, :], xx[:, 0, 1:7])           # Identity conv == the window itself
+    rv = sa.realized_variance(np.ones((2, 10)) * 0.1, [2, 5], vol=False)
+    assert rv.shape == (2, 2) and np.allclose(rv, 0.01 * 252)
+
+
+def test_predict_from_paths_with_a_fake_proba(monkeypatch):
+    """The body of predict_from_paths (select_out_context -> proba.avg/std over axis 1)
+    with a recording stand-in for the un-vendored scatspectra operators."""
+    calls = {}
+
+    class Fake:
+        def avg(self, x, axis):
+            calls["avg"] = (x.shape, axis)
+            return x.mean(axis)
+
+        def std(self, x, axis):
+            calls["std"] = (x.shape, axis)
+            return x.std(axis)
+
+    obj = sa.PathShadowing(sa.Identity(4), sa.RelativeMSE(), np.zeros((2, 32)), sa.PredictionContext(3))
+    monkeypatch.setattr(sa.PathShadowing, "init_averaging_proba", staticmethod(lambda n, d, e: (calls.setdefault("init", (n, d.shape, e)), Fake())[1]))
+    paths = np.random.default_rng(0).standard_normal((5, 6, 1, 7)).astype(np.float32)
+    m, s = obj.predict_from_paths(np.ones((5, 6), np.float32), paths, lambda f: (f ** 2).sum(-1), "softmax", 0.1)
+    assert calls["init"] == ("softmax", (5, 6, 1), 0.1) and calls["avg"] == ((5, 6, 1), 1)
+    assert np.allclose(m, (paths[..., -3:] ** 2).sum(-1).mean(1)) and m.shape == (5, 1) and s.shape == (5, 1)
+
+
+def test_predict_runs_on_the_host_path():
+    ds = syn.dataset(32, 256, 3)
+    obj = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), ds, sa.PredictionContext(10))
+    q = syn.rolling_queries(4, 20, 4)
+    m, s = obj.predict(q, k=16, to_predict=lambda f: sa.realized_variance(f, [5, 10], vol=False),
+                       eta=0.5, n_context_splits=2, cuda=False)
+    assert m.shape == (4, 1, 2) and s.shape == (4, 1, 2) and np.all(np.isfinite(m)) and np.all(s >= 0)
+    mu, _ = obj.predict(q, k=16, to_predict=lambda f: f.mean(-1), proba_name="uniform", cuda=False)
+    d, paths, _ = obj.shadow(q, k=16)
+    assert np.allclose(mu, paths[..., -10:].mean(-1).mean(1))
