@@ -54,7 +54,10 @@ __device__ __forceinline__ void wave_lds_fence() {
 // IEEE correctly rounded, denormal-preserving: the same results as the host's
 // sqrtf / division the reference's CPU path goes through.
 __device__ __forceinline__ float dist_from_acc(float acc, float xn) {
-    return __fdiv_rn(__fsqrt_rn(acc), xn);
+    // plain sqrtf and '/' : hipcc's default code generation for both is the correctly
+    // rounded, denormal-preserving sequence (-fhip-fp32-correctly-rounded-divide-sqrt);
+    // the __fsqrt_rn intrinsic is NOT (it maps to the approximate native sqrt).
+    return __builtin_sqrtf(acc) / xn;
 }
 
 // sum of squares in the order of ATen's contiguous last-dim norm reduce (see
@@ -96,7 +99,7 @@ __global__ void prep_kernel(PrepArgs a) {
     if (b >= a.B) return;
     const float* x = a.queries + (int64_t)b * a.W;
     const float s = sumsq8([&](int j) { return x[j]; }, a.W);
-    a.qstate[b].xn = a.qnorm_in ? a.qnorm_in[b] : __fsqrt_rn(s);
+    a.qstate[b].xn = a.qnorm_in ? a.qnorm_in[b] : __builtin_sqrtf(s);
     // bins cover acc in [s/64, s*2^10): d in [0.125, 32)
     int base = (int)(__float_as_uint(s) >> 16) - 6 * 128;
     a.qstate[b].base = base < 0 ? 0 : base;
@@ -110,7 +113,7 @@ __global__ void qnorm_kernel(const float* queries, int B, int W, float* out) {
     const int b = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (b >= B) return;
     const float* x = queries + (int64_t)b * W;
-    out[b] = __fsqrt_rn(sumsq8([&](int j) { return x[j]; }, W));
+    out[b] = __builtin_sqrtf(sumsq8([&](int j) { return x[j]; }, W));
 }
 
 // ----------------------------------------------------------------------------------

@@ -1,0 +1,186 @@
+"""Parity tests proper: the HIP path, called through the C ABI (ctypes binding
+shadowing_amd._native), against the CPU oracle on the same seeded inputs, against the
+committed golden vectors of the reference, and -- at BASELINE.json's full sizes --
+through size-independent properties.  Bar: distances BIT-exact, indices identical."""
+import numpy as np
+import pytest
+import torch
+
+from _util import (BIG_GOLDENS, SMALL_GOLDENS, assert_exact, assert_matches_reference, bits, canonical, load_golden,
+                   rows3)
+from shadowing_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def hip_scan(dev, ds, q, k, h, **kw):
+    from shadowing_amd import _native
+    ds_t = torch.as_tensor(np.ascontiguousarray(rows3(ds)[:, 0, :])).to(dev)
+    q_t = torch.as_tensor(np.ascontiguousarray(np.atleast_2d(q), dtype=np.float32)).to(dev)
+    out = _native.scan_topk(ds_t, q_t, k, h=h, **kw)
+    torch.cuda.synchronize(dev)
+    return out[0].cpu().numpy(), out[1].cpu().numpy(), out[2].cpu().numpy(), out[3:] and out[3]
+
+
+@pytest.mark.parametrize("name", SMALL_GOLDENS)
+def test_hip_matches_reference_goldens_small(hip_device, oracle_mod, name):
+    g = load_golden(name)
+    ds = rows3(g["dataset"])
+    h = g["h"] or 0
+    d, idx, status, _ = hip_scan(hip_device, ds, g["queries"], g["k"], h)
+    assert np.all(status == 0)
+    all_dist = [oracle_mod.all_distances(ds, q, h) for q in g["queries"]]
+    assert_matches_reference(d, idx, g, all_dist, what=name)
+    od, oidx = oracle_mod.scan_topk(ds, g["queries"], g["k"], h=h)
+    assert_exact(d, idx, od, oidx, name + " vs oracle")
+
+
+@pytest.mark.parametrize("name", BIG_GOLDENS)
+def test_hip_matches_reference_goldens_full_size(hip_device, name):
+    """BASELINE.json configs[1] (R=32768, T=4096, W=20, k=1024) and the rolling-query
+    shape of configs[2]: the reference's own CPU output, regenerated dataset checked by
+    SHA-256."""
+    g = load_golden(name)
+    d, idx, status, _ = hip_scan(hip_device, g["dataset"], g["queries"], g["k"], g["h"] or 0)
+    assert np.all(status == 0)
+    assert_matches_reference(d, idx, g, None, what=name)
+
+
+CASES = [  # R, T, W, h, k, B
+    (64, 1024, 20, 20, 64, 1),
+    (300, 1100, 20, 20, 128, 3),      # ragged last segment (T' = 1061)
+    (17, 4096, 20, 0, 1000, 2),
+    (50, 515, 20, 7, 33, 2),          # T % 4 != 0: unaligned rows
+    (40, 600, 8, 3, 50, 2),           # runtime-W kernel, W < 16
+    (40, 600, 16, 0, 50, 2),          # W == 16: exactly one block
+    (40, 600, 37, 5, 50, 2),          # W = 2 blocks + 5
+    (24, 900, 256, 10, 20, 1),        # PSH_MAX_W
+    (6, 2100, 20, 20, 1, 1),          # k = 1
+    (2048, 512, 20, 20, 777, 4),
+]
+
+
+@pytest.mark.parametrize("R,T,W,h,k,B", CASES)
+def test_hip_equals_oracle_seeded(hip_device, oracle_mod, R, T, W, h, k, B):
+    ds = syn.dataset(R, T, 100 + R)
+    q = syn.gbm_log_returns((B, W), 200 + W)
+    d, idx, status, _ = hip_scan(hip_device, ds, q, k, h)
+    assert np.all(status == 0)
+    od, oidx = oracle_mod.scan_topk(ds, q, k, h=h)
+    assert_exact(d, idx, od, oidx, f"R={R} T={T} W={W} h={h} k={k} B={B}")
+
+
+@pytest.mark.parametrize("R,T,W,h,k,B", [(2048, 512, 20, 20, 777, 4), (300, 1100, 20, 20, 128, 3), (40, 600, 37, 5, 50, 2)])
+def test_exhaustive_path_equals_oracle(hip_device, oracle_mod, R, T, W, h, k, B):
+    ds = syn.dataset(R, T, 100 + R)
+    q = syn.gbm_log_returns((B, W), 200 + W)
+    d, idx, status, _ = hip_scan(hip_device, ds, q, k, h, exhaustive=True)
+    od, oidx = oracle_mod.scan_topk(ds, q, k, h=h)
+    assert_exact(d, idx, od, oidx, "exhaustive")
+
+
+def test_sampled_path_is_taken_and_profiled(hip_device, oracle_mod):
+    """Big enough that the threshold path (sample -> tau -> filter -> select) runs."""
+    R, T, W, h, k = 4096, 4096, 20, 20, 1024
+    ds = syn.dataset(R, T, 7)
+    q = syn.single_query(W, 8)
+    d, idx, status, prof = hip_scan(hip_device, ds, q, k, h, profile=True)
+    assert prof["path"] == 0 and prof["n_sample_rows"] > 0 and prof["scan_ms"] > 0
+    assert np.all(status == 0)
+    od, oidx = oracle_mod.scan_topk(ds, q, k, h=h)
+    assert_exact(d, idx, od, oidx, "sampled path")
+
+
+def test_massive_ties_overflow_is_reported_and_exhaustive_is_exact(hip_device, oracle_mod):
+    """A constant dataset: every window ties.  The threshold path must flag the
+    overflow (never return silently wrong rows); the exhaustive path returns the
+    canonical first-k windows, as the oracle does."""
+    R, T, W, h, k = 4096, 1024, 20, 20, 64
+    ds = np.full((R, 1, T), 0.01, np.float32)
+    q = syn.single_query(W, 9)
+    d, idx, status, prof = hip_scan(hip_device, ds, q, k, h, profile=True)
+    od, oidx = oracle_mod.scan_topk(ds, q, k, h=h)
+    if prof["path"] == 0:
+        assert np.all(status == 1), "overflow must be reported"
+    d2, idx2, _, _ = hip_scan(hip_device, ds, q, k, h, exhaustive=True)
+    assert_exact(d2, idx2, od, oidx, "ties, exhaustive")
+    # and the host wrapper resolves it transparently
+    import shadowing_amd as sa
+    obj = sa.PathShadowing(sa.Identity(W), sa.RelativeMSE(), ds, sa.PredictionContext(h))
+    d3, _, idx3 = obj.shadow(q, k=k, cuda=True)
+    assert_exact(d3, idx3, od, oidx, "ties, PathShadowing")
+
+
+def test_query_norm_kernel(hip_device, oracle_mod):
+    from shadowing_amd import _native
+    rng = np.random.default_rng(3)
+    for W in list(range(1, 40)) + [63, 64, 126, 256]:
+        x = (rng.standard_normal((5, W)) * 0.0126).astype(np.float32)
+        got = _native.query_norm(torch.as_tensor(x).to(hip_device)).cpu().numpy()
+        assert np.array_equal(bits(got), bits(oracle_mod.qnorm(x))), W
+
+
+def test_shard_and_merge_invariance(hip_device, oracle_mod):
+    """Scanning row shards with r_offset and merging on the device equals the whole."""
+    from shadowing_amd import _native
+    R, T, W, h, k, B = 1000, 800, 20, 20, 300, 3
+    ds = syn.dataset(R, T, 11)
+    q = syn.gbm_log_returns((B, W), 12)
+    whole = hip_scan(hip_device, ds, q, k, h)
+    parts_d, parts_i = [], []
+    for lo, hi in ((0, 1), (1, 400), (400, 1000)):    # first shard has fewer than k windows? (1 row: 741) no -> use k_local
+        n_local = (hi - lo) * (T - W - h + 1)
+        kl = min(k, n_local)
+        ds_t = torch.as_tensor(ds[lo:hi, 0, :].copy()).to(hip_device)
+        dd, ii, st = _native.scan_topk(ds_t, torch.as_tensor(q).to(hip_device), kl, h=h, r_offset=lo)
+        if kl < k:
+            dd = torch.cat([dd, dd.new_full((B, k - kl), float("inf"))], 1)
+            ii = torch.cat([ii, ii.new_full((B, k - kl, 2), -1)], 1)
+        parts_d.append(dd)
+        parts_i.append(ii)
+    md, mi = _native.merge_topk(torch.cat(parts_d, 1).contiguous(), torch.cat(parts_i, 1).contiguous(), k)
+    torch.cuda.synchronize()
+    assert_exact(md.cpu().numpy(), mi.cpu().numpy(), whole[0], whole[1], "sharded + merged")
+    od, oidx = oracle_mod.scan_topk(ds, q, k, h=h)
+    assert_exact(whole[0], whole[1], od, oidx, "whole")
+
+
+def test_gather_paths_kernel(hip_device, oracle_mod):
+    from shadowing_amd import _native
+    ds = syn.dataset(50, 300, 13)
+    q = syn.gbm_log_returns((2, 20), 14)
+    d, idx = oracle_mod.scan_topk(ds, q, 25, h=20)
+    got = _native.gather_paths(torch.as_tensor(ds).to(hip_device), torch.as_tensor(idx).to(hip_device), 40)
+    assert np.array_equal(got.cpu().numpy()[:, :, 0, :], oracle_mod.gather_paths(ds, idx, 40))
+
+
+def test_scale_invariance_of_indices(hip_device):
+    """RelativeMSE is scale-free: dataset*c, query*c (c a power of two: exact) gives the
+    same indices and bit-identical distances."""
+    ds = syn.dataset(512, 1024, 15)
+    q = syn.single_query(20, 16)
+    a = hip_scan(hip_device, ds, q, 200, 20)
+    b = hip_scan(hip_device, ds * 4.0, q * 4.0, 200, 20)
+    assert_exact(b[0], b[1], a[0], a[1], "scale invariance")
+
+
+def test_full_size_properties(hip_device):
+    """configs[1] size: rows sorted, indices admissible and distinct, every returned
+    distance re-derivable from the dataset, halves + merge == whole."""
+    from shadowing_amd import _native
+    g = load_golden("cfg2_R32768")
+    ds, q, k, h, W = g["dataset"], g["queries"], g["k"], g["h"], g["W"]
+    d, idx, status, _ = hip_scan(hip_device, ds, q, k, h)
+    assert np.all(status == 0) and np.all(np.diff(d[0]) >= 0)
+    assert idx[..., 0].min() >= 0 and idx[..., 0].max() < ds.shape[0]
+    assert idx[..., 1].min() >= 0 and idx[..., 1].max() <= ds.shape[-1] - W - h
+    assert len({tuple(v) for v in idx[0]}) == k
+    # recompute each returned distance on the host in the reference's order
+    xn = np.float32(g["xn"][0])
+    for j in range(0, k, 37):
+        r, t = idx[0, j]
+        acc = np.float32(0)
+        for i in range(W):
+            D = np.float32(q[0, i] - ds[r, 0, t + i])
+            acc = np.float32(np.float64(D) * np.float64(D) + np.float64(acc))
+        assert bits(np.float32(np.sqrt(acc)) / xn) == bits(d[0, j])
