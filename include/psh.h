@@ -51,9 +51,22 @@ extern "C" {
 #define PSH_STATUS_OVERFLOW  1     /* candidate buffer overflowed: results of that query are
                                       INVALID, rerun it with psh_scan_topk_exhaustive */
 
-/* Stage timings (milliseconds, HIP events on `stream`) filled when a non-NULL
- * psh_profile is passed; doing so makes the call synchronise the stream. */
+/*
+ * Optional instrumentation of psh_scan_topk / psh_scan_topk_exhaustive.
+ *   mode PSH_PROFILE_STAGES: HIP events are recorded on `stream` between the stages,
+ *        the call SYNCHRONISES the stream and fills the *_ms fields.
+ *   mode PSH_PROFILE_EVENTS: nothing is synchronised; the two caller-created
+ *        hipEvent_t handles are recorded on `stream` immediately before and after the
+ *        dominant kernel (the full sliding-window scan), so that a benchmark can time
+ *        that kernel live inside its own timed loop.
+ */
+#define PSH_PROFILE_STAGES 0
+#define PSH_PROFILE_EVENTS 1
 typedef struct psh_profile {
+    int   mode;           /* in */
+    int   reserved;
+    void* ev_scan_begin;  /* in (PSH_PROFILE_EVENTS): hipEvent_t */
+    void* ev_scan_end;    /* in (PSH_PROFILE_EVENTS): hipEvent_t */
     float prep_ms;        /* query norms + state reset                      */
     float sample_ms;      /* sample-rows scan -> histogram of lane minima   */
     float threshold_ms;   /* histogram -> admission threshold               */
@@ -63,7 +76,7 @@ typedef struct psh_profile {
     int   path;           /* 0 = sampled threshold path, 1 = exhaustive path */
     int   n_sample_rows;
     int   grid_blocks;    /* blocks of the scan kernel */
-    int   reserved;
+    int   n_candidates;   /* PSH_PROFILE_STAGES: largest per-query candidate count the scan admitted */
 } psh_profile;
 
 int         psh_version(void);

@@ -15,7 +15,7 @@ from . import _build
 
 PSH_OK = 0
 PSH_STATUS_OK, PSH_STATUS_OVERFLOW = 0, 1
-PSH_MAX_W, PSH_MAX_K = 256, 16384
+PSH_MAX_W, PSH_MAX_K, PSH_MAX_B_PER_LAUNCH = 256, 16384, 1024
 
 
 class NativeLibraryError(RuntimeError):
@@ -23,13 +23,15 @@ class NativeLibraryError(RuntimeError):
 
 
 class PshProfile(C.Structure):
-    _fields_ = [("prep_ms", C.c_float), ("sample_ms", C.c_float), ("threshold_ms", C.c_float),
+    _fields_ = [("mode", C.c_int), ("reserved", C.c_int), ("ev_scan_begin", C.c_void_p), ("ev_scan_end", C.c_void_p),
+                ("prep_ms", C.c_float), ("sample_ms", C.c_float), ("threshold_ms", C.c_float),
                 ("scan_ms", C.c_float), ("select_ms", C.c_float), ("total_ms", C.c_float),
                 ("path", C.c_int), ("n_sample_rows", C.c_int), ("grid_blocks", C.c_int),
-                ("reserved", C.c_int)]
+                ("n_candidates", C.c_int)]
 
     def as_dict(self) -> dict:
-        return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
+        skip = ("mode", "reserved", "ev_scan_begin", "ev_scan_end")
+        return {name: getattr(self, name) for name, _ in self._fields_ if name not in skip}
 
 
 EXPORTS = ("psh_version", "psh_strerror", "psh_last_hip_error", "psh_workspace_bytes", "psh_query_norm",
@@ -141,12 +143,17 @@ def query_norm(queries: torch.Tensor) -> torch.Tensor:
 
 def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, r_offset: int = 0,
               qnorm: torch.Tensor | None = None, workspace: Workspace | None = None,
-              exhaustive: bool = False, profile: bool = False, extra_workspace_factor: float = 1.0):
+              exhaustive: bool = False, profile: bool = False, extra_workspace_factor: float = 1.0,
+              scan_events: tuple | None = None):
     """Enqueue the scan on the current stream.
 
     dataset (R, T) float32 device, queries (B, W) float32 device.  Returns
     (d (B,k) f32, idx (B,k,2) i32, status (B,) i32[, profile dict]) -- device tensors,
     NOT synchronised; status must be inspected (after a sync) unless exhaustive=True.
+    `profile=True` synchronises and adds the per-stage HIP-event timings;
+    `scan_events=(begin, end)` (two torch.cuda.Event(enable_timing=True), each recorded
+    once beforehand so that the handle exists) are re-recorded on the current stream
+    right around the dominant scan kernel, without any synchronisation.
     """
     ds = _dev_tensor(dataset, torch.float32, "dataset")
     q = _dev_tensor(queries, torch.float32, "queries")
@@ -159,12 +166,27 @@ def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, 
     dev = ds.device
     if qnorm is not None:
         qnorm = _dev_tensor(qnorm, torch.float32, "qnorm")
+    if B > PSH_MAX_B_PER_LAUNCH and not profile and scan_events is None:
+        # one launch keeps a per-block append cursor per query in LDS: batch the queries
+        parts = [scan_topk(ds, q[i:i + PSH_MAX_B_PER_LAUNCH].contiguous(), k, h=h, r_offset=r_offset,
+                           qnorm=None if qnorm is None else qnorm[i:i + PSH_MAX_B_PER_LAUNCH].contiguous(),
+                           workspace=workspace, exhaustive=exhaustive, extra_workspace_factor=extra_workspace_factor)
+                 for i in range(0, B, PSH_MAX_B_PER_LAUNCH)]
+        return tuple(torch.cat([p[j] for p in parts], dim=0) for j in range(3))
     nbytes = int(workspace_bytes(R, T, B, W, h, k) * extra_workspace_factor)
     ws = (workspace or Workspace(dev)).get(nbytes)
     out_d = torch.empty((B, k), dtype=torch.float32, device=dev)
     out_idx = torch.empty((B, k, 2), dtype=torch.int32, device=dev)
     status = torch.empty((B,), dtype=torch.int32, device=dev)
-    prof = PshProfile() if profile else None
+    prof = None
+    if profile:
+        prof = PshProfile()
+        prof.mode = 0
+    elif scan_events is not None:
+        prof = PshProfile()
+        prof.mode = 1
+        prof.ev_scan_begin = scan_events[0].cuda_event
+        prof.ev_scan_end = scan_events[1].cuda_event
     fn = load().psh_scan_topk_exhaustive if exhaustive else load().psh_scan_topk
     rc = fn(dev.index, _stream_ptr(dev), ds.data_ptr(), R, T, r_offset, q.data_ptr(),
             None if qnorm is None else qnorm.data_ptr(), B, W, h, k,

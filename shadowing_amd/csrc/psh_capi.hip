@@ -44,50 +44,87 @@ inline int tile_floats_for(int W) {
 
 struct Workspace {
     QueryState* qstate;
-    int* counts;
-    unsigned* hist;
+    int* total;
+    float* minbuf;
+    int64_t min_stride;
+    int* bcount;
     int2* sel_rt;
     float* cand_d;
     int2* cand_rt;
+    float* cmp_d;
+    int2* cmp_rt;
     int cap;
     int kpad;
 };
 
-// fixed part + cap * 12 bytes per query
-size_t fixed_bytes(int B, int kpad) {
+// bootstrap sample: which rows (spread over the ensemble) feed the admission threshold,
+// and at which granularity their minima are kept.  The scan then admits about
+// k * R / rows windows.
+//   per-wave mode: one minimum per 1024-window segment, 1/16 of the rows (more, up to a
+//                  quarter, until there are >= 8k of them);
+//   per-lane mode: one minimum per 16 windows, for ensembles too small for the above;
+//   rows == 0    : sample too thin to be useful -> exhaustive path.
+struct BootPlan { int64_t rows; int per_wave; int64_t entries; };
+BootPlan boot_plan(int64_t R, int64_t Tp, int k) {
+    BootPlan bp{0, 0, 0};
+    const int64_t nseg = (Tp + PSH_SEG - 1) / PSH_SEG;
+    const int64_t quarter = R / 4;
+    int64_t rows = R / 16;
+    const int64_t need_rows = (8 * (int64_t)k + nseg - 1) / nseg;      // >= 8k segment minima
+    if (rows < need_rows) rows = need_rows;
+    if (rows >= 1 && rows <= quarter) { bp.rows = rows; bp.per_wave = 1; bp.entries = rows * nseg; return bp; }
+    const int64_t lanes_per_row = (Tp + PSH_L - 1) / PSH_L;             // real minima per row
+    rows = (32 * (int64_t)k + lanes_per_row - 1) / lanes_per_row;
+    if (rows > quarter) rows = quarter;
+    if (rows < 1 || rows * lanes_per_row < 4 * (int64_t)k) return bp;
+    bp.rows = rows; bp.per_wave = 0; bp.entries = rows * nseg * 64;
+    return bp;
+}
+int64_t boot_entries(int64_t R, int64_t Tp, int k) { return boot_plan(R, Tp, k).entries; }
+
+// fixed part + cap * 24 bytes per query (block slices + their compacted copy)
+size_t fixed_bytes(int B, int kpad, int64_t min_stride) {
     size_t o = 0;
     o += align_up(sizeof(QueryState) * (size_t)B, 256);
     o += align_up(sizeof(int) * (size_t)B, 256);
-    o += align_up(sizeof(unsigned) * (size_t)B * PSH_NBINS, 256);
+    o += align_up(sizeof(float) * (size_t)B * (size_t)min_stride, 256);
+    o += align_up(sizeof(int) * (size_t)B * PSH_MAX_BLOCKS, 256);
     o += align_up(sizeof(int2) * (size_t)B * kpad, 256);
-    return o + 512;  // alignment slack for the two candidate arrays
+    return o + 1024;  // alignment slack for the four candidate arrays
 }
 
-int carve(void* ws, size_t bytes, int B, int k, Workspace* out) {
+int carve(void* ws, size_t bytes, int B, int k, int64_t min_stride, Workspace* out) {
     const int kpad = next_pow2(k);
-    const size_t fixed = fixed_bytes(B, kpad);
+    const size_t fixed = fixed_bytes(B, kpad, min_stride);
     if (!ws || bytes <= fixed) return PSH_ERR_WORKSPACE;
-    int64_t cap = (int64_t)((bytes - fixed) / (12 * (size_t)B));
+    int64_t cap = (int64_t)((bytes - fixed) / (24 * (size_t)B));
     cap &= ~(int64_t)63;
     if (cap > (1 << 30)) cap = 1 << 30;
     if (cap <= 0) return PSH_ERR_WORKSPACE;
     char* p = (char*)ws;
     if (((uintptr_t)p & 255u) != 0) return PSH_ERR_ARG;   // torch allocations are >= 512-byte aligned
     out->qstate = (QueryState*)p; p += align_up(sizeof(QueryState) * (size_t)B, 256);
-    out->counts = (int*)p;        p += align_up(sizeof(int) * (size_t)B, 256);
-    out->hist = (unsigned*)p;     p += align_up(sizeof(unsigned) * (size_t)B * PSH_NBINS, 256);
+    out->total = (int*)p;         p += align_up(sizeof(int) * (size_t)B, 256);
+    out->minbuf = (float*)p;      p += align_up(sizeof(float) * (size_t)B * (size_t)min_stride, 256);
+    out->min_stride = min_stride;
+    out->bcount = (int*)p;        p += align_up(sizeof(int) * (size_t)B * PSH_MAX_BLOCKS, 256);
     out->sel_rt = (int2*)p;       p += align_up(sizeof(int2) * (size_t)B * kpad, 256);
     out->cand_d = (float*)p;      p += align_up(sizeof(float) * (size_t)B * cap, 256);
-    out->cand_rt = (int2*)p;
+    out->cand_rt = (int2*)p;      p += align_up(sizeof(int2) * (size_t)B * cap, 256);
+    out->cmp_d = (float*)p;       p += align_up(sizeof(float) * (size_t)B * cap, 256);
+    out->cmp_rt = (int2*)p;
     out->cap = (int)cap;
     out->kpad = kpad;
     return PSH_OK;
 }
 
+// candidate capacity per query: the scan writes one slice per block (up to
+// PSH_MAX_BLOCKS of them), the exhaustive path one slot per window of a row chunk
 int recommended_cap(int64_t Tp, int k) {
-    int64_t cap = 64 * (int64_t)k;
-    if (cap < 65536) cap = 65536;
-    if (cap < k + 4 * Tp) cap = k + 4 * Tp;   // exhaustive path: >= 4 rows per chunk
+    const int64_t nseg = (Tp + PSH_SEG - 1) / PSH_SEG;
+    int64_t cap = 128 * (int64_t)PSH_MAX_BLOCKS;          // 128 entries per block slice
+    if (cap < 64 * (int64_t)k) cap = 64 * (int64_t)k;
+    if (cap < k + 4 * nseg * PSH_SEG) cap = k + 4 * nseg * PSH_SEG;   // exhaustive: >= 4 rows per chunk
     return (int)((cap + 63) & ~(int64_t)63);
 }
 
@@ -101,7 +138,7 @@ int check_problem(const float* dataset, int64_t R, int64_t T, int64_t r_offset, 
                   int B, int W, int h, int k, float* out_d, int32_t* out_idx, Problem* p) {
     if (!dataset || !queries || !out_d || !out_idx) return PSH_ERR_ARG;
     if (R <= 0 || T <= 0 || B <= 0 || W <= 0 || h < 0 || k <= 0 || r_offset < 0) return PSH_ERR_ARG;
-    if (W > PSH_MAX_W || k > PSH_MAX_K) return PSH_ERR_UNSUPPORTED;
+    if (W > PSH_MAX_W || k > PSH_MAX_K || B > PSH_MAX_B_PER_LAUNCH) return PSH_ERR_UNSUPPORTED;
     const int64_t Tp = T - W - h + 1;
     if (Tp <= 0) return PSH_ERR_ARG;
     if (T >= (1ll << 31) - PSH_SEG - 1024 || r_offset + R >= (1ll << 31)) return PSH_ERR_UNSUPPORTED;
@@ -117,7 +154,7 @@ struct Plan { int grid; int n_qgroups; int q_per_group; int tile_floats; };
 
 int plan_scan(int device, const Problem& p, int64_t n_rows, Plan* plan) {
     const int tile_floats = tile_floats_for(p.W);
-    const size_t shmem = (size_t)tile_floats * (PSH_SCAN_THREADS / 64) * sizeof(float);
+    const size_t shmem = scan_shmem_bytes(tile_floats, p.B);
     int bpc = 0, ncu = 0;
     HIP_TRY(scan_blocks_per_cu(p.W, p.aligned, shmem, &bpc));
     HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
@@ -135,8 +172,10 @@ int plan_scan(int device, const Problem& p, int64_t n_rows, Plan* plan) {
     const int q_per_group = (p.B + n_qgroups - 1) / n_qgroups;
     n_qgroups = (p.B + q_per_group - 1) / q_per_group;
     const int64_t units = n_rs * n_qgroups;
+    if (units >= (1ll << 31)) return PSH_ERR_UNSUPPORTED;
     int64_t grid = (units + (PSH_SCAN_THREADS / 64) - 1) / (PSH_SCAN_THREADS / 64);
     if (grid > (int64_t)bpc * ncu) grid = (int64_t)bpc * ncu;
+    if (grid > PSH_MAX_BLOCKS) grid = PSH_MAX_BLOCKS;
     if (grid < 1) grid = 1;
     plan->grid = (int)grid;
     plan->n_qgroups = n_qgroups;
@@ -163,33 +202,56 @@ ScanArgs make_scan_args(const float* dataset, const float* queries, const Proble
     a.n_qgroups = plan.n_qgroups;
     a.q_per_group = plan.q_per_group;
     a.tile_floats = plan.tile_floats;
+    a.k = p.k;
     a.qstate = w.qstate;
-    a.hist = w.hist;
+    a.minbuf = w.minbuf;
+    a.min_stride = w.min_stride;
     a.cand_d = w.cand_d;
     a.cand_rt = w.cand_rt;
-    a.counts = w.counts;
+    a.bcount = w.bcount;
+    a.slice = w.cap / plan.grid;
     a.cap = w.cap;
     return a;
 }
 
-SelectArgs make_select_args(const Problem& p, const Workspace& w, float* out_d, int32_t* out_idx, int* status) {
+// slices = true : rank what the FILTER scan left in `nblk` block slices
+// slices = false: rank the first n_fixed flat entries (r < 0 = empty)
+SelectArgs make_select_args(const Problem& p, const Workspace& w, float* out_d, int32_t* out_idx, int* status,
+                            bool slices, int nblk, int n_fixed) {
     SelectArgs s;
     memset(&s, 0, sizeof(s));
     s.cand_d = w.cand_d;
     s.cand_rt = w.cand_rt;
     s.cand_stride = w.cap;
-    s.counts = w.counts;
-    s.n_fixed = 0;
+    s.bcount = slices ? w.bcount : nullptr;
+    s.nblk = nblk;
+    s.slice = slices ? w.cap / nblk : 0;
+    s.cmp_d = w.cmp_d;
+    s.cmp_rt = w.cmp_rt;
+    s.total = w.total;
+    s.n_fixed = n_fixed;
     s.cap = w.cap;
     s.k = p.k;
     s.kpad = w.kpad;
-    s.skip_negative_rows = 0;
+    s.skip_negative_rows = slices ? 0 : 1;
     s.out_d = out_d;
     s.out_idx = out_idx;
     s.sel_rt = w.sel_rt;
     s.status = status;
     s.qstate = w.qstate;
     return s;
+}
+
+int max_total(const Workspace& w, int B, int* out) {
+    int cmax = 0;
+    for (int b0 = 0; b0 < B; b0 += 256) {
+        int tmp[256];
+        const int nb = (B - b0) < 256 ? (B - b0) : 256;
+        HIP_TRY(hipMemcpy(tmp, w.total + b0, sizeof(int) * nb, hipMemcpyDeviceToHost));
+        for (int i = 0; i < nb; ++i) cmax = tmp[i] > cmax ? tmp[i] : cmax;
+    }
+    *out = cmax;
+    return PSH_OK;
 }
 
 struct Timer {   // optional per-stage HIP events
@@ -220,14 +282,19 @@ struct Timer {   // optional per-stage HIP events
 int run_exhaustive(int device, hipStream_t s, const float* dataset, const float* queries, const float* qnorm,
                    const Problem& p, const Workspace& w, float* out_d, int32_t* out_idx, int32_t* out_status,
                    psh_profile* prof) {
-    if ((int64_t)w.cap < (int64_t)p.k + p.Tp) return PSH_ERR_WORKSPACE;
-    Timer tm(prof != nullptr, s);
+    const int64_t nseg = (p.Tp + PSH_SEG - 1) / PSH_SEG;
+    const int64_t slots_per_row = nseg * PSH_SEG;
+    if ((int64_t)w.cap < (int64_t)p.k + slots_per_row) return PSH_ERR_WORKSPACE;
+    const bool stages = prof && prof->mode == PSH_PROFILE_STAGES;
+    const bool events = prof && prof->mode == PSH_PROFILE_EVENTS && prof->ev_scan_begin && prof->ev_scan_end;
+    Timer tm(stages, s);
     int rc = tm.init(); if (rc) return rc;
     rc = tm.mark(); if (rc) return rc;
-    PrepArgs pa{queries, qnorm, p.B, p.W, w.qstate, w.counts, out_status};
+    PrepArgs pa{queries, qnorm, p.B, p.W, w.qstate, w.total, out_status};
     HIP_TRY(launch_prep(pa, s));
     rc = tm.mark(); if (rc) return rc;
-    int64_t rows_per_chunk = ((int64_t)w.cap - p.k) / p.Tp;
+    if (events) HIP_TRY(hipEventRecord((hipEvent_t)prof->ev_scan_begin, s));
+    int64_t rows_per_chunk = ((int64_t)w.cap - p.k) / slots_per_row;
     if (rows_per_chunk > p.R) rows_per_chunk = p.R;
     int grid_used = 0;
     for (int64_t r0 = 0; r0 < p.R; r0 += rows_per_chunk) {
@@ -235,24 +302,25 @@ int run_exhaustive(int device, hipStream_t s, const float* dataset, const float*
         Plan plan;
         rc = plan_scan(device, p, nr, &plan); if (rc) return rc;
         grid_used = plan.grid;
-        if (r0 > 0) {
-            ReseedArgs ra{out_d, out_idx, w.qstate, w.cand_d, w.cand_rt, w.counts, w.cap, p.k};
-            HIP_TRY(launch_reseed(ra, p.B, s));
-        }
+        const int n_slots = (int)(nr * slots_per_row);
+        // the running best (empty on the first chunk) sits right behind the window slots
+        ReseedArgs ra{out_d, out_idx, w.qstate, w.cand_d, w.cand_rt, (int64_t)w.cap, n_slots, p.k};
+        HIP_TRY(launch_reseed(ra, p.B, s));
         ScanArgs sa = make_scan_args(dataset, queries, p, w, plan, r0, 1, nr);
         HIP_TRY(launch_scan(sa, PSH_MODE_ALL, p.aligned, plan.grid, s));
-        SelectArgs se = make_select_args(p, w, out_d, out_idx, nullptr);   // cannot overflow by construction
+        SelectArgs se = make_select_args(p, w, out_d, out_idx, nullptr, false, 0, n_slots + p.k);
         HIP_TRY(launch_select(se, p.B, s));
     }
     rc = tm.mark(); if (rc) return rc;
-    if (prof) {
+    if (events) HIP_TRY(hipEventRecord((hipEvent_t)prof->ev_scan_end, s));
+    if (prof) { prof->path = 1; prof->grid_blocks = grid_used; prof->n_sample_rows = 0; }
+    if (stages) {
         HIP_TRY(hipStreamSynchronize(s));
-        memset(prof, 0, sizeof(*prof));
         tm.elapsed(0, 1, &prof->prep_ms);
         tm.elapsed(1, 2, &prof->scan_ms);
         tm.elapsed(0, 2, &prof->total_ms);
-        prof->path = 1;
-        prof->grid_blocks = grid_used;
+        prof->sample_ms = prof->threshold_ms = prof->select_ms = 0.f;
+        rc = max_total(w, p.B, &prof->n_candidates); if (rc) return rc;
     }
     return PSH_OK;
 }
@@ -282,7 +350,7 @@ int psh_workspace_bytes(int64_t R, int64_t T, int B, int W, int h, int k, size_t
     const int64_t Tp = T - W - h + 1;
     if (Tp <= 0) return PSH_ERR_ARG;
     const int cap = recommended_cap(Tp, k);
-    *out_bytes = fixed_bytes(B, next_pow2(k)) + (size_t)12 * (size_t)B * (size_t)cap + 64 * 12 * (size_t)B;
+    *out_bytes = fixed_bytes(B, next_pow2(k), boot_entries(R, Tp, k)) + (size_t)24 * (size_t)B * (size_t)cap + 64 * 24 * (size_t)B;
     return PSH_OK;
 }
 
@@ -302,7 +370,7 @@ int psh_scan_topk_exhaustive(int device, void* stream, const float* dataset, int
     int rc = check_problem(dataset, R, T, r_offset, queries, B, W, h, k, out_d, out_idx, &p);
     if (rc) return rc;
     Workspace w;
-    rc = carve(workspace, workspace_bytes, B, k, &w);
+    rc = carve(workspace, workspace_bytes, B, k, boot_entries(p.R, p.Tp, k), &w);
     if (rc) return rc;
     DeviceGuard g(device);
     if (!g.ok) { snprintf(g_hip_err, sizeof(g_hip_err), "hipSetDevice(%d) failed", device); return PSH_ERR_HIP; }
@@ -318,66 +386,69 @@ int psh_scan_topk(int device, void* stream, const float* dataset, int64_t R, int
     if (rc) return rc;
     if (!out_status) return PSH_ERR_ARG;
     Workspace w;
-    rc = carve(workspace, workspace_bytes, B, k, &w);
+    rc = carve(workspace, workspace_bytes, B, k, boot_entries(p.R, p.Tp, k), &w);
     if (rc) return rc;
-    if ((int64_t)w.cap < (int64_t)k + p.Tp) return PSH_ERR_WORKSPACE;
+    if ((int64_t)w.cap < (int64_t)k + ((p.Tp + PSH_SEG - 1) / PSH_SEG) * PSH_SEG) return PSH_ERR_WORKSPACE;
     DeviceGuard g(device);
     if (!g.ok) { snprintf(g_hip_err, sizeof(g_hip_err), "hipSetDevice(%d) failed", device); return PSH_ERR_HIP; }
     hipStream_t s = (hipStream_t)stream;
 
-    // ---- plan the sample: expected survivors ~ k * R / n_sample_rows <= cap / 4, and the
-    // sample must hold >= 4k lane minima for the bound to be tight.
-    const int64_t lanes_per_row = (p.Tp + PSH_L - 1) / PSH_L;
-    int64_t ns_a = (4 * (int64_t)k * p.R + w.cap - 1) / w.cap;
-    int64_t ns_b = (4 * (int64_t)k + lanes_per_row - 1) / lanes_per_row;
-    int64_t n_sample = ns_a > ns_b ? ns_a : ns_b;
-    if (n_sample < 1) n_sample = 1;
-    // small problems (everything fits the candidate buffer) or an unhelpful sample: exhaustive
-    if (p.N + k <= (int64_t)w.cap || 2 * n_sample > p.R)
+    // small problems (everything fits the candidate buffer), one-window rows (their
+    // numerator uses another reduction order, handled by the exhaustive kernel only) or
+    // a sample too thin to be useful: exhaustive path
+    const BootPlan bp = boot_plan(p.R, p.Tp, k);
+    const int64_t n_sample = bp.rows;
+    if (p.R * ((p.Tp + PSH_SEG - 1) / PSH_SEG) * PSH_SEG + k <= (int64_t)w.cap || p.Tp == 1 || n_sample == 0)
         return run_exhaustive(device, s, dataset, queries, qnorm, p, w, out_d, out_idx, out_status, profile);
     const int64_t stride = p.R / n_sample;
     const int64_t row0 = stride / 2;
 
-    Timer tm(profile != nullptr, s);
+    const bool stages = profile && profile->mode == PSH_PROFILE_STAGES;
+    const bool events = profile && profile->mode == PSH_PROFILE_EVENTS && profile->ev_scan_begin && profile->ev_scan_end;
+    Timer tm(stages, s);
     rc = tm.init(); if (rc) return rc;
     rc = tm.mark(); if (rc) return rc;                                       // 0
-    PrepArgs pa{queries, qnorm, B, W, w.qstate, w.counts, out_status};
+    PrepArgs pa{queries, qnorm, B, W, w.qstate, w.total, out_status};
     HIP_TRY(launch_prep(pa, s));
-    HIP_TRY(hipMemsetAsync(w.hist, 0, sizeof(unsigned) * (size_t)B * PSH_NBINS, s));
     rc = tm.mark(); if (rc) return rc;                                       // 1
 
     Plan plan_s;
     rc = plan_scan(device, p, n_sample, &plan_s); if (rc) return rc;
     ScanArgs sa = make_scan_args(dataset, queries, p, w, plan_s, row0, stride, n_sample);
-    HIP_TRY(launch_scan(sa, PSH_MODE_SAMPLE, p.aligned, plan_s.grid, s));
+    sa.boot_per_wave = bp.per_wave;
+    HIP_TRY(launch_scan(sa, PSH_MODE_BOOT, p.aligned, plan_s.grid, s));
     rc = tm.mark(); if (rc) return rc;                                       // 2
 
-    ThresholdArgs ta{w.hist, w.qstate, k};
+    ThresholdArgs ta{w.minbuf, w.min_stride, (int)bp.entries, w.qstate, k};
     HIP_TRY(launch_threshold(ta, B, s));
     rc = tm.mark(); if (rc) return rc;                                       // 3
 
     Plan plan_f;
     rc = plan_scan(device, p, p.R, &plan_f); if (rc) return rc;
     ScanArgs fa = make_scan_args(dataset, queries, p, w, plan_f, 0, 1, p.R);
+    if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_begin, s));
     HIP_TRY(launch_scan(fa, PSH_MODE_FILTER, p.aligned, plan_f.grid, s));
+    if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_end, s));
     rc = tm.mark(); if (rc) return rc;                                       // 4
 
-    SelectArgs se = make_select_args(p, w, out_d, out_idx, out_status);
+    SelectArgs se = make_select_args(p, w, out_d, out_idx, out_status, true, plan_f.grid, 0);
     HIP_TRY(launch_select(se, B, s));
     rc = tm.mark(); if (rc) return rc;                                       // 5
 
     if (profile) {
+        profile->path = 0;
+        profile->n_sample_rows = (int)n_sample;
+        profile->grid_blocks = plan_f.grid;
+    }
+    if (stages) {
         HIP_TRY(hipStreamSynchronize(s));
-        memset(profile, 0, sizeof(*profile));
         tm.elapsed(0, 1, &profile->prep_ms);
         tm.elapsed(1, 2, &profile->sample_ms);
         tm.elapsed(2, 3, &profile->threshold_ms);
         tm.elapsed(3, 4, &profile->scan_ms);
         tm.elapsed(4, 5, &profile->select_ms);
         tm.elapsed(0, 5, &profile->total_ms);
-        profile->path = 0;
-        profile->n_sample_rows = (int)n_sample;
-        profile->grid_blocks = plan_f.grid;
+        rc = max_total(w, B, &profile->n_candidates); if (rc) return rc;
     }
     return PSH_OK;
 }
@@ -403,7 +474,7 @@ int psh_merge_topk(int device, void* stream, const float* d_lists, const int32_t
     s.cand_d = d_lists;
     s.cand_rt = (const int2*)idx_lists;
     s.cand_stride = n_in;
-    s.counts = nullptr;
+    s.bcount = nullptr;
     s.n_fixed = n_in;
     s.cap = n_in;
     s.k = k;

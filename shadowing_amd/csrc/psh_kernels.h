@@ -10,30 +10,32 @@
 #define PSH_NSTAGE 5                 // 16-byte loads per lane per segment: ceil((SEG + W_max - 1) / 256)
 #define PSH_SCAN_THREADS 256
 #define PSH_SELECT_THREADS 1024
-#define PSH_NBINS 2048               // log-spaced histogram bins per query
 
-#define PSH_MODE_SAMPLE 0
-#define PSH_MODE_FILTER 1
-#define PSH_MODE_ALL 2
+#define PSH_MODE_BOOT 0              // bootstrap sample: per-lane (or per-wave) minima -> buffer
+#define PSH_MODE_FILTER 1            // the full scan: admit acc < tau
+#define PSH_MODE_ALL 2               // exhaustive: admit every window
 
 #define PSH_STATUS_OK_ 0
 #define PSH_STATUS_OVERFLOW_ 1
 
 namespace psh {
 
-struct QueryState {   // one per query, device
-    float xn;         // ||x||
-    float tau;        // admission threshold on acc (exclusive)
-    int base;         // histogram key base
-    int n_valid;      // valid entries in out_d/out_idx after the last select
+struct QueryState {   // one per query, device, 32 bytes
+    float xn;             // ||x||
+    unsigned tau_bits;    // admission threshold on acc (exclusive), float bits
+    int n_valid;          // valid entries in out_d/out_idx after the last select
+    int pad[5];
 };
+
+#define PSH_MAX_BLOCKS 2048          // upper bound of the scan grid (8 blocks x 256 CUs)
+#define PSH_MAX_B_PER_LAUNCH 1024    // per-block LDS append counters: one int per query
 
 struct PrepArgs {
     const float* queries;
     const float* qnorm_in;   // nullable
     int B, W;
     QueryState* qstate;
-    int* counts;
+    int* total;              // B: candidates seen by the last select (diagnostics)
     int* status;             // nullable
 };
 
@@ -50,16 +52,22 @@ struct ScanArgs {
     int B;
     int n_qgroups, q_per_group;
     int tile_floats;         // LDS floats per wave
+    int k;
     QueryState* qstate;
-    unsigned* hist;          // B x PSH_NBINS          (SAMPLE)
-    float* cand_d;           // B x cap                (FILTER / ALL)
-    int2* cand_rt;           // B x cap
-    int* counts;             // B
+    float* minbuf;           // B x min_stride          (BOOT)
+    int64_t min_stride;
+    int boot_per_wave;       // BOOT: 1 = one minimum per wave-segment, 0 = one per lane
+    float* cand_d;           // B x cap: FILTER: one slice of `slice` entries per block;
+    int2* cand_rt;           //          ALL: slot = unit * 1024 + 16 * lane + i
+    int* bcount;             // B x PSH_MAX_BLOCKS: entries each block appended (FILTER)
+    int slice;               // entries per block slice (FILTER)
     int cap;
 };
 
 struct ThresholdArgs {
-    const unsigned* hist;
+    const float* minbuf;
+    int64_t min_stride;
+    int n_entries;
     QueryState* qstate;
     int k;
 };
@@ -68,8 +76,12 @@ struct SelectArgs {
     const float* cand_d;
     const int2* cand_rt;
     int64_t cand_stride;     // elements between queries
-    const int* counts;       // nullable -> n_fixed
-    int n_fixed;
+    const int* bcount;       // nullable: per-block slice counts (B x PSH_MAX_BLOCKS) -> compaction first
+    int nblk, slice;
+    float* cmp_d;            // B x cand_stride: compacted candidates (slice mode)
+    int2* cmp_rt;
+    int* total;              // nullable: B, number of candidates ranked
+    int n_fixed;             // flat mode: candidates per query
     int cap;
     int k, kpad;
     int skip_negative_rows;  // merge: entries with r < 0 are padding
@@ -80,14 +92,14 @@ struct SelectArgs {
     QueryState* qstate;      // nullable
 };
 
-struct ReseedArgs {
+struct ReseedArgs {      // exhaustive path: running best -> cand[b][offset .. offset + k)
     const float* out_d;
     const int32_t* out_idx;
     QueryState* qstate;
     float* cand_d;
     int2* cand_rt;
-    int* counts;
-    int cap, k;
+    int64_t cand_stride;
+    int offset, k;
 };
 
 struct GatherArgs {
@@ -102,6 +114,7 @@ struct GatherArgs {
 hipError_t launch_prep(const PrepArgs& a, hipStream_t s);
 hipError_t launch_qnorm(const float* q, int B, int W, float* out, hipStream_t s);
 hipError_t launch_scan(const ScanArgs& a, int mode, bool aligned, int grid, hipStream_t s);
+size_t scan_shmem_bytes(int tile_floats, int B);
 hipError_t scan_blocks_per_cu(int W, bool aligned, size_t shmem, int* out);
 hipError_t launch_threshold(const ThresholdArgs& a, int B, hipStream_t s);
 hipError_t launch_select(const SelectArgs& a, int B, hipStream_t s);

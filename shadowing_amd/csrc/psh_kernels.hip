@@ -17,10 +17,14 @@
 //     element is fetched from HBM once and from LDS ~1.3 times.
 //   * the per-window chain is kept in the reference's exact order (bit-exact
 //     distances are what make indices bit-exact) -- no tree/shuffle reduction.
-//   * selection never ranks on anything but the exact value: a cheap sample pass
-//     gives a provable upper bound tau on the k-th smallest acc, the scan keeps
-//     only windows below tau (a few thousand out of 1e8), and a one-block radix
-//     select + bitonic sort orders the survivors by (d, r, t).
+//   * selection never ranks on anything but the exact value.  An admission threshold
+//     tau (a provable upper bound of the k-th smallest acc: the k-th smallest over ANY
+//     subset of the windows bounds the global one) keeps all but ~1e4 of the 1e8
+//     windows out of the candidate list; it comes from a bootstrap pass over 1/16 of the
+//     rows.  Survivors are appended to per-block slices with an LDS cursor -- no global
+//     atomics anywhere (device-scope atomics on one line cost ~25 ns each on this
+//     8-XCD part; 5e4 of them were 5x the whole scan).  A one-block radix select +
+//     bitonic sort then orders the survivors by (d, r, t).
 //   * no MFMA: the work is a streaming scan, not a contraction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,6 +38,12 @@ namespace psh {
 // ----------------------------------------------------------------------------------
 typedef const __attribute__((address_space(4))) float* const_f32p;  // scalar (SGPR) loads
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PSH_INF_BITS 0x7f800000u
+// relative margin put on every threshold derived from a bin edge or a sample value: a
+// window at or above tau then has a strictly larger DISTANCE than anything counted
+// below it (sqrt and the division compress a few ulps, 2^-16 is ~250 ulps)
+#define PSH_TAU_MARGIN (1.0f + 1.0f / 65536.0f)
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
@@ -60,10 +70,10 @@ __device__ __forceinline__ float dist_from_acc(float acc, float xn) {
     return __builtin_sqrtf(acc) / xn;
 }
 
-// sum of squares in the order of ATen's contiguous last-dim norm reduce (see
-// oracle/psh_oracle.c: psh_oracle_sumsq8): 8 lanes of fma over whole blocks of 8,
-// lanes added left to right, tail: groups of 4 as rounded products added one by one,
-// then a scalar fma chain for the last < 4.
+// sum of squares in the order of ATen's contiguous last-dim norm reduce (the oracle's
+// sumsq8 documents the probe): 8 lanes of fma over whole blocks of 8, lanes added left
+// to right, tail: groups of 4 as rounded products added one by one, then a scalar fma
+// chain for the last < 4.
 template <typename F>
 __device__ inline float sumsq8(F get, int W) {
     float lane[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -84,29 +94,23 @@ __device__ inline float sumsq8(F get, int W) {
     return s;
 }
 
-__device__ __forceinline__ int hist_key(float acc, int base) {
-    // log-spaced bins for free: sign(0) | 8 exponent bits | 7 mantissa bits
-    int key = (int)(__float_as_uint(acc) >> 16) - base;
-    key = key < 0 ? 0 : key;
-    return key > (PSH_NBINS - 1) ? (PSH_NBINS - 1) : key;
-}
-
 // ----------------------------------------------------------------------------------
-// K0: per-query preparation -- ||x||, histogram base, state reset
+// K0: per-query preparation -- ||x||, state reset
 // ----------------------------------------------------------------------------------
 __global__ void prep_kernel(PrepArgs a) {
-    const int b = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (b >= a.B) return;
-    const float* x = a.queries + (int64_t)b * a.W;
-    const float s = sumsq8([&](int j) { return x[j]; }, a.W);
-    a.qstate[b].xn = a.qnorm_in ? a.qnorm_in[b] : __builtin_sqrtf(s);
-    // bins cover acc in [s/64, s*2^10): d in [0.125, 32)
-    int base = (int)(__float_as_uint(s) >> 16) - 6 * 128;
-    a.qstate[b].base = base < 0 ? 0 : base;
-    a.qstate[b].tau = __uint_as_float(0x7f800000u);  // +inf until K2 lowers it
-    a.qstate[b].n_valid = 0;
-    a.counts[b] = 0;
-    if (a.status) a.status[b] = PSH_STATUS_OK_;
+    const int b = (int)blockIdx.x;
+    if (threadIdx.x == 0) {
+        const float* x = a.queries + (int64_t)b * a.W;
+        const float s = sumsq8([&](int j) { return x[j]; }, a.W);
+        QueryState q;
+        q.xn = a.qnorm_in ? a.qnorm_in[b] : __builtin_sqrtf(s);
+        q.tau_bits = PSH_INF_BITS;       // +inf until the bootstrap lowers it
+        q.n_valid = 0;
+        q.pad[0] = q.pad[1] = q.pad[2] = q.pad[3] = q.pad[4] = 0;
+        a.qstate[b] = q;
+        a.total[b] = 0;
+        if (a.status) a.status[b] = PSH_STATUS_OK_;
+    }
 }
 
 __global__ void qnorm_kernel(const float* queries, int B, int W, float* out) {
@@ -117,7 +121,7 @@ __global__ void qnorm_kernel(const float* queries, int B, int W, float* out) {
 }
 
 // ----------------------------------------------------------------------------------
-// K1/K3: the sliding-window scan
+// the sliding-window scan
 // ----------------------------------------------------------------------------------
 // Per-lane accumulation of the L=16 consecutive windows starting at logical tile
 // index 16*lane.  win[s] holds y[16*lane + m] for the newest m = s (mod 16); at step
@@ -188,8 +192,8 @@ __device__ __forceinline__ void accumulate16(const float* tile, int lane, const_
 }
 
 // One-window-per-row edge case (T == W + h): the reference's numerator uses the
-// 8-lane order instead of the sequential chain (oracle/psh_oracle.c).  Only lane
-// window 0 of segment 0 exists; computed by every lane for its first window only.
+// 8-lane order instead of the sequential chain (probed; see the oracle).  Only window 0
+// of segment 0 exists; exhaustive path only.
 __device__ inline float acc_single_window(const float* tile, int lane, const_f32p x, int W) {
     const int base = PSH_L * lane;
     return sumsq8([&](int j) { return __fsub_rn(x[j], tile[lds_pad(base + j)]); }, W);
@@ -214,11 +218,11 @@ __device__ __forceinline__ void stage_load(Stage& st, const float* __restrict__ 
     if (ALIGNED) {
         const f32x4* src = reinterpret_cast<const f32x4*>(row + seg_start);
         const int last = (int)((T - seg_start) >> 2) - 1;  // last float4 inside the row
-        const int nq = (nfloat + 3) >> 2;
+        const int nq = (nfloat + 3) >> 2;                   // 256 <= nq <= 320
 #pragma unroll
         for (int q = 0; q < PSH_NSTAGE; ++q) {
             int m = lane + 64 * q;
-            if (m < nq) {
+            if (q < PSH_NSTAGE - 1 || m < nq) {
                 m = m > last ? last : m;
                 st.v[q] = __builtin_nontemporal_load(src + m);
             }
@@ -244,50 +248,59 @@ __device__ __forceinline__ void stage_store(const Stage& st, float* tile, int nf
 #pragma unroll
     for (int q = 0; q < PSH_NSTAGE; ++q) {
         const int m = lane + 64 * q;
-        if (m < nq) *reinterpret_cast<f32x4*>(tile + lds_pad(4 * m)) = st.v[q];
+        if (q < PSH_NSTAGE - 1 || m < nq) *reinterpret_cast<f32x4*>(tile + lds_pad(4 * m)) = st.v[q];
     }
 }
 
-// MODE_SAMPLE: histogram of per-lane minima (a subset of the windows => its k-th
-//              smallest is an upper bound of the global k-th smallest)
-// MODE_FILTER: append windows with acc < tau
-// MODE_ALL   : append every admissible window (exhaustive path)
+// MODE_BOOT  : minimum over the admissible windows of each lane (or of the whole wave
+//              segment) -> minbuf: a subset of the windows, so its k-th smallest bounds
+//              the global k-th smallest from above
+// MODE_FILTER: append windows with acc < tau to this block's slice
+// MODE_ALL   : every admissible window to its own slot (exhaustive path)
 template <int WT, bool ALIGNED, int MODE>
 __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = lane_id();
-    const int wave_in_block = (int)(threadIdx.x >> 6);
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // provably uniform
     float* tile = smem + (size_t)wave_in_block * a.tile_floats;
+    // FILTER: this block's append cursor per query lives in LDS -- same-address global
+    // atomics are served at the memory side of the 8 non-coherent XCD L2s (tens of ns
+    // each, serialised), so the candidate list is written in per-block slices instead
+    int* lcount = reinterpret_cast<int*>(smem + (size_t)(PSH_SCAN_THREADS / 64) * a.tile_floats);
+    if (MODE == PSH_MODE_FILTER) {
+        for (int q = (int)threadIdx.x; q < a.B; q += PSH_SCAN_THREADS) lcount[q] = 0;
+        __syncthreads();
+    }
 
     const int W = WT > 0 ? WT : a.W;
     const int nfloat = PSH_SEG + W - 1;
-    const int64_t n_rs = (int64_t)a.n_rows * a.nseg;      // (row, segment) units
-    const int64_t n_units = n_rs * a.n_qgroups;
-    const int64_t gw = (int64_t)blockIdx.x * (PSH_SCAN_THREADS / 64) + wave_in_block;
-    const int64_t GW = (int64_t)gridDim.x * (PSH_SCAN_THREADS / 64);
+    const unsigned n_rs = (unsigned)a.n_rows * (unsigned)a.nseg;      // (row, segment) units
+    const unsigned n_units = n_rs * (unsigned)a.n_qgroups;             // host guarantees < 2^31
+    const unsigned gw = blockIdx.x * (PSH_SCAN_THREADS / 64) + (unsigned)wave_in_block;
+    const unsigned GW = gridDim.x * (PSH_SCAN_THREADS / 64);
     const const_f32p xq = (const_f32p)a.queries;
 
     Stage st;
-    int64_t u = gw;
+    unsigned u = gw;
     if (u < n_units) {
-        const int64_t rs = u % n_rs;
-        const int64_t row = a.row0 + (rs / a.nseg) * a.row_stride;
-        stage_load<ALIGNED>(st, a.dataset + row * a.T, a.T, (int)(rs % a.nseg) * PSH_SEG, nfloat, lane);
+        const unsigned rs = u % n_rs;
+        const int64_t row = a.row0 + (int64_t)(rs / (unsigned)a.nseg) * a.row_stride;
+        stage_load<ALIGNED>(st, a.dataset + row * a.T, a.T, (int)(rs % (unsigned)a.nseg) * PSH_SEG, nfloat, lane);
     }
     for (; u < n_units; u += GW) {
-        const int64_t rs = u % n_rs;
+        const unsigned rs = u % n_rs;
         const int qg = (int)(u / n_rs);
-        const int64_t row = a.row0 + (rs / a.nseg) * a.row_stride;
-        const int seg_start = (int)(rs % a.nseg) * PSH_SEG;
+        const int64_t row = a.row0 + (int64_t)(rs / (unsigned)a.nseg) * a.row_stride;
+        const int seg_start = (int)(rs % (unsigned)a.nseg) * PSH_SEG;
 
         stage_store(st, tile, nfloat, lane);
         wave_lds_fence();
         {   // prefetch the next unit of this wave while this one is computed
-            const int64_t un = u + GW;
+            const unsigned un = u + GW;
             if (un < n_units) {
-                const int64_t rsn = un % n_rs;
-                const int64_t rown = a.row0 + (rsn / a.nseg) * a.row_stride;
-                stage_load<ALIGNED>(st, a.dataset + rown * a.T, a.T, (int)(rsn % a.nseg) * PSH_SEG, nfloat, lane);
+                const unsigned rsn = un % n_rs;
+                const int64_t rown = a.row0 + (int64_t)(rsn / (unsigned)a.nseg) * a.row_stride;
+                stage_load<ALIGNED>(st, a.dataset + rown * a.T, a.T, (int)(rsn % (unsigned)a.nseg) * PSH_SEG, nfloat, lane);
             }
         }
 
@@ -300,8 +313,12 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
         const int q_end = (q_begin + a.q_per_group) < a.B ? (q_begin + a.q_per_group) : a.B;
         for (int b = q_begin; b < q_end; ++b) {
             const const_f32p x = xq + (int64_t)b * W;
+            QueryState* qs = a.qstate + b;
+            float tau = 0.0f;
+            if (MODE == PSH_MODE_FILTER) tau = __uint_as_float(qs->tau_bits);
+
             float acc[PSH_L];
-            if (a.Tp == 1) {
+            if (MODE == PSH_MODE_ALL && a.Tp == 1) {
 #pragma unroll
                 for (int i = 0; i < PSH_L; ++i) acc[i] = 0.0f;
                 acc[0] = acc_single_window(tile, lane, x, W);
@@ -309,33 +326,43 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
                 accumulate16<WT>(tile, lane, x, W, acc);
             }
 
-            if (MODE == PSH_MODE_SAMPLE) {
+            if (MODE == PSH_MODE_BOOT) {
                 float m;
                 if (__all(nvalid == PSH_L)) {
                     m = min16(acc);
                 } else {
-                    m = __uint_as_float(0x7f800000u);
+                    m = __uint_as_float(PSH_INF_BITS);
 #pragma unroll
                     for (int i = 0; i < PSH_L; ++i) m = (i < nvalid) ? fminf(m, acc[i]) : m;
                 }
-                if (nvalid > 0) atomicAdd(a.hist + (int64_t)b * PSH_NBINS + hist_key(m, a.qstate[b].base), 1u);
+                if (a.boot_per_wave) {
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+                    if (lane == 0) a.minbuf[(int64_t)b * a.min_stride + (int64_t)rs] = m;
+                } else {
+                    a.minbuf[(int64_t)b * a.min_stride + (int64_t)rs * 64 + lane] = m;
+                }
+            } else if (MODE == PSH_MODE_ALL) {
+                // every window has its own slot: no cursor, no atomics; inadmissible -> r = -1
+                const float xn = qs->xn;
+                const int64_t base = (int64_t)b * a.cap + (int64_t)rs * PSH_SEG + PSH_L * lane;
+#pragma unroll
+                for (int i = 0; i < PSH_L; ++i) {
+                    const bool ok = i < nvalid;
+                    a.cand_d[base + i] = ok ? dist_from_acc(acc[i], xn) : __uint_as_float(PSH_INF_BITS);
+                    a.cand_rt[base + i] = ok ? make_int2(r_global, t_lane + i) : make_int2(-1, -1);
+                }
             } else {
-                const float tau = (MODE == PSH_MODE_FILTER) ? a.qstate[b].tau : 0.0f;
-                bool any_hit;
-                if (MODE == PSH_MODE_FILTER) any_hit = __any(min16(acc) < tau);
-                else any_hit = true;
-                if (any_hit) {  // rare in FILTER mode: ~1e-4 of the windows survive
-                    const float xn = a.qstate[b].xn;
-                    float* cd = a.cand_d + (int64_t)b * a.cap;
-                    int2* crt = a.cand_rt + (int64_t)b * a.cap;
+                if (__any(min16(acc) < tau)) {  // rare: ~1e-4 of the windows survive
+                    const float xn = qs->xn;
+                    const int64_t sbase = (int64_t)b * a.cap + (int64_t)blockIdx.x * a.slice;
 #pragma unroll
                     for (int i = 0; i < PSH_L; ++i) {
-                        const bool hit = (i < nvalid) && (MODE == PSH_MODE_ALL || acc[i] < tau);
-                        if (hit) {
-                            const int pos = atomicAdd(a.counts + b, 1);
-                            if (pos < a.cap) {
-                                cd[pos] = dist_from_acc(acc[i], xn);
-                                crt[pos] = make_int2(r_global, t_lane + i);
+                        if ((i < nvalid) && (acc[i] < tau)) {
+                            const int pos = atomicAdd(&lcount[b], 1);          // LDS
+                            if (pos < a.slice) {
+                                a.cand_d[sbase + pos] = dist_from_acc(acc[i], xn);
+                                a.cand_rt[sbase + pos] = make_int2(r_global, t_lane + i);
                             }
                         }
                     }
@@ -344,64 +371,147 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
         }
         wave_lds_fence();  // all lanes done with the tile before it is overwritten
     }
+    if (MODE == PSH_MODE_FILTER) {
+        __syncthreads();
+        for (int q = (int)threadIdx.x; q < a.B; q += PSH_SCAN_THREADS)
+            a.bcount[(int64_t)q * PSH_MAX_BLOCKS + blockIdx.x] = lcount[q];
+    }
 }
 
 // ----------------------------------------------------------------------------------
-// K2: histogram of sample minima -> admission threshold tau (upper bin edge + margin)
+// one-block selection machinery (threshold of the bootstrap sample, final top-k, merge)
 // ----------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void threshold_kernel(ThresholdArgs a) {
-    __shared__ unsigned part[256];
-    __shared__ int found_bin;
+struct SelectShared {
+    unsigned hist[256];
+    uint64_t prefix, kmin, kmax;
+    int remaining, done, nsel, cnt, overflow;
+    int offs[PSH_MAX_BLOCKS + 1];
+};
+
+// min / max of the live 64-bit keys over the block (kmin > kmax when nothing is live)
+template <typename KeyFn, typename LiveFn>
+__device__ inline void block_minmax64(KeyFn key_of, LiveFn live, int n, SelectShared* sm,
+                                      uint64_t* out_min, uint64_t* out_max) {
+    const int tid = (int)threadIdx.x;
+    __syncthreads();
+    if (tid == 0) { sm->kmin = ~0ull; sm->kmax = 0ull; }
+    __syncthreads();
+    uint64_t lo = ~0ull, hi = 0ull;
+    for (int i = tid; i < n; i += PSH_SELECT_THREADS) {
+        if (!live(i)) continue;
+        const uint64_t k = key_of(i);
+        lo = k < lo ? k : lo;
+        hi = k > hi ? k : hi;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t l2 = __shfl_xor(lo, off, 64), h2 = __shfl_xor(hi, off, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((tid & 63) == 0) { atomicMin((unsigned long long*)&sm->kmin, (unsigned long long)lo); atomicMax((unsigned long long*)&sm->kmax, (unsigned long long)hi); }
+    __syncthreads();
+    *out_min = sm->kmin;
+    *out_max = sm->kmax;
+    __syncthreads();
+}
+
+// Rank-`rank` (1-based) smallest 64-bit key among the candidates i with live(i); only
+// key bits >= sh_floor are examined.  MSB-first, 8 bits per pass, starting at the first
+// bit in which the keys differ at all (a pass over a digit every key shares would only
+// serialise 1e4 LDS atomics on one counter).  On return, in every thread: the live
+// candidates with (key >> sh) <= (prefix >> sh) are exactly the `rank` smallest -- unless
+// keys tie down to sh_floor (*exact false): then more may match and *remaining of the
+// ones equal to prefix at sh_floor are still wanted.
+template <typename KeyFn, typename LiveFn>
+__device__ inline void radix_select64(KeyFn key_of, LiveFn live, int n, int rank, int sh_floor,
+                                      SelectShared* sm, uint64_t* out_prefix, int* out_sh, bool* out_exact,
+                                      int* out_remaining) {
+    const int tid = (int)threadIdx.x;
+    uint64_t kmin, kmax;
+    block_minmax64(key_of, live, n, sm, &kmin, &kmax);
+    const uint64_t diff = (kmin ^ kmax) >> sh_floor;
+    if (kmin > kmax || diff == 0ull) {       // nothing live, or every key equal above the floor
+        *out_prefix = (kmin > kmax) ? 0ull : ((kmin >> sh_floor) << sh_floor);
+        *out_sh = sh_floor;
+        *out_exact = false;
+        *out_remaining = rank;
+        return;
+    }
+    const int top_bit = 63 - __clzll((unsigned long long)(diff << sh_floor));   // highest differing bit
+    int sh = sh_floor + 8 * ((top_bit - sh_floor) / 8);                            // digit holding it
+    __syncthreads();
+    if (tid == 0) {
+        sm->prefix = (sh + 8 >= 64) ? 0ull : ((kmin >> (sh + 8)) << (sh + 8));   // shared high bits
+        sm->remaining = rank;
+        sm->done = 0;
+    }
+    __syncthreads();
+    int sh_done = sh;
+    bool first = true;
+    for (; sh >= sh_floor; sh -= 8) {
+        for (int i = tid; i < 256; i += PSH_SELECT_THREADS) sm->hist[i] = 0u;
+        __syncthreads();
+        const uint64_t prefix = sm->prefix;
+        for (int i = tid; i < n; i += PSH_SELECT_THREADS) {
+            if (!live(i)) continue;
+            const uint64_t key = key_of(i);
+            const bool match = first || ((key >> (sh + 8)) == (prefix >> (sh + 8)));
+            if (match) atomicAdd(&sm->hist[(unsigned)(key >> sh) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int rem = sm->remaining;
+            unsigned cum = 0;
+            int bucket = 255;
+            for (int i = 0; i < 256; ++i) {
+                if (cum + sm->hist[i] >= (unsigned)rem) { bucket = i; break; }
+                cum += sm->hist[i];
+            }
+            rem -= (int)cum;
+            sm->remaining = rem;
+            sm->prefix = prefix | ((uint64_t)(unsigned)bucket << sh);
+            sm->done = ((int)sm->hist[bucket] == rem) ? 1 : 0;
+        }
+        __syncthreads();
+        sh_done = sh;
+        first = false;
+        if (sm->done) break;
+    }
+    *out_prefix = sm->prefix;
+    *out_sh = sh_done;
+    *out_exact = sm->done != 0;
+    *out_remaining = sm->remaining;
+    __syncthreads();
+}
+
+// bootstrap threshold: tau = k-th smallest of the sampled minima (+ margin)
+__global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(ThresholdArgs a) {
+    __shared__ SelectShared sm;
     const int b = (int)blockIdx.x;
-    const unsigned* h = a.hist + (int64_t)b * PSH_NBINS;
-    constexpr int PER = PSH_NBINS / 256;
-    unsigned loc[PER];
-    unsigned s = 0;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) { loc[i] = h[threadIdx.x * PER + i]; s += loc[i]; }
-    part[threadIdx.x] = s;
-    if (threadIdx.x == 0) found_bin = PSH_NBINS;  // "not found"
-    __syncthreads();
-    // exclusive prefix of the 256 partial sums (serial in one thread: 256 adds)
+    const float* v = a.minbuf + (int64_t)b * a.min_stride;
+    const int n = a.n_entries;
+    if (n < a.k) return;                                   // tau stays +inf (host avoids this)
+    uint64_t prefix;
+    int sh, rem;
+    bool exact;
+    radix_select64([&](int i) { return (uint64_t)__float_as_uint(v[i]) << 32; }, [](int) { return true; },
+                   n, a.k, 32, &sm, &prefix, &sh, &exact, &rem);
     if (threadIdx.x == 0) {
-        unsigned run = 0;
-        for (int i = 0; i < 256; ++i) { const unsigned v = part[i]; part[i] = run; run += v; }
-    }
-    __syncthreads();
-    unsigned cum = part[threadIdx.x];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const unsigned before = cum;
-        cum += loc[i];
-        if (before < (unsigned)a.k && cum >= (unsigned)a.k) found_bin = (int)threadIdx.x * PER + i;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float tau = __uint_as_float(0x7f800000u);
-        const int bin = found_bin;
-        if (bin < PSH_NBINS - 1) {  // the last bin is the open-ended overflow bin
-            // every sample value counted in bins <= bin is < edge
-            const unsigned edge_bits = (unsigned)(a.qstate[b].base + bin + 1) << 16;
-            if (edge_bits < 0x7f800000u) {
-                // margin: a window at or above tau must have a strictly larger *distance*
-                // than anything below the edge (sqrt and the division compress ulps)
-                tau = __uint_as_float(edge_bits) * (1.0f + 1.0f / 262144.0f);
+        // every sampled value whose bits >> (sh-32) are <= the prefix's is among the k
+        // smallest: the largest float with that truncated prefix bounds them all
+        const unsigned hi_bits = (unsigned)(prefix >> 32) | ((sh > 32) ? ((1u << (sh - 32)) - 1u) : 0u);
+        if (hi_bits < PSH_INF_BITS) {
+            const float tau0 = __uint_as_float(hi_bits) * PSH_TAU_MARGIN;   // strictly above the k-th value
+            if (tau0 < __uint_as_float(PSH_INF_BITS) && tau0 > 0.0f) {
+                a.qstate[b].tau_bits = __float_as_uint(tau0);
             }
         }
-        a.qstate[b].tau = tau;
     }
 }
 
-// ----------------------------------------------------------------------------------
-// K4: survivors -> k best by (d, r, t): MSB radix select on the 96-bit key, then an
-// in-LDS bitonic sort of the selected k
-// ----------------------------------------------------------------------------------
-typedef unsigned __int128 u128;
-
-__device__ __forceinline__ u128 key96(float d, int2 rt) {
-    return ((u128)__float_as_uint(d) << 64) | ((u128)(unsigned)rt.x << 32) | (u128)(unsigned)rt.y;
-}
-
+// survivors -> k best by (d, r, t): radix select on the distance bits, ties at the k-th
+// VALUE broken by a second radix select on (r, t), then an in-LDS bitonic sort
 __device__ __forceinline__ bool item_less(uint64_t x, uint64_t y, const int2* rt) {
     const unsigned dx = (unsigned)(x >> 32), dy = (unsigned)(y >> 32);
     if (dx != dy) return dx < dy;
@@ -416,88 +526,128 @@ __device__ __forceinline__ bool item_less(uint64_t x, uint64_t y, const int2* rt
 
 __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t items[];   // kpad entries
-    __shared__ unsigned hist[256];
-    __shared__ u128 s_prefix;
-    __shared__ int s_remaining, s_done, s_nsel;
+    __shared__ SelectShared sm;
 
     const int b = (int)blockIdx.x;
     const int tid = (int)threadIdx.x;
-    const float* cd = a.cand_d + (int64_t)b * a.cand_stride;
-    const int2* crt = a.cand_rt + (int64_t)b * a.cand_stride;
-    int n = a.counts ? a.counts[b] : a.n_fixed;
-    if (a.counts && n > a.cap) {
-        n = a.cap;
-        if (tid == 0 && a.status) a.status[b] = PSH_STATUS_OVERFLOW_;
-    }
-    int2* sel_rt = a.sel_rt + (int64_t)b * a.kpad;
-
-    // merge inputs may carry padding entries (r < 0): only real candidates are ranked
-    int n_real = n;
-    if (a.skip_negative_rows) {
-        if (tid == 0) s_nsel = 0;
+    const float* cd;
+    const int2* crt;
+    int n;
+    if (a.bcount) {
+        // ---- the scan left one slice per block: compact them into one list
+        const int* bc = a.bcount + (int64_t)b * PSH_MAX_BLOCKS;
+        if (tid == 0) { sm.overflow = 0; sm.offs[0] = 0; }
         __syncthreads();
+        for (int i = tid; i < a.nblk; i += PSH_SELECT_THREADS) {
+            int c = bc[i];
+            if (c > a.slice) { c = a.slice; sm.overflow = 1; }
+            sm.offs[i + 1] = c;
+        }
+        __syncthreads();
+        for (int off = 1; off < a.nblk; off <<= 1) {            // inclusive scan of offs[1..nblk]
+            int v[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int i = tid + e * PSH_SELECT_THREADS + 1;
+                v[e] = (i <= a.nblk && i - off >= 1) ? sm.offs[i - off] : 0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int i = tid + e * PSH_SELECT_THREADS + 1;
+                if (i <= a.nblk) sm.offs[i] += v[e];
+            }
+            __syncthreads();
+        }
+        n = sm.offs[a.nblk];
+        float* od = a.cmp_d + (int64_t)b * a.cand_stride;
+        int2* ort = a.cmp_rt + (int64_t)b * a.cand_stride;
+        const float* sd = a.cand_d + (int64_t)b * a.cand_stride;
+        const int2* srt = a.cand_rt + (int64_t)b * a.cand_stride;
+        // flat copy, every element independent (a per-slice loop would serialise one
+        // global round trip per slice): binary search of the owning slice in LDS
+        for (int e = tid; e < n; e += PSH_SELECT_THREADS) {
+            int lo = 0, hi = a.nblk;              // offs[lo] <= e < offs[hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (sm.offs[mid] <= e) lo = mid; else hi = mid;
+            }
+            const int64_t src = (int64_t)lo * a.slice + (e - sm.offs[lo]);
+            od[e] = sd[src];
+            ort[e] = srt[src];
+        }
+        if (tid == 0 && sm.overflow && a.status) a.status[b] = PSH_STATUS_OVERFLOW_;
+        __syncthreads();
+        cd = od;
+        crt = ort;
+    } else {
+        cd = a.cand_d + (int64_t)b * a.cand_stride;
+        crt = a.cand_rt + (int64_t)b * a.cand_stride;
+        n = a.n_fixed;
+    }
+    if (tid == 0 && a.total) a.total[b] = n;
+    int2* sel_rt = a.sel_rt + (int64_t)b * a.kpad;
+    const bool skip_neg = a.skip_negative_rows != 0;
+    auto live = [&](int i) { return !skip_neg || crt[i].x >= 0; };
+
+    // flat inputs may carry padding entries (r < 0): only real candidates are ranked
+    if (tid == 0) sm.cnt = 0;
+    __syncthreads();
+    int n_real = n;
+    if (skip_neg) {
         int c = 0;
         for (int i = tid; i < n; i += PSH_SELECT_THREADS) c += (crt[i].x >= 0) ? 1 : 0;
-        if (c) atomicAdd(&s_nsel, c);
+        if (c) atomicAdd(&sm.cnt, c);
         __syncthreads();
-        n_real = s_nsel;
-        __syncthreads();
+        n_real = sm.cnt;
     }
     const int need = a.k < n_real ? a.k : n_real;
 
-    if (tid == 0) { s_prefix = 0; s_remaining = need; s_done = (need == n_real) ? 1 : 0; s_nsel = 0; }
-    __syncthreads();
-
-    // ---- radix select: find the truncated key below/at which exactly `need` candidates lie
-    int p_done = -1;   // index of the last digit fixed in s_prefix
-    if (!s_done && need > 0) {
-        for (int p = 0; p < 12; ++p) {
-            for (int i = tid; i < 256; i += PSH_SELECT_THREADS) hist[i] = 0;
-            __syncthreads();
-            const u128 prefix = s_prefix;
-            const int sh_digit = 88 - 8 * p;
-            for (int i = tid; i < n; i += PSH_SELECT_THREADS) {
-                const int2 rt = crt[i];
-                if (a.skip_negative_rows && rt.x < 0) continue;
-                const u128 key = key96(cd[i], rt);
-                const bool match = (p == 0) || ((key >> (sh_digit + 8)) == (prefix >> (sh_digit + 8)));
-                if (match) atomicAdd(&hist[(unsigned)(key >> sh_digit) & 255u], 1u);
-            }
-            __syncthreads();
-            if (tid == 0) {
-                int rem = s_remaining;
-                unsigned cum = 0;
-                int bucket = 255;
-                for (int i = 0; i < 256; ++i) {
-                    if (cum + hist[i] >= (unsigned)rem) { bucket = i; break; }
-                    cum += hist[i];
-                }
-                rem -= (int)cum;
-                s_remaining = rem;
-                s_prefix = prefix | ((u128)(unsigned)bucket << sh_digit);
-                s_done = ((int)hist[bucket] == rem) ? 1 : 0;
-            }
-            __syncthreads();
-            p_done = p;
-            if (s_done) break;
+    // ---- which candidates are in
+    uint64_t d_prefix = ~0ull, rt_prefix = ~0ull;
+    int d_sh = 64, rt_sh = 64;       // 64: no restriction
+    bool tie_select = false;
+    if (need > 0 && need < n_real) {
+        bool exact;
+        int rem;
+        radix_select64([&](int i) { return (uint64_t)__float_as_uint(cd[i]) << 32; }, live, n, need, 32,
+                       &sm, &d_prefix, &d_sh, &exact, &rem);
+        if (!exact) {
+            // the k-th distance VALUE is shared by more candidates than fit: the canonical
+            // order keeps the smallest (r, t) among those ties
+            tie_select = true;
+            const unsigned dk = (unsigned)(d_prefix >> 32);
+            bool exact2;
+            int rem2;
+            radix_select64([&](int i) { return ((uint64_t)(unsigned)crt[i].x << 32) | (uint64_t)(unsigned)crt[i].y; },
+                           [&](int i) { return live(i) && __float_as_uint(cd[i]) == dk; }, n, rem, 0,
+                           &sm, &rt_prefix, &rt_sh, &exact2, &rem2);
         }
     }
 
     // ---- collect the selected candidates
     for (int i = tid; i < a.kpad; i += PSH_SELECT_THREADS) items[i] = ~0ull;
+    if (tid == 0) sm.nsel = 0;
     __syncthreads();
     if (need > 0) {
-        const u128 prefix = s_prefix;
-        const int sh = (p_done < 0) ? 96 : (88 - 8 * p_done);
+        const unsigned dk = (unsigned)(d_prefix >> 32);
         for (int i = tid; i < n; i += PSH_SELECT_THREADS) {
+            if (!live(i)) continue;
             const int2 rt = crt[i];
-            if (a.skip_negative_rows && rt.x < 0) continue;
-            const float d = cd[i];
-            const bool take = (sh >= 96) ? true : ((key96(d, rt) >> sh) <= (prefix >> sh));
+            const unsigned db = __float_as_uint(cd[i]);
+            bool take;
+            if (d_sh >= 64) {
+                take = true;
+            } else if (!tie_select) {
+                take = (((uint64_t)db << 32) >> d_sh) <= (d_prefix >> d_sh);
+            } else {
+                const uint64_t rk = ((uint64_t)(unsigned)rt.x << 32) | (uint64_t)(unsigned)rt.y;
+                take = (db < dk) || (db == dk && (rk >> rt_sh) <= (rt_prefix >> rt_sh));
+            }
             if (take) {
-                const int slot = atomicAdd(&s_nsel, 1);
+                const int slot = atomicAdd(&sm.nsel, 1);
                 if (slot < a.kpad) {
-                    items[slot] = ((uint64_t)__float_as_uint(d) << 32) | (uint64_t)(unsigned)slot;
+                    items[slot] = ((uint64_t)db << 32) | (uint64_t)(unsigned)slot;
                     sel_rt[slot] = rt;
                 }
             }
@@ -522,9 +672,9 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
     __syncthreads();
 
     // ---- write out
-    int nsel = s_nsel < need ? s_nsel : need;
+    const int nsel = sm.nsel < need ? sm.nsel : need;
     for (int i = tid; i < a.k; i += PSH_SELECT_THREADS) {
-        float d = __uint_as_float(0x7f800000u);
+        float d = __uint_as_float(PSH_INF_BITS);
         int2 rt = make_int2(-1, -1);
         if (i < nsel) {
             const uint64_t it = items[i];
@@ -538,17 +688,16 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
     if (tid == 0 && a.qstate) a.qstate[b].n_valid = nsel;
 }
 
-// exhaustive path: seed the candidate buffer of the next chunk with the running best
+// exhaustive path: the running best goes behind the next chunk's window slots
 __global__ void reseed_kernel(ReseedArgs a) {
     const int b = (int)blockIdx.y;
-    const int nv = a.qstate[b].n_valid;
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i == 0) a.counts[b] = nv;
-    if (i < nv) {
-        a.cand_d[(int64_t)b * a.cap + i] = a.out_d[(int64_t)b * a.k + i];
-        a.cand_rt[(int64_t)b * a.cap + i] =
-            make_int2(a.out_idx[((int64_t)b * a.k + i) * 2], a.out_idx[((int64_t)b * a.k + i) * 2 + 1]);
-    }
+    if (i >= a.k) return;
+    const bool ok = i < a.qstate[b].n_valid;
+    const int64_t o = (int64_t)b * a.cand_stride + a.offset + i;
+    a.cand_d[o] = ok ? a.out_d[(int64_t)b * a.k + i] : __uint_as_float(PSH_INF_BITS);
+    a.cand_rt[o] = ok ? make_int2(a.out_idx[((int64_t)b * a.k + i) * 2], a.out_idx[((int64_t)b * a.k + i) * 2 + 1])
+                      : make_int2(-1, -1);
 }
 
 // ----------------------------------------------------------------------------------
@@ -573,8 +722,8 @@ __global__ void gather_kernel(GatherArgs a) {
 template <int WT, bool ALIGNED>
 static hipError_t launch_scan_mode(const ScanArgs& a, int mode, int grid, size_t shmem, hipStream_t s) {
     switch (mode) {
-        case PSH_MODE_SAMPLE:
-            hipLaunchKernelGGL((scan_kernel<WT, ALIGNED, PSH_MODE_SAMPLE>), dim3(grid), dim3(PSH_SCAN_THREADS), shmem, s, a);
+        case PSH_MODE_BOOT:
+            hipLaunchKernelGGL((scan_kernel<WT, ALIGNED, PSH_MODE_BOOT>), dim3(grid), dim3(PSH_SCAN_THREADS), shmem, s, a);
             break;
         case PSH_MODE_FILTER:
             hipLaunchKernelGGL((scan_kernel<WT, ALIGNED, PSH_MODE_FILTER>), dim3(grid), dim3(PSH_SCAN_THREADS), shmem, s, a);
@@ -586,8 +735,12 @@ static hipError_t launch_scan_mode(const ScanArgs& a, int mode, int grid, size_t
     return hipGetLastError();
 }
 
+size_t scan_shmem_bytes(int tile_floats, int B) {
+    return (size_t)tile_floats * (PSH_SCAN_THREADS / 64) * sizeof(float) + (size_t)B * sizeof(int);
+}
+
 hipError_t launch_scan(const ScanArgs& a, int mode, bool aligned, int grid, hipStream_t s) {
-    const size_t shmem = (size_t)a.tile_floats * (PSH_SCAN_THREADS / 64) * sizeof(float);
+    const size_t shmem = scan_shmem_bytes(a.tile_floats, a.B);
     if (a.W == 20) {
         return aligned ? launch_scan_mode<20, true>(a, mode, grid, shmem, s)
                        : launch_scan_mode<20, false>(a, mode, grid, shmem, s);
@@ -611,7 +764,7 @@ hipError_t scan_blocks_per_cu(int W, bool aligned, size_t shmem, int* out) {
 }
 
 hipError_t launch_prep(const PrepArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(prep_kernel, dim3((a.B + 63) / 64), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(prep_kernel, dim3(a.B), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_qnorm(const float* q, int B, int W, float* out, hipStream_t s) {
@@ -619,7 +772,7 @@ hipError_t launch_qnorm(const float* q, int B, int W, float* out, hipStream_t s)
     return hipGetLastError();
 }
 hipError_t launch_threshold(const ThresholdArgs& a, int B, hipStream_t s) {
-    hipLaunchKernelGGL(threshold_kernel, dim3(B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(threshold_kernel, dim3(B), dim3(PSH_SELECT_THREADS), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_select(const SelectArgs& a, int B, hipStream_t s) {
