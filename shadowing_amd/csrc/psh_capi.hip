@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "psh.h"
@@ -158,6 +159,7 @@ int plan_scan(int device, const Problem& p, int64_t n_rows, Plan* plan) {
     int bpc = 0, ncu = 0;
     HIP_TRY(scan_blocks_per_cu(p.W, p.aligned, shmem, &bpc));
     HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+    if (const char* e = getenv("PSH_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) bpc = v; }   // tuning aid
     if (bpc < 1) bpc = 1;
     if (bpc > 8) bpc = 8;
     const int nseg = (int)((p.Tp + PSH_SEG - 1) / PSH_SEG);
@@ -426,6 +428,7 @@ int psh_scan_topk(int device, void* stream, const float* dataset, int64_t R, int
     Plan plan_f;
     rc = plan_scan(device, p, p.R, &plan_f); if (rc) return rc;
     ScanArgs fa = make_scan_args(dataset, queries, p, w, plan_f, 0, 1, p.R);
+    if (const char* e = getenv("PSH_DBG_TIMES_PTR")) fa.dbg_times = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning aid
     if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_begin, s));
     HIP_TRY(launch_scan(fa, PSH_MODE_FILTER, p.aligned, plan_f.grid, s));
     if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_end, s));

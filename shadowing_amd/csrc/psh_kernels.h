@@ -8,7 +8,7 @@
 #define PSH_L 16                     // consecutive windows per lane
 #define PSH_SEG (64 * PSH_L)         // windows per wave-segment
 #define PSH_NSTAGE 5                 // 16-byte loads per lane per segment: ceil((SEG + W_max - 1) / 256)
-#define PSH_SCAN_THREADS 256
+#define PSH_SCAN_THREADS 1024           // one 16-wave block per CU: its waves share one work queue in LDS
 #define PSH_SELECT_THREADS 1024
 
 #define PSH_MODE_BOOT 0              // bootstrap sample: per-lane (or per-wave) minima -> buffer
@@ -27,7 +27,7 @@ struct QueryState {   // one per query, device, 32 bytes
     int pad[5];
 };
 
-#define PSH_MAX_BLOCKS 2048          // upper bound of the scan grid (8 blocks x 256 CUs)
+#define PSH_MAX_BLOCKS 2048          // upper bound of the scan grid
 #define PSH_MAX_B_PER_LAUNCH 1024    // per-block LDS append counters: one int per query
 
 struct PrepArgs {
@@ -62,6 +62,7 @@ struct ScanArgs {
     int* bcount;             // B x PSH_MAX_BLOCKS: entries each block appended (FILTER)
     int slice;               // entries per block slice (FILTER)
     int cap;
+    unsigned long long* dbg_times;   // tuning aid (nullable): per wave {start, end} wall-clock ticks (100 MHz)
 };
 
 struct ThresholdArgs {

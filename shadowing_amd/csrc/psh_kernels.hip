@@ -127,6 +127,48 @@ __global__ void qnorm_kernel(const float* queries, int B, int W, float* out) {
 // index 16*lane.  win[s] holds y[16*lane + m] for the newest m = s (mod 16); at step
 // j window i reads slot (i + j) & 15 and slot j & 15 is then refilled with y[.. + j + 16].
 // The chain over j is strictly sequential per window: the reference's order.
+// One step j of the 16 chains of a lane: D_i = x_j - y_{i+j}; acc_i = fma(D_i, D_i, acc_i)
+// -- the reference's two roundings per term, in its order.  Written as two blocks of
+// 8 v_sub_f32 followed by their 8 v_fmac_f32: left to itself hipcc emits every FMA right
+// behind the subtraction it depends on (one temporary register), and a back-to-back
+// dependent VALU pair issues at about half rate unless the SIMD has other waves to
+// switch to (measured: 45 vs 63 T lane-ops/s at 4 waves/SIMD).  Plain VALU RAW hazards
+// are interlocked in hardware, so nothing inside the block needs a wait state.
+__device__ __forceinline__ void step8(float xj, float w0, float w1, float w2, float w3, float w4, float w5,
+                                      float w6, float w7, float& a0, float& a1, float& a2, float& a3,
+                                      float& a4, float& a5, float& a6, float& a7) {
+    float t0, t1, t2, t3, t4, t5, t6, t7;
+    asm volatile(
+        "v_sub_f32 %8, %16, %17\n\t"
+        "v_sub_f32 %9, %16, %18\n\t"
+        "v_sub_f32 %10, %16, %19\n\t"
+        "v_sub_f32 %11, %16, %20\n\t"
+        "v_sub_f32 %12, %16, %21\n\t"
+        "v_sub_f32 %13, %16, %22\n\t"
+        "v_sub_f32 %14, %16, %23\n\t"
+        "v_sub_f32 %15, %16, %24\n\t"
+        "v_fmac_f32 %0, %8, %8\n\t"
+        "v_fmac_f32 %1, %9, %9\n\t"
+        "v_fmac_f32 %2, %10, %10\n\t"
+        "v_fmac_f32 %3, %11, %11\n\t"
+        "v_fmac_f32 %4, %12, %12\n\t"
+        "v_fmac_f32 %5, %13, %13\n\t"
+        "v_fmac_f32 %6, %14, %14\n\t"
+        "v_fmac_f32 %7, %15, %15"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7),
+          "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+        : "s"(xj), "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4), "v"(w5), "v"(w6), "v"(w7));
+}
+
+__device__ __forceinline__ void step16(float xj, const float (&win)[PSH_L], int jj, float (&acc)[PSH_L]) {
+    step8(xj, win[(0 + jj) & 15], win[(1 + jj) & 15], win[(2 + jj) & 15], win[(3 + jj) & 15],
+          win[(4 + jj) & 15], win[(5 + jj) & 15], win[(6 + jj) & 15], win[(7 + jj) & 15],
+          acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
+    step8(xj, win[(8 + jj) & 15], win[(9 + jj) & 15], win[(10 + jj) & 15], win[(11 + jj) & 15],
+          win[(12 + jj) & 15], win[(13 + jj) & 15], win[(14 + jj) & 15], win[(15 + jj) & 15],
+          acc[8], acc[9], acc[10], acc[11], acc[12], acc[13], acc[14], acc[15]);
+}
+
 template <int WT>
 __device__ __forceinline__ void accumulate16(const float* tile, int lane, const_f32p x, int W,
                                              float (&acc)[PSH_L]) {
@@ -152,11 +194,7 @@ __device__ __forceinline__ void accumulate16(const float* tile, int lane, const_
             for (int q = 0; q < 4; ++q) {
                 const int jj = 4 * g + q;
                 const float xj = x[jb + jj];
-#pragma unroll
-                for (int i = 0; i < PSH_L; ++i) {
-                    const float D = __fsub_rn(xj, win[(i + jj) & 15]);
-                    acc[i] = __builtin_fmaf(D, D, acc[i]);
-                }
+                step16(xj, win, jj, acc);
                 win[jj] = nv[q];
             }
         }
@@ -179,11 +217,7 @@ __device__ __forceinline__ void accumulate16(const float* tile, int lane, const_
                 const int jj = 4 * g + q;
                 if (jj < rem) {
                     const float xj = x[j0 + jj];
-#pragma unroll
-                    for (int i = 0; i < PSH_L; ++i) {
-                        const float D = __fsub_rn(xj, win[(i + jj) & 15]);
-                        acc[i] = __builtin_fmaf(D, D, acc[i]);
-                    }
+                    step16(xj, win, jj, acc);
                     win[jj] = nv[q];
                 }
             }
@@ -252,6 +286,30 @@ __device__ __forceinline__ void stage_store(const Stage& st, float* tile, int nf
     }
 }
 
+// ---- deferred candidate append -----------------------------------------------------
+// vmcnt retires in order: a global store issued by the (rare) admission path would be
+// YOUNGER than the prefetch of the next segment, so anything that later waits for that
+// store -- including the compiler's conservative wait at the loop head -- would also wait
+// for the prefetch and serialise HBM latency with compute.  Admitted windows therefore go
+// to a wave-private LDS buffer first (LDS traffic only inside the hot loop) and are
+// written out at the top of the next iteration, BEFORE the next prefetch is issued.
+#define PSH_PEND 64                       // entries per wave: one flush lane each
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void pend_flush(const u32x4* pend, int npend, int* lcount, const ScanArgs& a, int lane) {
+    wave_lds_fence();                                  // other lanes' entries
+    if (lane < npend) {
+        const u32x4 e = pend[lane];                    // {acc bits, r, t, query}
+        const int b = (int)e[3];
+        const int pos = atomicAdd(&lcount[b], 1);      // LDS: this block's cursor for query b
+        if (pos < a.slice) {
+            const int64_t o = (int64_t)b * a.cap + (int64_t)blockIdx.x * a.slice + pos;
+            a.cand_d[o] = dist_from_acc(__uint_as_float(e[0]), a.qstate[b].xn);
+            a.cand_rt[o] = make_int2((int)e[1], (int)e[2]);
+        }
+    }
+}
+
 // MODE_BOOT  : minimum over the admissible windows of each lane (or of the whole wave
 //              segment) -> minbuf: a subset of the windows, so its k-th smallest bounds
 //              the global k-th smallest from above
@@ -267,27 +325,46 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
     // atomics are served at the memory side of the 8 non-coherent XCD L2s (tens of ns
     // each, serialised), so the candidate list is written in per-block slices instead
     int* lcount = reinterpret_cast<int*>(smem + (size_t)(PSH_SCAN_THREADS / 64) * a.tile_floats);
-    if (MODE == PSH_MODE_FILTER) {
+    u32x4* pend = reinterpret_cast<u32x4*>(lcount + ((a.B + 3) & ~3) + 4) + (size_t)wave_in_block * PSH_PEND;
+    int npend = 0;                                       // wave-uniform
+    // lcount[B .. ]: the block's work cursor.  Waves of one SIMD are served oldest first,
+    // so with a static split the young waves of every SIMD finish up to 2x later than the
+    // old ones and the tail of the launch runs at a fraction of the occupancy (measured:
+    // waves end between 69 and 149 us).  All 16 waves of the block therefore pull
+    // segments from one LDS counter; the block's own share of the units is static.
+    int* next_unit = lcount + ((a.B + 3) & ~3);
+    if (threadIdx.x == 0) *next_unit = 0;
+    if (MODE == PSH_MODE_FILTER)
         for (int q = (int)threadIdx.x; q < a.B; q += PSH_SCAN_THREADS) lcount[q] = 0;
-        __syncthreads();
-    }
+    __syncthreads();
 
     const int W = WT > 0 ? WT : a.W;
     const int nfloat = PSH_SEG + W - 1;
     const unsigned n_rs = (unsigned)a.n_rows * (unsigned)a.nseg;      // (row, segment) units
     const unsigned n_units = n_rs * (unsigned)a.n_qgroups;             // host guarantees < 2^31
+    const unsigned u_lo = (unsigned)(((unsigned long long)n_units * blockIdx.x) / gridDim.x);
+    const unsigned u_hi = (unsigned)(((unsigned long long)n_units * (blockIdx.x + 1)) / gridDim.x);
     const unsigned gw = blockIdx.x * (PSH_SCAN_THREADS / 64) + (unsigned)wave_in_block;
-    const unsigned GW = gridDim.x * (PSH_SCAN_THREADS / 64);
     const const_f32p xq = (const_f32p)a.queries;
+    // per-query state through the scalar cache: no VGPR destination, no vmcnt
+    typedef const __attribute__((address_space(4))) QueryState* const_qsp;
+    const const_qsp qstate_k = (const_qsp)a.qstate;
 
+    auto grab = [&]() -> unsigned {   // next unit of this block (wave-uniform), >= u_hi when exhausted
+        int v = 0;
+        if (lane == 0) v = atomicAdd(next_unit, 1);
+        return u_lo + (unsigned)__builtin_amdgcn_readfirstlane(v);
+    };
+
+    if (a.dbg_times && lane == 0) a.dbg_times[2 * gw] = wall_clock64();
     Stage st;
-    unsigned u = gw;
-    if (u < n_units) {
+    unsigned u = grab();
+    if (u < u_hi) {
         const unsigned rs = u % n_rs;
         const int64_t row = a.row0 + (int64_t)(rs / (unsigned)a.nseg) * a.row_stride;
         stage_load<ALIGNED>(st, a.dataset + row * a.T, a.T, (int)(rs % (unsigned)a.nseg) * PSH_SEG, nfloat, lane);
     }
-    for (; u < n_units; u += GW) {
+    while (u < u_hi) {
         const unsigned rs = u % n_rs;
         const int qg = (int)(u / n_rs);
         const int64_t row = a.row0 + (int64_t)(rs / (unsigned)a.nseg) * a.row_stride;
@@ -295,9 +372,13 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
 
         stage_store(st, tile, nfloat, lane);
         wave_lds_fence();
+        if (MODE == PSH_MODE_FILTER && npend > 0) {   // last iteration's admissions, ahead of the prefetch
+            pend_flush(pend, npend, lcount, a, lane);
+            npend = 0;
+        }
+        const unsigned un = grab();
         {   // prefetch the next unit of this wave while this one is computed
-            const unsigned un = u + GW;
-            if (un < n_units) {
+            if (un < u_hi) {
                 const unsigned rsn = un % n_rs;
                 const int64_t rown = a.row0 + (int64_t)(rsn / (unsigned)a.nseg) * a.row_stride;
                 stage_load<ALIGNED>(st, a.dataset + rown * a.T, a.T, (int)(rsn % (unsigned)a.nseg) * PSH_SEG, nfloat, lane);
@@ -313,9 +394,8 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
         const int q_end = (q_begin + a.q_per_group) < a.B ? (q_begin + a.q_per_group) : a.B;
         for (int b = q_begin; b < q_end; ++b) {
             const const_f32p x = xq + (int64_t)b * W;
-            QueryState* qs = a.qstate + b;
-            float tau = 0.0f;
-            if (MODE == PSH_MODE_FILTER) tau = __uint_as_float(qs->tau_bits);
+            const float tau = (MODE == PSH_MODE_FILTER) ? __uint_as_float(qstate_k[b].tau_bits) : 0.0f;
+            const float xn = (MODE != PSH_MODE_BOOT) ? qstate_k[b].xn : 0.0f;
 
             float acc[PSH_L];
             if (MODE == PSH_MODE_ALL && a.Tp == 1) {
@@ -344,7 +424,6 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
                 }
             } else if (MODE == PSH_MODE_ALL) {
                 // every window has its own slot: no cursor, no atomics; inadmissible -> r = -1
-                const float xn = qs->xn;
                 const int64_t base = (int64_t)b * a.cap + (int64_t)rs * PSH_SEG + PSH_L * lane;
 #pragma unroll
                 for (int i = 0; i < PSH_L; ++i) {
@@ -354,24 +433,40 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
                 }
             } else {
                 if (__any(min16(acc) < tau)) {  // rare: ~1e-4 of the windows survive
-                    const float xn = qs->xn;
-                    const int64_t sbase = (int64_t)b * a.cap + (int64_t)blockIdx.x * a.slice;
+                    // kept small on purpose (a rolled loop, one flush site): unrolling this
+                    // path 16x costs the hot loop ~30 VGPRs and a wave of occupancy
+                    unsigned hm = 0u;                            // bit i: window i admitted
 #pragma unroll
+                    for (int i = 0; i < PSH_L; ++i) hm |= ((i < nvalid) && (acc[i] < tau)) ? (1u << i) : 0u;
+#pragma unroll 1
                     for (int i = 0; i < PSH_L; ++i) {
-                        if ((i < nvalid) && (acc[i] < tau)) {
-                            const int pos = atomicAdd(&lcount[b], 1);          // LDS
-                            if (pos < a.slice) {
-                                a.cand_d[sbase + pos] = dist_from_acc(acc[i], xn);
-                                a.cand_rt[sbase + pos] = make_int2(r_global, t_lane + i);
-                            }
+                        const bool hit = ((hm >> i) & 1u) != 0u;
+                        const unsigned long long mask = __ballot(hit);
+                        if (!mask) continue;
+                        float v = acc[0];
+#pragma unroll
+                        for (int j = 1; j < PSH_L; ++j) v = (i == j) ? acc[j] : v;   // i is wave-uniform
+                        const int nh = __popcll(mask);
+                        if (npend + nh > PSH_PEND) {           // buffer full: write it out now
+                            pend_flush(pend, npend, lcount, a, lane);
+                            npend = 0;
                         }
+                        if (hit) {
+                            const int slot = npend + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                            pend[slot] = u32x4{__float_as_uint(v), (unsigned)r_global, (unsigned)(t_lane + i), (unsigned)b};
+                        }
+                        npend += nh;
                     }
                 }
             }
         }
         wave_lds_fence();  // all lanes done with the tile before it is overwritten
+        u = un;
     }
+    if (a.dbg_times && lane == 0) a.dbg_times[2 * gw + 1] = wall_clock64();
     if (MODE == PSH_MODE_FILTER) {
+        if (npend > 0) pend_flush(pend, npend, lcount, a, lane);
         __syncthreads();
         for (int q = (int)threadIdx.x; q < a.B; q += PSH_SCAN_THREADS)
             a.bcount[(int64_t)q * PSH_MAX_BLOCKS + blockIdx.x] = lcount[q];
@@ -719,8 +814,18 @@ __global__ void gather_kernel(GatherArgs a) {
 // ----------------------------------------------------------------------------------
 // launchers (host)
 // ----------------------------------------------------------------------------------
+template <int WT, bool ALIGNED, int MODE>
+static hipError_t allow_big_lds(size_t shmem) {
+    if (shmem <= 48 * 1024) return hipSuccess;
+    return hipFuncSetAttribute((const void*)scan_kernel<WT, ALIGNED, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+}
+
 template <int WT, bool ALIGNED>
 static hipError_t launch_scan_mode(const ScanArgs& a, int mode, int grid, size_t shmem, hipStream_t s) {
+    hipError_t e = mode == PSH_MODE_BOOT ? allow_big_lds<WT, ALIGNED, PSH_MODE_BOOT>(shmem)
+                 : mode == PSH_MODE_FILTER ? allow_big_lds<WT, ALIGNED, PSH_MODE_FILTER>(shmem)
+                                           : allow_big_lds<WT, ALIGNED, PSH_MODE_ALL>(shmem);
+    if (e != hipSuccess) return e;
     switch (mode) {
         case PSH_MODE_BOOT:
             hipLaunchKernelGGL((scan_kernel<WT, ALIGNED, PSH_MODE_BOOT>), dim3(grid), dim3(PSH_SCAN_THREADS), shmem, s, a);
@@ -736,7 +841,9 @@ static hipError_t launch_scan_mode(const ScanArgs& a, int mode, int grid, size_t
 }
 
 size_t scan_shmem_bytes(int tile_floats, int B) {
-    return (size_t)tile_floats * (PSH_SCAN_THREADS / 64) * sizeof(float) + (size_t)B * sizeof(int);
+    return (size_t)tile_floats * (PSH_SCAN_THREADS / 64) * sizeof(float)      // wave-private tiles
+           + (size_t)(((B + 3) & ~3) + 4) * sizeof(int)                         // per-query append cursors + work cursor
+           + (size_t)(PSH_SCAN_THREADS / 64) * PSH_PEND * 16;                   // wave-private pending admissions
 }
 
 hipError_t launch_scan(const ScanArgs& a, int mode, bool aligned, int grid, hipStream_t s) {
