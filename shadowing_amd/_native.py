@@ -42,7 +42,9 @@ _lib = None
 
 
 def library_path() -> Path:
-    return _build.LIB
+    import os
+    override = os.environ.get("PSH_LIB")          # tuning aid: load an experimental build
+    return Path(override) if override else _build.LIB
 
 
 def load() -> C.CDLL:

@@ -24,7 +24,9 @@ struct QueryState {   // one per query, device, 32 bytes
     float xn;             // ||x||
     unsigned tau_bits;    // admission threshold on acc (exclusive), float bits
     int n_valid;          // valid entries in out_d/out_idx after the last select
-    int pad[5];
+    float nx;             // sum of squares of the query (float, reference order)
+    float thr_base;       // bound-then-verify filter: reject iff  ny - 2c > thr_base + 2^-16 * NY
+    int pad[3];
 };
 
 #define PSH_MAX_BLOCKS 2048          // upper bound of the scan grid

@@ -106,7 +106,9 @@ __global__ void prep_kernel(PrepArgs a) {
         q.xn = a.qnorm_in ? a.qnorm_in[b] : __builtin_sqrtf(s);
         q.tau_bits = PSH_INF_BITS;       // +inf until the bootstrap lowers it
         q.n_valid = 0;
-        q.pad[0] = q.pad[1] = q.pad[2] = q.pad[3] = q.pad[4] = 0;
+        q.nx = s;
+        q.thr_base = __uint_as_float(PSH_INF_BITS);   // rejects nothing until the threshold kernel sets it
+        q.pad[0] = q.pad[1] = q.pad[2] = 0;
         a.qstate[b] = q;
         a.total[b] = 0;
         if (a.status) a.status[b] = PSH_STATUS_OK_;
@@ -223,6 +225,72 @@ __device__ __forceinline__ void accumulate16(const float* tile, int lane, const_
             }
         }
     }
+}
+
+// ---- bound-then-verify: the cheap test of the full scan -------------------------------
+// The exact chain costs 2 VALU operations per term (subtract, fma) and that, not HBM, is
+// what bounds the scan: 41 lane-operations per window against ~64 T lane-ops/s is
+// 83 us for the 1.3e8 windows of one query, HBM needs ~85.  But only ~1e-4 of the windows
+// can be admitted, so the scan first evaluates   S = nx + ny - 2c   (c: correlation with
+// the query, 1 fma per term; ny: window energy from a running prefix sum, ~3 operations
+// per window) -- 25 operations per window -- with a rigorous rounding-error bound, rejects
+// every window that provably cannot satisfy acc < tau, and re-evaluates the survivors
+// with the exact chain.  Ranking only ever sees exact values.
+//   t_i  = ny_i - 2 c_i  (computed),   |t_i - (ny_i - 2c_i)| <= 2^-17 (nx + NY)
+//   NY   = energy of the lane's W+15 values (bounds every prefix-sum error)
+// Compile-time W >= 17 only (the prefix differences P_{i+W} - P_i are taken while the
+// values stream through the 16-register window).
+template <int WT>
+__device__ __forceinline__ void approx16(const float* tile, int lane, const_f32p x, float (&t)[PSH_L], float& NY) {
+    static_assert(WT >= 17 && WT <= 32, "approx16 streams W in [17, 32]");
+    float win[PSH_L], c[PSH_L], Ps[PSH_L];
+    const int base = PSH_L * lane;
+#pragma unroll
+    for (int q = 0; q < PSH_L / 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(tile + lds_pad(base + 4 * q));
+        win[4 * q + 0] = v[0]; win[4 * q + 1] = v[1]; win[4 * q + 2] = v[2]; win[4 * q + 3] = v[3];
+    }
+    float P = 0.0f;                                   // P_m = sum_{n<m} y_n^2
+#pragma unroll
+    for (int m = 0; m < PSH_L; ++m) { Ps[m] = P; P = __builtin_fmaf(win[m], win[m], P); c[m] = 0.0f; }
+    // steps j = 0 .. WT-1; after step j the value y_{j+16} replaces y_j in slot j & 15
+#pragma unroll
+    for (int g = 0; g < (WT + 3) / 4; ++g) {
+        f32x4 nx4 = {0.f, 0.f, 0.f, 0.f};
+        if (4 * g + 16 <= WT + 14) nx4 = *reinterpret_cast<const f32x4*>(tile + lds_pad(base + PSH_L + 4 * g));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = 4 * g + q;
+            if (j < WT) {
+                const float xj = x[j];
+                // left to the compiler: it pairs the 16 chains into v_pk_fma_f32 (measured
+                // 118 us for the full scan vs 126 us with 320 hand-placed scalar v_fmac)
+#pragma unroll
+                for (int i = 0; i < PSH_L; ++i) c[i] = __builtin_fmaf(xj, win[(i + j) & 15], c[i]);
+                if (j + 16 <= WT + 14) {              // y_{j+16} is still needed by some window
+                    const float v = nx4[q];
+                    win[j & 15] = v;
+                    P = __builtin_fmaf(v, v, P);        // P_{j+17}
+                    if (j + 17 >= WT) Ps[j + 17 - WT] = P - Ps[j + 17 - WT];   // ny_i, i = j + 17 - W
+                }
+            }
+        }
+    }
+    NY = P;
+#pragma unroll
+    for (int i = 0; i < PSH_L; ++i) t[i] = __builtin_fmaf(-2.0f, c[i], Ps[i]);
+}
+
+// the exact chain of ONE window (survivors of the cheap test): tile index p = first value
+template <int WT>
+__device__ __forceinline__ float exact_one(const float* tile, int p, const_f32p x) {
+    float y[WT];
+#pragma unroll
+    for (int j = 0; j < WT; ++j) y[j] = tile[lds_pad(p + j)];
+    float a = 0.0f;
+#pragma unroll
+    for (int j = 0; j < WT; ++j) { const float D = __fsub_rn(x[j], y[j]); a = __builtin_fmaf(D, D, a); }
+    return a;
 }
 
 // One-window-per-row edge case (T == W + h): the reference's numerator uses the
@@ -378,7 +446,11 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
         }
         const unsigned un = grab();
         {   // prefetch the next unit of this wave while this one is computed
+#if defined(PSH_ABL) && (PSH_ABL == 1)
+            if (false) {                                   // ablation 1: no HBM traffic after the first segment
+#else
             if (un < u_hi) {
+#endif
                 const unsigned rsn = un % n_rs;
                 const int64_t rown = a.row0 + (int64_t)(rsn / (unsigned)a.nseg) * a.row_stride;
                 stage_load<ALIGNED>(st, a.dataset + rown * a.T, a.T, (int)(rsn % (unsigned)a.nseg) * PSH_SEG, nfloat, lane);
@@ -397,8 +469,20 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
             const float tau = (MODE == PSH_MODE_FILTER) ? __uint_as_float(qstate_k[b].tau_bits) : 0.0f;
             const float xn = (MODE != PSH_MODE_BOOT) ? qstate_k[b].xn : 0.0f;
 
+            constexpr bool CHEAP = (MODE == PSH_MODE_FILTER) && (WT >= 17) && (WT <= 32);
             float acc[PSH_L];
-            if (MODE == PSH_MODE_ALL && a.Tp == 1) {
+            float thr = 0.0f;
+            if (CHEAP) {
+                float NY;
+#if defined(PSH_ABL) && (PSH_ABL == 2)
+                NY = tile[lds_pad(PSH_L * lane)];                          // ablation 2: no arithmetic
+#pragma unroll
+                for (int i = 0; i < PSH_L; ++i) acc[i] = 1e30f;
+#else
+                approx16<(CHEAP ? WT : 20)>(tile, lane, x, acc, NY);     // acc[] holds t_i = ny_i - 2 c_i here
+#endif
+                thr = __builtin_fmaf(1.0f / 65536.0f, NY, qstate_k[b].thr_base);
+            } else if (MODE == PSH_MODE_ALL && a.Tp == 1) {
 #pragma unroll
                 for (int i = 0; i < PSH_L; ++i) acc[i] = 0.0f;
                 acc[0] = acc_single_window(tile, lane, x, W);
@@ -432,20 +516,30 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
                     a.cand_rt[base + i] = ok ? make_int2(r_global, t_lane + i) : make_int2(-1, -1);
                 }
             } else {
-                if (__any(min16(acc) < tau)) {  // rare: ~1e-4 of the windows survive
+                // CHEAP: keep unless provably rejected (NaN-safe: !(t > thr)); else the exact test
+                const bool wave_hit = CHEAP ? __any(!(min16(acc) > thr)) : __any(min16(acc) < tau);
+                if (wave_hit) {  // rare: ~1e-4 of the windows survive
                     // kept small on purpose (a rolled loop, one flush site): unrolling this
                     // path 16x costs the hot loop ~30 VGPRs and a wave of occupancy
                     unsigned hm = 0u;                            // bit i: window i admitted
 #pragma unroll
-                    for (int i = 0; i < PSH_L; ++i) hm |= ((i < nvalid) && (acc[i] < tau)) ? (1u << i) : 0u;
+                    for (int i = 0; i < PSH_L; ++i)
+                        hm |= ((i < nvalid) && (CHEAP ? !(acc[i] > thr) : (acc[i] < tau))) ? (1u << i) : 0u;
 #pragma unroll 1
                     for (int i = 0; i < PSH_L; ++i) {
-                        const bool hit = ((hm >> i) & 1u) != 0u;
+                        bool hit = ((hm >> i) & 1u) != 0u;
+                        if (!__ballot(hit)) continue;
+                        float v;
+                        if (CHEAP) {      // survivors of the cheap test: the exact chain decides
+                            v = hit ? exact_one<(CHEAP ? WT : 20)>(tile, PSH_L * lane + i, x) : 0.0f;
+                            hit = hit && (v < tau);
+                        } else {
+                            v = acc[0];
+#pragma unroll
+                            for (int j = 1; j < PSH_L; ++j) v = (i == j) ? acc[j] : v;   // i is wave-uniform
+                        }
                         const unsigned long long mask = __ballot(hit);
                         if (!mask) continue;
-                        float v = acc[0];
-#pragma unroll
-                        for (int j = 1; j < PSH_L; ++j) v = (i == j) ? acc[j] : v;   // i is wave-uniform
                         const int nh = __popcll(mask);
                         if (npend + nh > PSH_PEND) {           // buffer full: write it out now
                             pend_flush(pend, npend, lcount, a, lane);
@@ -599,7 +693,19 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
         if (hi_bits < PSH_INF_BITS) {
             const float tau0 = __uint_as_float(hi_bits) * PSH_TAU_MARGIN;   // strictly above the k-th value
             if (tau0 < __uint_as_float(PSH_INF_BITS) && tau0 > 0.0f) {
-                a.qstate[b].tau_bits = __float_as_uint(tau0);
+                QueryState* qs = a.qstate + b;
+                qs->tau_bits = __float_as_uint(tau0);
+                // bound-then-verify filter (see approx16): with S = nx + ny - 2c the real
+                // value of a window's sum, a window the exact fp32 chain would admit
+                // (acc < tau) satisfies  ny - 2c < tau(1+23u) - nx, and the computed
+                // t = ny^ - 2c^ is within 2^-17 (nx + NY) of ny - 2c.  Everything rounded
+                // towards "keep": in double, then up to the next float.
+                const double e16 = 1.0 / 65536.0;
+                const double nx = (double)qs->nx;
+                const double A = (double)tau0 * (1.0 + e16) - nx * (1.0 - e16) + (nx * (1.0 + e16)) / 65536.0;
+                float Af = (float)A;
+                if ((double)Af < A) Af = __uint_as_float(Af >= 0.0f ? __float_as_uint(Af) + 1u : __float_as_uint(Af) - 1u);
+                qs->thr_base = Af;
             }
         }
     }
