@@ -52,8 +52,6 @@ struct Workspace {
     int2* sel_rt;
     float* cand_d;
     int2* cand_rt;
-    float* cmp_d;
-    int2* cmp_rt;
     int cap;
     int kpad;
 };
@@ -83,7 +81,7 @@ BootPlan boot_plan(int64_t R, int64_t Tp, int k) {
 }
 int64_t boot_entries(int64_t R, int64_t Tp, int k) { return boot_plan(R, Tp, k).entries; }
 
-// fixed part + cap * 24 bytes per query (block slices + their compacted copy)
+// fixed part + cap * 12 bytes per query (the block slices / window slots)
 size_t fixed_bytes(int B, int kpad, int64_t min_stride) {
     size_t o = 0;
     o += align_up(sizeof(QueryState) * (size_t)B, 256);
@@ -98,7 +96,7 @@ int carve(void* ws, size_t bytes, int B, int k, int64_t min_stride, Workspace* o
     const int kpad = next_pow2(k);
     const size_t fixed = fixed_bytes(B, kpad, min_stride);
     if (!ws || bytes <= fixed) return PSH_ERR_WORKSPACE;
-    int64_t cap = (int64_t)((bytes - fixed) / (24 * (size_t)B));
+    int64_t cap = (int64_t)((bytes - fixed) / (12 * (size_t)B));
     cap &= ~(int64_t)63;
     if (cap > (1 << 30)) cap = 1 << 30;
     if (cap <= 0) return PSH_ERR_WORKSPACE;
@@ -111,9 +109,7 @@ int carve(void* ws, size_t bytes, int B, int k, int64_t min_stride, Workspace* o
     out->bcount = (int*)p;        p += align_up(sizeof(int) * (size_t)B * PSH_MAX_BLOCKS, 256);
     out->sel_rt = (int2*)p;       p += align_up(sizeof(int2) * (size_t)B * kpad, 256);
     out->cand_d = (float*)p;      p += align_up(sizeof(float) * (size_t)B * cap, 256);
-    out->cand_rt = (int2*)p;      p += align_up(sizeof(int2) * (size_t)B * cap, 256);
-    out->cmp_d = (float*)p;       p += align_up(sizeof(float) * (size_t)B * cap, 256);
-    out->cmp_rt = (int2*)p;
+    out->cand_rt = (int2*)p;
     out->cap = (int)cap;
     out->kpad = kpad;
     return PSH_OK;
@@ -228,8 +224,6 @@ SelectArgs make_select_args(const Problem& p, const Workspace& w, float* out_d, 
     s.bcount = slices ? w.bcount : nullptr;
     s.nblk = nblk;
     s.slice = slices ? w.cap / nblk : 0;
-    s.cmp_d = w.cmp_d;
-    s.cmp_rt = w.cmp_rt;
     s.total = w.total;
     s.n_fixed = n_fixed;
     s.cap = w.cap;
@@ -352,7 +346,7 @@ int psh_workspace_bytes(int64_t R, int64_t T, int B, int W, int h, int k, size_t
     const int64_t Tp = T - W - h + 1;
     if (Tp <= 0) return PSH_ERR_ARG;
     const int cap = recommended_cap(Tp, k);
-    *out_bytes = fixed_bytes(B, next_pow2(k), boot_entries(R, Tp, k)) + (size_t)24 * (size_t)B * (size_t)cap + 64 * 24 * (size_t)B;
+    *out_bytes = fixed_bytes(B, next_pow2(k), boot_entries(R, Tp, k)) + (size_t)12 * (size_t)B * (size_t)cap + 64 * 12 * (size_t)B;
     return PSH_OK;
 }
 
@@ -421,7 +415,7 @@ int psh_scan_topk(int device, void* stream, const float* dataset, int64_t R, int
     HIP_TRY(launch_scan(sa, PSH_MODE_BOOT, p.aligned, plan_s.grid, s));
     rc = tm.mark(); if (rc) return rc;                                       // 2
 
-    ThresholdArgs ta{w.minbuf, w.min_stride, (int)bp.entries, w.qstate, k};
+    ThresholdArgs ta{w.minbuf, w.min_stride, (int)bp.entries, w.qstate, k, 0};
     HIP_TRY(launch_threshold(ta, B, s));
     rc = tm.mark(); if (rc) return rc;                                       // 3
 

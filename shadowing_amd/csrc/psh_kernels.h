@@ -73,6 +73,7 @@ struct ThresholdArgs {
     int n_entries;
     QueryState* qstate;
     int k;
+    int keys_in_lds;         // set by the launcher
 };
 
 struct SelectArgs {
@@ -81,8 +82,7 @@ struct SelectArgs {
     int64_t cand_stride;     // elements between queries
     const int* bcount;       // nullable: per-block slice counts (B x PSH_MAX_BLOCKS) -> compaction first
     int nblk, slice;
-    float* cmp_d;            // B x cand_stride: compacted candidates (slice mode)
-    int2* cmp_rt;
+    int key_cap;             // distance keys that fit in LDS (set by the launcher)
     int* total;              // nullable: B, number of candidates ranked
     int n_fixed;             // flat mode: candidates per query
     int cap;

@@ -649,18 +649,34 @@ __device__ inline void radix_select64(KeyFn key_of, LiveFn live, int n, int rank
             if (match) atomicAdd(&sm->hist[(unsigned)(key >> sh) & 255u], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            int rem = sm->remaining;
-            unsigned cum = 0;
-            int bucket = 255;
-            for (int i = 0; i < 256; ++i) {
-                if (cum + sm->hist[i] >= (unsigned)rem) { bucket = i; break; }
-                cum += sm->hist[i];
+        if (tid < 64) {
+            // bucket holding the rank: wave-wide prefix over the 256 counters, 4 per lane
+            // (a serial walk by one thread is 256 dependent LDS round trips: ~10 us a pass)
+            const int rem = sm->remaining;
+            unsigned h[4];
+            unsigned s4 = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { h[q] = sm->hist[4 * tid + q]; s4 += h[q]; }
+            unsigned inc = s4;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned v = __shfl_up(inc, off, 64);
+                if (tid >= off) inc += v;
             }
-            rem -= (int)cum;
-            sm->remaining = rem;
-            sm->prefix = prefix | ((uint64_t)(unsigned)bucket << sh);
-            sm->done = ((int)sm->hist[bucket] == rem) ? 1 : 0;
+            unsigned cum = inc - s4;
+            if (cum < (unsigned)rem && inc >= (unsigned)rem) {      // exactly one lane
+                int bucket = 4 * tid;
+                unsigned before = cum;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (cum < (unsigned)rem && cum + h[q] >= (unsigned)rem) { bucket = 4 * tid + q; before = cum; }
+                    cum += h[q];
+                }
+                const int r2 = rem - (int)before;
+                sm->remaining = r2;
+                sm->prefix = prefix | ((uint64_t)(unsigned)bucket << sh);
+                sm->done = ((int)h[bucket & 3] == r2) ? 1 : 0;
+            }
         }
         __syncthreads();
         sh_done = sh;
@@ -674,19 +690,28 @@ __device__ inline void radix_select64(KeyFn key_of, LiveFn live, int n, int rank
     __syncthreads();
 }
 
-// bootstrap threshold: tau = k-th smallest of the sampled minima (+ margin)
+// bootstrap threshold: tau = k-th smallest of the sampled minima (+ margin).  The sample
+// is staged in LDS once; every selection pass then runs at LDS latency.
 __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(ThresholdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned tkeys[];   // n_entries (or nothing)
     __shared__ SelectShared sm;
     const int b = (int)blockIdx.x;
+    const int tid = (int)threadIdx.x;
     const float* v = a.minbuf + (int64_t)b * a.min_stride;
     const int n = a.n_entries;
     if (n < a.k) return;                                   // tau stays +inf (host avoids this)
+    const bool in_lds = a.keys_in_lds != 0;
+    if (in_lds) {
+#pragma unroll 4
+        for (int i = tid; i < n; i += PSH_SELECT_THREADS) tkeys[i] = __float_as_uint(v[i]);
+        __syncthreads();
+    }
     uint64_t prefix;
     int sh, rem;
     bool exact;
-    radix_select64([&](int i) { return (uint64_t)__float_as_uint(v[i]) << 32; }, [](int) { return true; },
-                   n, a.k, 32, &sm, &prefix, &sh, &exact, &rem);
-    if (threadIdx.x == 0) {
+    radix_select64([&](int i) { return (uint64_t)(in_lds ? tkeys[i] : __float_as_uint(v[i])) << 32; },
+                   [](int) { return true; }, n, a.k, 32, &sm, &prefix, &sh, &exact, &rem);
+    if (tid == 0) {
         // every sampled value whose bits >> (sh-32) are <= the prefix's is among the k
         // smallest: the largest float with that truncated prefix bounds them all
         const unsigned hi_bits = (unsigned)(prefix >> 32) | ((sh > 32) ? ((1u << (sh - 32)) - 1u) : 0u);
@@ -712,7 +737,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
 }
 
 // survivors -> k best by (d, r, t): radix select on the distance bits, ties at the k-th
-// VALUE broken by a second radix select on (r, t), then an in-LDS bitonic sort
+// VALUE broken by a second radix select on (r, t), then a bitonic sort of the k selected
 __device__ __forceinline__ bool item_less(uint64_t x, uint64_t y, const int2* rt) {
     const unsigned dx = (unsigned)(x >> 32), dy = (unsigned)(y >> 32);
     if (dx != dy) return dx < dy;
@@ -726,16 +751,18 @@ __device__ __forceinline__ bool item_less(uint64_t x, uint64_t y, const int2* rt
 }
 
 __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t items[];   // kpad entries
+    extern __shared__ __attribute__((aligned(16))) uint64_t items[];   // kpad entries, then key_cap u32 keys
     __shared__ SelectShared sm;
+    unsigned* keys = reinterpret_cast<unsigned*>(items + a.kpad);
 
     const int b = (int)blockIdx.x;
     const int tid = (int)threadIdx.x;
-    const float* cd;
-    const int2* crt;
+    const float* cd = a.cand_d + (int64_t)b * a.cand_stride;
+    const int2* crt = a.cand_rt + (int64_t)b * a.cand_stride;
+    const bool slices = a.bcount != nullptr;
     int n;
-    if (a.bcount) {
-        // ---- the scan left one slice per block: compact them into one list
+    if (slices) {
+        // ---- the scan left one slice per block: offs[] = exclusive prefix of their sizes
         const int* bc = a.bcount + (int64_t)b * PSH_MAX_BLOCKS;
         if (tid == 0) { sm.overflow = 0; sm.offs[0] = 0; }
         __syncthreads();
@@ -761,35 +788,65 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
             __syncthreads();
         }
         n = sm.offs[a.nblk];
-        float* od = a.cmp_d + (int64_t)b * a.cand_stride;
-        int2* ort = a.cmp_rt + (int64_t)b * a.cand_stride;
-        const float* sd = a.cand_d + (int64_t)b * a.cand_stride;
-        const int2* srt = a.cand_rt + (int64_t)b * a.cand_stride;
-        // flat copy, every element independent (a per-slice loop would serialise one
-        // global round trip per slice): binary search of the owning slice in LDS
-        for (int e = tid; e < n; e += PSH_SELECT_THREADS) {
-            int lo = 0, hi = a.nblk;              // offs[lo] <= e < offs[hi]
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (sm.offs[mid] <= e) lo = mid; else hi = mid;
-            }
-            const int64_t src = (int64_t)lo * a.slice + (e - sm.offs[lo]);
-            od[e] = sd[src];
-            ort[e] = srt[src];
-        }
         if (tid == 0 && sm.overflow && a.status) a.status[b] = PSH_STATUS_OVERFLOW_;
-        __syncthreads();
-        cd = od;
-        crt = ort;
     } else {
-        cd = a.cand_d + (int64_t)b * a.cand_stride;
-        crt = a.cand_rt + (int64_t)b * a.cand_stride;
         n = a.n_fixed;
     }
     if (tid == 0 && a.total) a.total[b] = n;
+    // candidate e lives at src(e): identity for flat inputs, slice lookup (binary search of
+    // the owning block in LDS) otherwise -- no compaction pass over global memory
+    auto src = [&](int e) -> int64_t {
+        if (!slices) return e;
+        int lo = 0, hi = a.nblk;              // offs[lo] <= e < offs[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (sm.offs[mid] <= e) lo = mid; else hi = mid;
+        }
+        return (int64_t)lo * a.slice + (e - sm.offs[lo]);
+    };
+    // walk the candidates as (e, src) pairs without a search: a group of threads per slice
+    // (flat inputs: e == src).  Four independent loads in flight per thread.
+    const int tps = slices ? ((a.nblk >= PSH_SELECT_THREADS) ? 1 : PSH_SELECT_THREADS / a.nblk) : 1;
+    auto for_each_cand = [&](auto&& body) {
+        if (slices) {
+            const int q = tid % tps, sstep = PSH_SELECT_THREADS / tps;
+            for (int sl = tid / tps; sl < a.nblk; sl += sstep) {
+                const int e0 = sm.offs[sl], cnt = sm.offs[sl + 1] - e0;
+                const int64_t s0 = (int64_t)sl * a.slice;
+                for (int j = q; j < cnt; j += tps) body(e0 + j, s0 + j);
+            }
+        } else {
+            for (int e = tid; e < n; e += PSH_SELECT_THREADS) body(e, (int64_t)e);
+        }
+    };
+    // distance bits are staged in LDS when they fit: every later pass runs at LDS latency
+    const bool in_lds = n <= a.key_cap;
+    if (in_lds) {
+        if (slices) {
+            const int q = tid % tps, sstep = PSH_SELECT_THREADS / tps;
+            for (int sl = tid / tps; sl < a.nblk; sl += sstep) {
+                const int e0 = sm.offs[sl], cnt = sm.offs[sl + 1] - e0;
+                const float* sp = cd + (int64_t)sl * a.slice;
+                for (int j = q; j < cnt; j += 4 * tps) {
+                    float v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = (j + u * tps < cnt) ? sp[j + u * tps] : 0.0f;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (j + u * tps < cnt) keys[e0 + j + u * tps] = __float_as_uint(v[u]);
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int e = tid; e < n; e += PSH_SELECT_THREADS) keys[e] = __float_as_uint(cd[e]);
+        }
+        __syncthreads();
+    }
+    auto dkey = [&](int e) -> unsigned { return in_lds ? keys[e] : __float_as_uint(cd[src(e)]); };
+    auto rt_of = [&](int e) -> int2 { return crt[src(e)]; };
+
     int2* sel_rt = a.sel_rt + (int64_t)b * a.kpad;
     const bool skip_neg = a.skip_negative_rows != 0;
-    auto live = [&](int i) { return !skip_neg || crt[i].x >= 0; };
+    auto live = [&](int e) { return !skip_neg || rt_of(e).x >= 0; };
 
     // flat inputs may carry padding entries (r < 0): only real candidates are ranked
     if (tid == 0) sm.cnt = 0;
@@ -797,7 +854,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
     int n_real = n;
     if (skip_neg) {
         int c = 0;
-        for (int i = tid; i < n; i += PSH_SELECT_THREADS) c += (crt[i].x >= 0) ? 1 : 0;
+        for (int e = tid; e < n; e += PSH_SELECT_THREADS) c += (crt[e].x >= 0) ? 1 : 0;
         if (c) atomicAdd(&sm.cnt, c);
         __syncthreads();
         n_real = sm.cnt;
@@ -811,7 +868,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
     if (need > 0 && need < n_real) {
         bool exact;
         int rem;
-        radix_select64([&](int i) { return (uint64_t)__float_as_uint(cd[i]) << 32; }, live, n, need, 32,
+        radix_select64([&](int e) { return (uint64_t)dkey(e) << 32; }, live, n, need, 32,
                        &sm, &d_prefix, &d_sh, &exact, &rem);
         if (!exact) {
             // the k-th distance VALUE is shared by more candidates than fit: the canonical
@@ -820,8 +877,8 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
             const unsigned dk = (unsigned)(d_prefix >> 32);
             bool exact2;
             int rem2;
-            radix_select64([&](int i) { return ((uint64_t)(unsigned)crt[i].x << 32) | (uint64_t)(unsigned)crt[i].y; },
-                           [&](int i) { return live(i) && __float_as_uint(cd[i]) == dk; }, n, rem, 0,
+            radix_select64([&](int e) { const int2 rt = rt_of(e); return ((uint64_t)(unsigned)rt.x << 32) | (uint64_t)(unsigned)rt.y; },
+                           [&](int e) { return live(e) && dkey(e) == dk; }, n, rem, 0,
                            &sm, &rt_prefix, &rt_sh, &exact2, &rem2);
         }
     }
@@ -832,41 +889,66 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
     __syncthreads();
     if (need > 0) {
         const unsigned dk = (unsigned)(d_prefix >> 32);
-        for (int i = tid; i < n; i += PSH_SELECT_THREADS) {
-            if (!live(i)) continue;
-            const int2 rt = crt[i];
-            const unsigned db = __float_as_uint(cd[i]);
+        for_each_cand([&](int e, int64_t sidx) {
+            const unsigned db = in_lds ? keys[e] : __float_as_uint(cd[sidx]);
             bool take;
-            if (d_sh >= 64) {
-                take = true;
-            } else if (!tie_select) {
-                take = (((uint64_t)db << 32) >> d_sh) <= (d_prefix >> d_sh);
-            } else {
+            if (d_sh >= 64) take = true;
+            else if (!tie_select) take = (((uint64_t)db << 32) >> d_sh) <= (d_prefix >> d_sh);
+            else take = db <= dk;                      // ties resolved below
+            if (!take) return;
+            const int2 rt = crt[sidx];
+            if (skip_neg && rt.x < 0) return;
+            if (tie_select && db == dk) {
                 const uint64_t rk = ((uint64_t)(unsigned)rt.x << 32) | (uint64_t)(unsigned)rt.y;
-                take = (db < dk) || (db == dk && (rk >> rt_sh) <= (rt_prefix >> rt_sh));
+                if (!((rk >> rt_sh) <= (rt_prefix >> rt_sh))) return;
             }
-            if (take) {
-                const int slot = atomicAdd(&sm.nsel, 1);
-                if (slot < a.kpad) {
-                    items[slot] = ((uint64_t)db << 32) | (uint64_t)(unsigned)slot;
-                    sel_rt[slot] = rt;
-                }
+            const int slot = atomicAdd(&sm.nsel, 1);
+            if (slot < a.kpad) {
+                items[slot] = ((uint64_t)db << 32) | (uint64_t)(unsigned)slot;
+                sel_rt[slot] = rt;
             }
-        }
+        });
     }
     __syncthreads();
 
-    // ---- bitonic sort of kpad items by (d bits, r, t)
-    for (int size = 2; size <= a.kpad; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
-            for (int i = tid; i < (a.kpad >> 1); i += PSH_SELECT_THREADS) {
-                const int lo = ((i / stride) * (stride << 1)) + (i % stride);
-                const int hi = lo + stride;
-                const bool ascending = ((lo & size) == 0);
-                const uint64_t x = items[lo], y = items[hi];
-                const bool swap = ascending ? item_less(y, x, sel_rt) : item_less(x, y, sel_rt);
-                if (swap) { items[lo] = y; items[hi] = x; }
+    // ---- bitonic sort of kpad items by (d bits, r, t): strides below 64 stay inside a
+    // wave (shuffles, no barrier), only the wider ones go through LDS
+    if (a.kpad <= PSH_SELECT_THREADS) {
+        uint64_t mine = (tid < a.kpad) ? items[tid] : ~0ull;
+        for (int size = 2; size <= a.kpad; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                const bool ascending = ((tid & size) == 0);
+                uint64_t other;
+                if (stride >= 64) {
+                    __syncthreads();
+                    if (tid < a.kpad) items[tid] = mine;
+                    __syncthreads();
+                    other = (tid < a.kpad) ? items[tid ^ stride] : ~0ull;
+                } else {
+                    other = __shfl_xor(mine, stride, 64);
+                }
+                const bool i_am_low = (tid & stride) == 0;
+                // the low partner keeps the smaller item in an ascending run
+                const bool other_less = item_less(other, mine, sel_rt);
+                const bool mine_less = item_less(mine, other, sel_rt);
+                const bool take_other = (i_am_low == ascending) ? other_less : mine_less;
+                if (take_other) mine = other;
+            }
+        }
+        __syncthreads();
+        if (tid < a.kpad) items[tid] = mine;
+    } else {
+        for (int size = 2; size <= a.kpad; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                __syncthreads();
+                for (int i = tid; i < (a.kpad >> 1); i += PSH_SELECT_THREADS) {
+                    const int lo = ((i / stride) * (stride << 1)) + (i % stride);
+                    const int hi = lo + stride;
+                    const bool ascending = ((lo & size) == 0);
+                    const uint64_t x = items[lo], y = items[hi];
+                    const bool swap = ascending ? item_less(y, x, sel_rt) : item_less(x, y, sel_rt);
+                    if (swap) { items[lo] = y; items[hi] = x; }
+                }
             }
         }
     }
@@ -984,12 +1066,28 @@ hipError_t launch_qnorm(const float* q, int B, int W, float* out, hipStream_t s)
     hipLaunchKernelGGL(qnorm_kernel, dim3((B + 63) / 64), dim3(64), 0, s, q, B, W, out);
     return hipGetLastError();
 }
-hipError_t launch_threshold(const ThresholdArgs& a, int B, hipStream_t s) {
-    hipLaunchKernelGGL(threshold_kernel, dim3(B), dim3(PSH_SELECT_THREADS), 0, s, a);
+hipError_t launch_threshold(const ThresholdArgs& a0, int B, hipStream_t s) {
+    ThresholdArgs a = a0;
+    size_t shmem = (size_t)a.n_entries * sizeof(unsigned);
+    a.keys_in_lds = shmem <= 128 * 1024;
+    if (!a.keys_in_lds) shmem = 0;
+    if (shmem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)threshold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(threshold_kernel, dim3(B), dim3(PSH_SELECT_THREADS), shmem, s, a);
     return hipGetLastError();
 }
-hipError_t launch_select(const SelectArgs& a, int B, hipStream_t s) {
-    const size_t shmem = (size_t)a.kpad * sizeof(uint64_t);
+hipError_t launch_select(const SelectArgs& a0, int B, hipStream_t s) {
+    SelectArgs a = a0;
+    // LDS: the k items being sorted + as many staged distance keys as fit next to them
+    const size_t lds_budget = 144 * 1024;      // of 160 KB; SelectShared (static) takes ~10 KB
+    const size_t items_bytes = (size_t)a.kpad * sizeof(uint64_t);
+    int64_t key_cap = items_bytes < lds_budget ? (int64_t)((lds_budget - items_bytes) / sizeof(unsigned)) : 0;
+    const int64_t n_max = a.bcount ? (int64_t)a.nblk * a.slice : (int64_t)a.n_fixed;
+    if (key_cap > n_max) key_cap = n_max;
+    a.key_cap = (int)key_cap;
+    const size_t shmem = items_bytes + (size_t)key_cap * sizeof(unsigned);
     if (shmem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
