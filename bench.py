@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--queries", type=int, default=1, help="B: 1 = configs[1]; 512 = configs[2] (rolling windows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the golden-vector check of the first result")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="exercise the multi-GPU code path (process group, all-gather, merge) even with one rank")
     return ap.parse_args()
 
 
@@ -97,8 +99,10 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
-    if world > 1:
+    use_pg = world > 1 or args.force_sharded
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
 
     import shadowing_amd as sa
@@ -117,8 +121,9 @@ def main():
     ws = _native.Workspace(dev)
 
     sharded = None
-    if world > 1:
-        sharded = ShardedPathShadowing(sa.Identity(W), sa.RelativeMSE(), ds, rank * R, sa.PredictionContext(h), device=dev)
+    if use_pg:
+        sharded = ShardedPathShadowing(sa.Identity(W), sa.RelativeMSE(), ds, rank * R, sa.PredictionContext(h), device=dev,
+                                       always_exchange=args.force_sharded)
 
     ev_pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for a, b in ev_pairs:   # materialise the hipEvent handles
@@ -129,7 +134,9 @@ def main():
 
     def step(i=None):
         if sharded is not None:
-            return sharded.scan(q, k)
+            out = sharded.scan(q, k, check=False)     # no host sync inside the timed loop
+            statuses.append(sharded.last_status)
+            return out
         ev = ev_pairs[i] if i is not None else None
         d, idx, st = _native.scan_topk(ds[:, 0, :], q, k, h=h, workspace=ws, scan_events=ev)
         statuses.append(st)
@@ -155,18 +162,18 @@ def main():
         step()
     statuses.clear()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_pg:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_pg:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -235,7 +242,7 @@ def main():
             "parity_vs_reference_golden": parity,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

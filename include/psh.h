@@ -140,6 +140,13 @@ int psh_scan_topk_exhaustive(int device, void* stream,
  *   workspace device, >= psh_merge_workspace_bytes(B, k)
  */
 int psh_merge_workspace_bytes(int B, int k, size_t* out_bytes);
+/* The same for G lists that sit where an all-gather left them, without a repacking copy:
+ * list g of query b starts at d_gathered + g*rank_stride + b*k_in (floats) and at
+ * idx_gathered + 2*(g*rank_stride_idx + b*k_in) (int32; the stride counts (r,t) pairs). */
+int psh_merge_topk_gathered(int device, void* stream,
+                            const float* d_gathered, const int32_t* idx_gathered,
+                            int G, int64_t rank_stride, int64_t rank_stride_idx, int B, int k_in, int k,
+                            float* out_d, int32_t* out_idx, void* workspace, size_t workspace_bytes);
 int psh_merge_topk(int device, void* stream,
                    const float* d_lists, const int32_t* idx_lists, int B, int n_in, int k,
                    float* out_d, int32_t* out_idx, void* workspace, size_t workspace_bytes);

@@ -36,7 +36,7 @@ class PshProfile(C.Structure):
 
 EXPORTS = ("psh_version", "psh_strerror", "psh_last_hip_error", "psh_workspace_bytes", "psh_query_norm",
            "psh_scan_topk", "psh_scan_topk_exhaustive", "psh_merge_workspace_bytes", "psh_merge_topk",
-           "psh_gather_paths")
+           "psh_merge_topk_gathered", "psh_gather_paths")
 
 _lib = None
 
@@ -82,6 +82,8 @@ def load() -> C.CDLL:
     L.psh_merge_workspace_bytes.argtypes = [i32, i32, C.POINTER(C.c_size_t)]
     L.psh_merge_topk.restype = i32
     L.psh_merge_topk.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, C.c_size_t]
+    L.psh_merge_topk_gathered.restype = i32
+    L.psh_merge_topk_gathered.argtypes = [i32, vp, vp, vp, i32, i64, i64, i32, i32, i32, vp, vp, vp, C.c_size_t]
     L.psh_gather_paths.restype = i32
     L.psh_gather_paths.argtypes = [i32, vp, vp, i64, i64, i64, i64, vp, i64, i32, vp]
     _lib = L
@@ -146,7 +148,7 @@ def query_norm(queries: torch.Tensor) -> torch.Tensor:
 def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, r_offset: int = 0,
               qnorm: torch.Tensor | None = None, workspace: Workspace | None = None,
               exhaustive: bool = False, profile: bool = False, extra_workspace_factor: float = 1.0,
-              scan_events: tuple | None = None):
+              scan_events: tuple | None = None, out: tuple | None = None):
     """Enqueue the scan on the current stream.
 
     dataset (R, T) float32 device, queries (B, W) float32 device.  Returns
@@ -177,8 +179,14 @@ def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, 
         return tuple(torch.cat([p[j] for p in parts], dim=0) for j in range(3))
     nbytes = int(workspace_bytes(R, T, B, W, h, k) * extra_workspace_factor)
     ws = (workspace or Workspace(dev)).get(nbytes)
-    out_d = torch.empty((B, k), dtype=torch.float32, device=dev)
-    out_idx = torch.empty((B, k, 2), dtype=torch.int32, device=dev)
+    if out is not None:       # caller-provided (B,k) f32 / (B,k,2) i32 contiguous device tensors (e.g. views of a send buffer)
+        out_d = _dev_tensor(out[0], torch.float32, "out[0]")
+        out_idx = _dev_tensor(out[1], torch.int32, "out[1]")
+        if tuple(out_d.shape) != (B, k) or tuple(out_idx.shape) != (B, k, 2):
+            raise ValueError("out must be ((B,k) float32, (B,k,2) int32)")
+    else:
+        out_d = torch.empty((B, k), dtype=torch.float32, device=dev)
+        out_idx = torch.empty((B, k, 2), dtype=torch.int32, device=dev)
     status = torch.empty((B,), dtype=torch.int32, device=dev)
     prof = None
     if profile:
@@ -215,6 +223,29 @@ def merge_topk(d_lists: torch.Tensor, idx_lists: torch.Tensor, k: int):
     _check(load().psh_merge_topk(d.device.index, _stream_ptr(d.device), d.data_ptr(), ix.data_ptr(), B, n, k,
                                  out_d.data_ptr(), out_idx.data_ptr(), ws.data_ptr(), ws.numel()),
            "psh_merge_topk")
+    return out_d, out_idx
+
+
+def merge_topk_gathered(gathered: torch.Tensor, G: int, B: int, k_in: int, k: int):
+    """Merge what one all-gather delivered.  `gathered`: int32 (G, 3*B*k_in): per rank the
+    (B,k_in) float32 distances (bit pattern) followed by the (B,k_in,2) int32 indices."""
+    g = _dev_tensor(gathered, torch.int32, "gathered")
+    if tuple(g.shape) != (G, 3 * B * k_in):
+        raise ValueError("gathered must be (G, 3*B*k_in) int32")
+    need = C.c_size_t(0)
+    _check(load().psh_merge_workspace_bytes(B, k, C.byref(need)), "psh_merge_workspace_bytes")
+    ws = torch.empty(int(need.value), dtype=torch.uint8, device=g.device)
+    out_d = torch.empty((B, k), dtype=torch.float32, device=g.device)
+    out_idx = torch.empty((B, k, 2), dtype=torch.int32, device=g.device)
+    base = g.data_ptr()
+    # distances: rank stride 3*B*k_in floats; indices: the (r,t) pairs start B*k_in ints in
+    # and their rank stride is 3*B*k_in/2 pairs -- whole (and 8-byte aligned) when B*k_in is even
+    if (B * k_in) % 2:
+        raise ValueError("B*k_in must be even for the in-place gathered merge")
+    _check(load().psh_merge_topk_gathered(g.device.index, _stream_ptr(g.device), base, base + 4 * B * k_in,
+                                          G, 3 * B * k_in, (3 * B * k_in) // 2, B, k_in, k,
+                                          out_d.data_ptr(), out_idx.data_ptr(),
+                                          ws.data_ptr(), ws.numel()), "psh_merge_topk_gathered")
     return out_d, out_idx
 
 

@@ -171,6 +171,16 @@ int plan_scan(int device, const Problem& p, int64_t n_rows, Plan* plan) {
     n_qgroups = (p.B + q_per_group - 1) / q_per_group;
     const int64_t units = n_rs * n_qgroups;
     if (units >= (1ll << 31)) return PSH_ERR_UNSUPPORTED;
+    {   // the kernel divides by multiplication: umulhi(u, ceil(2^32/d)) == u / d needs u * e < 2^32, e = magic*d - 2^32
+        const uint64_t ds[2] = {(uint64_t)n_rs, (uint64_t)nseg};
+        const uint64_t umax[2] = {(uint64_t)units, (uint64_t)n_rs};
+        for (int i = 0; i < 2; ++i) {
+            if (ds[i] <= 1) continue;
+            const uint64_t magic = ((1ull << 32) + ds[i] - 1) / ds[i];
+            const uint64_t e = magic * ds[i] - (1ull << 32);
+            if (magic >= (1ull << 32) || umax[i] * e >= (1ull << 32)) return PSH_ERR_UNSUPPORTED;
+        }
+    }
     int64_t grid = (units + (PSH_SCAN_THREADS / 64) - 1) / (PSH_SCAN_THREADS / 64);
     if (grid > (int64_t)bpc * ncu) grid = (int64_t)bpc * ncu;
     if (grid > PSH_MAX_BLOCKS) grid = PSH_MAX_BLOCKS;
@@ -194,6 +204,11 @@ ScanArgs make_scan_args(const float* dataset, const float* queries, const Proble
     a.row0 = row0;
     a.row_stride = row_stride;
     a.n_rows = (int)n_rows;
+    {   // magic numbers of the unit decode: ceil(2^32 / d)
+        const uint64_t n_rs = (uint64_t)n_rows * (uint64_t)a.nseg;
+        a.magic_nrs = n_rs > 1 ? (unsigned)(((1ull << 32) + n_rs - 1) / n_rs) : 0u;
+        a.magic_nseg = a.nseg > 1 ? (unsigned)(((1ull << 32) + (uint64_t)a.nseg - 1) / (uint64_t)a.nseg) : 0u;
+    }
     a.r_offset = p.r_offset;
     a.queries = queries;
     a.B = p.B;
@@ -482,6 +497,38 @@ int psh_merge_topk(int device, void* stream, const float* d_lists, const int32_t
     s.sel_rt = (int2*)workspace;
     s.status = nullptr;
     s.qstate = nullptr;
+    HIP_TRY(launch_select(s, B, (hipStream_t)stream));
+    return PSH_OK;
+}
+
+int psh_merge_topk_gathered(int device, void* stream, const float* d_gathered, const int32_t* idx_gathered,
+                            int G, int64_t rank_stride, int64_t rank_stride_idx, int B, int k_in, int k,
+                            float* out_d, int32_t* out_idx, void* workspace, size_t workspace_bytes) {
+    if (!d_gathered || !idx_gathered || !out_d || !out_idx || !workspace || G <= 0 || B <= 0 || k_in <= 0 || k <= 0) return PSH_ERR_ARG;
+    if (rank_stride < (int64_t)B * k_in || rank_stride_idx < (int64_t)B * k_in || (int64_t)G * k_in >= (1ll << 31)) return PSH_ERR_ARG;
+    if (k > PSH_MAX_K) return PSH_ERR_UNSUPPORTED;
+    if (((uintptr_t)idx_gathered & 7u) != 0 || ((uintptr_t)workspace & 7u) != 0) return PSH_ERR_ARG;
+    const int kpad = next_pow2(k);
+    if (workspace_bytes < sizeof(int2) * (size_t)B * kpad) return PSH_ERR_WORKSPACE;
+    DeviceGuard g(device);
+    if (!g.ok) { snprintf(g_hip_err, sizeof(g_hip_err), "hipSetDevice(%d) failed", device); return PSH_ERR_HIP; }
+    SelectArgs s;
+    memset(&s, 0, sizeof(s));
+    s.cand_d = d_gathered;
+    s.cand_rt = (const int2*)idx_gathered;
+    s.cand_stride = k_in;              // query b's lists start b * k_in into every rank block
+    s.bcount = nullptr;
+    s.n_fixed = G * k_in;
+    s.list_len = k_in;
+    s.list_stride = rank_stride;
+    s.list_stride_rt = rank_stride_idx;
+    s.cap = G * k_in;
+    s.k = k;
+    s.kpad = kpad;
+    s.skip_negative_rows = 1;
+    s.out_d = out_d;
+    s.out_idx = out_idx;
+    s.sel_rt = (int2*)workspace;
     HIP_TRY(launch_select(s, B, (hipStream_t)stream));
     return PSH_OK;
 }

@@ -49,6 +49,7 @@ struct ScanArgs {
     int W;
     int64_t row0, row_stride;
     int n_rows;              // rows visited: row0 + i * row_stride
+    unsigned magic_nrs, magic_nseg;   // ceil(2^32 / d): u / d == umulhi(u, magic) for u * d-error < 2^32 (host checks)
     int64_t r_offset;
     const float* queries;    // B x W
     int B;
@@ -85,6 +86,9 @@ struct SelectArgs {
     int key_cap;             // distance keys that fit in LDS (set by the launcher)
     int* total;              // nullable: B, number of candidates ranked
     int n_fixed;             // flat mode: candidates per query
+    int list_len;            // flat mode, gathered lists: candidate e sits at (e / list_len) * list_stride + e % list_len
+    int64_t list_stride;     //   in cand_d (floats); 0 = one contiguous list per query
+    int64_t list_stride_rt;  //   in cand_rt (int2 units)
     int cap;
     int k, kpad;
     int skip_negative_rows;  // merge: entries with r < 0 are padding

@@ -47,6 +47,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
+// u / d without the ~40-instruction scalar division sequence (two of them per segment
+// sat on every wave's critical path: ~1000 cycles): magic = ceil(2^32 / d), exact for
+// every u the host admits (u * (magic * d - 2^32) < 2^32, checked in plan_scan)
+__device__ __forceinline__ unsigned fast_div(unsigned u, unsigned magic, unsigned d) {
+    return d == 1u ? u : __umulhi(u, magic);
+}
+
 // LDS tile layout: logical float p lives at p + 4*(p/64): one 16-byte pad slot after
 // every 16 slots.  Lanes read 16-byte slots at a stride of 4 slots (16 windows); the
 // pad makes the 16 lanes of every ds_read_b128 service group hit 16 distinct slots.
@@ -425,21 +432,41 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
     };
 
     if (a.dbg_times && lane == 0) a.dbg_times[2 * gw] = wall_clock64();
+#ifdef PSH_PHASE_TIMING
+    unsigned long long ph[5] = {0, 0, 0, 0, 0};
+#endif
     Stage st;
     unsigned u = grab();
+    // unit -> (query group, row index, segment)
+    auto decode = [&](unsigned uu, unsigned& rs, unsigned& ri, unsigned& sg, unsigned& qgi) {
+        qgi = fast_div(uu, a.magic_nrs, n_rs);
+        rs = uu - qgi * n_rs;
+        ri = fast_div(rs, a.magic_nseg, (unsigned)a.nseg);
+        sg = rs - ri * (unsigned)a.nseg;
+    };
+    unsigned rs, ri, sg, qgi;
     if (u < u_hi) {
-        const unsigned rs = u % n_rs;
-        const int64_t row = a.row0 + (int64_t)(rs / (unsigned)a.nseg) * a.row_stride;
-        stage_load<ALIGNED>(st, a.dataset + row * a.T, a.T, (int)(rs % (unsigned)a.nseg) * PSH_SEG, nfloat, lane);
+        decode(u, rs, ri, sg, qgi);
+        const int64_t row = a.row0 + (int64_t)ri * a.row_stride;
+        stage_load<ALIGNED>(st, a.dataset + row * a.T, a.T, (int)sg * PSH_SEG, nfloat, lane);
     }
     while (u < u_hi) {
-        const unsigned rs = u % n_rs;
-        const int qg = (int)(u / n_rs);
-        const int64_t row = a.row0 + (int64_t)(rs / (unsigned)a.nseg) * a.row_stride;
-        const int seg_start = (int)(rs % (unsigned)a.nseg) * PSH_SEG;
+        decode(u, rs, ri, sg, qgi);
+        const int qg = (int)qgi;
+        const int64_t row = a.row0 + (int64_t)ri * a.row_stride;
+        const int seg_start = (int)sg * PSH_SEG;
 
+#ifdef PSH_PHASE_TIMING
+        const unsigned long long tp0 = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long tp1 = __builtin_readcyclecounter();
+#endif
         stage_store(st, tile, nfloat, lane);
         wave_lds_fence();
+#ifdef PSH_PHASE_TIMING
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long tp2 = __builtin_readcyclecounter();
+#endif
         if (MODE == PSH_MODE_FILTER && npend > 0) {   // last iteration's admissions, ahead of the prefetch
             pend_flush(pend, npend, lcount, a, lane);
             npend = 0;
@@ -451,12 +478,16 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
 #else
             if (un < u_hi) {
 #endif
-                const unsigned rsn = un % n_rs;
-                const int64_t rown = a.row0 + (int64_t)(rsn / (unsigned)a.nseg) * a.row_stride;
-                stage_load<ALIGNED>(st, a.dataset + rown * a.T, a.T, (int)(rsn % (unsigned)a.nseg) * PSH_SEG, nfloat, lane);
+                unsigned rsn, rin, sgn, qgn;
+                decode(un, rsn, rin, sgn, qgn);
+                const int64_t rown = a.row0 + (int64_t)rin * a.row_stride;
+                stage_load<ALIGNED>(st, a.dataset + rown * a.T, a.T, (int)sgn * PSH_SEG, nfloat, lane);
             }
         }
 
+#ifdef PSH_PHASE_TIMING
+        const unsigned long long tp3 = __builtin_readcyclecounter();
+#endif
         const int t_lane = seg_start + PSH_L * lane;           // first window of this lane
         int nvalid = a.Tp - t_lane;                             // admissible windows of this lane
         nvalid = nvalid < 0 ? 0 : (nvalid > PSH_L ? PSH_L : nvalid);
@@ -556,8 +587,17 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
             }
         }
         wave_lds_fence();  // all lanes done with the tile before it is overwritten
+#ifdef PSH_PHASE_TIMING
+        {
+            const unsigned long long tp4 = __builtin_readcyclecounter();
+            ph[0] += tp1 - tp0; ph[1] += tp2 - tp1; ph[2] += tp3 - tp2; ph[3] += tp4 - tp3; ph[4] += 1;
+        }
+#endif
         u = un;
     }
+#ifdef PSH_PHASE_TIMING
+    if (a.dbg_times && lane == 0) for (int i = 0; i < 5; ++i) a.dbg_times[2 * 8192 + 5 * gw + i] = ph[i];
+#endif
     if (a.dbg_times && lane == 0) a.dbg_times[2 * gw + 1] = wall_clock64();
     if (MODE == PSH_MODE_FILTER) {
         if (npend > 0) pend_flush(pend, npend, lcount, a, lane);
@@ -796,7 +836,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
     // candidate e lives at src(e): identity for flat inputs, slice lookup (binary search of
     // the owning block in LDS) otherwise -- no compaction pass over global memory
     auto src = [&](int e) -> int64_t {
-        if (!slices) return e;
+        if (!slices) return a.list_stride ? (int64_t)(e / a.list_len) * a.list_stride + (e % a.list_len) : (int64_t)e;
         int lo = 0, hi = a.nblk;              // offs[lo] <= e < offs[hi]
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
@@ -816,7 +856,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
                 for (int j = q; j < cnt; j += tps) body(e0 + j, s0 + j);
             }
         } else {
-            for (int e = tid; e < n; e += PSH_SELECT_THREADS) body(e, (int64_t)e);
+            for (int e = tid; e < n; e += PSH_SELECT_THREADS) body(e, src(e));
         }
     };
     // distance bits are staged in LDS when they fit: every later pass runs at LDS latency
@@ -837,12 +877,16 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
             }
         } else {
 #pragma unroll 4
-            for (int e = tid; e < n; e += PSH_SELECT_THREADS) keys[e] = __float_as_uint(cd[e]);
+            for (int e = tid; e < n; e += PSH_SELECT_THREADS) keys[e] = __float_as_uint(cd[src(e)]);
         }
         __syncthreads();
     }
     auto dkey = [&](int e) -> unsigned { return in_lds ? keys[e] : __float_as_uint(cd[src(e)]); };
-    auto rt_of = [&](int e) -> int2 { return crt[src(e)]; };
+    // gathered lists keep distances and indices in separate blocks with different strides
+    auto rt_index = [&](int e, int64_t sidx) -> int64_t {
+        return (!slices && a.list_stride) ? (int64_t)(e / a.list_len) * a.list_stride_rt + (e % a.list_len) : sidx;
+    };
+    auto rt_of = [&](int e) -> int2 { return crt[rt_index(e, src(e))]; };
 
     int2* sel_rt = a.sel_rt + (int64_t)b * a.kpad;
     const bool skip_neg = a.skip_negative_rows != 0;
@@ -854,7 +898,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
     int n_real = n;
     if (skip_neg) {
         int c = 0;
-        for (int e = tid; e < n; e += PSH_SELECT_THREADS) c += (crt[e].x >= 0) ? 1 : 0;
+        for (int e = tid; e < n; e += PSH_SELECT_THREADS) c += (rt_of(e).x >= 0) ? 1 : 0;
         if (c) atomicAdd(&sm.cnt, c);
         __syncthreads();
         n_real = sm.cnt;
@@ -896,7 +940,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
             else if (!tie_select) take = (((uint64_t)db << 32) >> d_sh) <= (d_prefix >> d_sh);
             else take = db <= dk;                      // ties resolved below
             if (!take) return;
-            const int2 rt = crt[sidx];
+            const int2 rt = crt[rt_index(e, sidx)];
             if (skip_neg && rt.x < 0) return;
             if (tie_select && db == dk) {
                 const uint64_t rk = ((uint64_t)(unsigned)rt.x << 32) | (uint64_t)(unsigned)rt.y;

@@ -184,3 +184,45 @@ def test_full_size_properties(hip_device):
             D = np.float32(q[0, i] - ds[r, 0, t + i])
             acc = np.float32(np.float64(D) * np.float64(D) + np.float64(acc))
         assert bits(np.float32(np.sqrt(acc)) / xn) == bits(d[0, j])
+
+
+def test_merge_of_gathered_lists_in_place(hip_device, oracle_mod):
+    """What the multi-GPU path does after its one all-gather, emulated on one GPU: three
+    row shards scanned with r_offset, their (d | idx) send buffers laid out rank-major as
+    all_gather_into_tensor would leave them, merged in place."""
+    from shadowing_amd import _native
+    R, T, W, h, k, B = 900, 700, 20, 20, 256, 2
+    ds = syn.dataset(R, T, 21)
+    q = syn.gbm_log_returns((B, W), 22)
+    shards = ((0, 300), (300, 650), (650, 900))
+    gathered = torch.empty((len(shards), 3 * B * k), dtype=torch.int32, device=hip_device)
+    for g, (lo, hi) in enumerate(shards):
+        send = gathered[g]
+        out = (send[:B * k].view(torch.float32).view(B, k), send[B * k:].view(B, k, 2))
+        _native.scan_topk(torch.as_tensor(ds[lo:hi, 0, :].copy()).to(hip_device), torch.as_tensor(q).to(hip_device),
+                          k, h=h, r_offset=lo, out=out)
+    md, mi = _native.merge_topk_gathered(gathered, len(shards), B, k, k)
+    torch.cuda.synchronize()
+    od, oidx = oracle_mod.scan_topk(ds, q, k, h=h)
+    assert_exact(md.cpu().numpy(), mi.cpu().numpy(), od, oidx, "gathered merge")
+
+
+def test_sharded_class_with_rccl_process_group(hip_device, oracle_mod, tmp_path):
+    """ShardedPathShadowing end to end over a real RCCL process group (one rank: the
+    all-gather and the merge still run)."""
+    import torch.distributed as dist
+    import shadowing_amd as sa
+    from shadowing_amd.distributed import ShardedPathShadowing
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/pg", rank=0, world_size=1, device_id=hip_device)
+    try:
+        R, T, W, h, k, B = 600, 900, 20, 20, 128, 3
+        ds = syn.dataset(R, T, 23)
+        q = syn.rolling_queries(B, W, 24)
+        obj = ShardedPathShadowing(sa.Identity(W), sa.RelativeMSE(), ds, 0, sa.PredictionContext(h),
+                                   device=hip_device, always_exchange=True)
+        d, paths, idx = obj.shadow(q, k)
+        od, opaths, oidx = oracle_mod.shadow(ds, q, k, h)
+        assert_exact(d, idx, od, oidx, "sharded class")
+        assert np.array_equal(paths, opaths)
+    finally:
+        dist.destroy_process_group()
