@@ -444,6 +444,7 @@ int psh_scan_topk(int device, void* stream, const float* dataset, int64_t R, int
     rc = tm.mark(); if (rc) return rc;                                       // 4
 
     SelectArgs se = make_select_args(p, w, out_d, out_idx, out_status, true, plan_f.grid, 0);
+    if (const char* e = getenv("PSH_DBG_SELECT_PTR")) se.dbg_times = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning aid
     HIP_TRY(launch_select(se, B, s));
     rc = tm.mark(); if (rc) return rc;                                       // 5
 

@@ -97,6 +97,7 @@ struct SelectArgs {
     int2* sel_rt;            // B x kpad scratch
     int* status;             // nullable
     QueryState* qstate;      // nullable
+    unsigned long long* dbg_times;   // tuning aid (nullable): phase boundaries of block 0 in wall-clock ticks (100 MHz)
 };
 
 struct ReseedArgs {      // exhaustive path: running best -> cand[b][offset .. offset + k)

@@ -319,37 +319,39 @@ struct Stage {  // one segment in flight from HBM, 5 x 16 bytes per lane
     f32x4 v[PSH_NSTAGE];
 };
 
+// one of the PSH_NSTAGE 16-byte loads of a segment (q is a compile-time index at every
+// call site).  row: first float of the row; floats [seg_start, seg_start + nfloat) are
+// wanted, clamped to the row (the clamped tail only feeds inadmissible windows).
 template <bool ALIGNED>
-__device__ __forceinline__ void stage_load(Stage& st, const float* __restrict__ row, int64_t T,
-                                           int seg_start, int nfloat, int lane) {
-    // row: first float of the row; floats [seg_start, seg_start + nfloat) wanted, clamped
-    // to the row (the clamped tail only feeds inadmissible windows).
+__device__ __forceinline__ void stage_load_one(Stage& st, int q, const float* __restrict__ row, int64_t T,
+                                               int seg_start, int nfloat, int lane) {
     if (ALIGNED) {
         const f32x4* src = reinterpret_cast<const f32x4*>(row + seg_start);
         const int last = (int)((T - seg_start) >> 2) - 1;  // last float4 inside the row
         const int nq = (nfloat + 3) >> 2;                   // 256 <= nq <= 320
-#pragma unroll
-        for (int q = 0; q < PSH_NSTAGE; ++q) {
-            int m = lane + 64 * q;
-            if (q < PSH_NSTAGE - 1 || m < nq) {
-                m = m > last ? last : m;
-                st.v[q] = __builtin_nontemporal_load(src + m);
-            }
+        int m = lane + 64 * q;
+        if (q < PSH_NSTAGE - 1 || m < nq) {
+            m = m > last ? last : m;
+            st.v[q] = __builtin_nontemporal_load(src + m);
         }
     } else {
         const int lastf = (int)(T - seg_start) - 1;
+        float e[4];
 #pragma unroll
-        for (int q = 0; q < PSH_NSTAGE; ++q) {
-            float e[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                int p = 4 * (lane + 64 * q) + c;
-                p = p > lastf ? lastf : p;
-                e[c] = (4 * (lane + 64 * q) < nfloat) ? row[seg_start + p] : 0.0f;
-            }
-            st.v[q] = f32x4{e[0], e[1], e[2], e[3]};
+        for (int c = 0; c < 4; ++c) {
+            int p = 4 * (lane + 64 * q) + c;
+            p = p > lastf ? lastf : p;
+            e[c] = (4 * (lane + 64 * q) < nfloat) ? row[seg_start + p] : 0.0f;
         }
+        st.v[q] = f32x4{e[0], e[1], e[2], e[3]};
     }
+}
+
+template <bool ALIGNED>
+__device__ __forceinline__ void stage_load(Stage& st, const float* __restrict__ row, int64_t T,
+                                           int seg_start, int nfloat, int lane) {
+#pragma unroll
+    for (int q = 0; q < PSH_NSTAGE; ++q) stage_load_one<ALIGNED>(st, q, row, T, seg_start, nfloat, lane);
 }
 
 __device__ __forceinline__ void stage_store(const Stage& st, float* tile, int nfloat, int lane) {
@@ -472,7 +474,9 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
             npend = 0;
         }
         const unsigned un = grab();
-        {   // prefetch the next unit of this wave while this one is computed
+        {   // prefetch the next unit of this wave while this one is computed.  (Spreading
+            // these five loads over the arithmetic through a hook was tried: +6 % time --
+            // the extra live ranges cost a spill at the 128-VGPR cap.)
 #if defined(PSH_ABL) && (PSH_ABL == 1)
             if (false) {                                   // ablation 1: no HBM traffic after the first segment
 #else
@@ -610,8 +614,9 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
 // ----------------------------------------------------------------------------------
 // one-block selection machinery (threshold of the bootstrap sample, final top-k, merge)
 // ----------------------------------------------------------------------------------
+#define PSH_RB 11                          // radix-select digit width: 2048 counters per pass
 struct SelectShared {
-    unsigned hist[256];
+    unsigned hist[1 << PSH_RB];
     uint64_t prefix, kmin, kmax;
     int remaining, done, nsel, cnt, overflow;
     int offs[PSH_MAX_BLOCKS + 1];
@@ -646,19 +651,22 @@ __device__ inline void block_minmax64(KeyFn key_of, LiveFn live, int n, SelectSh
 }
 
 // Rank-`rank` (1-based) smallest 64-bit key among the candidates i with live(i); only
-// key bits >= sh_floor are examined.  MSB-first, 8 bits per pass, starting at the first
-// bit in which the keys differ at all (a pass over a digit every key shares would only
-// serialise 1e4 LDS atomics on one counter).  On return, in every thread: the live
-// candidates with (key >> sh) <= (prefix >> sh) are exactly the `rank` smallest -- unless
-// keys tie down to sh_floor (*exact false): then more may match and *remaining of the
-// ones equal to prefix at sh_floor are still wanted.
+// key bits >= sh_floor are examined.  MSB-first, PSH_RB bits per pass (two passes cover
+// the ~20 bits in which distance keys differ), starting at the first bit in which the
+// keys differ at all.  [kmin, kmax] may be passed in (have_minmax) when the caller
+// already knows them.  On return, in every thread: the live candidates with
+// (key >> sh) <= (prefix >> sh) are exactly the `rank` smallest -- unless keys tie down to
+// sh_floor (*exact false): then more may match and *remaining of the ones equal to
+// prefix at sh_floor are still wanted.
 template <typename KeyFn, typename LiveFn>
 __device__ inline void radix_select64(KeyFn key_of, LiveFn live, int n, int rank, int sh_floor,
                                       SelectShared* sm, uint64_t* out_prefix, int* out_sh, bool* out_exact,
-                                      int* out_remaining) {
+                                      int* out_remaining, bool have_minmax = false, uint64_t kmin_in = 0,
+                                      uint64_t kmax_in = 0) {
     const int tid = (int)threadIdx.x;
-    uint64_t kmin, kmax;
-    block_minmax64(key_of, live, n, sm, &kmin, &kmax);
+    constexpr unsigned NB = 1u << PSH_RB;
+    uint64_t kmin = kmin_in, kmax = kmax_in;
+    if (!have_minmax) block_minmax64(key_of, live, n, sm, &kmin, &kmax);
     const uint64_t diff = (kmin ^ kmax) >> sh_floor;
     if (kmin > kmax || diff == 0ull) {       // nothing live, or every key equal above the floor
         *out_prefix = (kmin > kmax) ? 0ull : ((kmin >> sh_floor) << sh_floor);
@@ -668,54 +676,56 @@ __device__ inline void radix_select64(KeyFn key_of, LiveFn live, int n, int rank
         return;
     }
     const int top_bit = 63 - __clzll((unsigned long long)(diff << sh_floor));   // highest differing bit
-    int sh = sh_floor + 8 * ((top_bit - sh_floor) / 8);                            // digit holding it
+    int sh = sh_floor + PSH_RB * ((top_bit - sh_floor) / PSH_RB);                  // digit holding it
     __syncthreads();
     if (tid == 0) {
-        sm->prefix = (sh + 8 >= 64) ? 0ull : ((kmin >> (sh + 8)) << (sh + 8));   // shared high bits
+        sm->prefix = (sh + PSH_RB >= 64) ? 0ull : ((kmin >> (sh + PSH_RB)) << (sh + PSH_RB));   // shared high bits
         sm->remaining = rank;
         sm->done = 0;
     }
     __syncthreads();
     int sh_done = sh;
     bool first = true;
-    for (; sh >= sh_floor; sh -= 8) {
-        for (int i = tid; i < 256; i += PSH_SELECT_THREADS) sm->hist[i] = 0u;
+    for (; sh >= sh_floor; sh -= PSH_RB) {
+        for (unsigned i = (unsigned)tid; i < NB; i += PSH_SELECT_THREADS) sm->hist[i] = 0u;
         __syncthreads();
         const uint64_t prefix = sm->prefix;
+        const int shp = sh + PSH_RB;
         for (int i = tid; i < n; i += PSH_SELECT_THREADS) {
             if (!live(i)) continue;
             const uint64_t key = key_of(i);
-            const bool match = first || ((key >> (sh + 8)) == (prefix >> (sh + 8)));
-            if (match) atomicAdd(&sm->hist[(unsigned)(key >> sh) & 255u], 1u);
+            const bool match = first || shp >= 64 || ((key >> shp) == (prefix >> shp));
+            if (match) atomicAdd(&sm->hist[(unsigned)(key >> sh) & (NB - 1u)], 1u);
         }
         __syncthreads();
         if (tid < 64) {
-            // bucket holding the rank: wave-wide prefix over the 256 counters, 4 per lane
-            // (a serial walk by one thread is 256 dependent LDS round trips: ~10 us a pass)
+            // bucket holding the rank: wave-wide prefix over the counters, NB/64 per lane
+            // (a serial walk by one thread is NB dependent LDS round trips)
+            constexpr int PER = (int)(NB / 64);
             const int rem = sm->remaining;
-            unsigned h[4];
-            unsigned s4 = 0;
+            unsigned h[PER];
+            unsigned sl = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { h[q] = sm->hist[4 * tid + q]; s4 += h[q]; }
-            unsigned inc = s4;
+            for (int q = 0; q < PER; ++q) { h[q] = sm->hist[PER * tid + q]; sl += h[q]; }
+            unsigned inc = sl;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
                 const unsigned v = __shfl_up(inc, off, 64);
                 if (tid >= off) inc += v;
             }
-            unsigned cum = inc - s4;
+            unsigned cum = inc - sl;
             if (cum < (unsigned)rem && inc >= (unsigned)rem) {      // exactly one lane
-                int bucket = 4 * tid;
-                unsigned before = cum;
+                int bucket = PER * tid;
+                unsigned before = cum, hb = 0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (cum < (unsigned)rem && cum + h[q] >= (unsigned)rem) { bucket = 4 * tid + q; before = cum; }
+                for (int q = 0; q < PER; ++q) {
+                    if (cum < (unsigned)rem && cum + h[q] >= (unsigned)rem) { bucket = PER * tid + q; before = cum; hb = h[q]; }
                     cum += h[q];
                 }
                 const int r2 = rem - (int)before;
                 sm->remaining = r2;
                 sm->prefix = prefix | ((uint64_t)(unsigned)bucket << sh);
-                sm->done = ((int)h[bucket & 3] == r2) ? 1 : 0;
+                sm->done = ((int)hb == r2) ? 1 : 0;
             }
         }
         __syncthreads();
@@ -797,6 +807,9 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
 
     const int b = (int)blockIdx.x;
     const int tid = (int)threadIdx.x;
+    int dbg_i = 0;
+    auto mark = [&]() { if (a.dbg_times && b == 0 && tid == 0) a.dbg_times[dbg_i] = wall_clock64(); ++dbg_i; };
+    mark();                                              // 0: start
     const float* cd = a.cand_d + (int64_t)b * a.cand_stride;
     const int2* crt = a.cand_rt + (int64_t)b * a.cand_stride;
     const bool slices = a.bcount != nullptr;
@@ -832,6 +845,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
     } else {
         n = a.n_fixed;
     }
+    mark();                                              // 1: slice prefix done
     if (tid == 0 && a.total) a.total[b] = n;
     // candidate e lives at src(e): identity for flat inputs, slice lookup (binary search of
     // the owning block in LDS) otherwise -- no compaction pass over global memory
@@ -859,8 +873,10 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
             for (int e = tid; e < n; e += PSH_SELECT_THREADS) body(e, src(e));
         }
     };
-    // distance bits are staged in LDS when they fit: every later pass runs at LDS latency
+    // distance bits are staged in LDS when they fit: every later pass runs at LDS latency;
+    // their min / max fall out of the same pass
     const bool in_lds = n <= a.key_cap;
+    unsigned kmin32 = 0xffffffffu, kmax32 = 0u;
     if (in_lds) {
         if (slices) {
             const int q = tid % tps, sstep = PSH_SELECT_THREADS / tps;
@@ -872,15 +888,38 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
 #pragma unroll
                     for (int u = 0; u < 4; ++u) v[u] = (j + u * tps < cnt) ? sp[j + u * tps] : 0.0f;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) if (j + u * tps < cnt) keys[e0 + j + u * tps] = __float_as_uint(v[u]);
+                    for (int u = 0; u < 4; ++u)
+                        if (j + u * tps < cnt) {
+                            const unsigned kb = __float_as_uint(v[u]);
+                            keys[e0 + j + u * tps] = kb;
+                            kmin32 = kb < kmin32 ? kb : kmin32;
+                            kmax32 = kb > kmax32 ? kb : kmax32;
+                        }
                 }
             }
         } else {
 #pragma unroll 4
             for (int e = tid; e < n; e += PSH_SELECT_THREADS) keys[e] = __float_as_uint(cd[src(e)]);
         }
+        mark();                                          // 2: keys loaded
+        if (slices) {      // block min / max of the staged keys
+            if (tid == 0) { sm.kmin = ~0ull; sm.kmax = 0ull; }
+            __syncthreads();
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned l2 = __shfl_xor(kmin32, off, 64), h2 = __shfl_xor(kmax32, off, 64);
+                kmin32 = l2 < kmin32 ? l2 : kmin32;
+                kmax32 = h2 > kmax32 ? h2 : kmax32;
+            }
+            if ((tid & 63) == 0) {
+                atomicMin((unsigned long long*)&sm.kmin, (unsigned long long)kmin32 << 32);
+                atomicMax((unsigned long long*)&sm.kmax, (unsigned long long)kmax32 << 32);
+            }
+        }
         __syncthreads();
     }
+    const bool have_mm = in_lds && slices;
+    const uint64_t kmin64 = have_mm ? sm.kmin : 0ull, kmax64 = have_mm ? sm.kmax : 0ull;
     auto dkey = [&](int e) -> unsigned { return in_lds ? keys[e] : __float_as_uint(cd[src(e)]); };
     // gathered lists keep distances and indices in separate blocks with different strides
     auto rt_index = [&](int e, int64_t sidx) -> int64_t {
@@ -913,7 +952,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
         bool exact;
         int rem;
         radix_select64([&](int e) { return (uint64_t)dkey(e) << 32; }, live, n, need, 32,
-                       &sm, &d_prefix, &d_sh, &exact, &rem);
+                       &sm, &d_prefix, &d_sh, &exact, &rem, have_mm, kmin64, kmax64);
         if (!exact) {
             // the k-th distance VALUE is shared by more candidates than fit: the canonical
             // order keeps the smallest (r, t) among those ties
@@ -927,11 +966,14 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
         }
     }
 
+    mark();                                              // 4: radix select done
     // ---- collect the selected candidates
     for (int i = tid; i < a.kpad; i += PSH_SELECT_THREADS) items[i] = ~0ull;
     if (tid == 0) sm.nsel = 0;
     __syncthreads();
     if (need > 0) {
+        // phase A: slots for the taken candidates, (r,t) still in global memory (a load
+        // inside this loop would put one global round trip on every iteration)
         const unsigned dk = (unsigned)(d_prefix >> 32);
         for_each_cand([&](int e, int64_t sidx) {
             const unsigned db = in_lds ? keys[e] : __float_as_uint(cd[sidx]);
@@ -940,21 +982,36 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
             else if (!tie_select) take = (((uint64_t)db << 32) >> d_sh) <= (d_prefix >> d_sh);
             else take = db <= dk;                      // ties resolved below
             if (!take) return;
-            const int2 rt = crt[rt_index(e, sidx)];
-            if (skip_neg && rt.x < 0) return;
-            if (tie_select && db == dk) {
-                const uint64_t rk = ((uint64_t)(unsigned)rt.x << 32) | (uint64_t)(unsigned)rt.y;
-                if (!((rk >> rt_sh) <= (rt_prefix >> rt_sh))) return;
+            const int64_t ridx = rt_index(e, sidx);
+            if (skip_neg || (tie_select && db == dk)) {          // flat inputs / tied values: the index decides
+                const int2 rt = crt[ridx];
+                if (skip_neg && rt.x < 0) return;
+                if (tie_select && db == dk) {
+                    const uint64_t rk = ((uint64_t)(unsigned)rt.x << 32) | (uint64_t)(unsigned)rt.y;
+                    if (!((rk >> rt_sh) <= (rt_prefix >> rt_sh))) return;
+                }
             }
             const int slot = atomicAdd(&sm.nsel, 1);
             if (slot < a.kpad) {
                 items[slot] = ((uint64_t)db << 32) | (uint64_t)(unsigned)slot;
-                sel_rt[slot] = rt;
+                sel_rt[slot] = make_int2((int)(ridx & 0xffffffffll), (int)(ridx >> 32));   // parked: where its (r,t) is
             }
         });
     }
     __syncthreads();
+    mark();                                              // 5: slots assigned
+    {   // phase B: one independent load per selected candidate
+        const int ns = sm.nsel < a.kpad ? sm.nsel : a.kpad;
+        for (int sl = tid; sl < ns; sl += PSH_SELECT_THREADS) {
+            const int2 parked = sel_rt[sl];
+            const int64_t ridx = ((int64_t)parked.y << 32) | (int64_t)(unsigned)parked.x;
+            sel_rt[sl] = crt[ridx];
+        }
+    }
+    __syncthreads();
 
+    mark();                                              // 4: collected
+    mark();                                              // 6: (r,t) fetched
     // ---- bitonic sort of kpad items by (d bits, r, t): strides below 64 stay inside a
     // wave (shuffles, no barrier), only the wider ones go through LDS
     if (a.kpad <= PSH_SELECT_THREADS) {
@@ -998,6 +1055,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
     }
     __syncthreads();
 
+    mark();                                              // 7: sorted
     // ---- write out
     const int nsel = sm.nsel < need ? sm.nsel : need;
     for (int i = tid; i < a.k; i += PSH_SELECT_THREADS) {
@@ -1013,6 +1071,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
         a.out_idx[((int64_t)b * a.k + i) * 2 + 1] = rt.y;
     }
     if (tid == 0 && a.qstate) a.qstate[b].n_valid = nsel;
+    mark();                                              // 6: written
 }
 
 // exhaustive path: the running best goes behind the next chunk's window slots
@@ -1125,7 +1184,7 @@ hipError_t launch_threshold(const ThresholdArgs& a0, int B, hipStream_t s) {
 hipError_t launch_select(const SelectArgs& a0, int B, hipStream_t s) {
     SelectArgs a = a0;
     // LDS: the k items being sorted + as many staged distance keys as fit next to them
-    const size_t lds_budget = 144 * 1024;      // of 160 KB; SelectShared (static) takes ~10 KB
+    const size_t lds_budget = 136 * 1024;      // of 160 KB; SelectShared (static) takes ~16 KB
     const size_t items_bytes = (size_t)a.kpad * sizeof(uint64_t);
     int64_t key_cap = items_bytes < lds_budget ? (int64_t)((lds_budget - items_bytes) / sizeof(unsigned)) : 0;
     const int64_t n_max = a.bcount ? (int64_t)a.nblk * a.slice : (int64_t)a.n_fixed;
