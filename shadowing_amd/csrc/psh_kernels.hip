@@ -234,6 +234,27 @@ __device__ __forceinline__ void accumulate16(const float* tile, int lane, const_
     }
 }
 
+// 8 correlation chains, one v_fmac_f32 each, with the query tap in a VGPR.  Measured issue
+// cost per wave64 instruction on this part (tools/ubench_dot2.hip, 4 waves/SIMD):
+//   v_sub/v_fmac with <= 2 distinct VGPR sources 1.12 ns,  v_fmac c, x(VGPR), w 1.39 ns,
+//   v_fmac c, x(SGPR), w 1.98 ns,  v_dot2c_f32_bf16 2.0 ns,  v_cvt_pk_bf16_f32 3.0 ns
+// -- so the tap is kept in a VGPR although it is wave-uniform.
+__device__ __forceinline__ void corr8(float xj, float w0, float w1, float w2, float w3, float w4, float w5,
+                                      float w6, float w7, float& c0, float& c1, float& c2, float& c3,
+                                      float& c4, float& c5, float& c6, float& c7) {
+    asm volatile(
+        "v_fmac_f32 %0, %8, %9\n\t"
+        "v_fmac_f32 %1, %8, %10\n\t"
+        "v_fmac_f32 %2, %8, %11\n\t"
+        "v_fmac_f32 %3, %8, %12\n\t"
+        "v_fmac_f32 %4, %8, %13\n\t"
+        "v_fmac_f32 %5, %8, %14\n\t"
+        "v_fmac_f32 %6, %8, %15\n\t"
+        "v_fmac_f32 %7, %8, %16"
+        : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7)
+        : "v"(xj), "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4), "v"(w5), "v"(w6), "v"(w7));
+}
+
 // ---- bound-then-verify: the cheap test of the full scan -------------------------------
 // The exact chain costs 2 VALU operations per term (subtract, fma) and that, not HBM, is
 // what bounds the scan: 41 lane-operations per window against ~64 T lane-ops/s is
@@ -248,7 +269,7 @@ __device__ __forceinline__ void accumulate16(const float* tile, int lane, const_
 // Compile-time W >= 17 only (the prefix differences P_{i+W} - P_i are taken while the
 // values stream through the 16-register window).
 template <int WT>
-__device__ __forceinline__ void approx16(const float* tile, int lane, const_f32p x, float (&t)[PSH_L], float& NY) {
+__device__ __forceinline__ void approx16(const float* tile, int lane, const float (&xv)[WT], float (&t)[PSH_L], float& NY) {
     static_assert(WT >= 17 && WT <= 32, "approx16 streams W in [17, 32]");
     float win[PSH_L], c[PSH_L], Ps[PSH_L];
     const int base = PSH_L * lane;
@@ -269,11 +290,13 @@ __device__ __forceinline__ void approx16(const float* tile, int lane, const_f32p
         for (int q = 0; q < 4; ++q) {
             const int j = 4 * g + q;
             if (j < WT) {
-                const float xj = x[j];
-                // left to the compiler: it pairs the 16 chains into v_pk_fma_f32 (measured
-                // 118 us for the full scan vs 126 us with 320 hand-placed scalar v_fmac)
-#pragma unroll
-                for (int i = 0; i < PSH_L; ++i) c[i] = __builtin_fmaf(xj, win[(i + j) & 15], c[i]);
+                const float xj = xv[j];
+                corr8(xj, win[(0 + j) & 15], win[(1 + j) & 15], win[(2 + j) & 15], win[(3 + j) & 15],
+                      win[(4 + j) & 15], win[(5 + j) & 15], win[(6 + j) & 15], win[(7 + j) & 15],
+                      c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
+                corr8(xj, win[(8 + j) & 15], win[(9 + j) & 15], win[(10 + j) & 15], win[(11 + j) & 15],
+                      win[(12 + j) & 15], win[(13 + j) & 15], win[(14 + j) & 15], win[(15 + j) & 15],
+                      c[8], c[9], c[10], c[11], c[12], c[13], c[14], c[15]);
                 if (j + 16 <= WT + 14) {              // y_{j+16} is still needed by some window
                     const float v = nx4[q];
                     win[j & 15] = v;
@@ -509,12 +532,16 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
             float thr = 0.0f;
             if (CHEAP) {
                 float NY;
+                constexpr int WX = CHEAP ? WT : 20;
+                float xv[WX];                              // the query taps as VGPRs (see corr8)
+#pragma unroll
+                for (int j = 0; j < WX; ++j) { xv[j] = x[j]; asm volatile("" : "+v"(xv[j])); }
 #if defined(PSH_ABL) && (PSH_ABL == 2)
                 NY = tile[lds_pad(PSH_L * lane)];                          // ablation 2: no arithmetic
 #pragma unroll
                 for (int i = 0; i < PSH_L; ++i) acc[i] = 1e30f;
 #else
-                approx16<(CHEAP ? WT : 20)>(tile, lane, x, acc, NY);     // acc[] holds t_i = ny_i - 2 c_i here
+                approx16<WX>(tile, lane, xv, acc, NY);     // acc[] holds t_i = ny_i - 2 c_i here
 #endif
                 thr = __builtin_fmaf(1.0f / 65536.0f, NY, qstate_k[b].thr_base);
             } else if (MODE == PSH_MODE_ALL && a.Tp == 1) {

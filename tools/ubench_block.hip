@@ -16,7 +16,7 @@ __global__ __launch_bounds__(1024) void bench(const float* q, float* out, int it
     for (int it = 0; it < iters; ++it) {
         float acc[PSH_L];
         if (VARIANT == 0) { accumulate16<20>(tile, lane, x, 20, acc); }
-        else { float NY; approx16<20>(tile, lane, x, acc, NY); sum += NY; }
+        else { float NY; float xv[20]; for (int j = 0; j < 20; ++j) { xv[j] = x[j]; asm volatile("" : "+v"(xv[j])); } approx16<20>(tile, lane, xv, acc, NY); sum += NY; }
         float m = min16(acc);
         if (__any(m < -1e30f)) sum += m;    // keep the result live, never taken
         wave_lds_fence();
