@@ -703,26 +703,31 @@ __device__ inline void radix_select64(KeyFn key_of, LiveFn live, int n, int rank
         return;
     }
     const int top_bit = 63 - __clzll((unsigned long long)(diff << sh_floor));   // highest differing bit
-    int sh = sh_floor + PSH_RB * ((top_bit - sh_floor) / PSH_RB);                  // digit holding it
+    // the first digit's MSB is the highest differing bit, so its 2^PSH_RB counters spread
+    // over [kmin, kmax]; a digit grid fixed to sh_floor can leave the first pass two or
+    // three live counters and 1e4 LDS atomics serialised on them (15 us of a 20 us select)
+    int bits = (top_bit - sh_floor + 1) < PSH_RB ? (top_bit - sh_floor + 1) : PSH_RB;
+    int sh = top_bit + 1 - bits;
     __syncthreads();
     if (tid == 0) {
-        sm->prefix = (sh + PSH_RB >= 64) ? 0ull : ((kmin >> (sh + PSH_RB)) << (sh + PSH_RB));   // shared high bits
+        sm->prefix = (top_bit + 1 >= 64) ? 0ull : ((kmin >> (top_bit + 1)) << (top_bit + 1));   // shared high bits
         sm->remaining = rank;
         sm->done = 0;
     }
     __syncthreads();
     int sh_done = sh;
     bool first = true;
-    for (; sh >= sh_floor; sh -= PSH_RB) {
+    for (;;) {
         for (unsigned i = (unsigned)tid; i < NB; i += PSH_SELECT_THREADS) sm->hist[i] = 0u;
         __syncthreads();
         const uint64_t prefix = sm->prefix;
-        const int shp = sh + PSH_RB;
+        const int shp = sh + bits;
+        const unsigned dmask = (1u << bits) - 1u;
         for (int i = tid; i < n; i += PSH_SELECT_THREADS) {
             if (!live(i)) continue;
             const uint64_t key = key_of(i);
             const bool match = first || shp >= 64 || ((key >> shp) == (prefix >> shp));
-            if (match) atomicAdd(&sm->hist[(unsigned)(key >> sh) & (NB - 1u)], 1u);
+            if (match) atomicAdd(&sm->hist[(unsigned)(key >> sh) & dmask], 1u);
         }
         __syncthreads();
         if (tid < 64) {
@@ -758,7 +763,9 @@ __device__ inline void radix_select64(KeyFn key_of, LiveFn live, int n, int rank
         __syncthreads();
         sh_done = sh;
         first = false;
-        if (sm->done) break;
+        if (sm->done || sh <= sh_floor) break;
+        bits = (sh - sh_floor) < PSH_RB ? (sh - sh_floor) : PSH_RB;
+        sh -= bits;
     }
     *out_prefix = sm->prefix;
     *out_sh = sh_done;
@@ -1002,28 +1009,49 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
         // phase A: slots for the taken candidates, (r,t) still in global memory (a load
         // inside this loop would put one global round trip on every iteration)
         const unsigned dk = (unsigned)(d_prefix >> 32);
-        for_each_cand([&](int e, int64_t sidx) {
-            const unsigned db = in_lds ? keys[e] : __float_as_uint(cd[sidx]);
-            bool take;
-            if (d_sh >= 64) take = true;
-            else if (!tie_select) take = (((uint64_t)db << 32) >> d_sh) <= (d_prefix >> d_sh);
-            else take = db <= dk;                      // ties resolved below
-            if (!take) return;
-            const int64_t ridx = rt_index(e, sidx);
-            if (skip_neg || (tie_select && db == dk)) {          // flat inputs / tied values: the index decides
-                const int2 rt = crt[ridx];
-                if (skip_neg && rt.x < 0) return;
-                if (tie_select && db == dk) {
-                    const uint64_t rk = ((uint64_t)(unsigned)rt.x << 32) | (uint64_t)(unsigned)rt.y;
-                    if (!((rk >> rt_sh) <= (rt_prefix >> rt_sh))) return;
-                }
-            }
-            const int slot = atomicAdd(&sm.nsel, 1);
+        auto park = [&](int slot, unsigned db, int64_t ridx) {
             if (slot < a.kpad) {
                 items[slot] = ((uint64_t)db << 32) | (uint64_t)(unsigned)slot;
                 sel_rt[slot] = make_int2((int)(ridx & 0xffffffffll), (int)(ridx >> 32));   // parked: where its (r,t) is
             }
-        });
+        };
+        if (in_lds && !skip_neg && !tie_select) {
+            // the common case walks the staged keys in lock step, so the waves can claim
+            // their slots with ONE LDS atomic per 64 keys (1024 single atomics on one word
+            // took 7 us); only the ~k takers look up where their (r,t) lives
+            const int n_up = (n + 63) & ~63;
+            for (int e = tid; e < n_up; e += PSH_SELECT_THREADS) {
+                const unsigned db = e < n ? keys[e] : 0xffffffffu;
+                const bool take = e < n && (d_sh >= 64 || ((((uint64_t)db << 32) >> d_sh) <= (d_prefix >> d_sh)));
+                const unsigned long long mask = __ballot(take);
+                if (!mask) continue;
+                int base = 0;
+                if ((tid & 63) == 0) base = atomicAdd(&sm.nsel, __popcll(mask));
+                base = __builtin_amdgcn_readfirstlane(base);
+                // parked as -(e+1): phase B finds where candidate e lives (a search here would
+                // serialise 8 dependent LDS reads into every iteration of this loop)
+                if (take) park(base + __popcll(mask & ((1ull << (tid & 63)) - 1ull)), db, -(int64_t)e - 1);
+            }
+        } else {
+            for_each_cand([&](int e, int64_t sidx) {
+                const unsigned db = in_lds ? keys[e] : __float_as_uint(cd[sidx]);
+                bool take;
+                if (d_sh >= 64) take = true;
+                else if (!tie_select) take = (((uint64_t)db << 32) >> d_sh) <= (d_prefix >> d_sh);
+                else take = db <= dk;                      // ties resolved below
+                if (!take) return;
+                const int64_t ridx = rt_index(e, sidx);
+                if (skip_neg || (tie_select && db == dk)) {          // flat inputs / tied values: the index decides
+                    const int2 rt = crt[ridx];
+                    if (skip_neg && rt.x < 0) return;
+                    if (tie_select && db == dk) {
+                        const uint64_t rk = ((uint64_t)(unsigned)rt.x << 32) | (uint64_t)(unsigned)rt.y;
+                        if (!((rk >> rt_sh) <= (rt_prefix >> rt_sh))) return;
+                    }
+                }
+                park(atomicAdd(&sm.nsel, 1), db, ridx);
+            });
+        }
     }
     __syncthreads();
     mark();                                              // 5: slots assigned
@@ -1031,40 +1059,55 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
         const int ns = sm.nsel < a.kpad ? sm.nsel : a.kpad;
         for (int sl = tid; sl < ns; sl += PSH_SELECT_THREADS) {
             const int2 parked = sel_rt[sl];
-            const int64_t ridx = ((int64_t)parked.y << 32) | (int64_t)(unsigned)parked.x;
+            int64_t ridx = ((int64_t)parked.y << 32) | (int64_t)(unsigned)parked.x;
+            if (ridx < 0) { const int e = (int)(-ridx - 1); ridx = rt_index(e, src(e)); }
             sel_rt[sl] = crt[ridx];
         }
     }
     __syncthreads();
 
-    mark();                                              // 4: collected
     mark();                                              // 6: (r,t) fetched
     // ---- bitonic sort of kpad items by (d bits, r, t): strides below 64 stay inside a
     // wave (shuffles, no barrier), only the wider ones go through LDS
     if (a.kpad <= PSH_SELECT_THREADS) {
-        uint64_t mine = (tid < a.kpad) ? items[tid] : ~0ull;
-        for (int size = 2; size <= a.kpad; size <<= 1) {
-            for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                const bool ascending = ((tid & size) == 0);
-                uint64_t other;
-                if (stride >= 64) {
-                    __syncthreads();
-                    if (tid < a.kpad) items[tid] = mine;
-                    __syncthreads();
-                    other = (tid < a.kpad) ? items[tid ^ stride] : ~0ull;
-                } else {
-                    other = __shfl_xor(mine, stride, 64);
+        // one item per thread.  Pass 0 orders the 64-bit items as plain integers (distance
+        // bits, then slot): exact unless two selected candidates share a distance value;
+        // only then pass 1 repeats the network with the full (d, r, t) comparison.
+        for (int pass = 0; pass < 2; ++pass) {
+            uint64_t mine = (tid < a.kpad) ? items[tid] : ~0ull;
+            for (int size = 2; size <= a.kpad; size <<= 1) {
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    const bool ascending = ((tid & size) == 0);
+                    uint64_t other;
+                    if (stride >= 64) {
+                        __syncthreads();
+                        if (tid < a.kpad) items[tid] = mine;
+                        __syncthreads();
+                        other = (tid < a.kpad) ? items[tid ^ stride] : ~0ull;
+                    } else {
+                        other = __shfl_xor(mine, stride, 64);
+                    }
+                    const bool i_am_low = (tid & stride) == 0;
+                    // the low partner keeps the smaller item in an ascending run
+                    bool other_less, mine_less;
+                    if (pass == 0) { other_less = other < mine; mine_less = mine < other; }
+                    else { other_less = item_less(other, mine, sel_rt); mine_less = item_less(mine, other, sel_rt); }
+                    const bool take_other = (i_am_low == ascending) ? other_less : mine_less;
+                    if (take_other) mine = other;
                 }
-                const bool i_am_low = (tid & stride) == 0;
-                // the low partner keeps the smaller item in an ascending run
-                const bool other_less = item_less(other, mine, sel_rt);
-                const bool mine_less = item_less(mine, other, sel_rt);
-                const bool take_other = (i_am_low == ascending) ? other_less : mine_less;
-                if (take_other) mine = other;
+            }
+            __syncthreads();
+            if (tid < a.kpad) items[tid] = mine;
+            if (tid == 0) sm.cnt = 0;
+            __syncthreads();
+            if (pass == 0) {      // any equal distance values next to each other?
+                const bool tie = tid + 1 < a.kpad && (unsigned)(mine >> 32) != 0xffffffffu &&
+                                 (unsigned)(items[tid + 1] >> 32) == (unsigned)(mine >> 32);
+                if (tie) sm.cnt = 1;
+                __syncthreads();
+                if (sm.cnt == 0) break;
             }
         }
-        __syncthreads();
-        if (tid < a.kpad) items[tid] = mine;
     } else {
         for (int size = 2; size <= a.kpad; size <<= 1) {
             for (int stride = size >> 1; stride > 0; stride >>= 1) {
