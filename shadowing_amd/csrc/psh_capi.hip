@@ -419,8 +419,7 @@ int psh_scan_topk(int device, void* stream, const float* dataset, int64_t R, int
     Timer tm(stages, s);
     rc = tm.init(); if (rc) return rc;
     rc = tm.mark(); if (rc) return rc;                                       // 0
-    PrepArgs pa{queries, qnorm, B, W, w.qstate, w.total, out_status};
-    HIP_TRY(launch_prep(pa, s));
+    PrepArgs pa{queries, qnorm, B, W, w.qstate, w.total, out_status};       // runs inside the threshold kernel
     rc = tm.mark(); if (rc) return rc;                                       // 1
 
     Plan plan_s;
@@ -430,7 +429,7 @@ int psh_scan_topk(int device, void* stream, const float* dataset, int64_t R, int
     HIP_TRY(launch_scan(sa, PSH_MODE_BOOT, p.aligned, plan_s.grid, s));
     rc = tm.mark(); if (rc) return rc;                                       // 2
 
-    ThresholdArgs ta{w.minbuf, w.min_stride, (int)bp.entries, w.qstate, k, 0};
+    ThresholdArgs ta{w.minbuf, w.min_stride, (int)bp.entries, w.qstate, k, 0, pa};
     HIP_TRY(launch_threshold(ta, B, s));
     rc = tm.mark(); if (rc) return rc;                                       // 3
 

@@ -75,6 +75,7 @@ struct ThresholdArgs {
     QueryState* qstate;
     int k;
     int keys_in_lds;         // set by the launcher
+    PrepArgs prep;           // the per-query preparation runs here too (one launch less on the sampled path)
 };
 
 struct SelectArgs {

@@ -104,9 +104,8 @@ __device__ inline float sumsq8(F get, int W) {
 // ----------------------------------------------------------------------------------
 // K0: per-query preparation -- ||x||, state reset
 // ----------------------------------------------------------------------------------
-__global__ void prep_kernel(PrepArgs a) {
-    const int b = (int)blockIdx.x;
-    if (threadIdx.x == 0) {
+__device__ __forceinline__ void prep_query(const PrepArgs& a, int b) {
+    {
         const float* x = a.queries + (int64_t)b * a.W;
         const float s = sumsq8([&](int j) { return x[j]; }, a.W);
         QueryState q;
@@ -120,6 +119,10 @@ __global__ void prep_kernel(PrepArgs a) {
         a.total[b] = 0;
         if (a.status) a.status[b] = PSH_STATUS_OK_;
     }
+}
+
+__global__ void prep_kernel(PrepArgs a) {
+    if (threadIdx.x == 0) prep_query(a, (int)blockIdx.x);
 }
 
 __global__ void qnorm_kernel(const float* queries, int B, int W, float* out) {
@@ -783,6 +786,8 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
     const int tid = (int)threadIdx.x;
     const float* v = a.minbuf + (int64_t)b * a.min_stride;
     const int n = a.n_entries;
+    if (tid == 0) prep_query(a.prep, b);                   // ||x||, sum of squares, state reset
+    __syncthreads();                                       // (block-scope visibility of qstate[b] for thread 0 below)
     if (n < a.k) return;                                   // tau stays +inf (host avoids this)
     const bool in_lds = a.keys_in_lds != 0;
     if (in_lds) {
@@ -1085,7 +1090,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
                         __syncthreads();
                         other = (tid < a.kpad) ? items[tid ^ stride] : ~0ull;
                     } else {
-                        other = __shfl_xor(mine, stride, 64);
+                        other = __shfl_xor(mine, stride, 64);    // (quad DPP moves and a two-buffer exchange were tried: slower)
                     }
                     const bool i_am_low = (tid & stride) == 0;
                     // the low partner keeps the smaller item in an ascending run
