@@ -132,6 +132,37 @@ int psh_scan_topk_exhaustive(int device, void* stream,
                              void* workspace, size_t workspace_bytes, psh_profile* profile);
 
 /*
+ * The scan behind a general LINEAR embedding (Foveal, any PathEmbedding kernel):
+ * replaces the same loop body (path_shadowing.py:149-173) when the embedding is
+ * conv1d with a (d, 1, K) kernel (path_embedding.py:117-132, Foveal :142-172) and the
+ * distance is RelativeMSE.  For every window t in [0, T-K-h] of every row
+ *     hy_i = sum_j kernel[i][j] * y[t+j]         i < d   (fma chain, increasing j)
+ *     acc  = sum_i (hx_i - hy_i)^2                        (fma chain, increasing i)
+ *     d    = sqrt(acc) / hxnorm
+ *   kernel  device, d x K row-major float32 (the UNPADDED kernel: the context's zero
+ *           taps over the horizon are the integer h)
+ *   hx      device, B x d float32: the embedded queries (embedding(x_context))
+ *   hxnorm  device, B floats, or NULL: ||hx|| in the order of psh_query_norm
+ * Everything else as psh_scan_topk (same workspace: psh_workspace_bytes with W = K).
+ * The reference evaluates these sums in library-chosen orders, so agreement with IT is
+ * to ~1e-6 relative (tested at 1e-5) with indices equal outside near-ties; agreement
+ * with the oracle's restatement of the order above is bit-exact.  Requires d <= 128 and
+ * d * roundup4(K) <= 8192 (the kernel matrix lives in LDS), finite data.
+ */
+int psh_scan_topk_embedded(int device, void* stream,
+                           const float* dataset, int64_t R, int64_t T, int64_t r_offset,
+                           const float* kernel, int d, int K,
+                           const float* hx, const float* hxnorm, int B, int h, int k,
+                           float* out_d, int32_t* out_idx, int32_t* out_status,
+                           void* workspace, size_t workspace_bytes, psh_profile* profile);
+int psh_scan_topk_embedded_exhaustive(int device, void* stream,
+                           const float* dataset, int64_t R, int64_t T, int64_t r_offset,
+                           const float* kernel, int d, int K,
+                           const float* hx, const float* hxnorm, int B, int h, int k,
+                           float* out_d, int32_t* out_idx, int32_t* out_status,
+                           void* workspace, size_t workspace_bytes, psh_profile* profile);
+
+/*
  * Merge G sorted-or-not candidate lists per query into the k best by (d, r, t):
  * the running merge of path_shadowing.py:170-173 and the cross-GPU merge after
  * the all-gather of per-shard results.

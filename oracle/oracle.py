@@ -39,6 +39,12 @@ def lib() -> C.CDLL:
         L.psh_oracle_gather_paths.restype = C.c_int
         L.psh_oracle_gather_paths.argtypes = [f32p, C.c_int64, C.c_int64, C.c_int64, i32p,
                                               C.c_int64, C.c_int, f32p]
+        L.psh_oracle_scan_topk_embedded.restype = C.c_int
+        L.psh_oracle_scan_topk_embedded.argtypes = [f32p, C.c_int64, C.c_int64, C.c_int64, f32p, C.c_int, C.c_int,
+                                                    f32p, f32p, C.c_int, C.c_int, C.c_int, f32p, i32p, C.c_int]
+        L.psh_oracle_all_distances_embedded.restype = C.c_int
+        L.psh_oracle_all_distances_embedded.argtypes = [f32p, C.c_int64, C.c_int64, f32p, C.c_int, C.c_int,
+                                                        f32p, C.c_float, C.c_int, f32p]
         _lib = L
     return _lib
 
@@ -99,6 +105,51 @@ def all_distances(dataset, query, h: int = 0, qn=None) -> np.ndarray:
                                         _p(out, C.c_float))
     if rc != 0:
         raise RuntimeError("psh_oracle_all_distances failed")
+    return out
+
+
+def scan_topk_embedded(dataset, kernel, hx, k: int, h: int = 0, r_offset: int = 0, hxnorm=None,
+                       nthreads: int = 0):
+    """Embedded scan: kernel (d, K) or (d, 1, K) unpadded, hx (B, d) embedded queries.
+    (d (B,k) f32, idx (B,k,2) i32) in canonical order."""
+    ds = _rows(dataset)
+    ker = _f32(kernel)
+    if ker.ndim == 3:
+        ker = ker[:, 0, :]
+    ker = np.ascontiguousarray(ker)
+    d_, K = ker.shape
+    q = np.atleast_2d(_f32(hx))
+    B = q.shape[0]
+    assert q.shape[1] == d_
+    R, T = ds.shape
+    d = np.empty((B, k), np.float32)
+    idx = np.empty((B, k, 2), np.int32)
+    qn_arr = None if hxnorm is None else _f32(hxnorm).reshape(B)
+    rc = lib().psh_oracle_scan_topk_embedded(_p(ds, C.c_float), R, T, r_offset, _p(ker, C.c_float), d_, K,
+                                             _p(q, C.c_float),
+                                             None if qn_arr is None else _p(qn_arr, C.c_float),
+                                             B, h, k, _p(d, C.c_float), _p(idx, C.c_int32), nthreads)
+    if rc != 0:
+        raise RuntimeError(f"psh_oracle_scan_topk_embedded failed: {rc}")
+    return d, idx
+
+
+def all_distances_embedded(dataset, kernel, hx, h: int = 0, hxnorm=None) -> np.ndarray:
+    ds = _rows(dataset)
+    ker = _f32(kernel)
+    if ker.ndim == 3:
+        ker = ker[:, 0, :]
+    ker = np.ascontiguousarray(ker)
+    d_, K = ker.shape
+    x = _f32(hx).reshape(-1)
+    R, T = ds.shape
+    Tp = T - K - h + 1
+    out = np.empty((R, Tp), np.float32)
+    xn = float(qnorm(x)[0]) if hxnorm is None else float(hxnorm)
+    rc = lib().psh_oracle_all_distances_embedded(_p(ds, C.c_float), R, T, _p(ker, C.c_float), d_, K,
+                                                 _p(x, C.c_float), xn, h, _p(out, C.c_float))
+    if rc != 0:
+        raise RuntimeError("psh_oracle_all_distances_embedded failed")
     return out
 
 

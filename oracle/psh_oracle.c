@@ -225,6 +225,111 @@ int psh_oracle_scan_topk(const float* dataset, int64_t R, int64_t T, int64_t r_o
     return 0;
 }
 
+/*
+ * The scan behind a general linear embedding (Foveal, user kernels): reference
+ * path_embedding.py:117-132 (PathEmbedding.forward = conv1d with a (d,1,K) kernel;
+ * Foveal's kernel :142-172) feeding RelativeMSE (path_distance.py:62-65) inside the
+ * loop of path_shadowing.py:149-173.
+ *   hy_i = sum_j ker[i][j] * y[t+j]   fma chain over increasing j
+ *   acc  = sum_i (hx_i - hy_i)^2      D rounded, fma chain over increasing i
+ *   d    = sqrt(acc) / hxnorm
+ * The reference leaves both reduction orders to its libraries (MKL-DNN conv1d, the
+ * vectorised norm), so THIS restatement is pinned against the reference's outputs to a
+ * tolerance (tests/golden/foveal_*.npz, rtol 1e-5, indices equal outside near-ties),
+ * not bit for bit; the HIP kernel is then held bit-exactly to this function.
+ * ker: d x K row-major (unpadded; the context's zero taps are the integer h).
+ * hx: B x d embedded queries.  hxnorm: B or NULL (-> psh_oracle_qnorm(hx, d)).
+ */
+static inline float embedded_acc(const float* y, const float* ker, int d, int K, const float* hx) {
+    float acc = 0.0f;
+    for (int i = 0; i < d; ++i) {
+        const float* kr = ker + (int64_t)i * K;
+        float e = 0.0f;
+        for (int j = 0; j < K; ++j) e = fmaf(kr[j], y[j], e);
+        const float D = hx[i] - e;
+        acc = fmaf(D, D, acc);
+    }
+    return acc;
+}
+
+int psh_oracle_scan_topk_embedded(const float* dataset, int64_t R, int64_t T, int64_t r_offset,
+                                  const float* ker, int d, int K,
+                                  const float* hx, const float* hxnorm, int B, int h, int k,
+                                  float* out_d, int32_t* out_idx, int nthreads) {
+    if (!dataset || !ker || !hx || !out_d || !out_idx) return -1;
+    if (R < 0 || T <= 0 || B < 0 || K <= 0 || d <= 0 || h < 0 || k <= 0) return -1;
+    const int64_t Tp = T - K - h + 1;
+    if (Tp <= 0) return -1;
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#else
+    nthreads = 1;
+#endif
+    /* the embedding of a window does not depend on the query: embed once per window,
+     * then one pass per query over the d coordinates */
+    for (int b = 0; b < B; ++b) {
+        const float* x = hx + (int64_t)b * d;
+        const float xn = hxnorm ? hxnorm[b] : psh_oracle_qnorm(x, d);
+        cand_t* all = (cand_t*)malloc(sizeof(cand_t) * (size_t)k * (size_t)nthreads);
+        int* counts = (int*)calloc((size_t)nthreads, sizeof(int));
+        if (!all || !counts) { free(all); free(counts); return -2; }
+#pragma omp parallel num_threads(nthreads)
+        {
+#ifdef _OPENMP
+            const int tid = omp_get_thread_num();
+#else
+            const int tid = 0;
+#endif
+            heap_t hp; hp.v = all + (size_t)tid * k; hp.n = 0; hp.k = k;
+#pragma omp for schedule(dynamic, 4)
+            for (int64_t r = 0; r < R; ++r) {
+                const float* y = dataset + r * T;
+                for (int64_t t = 0; t < Tp; ++t) {
+                    cand_t c;
+                    c.d = sqrtf(embedded_acc(y + t, ker, d, K, x)) / xn;
+                    c.r = (int32_t)(r_offset + r);
+                    c.t = (int32_t)t;
+                    if (hp.n < k) { if (c.d == c.d) heap_offer(&hp, c); }
+                    else if (cand_less(&c, &hp.v[0])) heap_offer(&hp, c);
+                }
+            }
+            counts[tid] = hp.n;
+        }
+        int n = 0;
+        for (int t = 0; t < nthreads; ++t) {
+            if (t * k != n) memmove(all + n, all + (size_t)t * k, sizeof(cand_t) * (size_t)counts[t]);
+            n += counts[t];
+        }
+        qsort(all, (size_t)n, sizeof(cand_t), cand_cmp_qsort);
+        for (int i = 0; i < k; ++i) {
+            if (i < n) {
+                out_d[(int64_t)b * k + i] = all[i].d;
+                out_idx[((int64_t)b * k + i) * 2 + 0] = all[i].r;
+                out_idx[((int64_t)b * k + i) * 2 + 1] = all[i].t;
+            } else {
+                out_d[(int64_t)b * k + i] = INFINITY;
+                out_idx[((int64_t)b * k + i) * 2 + 0] = -1;
+                out_idx[((int64_t)b * k + i) * 2 + 1] = -1;
+            }
+        }
+        free(all); free(counts);
+    }
+    return 0;
+}
+
+/* every window's embedded distance for one query */
+int psh_oracle_all_distances_embedded(const float* dataset, int64_t R, int64_t T,
+                                      const float* ker, int d, int K, const float* hx, float xn,
+                                      int h, float* out /* R x Tp */) {
+    const int64_t Tp = T - K - h + 1;
+    if (Tp <= 0) return -1;
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < R; ++r)
+        for (int64_t t = 0; t < Tp; ++t)
+            out[r * Tp + t] = sqrtf(embedded_acc(dataset + r * T + t, ker, d, K, hx)) / xn;
+    return 0;
+}
+
 /* every window's distance for one query (small cases: brute-force checks) */
 int psh_oracle_all_distances(const float* dataset, int64_t R, int64_t T,
                              const float* x, float xn, int W, int h, float* out /* R x Tp */) {

@@ -35,7 +35,8 @@ class PshProfile(C.Structure):
 
 
 EXPORTS = ("psh_version", "psh_strerror", "psh_last_hip_error", "psh_workspace_bytes", "psh_query_norm",
-           "psh_scan_topk", "psh_scan_topk_exhaustive", "psh_merge_workspace_bytes", "psh_merge_topk",
+           "psh_scan_topk", "psh_scan_topk_exhaustive", "psh_scan_topk_embedded",
+           "psh_scan_topk_embedded_exhaustive", "psh_merge_workspace_bytes", "psh_merge_topk",
            "psh_merge_topk_gathered", "psh_gather_paths")
 
 _lib = None
@@ -78,6 +79,12 @@ def load() -> C.CDLL:
     L.psh_scan_topk.argtypes = scan_args
     L.psh_scan_topk_exhaustive.restype = i32
     L.psh_scan_topk_exhaustive.argtypes = scan_args
+    emb_args = [i32, vp, vp, i64, i64, i64, vp, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, C.c_size_t,
+                C.POINTER(PshProfile)]
+    L.psh_scan_topk_embedded.restype = i32
+    L.psh_scan_topk_embedded.argtypes = emb_args
+    L.psh_scan_topk_embedded_exhaustive.restype = i32
+    L.psh_scan_topk_embedded_exhaustive.argtypes = emb_args
     L.psh_merge_workspace_bytes.restype = i32
     L.psh_merge_workspace_bytes.argtypes = [i32, i32, C.POINTER(C.c_size_t)]
     L.psh_merge_topk.restype = i32
@@ -203,6 +210,63 @@ def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, 
             out_d.data_ptr(), out_idx.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(),
             C.byref(prof) if prof is not None else None)
     _check(rc, "psh_scan_topk_exhaustive" if exhaustive else "psh_scan_topk")
+    if profile:
+        return out_d, out_idx, status, prof.as_dict()
+    return out_d, out_idx, status
+
+
+PSH_EMB_MAX_D, PSH_EMB_MAX_TAPS = 128, 8192
+
+
+def embedding_supported(d: int, K: int) -> bool:
+    """Whether psh_scan_topk_embedded takes a (d, K) kernel (it lives in LDS)."""
+    return 0 < d <= PSH_EMB_MAX_D and 0 < K <= PSH_MAX_W and d * ((K + 3) // 4 * 4) <= PSH_EMB_MAX_TAPS
+
+
+def scan_topk_embedded(dataset: torch.Tensor, kernel: torch.Tensor, hx: torch.Tensor, k: int, h: int = 0,
+                       r_offset: int = 0, hxnorm: torch.Tensor | None = None, workspace: Workspace | None = None,
+                       exhaustive: bool = False, profile: bool = False, out: tuple | None = None):
+    """The scan behind a linear embedding: kernel (d, K) float32 device (unpadded), hx (B, d)
+    embedded queries.  Same returns and conventions as scan_topk."""
+    ds = _dev_tensor(dataset, torch.float32, "dataset")
+    ker = _dev_tensor(kernel, torch.float32, "kernel")
+    q = _dev_tensor(hx, torch.float32, "hx")
+    if ds.dim() != 2 or ker.dim() != 2 or q.dim() != 2 or q.shape[1] != ker.shape[0]:
+        raise ValueError("dataset must be (R, T), kernel (d, K) and hx (B, d)")
+    if q.device != ds.device or ker.device != ds.device:
+        raise ValueError("dataset, kernel and hx must live on the same device")
+    R, T = ds.shape
+    d, K = ker.shape
+    B = q.shape[0]
+    dev = ds.device
+    if hxnorm is not None:
+        hxnorm = _dev_tensor(hxnorm, torch.float32, "hxnorm")
+    if B > PSH_MAX_B_PER_LAUNCH and not profile:
+        parts = [scan_topk_embedded(ds, ker, q[i:i + PSH_MAX_B_PER_LAUNCH].contiguous(), k, h=h, r_offset=r_offset,
+                                    hxnorm=None if hxnorm is None else hxnorm[i:i + PSH_MAX_B_PER_LAUNCH].contiguous(),
+                                    workspace=workspace, exhaustive=exhaustive)
+                 for i in range(0, B, PSH_MAX_B_PER_LAUNCH)]
+        return tuple(torch.cat([p[j] for p in parts], dim=0) for j in range(3))
+    ws = (workspace or Workspace(dev)).get(workspace_bytes(R, T, B, K, h, k))
+    if out is not None:
+        out_d = _dev_tensor(out[0], torch.float32, "out[0]")
+        out_idx = _dev_tensor(out[1], torch.int32, "out[1]")
+        if tuple(out_d.shape) != (B, k) or tuple(out_idx.shape) != (B, k, 2):
+            raise ValueError("out must be ((B,k) float32, (B,k,2) int32)")
+    else:
+        out_d = torch.empty((B, k), dtype=torch.float32, device=dev)
+        out_idx = torch.empty((B, k, 2), dtype=torch.int32, device=dev)
+    status = torch.empty((B,), dtype=torch.int32, device=dev)
+    prof = None
+    if profile:
+        prof = PshProfile()
+        prof.mode = 0
+    name = "psh_scan_topk_embedded_exhaustive" if exhaustive else "psh_scan_topk_embedded"
+    rc = getattr(load(), name)(dev.index, _stream_ptr(dev), ds.data_ptr(), R, T, r_offset, ker.data_ptr(), d, K,
+                               q.data_ptr(), None if hxnorm is None else hxnorm.data_ptr(), B, h, k,
+                               out_d.data_ptr(), out_idx.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(),
+                               C.byref(prof) if prof is not None else None)
+    _check(rc, name)
     if profile:
         return out_d, out_idx, status, prof.as_dict()
     return out_d, out_idx, status

@@ -129,11 +129,17 @@ struct Problem {
     int64_t R, T, r_offset, Tp, N;
     int B, W, h, k;
     bool aligned;
+    const float* ker;     // embedded scan: emb_d x W kernel matrix (device), else nullptr
+    int emb_d;
+    int qlen;             // floats per query vector handed over: W, or emb_d (pre-embedded queries)
 };
 
 int check_problem(const float* dataset, int64_t R, int64_t T, int64_t r_offset, const float* queries,
-                  int B, int W, int h, int k, float* out_d, int32_t* out_idx, Problem* p) {
+                  int B, int W, int h, int k, float* out_d, int32_t* out_idx, Problem* p,
+                  const float* ker = nullptr, int emb_d = 0) {
     if (!dataset || !queries || !out_d || !out_idx) return PSH_ERR_ARG;
+    if (emb_d < 0 || (emb_d > 0 && !ker)) return PSH_ERR_ARG;
+    if (emb_d > PSH_EMB_MAX_D || (int64_t)emb_d * ((W + 3) & ~3) > PSH_EMB_MAX_TAPS) return PSH_ERR_UNSUPPORTED;
     if (R <= 0 || T <= 0 || B <= 0 || W <= 0 || h < 0 || k <= 0 || r_offset < 0) return PSH_ERR_ARG;
     if (W > PSH_MAX_W || k > PSH_MAX_K || B > PSH_MAX_B_PER_LAUNCH) return PSH_ERR_UNSUPPORTED;
     const int64_t Tp = T - W - h + 1;
@@ -144,6 +150,9 @@ int check_problem(const float* dataset, int64_t R, int64_t T, int64_t r_offset, 
     p->R = R; p->T = T; p->r_offset = r_offset; p->Tp = Tp; p->N = N;
     p->B = B; p->W = W; p->h = h; p->k = k;
     p->aligned = (((uintptr_t)dataset & 15u) == 0) && (T % 4 == 0);
+    p->ker = emb_d > 0 ? ker : nullptr;
+    p->emb_d = emb_d;
+    p->qlen = emb_d > 0 ? emb_d : W;
     return PSH_OK;
 }
 
@@ -151,9 +160,10 @@ struct Plan { int grid; int n_qgroups; int q_per_group; int tile_floats; };
 
 int plan_scan(int device, const Problem& p, int64_t n_rows, Plan* plan) {
     const int tile_floats = tile_floats_for(p.W);
-    const size_t shmem = scan_shmem_bytes(tile_floats, p.B);
+    const size_t shmem = scan_shmem_bytes(tile_floats, p.B, p.emb_d, p.W);
+    if (shmem > 160 * 1024) return PSH_ERR_UNSUPPORTED;
     int bpc = 0, ncu = 0;
-    HIP_TRY(scan_blocks_per_cu(p.W, p.aligned, shmem, &bpc));
+    HIP_TRY(scan_blocks_per_cu(p.W, p.aligned, p.ker != nullptr, shmem, &bpc));
     HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
     if (const char* e = getenv("PSH_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) bpc = v; }   // tuning aid
     if (bpc < 1) bpc = 1;
@@ -211,6 +221,9 @@ ScanArgs make_scan_args(const float* dataset, const float* queries, const Proble
     }
     a.r_offset = p.r_offset;
     a.queries = queries;
+    a.ker = p.ker;
+    a.hx = p.ker ? queries : nullptr;
+    a.emb_d = p.emb_d;
     a.B = p.B;
     a.n_qgroups = plan.n_qgroups;
     a.q_per_group = plan.q_per_group;
@@ -301,7 +314,7 @@ int run_exhaustive(int device, hipStream_t s, const float* dataset, const float*
     Timer tm(stages, s);
     int rc = tm.init(); if (rc) return rc;
     rc = tm.mark(); if (rc) return rc;
-    PrepArgs pa{queries, qnorm, p.B, p.W, w.qstate, w.total, out_status};
+    PrepArgs pa{queries, qnorm, p.B, p.qlen, w.qstate, w.total, out_status};
     HIP_TRY(launch_prep(pa, s));
     rc = tm.mark(); if (rc) return rc;
     if (events) HIP_TRY(hipEventRecord((hipEvent_t)prof->ev_scan_begin, s));
@@ -373,12 +386,13 @@ int psh_query_norm(int device, void* stream, const float* queries, int B, int W,
     return PSH_OK;
 }
 
-int psh_scan_topk_exhaustive(int device, void* stream, const float* dataset, int64_t R, int64_t T, int64_t r_offset,
-                             const float* queries, const float* qnorm, int B, int W, int h, int k,
-                             float* out_d, int32_t* out_idx, int32_t* out_status,
-                             void* workspace, size_t workspace_bytes, psh_profile* profile) {
+static int scan_exhaustive_impl(int device, void* stream, const float* dataset, int64_t R, int64_t T, int64_t r_offset,
+                                const float* queries, const float* qnorm, int B, int W, int h, int k,
+                                const float* ker, int emb_d,
+                                float* out_d, int32_t* out_idx, int32_t* out_status,
+                                void* workspace, size_t workspace_bytes, psh_profile* profile) {
     Problem p;
-    int rc = check_problem(dataset, R, T, r_offset, queries, B, W, h, k, out_d, out_idx, &p);
+    int rc = check_problem(dataset, R, T, r_offset, queries, B, W, h, k, out_d, out_idx, &p, ker, emb_d);
     if (rc) return rc;
     Workspace w;
     rc = carve(workspace, workspace_bytes, B, k, boot_entries(p.R, p.Tp, k), &w);
@@ -388,12 +402,31 @@ int psh_scan_topk_exhaustive(int device, void* stream, const float* dataset, int
     return run_exhaustive(device, (hipStream_t)stream, dataset, queries, qnorm, p, w, out_d, out_idx, out_status, profile);
 }
 
-int psh_scan_topk(int device, void* stream, const float* dataset, int64_t R, int64_t T, int64_t r_offset,
-                  const float* queries, const float* qnorm, int B, int W, int h, int k,
-                  float* out_d, int32_t* out_idx, int32_t* out_status,
-                  void* workspace, size_t workspace_bytes, psh_profile* profile) {
+int psh_scan_topk_exhaustive(int device, void* stream, const float* dataset, int64_t R, int64_t T, int64_t r_offset,
+                             const float* queries, const float* qnorm, int B, int W, int h, int k,
+                             float* out_d, int32_t* out_idx, int32_t* out_status,
+                             void* workspace, size_t workspace_bytes, psh_profile* profile) {
+    return scan_exhaustive_impl(device, stream, dataset, R, T, r_offset, queries, qnorm, B, W, h, k, nullptr, 0,
+                                out_d, out_idx, out_status, workspace, workspace_bytes, profile);
+}
+
+int psh_scan_topk_embedded_exhaustive(int device, void* stream, const float* dataset, int64_t R, int64_t T,
+                                      int64_t r_offset, const float* kernel, int d, int K,
+                                      const float* hx, const float* hxnorm, int B, int h, int k,
+                                      float* out_d, int32_t* out_idx, int32_t* out_status,
+                                      void* workspace, size_t workspace_bytes, psh_profile* profile) {
+    if (!kernel || d <= 0) return PSH_ERR_ARG;
+    return scan_exhaustive_impl(device, stream, dataset, R, T, r_offset, hx, hxnorm, B, K, h, k, kernel, d,
+                                out_d, out_idx, out_status, workspace, workspace_bytes, profile);
+}
+
+static int scan_topk_impl(int device, void* stream, const float* dataset, int64_t R, int64_t T, int64_t r_offset,
+                          const float* queries, const float* qnorm, int B, int W, int h, int k,
+                          const float* ker, int emb_d,
+                          float* out_d, int32_t* out_idx, int32_t* out_status,
+                          void* workspace, size_t workspace_bytes, psh_profile* profile) {
     Problem p;
-    int rc = check_problem(dataset, R, T, r_offset, queries, B, W, h, k, out_d, out_idx, &p);
+    int rc = check_problem(dataset, R, T, r_offset, queries, B, W, h, k, out_d, out_idx, &p, ker, emb_d);
     if (rc) return rc;
     if (!out_status) return PSH_ERR_ARG;
     Workspace w;
@@ -419,7 +452,7 @@ int psh_scan_topk(int device, void* stream, const float* dataset, int64_t R, int
     Timer tm(stages, s);
     rc = tm.init(); if (rc) return rc;
     rc = tm.mark(); if (rc) return rc;                                       // 0
-    PrepArgs pa{queries, qnorm, B, W, w.qstate, w.total, out_status};       // runs inside the threshold kernel
+    PrepArgs pa{queries, qnorm, B, p.qlen, w.qstate, w.total, out_status};  // runs inside the threshold kernel
     rc = tm.mark(); if (rc) return rc;                                       // 1
 
     Plan plan_s;
@@ -463,6 +496,23 @@ int psh_scan_topk(int device, void* stream, const float* dataset, int64_t R, int
         rc = max_total(w, B, &profile->n_candidates); if (rc) return rc;
     }
     return PSH_OK;
+}
+
+int psh_scan_topk(int device, void* stream, const float* dataset, int64_t R, int64_t T, int64_t r_offset,
+                  const float* queries, const float* qnorm, int B, int W, int h, int k,
+                  float* out_d, int32_t* out_idx, int32_t* out_status,
+                  void* workspace, size_t workspace_bytes, psh_profile* profile) {
+    return scan_topk_impl(device, stream, dataset, R, T, r_offset, queries, qnorm, B, W, h, k, nullptr, 0,
+                          out_d, out_idx, out_status, workspace, workspace_bytes, profile);
+}
+
+int psh_scan_topk_embedded(int device, void* stream, const float* dataset, int64_t R, int64_t T, int64_t r_offset,
+                           const float* kernel, int d, int K, const float* hx, const float* hxnorm, int B, int h, int k,
+                           float* out_d, int32_t* out_idx, int32_t* out_status,
+                           void* workspace, size_t workspace_bytes, psh_profile* profile) {
+    if (!kernel || d <= 0) return PSH_ERR_ARG;
+    return scan_topk_impl(device, stream, dataset, R, T, r_offset, hx, hxnorm, B, K, h, k, kernel, d,
+                          out_d, out_idx, out_status, workspace, workspace_bytes, profile);
 }
 
 int psh_merge_workspace_bytes(int B, int k, size_t* out_bytes) {

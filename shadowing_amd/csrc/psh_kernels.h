@@ -66,7 +66,15 @@ struct ScanArgs {
     int slice;               // entries per block slice (FILTER)
     int cap;
     unsigned long long* dbg_times;   // tuning aid (nullable): per wave {start, end} wall-clock ticks (100 MHz)
+    // embedded scan (ker != nullptr): windows of W = K samples are compared through a linear
+    // embedding  h(y)_i = sum_j ker[i][j] * y[t + j]  against pre-embedded queries hx (B x emb_d)
+    const float* ker;        // emb_d x W row-major
+    const float* hx;         // B x emb_d
+    int emb_d;
 };
+
+#define PSH_EMB_MAX_D 128            // embedding rows handled natively
+#define PSH_EMB_MAX_TAPS 8192        // emb_d * roundup4(K) floats of LDS for the kernel matrix
 
 struct ThresholdArgs {
     const float* minbuf;
@@ -123,8 +131,8 @@ struct GatherArgs {
 hipError_t launch_prep(const PrepArgs& a, hipStream_t s);
 hipError_t launch_qnorm(const float* q, int B, int W, float* out, hipStream_t s);
 hipError_t launch_scan(const ScanArgs& a, int mode, bool aligned, int grid, hipStream_t s);
-size_t scan_shmem_bytes(int tile_floats, int B);
-hipError_t scan_blocks_per_cu(int W, bool aligned, size_t shmem, int* out);
+size_t scan_shmem_bytes(int tile_floats, int B, int emb_d, int W);
+hipError_t scan_blocks_per_cu(int W, bool aligned, bool embedded, size_t shmem, int* out);
 hipError_t launch_threshold(const ThresholdArgs& a, int B, hipStream_t s);
 hipError_t launch_select(const SelectArgs& a, int B, hipStream_t s);
 hipError_t launch_reseed(const ReseedArgs& a, int B, hipStream_t s);

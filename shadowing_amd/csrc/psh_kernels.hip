@@ -642,6 +642,241 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
 }
 
 // ----------------------------------------------------------------------------------
+// the embedded scan: a general linear embedding (Foveal, user kernels) in front of the
+// distance -- reference path_embedding.py:117-132 (conv1d with a (d,1,K) kernel) feeding
+// path_distance.py:62-65, i.e. for every window t of every row
+//     hy_i = sum_j ker[i][j] * y[t + j]      (fma chain, increasing j)
+//     acc  = sum_i (hx_i - hy_i)^2           (D = hx_i - hy_i rounded, fma chain, increasing i)
+//     d    = sqrt(acc) / ||hx||
+// The reference evaluates these sums in library-chosen orders (MKL-DNN / MIOpen conv1d,
+// vectorised norm), so parity with it is a tolerance (1e-5 relative), not bit equality;
+// the order above is the oracle's (oracle/psh_oracle.c: psh_oracle_scan_topk_embedded) and
+// the kernel reproduces THAT bit for bit.
+//
+// Same skeleton as scan_kernel (one 16-wave block per CU, LDS work queue, wave-private
+// padded tile, per-block candidate slices), but VALU-bound by a wide margin (d*K fma per
+// window against 4 bytes), so segments are loaded synchronously and the registers go to
+// the accumulators of PSH_EMB_BG queries that share one evaluation of the embedding.
+// ----------------------------------------------------------------------------------
+#define PSH_EMB_BG 3
+
+__device__ __forceinline__ void corr16(float tap, const float (&win)[PSH_L], int jj, float (&c)[PSH_L]) {
+    corr8(tap, win[(0 + jj) & 15], win[(1 + jj) & 15], win[(2 + jj) & 15], win[(3 + jj) & 15],
+          win[(4 + jj) & 15], win[(5 + jj) & 15], win[(6 + jj) & 15], win[(7 + jj) & 15],
+          c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
+    corr8(tap, win[(8 + jj) & 15], win[(9 + jj) & 15], win[(10 + jj) & 15], win[(11 + jj) & 15],
+          win[(12 + jj) & 15], win[(13 + jj) & 15], win[(14 + jj) & 15], win[(15 + jj) & 15],
+          c[8], c[9], c[10], c[11], c[12], c[13], c[14], c[15]);
+}
+
+// c_w = sum_{j < n} taps[j] * tile[base + w + j] for the 16 windows w of a lane.  taps: LDS,
+// 16-byte aligned, readable (zero padded) up to the next multiple of 4 past n; base % 4 == 0.
+// Every tile slot this reads was written by stage_store or by the zero fill at kernel
+// start, so a zero tap never meets a non-finite stale value.
+__device__ __forceinline__ void correlate16(const float* tile, int base, const float* taps, int n,
+                                            float (&c)[PSH_L]) {
+    float win[PSH_L];
+#pragma unroll
+    for (int q = 0; q < PSH_L / 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(tile + lds_pad(base + 4 * q));
+        win[4 * q + 0] = v[0]; win[4 * q + 1] = v[1]; win[4 * q + 2] = v[2]; win[4 * q + 3] = v[3];
+    }
+#pragma unroll
+    for (int i = 0; i < PSH_L; ++i) c[i] = 0.0f;
+#pragma unroll 1
+    for (int jb = 0; jb < n; jb += PSH_L) {
+        const int rem = n - jb;                              // wave-uniform
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (4 * g < rem) {
+                const f32x4 nx = *reinterpret_cast<const f32x4*>(tile + lds_pad(base + jb + PSH_L + 4 * g));
+                const f32x4 tp = *reinterpret_cast<const f32x4*>(taps + jb + 4 * g);   // broadcast read
+                const float nv[4] = {nx[0], nx[1], nx[2], nx[3]};
+                const float tv[4] = {tp[0], tp[1], tp[2], tp[3]};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int jj = 4 * g + q;
+                    corr16(tv[q], win, jj, c);
+                    win[jj] = nv[q];
+                }
+            }
+        }
+    }
+}
+
+// what one query keeps of the 16 accumulators of a lane (the three modes of scan_kernel)
+template <int MODE>
+__device__ __forceinline__ void emit16(const ScanArgs& a, int b, const float (&acc)[PSH_L], int nvalid, int lane,
+                                       unsigned rs, int r_global, int t_lane, float tau, float xn,
+                                       u32x4* pend, int& npend, int* lcount) {
+    if (MODE == PSH_MODE_BOOT) {
+        float m = __uint_as_float(PSH_INF_BITS);
+#pragma unroll
+        for (int i = 0; i < PSH_L; ++i) m = (i < nvalid) ? fminf(m, acc[i]) : m;
+        if (a.boot_per_wave) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+            if (lane == 0) a.minbuf[(int64_t)b * a.min_stride + (int64_t)rs] = m;
+        } else {
+            a.minbuf[(int64_t)b * a.min_stride + (int64_t)rs * 64 + lane] = m;
+        }
+    } else if (MODE == PSH_MODE_ALL) {
+        const int64_t base = (int64_t)b * a.cap + (int64_t)rs * PSH_SEG + PSH_L * lane;
+#pragma unroll
+        for (int i = 0; i < PSH_L; ++i) {
+            const bool ok = i < nvalid;
+            a.cand_d[base + i] = ok ? dist_from_acc(acc[i], xn) : __uint_as_float(PSH_INF_BITS);
+            a.cand_rt[base + i] = ok ? make_int2(r_global, t_lane + i) : make_int2(-1, -1);
+        }
+    } else {
+        if (!__any(min16(acc) < tau)) return;
+        unsigned hm = 0u;
+#pragma unroll
+        for (int i = 0; i < PSH_L; ++i) hm |= ((i < nvalid) && (acc[i] < tau)) ? (1u << i) : 0u;
+#pragma unroll 1
+        for (int i = 0; i < PSH_L; ++i) {
+            const bool hit = ((hm >> i) & 1u) != 0u;
+            const unsigned long long mask = __ballot(hit);
+            if (!mask) continue;
+            float v = acc[0];
+#pragma unroll
+            for (int j = 1; j < PSH_L; ++j) v = (i == j) ? acc[j] : v;   // i is wave-uniform
+            const int nh = __popcll(mask);
+            if (npend + nh > PSH_PEND) {
+                pend_flush(pend, npend, lcount, a, lane);
+                npend = 0;
+                wave_lds_fence();                            // the flush has read pend before it is refilled
+            }
+            if (hit) {
+                const int slot = npend + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                             __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                pend[slot] = u32x4{__float_as_uint(v), (unsigned)r_global, (unsigned)(t_lane + i), (unsigned)b};
+            }
+            npend += nh;
+        }
+    }
+}
+
+template <bool ALIGNED, int MODE>
+__global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = lane_id();
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr int NW = PSH_SCAN_THREADS / 64;
+    float* tile = smem + (size_t)wave_in_block * a.tile_floats;
+    int* lcount = reinterpret_cast<int*>(smem + (size_t)NW * a.tile_floats);
+    int* next_unit = lcount + ((a.B + 3) & ~3);
+    u32x4* pend0 = reinterpret_cast<u32x4*>(lcount + ((a.B + 3) & ~3) + 4);
+    u32x4* pend = pend0 + (size_t)wave_in_block * PSH_PEND;
+    const int K = a.W, Kp = (K + 3) & ~3, d = a.emb_d;
+    float* kerL = reinterpret_cast<float*>(pend0 + (size_t)NW * PSH_PEND);   // d x Kp, rows zero padded
+    int2* rng = reinterpret_cast<int2*>(kerL + (size_t)d * Kp);              // per row: {first tap & ~3, taps to visit}
+    int npend = 0;
+
+    if (threadIdx.x == 0) *next_unit = 0;
+    if (MODE == PSH_MODE_FILTER)
+        for (int q = (int)threadIdx.x; q < a.B; q += PSH_SCAN_THREADS) lcount[q] = 0;
+    for (int e = (int)threadIdx.x; e < d * Kp; e += PSH_SCAN_THREADS) {
+        const int i = e / Kp, j = e - i * Kp;
+        kerL[e] = j < K ? a.ker[(int64_t)i * K + j] : 0.0f;
+    }
+    for (int p = lane; p < a.tile_floats; p += 64) tile[p] = 0.0f;   // no slot is ever read uninitialised
+    __syncthreads();
+    if ((int)threadIdx.x < d) {
+        const float* row = kerL + (size_t)threadIdx.x * Kp;
+        int lo = K, hi = 0;
+        for (int j = 0; j < K; ++j)
+            if (row[j] != 0.0f) { lo = j < lo ? j : lo; hi = j + 1; }
+        if (hi == 0) lo = 0;
+        lo &= ~3;
+        rng[threadIdx.x] = make_int2(lo, hi - lo);
+    }
+    __syncthreads();
+
+    const int nfloat = PSH_SEG + K - 1;
+    const unsigned n_rs = (unsigned)a.n_rows * (unsigned)a.nseg;
+    const unsigned n_units = n_rs * (unsigned)a.n_qgroups;
+    const unsigned u_lo = (unsigned)(((unsigned long long)n_units * blockIdx.x) / gridDim.x);
+    const unsigned u_hi = (unsigned)(((unsigned long long)n_units * (blockIdx.x + 1)) / gridDim.x);
+    const const_f32p hxk = (const_f32p)a.hx;
+    typedef const __attribute__((address_space(4))) QueryState* const_qsp;
+    const const_qsp qstate_k = (const_qsp)a.qstate;
+
+    for (;;) {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(next_unit, 1);
+        const unsigned u = u_lo + (unsigned)__builtin_amdgcn_readfirstlane(v);
+        if (u >= u_hi) break;
+        const unsigned qgi = fast_div(u, a.magic_nrs, n_rs);
+        const unsigned rs = u - qgi * n_rs;
+        const unsigned ri = fast_div(rs, a.magic_nseg, (unsigned)a.nseg);
+        const unsigned sg = rs - ri * (unsigned)a.nseg;
+        const int64_t row = a.row0 + (int64_t)ri * a.row_stride;
+        const int seg_start = (int)sg * PSH_SEG;
+
+        if (MODE == PSH_MODE_FILTER && npend > 0) {   // stores ahead of the loads: vmcnt retires in order
+            pend_flush(pend, npend, lcount, a, lane);
+            npend = 0;
+        }
+        {
+            Stage st;
+            stage_load<ALIGNED>(st, a.dataset + row * a.T, a.T, seg_start, nfloat, lane);
+            stage_store(st, tile, nfloat, lane);
+        }
+        wave_lds_fence();
+
+        const int t_lane = seg_start + PSH_L * lane;
+        int nvalid = a.Tp - t_lane;
+        nvalid = nvalid < 0 ? 0 : (nvalid > PSH_L ? PSH_L : nvalid);
+        const int r_global = (int)(row + a.r_offset);
+        const int q_begin = (int)qgi * a.q_per_group;
+        const int q_end = (q_begin + a.q_per_group) < a.B ? (q_begin + a.q_per_group) : a.B;
+
+        for (int b0 = q_begin; b0 < q_end; b0 += PSH_EMB_BG) {
+            float acc[PSH_EMB_BG][PSH_L];
+#pragma unroll
+            for (int g = 0; g < PSH_EMB_BG; ++g)
+#pragma unroll
+                for (int w = 0; w < PSH_L; ++w) acc[g][w] = 0.0f;
+#pragma unroll 1
+            for (int i = 0; i < d; ++i) {
+                const int2 rg = rng[i];
+                const int jlo = __builtin_amdgcn_readfirstlane(rg.x);
+                const int n = __builtin_amdgcn_readfirstlane(rg.y);
+                float c[PSH_L];
+                correlate16(tile, PSH_L * lane + jlo, kerL + (size_t)i * Kp + jlo, n, c);
+#pragma unroll
+                for (int g = 0; g < PSH_EMB_BG; ++g) {
+                    const int b = (b0 + g) < q_end ? (b0 + g) : (q_end - 1);
+                    const float hxv = hxk[(int64_t)b * d + i];
+#pragma unroll
+                    for (int w = 0; w < PSH_L; ++w) {
+                        const float D = __fsub_rn(hxv, c[w]);
+                        acc[g][w] = __builtin_fmaf(D, D, acc[g][w]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < PSH_EMB_BG; ++g) {
+                const int b = b0 + g;
+                if (b < q_end) {
+                    const float tau = (MODE == PSH_MODE_FILTER) ? __uint_as_float(qstate_k[b].tau_bits) : 0.0f;
+                    const float xn = (MODE == PSH_MODE_ALL) ? qstate_k[b].xn : 0.0f;
+                    emit16<MODE>(a, b, acc[g], nvalid, lane, rs, r_global, t_lane, tau, xn, pend, npend, lcount);
+                }
+            }
+        }
+        wave_lds_fence();  // all lanes done with the tile before it is overwritten
+    }
+    if (MODE == PSH_MODE_FILTER) {
+        if (npend > 0) pend_flush(pend, npend, lcount, a, lane);
+        __syncthreads();
+        for (int q = (int)threadIdx.x; q < a.B; q += PSH_SCAN_THREADS)
+            a.bcount[(int64_t)q * PSH_MAX_BLOCKS + blockIdx.x] = lcount[q];
+    }
+}
+
+// ----------------------------------------------------------------------------------
 // one-block selection machinery (threshold of the bootstrap sample, final top-k, merge)
 // ----------------------------------------------------------------------------------
 #define PSH_RB 11                          // radix-select digit width: 2048 counters per pass
@@ -1206,14 +1441,37 @@ static hipError_t launch_scan_mode(const ScanArgs& a, int mode, int grid, size_t
     return hipGetLastError();
 }
 
-size_t scan_shmem_bytes(int tile_floats, int B) {
-    return (size_t)tile_floats * (PSH_SCAN_THREADS / 64) * sizeof(float)      // wave-private tiles
-           + (size_t)(((B + 3) & ~3) + 4) * sizeof(int)                         // per-query append cursors + work cursor
-           + (size_t)(PSH_SCAN_THREADS / 64) * PSH_PEND * 16;                   // wave-private pending admissions
+size_t scan_shmem_bytes(int tile_floats, int B, int emb_d, int W) {
+    size_t n = (size_t)tile_floats * (PSH_SCAN_THREADS / 64) * sizeof(float)      // wave-private tiles
+               + (size_t)(((B + 3) & ~3) + 4) * sizeof(int)                         // per-query append cursors + work cursor
+               + (size_t)(PSH_SCAN_THREADS / 64) * PSH_PEND * 16;                   // wave-private pending admissions
+    if (emb_d > 0) n += (size_t)emb_d * ((W + 3) & ~3) * sizeof(float) + (size_t)emb_d * sizeof(int2);   // kernel matrix, tap spans
+    return n;
+}
+
+template <bool ALIGNED, int MODE>
+static hipError_t launch_embed_mode(const ScanArgs& a, int grid, size_t shmem, hipStream_t s) {
+    if (shmem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)embed_scan_kernel<ALIGNED, MODE>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((embed_scan_kernel<ALIGNED, MODE>), dim3(grid), dim3(PSH_SCAN_THREADS), shmem, s, a);
+    return hipGetLastError();
+}
+
+template <bool ALIGNED>
+static hipError_t launch_embed(const ScanArgs& a, int mode, int grid, size_t shmem, hipStream_t s) {
+    switch (mode) {
+        case PSH_MODE_BOOT: return launch_embed_mode<ALIGNED, PSH_MODE_BOOT>(a, grid, shmem, s);
+        case PSH_MODE_FILTER: return launch_embed_mode<ALIGNED, PSH_MODE_FILTER>(a, grid, shmem, s);
+        default: return launch_embed_mode<ALIGNED, PSH_MODE_ALL>(a, grid, shmem, s);
+    }
 }
 
 hipError_t launch_scan(const ScanArgs& a, int mode, bool aligned, int grid, hipStream_t s) {
-    const size_t shmem = scan_shmem_bytes(a.tile_floats, a.B);
+    const size_t shmem = scan_shmem_bytes(a.tile_floats, a.B, a.ker ? a.emb_d : 0, a.W);
+    if (a.ker) return aligned ? launch_embed<true>(a, mode, grid, shmem, s) : launch_embed<false>(a, mode, grid, shmem, s);
     if (a.W == 20) {
         return aligned ? launch_scan_mode<20, true>(a, mode, grid, shmem, s)
                        : launch_scan_mode<20, false>(a, mode, grid, shmem, s);
@@ -1222,10 +1480,13 @@ hipError_t launch_scan(const ScanArgs& a, int mode, bool aligned, int grid, hipS
                    : launch_scan_mode<0, false>(a, mode, grid, shmem, s);
 }
 
-hipError_t scan_blocks_per_cu(int W, bool aligned, size_t shmem, int* out) {
+hipError_t scan_blocks_per_cu(int W, bool aligned, bool embedded, size_t shmem, int* out) {
     int n = 0;
     hipError_t e;
-    if (W == 20) {
+    if (embedded) {
+        e = aligned ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, embed_scan_kernel<true, PSH_MODE_FILTER>, PSH_SCAN_THREADS, shmem)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, embed_scan_kernel<false, PSH_MODE_FILTER>, PSH_SCAN_THREADS, shmem);
+    } else if (W == 20) {
         e = aligned ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, scan_kernel<20, true, PSH_MODE_FILTER>, PSH_SCAN_THREADS, shmem)
                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, scan_kernel<20, false, PSH_MODE_FILTER>, PSH_SCAN_THREADS, shmem);
     } else {

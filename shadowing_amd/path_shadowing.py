@@ -10,9 +10,12 @@ inside `batched_distance(..., cuda=True)` is new:
     trajectory ensemble RESIDENT in HBM (uploaded once per dataset, not once per
     split per call as path_shadowing.py:154-155 does), exact fp32 distances in
     the reference CPU path's arithmetic order, rows ordered by (d, r, t).
-  * any other plugin combination (Foveal, user subclasses, other contexts,
-    several channels) -> a generic torch path with the reference's semantics, on
-    the HIP device when cuda=True.
+  * any other linear embedding whose forward is the stock conv1d (Foveal,
+    PathEmbedding(kernel)) + RelativeMSE + PredictionContext -> psh_scan_topk_embedded:
+    embedding, distance, filter and top-k fused in one pass over the resident ensemble.
+  * any other plugin combination (user subclasses overriding forward, other
+    contexts, several channels) -> a generic torch path with the reference's
+    semantics, on the HIP device when cuda=True.
 
 `cuda=True` never falls back to the CPU: if the HIP library is missing or no
 device is present it raises.  `cuda=False` is the reference's own meaning: run
@@ -104,15 +107,31 @@ class PathShadowing:
         return dataset
 
     # ------------------------------------------------------------------ native path
+    def _native_kind(self, x: torch.Tensor, y: torch.Tensor, k: int) -> str | None:
+        """Which HIP path implements this configuration, if any (types compared with
+        `is`, so user subclasses keep their own behaviour on the generic path):
+          "identity": Identity + RelativeMSE + PredictionContext -- windows read in place;
+          "linear"  : any other PathEmbedding whose forward is the stock conv1d (Foveal,
+                      PathEmbedding(kernel)) + RelativeMSE + PredictionContext, one-window
+                      queries, kernel small enough for LDS -- psh_scan_topk_embedded."""
+        if not (type(self.distance) is RelativeMSE and type(self.context) is PredictionContext
+                and x.shape[1] == 1 and y.ndim == 3 and y.shape[1] == 1
+                and x.dtype == torch.float32 and y.dtype == torch.float32 and k <= _native.PSH_MAX_K):
+            return None
+        emb = self.embedding
+        if type(emb) is Identity:
+            ok = x.shape[-1] == emb.kernel.shape[0] and x.shape[-1] <= _native.PSH_MAX_W
+            return "identity" if ok else None
+        if (isinstance(emb, PathEmbedding) and type(emb).forward is PathEmbedding.forward
+                and type(emb).adjust_to_context is PathEmbedding.adjust_to_context
+                and emb.kernel.ndim == 3 and emb.kernel.shape[1] == 1 and emb.kernel.dtype == torch.float32
+                and emb.kernel.shape[-1] == x.shape[-1]
+                and _native.embedding_supported(emb.kernel.shape[0], emb.kernel.shape[-1])):
+            return "linear"
+        return None
+
     def _native_ok(self, x: torch.Tensor, y: torch.Tensor, k: int) -> bool:
-        """Exactly the configuration the HIP kernels implement (types compared with
-        `is`, so user subclasses keep their own behaviour on the generic path)."""
-        return (type(self.embedding) is Identity and type(self.distance) is RelativeMSE
-                and type(self.context) is PredictionContext
-                and x.shape[1] == 1 and y.shape[1] == 1 and y.ndim == 3
-                and x.shape[-1] == self.embedding.kernel.shape[0]
-                and x.dtype == torch.float32 and y.dtype == torch.float32
-                and x.shape[-1] <= _native.PSH_MAX_W and k <= _native.PSH_MAX_K)
+        return self._native_kind(x, y, k) is not None
 
     @staticmethod
     def _hip_device() -> torch.device:
@@ -136,20 +155,35 @@ class PathShadowing:
         dev = self._hip_device()
         _native.load()
         ds = self._resident_dataset(y, dev)
-        q = x[:, 0, :].contiguous().to(dev)
         h = self.context.get_out_times()
         if self._workspace is None or self._workspace.device != dev:
             self._workspace = _native.Workspace(dev)
-        n_windows = ds.shape[0] * (ds.shape[-1] - q.shape[-1] - h + 1)
+        n_windows = ds.shape[0] * (ds.shape[-1] - x.shape[-1] - h + 1)
         if k > n_windows:
             # the reference fails inside torch.topk (ref :165) with the same exception type
             raise RuntimeError("selected index k out of range")
-        d, idx, status = _native.scan_topk(ds[:, 0, :], q, k, h=h, workspace=self._workspace)
+        if self._native_kind(x, y, k) == "linear":
+            # the (tiny) query embedding stays the module's own conv1d (ref :140); the scan
+            # over the ensemble takes the unpadded kernel and the horizon as an integer
+            ker = self.embedding.kernel
+            hx = self.embedding(x.to(ker.device))[:, 0, :].contiguous().to(dev)
+            ker2 = ker[:, 0, :].contiguous().to(dev)
+
+            def scan(sel, exhaustive):
+                q = hx if sel is None else hx[sel].contiguous()
+                return _native.scan_topk_embedded(ds[:, 0, :], ker2, q, k, h=h, workspace=self._workspace,
+                                                  exhaustive=exhaustive)
+        else:
+            xq = x[:, 0, :].contiguous().to(dev)
+
+            def scan(sel, exhaustive):
+                q = xq if sel is None else xq[sel].contiguous()
+                return _native.scan_topk(ds[:, 0, :], q, k, h=h, workspace=self._workspace, exhaustive=exhaustive)
+        d, idx, status = scan(None, False)
         bad = torch.nonzero(status != _native.PSH_STATUS_OK).flatten()
         if bad.numel():
             # candidate buffer overflowed (massive ties / adversarial data): exact slow path
-            d2, idx2, _ = _native.scan_topk(ds[:, 0, :], q[bad].contiguous(), k, h=h,
-                                            workspace=self._workspace, exhaustive=True)
+            d2, idx2, _ = scan(bad, True)
             d[bad] = d2
             idx[bad] = idx2
         return d, idx, ds

@@ -14,12 +14,16 @@ SMALL_GOLDENS = ["cfg1_h20", "cfg1_hNone", "multiquery_splits", "remainder_split
                  "W7_h0", "duplicated_paths", "zero_query", "self_match", "single_window_rows",
                  "k1_2d_dataset"]
 BIG_GOLDENS = ["cfg2_R32768", "cfg3_rolling_R2048"]
+# linear embeddings (Foveal / user kernels) in front of RelativeMSE: psh_scan_topk_embedded
+EMBEDDED_GOLDENS = ["foveal_tutorial_small", "foveal_a2_hNone", "user_kernel_d5_K23", "foveal_ragged_B7",
+                    "foveal_tutorial_R1024"]
 
 
 @lru_cache(maxsize=4)
 def _regen(expr: str) -> np.ndarray:
     return eval(expr, {"__builtins__": {}}, {"dataset": syn.dataset, "single_query": syn.single_query,
-                                             "rolling_queries": syn.rolling_queries})
+                                             "rolling_queries": syn.rolling_queries,
+                                             "gbm_log_returns": syn.gbm_log_returns})
 
 
 def load_golden(name: str) -> dict:
@@ -30,7 +34,8 @@ def load_golden(name: str) -> dict:
     g["meta"] = json.loads(str(g["meta"]))
     g["h"] = None if int(g["h"]) < 0 else int(g["h"])
     for key in ("W", "k", "n_splits"):
-        g[key] = int(g[key])
+        if key in g:
+            g[key] = int(g[key])
     if "dataset" not in g:
         ds = _regen(g["meta"]["gen"])
         assert syn.sha256(ds) == str(g["dataset_sha256"]), (

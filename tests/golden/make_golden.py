@@ -44,6 +44,8 @@ def load_reference():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also the cfg-2 / cfg-3 sized cases (~2 min)")
+    ap.add_argument("--embedded", action="store_true",
+                    help="ONLY the linear-embedding cases (Foveal / user kernels); the Identity fixtures are left alone")
     args = ap.parse_args()
 
     ref = load_reference()
@@ -72,6 +74,49 @@ def main():
         out["meta"] = json.dumps(m)
         np.savez_compressed(HERE / f"{name}.npz", **out)
         print(f"{name}: d{d.shape} idx{idx.shape} paths{paths.shape} ref {dt:.2f}s")
+
+    def run_embedded(name, emb, ds, q, h, k, n_splits, store_dataset, meta=None):
+        """A PathEmbedding with a (d,1,K) kernel in front of RelativeMSE: besides the outputs,
+        the fixture keeps the kernel and the reference's embedded queries hx = embedding(x)."""
+        obj = ref.PathShadowing(emb, ref.RelativeMSE(), ds, ref.PredictionContext(horizon=h))
+        t0 = time.time()
+        d, paths, idx = obj.shadow(q, k=k, n_splits=n_splits, cuda=False)
+        dt = time.time() - t0
+        q2 = np.atleast_2d(q).astype(np.float32)
+        hx = emb(torch.tensor(q2)[:, None, :])[:, 0, :]
+        out = dict(queries=q2, kernel=emb.kernel[:, 0, :].numpy(), hx=hx.numpy(), hxnorm=hx.norm(dim=-1).numpy(),
+                   d=d, idx=idx, paths=paths, h=-1 if h is None else h, k=k, n_splits=n_splits,
+                   dataset_sha256=syn.sha256(ds), dataset_shape=np.array(ds.shape))
+        if store_dataset:
+            out["dataset"] = ds
+        else:   # generated ensemble, large k: keep the head of the gathered paths only
+            out["paths"] = paths[:, :32]
+        m = dict(meta or {})
+        m.update(reference_seconds=round(dt, 3), numpy=np.__version__, torch=torch.__version__)
+        out["meta"] = json.dumps(m)
+        np.savez_compressed(HERE / f"{name}.npz", **out)
+        print(f"{name}: kernel{tuple(emb.kernel.shape)} d{d.shape} idx{idx.shape} paths{paths.shape} ref {dt:.2f}s")
+
+    if args.embedded:
+        # the tutorial's embedding (tutorial.ipynb cell 8): Foveal(1.15, 0.9, 126)
+        fov = ref.Foveal(alpha=1.15, beta=0.9, max_context=126)
+        run_embedded("foveal_tutorial_small", fov, syn.dataset(64, 600, 30), syn.gbm_log_returns((3, 126), 31),
+                     20, 64, 2, True)
+        run_embedded("foveal_a2_hNone", ref.Foveal(alpha=2.0, beta=0.5, max_context=64), syn.dataset(48, 400, 32),
+                     syn.gbm_log_returns((2, 64), 33), None, 32, 1, True)
+        # a user kernel through the base class: dense random taps, K not a multiple of 4
+        g = torch.Generator().manual_seed(34)
+        user = ref.PathEmbedding(torch.randn(5, 1, 23, generator=g))
+        run_embedded("user_kernel_d5_K23", user, syn.dataset(40, 256, 35), syn.gbm_log_returns((4, 23), 36),
+                     7, 20, 1, True)
+        # ragged rows + more queries than one accumulator group
+        run_embedded("foveal_ragged_B7", ref.Foveal(alpha=1.3, beta=1.0, max_context=40), syn.dataset(33, 1100, 37),
+                     syn.gbm_log_returns((7, 40), 38), 3, 100, 3, True)
+        if args.big:
+            # the tutorial's shape (k = 8192, horizon 252) on a generated ensemble
+            run_embedded("foveal_tutorial_R1024", fov, syn.dataset(1024, 2048, 39), syn.gbm_log_returns((2, 126), 40),
+                         252, 8192, 8, False, dict(gen="dataset(1024,2048,39)", qgen="gbm_log_returns((2,126),40)"))
+        return
 
     # --- BASELINE.json configs[0]: the reference's own CPU-runnable case ----------------
     ds = syn.dataset(256, 1024, 0)

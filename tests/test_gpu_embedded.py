@@ -1,0 +1,155 @@
+"""Parity of the embedded scan (psh_scan_topk_embedded: Foveal and user kernels in front of
+RelativeMSE) on the GPU: against the reference's golden vectors, and bit for bit against the
+CPU oracle's restatement of the same arithmetic order."""
+import numpy as np
+import pytest
+import torch
+
+from _util import EMBEDDED_GOLDENS, assert_exact, assert_matches_reference, bits, load_golden, rows3
+from shadowing_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def hip_scan_embedded(dev, ds, ker, hx, k, h, **kw):
+    from shadowing_amd import _native
+    ds_t = torch.as_tensor(np.ascontiguousarray(rows3(ds)[:, 0, :])).to(dev)
+    ker_t = torch.as_tensor(np.ascontiguousarray(ker, dtype=np.float32)).to(dev)
+    hx_t = torch.as_tensor(np.ascontiguousarray(np.atleast_2d(hx), dtype=np.float32)).to(dev)
+    out = _native.scan_topk_embedded(ds_t, ker_t, hx_t, k, h=h, **kw)
+    torch.cuda.synchronize(dev)
+    return out[0].cpu().numpy(), out[1].cpu().numpy(), out[2].cpu().numpy(), out[3:] and out[3]
+
+
+@pytest.mark.parametrize("name", EMBEDDED_GOLDENS)
+def test_hip_embedded_matches_reference_goldens(hip_device, oracle_mod, name):
+    g = load_golden(name)
+    ds = rows3(g["dataset"])
+    h = g["h"] or 0
+    d, idx, status, _ = hip_scan_embedded(hip_device, ds, g["kernel"], g["hx"], g["k"], h)
+    assert np.all(status == 0)
+    np.testing.assert_allclose(d, np.sort(g["d"], axis=1), rtol=1e-5, atol=0)   # the documented bar
+    small = ds.shape[0] * ds.shape[2] <= 1 << 17
+    all_dist = [oracle_mod.all_distances_embedded(ds, g["kernel"], q, h) for q in g["hx"]] if small else None
+    assert_matches_reference(d, idx, g, all_dist, what=name)                     # what actually holds: bit equality
+    od, oidx = oracle_mod.scan_topk_embedded(ds, g["kernel"], g["hx"], g["k"], h=h)
+    assert_exact(d, idx, od, oidx, name + " vs oracle")
+
+
+def _foveal_kernel(alpha, beta, K):
+    dim = int(np.floor(np.log(K) / np.log(alpha)))
+    ker = np.zeros((dim, K), np.float32)
+    for i in range(dim):
+        n = int(alpha ** (i + 1))
+        ker[i, K - n:] = np.float32(n ** (-beta))
+    return ker
+
+
+EMB_CASES = [  # R, T, d, K, h, k, B, kind
+    (64, 1024, 8, 24, 20, 64, 1, "dense"),
+    (300, 1100, 5, 23, 20, 128, 3, "dense"),       # ragged last segment, K % 4 != 0
+    (50, 515, 6, 31, 7, 33, 2, "dense"),           # T % 4 != 0: unaligned rows
+    (17, 4096, 0, 126, 0, 1000, 2, "foveal"),      # the tutorial's embedding, exhaustive-sized
+    (40, 700, 32, 256, 10, 20, 1, "dense"),        # PSH_MAX_W, d*K = 8192: the LDS limit
+    (40, 600, 3, 1, 0, 50, 2, "dense"),            # K = 1
+    (6, 2100, 0, 64, 20, 1, 1, "foveal"),          # k = 1
+    (2048, 512, 0, 40, 20, 777, 7, "foveal"),      # sampled path, 3 accumulator groups (B = 7)
+    (1500, 900, 4, 20, 5, 300, 4, "gaps"),         # rows with leading/trailing/interior zero taps, one all-zero row
+]
+
+
+def _case_inputs(R, T, d, K, B, kind, seed):
+    rng = np.random.default_rng(seed)
+    ds = syn.dataset(R, T, seed)
+    if kind == "foveal":
+        ker = _foveal_kernel(1.15 if K > 100 else 1.4, 0.9, K)
+    else:
+        ker = rng.standard_normal((d, K)).astype(np.float32)
+        if kind == "gaps":
+            ker[0, :9] = 0; ker[1, 11:] = 0; ker[2, 5:13] = 0; ker[3, :] = 0
+    x = syn.gbm_log_returns((B, K), seed + 1)
+    hx = torch.nn.functional.conv1d(torch.tensor(x)[:, None, :], torch.tensor(ker)[:, None, :])[:, :, 0].numpy()
+    return ds, ker, hx
+
+
+@pytest.mark.parametrize("R,T,d,K,h,k,B,kind", EMB_CASES)
+def test_hip_embedded_equals_oracle_seeded(hip_device, oracle_mod, R, T, d, K, h, k, B, kind):
+    ds, ker, hx = _case_inputs(R, T, d, K, B, kind, 100 + R + K)
+    dd, idx, status, _ = hip_scan_embedded(hip_device, ds, ker, hx, k, h)
+    assert np.all(status == 0)
+    od, oidx = oracle_mod.scan_topk_embedded(ds, ker, hx, k, h=h)
+    assert_exact(dd, idx, od, oidx, f"embedded {(R, T, d, K, h, k, B, kind)}")
+
+
+@pytest.mark.parametrize("R,T,d,K,h,k,B,kind", [(2048, 512, 0, 40, 20, 777, 7, "foveal"), (300, 1100, 5, 23, 20, 128, 3, "dense")])
+def test_embedded_exhaustive_path_equals_oracle(hip_device, oracle_mod, R, T, d, K, h, k, B, kind):
+    ds, ker, hx = _case_inputs(R, T, d, K, B, kind, 7 + R)
+    dd, idx, status, _ = hip_scan_embedded(hip_device, ds, ker, hx, k, h, exhaustive=True)
+    od, oidx = oracle_mod.scan_topk_embedded(ds, ker, hx, k, h=h)
+    assert_exact(dd, idx, od, oidx, "embedded exhaustive")
+
+
+def test_embedded_sampled_path_is_taken(hip_device):
+    ds, ker, hx = _case_inputs(2048, 2048, 0, 126, 2, "foveal", 5)
+    _, _, status, prof = hip_scan_embedded(hip_device, ds, ker, hx, 1024, 252, profile=True)
+    assert np.all(status == 0) and prof["path"] == 0 and prof["n_sample_rows"] > 0
+    assert 1024 <= prof["n_candidates"] < 200 * 1024
+
+
+def test_identity_kernel_through_the_embedded_scan_is_the_plain_scan(hip_device, oracle_mod):
+    ds = syn.dataset(200, 1024, 71)
+    q = syn.gbm_log_returns((2, 20), 72)
+    dd, idx, status, _ = hip_scan_embedded(hip_device, ds, np.eye(20, dtype=np.float32), q, 100, 20)
+    od, oidx = oracle_mod.scan_topk(ds, q, 100, h=20)
+    assert_exact(dd, idx, od, oidx, "eye(20)")
+
+
+def test_embedded_argument_errors(hip_device):
+    from shadowing_amd import _native
+    ds = torch.zeros((8, 600), device=hip_device)
+    hx = torch.ones((1, 64), device=hip_device)
+    with pytest.raises(_native.NativeLibraryError):          # d * K over the LDS limit -> unsupported
+        _native.scan_topk_embedded(ds, torch.ones((64, 256), device=hip_device), hx, 4)
+    assert not _native.embedding_supported(64, 256) and _native.embedding_supported(34, 126)
+    with pytest.raises(ValueError):                           # k larger than the number of windows
+        _native.scan_topk_embedded(ds, torch.ones((4, 500), device=hip_device)[:, :200].contiguous(),
+                                   torch.ones((1, 4), device=hip_device), 8 * 401 + 1)
+
+
+# ---- through the reference's own API -----------------------------------------------------------------
+@pytest.mark.parametrize("name", ["foveal_tutorial_small", "user_kernel_d5_K23", "foveal_ragged_B7"])
+def test_path_shadowing_with_linear_embedding_runs_native(hip_device, name):
+    """PathShadowing(Foveal / PathEmbedding(kernel), RelativeMSE, ds, PredictionContext).shadow(cuda=True)
+    reproduces the reference's shadow(cuda=False) output, through libpsh_hip.so."""
+    from shadowing import Foveal, PathEmbedding, PathShadowing, PredictionContext, RelativeMSE
+    g = load_golden(name)
+    emb = PathEmbedding(torch.tensor(g["kernel"])[:, None, :])
+    obj = PathShadowing(emb, RelativeMSE(), g["dataset"], PredictionContext(horizon=g["h"]))
+    d, paths, idx = obj.shadow(g["queries"], k=g["k"], n_splits=g["n_splits"], cuda=True)
+    assert obj.last_path == "hip"
+    assert d.dtype == np.float32 and idx.dtype == np.int32
+    assert_matches_reference(d, idx, g, None, what=name)
+    K, h = g["kernel"].shape[1], g["h"] or 0
+    ds = rows3(g["dataset"])
+    for b in range(d.shape[0]):
+        for i in (0, d.shape[1] // 2, d.shape[1] - 1):
+            r, t = idx[b, i]
+            assert np.array_equal(paths[b, i, 0], ds[r, 0, t:t + K + h])
+    if name == "foveal_tutorial_small":      # the class itself, not only its kernel
+        obj2 = PathShadowing(Foveal(alpha=1.15, beta=0.9, max_context=126), RelativeMSE(), g["dataset"],
+                             PredictionContext(horizon=g["h"]))
+        d2, _, idx2 = obj2.shadow(g["queries"], k=g["k"], cuda=True)
+        assert obj2.last_path == "hip" and np.array_equal(bits(d2), bits(d)) and np.array_equal(idx2, idx)
+
+
+def test_overridden_forward_keeps_the_generic_path(hip_device):
+    from shadowing import PathEmbedding, PathShadowing, PredictionContext, RelativeMSE
+
+    class Squared(PathEmbedding):
+        def forward(self, x):
+            return super().forward(x) ** 2
+
+    ds = syn.dataset(16, 200, 3)
+    obj = PathShadowing(Squared(torch.randn(3, 1, 10)), RelativeMSE(), ds, PredictionContext(horizon=2))
+    obj.shadow(syn.gbm_log_returns((1, 10), 4), k=5, cuda=True)
+    assert obj.last_path == "torch"

@@ -6,7 +6,8 @@ order among exact ties, gathered paths identical."""
 import numpy as np
 import pytest
 
-from _util import (BIG_GOLDENS, SMALL_GOLDENS, assert_matches_reference, bits, canonical, load_golden, rows3)
+from _util import (BIG_GOLDENS, EMBEDDED_GOLDENS, SMALL_GOLDENS, assert_matches_reference, bits, canonical,
+                   load_golden, rows3)
 
 
 @pytest.mark.parametrize("name", SMALL_GOLDENS + BIG_GOLDENS)
@@ -77,3 +78,55 @@ def test_oracle_thread_count_invariance(oracle_mod):
     a = oracle_mod.scan_topk(ds, q, 100, h=5, nthreads=1)
     b = oracle_mod.scan_topk(ds, q, 100, h=5, nthreads=5)
     assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(a[1], b[1])
+
+
+# ---- linear embeddings (Foveal, user kernels): oracle/psh_oracle.c psh_oracle_scan_topk_embedded ----------
+@pytest.mark.parametrize("name", EMBEDDED_GOLDENS)
+def test_embedded_oracle_reproduces_reference(oracle_mod, name):
+    """The reference leaves the two reduction orders of this path to its libraries, so the
+    documented bar is 1e-5 relative; on every fixture the restated order (fma chains over
+    increasing tap / coordinate) in fact reproduces the reference's CPU output BIT FOR BIT,
+    and that is what is asserted -- the tolerance check below it would still catch a
+    regression if a fixture regenerated on other hardware stopped matching exactly."""
+    g = load_golden(name)
+    ds = rows3(g["dataset"])
+    h = g["h"] or 0
+    d, idx = oracle_mod.scan_topk_embedded(ds, g["kernel"], g["hx"], g["k"], h=h)
+    assert d.shape == g["d"].shape and idx.shape == g["idx"].shape
+    np.testing.assert_allclose(d, np.sort(g["d"], axis=1), rtol=1e-5, atol=0)
+    small = ds.shape[0] * ds.shape[2] <= 1 << 17
+    all_dist = [oracle_mod.all_distances_embedded(ds, g["kernel"], q, h) for q in g["hx"]] if small else None
+    assert_matches_reference(d, idx, g, all_dist, what=name)
+    # ||hx|| in the reference's reduction order
+    assert np.array_equal(bits(oracle_mod.qnorm(g["hx"])), bits(g["hxnorm"]))
+    # the reference's gathered paths at the reference's indices
+    n = g["paths"].shape[1]
+    K = g["kernel"].shape[1]
+    ref_paths = oracle_mod.gather_paths(ds, g["idx"][:, :n], K + h)[:, :, None, :]
+    assert np.array_equal(ref_paths, g["paths"])
+
+
+def test_embedded_oracle_with_identity_kernel_is_the_plain_scan(oracle_mod):
+    """kernel = eye(W): the embedded distance is the Identity distance, term for term."""
+    from shadowing_amd import synthetic as syn
+    ds = syn.dataset(40, 300, 41)
+    q = syn.gbm_log_returns((2, 20), 42)
+    d0, i0 = oracle_mod.scan_topk(ds, q, 30, h=5)
+    d1, i1 = oracle_mod.scan_topk_embedded(ds, np.eye(20, dtype=np.float32), q, 30, h=5)
+    assert np.array_equal(bits(d0), bits(d1)) and np.array_equal(i0, i1)
+
+
+def test_embedded_oracle_is_k_minimal_against_brute_force(oracle_mod):
+    from shadowing_amd import synthetic as syn
+    rng = np.random.default_rng(43)
+    ds = syn.dataset(30, 220, 44)
+    ker = rng.standard_normal((6, 17)).astype(np.float32)
+    hx = rng.standard_normal((2, 6)).astype(np.float32) * 0.05
+    k, h = 41, 4
+    d, idx = oracle_mod.scan_topk_embedded(ds, ker, hx, k, h=h)
+    for b in range(2):
+        full = oracle_mod.all_distances_embedded(ds, ker, hx[b], h)
+        Tp = full.shape[1]
+        order = np.lexsort((np.tile(np.arange(Tp), full.shape[0]), np.repeat(np.arange(full.shape[0]), Tp), full.ravel()))[:k]
+        assert np.array_equal(bits(full.ravel()[order]), bits(d[b]))
+        assert np.array_equal(np.stack([order // Tp, order % Tp], -1).astype(np.int32), idx[b])
