@@ -181,16 +181,6 @@ int plan_scan(int device, const Problem& p, int64_t n_rows, Plan* plan) {
     n_qgroups = (p.B + q_per_group - 1) / q_per_group;
     const int64_t units = n_rs * n_qgroups;
     if (units >= (1ll << 31)) return PSH_ERR_UNSUPPORTED;
-    {   // the kernel divides by multiplication: umulhi(u, ceil(2^32/d)) == u / d needs u * e < 2^32, e = magic*d - 2^32
-        const uint64_t ds[2] = {(uint64_t)n_rs, (uint64_t)nseg};
-        const uint64_t umax[2] = {(uint64_t)units, (uint64_t)n_rs};
-        for (int i = 0; i < 2; ++i) {
-            if (ds[i] <= 1) continue;
-            const uint64_t magic = ((1ull << 32) + ds[i] - 1) / ds[i];
-            const uint64_t e = magic * ds[i] - (1ull << 32);
-            if (magic >= (1ull << 32) || umax[i] * e >= (1ull << 32)) return PSH_ERR_UNSUPPORTED;
-        }
-    }
     int64_t grid = (units + (PSH_SCAN_THREADS / 64) - 1) / (PSH_SCAN_THREADS / 64);
     if (grid > (int64_t)bpc * ncu) grid = (int64_t)bpc * ncu;
     if (grid > PSH_MAX_BLOCKS) grid = PSH_MAX_BLOCKS;
@@ -214,10 +204,10 @@ ScanArgs make_scan_args(const float* dataset, const float* queries, const Proble
     a.row0 = row0;
     a.row_stride = row_stride;
     a.n_rows = (int)n_rows;
-    {   // magic numbers of the unit decode: ceil(2^32 / d)
+    {   // magic numbers of the unit decode: floor(2^32 / d), see fast_div
         const uint64_t n_rs = (uint64_t)n_rows * (uint64_t)a.nseg;
-        a.magic_nrs = n_rs > 1 ? (unsigned)(((1ull << 32) + n_rs - 1) / n_rs) : 0u;
-        a.magic_nseg = a.nseg > 1 ? (unsigned)(((1ull << 32) + (uint64_t)a.nseg - 1) / (uint64_t)a.nseg) : 0u;
+        a.magic_nrs = n_rs > 1 ? (unsigned)((1ull << 32) / n_rs) : 0u;
+        a.magic_nseg = a.nseg > 1 ? (unsigned)((1ull << 32) / (uint64_t)a.nseg) : 0u;
     }
     a.r_offset = p.r_offset;
     a.queries = queries;

@@ -49,7 +49,7 @@ struct ScanArgs {
     int W;
     int64_t row0, row_stride;
     int n_rows;              // rows visited: row0 + i * row_stride
-    unsigned magic_nrs, magic_nseg;   // ceil(2^32 / d): u / d == umulhi(u, magic) for u * d-error < 2^32 (host checks)
+    unsigned magic_nrs, magic_nseg;   // floor(2^32 / d) of the unit decode (fast_div)
     int64_t r_offset;
     const float* queries;    // B x W
     int B;

@@ -48,10 +48,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
 // u / d without the ~40-instruction scalar division sequence (two of them per segment
-// sat on every wave's critical path: ~1000 cycles): magic = ceil(2^32 / d), exact for
-// every u the host admits (u * (magic * d - 2^32) < 2^32, checked in plan_scan)
+// sat on every wave's critical path: ~1000 cycles): magic = floor(2^32 / d) gives
+// umulhi(u, magic) in {u/d - 1, u/d} for every u < 2^32 (the product falls short of u/d
+// by u * frac(2^32/d) / 2^32 < 1), one compare-and-fix makes it exact.
 __device__ __forceinline__ unsigned fast_div(unsigned u, unsigned magic, unsigned d) {
-    return d == 1u ? u : __umulhi(u, magic);
+    if (d == 1u) return u;
+    unsigned q = __umulhi(u, magic);
+    q += (u - q * d >= d) ? 1u : 0u;
+    return q;
 }
 
 // LDS tile layout: logical float p lives at p + 4*(p/64): one 16-byte pad slot after
@@ -847,12 +851,13 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a
                 correlate16(tile, PSH_L * lane + jlo, kerL + (size_t)i * Kp + jlo, n, c);
 #pragma unroll
                 for (int g = 0; g < PSH_EMB_BG; ++g) {
-                    const int b = (b0 + g) < q_end ? (b0 + g) : (q_end - 1);
-                    const float hxv = hxk[(int64_t)b * d + i];
+                    if (b0 + g < q_end) {                    // wave-uniform
+                        const float hxv = hxk[(int64_t)(b0 + g) * d + i];
 #pragma unroll
-                    for (int w = 0; w < PSH_L; ++w) {
-                        const float D = __fsub_rn(hxv, c[w]);
-                        acc[g][w] = __builtin_fmaf(D, D, acc[g][w]);
+                        for (int w = 0; w < PSH_L; ++w) {
+                            const float D = __fsub_rn(hxv, c[w]);
+                            acc[g][w] = __builtin_fmaf(D, D, acc[g][w]);
+                        }
                     }
                 }
             }

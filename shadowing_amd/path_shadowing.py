@@ -188,6 +188,18 @@ class PathShadowing:
             idx[bad] = idx2
         return d, idx, ds
 
+    @staticmethod
+    def _to_host(*tensors: torch.Tensor) -> tuple[np.ndarray, ...]:
+        """Device results -> numpy through PINNED staging buffers, one synchronisation for
+        all of them (the gathered paths are B*k*(T_x+h) floats -- 74 MB for the tutorial's
+        call -- and a pageable .cpu() moves them at a third of the PCIe rate).  The arrays
+        own their pinned blocks; torch's host allocator recycles them when they die."""
+        host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in tensors]
+        for h_, t in zip(host, tensors):
+            h_.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(tensors[0].device).synchronize()
+        return tuple(h_.numpy() for h_ in host)
+
     # ------------------------------------------------------------------ generic path
     def _generic_scan(self, x: torch.Tensor, y: torch.Tensor, k: int, n_splits: int, cuda: bool):
         """The reference's formulation with stock torch ops (ref :129-177): embed the
@@ -248,7 +260,7 @@ class PathShadowing:
             d, idx, ds = self._native_scan(x, y, k)
             paths = _native.gather_paths(ds, idx, length)           # (B, k, C, len) on device
             self.last_path = "hip"
-            return d.cpu().numpy(), paths.cpu().numpy(), idx.cpu().numpy()
+            return self._to_host(d, paths, idx)
 
         d, idx = self._generic_scan(x, y, k, n_splits, cuda)
         self.last_path = "torch"

@@ -1,0 +1,93 @@
+#!/usr/bin/env python
+"""Timing of the embedded scan (psh_scan_topk_embedded) on the two Foveal workloads the
+reference itself runs:
+  tutorial : tutorial.ipynb cell 8   -- Foveal(1.15, 0.9, 126), horizon 252, k = 8192, B = 6, R = 2048, T = 4096
+  testing  : testing.ipynb:95-104    -- the same embedding, horizon 252, k = 10000, B = 1, R = 131072, T = 4096
+             (the reference prints 2.65 s per predict() call for it on an unnamed NVIDIA GPU, host copy included)
+Prints one JSON line per workload: native ms per call with the ensemble resident in HBM,
+the whole shadow() call through the reference API (host query -> host results), and the
+generic torch formulation on the same device for scale.
+
+    python tools/bench_foveal.py [--which tutorial testing] [--steps 20] [--rows 131072]
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from shadowing_amd import _native, synthetic as syn  # noqa: E402
+from shadowing_amd.path_embedding import Foveal, PathEmbedding, PredictionContext  # noqa: E402
+from shadowing_amd.path_distance import RelativeMSE  # noqa: E402
+from shadowing_amd.path_shadowing import PathShadowing  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--which", nargs="+", default=["tutorial", "testing"])
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=0, help="override R of the testing workload")
+    ap.add_argument("--generic", action="store_true", help="also time the generic torch path on the device")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    emb = Foveal(alpha=1.15, beta=0.9, max_context=126)
+    ker = emb.kernel[:, 0, :].contiguous().to(dev)
+    cfgs = {"tutorial": dict(R=2048, T=4096, B=6, k=8192, h=252),
+            "testing": dict(R=args.rows or 131072, T=4096, B=1, k=10000, h=252)}
+    for name in args.which:
+        c = cfgs[name]
+        g = torch.Generator(device=dev).manual_seed(1)
+        ds = torch.randn((c["R"], 1, c["T"]), generator=g, device=dev) * 0.0126      # testing.ipynb uses torch.randn
+        x = torch.tensor(syn.gbm_log_returns((c["B"], 126), 2))
+        hx = emb(x[:, None, :])[:, 0, :].contiguous().to(dev)
+        ws = _native.Workspace(dev)
+        out = _native.scan_topk_embedded(ds[:, 0, :], ker, hx, c["k"], h=c["h"], workspace=ws, profile=True)
+        assert int(out[2].max()) == 0, "overflow"
+        stages = out[3]
+        for _ in range(3):
+            _native.scan_topk_embedded(ds[:, 0, :], ker, hx, c["k"], h=c["h"], workspace=ws)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            _native.scan_topk_embedded(ds[:, 0, :], ker, hx, c["k"], h=c["h"], workspace=ws)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / args.steps * 1e3
+        windows = c["R"] * (c["T"] - 126 - c["h"] + 1)
+        taps = int((emb.kernel != 0).sum())
+        # through the reference API, dataset already a device tensor (resident)
+        obj = PathShadowing(emb, RelativeMSE(), ds, PredictionContext(horizon=c["h"]))
+        obj.shadow(x.numpy(), k=c["k"], cuda=True)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            d, paths, idx = obj.shadow(x.numpy(), k=c["k"], cuda=True)
+        api_ms = (time.perf_counter() - t0) / 5 * 1e3
+        assert obj.last_path == "hip"
+        line = dict(workload=name, config=c, embedding="Foveal(1.15,0.9,126) d=34", ms_per_call=round(ms, 4),
+                    windows=windows, query_windows_per_s=windows * c["B"] / (ms * 1e-3),
+                    nonzero_taps=taps, gfma_per_s=windows * taps * ((c["B"] + 2) // 3) / (ms * 1e-3) / 1e9,
+                    stages_ms={k: round(v, 4) for k, v in stages.items() if k.endswith("_ms")},
+                    n_candidates=stages["n_candidates"], shadow_api_ms=round(api_ms, 3),
+                    reference_published="2.65 s per predict() call (testing.ipynb:90, unnamed NVIDIA GPU, H2D included)"
+                    if name == "testing" else None)
+        if args.generic:
+            class Plain(PathEmbedding):           # a subclass: keeps the generic torch path
+                pass
+            obj_g = PathShadowing(Plain(emb.kernel), RelativeMSE(), ds, PredictionContext(horizon=c["h"]))
+            n_splits = 64 if name == "testing" else 8
+            try:
+                obj_g.shadow(x.numpy(), k=c["k"], n_splits=n_splits, cuda=True)
+                t0 = time.perf_counter()
+                dg, _, ig = obj_g.shadow(x.numpy(), k=c["k"], n_splits=n_splits, cuda=True)
+                line["generic_torch_on_device_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+                line["generic_max_rel_diff"] = float(np.max(np.abs(np.sort(dg, 1) - d) / d))
+            except Exception as e:  # noqa: BLE001
+                line["generic_torch_on_device_ms"] = f"failed: {type(e).__name__}: {str(e)[:80]}"
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()
