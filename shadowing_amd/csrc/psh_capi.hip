@@ -49,6 +49,7 @@ struct Workspace {
     float* minbuf;
     int64_t min_stride;
     int* bcount;
+    float* blockmax;      // PSH_MAX_BLOCKS floats: per-block max |y| of the bootstrap scan
     int2* sel_rt;
     float* cand_d;
     int2* cand_rt;
@@ -88,6 +89,7 @@ size_t fixed_bytes(int B, int kpad, int64_t min_stride) {
     o += align_up(sizeof(int) * (size_t)B, 256);
     o += align_up(sizeof(float) * (size_t)B * (size_t)min_stride, 256);
     o += align_up(sizeof(int) * (size_t)B * PSH_MAX_BLOCKS, 256);
+    o += align_up(sizeof(float) * PSH_MAX_BLOCKS, 256);
     o += align_up(sizeof(int2) * (size_t)B * kpad, 256);
     return o + 1024;  // alignment slack for the four candidate arrays
 }
@@ -107,6 +109,7 @@ int carve(void* ws, size_t bytes, int B, int k, int64_t min_stride, Workspace* o
     out->minbuf = (float*)p;      p += align_up(sizeof(float) * (size_t)B * (size_t)min_stride, 256);
     out->min_stride = min_stride;
     out->bcount = (int*)p;        p += align_up(sizeof(int) * (size_t)B * PSH_MAX_BLOCKS, 256);
+    out->blockmax = (float*)p;    p += align_up(sizeof(float) * PSH_MAX_BLOCKS, 256);
     out->sel_rt = (int2*)p;       p += align_up(sizeof(int2) * (size_t)B * kpad, 256);
     out->cand_d = (float*)p;      p += align_up(sizeof(float) * (size_t)B * cap, 256);
     out->cand_rt = (int2*)p;
@@ -447,18 +450,25 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
 
     Plan plan_s;
     rc = plan_scan(device, p, n_sample, &plan_s); if (rc) return rc;
+    // the cheap test of the full scan runs on the matrix cores where that is implemented
+    // (PSH_FILTER=valu keeps it on the vector ALUs: comparison runs, tools/)
+    bool use_mx = !p.ker && scan_mx_supported(p.W, p.B);
+    if (const char* e = getenv("PSH_FILTER")) { if (!strcmp(e, "valu")) use_mx = false; }
     ScanArgs sa = make_scan_args(dataset, queries, p, w, plan_s, row0, stride, n_sample);
     sa.boot_per_wave = bp.per_wave;
+    sa.blockmax = use_mx ? w.blockmax : nullptr;
     HIP_TRY(launch_scan(sa, PSH_MODE_BOOT, p.aligned, plan_s.grid, s));
     rc = tm.mark(); if (rc) return rc;                                       // 2
 
-    ThresholdArgs ta{w.minbuf, w.min_stride, (int)bp.entries, w.qstate, k, 0, pa};
+    ThresholdArgs ta{w.minbuf, w.min_stride, (int)bp.entries, w.qstate, k, 0,
+                     use_mx ? w.blockmax : nullptr, plan_s.grid, pa};
     HIP_TRY(launch_threshold(ta, B, s));
     rc = tm.mark(); if (rc) return rc;                                       // 3
 
     Plan plan_f;
     rc = plan_scan(device, p, p.R, &plan_f); if (rc) return rc;
     ScanArgs fa = make_scan_args(dataset, queries, p, w, plan_f, 0, 1, p.R);
+    fa.use_mx = use_mx ? 1 : 0;
     if (const char* e = getenv("PSH_DBG_TIMES_PTR")) fa.dbg_times = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning aid
     if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_begin, s));
     HIP_TRY(launch_scan(fa, PSH_MODE_FILTER, p.aligned, plan_f.grid, s));

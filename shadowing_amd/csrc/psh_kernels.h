@@ -26,7 +26,9 @@ struct QueryState {   // one per query, device, 32 bytes
     int n_valid;          // valid entries in out_d/out_idx after the last select
     float nx;             // sum of squares of the query (float, reference order)
     float thr_base;       // bound-then-verify filter: reject iff  ny - 2c > thr_base + 2^-16 * NY
-    int pad[3];
+    float mx_scale;       // matrix-core filter: power of two that brings data and query into f16 range (0 = unset)
+    float mx_thr;         //   reject iff  t^ > mx_thr  (t^ = sum y~^2 - 2 sum x~ y~ on the scaled f16 copies)
+    int pad;
 };
 
 #define PSH_MAX_BLOCKS 2048          // upper bound of the scan grid
@@ -68,6 +70,8 @@ struct ScanArgs {
     unsigned long long* dbg_times;   // tuning aid (nullable): per wave {start, end} wall-clock ticks (100 MHz)
     // embedded scan (ker != nullptr): windows of W = K samples are compared through a linear
     // embedding  h(y)_i = sum_j ker[i][j] * y[t + j]  against pre-embedded queries hx (B x emb_d)
+    float* blockmax;         // BOOT: max |y| each block saw (feeds the f16 scale of the matrix-core filter); nullable
+    int use_mx;              // FILTER: cheap test on the matrix cores (scan_mx_kernel) instead of the VALU
     const float* ker;        // emb_d x W row-major
     const float* hx;         // B x emb_d
     int emb_d;
@@ -83,6 +87,8 @@ struct ThresholdArgs {
     QueryState* qstate;
     int k;
     int keys_in_lds;         // set by the launcher
+    const float* blockmax;   // nullable: per-block max |y| of the bootstrap scan
+    int n_blockmax;
     PrepArgs prep;           // the per-query preparation runs here too (one launch less on the sampled path)
 };
 
@@ -132,6 +138,8 @@ hipError_t launch_prep(const PrepArgs& a, hipStream_t s);
 hipError_t launch_qnorm(const float* q, int B, int W, float* out, hipStream_t s);
 hipError_t launch_scan(const ScanArgs& a, int mode, bool aligned, int grid, hipStream_t s);
 size_t scan_shmem_bytes(int tile_floats, int B, int emb_d, int W);
+size_t scan_mx_shmem_bytes(int tile_floats, int B);
+bool scan_mx_supported(int W, int B);
 hipError_t scan_blocks_per_cu(int W, bool aligned, bool embedded, size_t shmem, int* out);
 hipError_t launch_threshold(const ThresholdArgs& a, int B, hipStream_t s);
 hipError_t launch_select(const SelectArgs& a, int B, hipStream_t s);

@@ -118,7 +118,9 @@ __device__ __forceinline__ void prep_query(const PrepArgs& a, int b) {
         q.n_valid = 0;
         q.nx = s;
         q.thr_base = __uint_as_float(PSH_INF_BITS);   // rejects nothing until the threshold kernel sets it
-        q.pad[0] = q.pad[1] = q.pad[2] = 0;
+        q.mx_scale = 0.0f;                            // the matrix-core filter is off until the threshold kernel arms it
+        q.mx_thr = __uint_as_float(PSH_INF_BITS);
+        q.pad = 0;
         a.qstate[b] = q;
         a.total[b] = 0;
         if (a.status) a.status[b] = PSH_STATUS_OK_;
@@ -440,10 +442,11 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
     // waves end between 69 and 149 us).  All 16 waves of the block therefore pull
     // segments from one LDS counter; the block's own share of the units is static.
     int* next_unit = lcount + ((a.B + 3) & ~3);
-    if (threadIdx.x == 0) *next_unit = 0;
+    if (threadIdx.x == 0) { next_unit[0] = 0; next_unit[1] = 0; }
     if (MODE == PSH_MODE_FILTER)
         for (int q = (int)threadIdx.x; q < a.B; q += PSH_SCAN_THREADS) lcount[q] = 0;
     __syncthreads();
+    float wmax = 0.0f;     // BOOT: largest |y| this lane has seen (-> f16 scale of the matrix-core filter)
 
     const int W = WT > 0 ? WT : a.W;
     const int nfloat = PSH_SEG + W - 1;
@@ -494,6 +497,14 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
         const unsigned long long tp1 = __builtin_readcyclecounter();
 #endif
         stage_store(st, tile, nfloat, lane);
+        if (MODE == PSH_MODE_BOOT && a.blockmax) {
+            const int nq = (nfloat + 3) >> 2;
+#pragma unroll
+            for (int q = 0; q < PSH_NSTAGE; ++q)
+                if (q < PSH_NSTAGE - 1 || lane + 64 * q < nq)
+                    wmax = fmaxf(fmaxf(wmax, fmaxf(fabsf(st.v[q][0]), fabsf(st.v[q][1]))),
+                                 fmaxf(fabsf(st.v[q][2]), fabsf(st.v[q][3])));
+        }
         wave_lds_fence();
 #ifdef PSH_PHASE_TIMING
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -643,6 +654,232 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
         for (int q = (int)threadIdx.x; q < a.B; q += PSH_SCAN_THREADS)
             a.bcount[(int64_t)q * PSH_MAX_BLOCKS + blockIdx.x] = lcount[q];
     }
+    if (MODE == PSH_MODE_BOOT && a.blockmax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off, 64));
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(next_unit + 1), __float_as_uint(wmax));   // >= 0: bits order as values
+        __syncthreads();
+        if (threadIdx.x == 0) a.blockmax[blockIdx.x] = __uint_as_float((unsigned)next_unit[1]);
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// the cheap test on the matrix cores (single query, compile-time W <= 33)
+// ----------------------------------------------------------------------------------
+// Exact fp32 costs 41 VALU lane-operations per window against 4 bytes of HBM traffic:
+// at 8 TB/s that is 82 T lane-ops/s, more than the vector ALUs deliver, so the scan is
+// co-limited by the VALU even with the 25-operation bound-then-verify test above (measured:
+// 71 us of VALU issue against 67 us of HBM time, 107 us together).  The REJECTION test does
+// not need fp32: any rigorous lower bound of acc will do, and the survivors (~1e-4 of the
+// windows) are re-evaluated with the exact chain anyway.  So the bound is evaluated where
+// the chip has 16x the arithmetic: as a banded (Toeplitz) product on the MFMA units, on
+// f16 copies of the data scaled by a power of two s (exact) into f16 range:
+//     t^ = sum_j (y~_j^2)^ * 1  +  sum_j y^_j * (-2 x^_j)         y~ = 2^s y,  x~ = 2^s x
+// One v_mfma_f32_32x32x16_f16 group covers the 1024 windows of a wave segment: row m of A
+// is the 64 consecutive values y^[32m .. 32m+63], column n of B is the query shifted down
+// by n (B[k][n] = -2 x^[k-n] for 0 <= k-n < W), so C[m][n] belongs to window 32m + n.  The
+// window energy comes from the same instruction with A = (y~^2)^ and B = the band of ones.
+// 8 MFMAs per segment, 256 matrix-core cycles; the VALU only converts (60 instructions per
+// lane and segment instead of 430).
+//
+// Error bound (u = 2^-11 f16 round-to-nearest, eta = 2^-25 half the smallest f16
+// subnormal -- MFMA keeps subnormal inputs, products are exact in the fp32 accumulator,
+// <= 128 fp32 additions): with real ny~ = sum y~^2, nx~ = sum x~^2, t~ = ny~ - 2 sum x~ y~
+//     |t^ - t~| <= (3u + 2^-15)(nx~ + ny~) + 41 * 2^-24  <=  a (nx~ + ny~) + b,
+//     a = 2^-9, b = 2^-18        (tools/ubench_mfma_filter.hip measures 0.19 of it)
+// and ny~ <= 2 (acc~ + nx~), so  acc~ (1 + 2a) >= nx~ (1 - 3a) + t^ - b:  a window with
+//     t^ > mx_thr := tau~ (1 + 2^-17)(1 + 2a) - nx~ (1 - 3a) + b
+// has a real acc above tau (1 + 2^-17), hence an fp32 chain value >= tau: it could not be
+// admitted and is skipped.  Everything else is handed to exact_one().  The bound needs
+// finite f16 values: a segment holding |y~| > 128 (an outlier 16x above anything the
+// bootstrap sample saw; y~^2 would leave f16 range) takes the exact fp32 path instead.
+// ----------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define PSH_MX_SLOTS 144                      // 16-byte slots per f16 array: 32*31 + 64 values, whole groups of 16 slots
+#define PSH_MX_NHALF (PSH_MX_SLOTS * 8)
+#define PSH_MX_PEND 64                        // >= 64: one ballot can admit a whole wave
+
+// logical f16 index -> LDS index.  A-fragment reads of the 32 rows sit 64 bytes apart
+// (4 slots): rotating the slot inside its group of 16 by the group number spreads 16
+// consecutive rows over 16 distinct slots without any padding.
+__device__ __forceinline__ int mx_half(int idx) {
+    const int slot = idx >> 3;
+    return (((slot & ~15) | ((slot + (slot >> 4)) & 15)) << 3) | (idx & 7);
+}
+
+template <int WT, bool ALIGNED>
+__global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
+    static_assert(WT >= 1 && WT <= 33, "the shifted-query band must fit K = 64");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NW = PSH_SCAN_THREADS / 64;
+    const int lane = lane_id();
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float* tile = smem + (size_t)wave_in_block * a.tile_floats;          // fp32 values: the exact recheck reads these
+    int* lcount = reinterpret_cast<int*>(smem + (size_t)NW * a.tile_floats);
+    int* next_unit = lcount + 4;                                          // B == 1: lcount[0] is the only cursor
+    u32x4* pend0 = reinterpret_cast<u32x4*>(lcount + 8);
+    u32x4* pend = pend0 + (size_t)wave_in_block * PSH_MX_PEND;
+    _Float16* ah = reinterpret_cast<_Float16*>(pend0 + (size_t)NW * PSH_MX_PEND) + (size_t)wave_in_block * 2 * PSH_MX_NHALF;
+    _Float16* a1 = ah;                                                    // y^
+    _Float16* a2 = ah + PSH_MX_NHALF;                                     // (y~^2)^
+    int npend = 0;
+    if (threadIdx.x == 0) { *next_unit = 0; lcount[0] = 0; }
+    {   // the tail slots no segment ever writes must hold finite values (0 * NaN poisons a row)
+        unsigned* z = reinterpret_cast<unsigned*>(ah);
+        for (int i = lane; i < PSH_MX_NHALF; i += 64) z[i] = 0u;          // 2 arrays x NHALF halves = NHALF dwords
+    }
+    __syncthreads();
+
+    constexpr int W = WT;
+    const int nfloat = PSH_SEG + W - 1;
+    const unsigned n_rs = (unsigned)a.n_rows * (unsigned)a.nseg;
+    const unsigned u_lo = (unsigned)(((unsigned long long)n_rs * blockIdx.x) / gridDim.x);
+    const unsigned u_hi = (unsigned)(((unsigned long long)n_rs * (blockIdx.x + 1)) / gridDim.x);
+    const const_f32p x = (const_f32p)a.queries;
+    typedef const __attribute__((address_space(4))) QueryState* const_qsp;
+    const const_qsp qs = (const_qsp)a.qstate;
+    const float tau = __uint_as_float(qs[0].tau_bits);
+    const float scale = qs[0].mx_scale;
+    const float thr = qs[0].mx_thr;
+
+    // B fragments: lane (n = lane & 31, hk = lane >> 5) holds k = 16 s + 8 hk + i, i < 8
+    f16x8 bx[4], bo[4];
+    {
+        const int n = lane & 31, hk = lane >> 5;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int j = 16 * s + 8 * hk + i - n;
+                const bool in = j >= 0 && j < W;
+                const float xv = x[in ? j : 0];
+                bx[s][i] = (_Float16)(in ? -2.0f * (xv * scale) : 0.0f);
+                bo[s][i] = (_Float16)(in ? 1.0f : 0.0f);
+            }
+    }
+
+    auto grab = [&]() -> unsigned {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(next_unit, 1);
+        return u_lo + (unsigned)__builtin_amdgcn_readfirstlane(v);
+    };
+    auto decode = [&](unsigned uu, unsigned& ri, unsigned& sg) {
+        ri = fast_div(uu, a.magic_nseg, (unsigned)a.nseg);
+        sg = uu - ri * (unsigned)a.nseg;
+    };
+
+    Stage st;
+    unsigned u = grab();
+    unsigned ri, sg;
+    if (u < u_hi) {
+        decode(u, ri, sg);
+        stage_load<ALIGNED>(st, a.dataset + (a.row0 + (int64_t)ri * a.row_stride) * a.T, a.T, (int)sg * PSH_SEG, nfloat, lane);
+    }
+    while (u < u_hi) {
+        decode(u, ri, sg);
+        const int64_t row = a.row0 + (int64_t)ri * a.row_stride;
+        const int seg_start = (int)sg * PSH_SEG;
+
+        stage_store(st, tile, nfloat, lane);
+        float lmax = 0.0f;
+        {   // the f16 copies: y^ and (y~^2)^, 4 values = one 8-byte store per array and chunk
+            const int nq = (nfloat + 3) >> 2;
+#pragma unroll
+            for (int q = 0; q < PSH_NSTAGE; ++q) {
+                const int m = lane + 64 * q;
+                if (q < PSH_NSTAGE - 1 || m < nq) {
+                    const f32x4 v = st.v[q] * scale;
+                    const f32x4 v2 = v * v;
+                    lmax = fmaxf(fmaxf(lmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                    *reinterpret_cast<f16x4*>(a1 + mx_half(4 * m)) = __builtin_convertvector(v, f16x4);
+                    *reinterpret_cast<f16x4*>(a2 + mx_half(4 * m)) = __builtin_convertvector(v2, f16x4);
+                }
+            }
+        }
+        wave_lds_fence();
+        if (npend > 0) {          // last segment's admissions, ahead of the prefetch (vmcnt retires in order)
+            pend_flush(pend, npend, lcount, a, lane);
+            npend = 0;
+        }
+        const unsigned un = grab();
+        if (un < u_hi) {
+            unsigned rin, sgn;
+            decode(un, rin, sgn);
+            stage_load<ALIGNED>(st, a.dataset + (a.row0 + (int64_t)rin * a.row_stride) * a.T, a.T, (int)sgn * PSH_SEG, nfloat, lane);
+        }
+
+        const int r_global = (int)(row + a.r_offset);
+        auto push = [&](bool hit, float v, int t) {      // wave-uniform control flow
+            const unsigned long long mask = __ballot(hit);
+            if (!mask) return;
+            const int nh = __popcll(mask);
+            if (npend + nh > PSH_MX_PEND) {
+                pend_flush(pend, npend, lcount, a, lane);
+                npend = 0;
+                wave_lds_fence();
+            }
+            if (hit) {
+                const int slot = npend + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                             __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                pend[slot] = u32x4{__float_as_uint(v), (unsigned)r_global, (unsigned)t, 0u};
+            }
+            npend += nh;
+        };
+
+        if (!__any(!(lmax <= 128.0f))) {
+            const int m = lane & 31, hk = lane >> 5;
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const f16x8 f = *reinterpret_cast<const f16x8*>(a2 + mx_half(32 * m + 16 * s + 8 * hk));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, bo[s], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const f16x8 f = *reinterpret_cast<const f16x8*>(a1 + mx_half(32 * m + 16 * s + 8 * hk));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, bx[s], acc, 0, 0, 0);
+            }
+            unsigned hm = 0u;                              // bit r: window of accumulator r survives (NaN-safe)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hm |= !(acc[r] > thr) ? (1u << r) : 0u;
+            if (__any(hm != 0u)) {
+#pragma unroll 1
+                for (int r = 0; r < 16; ++r) {
+                    const int p = 32 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + m;      // C layout: row -> window
+                    bool hit = (((hm >> r) & 1u) != 0u) && (seg_start + p < a.Tp);
+                    if (!__ballot(hit)) continue;
+                    const float v = hit ? exact_one<WT>(tile, p, x) : 0.0f;
+                    push(hit && (v < tau), v, seg_start + p);
+                }
+            }
+        } else {
+            // a value beyond f16 range in this segment: the exact chain for all of it
+            float acc[PSH_L];
+            accumulate16<WT>(tile, lane, x, W, acc);
+            const int t_lane = seg_start + PSH_L * lane;
+            int nvalid = a.Tp - t_lane;
+            nvalid = nvalid < 0 ? 0 : (nvalid > PSH_L ? PSH_L : nvalid);
+            unsigned hm = 0u;
+#pragma unroll
+            for (int i = 0; i < PSH_L; ++i) hm |= ((i < nvalid) && (acc[i] < tau)) ? (1u << i) : 0u;
+#pragma unroll 1
+            for (int i = 0; i < PSH_L; ++i) {
+                float v = acc[0];
+#pragma unroll
+                for (int j = 1; j < PSH_L; ++j) v = (i == j) ? acc[j] : v;
+                push(((hm >> i) & 1u) != 0u, v, t_lane + i);
+            }
+        }
+        wave_lds_fence();  // all lanes done with the tile before it is overwritten
+        u = un;
+    }
+    if (npend > 0) pend_flush(pend, npend, lcount, a, lane);
+    __syncthreads();
+    if (threadIdx.x == 0) a.bcount[blockIdx.x] = lcount[0];
 }
 
 // ----------------------------------------------------------------------------------
@@ -1026,8 +1263,17 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
     const int tid = (int)threadIdx.x;
     const float* v = a.minbuf + (int64_t)b * a.min_stride;
     const int n = a.n_entries;
-    if (tid == 0) prep_query(a.prep, b);                   // ||x||, sum of squares, state reset
+    __shared__ unsigned s_maxbits;                         // largest |value| among the sampled data and this query
+    if (tid == 0) { prep_query(a.prep, b); s_maxbits = 0u; }   // ||x||, sum of squares, state reset
     __syncthreads();                                       // (block-scope visibility of qstate[b] for thread 0 below)
+    if (a.blockmax) {
+        unsigned mb = 0u;                                  // non-negative floats order as their bit patterns
+        for (int i = tid; i < a.n_blockmax; i += PSH_SELECT_THREADS) mb = max(mb, __float_as_uint(a.blockmax[i]));
+        for (int j = tid; j < a.prep.W; j += PSH_SELECT_THREADS)
+            mb = max(mb, __float_as_uint(fabsf(a.prep.queries[(int64_t)b * a.prep.W + j])));
+        if (mb) atomicMax(&s_maxbits, mb);
+        __syncthreads();
+    }
     if (n < a.k) return;                                   // tau stays +inf (host avoids this)
     const bool in_lds = a.keys_in_lds != 0;
     if (in_lds) {
@@ -1060,6 +1306,28 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
                 float Af = (float)A;
                 if ((double)Af < A) Af = __uint_as_float(Af >= 0.0f ? __float_as_uint(Af) + 1u : __float_as_uint(Af) - 1u);
                 qs->thr_base = Af;
+                if (a.blockmax && s_maxbits < PSH_INF_BITS) {
+                    // matrix-core filter (scan_mx_kernel): scale = 2^s puts the largest sampled
+                    // |value| into [4, 8) -- f16 keeps 11 bits down to 2^-14 and y~^2 stays below
+                    // 65504 up to |y~| = 255 -- and mx_thr is the bound derived there, evaluated in
+                    // double and rounded up (towards "keep")
+                    int e = (int)((s_maxbits >> 23) & 255u) - 126;          // max in [2^(e-1), 2^e)
+                    int sexp = 3 - e;
+                    sexp = sexp > 60 ? 60 : (sexp < -60 ? -60 : sexp);
+                    const float sc = __uint_as_float((unsigned)(127 + sexp) << 23);
+                    const float* xq = a.prep.queries + (int64_t)b * a.prep.W;
+                    double nxs = 0.0;
+                    for (int j = 0; j < a.prep.W; ++j) { const double v = (double)xq[j] * (double)sc; nxs += v * v; }
+                    const double am = 1.0 / 512.0, bm = 1.0 / 262144.0;
+                    const double taus = (double)tau0 * (double)sc * (double)sc;
+                    const double T = taus * (1.0 + 1.0 / 131072.0) * (1.0 + 2.0 * am) - nxs * (1.0 - 3.0 * am) * (1.0 - 1e-12) + bm;
+                    float Tf = (float)T;
+                    if ((double)Tf < T) Tf = __uint_as_float(Tf >= 0.0f ? __float_as_uint(Tf) + 1u : __float_as_uint(Tf) - 1u);
+                    if (Tf == Tf && fabsf(Tf) < __uint_as_float(PSH_INF_BITS)) {
+                        qs->mx_thr = Tf;
+                        qs->mx_scale = sc;
+                    }
+                }
             }
         }
     }
@@ -1454,6 +1722,24 @@ size_t scan_shmem_bytes(int tile_floats, int B, int emb_d, int W) {
     return n;
 }
 
+bool scan_mx_supported(int W, int B) { return W == 20 && B == 1; }
+
+size_t scan_mx_shmem_bytes(int tile_floats, int /*B*/) {
+    return (size_t)tile_floats * (PSH_SCAN_THREADS / 64) * sizeof(float) + 32
+           + (size_t)(PSH_SCAN_THREADS / 64) * PSH_MX_PEND * 16
+           + (size_t)(PSH_SCAN_THREADS / 64) * 2 * PSH_MX_NHALF * sizeof(_Float16);
+}
+
+template <bool ALIGNED>
+static hipError_t launch_scan_mx(const ScanArgs& a, int grid, hipStream_t s) {
+    const size_t shmem = scan_mx_shmem_bytes(a.tile_floats, a.B);
+    hipError_t e = hipFuncSetAttribute((const void*)scan_mx_kernel<20, ALIGNED>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((scan_mx_kernel<20, ALIGNED>), dim3(grid), dim3(PSH_SCAN_THREADS), shmem, s, a);
+    return hipGetLastError();
+}
+
 template <bool ALIGNED, int MODE>
 static hipError_t launch_embed_mode(const ScanArgs& a, int grid, size_t shmem, hipStream_t s) {
     if (shmem > 48 * 1024) {
@@ -1477,6 +1763,8 @@ static hipError_t launch_embed(const ScanArgs& a, int mode, int grid, size_t shm
 hipError_t launch_scan(const ScanArgs& a, int mode, bool aligned, int grid, hipStream_t s) {
     const size_t shmem = scan_shmem_bytes(a.tile_floats, a.B, a.ker ? a.emb_d : 0, a.W);
     if (a.ker) return aligned ? launch_embed<true>(a, mode, grid, shmem, s) : launch_embed<false>(a, mode, grid, shmem, s);
+    if (a.use_mx && mode == PSH_MODE_FILTER && scan_mx_supported(a.W, a.B))
+        return aligned ? launch_scan_mx<true>(a, grid, s) : launch_scan_mx<false>(a, grid, s);
     if (a.W == 20) {
         return aligned ? launch_scan_mode<20, true>(a, mode, grid, shmem, s)
                        : launch_scan_mode<20, false>(a, mode, grid, shmem, s);
