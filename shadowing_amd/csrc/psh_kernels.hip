@@ -690,9 +690,13 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
 // and ny~ <= 2 (acc~ + nx~), so  acc~ (1 + 2a) >= nx~ (1 - 3a) + t^ - b:  a window with
 //     t^ > mx_thr := tau~ (1 + 2^-17)(1 + 2a) - nx~ (1 - 3a) + b
 // has a real acc above tau (1 + 2^-17), hence an fp32 chain value >= tau: it could not be
-// admitted and is skipped.  Everything else is handed to exact_one().  The bound needs
-// finite f16 values: a segment holding |y~| > 128 (an outlier 16x above anything the
-// bootstrap sample saw; y~^2 would leave f16 range) takes the exact fp32 path instead.
+// admitted and is skipped.  Everything else is handed to exact_one().
+// Values beyond f16 range need no special path.  The scale puts the largest |value| of the
+// bootstrap rows and of the query into [4, 8), and tau is an acc of a bootstrap window, so
+// tau~ <= 20 (8 + 8)^2 = 5120.  An unsampled outlier with y~^2 >= 65520 (|y~| > 255)
+// converts to +inf; a window that contains it has acc~ >= (255 - 8)^2 > tau~ and is
+// rightly rejected when its t^ comes out +inf, and is kept for the exact recheck when it
+// comes out NaN (inf * 0 from the zero part of the band, inf - inf): both are correct.
 // ----------------------------------------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -743,6 +747,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
     const float tau = __uint_as_float(qs[0].tau_bits);
     const float scale = qs[0].mx_scale;
     const float thr = qs[0].mx_thr;
+    const bool armed = scale > 0.0f;      // the threshold kernel could not set the filter up (absurd magnitudes): exact path
 
     // B fragments: lane (n = lane & 31, hk = lane >> 5) holds k = 16 s + 8 hk + i, i < 8
     f16x8 bx[4], bo[4];
@@ -783,7 +788,6 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
         const int seg_start = (int)sg * PSH_SEG;
 
         stage_store(st, tile, nfloat, lane);
-        float lmax = 0.0f;
         {   // the f16 copies: y^ and (y~^2)^, 4 values = one 8-byte store per array and chunk
             const int nq = (nfloat + 3) >> 2;
 #pragma unroll
@@ -792,7 +796,6 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
                 if (q < PSH_NSTAGE - 1 || m < nq) {
                     const f32x4 v = st.v[q] * scale;
                     const f32x4 v2 = v * v;
-                    lmax = fmaxf(fmaxf(lmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                     *reinterpret_cast<f16x4*>(a1 + mx_half(4 * m)) = __builtin_convertvector(v, f16x4);
                     *reinterpret_cast<f16x4*>(a2 + mx_half(4 * m)) = __builtin_convertvector(v2, f16x4);
                 }
@@ -828,25 +831,28 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
             npend += nh;
         };
 
-        if (!__any(!(lmax <= 128.0f))) {
+        if (armed) {
             const int m = lane & 31, hk = lane >> 5;
+            f16x8 fa[8];                                   // all eight A fragments first: one LDS round trip
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                fa[s] = *reinterpret_cast<const f16x8*>(a2 + mx_half(32 * m + 16 * s + 8 * hk));
+                fa[4 + s] = *reinterpret_cast<const f16x8*>(a1 + mx_half(32 * m + 16 * s + 8 * hk));
+            }
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const f16x8 f = *reinterpret_cast<const f16x8*>(a2 + mx_half(32 * m + 16 * s + 8 * hk));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, bo[s], acc, 0, 0, 0);
-            }
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s], bo[s], acc, 0, 0, 0);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const f16x8 f = *reinterpret_cast<const f16x8*>(a1 + mx_half(32 * m + 16 * s + 8 * hk));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f, bx[s], acc, 0, 0, 0);
-            }
-            unsigned hm = 0u;                              // bit r: window of accumulator r survives (NaN-safe)
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[4 + s], bx[s], acc, 0, 0, 0);
+            bool keep = false;                             // NaN-safe: !(t^ > thr)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hm |= !(acc[r] > thr) ? (1u << r) : 0u;
-            if (__any(hm != 0u)) {
+            for (int r = 0; r < 16; ++r) keep = keep || !(acc[r] > thr);
+            if (__any(keep)) {                             // about one segment in four
+                unsigned hm = 0u;                          // bit r: window of accumulator r survives
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hm |= !(acc[r] > thr) ? (1u << r) : 0u;
 #pragma unroll 1
                 for (int r = 0; r < 16; ++r) {
                     const int p = 32 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + m;      // C layout: row -> window
@@ -1312,8 +1318,8 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
                     // 65504 up to |y~| = 255 -- and mx_thr is the bound derived there, evaluated in
                     // double and rounded up (towards "keep")
                     int e = (int)((s_maxbits >> 23) & 255u) - 126;          // max in [2^(e-1), 2^e)
-                    int sexp = 3 - e;
-                    sexp = sexp > 60 ? 60 : (sexp < -60 ? -60 : sexp);
+                    const int sexp = 3 - e;
+                    const bool sane = sexp <= 60 && sexp >= -60 && s_maxbits >= 0x00800000u;   // normal, squares stay in fp32 range
                     const float sc = __uint_as_float((unsigned)(127 + sexp) << 23);
                     const float* xq = a.prep.queries + (int64_t)b * a.prep.W;
                     double nxs = 0.0;
@@ -1323,7 +1329,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
                     const double T = taus * (1.0 + 1.0 / 131072.0) * (1.0 + 2.0 * am) - nxs * (1.0 - 3.0 * am) * (1.0 - 1e-12) + bm;
                     float Tf = (float)T;
                     if ((double)Tf < T) Tf = __uint_as_float(Tf >= 0.0f ? __float_as_uint(Tf) + 1u : __float_as_uint(Tf) - 1u);
-                    if (Tf == Tf && fabsf(Tf) < __uint_as_float(PSH_INF_BITS)) {
+                    if (sane && Tf == Tf && fabsf(Tf) < __uint_as_float(PSH_INF_BITS)) {
                         qs->mx_thr = Tf;
                         qs->mx_scale = sc;
                     }
