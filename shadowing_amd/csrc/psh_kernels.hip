@@ -747,7 +747,8 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
     const float tau = __uint_as_float(qs[0].tau_bits);
     const float scale = qs[0].mx_scale;
     const float thr = qs[0].mx_thr;
-    const bool armed = scale > 0.0f;      // the threshold kernel could not set the filter up (absurd magnitudes): exact path
+    // (if the threshold kernel could not arm the filter -- absurd magnitudes -- scale is 0 and
+    // thr +inf: nothing is rejected, every window goes through exact_one: slow, still exact)
 
     // B fragments: lane (n = lane & 31, hk = lane >> 5) holds k = 16 s + 8 hk + i, i < 8
     f16x8 bx[4], bo[4];
@@ -775,26 +776,42 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
         sg = uu - ri * (unsigned)a.nseg;
     };
 
-    Stage st;
-    unsigned u = grab();
-    unsigned ri, sg;
-    if (u < u_hi) {
-        decode(u, ri, sg);
-        stage_load<ALIGNED>(st, a.dataset + (a.row0 + (int64_t)ri * a.row_stride) * a.T, a.T, (int)sg * PSH_SEG, nfloat, lane);
-    }
-    while (u < u_hi) {
-        decode(u, ri, sg);
+    const float xn = qs[0].xn;
+    // candidate append of this kernel: one query, its norm in an SGPR -- stores only, so that
+    // nothing issued here ever has to be waited for together with a prefetch (vmcnt is in order)
+    auto flush = [&]() {
+        wave_lds_fence();
+        if (lane < npend) {
+            const u32x4 e = pend[lane];
+            const int pos = atomicAdd(&lcount[0], 1);
+            if (pos < a.slice) {
+                const int64_t o = (int64_t)blockIdx.x * a.slice + pos;
+                a.cand_d[o] = dist_from_acc(__uint_as_float(e[0]), xn);
+                a.cand_rt[o] = make_int2((int)e[1], (int)e[2]);
+            }
+        }
+        npend = 0;
+    };
+    auto load_unit = [&](Stage& sx, unsigned uu) {
+        unsigned ri, sg;
+        decode(uu, ri, sg);
+        stage_load<ALIGNED>(sx, a.dataset + (a.row0 + (int64_t)ri * a.row_stride) * a.T, a.T, (int)sg * PSH_SEG, nfloat, lane);
+    };
+    // one segment: `cur` holds its values; returns the unit whose load now occupies `cur`
+    auto process = [&](Stage& cur, unsigned ucur) -> unsigned {
+        unsigned ri, sg;
+        decode(ucur, ri, sg);
         const int64_t row = a.row0 + (int64_t)ri * a.row_stride;
         const int seg_start = (int)sg * PSH_SEG;
 
-        stage_store(st, tile, nfloat, lane);
+        stage_store(cur, tile, nfloat, lane);
         {   // the f16 copies: y^ and (y~^2)^, 4 values = one 8-byte store per array and chunk
             const int nq = (nfloat + 3) >> 2;
 #pragma unroll
             for (int q = 0; q < PSH_NSTAGE; ++q) {
                 const int m = lane + 64 * q;
                 if (q < PSH_NSTAGE - 1 || m < nq) {
-                    const f32x4 v = st.v[q] * scale;
+                    const f32x4 v = cur.v[q] * scale;
                     const f32x4 v2 = v * v;
                     *reinterpret_cast<f16x4*>(a1 + mx_half(4 * m)) = __builtin_convertvector(v, f16x4);
                     *reinterpret_cast<f16x4*>(a2 + mx_half(4 * m)) = __builtin_convertvector(v2, f16x4);
@@ -802,16 +819,9 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
             }
         }
         wave_lds_fence();
-        if (npend > 0) {          // last segment's admissions, ahead of the prefetch (vmcnt retires in order)
-            pend_flush(pend, npend, lcount, a, lane);
-            npend = 0;
-        }
+        if (npend > 0) flush();   // last segment's admissions, ahead of the prefetch
         const unsigned un = grab();
-        if (un < u_hi) {
-            unsigned rin, sgn;
-            decode(un, rin, sgn);
-            stage_load<ALIGNED>(st, a.dataset + (a.row0 + (int64_t)rin * a.row_stride) * a.T, a.T, (int)sgn * PSH_SEG, nfloat, lane);
-        }
+        if (un < u_hi) load_unit(cur, un);
 
         const int r_global = (int)(row + a.r_offset);
         auto push = [&](bool hit, float v, int t) {      // wave-uniform control flow
@@ -819,8 +829,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
             if (!mask) return;
             const int nh = __popcll(mask);
             if (npend + nh > PSH_MX_PEND) {
-                pend_flush(pend, npend, lcount, a, lane);
-                npend = 0;
+                flush();
                 wave_lds_fence();
             }
             if (hit) {
@@ -831,21 +840,20 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
             npend += nh;
         };
 
-        if (armed) {
+        {
             const int m = lane & 31, hk = lane >> 5;
-            f16x8 fa[8];                                   // all eight A fragments first: one LDS round trip
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                fa[s] = *reinterpret_cast<const f16x8*>(a2 + mx_half(32 * m + 16 * s + 8 * hk));
-                fa[4 + s] = *reinterpret_cast<const f16x8*>(a1 + mx_half(32 * m + 16 * s + 8 * hk));
-            }
+            f16x8 fa[4];                                   // four A fragments per LDS round trip
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 #pragma unroll
+            for (int s = 0; s < 4; ++s) fa[s] = *reinterpret_cast<const f16x8*>(a2 + mx_half(32 * m + 16 * s + 8 * hk));
+#pragma unroll
             for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s], bo[s], acc, 0, 0, 0);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[4 + s], bx[s], acc, 0, 0, 0);
+            for (int s = 0; s < 4; ++s) fa[s] = *reinterpret_cast<const f16x8*>(a1 + mx_half(32 * m + 16 * s + 8 * hk));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s], bx[s], acc, 0, 0, 0);
             bool keep = false;                             // NaN-safe: !(t^ > thr)
 #pragma unroll
             for (int r = 0; r < 16; ++r) keep = keep || !(acc[r] > thr);
@@ -862,28 +870,18 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
                     push(hit && (v < tau), v, seg_start + p);
                 }
             }
-        } else {
-            // a value beyond f16 range in this segment: the exact chain for all of it
-            float acc[PSH_L];
-            accumulate16<WT>(tile, lane, x, W, acc);
-            const int t_lane = seg_start + PSH_L * lane;
-            int nvalid = a.Tp - t_lane;
-            nvalid = nvalid < 0 ? 0 : (nvalid > PSH_L ? PSH_L : nvalid);
-            unsigned hm = 0u;
-#pragma unroll
-            for (int i = 0; i < PSH_L; ++i) hm |= ((i < nvalid) && (acc[i] < tau)) ? (1u << i) : 0u;
-#pragma unroll 1
-            for (int i = 0; i < PSH_L; ++i) {
-                float v = acc[0];
-#pragma unroll
-                for (int j = 1; j < PSH_L; ++j) v = (i == j) ? acc[j] : v;
-                push(((hm >> i) & 1u) != 0u, v, t_lane + i);
-            }
         }
         wave_lds_fence();  // all lanes done with the tile before it is overwritten
-        u = un;
-    }
-    if (npend > 0) pend_flush(pend, npend, lcount, a, lane);
+        return un;
+    };
+
+    // one segment in flight per wave besides the one being processed.  (Two in flight --
+    // a second Stage, consumed one iteration later -- was measured: 89.6 us against 82.9.)
+    Stage st;
+    unsigned u = grab();
+    if (u < u_hi) load_unit(st, u);
+    while (u < u_hi) u = process(st, u);
+    if (npend > 0) flush();
     __syncthreads();
     if (threadIdx.x == 0) a.bcount[blockIdx.x] = lcount[0];
 }
