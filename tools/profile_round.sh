@@ -1,0 +1,26 @@
+#!/bin/bash
+# One call on the GPU box: PMC passes (own runs, no trace options) -> HBM traffic json, then the
+# bench line (which reads that json), then rocprofv3 kernel stats of the same bench command.
+# Results under gpurun_out/round/; the summaries are copied to profiles/ afterwards.
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/round
+rm -rf $OUT; mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+i=0
+for CTRS in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVES" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA SQ_ACTIVE_INST_MISC" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $CTRS --output-format csv -d $OUT/pmc_$i -o p -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity > $OUT/pmc_$i.log 2>&1
+done
+python $R/tools/summarize_pmc.py $OUT --traffic $OUT/hbm_traffic.json > $OUT/pmc_summary.txt 2>&1
+cp $OUT/hbm_traffic.json $R/profiles/hbm_traffic.json 2>/dev/null
+cd $R
+timeout 600 python bench.py --steps ${STEPS:-200} --warmup 20 > $OUT/bench_n1.json 2> $OUT/bench.err
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o scan -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_prof.log 2>&1
+for f in $(find $OUT/prof_stats -name "*kernel_stats.csv"); do cp $f $OUT/kernel_stats.csv; done
+cd $R
+timeout 300 python bench.py --steps 20 --warmup 3 --queries 512 --no-cpu-baseline > $OUT/bench_n1_q512.json 2>> $OUT/bench.err
+PSH_FILTER=valu timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_n1_valu_filter.json 2>> $OUT/bench.err
+tail -c 600 $OUT/pmc_summary.txt; head -8 $OUT/kernel_stats.csv; cat $OUT/bench_n1.json
