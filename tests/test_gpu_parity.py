@@ -226,3 +226,64 @@ def test_sharded_class_with_rccl_process_group(hip_device, oracle_mod, tmp_path)
         assert np.array_equal(paths, opaths)
     finally:
         dist.destroy_process_group()
+
+
+# ---- the matrix-core rejection test (scan_mx_kernel: W = 20, one query, sampled path) ----------------------
+def _adversarial(kind, R, T, seed):
+    rng = np.random.default_rng(seed)
+    ds = syn.dataset(R, T, seed)[:, 0, :].copy()
+    q = syn.gbm_log_returns((1, 20), seed + 1)
+    if kind == "spikes":                      # outliers in rows the bootstrap sample mostly never sees
+        for r in rng.integers(0, R, 8):
+            ds[r, rng.integers(0, T, 5)] *= float(10.0 ** rng.integers(2, 7))
+    elif kind == "tiny_query":
+        q *= 1e-4
+    elif kind == "huge_query":
+        q *= 1e3
+    elif kind == "scale_1e-12":
+        ds *= 1e-12; q *= 1e-12
+    elif kind == "scale_1e+12":
+        ds *= 1e12; q *= 1e12
+    elif kind == "planted":                   # near-copies and one exact copy of the query
+        for r in rng.integers(0, R, 40):
+            t = int(rng.integers(0, T - 20))
+            ds[r, t:t + 20] = q[0] * (1 + 1e-3 * rng.standard_normal(20).astype(np.float32))
+        ds[7, 100:120] = q[0]
+    elif kind == "student_t":
+        ds = (0.01 * rng.standard_t(2.5, size=ds.shape)).astype(np.float32)
+    elif kind == "zero_rows":
+        ds[::7] = 0; ds[3::11] = 0.01; q[0, ::3] = 0
+    elif kind == "one_loud_row":              # everything quiet, one unsampled row 1e5 x louder: f16 overflow
+        ds *= 1e-3; ds[1] *= 1e5
+    elif kind == "f16_overflow_inf":          # values whose scaled square leaves fp32/f16 range altogether
+        ds[5, 300:310] = 1e30; ds[9, 50] = -3e38
+    return ds, q
+
+
+MX_KINDS = ["spikes", "tiny_query", "huge_query", "scale_1e-12", "scale_1e+12", "planted", "student_t", "zero_rows",
+            "one_loud_row", "f16_overflow_inf"]
+
+
+@pytest.mark.parametrize("kind", MX_KINDS)
+def test_matrix_core_filter_is_exact_on_adversarial_data(hip_device, oracle_mod, kind):
+    """The f16 rejection test may only ever skip windows that provably cannot be admitted:
+    results stay bit-exact whatever the magnitudes."""
+    R, T, h, k = 6000, 2048, 11, 700
+    ds, q = _adversarial(kind, R, T, 900 + MX_KINDS.index(kind))
+    d, idx, status, prof = hip_scan(hip_device, ds, q, k, h, profile=True)
+    assert prof["path"] == 0                                    # the sampled path (the one that filters)
+    if status[0] != 0:                                          # legitimately overflowed (massive ties): exact net
+        d, idx, _, _ = hip_scan(hip_device, ds, q, k, h, exhaustive=True)
+    od, oidx = oracle_mod.scan_topk(ds, q, k, h=h)
+    assert_exact(d, idx, od, oidx, kind)
+
+
+def test_matrix_core_and_valu_filters_admit_the_same_windows(hip_device, monkeypatch):
+    ds = syn.dataset(8192, 4096, 77)
+    q = syn.single_query(20, 78)
+    d1, i1, s1, p1 = hip_scan(hip_device, ds, q, 1024, 20, profile=True)
+    monkeypatch.setenv("PSH_FILTER", "valu")
+    d2, i2, s2, p2 = hip_scan(hip_device, ds, q, 1024, 20, profile=True)
+    assert s1[0] == 0 and s2[0] == 0
+    assert_exact(d1, i1, d2, i2, "mx vs valu filter")
+    assert p1["n_candidates"] == p2["n_candidates"]             # the exact test decides admission in both
