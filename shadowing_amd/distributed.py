@@ -21,7 +21,7 @@ import torch.distributed as dist
 
 from . import _native
 from .path_distance import RelativeMSE
-from .path_embedding import Identity, PredictionContext
+from .path_embedding import Identity, PathEmbedding, PredictionContext
 
 
 def shard_rows(R: int, world_size: int, rank: int) -> tuple[int, int]:
@@ -32,35 +32,54 @@ def shard_rows(R: int, world_size: int, rank: int) -> tuple[int, int]:
 
 
 def _native_local_topk(ds2d: torch.Tensor, q: torch.Tensor, k: int, h: int, r_offset: int, workspace,
-                       out=None, check: bool = True):
-    d, idx, status = _native.scan_topk(ds2d, q, k, h=h, r_offset=r_offset, workspace=workspace, out=out)
+                       out=None, check: bool = True, ker: torch.Tensor | None = None):
+    """q: the query windows (B, W), or -- with `ker` (d, K), a linear embedding -- the embedded
+    queries (B, d)."""
+    def run(qq, exhaustive, out_):
+        if ker is None:
+            return _native.scan_topk(ds2d, qq, k, h=h, r_offset=r_offset, workspace=workspace, out=out_,
+                                     exhaustive=exhaustive)
+        return _native.scan_topk_embedded(ds2d, ker, qq, k, h=h, r_offset=r_offset, workspace=workspace, out=out_,
+                                          exhaustive=exhaustive)
+    d, idx, status = run(q, False, out)
     if check:    # one host sync: a query whose candidate slices overflowed is redone exactly
         bad = torch.nonzero(status != _native.PSH_STATUS_OK).flatten()
         if bad.numel():
-            d2, idx2, _ = _native.scan_topk(ds2d, q[bad].contiguous(), k, h=h, r_offset=r_offset,
-                                            workspace=workspace, exhaustive=True)
+            d2, idx2, _ = run(q[bad].contiguous(), True, None)
             d[bad] = d2
             idx[bad] = idx2
     return d, idx, status
 
 
 class ShardedPathShadowing:
-    """The Identity + RelativeMSE + PredictionContext scan over a row-sharded ensemble.
+    """The (Identity | stock linear embedding) + RelativeMSE + PredictionContext scan over a
+    row-sharded ensemble (BASELINE configs[3] and [4]).
 
     Every rank constructs it with ITS OWN rows (`local_dataset`, (R_local, 1, T) or
     (R_local, T)) and the global index of its first row.  `shadow()` is collective
     and returns the same global result on every rank.
 
     `local_topk` / `merge` are injection points for the CPU (gloo) tests of the
-    exchange logic; production leaves them None and runs the HIP kernels.
+    exchange logic; production leaves them None and runs the HIP kernels.  With a linear
+    embedding (Foveal, PathEmbedding(kernel)) `local_topk` receives the EMBEDDED queries.
     """
 
     def __init__(self, embedding: Identity, distance: RelativeMSE, local_dataset, row_offset: int,
                  context: PredictionContext | None = None, group=None, device: torch.device | None = None,
                  local_topk: Callable | None = None, merge: Callable | None = None, always_exchange: bool = False):
-        if type(embedding) is not Identity or type(distance) is not RelativeMSE:
-            raise TypeError("the sharded scan implements Identity + RelativeMSE only")
+        if type(distance) is not RelativeMSE:
+            raise TypeError("the sharded scan implements RelativeMSE only")
+        if type(embedding) is Identity:
+            self._linear = False
+        elif (isinstance(embedding, PathEmbedding) and type(embedding).forward is PathEmbedding.forward
+              and embedding.kernel.ndim == 3 and embedding.kernel.shape[1] == 1
+              and _native.embedding_supported(embedding.kernel.shape[0], embedding.kernel.shape[-1])):
+            self._linear = True
+        else:
+            raise TypeError("the sharded scan implements Identity and stock linear embeddings (kernel (d,1,K) that "
+                            "fits the native scan) only")
         self.embedding, self.distance = embedding, distance
+        self._ker = None
         self.context = context or PredictionContext(horizon=None)
         if type(self.context) is not PredictionContext:
             raise TypeError("the sharded scan implements PredictionContext only")
@@ -84,6 +103,8 @@ class ShardedPathShadowing:
             _native.load()
             ds = ds.to(device)
             self._workspace = _native.Workspace(device)
+            if self._linear:
+                self._ker = embedding.kernel[:, 0, :].to(device=device, dtype=torch.float32).contiguous()
         else:
             self._workspace = None
         self.dataset = ds.contiguous()
@@ -98,14 +119,14 @@ class ShardedPathShadowing:
         padded with (+inf, -1) when the shard holds fewer than k windows."""
         h = self.context.get_out_times()
         R_local, _, T = self.dataset.shape
-        n_local = R_local * (T - q.shape[-1] - h + 1)
+        n_local = R_local * (T - self.embedding.kernel.shape[-1] - h + 1)
         k_local = min(k, n_local)
         if self._local_topk is not None:            # CPU test path (oracle injected)
             d, idx = self._local_topk(self.dataset[:, 0, :], q, k_local, h, self.row_offset)
             status = None
         else:
             d, idx, status = _native_local_topk(self.dataset[:, 0, :], q, k_local, h, self.row_offset, self._workspace,
-                                                out=out if k_local == k else None, check=check)
+                                                out=out if k_local == k else None, check=check, ker=self._ker)
         if k_local < k:
             B = q.shape[0]
             d = torch.cat([d, d.new_full((B, k - k_local), float("inf"))], dim=1)
@@ -121,6 +142,11 @@ class ShardedPathShadowing:
         where the collective left them (no pack / unpack copies).  `check=False` skips the
         per-call host synchronisation that looks at the overflow status (benchmark loops
         check `last_status` once at the end)."""
+        if self._linear:
+            # the query embedding is the module's own conv1d (reference path_shadowing.py:140), on
+            # the module's device; what travels to the scan is (B, d)
+            kdev = self.embedding.kernel.device
+            queries = self.embedding(queries.to(kdev, dtype=torch.float32)[:, None, :])[:, 0, :]
         q = queries.to(self.device, dtype=torch.float32).contiguous()
         B = q.shape[0]
         G = self.world_size

@@ -55,5 +55,26 @@ def rolling_queries(B: int, W: int, seed: int = QUERY_SEED) -> np.ndarray:
     return np.lib.stride_tricks.sliding_window_view(path, W).copy()
 
 
+def wavelet_bank(n_scales: int, K: int, xi: float = 2.35) -> np.ndarray:
+    """(2 * n_scales + 1, K) float32 real filter bank for BASELINE.json configs[4] ("wavelet
+    conv, W=252"): cosine and sine parts of Morlet wavelets at dyadic scales 2^1 .. 2^n_scales
+    plus one Gaussian low-pass, each anchored at the END of the window (the most recent
+    samples) and L1-normalised -- the linear stage of a scattering embedding.  (Its modulus /
+    spectra stages live in the reference's un-vendored dependency and are out of reach.)"""
+    u = np.arange(K, dtype=np.float64)[::-1]           # 0 = the newest sample
+    rows = []
+    for j in range(1, n_scales + 1):
+        sigma = 0.8 * 2.0 ** j
+        env = np.exp(-0.5 * ((u - 3 * sigma) / sigma) ** 2)
+        for phase in (np.cos, np.sin):
+            w = env * phase(xi * (u - 3 * sigma) / 2.0 ** j)
+            w -= env * (w.sum() / env.sum())            # zero mean
+            rows.append(w / np.abs(w).sum())
+    sigma = 0.8 * 2.0 ** n_scales
+    low = np.exp(-0.5 * ((u - 3 * sigma) / sigma) ** 2)
+    rows.append(low / low.sum())
+    return np.asarray(rows, dtype=np.float32)
+
+
 def sha256(a: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()

@@ -16,7 +16,7 @@ SMALL_GOLDENS = ["cfg1_h20", "cfg1_hNone", "multiquery_splits", "remainder_split
 BIG_GOLDENS = ["cfg2_R32768", "cfg3_rolling_R2048"]
 # linear embeddings (Foveal / user kernels) in front of RelativeMSE: psh_scan_topk_embedded
 EMBEDDED_GOLDENS = ["foveal_tutorial_small", "foveal_a2_hNone", "user_kernel_d5_K23", "foveal_ragged_B7",
-                    "foveal_tutorial_R1024"]
+                    "foveal_tutorial_R1024", "wavelet_W252_rolling"]
 
 
 @lru_cache(maxsize=4)

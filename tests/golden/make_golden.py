@@ -112,6 +112,10 @@ def main():
         # ragged rows + more queries than one accumulator group
         run_embedded("foveal_ragged_B7", ref.Foveal(alpha=1.3, beta=1.0, max_context=40), syn.dataset(33, 1100, 37),
                      syn.gbm_log_returns((7, 40), 38), 3, 100, 3, True)
+        # BASELINE.json configs[4] in small: a real wavelet filter bank over a W = 252 window, batched queries
+        wav = ref.PathEmbedding(torch.tensor(syn.wavelet_bank(5, 252))[:, None, :])
+        run_embedded("wavelet_W252_rolling", wav, syn.dataset(48, 1500, 41), syn.rolling_queries(4, 252, 42),
+                     20, 128, 2, True)
         if args.big:
             # the tutorial's shape (k = 8192, horizon 252) on a generated ensemble
             run_embedded("foveal_tutorial_R1024", fov, syn.dataset(1024, 2048, 39), syn.gbm_log_returns((2, 126), 40),

@@ -69,6 +69,52 @@ def test_two_rank_gloo_matches_single_process(tmp_path, oracle_mod, R, k):
         assert np.array_equal(z["paths"], paths)
 
 
+def _worker_embedded(rank, world, port, R, T, h, k, B, tmp):
+    sys.path.insert(0, str(REPO))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        import shadowing_amd as sa
+        from shadowing_amd import synthetic as syn
+        from shadowing_amd.distributed import ShardedPathShadowing, shard_rows
+        ker = syn.wavelet_bank(3, 64)                                  # (7, 64)
+        emb = sa.PathEmbedding(torch.tensor(ker)[:, None, :])
+
+        def local(ds2d, hx, k_, h_, r_offset):
+            d, idx = oracle.scan_topk_embedded(ds2d.numpy(), ker, hx.numpy(), k_, h=h_, r_offset=r_offset, nthreads=2)
+            return torch.from_numpy(d), torch.from_numpy(idx)
+
+        lo, hi = shard_rows(R, world, rank)
+        obj = ShardedPathShadowing(emb, sa.RelativeMSE(), syn.dataset_rows(R, T, 5, lo, hi), lo, sa.PredictionContext(h),
+                                   local_topk=local, merge=_torch_merge)
+        d, paths, idx = obj.shadow(syn.rolling_queries(B, 64, 6), k)
+        np.savez(os.path.join(tmp, f"rank{rank}.npz"), d=d, paths=paths, idx=idx)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_linear_embedding_matches_single_process(tmp_path, oracle_mod):
+    """BASELINE configs[4] shape in small: a wavelet filter bank in front of RelativeMSE,
+    batched queries, rows sharded over two ranks."""
+    R, T, h, k, B = 23, 300, 9, 40, 3
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker_embedded, args=(2, port, R, T, h, k, B, str(tmp_path)), nprocs=2, join=True)
+    from shadowing_amd import synthetic as syn
+    ds = syn.dataset(R, T, 5)
+    ker = syn.wavelet_bank(3, 64)
+    x = syn.rolling_queries(B, 64, 6)
+    hx = torch.nn.functional.conv1d(torch.tensor(x)[:, None, :], torch.tensor(ker)[:, None, :])[:, :, 0].numpy()
+    d, idx = oracle_mod.scan_topk_embedded(ds, ker, hx, k, h=h)
+    paths = oracle_mod.gather_paths(ds, idx, 64 + h)[:, :, None, :]
+    for rank in range(2):
+        z = np.load(tmp_path / f"rank{rank}.npz")
+        assert np.array_equal(z["d"].view(np.uint32), d.view(np.uint32))
+        assert np.array_equal(z["idx"], idx)
+        assert np.array_equal(z["paths"], paths)
+
+
 def test_shard_rows_partition():
     from shadowing_amd.distributed import shard_rows
     for R in (1, 7, 8, 262144, 1000003):

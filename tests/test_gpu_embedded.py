@@ -153,3 +153,38 @@ def test_overridden_forward_keeps_the_generic_path(hip_device):
     obj = PathShadowing(Squared(torch.randn(3, 1, 10)), RelativeMSE(), ds, PredictionContext(horizon=2))
     obj.shadow(syn.gbm_log_returns((1, 10), 4), k=5, cuda=True)
     assert obj.last_path == "torch"
+
+
+def test_sharded_class_with_linear_embedding_over_rccl(hip_device, oracle_mod, tmp_path):
+    """BASELINE configs[4] in small: wavelet filter bank (W = 252) + RelativeMSE, batched rolling
+    queries, ShardedPathShadowing over a real RCCL process group (one rank: the all-gather
+    and the in-place merge still run), logical shards merged like the ranks of a node."""
+    import torch.distributed as dist
+    import shadowing_amd as sa
+    from shadowing_amd import _native
+    from shadowing_amd.distributed import ShardedPathShadowing, shard_rows
+    R, T, h, k, B = 3000, 1500, 20, 256, 6
+    ker = syn.wavelet_bank(5, 252)
+    emb = sa.PathEmbedding(torch.tensor(ker)[:, None, :])
+    ds = syn.dataset(R, T, 51)
+    x = syn.rolling_queries(B, 252, 52)
+    hx = emb(torch.tensor(x)[:, None, :])[:, 0, :].numpy()
+    od, oidx = oracle_mod.scan_topk_embedded(ds, ker, hx, k, h=h)
+    opaths = oracle_mod.gather_paths(ds, oidx, 252 + h)[:, :, None, :]
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/pg", rank=0, world_size=1, device_id=hip_device)
+    try:
+        obj = ShardedPathShadowing(emb, sa.RelativeMSE(), ds, 0, sa.PredictionContext(h), device=hip_device,
+                                   always_exchange=True)
+        d, paths, idx = obj.shadow(x, k)
+        assert_exact(d, idx, od, oidx, "sharded linear embedding")
+        assert np.array_equal(paths, opaths)
+    finally:
+        dist.destroy_process_group()
+    # 4 logical shards scanned one after the other on this GPU, merged by the device merge
+    parts = []
+    for g in range(4):
+        lo, hi = shard_rows(R, 4, g)
+        o = ShardedPathShadowing(emb, sa.RelativeMSE(), ds[lo:hi], lo, sa.PredictionContext(h), device=hip_device)
+        parts.append(o.local_scan(torch.tensor(hx).to(hip_device), k)[:2])
+    md, mi = _native.merge_topk(torch.cat([p[0] for p in parts], 1), torch.cat([p[1] for p in parts], 1), k)
+    assert_exact(md.cpu().numpy(), mi.cpu().numpy(), od, oidx, "4 logical shards")
