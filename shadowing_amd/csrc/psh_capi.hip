@@ -50,6 +50,7 @@ struct Workspace {
     int64_t min_stride;
     int* bcount;
     float* blockmax;      // PSH_MAX_BLOCKS floats: per-block max |y| of the bootstrap scan
+    void* mq_frag;        // (B rounded up to 4) x 256 f16: B fragments of the batched matrix-core scan
     int2* sel_rt;
     float* cand_d;
     int2* cand_rt;
@@ -90,6 +91,7 @@ size_t fixed_bytes(int B, int kpad, int64_t min_stride) {
     o += align_up(sizeof(float) * (size_t)B * (size_t)min_stride, 256);
     o += align_up(sizeof(int) * (size_t)B * PSH_MAX_BLOCKS, 256);
     o += align_up(sizeof(float) * PSH_MAX_BLOCKS, 256);
+    o += align_up((size_t)512 * (size_t)((B + 3) & ~3), 256);
     o += align_up(sizeof(int2) * (size_t)B * kpad, 256);
     return o + 1024;  // alignment slack for the four candidate arrays
 }
@@ -110,6 +112,7 @@ int carve(void* ws, size_t bytes, int B, int k, int64_t min_stride, Workspace* o
     out->min_stride = min_stride;
     out->bcount = (int*)p;        p += align_up(sizeof(int) * (size_t)B * PSH_MAX_BLOCKS, 256);
     out->blockmax = (float*)p;    p += align_up(sizeof(float) * PSH_MAX_BLOCKS, 256);
+    out->mq_frag = (void*)p;      p += align_up((size_t)512 * (size_t)((B + 3) & ~3), 256);
     out->sel_rt = (int2*)p;       p += align_up(sizeof(int2) * (size_t)B * kpad, 256);
     out->cand_d = (float*)p;      p += align_up(sizeof(float) * (size_t)B * cap, 256);
     out->cand_rt = (int2*)p;
@@ -453,15 +456,16 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     // the cheap test of the full scan runs on the matrix cores where that is implemented
     // (PSH_FILTER=valu keeps it on the vector ALUs: comparison runs, tools/)
     bool use_mx = !p.ker && scan_mx_supported(p.W, p.B);
-    if (const char* e = getenv("PSH_FILTER")) { if (!strcmp(e, "valu")) use_mx = false; }
+    bool use_mq = !p.ker && scan_mq_supported(p.W, p.B);      // batched queries: 4 queries x 8 shifts per MFMA
+    if (const char* e = getenv("PSH_FILTER")) { if (!strcmp(e, "valu")) use_mx = use_mq = false; }
     ScanArgs sa = make_scan_args(dataset, queries, p, w, plan_s, row0, stride, n_sample);
     sa.boot_per_wave = bp.per_wave;
-    sa.blockmax = use_mx ? w.blockmax : nullptr;
+    sa.blockmax = (use_mx || use_mq) ? w.blockmax : nullptr;
     HIP_TRY(launch_scan(sa, PSH_MODE_BOOT, p.aligned, plan_s.grid, s));
     rc = tm.mark(); if (rc) return rc;                                       // 2
 
     ThresholdArgs ta{w.minbuf, w.min_stride, (int)bp.entries, w.qstate, k, 0,
-                     use_mx ? w.blockmax : nullptr, plan_s.grid, pa};
+                     (use_mx || use_mq) ? w.blockmax : nullptr, plan_s.grid, use_mq ? w.mq_frag : nullptr, pa};
     HIP_TRY(launch_threshold(ta, B, s));
     rc = tm.mark(); if (rc) return rc;                                       // 3
 
@@ -471,11 +475,28 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     fa.use_mx = use_mx ? 1 : 0;
     if (const char* e = getenv("PSH_DBG_TIMES_PTR")) fa.dbg_times = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning aid
     if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_begin, s));
-    HIP_TRY(launch_scan(fa, PSH_MODE_FILTER, p.aligned, plan_f.grid, s));
+    int nblk = plan_f.grid;
+    if (use_mq) {
+        // one block of 8 waves per CU and query chunk; every block owns a slice of every query's list
+        int ncu = 0;
+        HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+        const int chunks = scan_mq_chunks(B);
+        const int64_t n_rs = p.R * ((p.Tp + PSH_SEG - 1) / PSH_SEG);
+        int64_t gx = (n_rs + 7) / 8;
+        if (gx > ncu) gx = ncu;
+        while (gx * chunks > PSH_MAX_BLOCKS) gx /= 2;
+        if (gx < 1) gx = 1;
+        nblk = (int)gx * chunks;
+        fa.mq_frag = w.mq_frag;
+        fa.slice = w.cap / nblk;
+        HIP_TRY(launch_scan_mq(fa, p.aligned, (int)gx, s));
+    } else {
+        HIP_TRY(launch_scan(fa, PSH_MODE_FILTER, p.aligned, plan_f.grid, s));
+    }
     if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_end, s));
     rc = tm.mark(); if (rc) return rc;                                       // 4
 
-    SelectArgs se = make_select_args(p, w, out_d, out_idx, out_status, true, plan_f.grid, 0);
+    SelectArgs se = make_select_args(p, w, out_d, out_idx, out_status, true, nblk, 0);
     if (const char* e = getenv("PSH_DBG_SELECT_PTR")) se.dbg_times = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning aid
     HIP_TRY(launch_select(se, B, s));
     rc = tm.mark(); if (rc) return rc;                                       // 5

@@ -72,6 +72,7 @@ struct ScanArgs {
     // embedding  h(y)_i = sum_j ker[i][j] * y[t + j]  against pre-embedded queries hx (B x emb_d)
     float* blockmax;         // BOOT: max |y| each block saw (feeds the f16 scale of the matrix-core filter); nullable
     int use_mx;              // FILTER: cheap test on the matrix cores (scan_mx_kernel) instead of the VALU
+    const void* mq_frag;     // batched matrix-core scan: B-fragment table written by the threshold kernel (f16)
     const float* ker;        // emb_d x W row-major
     const float* hx;         // B x emb_d
     int emb_d;
@@ -89,6 +90,7 @@ struct ThresholdArgs {
     int keys_in_lds;         // set by the launcher
     const float* blockmax;   // nullable: per-block max |y| of the bootstrap scan
     int n_blockmax;
+    void* mq_frag;           // nullable: B-fragment table of scan_mq_kernel, (B rounded up to 4) x 256 f16
     PrepArgs prep;           // the per-query preparation runs here too (one launch less on the sampled path)
 };
 
@@ -140,6 +142,10 @@ hipError_t launch_scan(const ScanArgs& a, int mode, bool aligned, int grid, hipS
 size_t scan_shmem_bytes(int tile_floats, int B, int emb_d, int W);
 size_t scan_mx_shmem_bytes(int tile_floats, int B);
 bool scan_mx_supported(int W, int B);
+bool scan_mq_supported(int W, int B);          // batched queries on the matrix cores
+size_t scan_mq_shmem_bytes(int tile_floats, int B);
+int scan_mq_chunks(int B);                      // grid.y: chunks of queries whose fragments fit LDS
+hipError_t launch_scan_mq(const ScanArgs& a, bool aligned, int grid_x, hipStream_t s);
 hipError_t scan_blocks_per_cu(int W, bool aligned, bool embedded, size_t shmem, int* out);
 hipError_t launch_threshold(const ThresholdArgs& a, int B, hipStream_t s);
 hipError_t launch_select(const SelectArgs& a, int B, hipStream_t s);

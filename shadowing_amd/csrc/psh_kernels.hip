@@ -412,7 +412,7 @@ __device__ __forceinline__ void pend_flush(const u32x4* pend, int npend, int* lc
         const int b = (int)e[3];
         const int pos = atomicAdd(&lcount[b], 1);      // LDS: this block's cursor for query b
         if (pos < a.slice) {
-            const int64_t o = (int64_t)b * a.cap + (int64_t)blockIdx.x * a.slice + pos;
+            const int64_t o = (int64_t)b * a.cap + (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * a.slice + pos;
             a.cand_d[o] = dist_from_acc(__uint_as_float(e[0]), a.qstate[b].xn);
             a.cand_rt[o] = make_int2((int)e[1], (int)e[2]);
         }
@@ -887,6 +887,206 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
 }
 
 // ----------------------------------------------------------------------------------
+// the matrix-core rejection test for BATCHED queries (BASELINE configs[2]: W <= 25)
+// ----------------------------------------------------------------------------------
+// Same bound, same exact recheck as scan_mx_kernel; the banded product is laid out for
+// several queries: the N dimension holds 4 queries x 8 shifts, row m of A is
+// y^[256 g + 8 m .. + 31] (g = 0..3 covers the segment), K = 32.  The window energies (A =
+// y~^2, B = band of ones) are computed once per segment into 4 accumulator tiles that seed
+// the 2 MFMAs per tile of every query group: 2 MFMAs and ~25 VALU instructions per query
+// and segment against 430 VALU instructions for the test on the vector ALUs.
+// Blocks of 8 waves (2 per SIMD: the tiles and the A fragments of a segment stay in
+// registers, 256 VGPRs); blockIdx.y selects a chunk of PSH_MQ_CHUNK queries whose B
+// fragments (built by the threshold kernel, one common power-of-two scale) and thresholds
+// sit in LDS.  A segment holding a value beyond f16 range keeps everything (exact path).
+#define PSH_MQ_THREADS 512
+#define PSH_MQ_CHUNK 128
+
+template <int WT, bool ALIGNED>
+__global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
+    static_assert(WT >= 1 && WT <= 25, "query + 7 shifts must fit K = 32");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NW = PSH_MQ_THREADS / 64;
+    const int lane = lane_id();
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float* tile = smem + (size_t)wave_in_block * a.tile_floats;
+    int* lcount = reinterpret_cast<int*>(smem + (size_t)NW * a.tile_floats);
+    int* next_unit = lcount + ((a.B + 3) & ~3);
+    u32x4* pend0 = reinterpret_cast<u32x4*>(next_unit + 4);
+    u32x4* pend = pend0 + (size_t)wave_in_block * PSH_PEND;
+    _Float16* hbase = reinterpret_cast<_Float16*>(pend0 + (size_t)NW * PSH_PEND);
+    _Float16* a1 = hbase + (size_t)wave_in_block * 2 * PSH_MX_NHALF;      // y^
+    _Float16* a2 = a1 + PSH_MX_NHALF;                                      // (y~^2)^
+    _Float16* fragL = hbase + (size_t)NW * 2 * PSH_MX_NHALF;               // [group][K-step][lane] x 8 halves
+    float* thrL = reinterpret_cast<float*>(fragL + (size_t)(PSH_MQ_CHUNK / 4) * 2 * 64 * 8);
+    float* tauL = thrL + PSH_MQ_CHUNK;
+    int npend = 0;
+
+    const int q0 = (int)blockIdx.y * PSH_MQ_CHUNK;                         // this block's queries: [q0, q0 + nq)
+    const int nq = (a.B - q0) < PSH_MQ_CHUNK ? (a.B - q0) : PSH_MQ_CHUNK;
+    const int ngroups = (nq + 3) >> 2;
+    if (threadIdx.x == 0) *next_unit = 0;
+    for (int q = (int)threadIdx.x; q < a.B; q += PSH_MQ_THREADS) lcount[q] = 0;
+    {
+        unsigned* z = reinterpret_cast<unsigned*>(a1);
+        for (int i = lane; i < PSH_MX_NHALF; i += 64) z[i] = 0u;
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.mq_frag) + (size_t)(q0 >> 2) * 2 * 64;   // 16 bytes = 8 halves
+        f32x4* dst = reinterpret_cast<f32x4*>(fragL);
+        for (int i = (int)threadIdx.x; i < ngroups * 2 * 64; i += PSH_MQ_THREADS) {
+            // lanes of queries past the end of the batch: zero fragments
+            const int ln = i & 63, qq = 4 * (i >> 7) + ((ln & 31) >> 3);
+            dst[i] = qq < nq ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int i = (int)threadIdx.x; i < PSH_MQ_CHUNK; i += PSH_MQ_THREADS) {
+            thrL[i] = i < nq ? a.qstate[q0 + i].mx_thr : -__uint_as_float(PSH_INF_BITS);   // -inf: reject everything
+            tauL[i] = i < nq ? __uint_as_float(a.qstate[q0 + i].tau_bits) : 0.0f;
+        }
+    }
+    __syncthreads();
+
+    constexpr int W = WT;
+    const int nfloat = PSH_SEG + W - 1;
+    const unsigned n_rs = (unsigned)a.n_rows * (unsigned)a.nseg;
+    const unsigned u_lo = (unsigned)(((unsigned long long)n_rs * blockIdx.x) / gridDim.x);
+    const unsigned u_hi = (unsigned)(((unsigned long long)n_rs * (blockIdx.x + 1)) / gridDim.x);
+    typedef const __attribute__((address_space(4))) QueryState* const_qsp;
+    const float scale = ((const_qsp)a.qstate)[0].mx_scale;                // one scale for the whole batch
+    const int n = lane & 31, hk = lane >> 5, qsub = n >> 3, shift = n & 7;
+
+    f16x8 bo[2];                                                           // the band of ones
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = 16 * s + 8 * hk + i - shift;
+            bo[s][i] = (_Float16)((j >= 0 && j < W) ? 1.0f : 0.0f);
+        }
+
+    auto grab = [&]() -> unsigned {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(next_unit, 1);
+        return u_lo + (unsigned)__builtin_amdgcn_readfirstlane(v);
+    };
+    auto load_unit = [&](Stage& sx, unsigned uu) {
+        const unsigned ri = fast_div(uu, a.magic_nseg, (unsigned)a.nseg);
+        const unsigned sg = uu - ri * (unsigned)a.nseg;
+        stage_load<ALIGNED>(sx, a.dataset + (a.row0 + (int64_t)ri * a.row_stride) * a.T, a.T, (int)sg * PSH_SEG, nfloat, lane);
+    };
+
+    Stage st;
+    unsigned u = grab();
+    if (u < u_hi) load_unit(st, u);
+    while (u < u_hi) {
+        const unsigned ri = fast_div(u, a.magic_nseg, (unsigned)a.nseg);
+        const unsigned sg = u - ri * (unsigned)a.nseg;
+        const int64_t row = a.row0 + (int64_t)ri * a.row_stride;
+        const int seg_start = (int)sg * PSH_SEG;
+        const int r_global = (int)(row + a.r_offset);
+
+        stage_store(st, tile, nfloat, lane);
+        float lmax = 0.0f;
+        {
+            const int nqd = (nfloat + 3) >> 2;
+#pragma unroll
+            for (int q = 0; q < PSH_NSTAGE; ++q) {
+                const int m = lane + 64 * q;
+                if (q < PSH_NSTAGE - 1 || m < nqd) {
+                    const f32x4 v = st.v[q] * scale;
+                    const f32x4 v2 = v * v;
+                    lmax = fmaxf(fmaxf(lmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                    *reinterpret_cast<f16x4*>(a1 + mx_half(4 * m)) = __builtin_convertvector(v, f16x4);
+                    *reinterpret_cast<f16x4*>(a2 + mx_half(4 * m)) = __builtin_convertvector(v2, f16x4);
+                }
+            }
+        }
+        wave_lds_fence();
+        if (npend > 0) { pend_flush(pend, npend, lcount, a, lane); npend = 0; }
+        const unsigned un = grab();
+        if (un < u_hi) load_unit(st, un);
+        // a value beyond f16 range (or no armed filter): nothing may be rejected in this segment
+        const bool keep_all = __any(!(lmax <= 128.0f)) || !(scale > 0.0f);
+
+        // window energies of the 4 row groups, and the y^ fragments, once per segment
+        f32x16 ny[4];
+        f16x8 fy[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f16x8 e0 = *reinterpret_cast<const f16x8*>(a2 + mx_half(256 * g + 8 * n + 8 * hk));
+            const f16x8 e1 = *reinterpret_cast<const f16x8*>(a2 + mx_half(256 * g + 8 * n + 16 + 8 * hk));
+            fy[g][0] = *reinterpret_cast<const f16x8*>(a1 + mx_half(256 * g + 8 * n + 8 * hk));
+            fy[g][1] = *reinterpret_cast<const f16x8*>(a1 + mx_half(256 * g + 8 * n + 16 + 8 * hk));
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ny[g][i] = 0.0f;
+            ny[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, bo[0], ny[g], 0, 0, 0);
+            ny[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, bo[1], ny[g], 0, 0, 0);
+        }
+
+#pragma unroll 1
+        for (int G = 0; G < ngroups; ++G) {
+            const f16x8 b0 = *reinterpret_cast<const f16x8*>(fragL + ((size_t)(2 * G + 0) * 64 + lane) * 8);
+            const f16x8 b1 = *reinterpret_cast<const f16x8*>(fragL + ((size_t)(2 * G + 1) * 64 + lane) * 8);
+            const int ql = 4 * G + qsub;                                   // this lane's query within the chunk
+            const float thr = keep_all ? __uint_as_float(PSH_INF_BITS) : thrL[ql];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fy[g][0], b0, ny[g], 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fy[g][1], b1, acc, 0, 0, 0);
+                float mn = fminf(fminf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+                for (int i = 3; i + 1 < 16; i += 2) mn = fminf(fminf(mn, acc[i]), acc[i + 1]);
+                mn = fminf(mn, acc[15]);
+                // values are finite here unless keep_all (then thr = +inf keeps NaN too)
+                if (!__any(!(mn > thr))) continue;
+                unsigned hm = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hm |= !(acc[r] > thr) ? (1u << r) : 0u;
+                if (ql >= nq) hm = 0u;
+                const int qg = q0 + ql;
+                const float tau = tauL[ql < PSH_MQ_CHUNK ? ql : 0];
+                while (__any(hm != 0u)) {                                  // usually one round
+                    const bool act = hm != 0u;
+                    const int r = act ? (int)__builtin_ctz(hm) : 0;
+                    hm &= hm - 1u;
+                    const int p = 256 * g + 8 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + shift;
+                    bool hit = act && (seg_start + p < a.Tp);
+                    float v = 0.0f;
+                    if (hit) {                                             // the exact chain, this lane's own query
+                        const float* xq = a.queries + (int64_t)qg * W;
+#pragma unroll
+                        for (int j = 0; j < W; ++j) {
+                            const float D = __fsub_rn(xq[j], tile[lds_pad(p + j)]);
+                            v = __builtin_fmaf(D, D, v);
+                        }
+                        hit = v < tau;
+                    }
+                    const unsigned long long mask = __ballot(hit);
+                    if (!mask) continue;
+                    const int nh = __popcll(mask);
+                    if (npend + nh > PSH_PEND) {
+                        pend_flush(pend, npend, lcount, a, lane);
+                        npend = 0;
+                        wave_lds_fence();
+                    }
+                    if (hit) {
+                        const int slot = npend + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                        pend[slot] = u32x4{__float_as_uint(v), (unsigned)r_global, (unsigned)(seg_start + p), (unsigned)qg};
+                    }
+                    npend += nh;
+                }
+            }
+        }
+        wave_lds_fence();  // all lanes done with the tile before it is overwritten
+        u = un;
+    }
+    if (npend > 0) pend_flush(pend, npend, lcount, a, lane);
+    __syncthreads();
+    const int blk = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    for (int q = (int)threadIdx.x; q < a.B; q += PSH_MQ_THREADS)
+        a.bcount[(int64_t)q * PSH_MAX_BLOCKS + blk] = lcount[q];
+}
+
+// ----------------------------------------------------------------------------------
 // the embedded scan: a general linear embedding (Foveal, user kernels) in front of the
 // distance -- reference path_embedding.py:117-132 (conv1d with a (d,1,K) kernel) feeding
 // path_distance.py:62-65, i.e. for every window t of every row
@@ -1273,8 +1473,11 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
     if (a.blockmax) {
         unsigned mb = 0u;                                  // non-negative floats order as their bit patterns
         for (int i = tid; i < a.n_blockmax; i += PSH_SELECT_THREADS) mb = max(mb, __float_as_uint(a.blockmax[i]));
-        for (int j = tid; j < a.prep.W; j += PSH_SELECT_THREADS)
-            mb = max(mb, __float_as_uint(fabsf(a.prep.queries[(int64_t)b * a.prep.W + j])));
+        // batched matrix-core scan: ONE scale for all queries (they share the f16 copy of the data)
+        const int64_t xlo = a.mq_frag ? 0 : (int64_t)b * a.prep.W;
+        const int64_t xhi = a.mq_frag ? (int64_t)a.prep.B * a.prep.W : xlo + a.prep.W;
+        for (int64_t j = xlo + tid; j < xhi; j += PSH_SELECT_THREADS)
+            mb = max(mb, __float_as_uint(fabsf(a.prep.queries[j])));
         if (mb) atomicMax(&s_maxbits, mb);
         __syncthreads();
     }
@@ -1333,6 +1536,21 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
                     }
                 }
             }
+        }
+    }
+    if (a.mq_frag) {
+        // this query's share of scan_mq_kernel's B-fragment table: group b / 4, K-step s, lane
+        // 32 hk + 8 (b & 3) + shift, element i holds -2 x~[k - shift] for k = 16 s + 8 hk + i in the band
+        __syncthreads();
+        const float sc = a.qstate[b].mx_scale;             // thread 0 above; 0 = filter not armed
+        if (tid < 256) {
+            const int i = tid & 7, shift = (tid >> 3) & 7, hk = (tid >> 6) & 1, s2 = tid >> 7;
+            const int j = 16 * s2 + 8 * hk + i - shift;
+            const bool in = j >= 0 && j < a.prep.W;
+            const float xv = in ? a.prep.queries[(int64_t)b * a.prep.W + j] : 0.0f;
+            const int ln = 32 * hk + 8 * (b & 3) + shift;
+            reinterpret_cast<_Float16*>(a.mq_frag)[(((int64_t)(b >> 2) * 2 + s2) * 64 + ln) * 8 + i] =
+                (_Float16)(in ? -2.0f * (xv * sc) : 0.0f);
         }
     }
 }
@@ -1741,6 +1959,32 @@ static hipError_t launch_scan_mx(const ScanArgs& a, int grid, hipStream_t s) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((scan_mx_kernel<20, ALIGNED>), dim3(grid), dim3(PSH_SCAN_THREADS), shmem, s, a);
+    return hipGetLastError();
+}
+
+bool scan_mq_supported(int W, int B) { return W == 20 && B >= 2; }
+
+size_t scan_mq_shmem_bytes(int tile_floats, int B) {
+    constexpr int NW = PSH_MQ_THREADS / 64;
+    return (size_t)tile_floats * NW * sizeof(float) + (size_t)(((B + 3) & ~3) + 4) * sizeof(int)
+           + (size_t)NW * PSH_PEND * 16 + (size_t)NW * 2 * PSH_MX_NHALF * sizeof(_Float16)
+           + (size_t)(PSH_MQ_CHUNK / 4) * 2 * 64 * 8 * sizeof(_Float16) + (size_t)2 * PSH_MQ_CHUNK * sizeof(float);
+}
+
+int scan_mq_chunks(int B) { return (B + PSH_MQ_CHUNK - 1) / PSH_MQ_CHUNK; }
+
+hipError_t launch_scan_mq(const ScanArgs& a, bool aligned, int grid_x, hipStream_t s) {
+    const size_t shmem = scan_mq_shmem_bytes(a.tile_floats, a.B);
+    const dim3 grid(grid_x, scan_mq_chunks(a.B));
+    if (aligned) {
+        hipError_t e = hipFuncSetAttribute((const void*)scan_mq_kernel<20, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((scan_mq_kernel<20, true>), grid, dim3(PSH_MQ_THREADS), shmem, s, a);
+    } else {
+        hipError_t e = hipFuncSetAttribute((const void*)scan_mq_kernel<20, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((scan_mq_kernel<20, false>), grid, dim3(PSH_MQ_THREADS), shmem, s, a);
+    }
     return hipGetLastError();
 }
 
