@@ -146,6 +146,8 @@ bool scan_mq_supported(int W, int B);          // batched queries on the matrix 
 size_t scan_mq_shmem_bytes(int tile_floats, int B);
 int scan_mq_chunks(int B);                      // grid.y: chunks of queries whose fragments fit LDS
 hipError_t launch_scan_mq(const ScanArgs& a, bool aligned, int grid_x, hipStream_t s);
+bool boot_mq_supported(int W);                  // bootstrap minima as matrix-core upper bounds
+hipError_t launch_boot_mq(const ScanArgs& a, bool aligned, int grid_x, hipStream_t s);
 hipError_t scan_blocks_per_cu(int W, bool aligned, bool embedded, size_t shmem, int* out);
 hipError_t launch_threshold(const ThresholdArgs& a, int B, hipStream_t s);
 hipError_t launch_select(const SelectArgs& a, int B, hipStream_t s);

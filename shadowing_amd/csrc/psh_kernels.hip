@@ -899,8 +899,14 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
 // registers, 256 VGPRs); blockIdx.y selects a chunk of PSH_MQ_CHUNK queries whose B
 // fragments (built by the threshold kernel, one common power-of-two scale) and thresholds
 // sit in LDS.  A segment holding a value beyond f16 range keeps everything (exact path).
+template <int MODE>
+__device__ __forceinline__ void emit16(const ScanArgs& a, int b, const float (&acc)[PSH_L], int nvalid, int lane,
+                                       unsigned rs, int r_global, int t_lane, float tau, float xn,
+                                       u32x4* pend, int& npend, int* lcount);      // defined with the embedded scan below
+
 #define PSH_MQ_THREADS 512
-#define PSH_MQ_CHUNK 128
+#define PSH_MQ_CHUNK 112          // queries per block pass (their fragments, thresholds and values sit in LDS)
+#define PSH_MQ_QCAP 192           // survivors of the cheap test queued per wave before a dense exact pass
 
 template <int WT, bool ALIGNED>
 __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
@@ -920,7 +926,10 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
     _Float16* fragL = hbase + (size_t)NW * 2 * PSH_MX_NHALF;               // [group][K-step][lane] x 8 halves
     float* thrL = reinterpret_cast<float*>(fragL + (size_t)(PSH_MQ_CHUNK / 4) * 2 * 64 * 8);
     float* tauL = thrL + PSH_MQ_CHUNK;
+    float* xL = tauL + PSH_MQ_CHUNK;                                       // the chunk's queries: the exact recheck reads them
+    unsigned* sq = reinterpret_cast<unsigned*>(xL + PSH_MQ_CHUNK * WT) + (size_t)wave_in_block * PSH_MQ_QCAP;   // survivor queue
     int npend = 0;
+    int nsq = 0;
 
     const int q0 = (int)blockIdx.y * PSH_MQ_CHUNK;                         // this block's queries: [q0, q0 + nq)
     const int nq = (a.B - q0) < PSH_MQ_CHUNK ? (a.B - q0) : PSH_MQ_CHUNK;
@@ -941,6 +950,7 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
             thrL[i] = i < nq ? a.qstate[q0 + i].mx_thr : -__uint_as_float(PSH_INF_BITS);   // -inf: reject everything
             tauL[i] = i < nq ? __uint_as_float(a.qstate[q0 + i].tau_bits) : 0.0f;
         }
+        for (int i = (int)threadIdx.x; i < nq * WT; i += PSH_MQ_THREADS) xL[i] = a.queries[(int64_t)q0 * WT + i];
     }
     __syncthreads();
 
@@ -1021,61 +1031,109 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
             ny[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, bo[1], ny[g], 0, 0, 0);
         }
 
+        // the exact chain for the queued survivors, one per lane
+        auto drain = [&]() {
+            wave_lds_fence();                                              // other lanes' queue entries
+            while (nsq > 0) {
+                const int m = nsq < 64 ? nsq : 64;
+                nsq -= m;
+                bool hit = lane < m;
+                const unsigned e = hit ? sq[nsq + lane] : 0u;
+                const int p = (int)(e & 0xffffu), ql2 = (int)(e >> 16);
+                hit = hit && (seg_start + p < a.Tp);
+                float v = 0.0f;
+                if (hit) {
+                    const float* xq = xL + ql2 * W;
+#pragma unroll
+                    for (int j2 = 0; j2 < W; ++j2) {
+                        const float D = __fsub_rn(xq[j2], tile[lds_pad(p + j2)]);
+                        v = __builtin_fmaf(D, D, v);
+                    }
+                    hit = v < tauL[ql2];
+                }
+                const unsigned long long mask = __ballot(hit);
+                if (!mask) continue;
+                const int nh = __popcll(mask);
+                if (npend + nh > PSH_PEND) {
+                    pend_flush(pend, npend, lcount, a, lane);
+                    npend = 0;
+                    wave_lds_fence();
+                }
+                if (hit) {
+                    const int slot = npend + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                 __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    pend[slot] = u32x4{__float_as_uint(v), (unsigned)r_global, (unsigned)(seg_start + p), (unsigned)(q0 + ql2)};
+                }
+                npend += nh;
+            }
+            wave_lds_fence();                                              // queue slots are reused
+        };
+
 #pragma unroll 1
         for (int G = 0; G < ngroups; ++G) {
             const f16x8 b0 = *reinterpret_cast<const f16x8*>(fragL + ((size_t)(2 * G + 0) * 64 + lane) * 8);
             const f16x8 b1 = *reinterpret_cast<const f16x8*>(fragL + ((size_t)(2 * G + 1) * 64 + lane) * 8);
             const int ql = 4 * G + qsub;                                   // this lane's query within the chunk
             const float thr = keep_all ? __uint_as_float(PSH_INF_BITS) : thrL[ql];
+            // all 8 MFMAs of the group first (4 independent accumulator tiles), then the tests:
+            // a test-and-branch per tile serialises MFMA latency, min tree and branch 4 times
+            f32x16 acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fy[g][0], b0, ny[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fy[g][1], b1, acc[g], 0, 0, 0);
+            float mn[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fy[g][0], b0, ny[g], 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fy[g][1], b1, acc, 0, 0, 0);
-                float mn = fminf(fminf(acc[0], acc[1]), acc[2]);
+                float m2 = fminf(fminf(acc[g][0], acc[g][1]), acc[g][2]);
 #pragma unroll
-                for (int i = 3; i + 1 < 16; i += 2) mn = fminf(fminf(mn, acc[i]), acc[i + 1]);
-                mn = fminf(mn, acc[15]);
-                // values are finite here unless keep_all (then thr = +inf keeps NaN too)
-                if (!__any(!(mn > thr))) continue;
-                unsigned hm = 0u;
+                for (int i = 3; i + 1 < 16; i += 2) m2 = fminf(fminf(m2, acc[g][i]), acc[g][i + 1]);
+                mn[g] = fminf(m2, acc[g][15]);
+            }
+            // values are finite here unless keep_all (then thr = +inf keeps NaN too)
+            if (!__any(!(fminf(fminf(mn[0], mn[1]), fminf(mn[2], mn[3])) > thr))) continue;
+            // survivors are only QUEUED here (window, query): a lane-by-lane exact chain would run ~140
+            // instructions for the one or two lanes that hold a survivor; the queue is drained 64 at a time
+            const bool lane_ok = ql < nq;
+            const int nsq0 = nsq;
+            bool full = false;                                             // wave-uniform
 #pragma unroll
-                for (int r = 0; r < 16; ++r) hm |= !(acc[r] > thr) ? (1u << r) : 0u;
-                if (ql >= nq) hm = 0u;
-                const int qg = q0 + ql;
-                const float tau = tauL[ql < PSH_MQ_CHUNK ? ql : 0];
-                while (__any(hm != 0u)) {                                  // usually one round
-                    const bool act = hm != 0u;
-                    const int r = act ? (int)__builtin_ctz(hm) : 0;
-                    hm &= hm - 1u;
-                    const int p = 256 * g + 8 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + shift;
-                    bool hit = act && (seg_start + p < a.Tp);
-                    float v = 0.0f;
-                    if (hit) {                                             // the exact chain, this lane's own query
-                        const float* xq = a.queries + (int64_t)qg * W;
+            for (int g = 0; g < 4; ++g) {
+                if (!__any(!(mn[g] > thr))) continue;
 #pragma unroll
-                        for (int j = 0; j < W; ++j) {
-                            const float D = __fsub_rn(xq[j], tile[lds_pad(p + j)]);
-                            v = __builtin_fmaf(D, D, v);
-                        }
-                        hit = v < tau;
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned long long M = __ballot(lane_ok && !(acc[g][r] > thr));
+                    if (!M) continue;                                      // wave-uniform
+                    const int nh = __popcll(M);
+                    if (nsq + nh > PSH_MQ_QCAP) { full = true; continue; }
+                    if ((M >> lane) & 1ull) {
+                        const int p = 256 * g + 8 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + shift;
+                        const int slot = nsq + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(M >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo((unsigned)M, 0u));
+                        sq[slot] = ((unsigned)ql << 16) | (unsigned)p;
                     }
-                    const unsigned long long mask = __ballot(hit);
-                    if (!mask) continue;
-                    const int nh = __popcll(mask);
-                    if (npend + nh > PSH_PEND) {
-                        pend_flush(pend, npend, lcount, a, lane);
-                        npend = 0;
-                        wave_lds_fence();
-                    }
-                    if (hit) {
-                        const int slot = npend + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                        pend[slot] = u32x4{__float_as_uint(v), (unsigned)r_global, (unsigned)(seg_start + p), (unsigned)qg};
-                    }
-                    npend += nh;
+                    nsq += nh;
                 }
             }
+            if (full) {
+                // more survivors in one group than the queue holds (massive near-ties, or nothing may be
+                // rejected in this segment): forget the group's entries and run its queries exactly
+                nsq = nsq0;
+                const int t_lane = seg_start + PSH_L * lane;
+                int nvalid = a.Tp - t_lane;
+                nvalid = nvalid < 0 ? 0 : (nvalid > PSH_L ? PSH_L : nvalid);
+#pragma unroll 1
+                for (int c = 0; c < 4; ++c) {
+                    const int ql2 = 4 * G + c;
+                    if (ql2 >= nq) break;
+                    float accv[PSH_L];
+                    accumulate16<WT>(tile, lane, (const_f32p)a.queries + (int64_t)(q0 + ql2) * W, W, accv);
+                    emit16<PSH_MODE_FILTER>(a, q0 + ql2, accv, nvalid, lane, u, r_global, t_lane, tauL[ql2], 0.0f, pend, npend, lcount);
+                }
+            }
+            if (nsq >= 64) drain();                                        // the ONE in-loop call site (the body is ~200 instructions)
         }
+        if (nsq > 0) drain();
         wave_lds_fence();  // all lanes done with the tile before it is overwritten
         u = un;
     }
@@ -1084,6 +1142,209 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
     const int blk = (int)(blockIdx.y * gridDim.x + blockIdx.x);
     for (int q = (int)threadIdx.x; q < a.B; q += PSH_MQ_THREADS)
         a.bcount[(int64_t)q * PSH_MAX_BLOCKS + blk] = lcount[q];
+}
+
+// ----------------------------------------------------------------------------------
+// the bootstrap on the matrix cores: upper bounds instead of exact minima
+// ----------------------------------------------------------------------------------
+// tau only has to be an upper bound of the k-th smallest acc, and the f16 product that
+// rejects windows in the full scan bounds acc from ABOVE just as rigorously:
+//     acc~ (1 - 2a) <= nx~ (1 + 3a) + t^ + b
+// so the minimum of that bound over a segment is an acc-or-more of one particular window of
+// the segment, and the k-th smallest of those minima still has k windows at or below it.
+// Same layout as scan_mq_kernel (4 queries x 8 shifts; a single query rides in a group of
+// its own), the scale comes from the queries alone (the bootstrap runs before anything is
+// known about the data): a segment holding |y~| > 128 falls back to the exact chain.
+// Also records the largest |y| per block for the scale of the full scan.
+template <int WT, bool ALIGNED>
+__global__ __launch_bounds__(PSH_MQ_THREADS) void boot_mq_kernel(ScanArgs a) {
+    static_assert(WT >= 1 && WT <= 25, "query + 7 shifts must fit K = 32");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NW = PSH_MQ_THREADS / 64;
+    const int lane = lane_id();
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float* tile = smem + (size_t)wave_in_block * a.tile_floats;
+    int* next_unit = reinterpret_cast<int*>(smem + (size_t)NW * a.tile_floats);      // [0] cursor, [1] max bits, [2] query max bits
+    _Float16* hbase = reinterpret_cast<_Float16*>(next_unit + 4);
+    _Float16* a1 = hbase + (size_t)wave_in_block * 2 * PSH_MX_NHALF;
+    _Float16* a2 = a1 + PSH_MX_NHALF;
+    _Float16* fragL = hbase + (size_t)NW * 2 * PSH_MX_NHALF;
+    float* nxL = reinterpret_cast<float*>(fragL + (size_t)(PSH_MQ_CHUNK / 4) * 2 * 64 * 8);   // nx~ per query of the chunk
+
+    constexpr int W = WT;
+    const int q0 = (int)blockIdx.y * PSH_MQ_CHUNK;
+    const int nq = (a.B - q0) < PSH_MQ_CHUNK ? (a.B - q0) : PSH_MQ_CHUNK;
+    const int ngroups = (nq + 3) >> 2;
+    if (threadIdx.x == 0) { next_unit[0] = 0; next_unit[1] = 0; next_unit[2] = 0; }
+    {
+        unsigned* z = reinterpret_cast<unsigned*>(a1);
+        for (int i = lane; i < PSH_MX_NHALF; i += 64) z[i] = 0u;
+    }
+    __syncthreads();
+    {   // scale: the largest |x| of the whole batch into [4, 8)
+        unsigned mb = 0u;
+        for (int64_t j = threadIdx.x; j < (int64_t)a.B * W; j += PSH_MQ_THREADS) mb = max(mb, __float_as_uint(fabsf(a.queries[j])));
+        if (mb) atomicMax(reinterpret_cast<unsigned*>(next_unit + 2), mb);
+    }
+    __syncthreads();
+    const unsigned qmaxbits = (unsigned)next_unit[2];
+    const int sexp = 3 - ((int)((qmaxbits >> 23) & 255u) - 126);
+    const bool sane = sexp <= 60 && sexp >= -60 && qmaxbits >= 0x00800000u && qmaxbits < PSH_INF_BITS;
+    const float scale = sane ? __uint_as_float((unsigned)(127 + sexp) << 23) : 0.0f;     // 0: exact chain everywhere
+    const float unscale2 = sane ? __uint_as_float((unsigned)(127 - 2 * sexp) << 23) : 0.0f;
+    for (int i = (int)threadIdx.x; i < ngroups * 2 * 64 * 8; i += PSH_MQ_THREADS) {
+        // fragment table entry i = ((2 G + s) * 64 + lane) * 8 + e
+        const int e = i & 7, ln = (i >> 3) & 63, s2 = (i >> 9) & 1, G = i >> 10;
+        const int hk = ln >> 5, qsub = (ln & 31) >> 3, shift = ln & 7;
+        const int j = 16 * s2 + 8 * hk + e - shift, ql = 4 * G + qsub;
+        const bool in = j >= 0 && j < W && ql < nq;
+        const float xv = in ? a.queries[(int64_t)(q0 + ql) * W + j] : 0.0f;
+        fragL[i] = (_Float16)(in ? -2.0f * (xv * scale) : 0.0f);
+    }
+    for (int i = (int)threadIdx.x; i < PSH_MQ_CHUNK; i += PSH_MQ_THREADS) {
+        float s = 0.0f;
+        if (i < nq)
+            for (int j = 0; j < W; ++j) { const float v = a.queries[(int64_t)(q0 + i) * W + j] * scale; s = __builtin_fmaf(v, v, s); }
+        nxL[i] = s;
+    }
+    __syncthreads();
+
+    const int nfloat = PSH_SEG + W - 1;
+    const unsigned n_rs = (unsigned)a.n_rows * (unsigned)a.nseg;
+    const unsigned u_lo = (unsigned)(((unsigned long long)n_rs * blockIdx.x) / gridDim.x);
+    const unsigned u_hi = (unsigned)(((unsigned long long)n_rs * (blockIdx.x + 1)) / gridDim.x);
+    const int n = lane & 31, hk = lane >> 5, qsub = n >> 3, shift = n & 7;
+    const const_f32p xk = (const_f32p)a.queries;
+    // acc~ <= (nx~ (1 + 3a) + t^ + b) / (1 - 2a), a = 2^-9, b = 2^-18; constants rounded up, fp32 slack included
+    const float C1 = 1.0f + 3.0f / 512.0f + 1.0f / 65536.0f, C2 = (1.0f / (1.0f - 2.0f / 512.0f)) * (1.0f + 1.0f / 32768.0f);
+    const float BB = 1.0f / 262144.0f;
+
+    f16x8 bo[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = 16 * s + 8 * hk + i - shift;
+            bo[s][i] = (_Float16)((j >= 0 && j < W) ? 1.0f : 0.0f);
+        }
+    auto grab = [&]() -> unsigned {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(next_unit, 1);
+        return u_lo + (unsigned)__builtin_amdgcn_readfirstlane(v);
+    };
+    auto load_unit = [&](Stage& sx, unsigned uu) {
+        const unsigned ri = fast_div(uu, a.magic_nseg, (unsigned)a.nseg);
+        const unsigned sg = uu - ri * (unsigned)a.nseg;
+        stage_load<ALIGNED>(sx, a.dataset + (a.row0 + (int64_t)ri * a.row_stride) * a.T, a.T, (int)sg * PSH_SEG, nfloat, lane);
+    };
+
+    float wmax = 0.0f;
+    Stage st;
+    unsigned u = grab();
+    if (u < u_hi) load_unit(st, u);
+    while (u < u_hi) {
+        const unsigned ri = fast_div(u, a.magic_nseg, (unsigned)a.nseg);
+        const unsigned sg = u - ri * (unsigned)a.nseg;
+        const int seg_start = (int)sg * PSH_SEG;
+        const bool ragged = seg_start + PSH_SEG > a.Tp;        // some windows of this segment are not admissible
+
+        float lmax = 0.0f;
+        {
+            const int nqd = (nfloat + 3) >> 2;
+#pragma unroll
+            for (int q = 0; q < PSH_NSTAGE; ++q) {
+                const int m = lane + 64 * q;
+                if (q < PSH_NSTAGE - 1 || m < nqd) {
+                    lmax = fmaxf(fmaxf(lmax, fmaxf(fabsf(st.v[q][0]), fabsf(st.v[q][1]))), fmaxf(fabsf(st.v[q][2]), fabsf(st.v[q][3])));
+                    const f32x4 v = st.v[q] * scale;
+                    const f32x4 v2 = v * v;
+                    *reinterpret_cast<f16x4*>(a1 + mx_half(4 * m)) = __builtin_convertvector(v, f16x4);
+                    *reinterpret_cast<f16x4*>(a2 + mx_half(4 * m)) = __builtin_convertvector(v2, f16x4);
+                }
+            }
+        }
+        wmax = fmaxf(wmax, lmax);
+        const bool exact = __any(!(lmax * scale <= 128.0f)) || !(scale > 0.0f);   // beyond f16 range: exact chain
+        if (exact) stage_store(st, tile, nfloat, lane);
+        wave_lds_fence();
+        const unsigned un = grab();
+        if (un < u_hi) load_unit(st, un);
+
+        if (!exact) {
+            f32x16 ny[4];
+            f16x8 fy[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f16x8 e0 = *reinterpret_cast<const f16x8*>(a2 + mx_half(256 * g + 8 * n + 8 * hk));
+                const f16x8 e1 = *reinterpret_cast<const f16x8*>(a2 + mx_half(256 * g + 8 * n + 16 + 8 * hk));
+                fy[g][0] = *reinterpret_cast<const f16x8*>(a1 + mx_half(256 * g + 8 * n + 8 * hk));
+                fy[g][1] = *reinterpret_cast<const f16x8*>(a1 + mx_half(256 * g + 8 * n + 16 + 8 * hk));
+#pragma unroll
+                for (int i = 0; i < 16; ++i) ny[g][i] = 0.0f;
+                ny[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, bo[0], ny[g], 0, 0, 0);
+                ny[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, bo[1], ny[g], 0, 0, 0);
+            }
+#pragma unroll 1
+            for (int G = 0; G < ngroups; ++G) {
+                const f16x8 b0 = *reinterpret_cast<const f16x8*>(fragL + ((size_t)(2 * G + 0) * 64 + lane) * 8);
+                const f16x8 b1 = *reinterpret_cast<const f16x8*>(fragL + ((size_t)(2 * G + 1) * 64 + lane) * 8);
+                const int ql = 4 * G + qsub;
+                float mn = __uint_as_float(PSH_INF_BITS);
+                f32x16 acc[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fy[g][0], b0, ny[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fy[g][1], b1, acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (ragged) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int p = 256 * g + 8 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + shift;
+                            acc[g][r] = (seg_start + p < a.Tp) ? acc[g][r] : __uint_as_float(PSH_INF_BITS);
+                        }
+                    }
+                    float m2 = fminf(fminf(acc[g][0], acc[g][1]), acc[g][2]);
+#pragma unroll
+                    for (int i = 3; i + 1 < 16; i += 2) m2 = fminf(fminf(m2, acc[g][i]), acc[g][i + 1]);
+                    mn = fminf(mn, fminf(m2, acc[g][15]));
+                }
+                // lanes of one query: 8 shifts x 2 halves
+                mn = fminf(mn, __shfl_xor(mn, 1, 64));
+                mn = fminf(mn, __shfl_xor(mn, 2, 64));
+                mn = fminf(mn, __shfl_xor(mn, 4, 64));
+                mn = fminf(mn, __shfl_xor(mn, 32, 64));
+                if (shift == 0 && hk == 0 && ql < nq) {
+                    const float ub = (__builtin_fmaf(nxL[ql], C1, mn) + BB) * C2;      // scaled units, >= acc~
+                    a.minbuf[(int64_t)(q0 + ql) * a.min_stride + (int64_t)u] = ub * unscale2;
+                }
+            }
+        } else {
+            const int t_lane = seg_start + PSH_L * lane;
+            int nvalid = a.Tp - t_lane;
+            nvalid = nvalid < 0 ? 0 : (nvalid > PSH_L ? PSH_L : nvalid);
+#pragma unroll 1
+            for (int ql = 0; ql < nq; ++ql) {
+                float acc[PSH_L];
+                accumulate16<WT>(tile, lane, xk + (int64_t)(q0 + ql) * W, W, acc);
+                float m = __uint_as_float(PSH_INF_BITS);
+#pragma unroll
+                for (int i = 0; i < PSH_L; ++i) m = (i < nvalid) ? fminf(m, acc[i]) : m;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+                if (lane == 0) a.minbuf[(int64_t)(q0 + ql) * a.min_stride + (int64_t)u] = m;
+            }
+        }
+        wave_lds_fence();
+        u = un;
+    }
+    if (a.blockmax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off, 64));
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(next_unit + 1), __float_as_uint(wmax));
+        __syncthreads();
+        if (threadIdx.x == 0) a.blockmax[blockIdx.y * gridDim.x + blockIdx.x] = __uint_as_float((unsigned)next_unit[1]);
+    }
 }
 
 // ----------------------------------------------------------------------------------
@@ -1968,10 +2229,34 @@ size_t scan_mq_shmem_bytes(int tile_floats, int B) {
     constexpr int NW = PSH_MQ_THREADS / 64;
     return (size_t)tile_floats * NW * sizeof(float) + (size_t)(((B + 3) & ~3) + 4) * sizeof(int)
            + (size_t)NW * PSH_PEND * 16 + (size_t)NW * 2 * PSH_MX_NHALF * sizeof(_Float16)
-           + (size_t)(PSH_MQ_CHUNK / 4) * 2 * 64 * 8 * sizeof(_Float16) + (size_t)2 * PSH_MQ_CHUNK * sizeof(float);
+           + (size_t)(PSH_MQ_CHUNK / 4) * 2 * 64 * 8 * sizeof(_Float16) + (size_t)2 * PSH_MQ_CHUNK * sizeof(float)
+           + (size_t)PSH_MQ_CHUNK * 20 * sizeof(float) + (size_t)NW * PSH_MQ_QCAP * sizeof(unsigned);
 }
 
 int scan_mq_chunks(int B) { return (B + PSH_MQ_CHUNK - 1) / PSH_MQ_CHUNK; }
+
+bool boot_mq_supported(int W) { return W == 20; }
+
+size_t boot_mq_shmem_bytes(int tile_floats) {
+    constexpr int NW = PSH_MQ_THREADS / 64;
+    return (size_t)tile_floats * NW * sizeof(float) + 16 + (size_t)NW * 2 * PSH_MX_NHALF * sizeof(_Float16)
+           + (size_t)(PSH_MQ_CHUNK / 4) * 2 * 64 * 8 * sizeof(_Float16) + (size_t)PSH_MQ_CHUNK * sizeof(float);
+}
+
+hipError_t launch_boot_mq(const ScanArgs& a, bool aligned, int grid_x, hipStream_t s) {
+    const size_t shmem = boot_mq_shmem_bytes(a.tile_floats);
+    const dim3 grid(grid_x, scan_mq_chunks(a.B));
+    if (aligned) {
+        hipError_t e = hipFuncSetAttribute((const void*)boot_mq_kernel<20, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((boot_mq_kernel<20, true>), grid, dim3(PSH_MQ_THREADS), shmem, s, a);
+    } else {
+        hipError_t e = hipFuncSetAttribute((const void*)boot_mq_kernel<20, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((boot_mq_kernel<20, false>), grid, dim3(PSH_MQ_THREADS), shmem, s, a);
+    }
+    return hipGetLastError();
+}
 
 hipError_t launch_scan_mq(const ScanArgs& a, bool aligned, int grid_x, hipStream_t s) {
     const size_t shmem = scan_mq_shmem_bytes(a.tile_floats, a.B);

@@ -286,4 +286,14 @@ def test_matrix_core_and_valu_filters_admit_the_same_windows(hip_device, monkeyp
     d2, i2, s2, p2 = hip_scan(hip_device, ds, q, 1024, 20, profile=True)
     assert s1[0] == 0 and s2[0] == 0
     assert_exact(d1, i1, d2, i2, "mx vs valu filter")
-    assert p1["n_candidates"] == p2["n_candidates"]             # the exact test decides admission in both
+    assert p1["n_candidates"] == p2["n_candidates"]             # same tau, and the exact test decides admission in both
+
+    # batched queries: the matrix-core bootstrap bounds tau from above (a little looser), the result is the same
+    q4 = syn.rolling_queries(6, 20, 79)
+    monkeypatch.delenv("PSH_FILTER")
+    d3, i3, s3, p3 = hip_scan(hip_device, ds, q4, 1024, 20, profile=True)
+    monkeypatch.setenv("PSH_FILTER", "valu")
+    d4, i4, s4, p4 = hip_scan(hip_device, ds, q4, 1024, 20, profile=True)
+    assert not s3.any() and not s4.any()
+    assert_exact(d3, i3, d4, i4, "mq vs valu filter")
+    assert p4["n_candidates"] <= p3["n_candidates"] <= 1.5 * p4["n_candidates"]
