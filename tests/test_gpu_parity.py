@@ -297,3 +297,37 @@ def test_matrix_core_and_valu_filters_admit_the_same_windows(hip_device, monkeyp
     assert not s3.any() and not s4.any()
     assert_exact(d3, i3, d4, i4, "mq vs valu filter")
     assert p4["n_candidates"] <= p3["n_candidates"] <= 1.5 * p4["n_candidates"]
+
+
+@pytest.mark.parametrize("kind", ["spikes", "tiny_query", "planted", "one_loud_row", "f16_overflow_inf", "zero_rows"])
+def test_batched_matrix_core_scan_is_exact_on_adversarial_data(hip_device, oracle_mod, kind):
+    """scan_mq_kernel / boot_mq_kernel (4 queries x 8 shifts per MFMA): same guarantee for a batch."""
+    R, T, h, k, B = 5000, 2048, 9, 300, 7                        # B = 7: a ragged last query group
+    ds, q1 = _adversarial(kind, R, T, 950 + MX_KINDS.index(kind))
+    q = np.concatenate([q1, syn.gbm_log_returns((B - 1, 20), 960) * np.float32(q1.std() / 0.0126 + 1e-30)], 0)
+    if kind == "planted":
+        q[3] = ds[11, 500:520]                                    # one query is an exact window of the data
+    d, idx, status, prof = hip_scan(hip_device, ds, q, k, h, profile=True)
+    assert prof["path"] == 0
+    bad = np.nonzero(status)[0]
+    if bad.size:
+        d2, idx2, _, _ = hip_scan(hip_device, ds, q[bad], k, h, exhaustive=True)
+        d[bad], idx[bad] = d2, idx2
+    od, oidx = oracle_mod.scan_topk(ds, q, k, h=h)
+    assert_exact(d, idx, od, oidx, kind)
+
+
+def test_batched_scan_with_more_survivors_than_the_queue_holds(hip_device, oracle_mod):
+    """Every row identical: every window position is a 3000-fold tie, the survivor queue of a query
+    group overflows and the group is redone with the exact chain (or the slices overflow and the host
+    reruns exhaustively): results stay exact."""
+    row = syn.dataset(1, 1500, 970)[0, 0]
+    ds = np.tile(row, (3000, 1))
+    q = np.stack([row[100:120], row[700:720], syn.gbm_log_returns((20,), 971)]).astype(np.float32)
+    d, idx, status, _ = hip_scan(hip_device, ds, q, 500, 5)
+    bad = np.nonzero(status)[0]
+    if bad.size:
+        d2, idx2, _, _ = hip_scan(hip_device, ds, q[bad], 500, 5, exhaustive=True)
+        d[bad], idx[bad] = d2, idx2
+    od, oidx = oracle_mod.scan_topk(ds, q, 500, h=5)
+    assert_exact(d, idx, od, oidx, "identical rows")
