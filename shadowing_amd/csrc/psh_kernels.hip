@@ -1634,7 +1634,7 @@ template <typename KeyFn, typename LiveFn>
 __device__ inline void radix_select64(KeyFn key_of, LiveFn live, int n, int rank, int sh_floor,
                                       SelectShared* sm, uint64_t* out_prefix, int* out_sh, bool* out_exact,
                                       int* out_remaining, bool have_minmax = false, uint64_t kmin_in = 0,
-                                      uint64_t kmax_in = 0) {
+                                      uint64_t kmax_in = 0, int good_enough_sh = -1) {
     const int tid = (int)threadIdx.x;
     constexpr unsigned NB = 1u << PSH_RB;
     uint64_t kmin = kmin_in, kmax = kmax_in;
@@ -1709,6 +1709,7 @@ __device__ inline void radix_select64(KeyFn key_of, LiveFn live, int n, int rank
         sh_done = sh;
         first = false;
         if (sm->done || sh <= sh_floor) break;
+        if (sh <= good_enough_sh) break;      // the caller only needs a bound of the rank-th key: bucket edge at 2^sh
         bits = (sh - sh_floor) < PSH_RB ? (sh - sh_floor) : PSH_RB;
         sh -= bits;
     }
@@ -1752,8 +1753,10 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
     uint64_t prefix;
     int sh, rem;
     bool exact;
+    // tau only has to bound the k-th smallest minimum from above: once the digits examined pin it to
+    // 2^15 ulps (0.4 %) the bucket's upper edge serves -- usually one pass instead of three
     radix_select64([&](int i) { return (uint64_t)(in_lds ? tkeys[i] : __float_as_uint(v[i])) << 32; },
-                   [](int) { return true; }, n, a.k, 32, &sm, &prefix, &sh, &exact, &rem);
+                   [](int) { return true; }, n, a.k, 32, &sm, &prefix, &sh, &exact, &rem, false, 0, 0, 32 + 15);
     if (tid == 0) {
         // every sampled value whose bits >> (sh-32) are <= the prefix's is among the k
         // smallest: the largest float with that truncated prefix bounds them all
