@@ -2072,7 +2072,61 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
         // one item per thread.  Pass 0 orders the 64-bit items as plain integers (distance
         // bits, then slot): exact unless two selected candidates share a distance value;
         // only then pass 1 repeats the network with the full (d, r, t) comparison.
-        for (int pass = 0; pass < 2; ++pass) {
+        {   // pass 0: every wave sorts its 64 items in registers (21 shuffle steps, no barrier), then each
+            // item finds its final position by counting, with one binary search per other run, the items
+            // below it: 15 independent 7-probe chains of LDS reads instead of 34 more exchange steps, ten of
+            // them through LDS with two block barriers each.  Keys are distinct (the slot is part of the key).
+            uint64_t mine = (tid < a.kpad) ? items[tid] : ~0ull;
+            if ((unsigned)(mine >> 32) == 0xffffffffu) mine = 0xffffffff00000000ull | (unsigned)tid;   // padding: distinct, last
+            // position inside the wave's run: count the lanes holding a smaller key (64 broadcasts and
+            // compares, no dependent chain; the 21-step shuffle network cost 5x that)
+            int wrank = 0;
+#pragma unroll 16
+            for (int j = 0; j < 64; ++j) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mine, j);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mine >> 32), j);
+                wrank += ((((uint64_t)hi << 32) | lo) < mine) ? 1 : 0;
+            }
+            __syncthreads();
+            if (tid < a.kpad) items[(tid & ~63) + wrank] = mine;      // runs of 64 (or the whole list), ascending
+            __syncthreads();
+            if (a.kpad > 64) {
+                int rank = wrank;
+                if (tid < a.kpad) {
+                    const int nruns = a.kpad >> 6, w = tid >> 6;
+                    // all (up to 16) binary searches advance together: 7 rounds of independent LDS probes
+                    int pos[16];
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) pos[c] = 0;
+#pragma unroll
+                    for (int step = 32; step > 0; step >>= 1)
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) {
+                            const int v = c < nruns ? c : w;
+                            if (items[64 * v + pos[c] + step - 1] < mine) pos[c] += step;
+                        }
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        const int v = c < nruns ? c : w;
+                        if (items[64 * v + pos[c]] < mine) pos[c] += 1;
+                        if (v != w) rank += pos[c];
+                    }
+                }
+                __syncthreads();
+                if (tid < a.kpad) items[rank] = mine;
+                __syncthreads();
+            }
+            mine = (tid < a.kpad) ? items[tid] : ~0ull;
+            if (tid == 0) sm.cnt = 0;
+            __syncthreads();
+            // any equal distance values next to each other?  Only then the order among them needs (r, t)
+            const bool tie = tid + 1 < a.kpad && (unsigned)(mine >> 32) != 0xffffffffu &&
+                             (unsigned)(items[tid + 1] >> 32) == (unsigned)(mine >> 32);
+            if (tie) sm.cnt = 1;
+            __syncthreads();
+        }
+        if (sm.cnt != 0) {
+            // pass 1 (rare): the bitonic network with the full (d, r, t) comparison
             uint64_t mine = (tid < a.kpad) ? items[tid] : ~0ull;
             for (int size = 2; size <= a.kpad; size <<= 1) {
                 for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -2087,25 +2141,14 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
                         other = __shfl_xor(mine, stride, 64);    // (quad DPP moves and a two-buffer exchange were tried: slower)
                     }
                     const bool i_am_low = (tid & stride) == 0;
-                    // the low partner keeps the smaller item in an ascending run
-                    bool other_less, mine_less;
-                    if (pass == 0) { other_less = other < mine; mine_less = mine < other; }
-                    else { other_less = item_less(other, mine, sel_rt); mine_less = item_less(mine, other, sel_rt); }
+                    const bool other_less = item_less(other, mine, sel_rt), mine_less = item_less(mine, other, sel_rt);
                     const bool take_other = (i_am_low == ascending) ? other_less : mine_less;
                     if (take_other) mine = other;
                 }
             }
             __syncthreads();
             if (tid < a.kpad) items[tid] = mine;
-            if (tid == 0) sm.cnt = 0;
             __syncthreads();
-            if (pass == 0) {      // any equal distance values next to each other?
-                const bool tie = tid + 1 < a.kpad && (unsigned)(mine >> 32) != 0xffffffffu &&
-                                 (unsigned)(items[tid + 1] >> 32) == (unsigned)(mine >> 32);
-                if (tie) sm.cnt = 1;
-                __syncthreads();
-                if (sm.cnt == 0) break;
-            }
         }
     } else {
         for (int size = 2; size <= a.kpad; size <<= 1) {
