@@ -143,3 +143,45 @@ def test_predict_runs_on_the_host_path():
     mu, _ = obj.predict(q, k=16, to_predict=lambda f: f.mean(-1), proba_name="uniform", cuda=False)
     d, paths, _ = obj.shadow(q, k=16)
     assert np.allclose(mu, paths[..., -10:].mean(-1).mean(1))
+
+
+def test_native_dispatch_rules():
+    """Which configurations the HIP kernels take (host logic only, no device needed): Identity -> the
+    plain scan, stock linear embeddings whose kernel fits LDS -> the embedded scan, everything else
+    (overridden forward, other distances/contexts, several channels, oversized kernels) -> torch."""
+    import torch
+    import shadowing_amd as sa
+    from shadowing_amd import _native
+
+    def kind(emb, dist=None, ctx=None, x=None, y=None, k=8):
+        obj = sa.PathShadowing(emb, dist or sa.RelativeMSE(), np.zeros((4, 1, 600), np.float32), ctx)
+        K = emb.kernel.shape[-1]
+        x = torch.zeros((2, 1, K)) if x is None else x
+        y = torch.zeros((4, 1, 600)) if y is None else y
+        return obj._native_kind(x, y, k)
+
+    assert kind(sa.Identity(20)) == "identity"
+    assert kind(sa.Foveal(1.15, 0.9, 126), ctx=sa.PredictionContext(252)) == "linear"
+    assert kind(sa.PathEmbedding(torch.randn(5, 1, 23))) == "linear"
+    assert kind(sa.PathEmbedding(torch.randn(64, 1, 256))) is None          # 64 x 256 taps do not fit LDS
+    assert _native.embedding_supported(32, 256) and not _native.embedding_supported(129, 4)
+
+    class Squared(sa.PathEmbedding):
+        def forward(self, x):
+            return super().forward(x) ** 2
+
+    class Padded(sa.PathEmbedding):
+        def adjust_to_context(self, context):
+            return self
+
+    class L1(sa.PathDistance):
+        def forward(self, x, y):
+            return (x - y).abs().sum(-1)
+
+    assert kind(Squared(torch.randn(3, 1, 10))) is None
+    assert kind(Padded(torch.randn(3, 1, 10))) is None
+    assert kind(sa.Identity(20), dist=L1()) is None
+    assert kind(sa.Identity(20), ctx=sa.ImputationContext((8, 4, 8))) is None
+    assert kind(sa.Identity(20), y=torch.zeros((4, 2, 600))) is None        # two channels
+    assert kind(sa.Identity(20), k=_native.PSH_MAX_K + 1) is None
+    assert kind(sa.Identity(20), x=torch.zeros((2, 1, 20), dtype=torch.float64)) is None
