@@ -545,7 +545,10 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
             const float tau = (MODE == PSH_MODE_FILTER) ? __uint_as_float(qstate_k[b].tau_bits) : 0.0f;
             const float xn = (MODE != PSH_MODE_BOOT) ? qstate_k[b].xn : 0.0f;
 
-            constexpr bool CHEAP = (MODE == PSH_MODE_FILTER) && (WT >= 17) && (WT <= 32);
+            // FILTER: the cheap quantity rejects; BOOT: the same quantity plus its error bound is an UPPER
+            // bound of acc, and upper bounds are all the threshold needs (25 lane-operations per window
+            // instead of 41 for the exact chain)
+            constexpr bool CHEAP = (MODE == PSH_MODE_FILTER || MODE == PSH_MODE_BOOT) && (WT >= 17) && (WT <= 32);
             float acc[PSH_L];
             float thr = 0.0f;
             if (CHEAP) {
@@ -561,7 +564,18 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
 #else
                 approx16<WX>(tile, lane, xv, acc, NY);     // acc[] holds t_i = ny_i - 2 c_i here
 #endif
-                thr = __builtin_fmaf(1.0f / 65536.0f, NY, qstate_k[b].thr_base);
+                if (MODE == PSH_MODE_BOOT) {
+                    // acc_i <= (nx + t_i + 2^-17 (nx + NY)) (1 + 2^-19): add nx (1 + 2^-16) + 2^-16 NY, both rounded
+                    // up generously; the query state is not set up yet (that happens in the threshold kernel)
+                    float nx = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < WX; ++j) nx = __builtin_fmaf(xv[j], xv[j], nx);
+                    const float add = __builtin_fmaf(NY, 1.0f / 65536.0f, nx * (1.0f + 1.0f / 32768.0f));
+#pragma unroll
+                    for (int i = 0; i < PSH_L; ++i) acc[i] = (acc[i] + add) * (1.0f + 1.0f / 65536.0f);
+                } else {
+                    thr = __builtin_fmaf(1.0f / 65536.0f, NY, qstate_k[b].thr_base);
+                }
             } else if (MODE == PSH_MODE_ALL && a.Tp == 1) {
 #pragma unroll
                 for (int i = 0; i < PSH_L; ++i) acc[i] = 0.0f;
