@@ -185,10 +185,11 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
 
     # ---- roofline of the dominant kernel: algorithmic bytes / live-measured duration
-    mx = (W == 20 and os.environ.get("PSH_FILTER") != "valu")
-    kernel_name = (("psh::scan_mx_kernel<20,true>" if B == 1 else "psh::scan_mq_kernel<20,true>")
+    mx = (W <= (33 if B == 1 else 25) and os.environ.get("PSH_FILTER") != "valu")
+    wt = "20" if W == 20 else "0"
+    kernel_name = (("psh::scan_mx_kernel<%s,true>" if B == 1 else "psh::scan_mq_kernel<%s,true>") % wt
                    + " (full scan: f16 matrix-core rejection test + exact fp32 recheck)" if mx
-                   else "psh::scan_kernel<%s,true,1> (full scan, VALU rejection test)" % ("20" if W == 20 else "0"))
+                   else "psh::scan_kernel<%s,true,1> (full scan, VALU rejection test)" % wt)
     alg_bytes = R * T * 4 + B * W * 4 + B * k * 12          # one read of the ensemble + query + result
     roofline = None
     if sharded is None:

@@ -489,6 +489,13 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     rc = plan_scan(device, p, p.R, &plan_f); if (rc) return rc;
     ScanArgs fa = make_scan_args(dataset, queries, p, w, plan_f, 0, 1, p.R);
     fa.use_mx = use_mx ? 1 : 0;
+    if (use_mx) {
+        // scan_mx_kernel reads the fp32 tile only window by window (no sliding refills past the segment):
+        // SEG + W - 1 values rounded up to whole float4 stores, padded layout -- every byte counts, the
+        // kernel uses 155+ of the 160 KB of LDS
+        const int logical = PSH_SEG + p.W + 3;
+        fa.tile_floats = (logical + ((logical >> 6) << 2) + 4 + 3) & ~3;
+    }
     if (const char* e = getenv("PSH_DBG_TIMES_PTR")) fa.dbg_times = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning aid
     if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_begin, s));
     int nblk = plan_f.grid;

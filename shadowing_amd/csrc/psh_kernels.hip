@@ -332,6 +332,13 @@ __device__ __forceinline__ float exact_one(const float* tile, int p, const_f32p 
     return a;
 }
 
+// the same with a run-time window length
+__device__ __forceinline__ float exact_one_rt(const float* tile, int p, const_f32p x, int W) {
+    float a = 0.0f;
+    for (int j = 0; j < W; ++j) { const float D = __fsub_rn(x[j], tile[lds_pad(p + j)]); a = __builtin_fmaf(D, D, a); }
+    return a;
+}
+
 // One-window-per-row edge case (T == W + h): the reference's numerator uses the
 // 8-lane order instead of the sequential chain (probed; see the oracle).  Only window 0
 // of segment 0 exists; exhaustive path only.
@@ -729,7 +736,7 @@ __device__ __forceinline__ int mx_half(int idx) {
 
 template <int WT, bool ALIGNED>
 __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
-    static_assert(WT >= 1 && WT <= 33, "the shifted-query band must fit K = 64");
+    static_assert(WT >= 0 && WT <= 33, "the shifted-query band must fit K = 64 (WT = 0: run-time W <= 33)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NW = PSH_SCAN_THREADS / 64;
     const int lane = lane_id();
@@ -750,7 +757,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
     }
     __syncthreads();
 
-    constexpr int W = WT;
+    const int W = WT > 0 ? WT : a.W;
     const int nfloat = PSH_SEG + W - 1;
     const unsigned n_rs = (unsigned)a.n_rows * (unsigned)a.nseg;
     const unsigned u_lo = (unsigned)(((unsigned long long)n_rs * blockIdx.x) / gridDim.x);
@@ -880,7 +887,8 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
                     const int p = 32 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + m;      // C layout: row -> window
                     bool hit = (((hm >> r) & 1u) != 0u) && (seg_start + p < a.Tp);
                     if (!__ballot(hit)) continue;
-                    const float v = hit ? exact_one<WT>(tile, p, x) : 0.0f;
+                    float v = 0.0f;
+                    if (hit) { if constexpr (WT > 0) v = exact_one<(WT > 0 ? WT : 20)>(tile, p, x); else v = exact_one_rt(tile, p, x, W); }
                     push(hit && (v < tau), v, seg_start + p);
                 }
             }
@@ -924,7 +932,7 @@ __device__ __forceinline__ void emit16(const ScanArgs& a, int b, const float (&a
 
 template <int WT, bool ALIGNED>
 __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
-    static_assert(WT >= 1 && WT <= 25, "query + 7 shifts must fit K = 32");
+    static_assert(WT >= 0 && WT <= 25, "query + 7 shifts must fit K = 32 (WT = 0: run-time W <= 25)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NW = PSH_MQ_THREADS / 64;
     const int lane = lane_id();
@@ -941,7 +949,8 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
     float* thrL = reinterpret_cast<float*>(fragL + (size_t)(PSH_MQ_CHUNK / 4) * 2 * 64 * 8);
     float* tauL = thrL + PSH_MQ_CHUNK;
     float* xL = tauL + PSH_MQ_CHUNK;                                       // the chunk's queries: the exact recheck reads them
-    unsigned* sq = reinterpret_cast<unsigned*>(xL + PSH_MQ_CHUNK * WT) + (size_t)wave_in_block * PSH_MQ_QCAP;   // survivor queue
+    unsigned* sq = reinterpret_cast<unsigned*>(xL + PSH_MQ_CHUNK * 25) + (size_t)wave_in_block * PSH_MQ_QCAP;   // survivor queue
+    const int W = WT > 0 ? WT : a.W;
     int npend = 0;
     int nsq = 0;
 
@@ -964,11 +973,10 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
             thrL[i] = i < nq ? a.qstate[q0 + i].mx_thr : -__uint_as_float(PSH_INF_BITS);   // -inf: reject everything
             tauL[i] = i < nq ? __uint_as_float(a.qstate[q0 + i].tau_bits) : 0.0f;
         }
-        for (int i = (int)threadIdx.x; i < nq * WT; i += PSH_MQ_THREADS) xL[i] = a.queries[(int64_t)q0 * WT + i];
+        for (int i = (int)threadIdx.x; i < nq * W; i += PSH_MQ_THREADS) xL[i] = a.queries[(int64_t)q0 * W + i];
     }
     __syncthreads();
 
-    constexpr int W = WT;
     const int nfloat = PSH_SEG + W - 1;
     const unsigned n_rs = (unsigned)a.n_rows * (unsigned)a.nseg;
     const unsigned u_lo = (unsigned)(((unsigned long long)n_rs * blockIdx.x) / gridDim.x);
@@ -1172,7 +1180,7 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
 // Also records the largest |y| per block for the scale of the full scan.
 template <int WT, bool ALIGNED>
 __global__ __launch_bounds__(PSH_MQ_THREADS) void boot_mq_kernel(ScanArgs a) {
-    static_assert(WT >= 1 && WT <= 25, "query + 7 shifts must fit K = 32");
+    static_assert(WT >= 0 && WT <= 25, "query + 7 shifts must fit K = 32 (WT = 0: run-time W <= 25)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NW = PSH_MQ_THREADS / 64;
     const int lane = lane_id();
@@ -1185,7 +1193,7 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void boot_mq_kernel(ScanArgs a) {
     _Float16* fragL = hbase + (size_t)NW * 2 * PSH_MX_NHALF;
     float* nxL = reinterpret_cast<float*>(fragL + (size_t)(PSH_MQ_CHUNK / 4) * 2 * 64 * 8);   // nx~ per query of the chunk
 
-    constexpr int W = WT;
+    const int W = WT > 0 ? WT : a.W;
     const int q0 = (int)blockIdx.y * PSH_MQ_CHUNK;
     const int nq = (a.B - q0) < PSH_MQ_CHUNK ? (a.B - q0) : PSH_MQ_CHUNK;
     const int ngroups = (nq + 3) >> 2;
@@ -2265,7 +2273,7 @@ size_t scan_shmem_bytes(int tile_floats, int B, int emb_d, int W) {
     return n;
 }
 
-bool scan_mx_supported(int W, int B) { return W == 20 && B == 1; }
+bool scan_mx_supported(int W, int B) { return W >= 1 && W <= 33 && B == 1; }
 
 size_t scan_mx_shmem_bytes(int tile_floats, int /*B*/) {
     return (size_t)tile_floats * (PSH_SCAN_THREADS / 64) * sizeof(float) + 32
@@ -2273,29 +2281,35 @@ size_t scan_mx_shmem_bytes(int tile_floats, int /*B*/) {
            + (size_t)(PSH_SCAN_THREADS / 64) * 2 * PSH_MX_NHALF * sizeof(_Float16);
 }
 
-template <bool ALIGNED>
-static hipError_t launch_scan_mx(const ScanArgs& a, int grid, hipStream_t s) {
-    const size_t shmem = scan_mx_shmem_bytes(a.tile_floats, a.B);
-    hipError_t e = hipFuncSetAttribute((const void*)scan_mx_kernel<20, ALIGNED>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+// launch a <WT, ALIGNED> kernel family member: W = 20 has its own instantiation, other lengths run WT = 0
+template <typename K>
+static hipError_t launch_big_lds(K kernel, dim3 grid, int threads, size_t shmem, hipStream_t s, const ScanArgs& a) {
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((scan_mx_kernel<20, ALIGNED>), dim3(grid), dim3(PSH_SCAN_THREADS), shmem, s, a);
+    hipLaunchKernelGGL(kernel, grid, dim3(threads), shmem, s, a);
     return hipGetLastError();
 }
 
-bool scan_mq_supported(int W, int B) { return W == 20 && B >= 2; }
+template <bool ALIGNED>
+static hipError_t launch_scan_mx(const ScanArgs& a, int grid, hipStream_t s) {
+    const size_t shmem = scan_mx_shmem_bytes(a.tile_floats, a.B);
+    return a.W == 20 ? launch_big_lds(scan_mx_kernel<20, ALIGNED>, dim3(grid), PSH_SCAN_THREADS, shmem, s, a)
+                     : launch_big_lds(scan_mx_kernel<0, ALIGNED>, dim3(grid), PSH_SCAN_THREADS, shmem, s, a);
+}
+
+bool scan_mq_supported(int W, int B) { return W >= 1 && W <= 25 && B >= 2; }
 
 size_t scan_mq_shmem_bytes(int tile_floats, int B) {
     constexpr int NW = PSH_MQ_THREADS / 64;
     return (size_t)tile_floats * NW * sizeof(float) + (size_t)(((B + 3) & ~3) + 4) * sizeof(int)
            + (size_t)NW * PSH_PEND * 16 + (size_t)NW * 2 * PSH_MX_NHALF * sizeof(_Float16)
            + (size_t)(PSH_MQ_CHUNK / 4) * 2 * 64 * 8 * sizeof(_Float16) + (size_t)2 * PSH_MQ_CHUNK * sizeof(float)
-           + (size_t)PSH_MQ_CHUNK * 20 * sizeof(float) + (size_t)NW * PSH_MQ_QCAP * sizeof(unsigned);
+           + (size_t)PSH_MQ_CHUNK * 25 * sizeof(float) + (size_t)NW * PSH_MQ_QCAP * sizeof(unsigned);
 }
 
 int scan_mq_chunks(int B) { return (B + PSH_MQ_CHUNK - 1) / PSH_MQ_CHUNK; }
 
-bool boot_mq_supported(int W) { return W == 20; }
+bool boot_mq_supported(int W) { return W >= 1 && W <= 25; }
 
 size_t boot_mq_shmem_bytes(int tile_floats) {
     constexpr int NW = PSH_MQ_THREADS / 64;
@@ -2306,31 +2320,21 @@ size_t boot_mq_shmem_bytes(int tile_floats) {
 hipError_t launch_boot_mq(const ScanArgs& a, bool aligned, int grid_x, hipStream_t s) {
     const size_t shmem = boot_mq_shmem_bytes(a.tile_floats);
     const dim3 grid(grid_x, scan_mq_chunks(a.B));
-    if (aligned) {
-        hipError_t e = hipFuncSetAttribute((const void*)boot_mq_kernel<20, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((boot_mq_kernel<20, true>), grid, dim3(PSH_MQ_THREADS), shmem, s, a);
-    } else {
-        hipError_t e = hipFuncSetAttribute((const void*)boot_mq_kernel<20, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((boot_mq_kernel<20, false>), grid, dim3(PSH_MQ_THREADS), shmem, s, a);
-    }
-    return hipGetLastError();
+    if (a.W == 20)
+        return aligned ? launch_big_lds(boot_mq_kernel<20, true>, grid, PSH_MQ_THREADS, shmem, s, a)
+                       : launch_big_lds(boot_mq_kernel<20, false>, grid, PSH_MQ_THREADS, shmem, s, a);
+    return aligned ? launch_big_lds(boot_mq_kernel<0, true>, grid, PSH_MQ_THREADS, shmem, s, a)
+                   : launch_big_lds(boot_mq_kernel<0, false>, grid, PSH_MQ_THREADS, shmem, s, a);
 }
 
 hipError_t launch_scan_mq(const ScanArgs& a, bool aligned, int grid_x, hipStream_t s) {
     const size_t shmem = scan_mq_shmem_bytes(a.tile_floats, a.B);
     const dim3 grid(grid_x, scan_mq_chunks(a.B));
-    if (aligned) {
-        hipError_t e = hipFuncSetAttribute((const void*)scan_mq_kernel<20, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((scan_mq_kernel<20, true>), grid, dim3(PSH_MQ_THREADS), shmem, s, a);
-    } else {
-        hipError_t e = hipFuncSetAttribute((const void*)scan_mq_kernel<20, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((scan_mq_kernel<20, false>), grid, dim3(PSH_MQ_THREADS), shmem, s, a);
-    }
-    return hipGetLastError();
+    if (a.W == 20)
+        return aligned ? launch_big_lds(scan_mq_kernel<20, true>, grid, PSH_MQ_THREADS, shmem, s, a)
+                       : launch_big_lds(scan_mq_kernel<20, false>, grid, PSH_MQ_THREADS, shmem, s, a);
+    return aligned ? launch_big_lds(scan_mq_kernel<0, true>, grid, PSH_MQ_THREADS, shmem, s, a)
+                   : launch_big_lds(scan_mq_kernel<0, false>, grid, PSH_MQ_THREADS, shmem, s, a);
 }
 
 template <bool ALIGNED, int MODE>

@@ -331,3 +331,16 @@ def test_batched_scan_with_more_survivors_than_the_queue_holds(hip_device, oracl
         d[bad], idx[bad] = d2, idx2
     od, oidx = oracle_mod.scan_topk(ds, q, 500, h=5)
     assert_exact(d, idx, od, oidx, "identical rows")
+
+
+@pytest.mark.parametrize("W,B", [(1, 1), (8, 1), (17, 1), (24, 1), (33, 1), (34, 1), (8, 3), (24, 5), (25, 6), (26, 2)])
+def test_matrix_core_kernels_at_run_time_window_lengths(hip_device, oracle_mod, W, B):
+    """W <= 33 (one query) and W <= 25 (batches) take the matrix-core kernels compiled for a run-time W;
+    W = 34 / (26, batch) are the first lengths that fall back to the VALU test."""
+    R, T, h, k = 5000, 1100, 7, 200
+    ds = syn.dataset(R, T, 1200 + W)
+    q = syn.gbm_log_returns((B, W), 1300 + W)
+    d, idx, status, prof = hip_scan(hip_device, ds, q, k, h, profile=True)
+    assert prof["path"] == 0 and not status.any()
+    od, oidx = oracle_mod.scan_topk(ds, q, k, h=h)
+    assert_exact(d, idx, od, oidx, f"W={W} B={B}")
