@@ -1122,13 +1122,22 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (!__any(!(mn[g] > thr))) continue;
+                // the survivors of this tile as a per-lane bit mask (pure VALU), then one queue round per
+                // survivor of the busiest lane (usually one): a ballot per accumulator register would put 16
+                // VALU -> SALU round trips on every tile that holds a survivor
+                unsigned hm = 0u;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const unsigned long long M = __ballot(lane_ok && !(acc[g][r] > thr));
-                    if (!M) continue;                                      // wave-uniform
+                for (int r = 0; r < 16; ++r) hm |= !(acc[g][r] > thr) ? (1u << r) : 0u;
+                if (!lane_ok) hm = 0u;
+                for (;;) {
+                    const bool act = hm != 0u;
+                    const unsigned long long M = __ballot(act);
+                    if (!M) break;
                     const int nh = __popcll(M);
-                    if (nsq + nh > PSH_MQ_QCAP) { full = true; continue; }
-                    if ((M >> lane) & 1ull) {
+                    if (nsq + nh > PSH_MQ_QCAP) { full = true; break; }
+                    if (act) {
+                        const int r = (int)__builtin_ctz(hm);
+                        hm &= hm - 1u;
                         const int p = 256 * g + 8 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + shift;
                         const int slot = nsq + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(M >> 32),
                                                      __builtin_amdgcn_mbcnt_lo((unsigned)M, 0u));
