@@ -62,9 +62,13 @@ extern "C" {
  */
 #define PSH_PROFILE_STAGES 0
 #define PSH_PROFILE_EVENTS 1
+/* flags: the k best of every query are returned in ARBITRARY order (the sharded scan merges and
+ * orders them after the all-gather anyway; saves the ordering stage of the selection kernel).
+ * Honoured by psh_scan_topk on the sampled path only. */
+#define PSH_FLAG_UNSORTED 1
 typedef struct psh_profile {
     int   mode;           /* in */
-    int   reserved;
+    int   flags;          /* in: PSH_FLAG_* */
     void* ev_scan_begin;  /* in (PSH_PROFILE_EVENTS): hipEvent_t */
     void* ev_scan_end;    /* in (PSH_PROFILE_EVENTS): hipEvent_t */
     float prep_ms;        /* query norms + state reset                      */

@@ -23,14 +23,14 @@ class NativeLibraryError(RuntimeError):
 
 
 class PshProfile(C.Structure):
-    _fields_ = [("mode", C.c_int), ("reserved", C.c_int), ("ev_scan_begin", C.c_void_p), ("ev_scan_end", C.c_void_p),
+    _fields_ = [("mode", C.c_int), ("flags", C.c_int), ("ev_scan_begin", C.c_void_p), ("ev_scan_end", C.c_void_p),
                 ("prep_ms", C.c_float), ("sample_ms", C.c_float), ("threshold_ms", C.c_float),
                 ("scan_ms", C.c_float), ("select_ms", C.c_float), ("total_ms", C.c_float),
                 ("path", C.c_int), ("n_sample_rows", C.c_int), ("grid_blocks", C.c_int),
                 ("n_candidates", C.c_int)]
 
     def as_dict(self) -> dict:
-        skip = ("mode", "reserved", "ev_scan_begin", "ev_scan_end")
+        skip = ("mode", "flags", "ev_scan_begin", "ev_scan_end")
         return {name: getattr(self, name) for name, _ in self._fields_ if name not in skip}
 
 
@@ -155,7 +155,7 @@ def query_norm(queries: torch.Tensor) -> torch.Tensor:
 def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, r_offset: int = 0,
               qnorm: torch.Tensor | None = None, workspace: Workspace | None = None,
               exhaustive: bool = False, profile: bool = False, extra_workspace_factor: float = 1.0,
-              scan_events: tuple | None = None, out: tuple | None = None):
+              scan_events: tuple | None = None, out: tuple | None = None, unsorted: bool = False):
     """Enqueue the scan on the current stream.
 
     dataset (R, T) float32 device, queries (B, W) float32 device.  Returns
@@ -165,6 +165,8 @@ def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, 
     `scan_events=(begin, end)` (two torch.cuda.Event(enable_timing=True), each recorded
     once beforehand so that the handle exists) are re-recorded on the current stream
     right around the dominant scan kernel, without any synchronisation.
+    `unsorted=True`: the k best come back in arbitrary order (PSH_FLAG_UNSORTED; for callers that
+    merge afterwards).
     """
     ds = _dev_tensor(dataset, torch.float32, "dataset")
     q = _dev_tensor(queries, torch.float32, "queries")
@@ -181,7 +183,8 @@ def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, 
         # one launch keeps a per-block append cursor per query in LDS: batch the queries
         parts = [scan_topk(ds, q[i:i + PSH_MAX_B_PER_LAUNCH].contiguous(), k, h=h, r_offset=r_offset,
                            qnorm=None if qnorm is None else qnorm[i:i + PSH_MAX_B_PER_LAUNCH].contiguous(),
-                           workspace=workspace, exhaustive=exhaustive, extra_workspace_factor=extra_workspace_factor)
+                           workspace=workspace, exhaustive=exhaustive, extra_workspace_factor=extra_workspace_factor,
+                           unsorted=unsorted)
                  for i in range(0, B, PSH_MAX_B_PER_LAUNCH)]
         return tuple(torch.cat([p[j] for p in parts], dim=0) for j in range(3))
     nbytes = int(workspace_bytes(R, T, B, W, h, k) * extra_workspace_factor)
@@ -204,6 +207,11 @@ def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, 
         prof.mode = 1
         prof.ev_scan_begin = scan_events[0].cuda_event
         prof.ev_scan_end = scan_events[1].cuda_event
+    if unsorted and not exhaustive:
+        if prof is None:
+            prof = PshProfile()
+            prof.mode = 1                 # no events given: nothing is recorded, nothing is synchronised
+        prof.flags = 1                    # PSH_FLAG_UNSORTED
     fn = load().psh_scan_topk_exhaustive if exhaustive else load().psh_scan_topk
     rc = fn(dev.index, _stream_ptr(dev), ds.data_ptr(), R, T, r_offset, q.data_ptr(),
             None if qnorm is None else qnorm.data_ptr(), B, W, h, k,

@@ -520,6 +520,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     rc = tm.mark(); if (rc) return rc;                                       // 4
 
     SelectArgs se = make_select_args(p, w, out_d, out_idx, out_status, true, nblk, 0);
+    se.unsorted_ok = (profile && (profile->flags & PSH_FLAG_UNSORTED)) ? 1 : 0;
     if (const char* e = getenv("PSH_DBG_SELECT_PTR")) se.dbg_times = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning aid
     HIP_TRY(launch_select(se, B, s));
     rc = tm.mark(); if (rc) return rc;                                       // 5

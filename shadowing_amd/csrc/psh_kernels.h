@@ -109,6 +109,7 @@ struct SelectArgs {
     int cap;
     int k, kpad;
     int skip_negative_rows;  // merge: entries with r < 0 are padding
+    int unsorted_ok;         // the k selected may be written in arbitrary order (a merge follows)
     float* out_d;
     int32_t* out_idx;
     int2* sel_rt;            // B x kpad scratch

@@ -2099,7 +2099,9 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
     mark();                                              // 6: (r,t) fetched
     // ---- bitonic sort of kpad items by (d bits, r, t): strides below 64 stay inside a
     // wave (shuffles, no barrier), only the wider ones go through LDS
-    if (a.kpad <= PSH_SELECT_THREADS) {
+    if (a.unsorted_ok) {
+        // the caller merges and orders later: the selected items stay where the collection put them
+    } else if (a.kpad <= PSH_SELECT_THREADS) {
         // one item per thread.  Pass 0 orders the 64-bit items as plain integers (distance
         // bits, then slot): exact unless two selected candidates share a distance value;
         // only then pass 1 repeats the network with the full (d, r, t) comparison.

@@ -32,13 +32,13 @@ def shard_rows(R: int, world_size: int, rank: int) -> tuple[int, int]:
 
 
 def _native_local_topk(ds2d: torch.Tensor, q: torch.Tensor, k: int, h: int, r_offset: int, workspace,
-                       out=None, check: bool = True, ker: torch.Tensor | None = None):
+                       out=None, check: bool = True, ker: torch.Tensor | None = None, unsorted: bool = False):
     """q: the query windows (B, W), or -- with `ker` (d, K), a linear embedding -- the embedded
     queries (B, d)."""
     def run(qq, exhaustive, out_):
         if ker is None:
             return _native.scan_topk(ds2d, qq, k, h=h, r_offset=r_offset, workspace=workspace, out=out_,
-                                     exhaustive=exhaustive)
+                                     exhaustive=exhaustive, unsorted=unsorted)
         return _native.scan_topk_embedded(ds2d, ker, qq, k, h=h, r_offset=r_offset, workspace=workspace, out=out_,
                                           exhaustive=exhaustive)
     d, idx, status = run(q, False, out)
@@ -114,7 +114,7 @@ class ShardedPathShadowing:
     def world_size(self) -> int:
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
-    def local_scan(self, q: torch.Tensor, k: int, out=None, check: bool = True):
+    def local_scan(self, q: torch.Tensor, k: int, out=None, check: bool = True, unsorted: bool = False):
         """This rank's candidates: (d (B,k), idx (B,k,2), status) with global row numbers,
         padded with (+inf, -1) when the shard holds fewer than k windows."""
         h = self.context.get_out_times()
@@ -126,7 +126,8 @@ class ShardedPathShadowing:
             status = None
         else:
             d, idx, status = _native_local_topk(self.dataset[:, 0, :], q, k_local, h, self.row_offset, self._workspace,
-                                                out=out if k_local == k else None, check=check, ker=self._ker)
+                                                out=out if k_local == k else None, check=check, ker=self._ker,
+                                                unsorted=unsorted)
         if k_local < k:
             B = q.shape[0]
             d = torch.cat([d, d.new_full((B, k - k_local), float("inf"))], dim=1)
@@ -154,7 +155,9 @@ class ShardedPathShadowing:
         if native and (B * k) % 2 == 0:
             send = torch.empty(3 * B * k, dtype=torch.int32, device=self.device)
             out = (send[:B * k].view(torch.float32).view(B, k), send[B * k:].view(B, k, 2))
-            d, idx, self.last_status = self.local_scan(q, k, out=out, check=check)
+            # the merge after the all-gather orders the result: the local selection may skip its ordering stage
+            exchange = G > 1 or self.always_exchange
+            d, idx, self.last_status = self.local_scan(q, k, out=out, check=check, unsorted=exchange)
             if d.data_ptr() != out[0].data_ptr():     # shard smaller than k: padded copies were made
                 out[0].copy_(d)
                 out[1].copy_(idx)

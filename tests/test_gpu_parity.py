@@ -344,3 +344,14 @@ def test_matrix_core_kernels_at_run_time_window_lengths(hip_device, oracle_mod, 
     assert prof["path"] == 0 and not status.any()
     od, oidx = oracle_mod.scan_topk(ds, q, k, h=h)
     assert_exact(d, idx, od, oidx, f"W={W} B={B}")
+
+
+def test_unsorted_flag_returns_the_same_set(hip_device, oracle_mod):
+    """PSH_FLAG_UNSORTED (what the sharded scan asks of its local selection): the k best, any order."""
+    ds = syn.dataset(4096, 2048, 1400)
+    q = syn.rolling_queries(3, 20, 1401)
+    d, idx, status, _ = hip_scan(hip_device, ds, q, 512, 20, unsorted=True)
+    assert not status.any()
+    od, oidx = oracle_mod.scan_topk(ds, q, 512, h=20)
+    dc, ic = canonical(d, idx)
+    assert_exact(dc, ic, od, oidx, "unsorted flag")
