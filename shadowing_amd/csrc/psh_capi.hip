@@ -49,6 +49,7 @@ struct Workspace {
     float* minbuf;
     int64_t min_stride;
     int* bcount;
+    int* bcount2;         // PSH_MAX_BLOCKS ints: second-class counts of the single-query matrix-core scan
     float* blockmax;      // PSH_MAX_BLOCKS floats: per-block max |y| of the bootstrap scan
     void* mq_frag;        // (B rounded up to 4) x 256 f16: B fragments of the batched matrix-core scan
     int2* sel_rt;
@@ -90,6 +91,7 @@ size_t fixed_bytes(int B, int kpad, int64_t min_stride) {
     o += align_up(sizeof(int) * (size_t)B, 256);
     o += align_up(sizeof(float) * (size_t)B * (size_t)min_stride, 256);
     o += align_up(sizeof(int) * (size_t)B * PSH_MAX_BLOCKS, 256);
+    o += align_up(sizeof(int) * PSH_MAX_BLOCKS, 256);
     o += align_up(sizeof(float) * PSH_MAX_BLOCKS, 256);
     o += align_up((size_t)512 * (size_t)((B + 3) & ~3), 256);
     o += align_up(sizeof(int2) * (size_t)B * kpad, 256);
@@ -111,6 +113,7 @@ int carve(void* ws, size_t bytes, int B, int k, int64_t min_stride, Workspace* o
     out->minbuf = (float*)p;      p += align_up(sizeof(float) * (size_t)B * (size_t)min_stride, 256);
     out->min_stride = min_stride;
     out->bcount = (int*)p;        p += align_up(sizeof(int) * (size_t)B * PSH_MAX_BLOCKS, 256);
+    out->bcount2 = (int*)p;       p += align_up(sizeof(int) * PSH_MAX_BLOCKS, 256);
     out->blockmax = (float*)p;    p += align_up(sizeof(float) * PSH_MAX_BLOCKS, 256);
     out->mq_frag = (void*)p;      p += align_up((size_t)512 * (size_t)((B + 3) & ~3), 256);
     out->sel_rt = (int2*)p;       p += align_up(sizeof(int2) * (size_t)B * kpad, 256);
@@ -480,8 +483,15 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     }
     rc = tm.mark(); if (rc) return rc;                                       // 2
 
+    // single query on the matrix cores: candidates are filed in two classes around an ESTIMATE of the k-th
+    // smallest acc (the rank2-th smallest sampled minimum ~ 2k windows of the whole ensemble below it)
+    int rank2 = 0;
+    if (use_mx) {
+        const int64_t r2 = (2 * (int64_t)k * n_sample + p.R - 1) / p.R + 8;
+        rank2 = (r2 < k && r2 <= bp.entries) ? (int)r2 : 0;
+    }
     ThresholdArgs ta{w.minbuf, w.min_stride, (int)bp.entries, w.qstate, k, 0,
-                     (use_mx || use_mq) ? w.blockmax : nullptr, n_blockmax, use_mq ? w.mq_frag : nullptr, pa};
+                     (use_mx || use_mq) ? w.blockmax : nullptr, n_blockmax, use_mq ? w.mq_frag : nullptr, rank2, pa};
     HIP_TRY(launch_threshold(ta, B, s));
     rc = tm.mark(); if (rc) return rc;                                       // 3
 
@@ -489,6 +499,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     rc = plan_scan(device, p, p.R, &plan_f); if (rc) return rc;
     ScanArgs fa = make_scan_args(dataset, queries, p, w, plan_f, 0, 1, p.R);
     fa.use_mx = use_mx ? 1 : 0;
+    fa.bcount2 = rank2 > 0 ? w.bcount2 : nullptr;
     if (use_mx) {
         // scan_mx_kernel reads the fp32 tile only window by window (no sliding refills past the segment):
         // SEG + W - 1 values rounded up to whole float4 stores, padded layout -- every byte counts, the
@@ -521,6 +532,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
 
     SelectArgs se = make_select_args(p, w, out_d, out_idx, out_status, true, nblk, 0);
     se.unsorted_ok = (profile && (profile->flags & PSH_FLAG_UNSORTED)) ? 1 : 0;
+    se.bcount2 = rank2 > 0 ? w.bcount2 : nullptr;
     if (const char* e = getenv("PSH_DBG_SELECT_PTR")) se.dbg_times = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning aid
     HIP_TRY(launch_select(se, B, s));
     rc = tm.mark(); if (rc) return rc;                                       // 5

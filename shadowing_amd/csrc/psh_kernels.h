@@ -28,7 +28,8 @@ struct QueryState {   // one per query, device, 32 bytes
     float thr_base;       // bound-then-verify filter: reject iff  ny - 2c > thr_base + 2^-16 * NY
     float mx_scale;       // matrix-core filter: power of two that brings data and query into f16 range (0 = unset)
     float mx_thr;         //   reject iff  t^ > mx_thr  (t^ = sum y~^2 - 2 sum x~ y~ on the scaled f16 copies)
-    int pad;
+    unsigned tau2_bits;   // ESTIMATE of the k-th smallest acc with a 2x margin (<= tau): candidates below it go to the
+                          //   front of a block's slice, the rest of the admitted ones to its back (see select_kernel)
 };
 
 #define PSH_MAX_BLOCKS 2048          // upper bound of the scan grid
@@ -65,6 +66,7 @@ struct ScanArgs {
     float* cand_d;           // B x cap: FILTER: one slice of `slice` entries per block;
     int2* cand_rt;           //          ALL: slot = unit * 1024 + 16 * lane + i
     int* bcount;             // B x PSH_MAX_BLOCKS: entries each block appended (FILTER)
+    int* bcount2;            // nullable: entries appended to the BACK of the slice (acc in [tau2, tau)); scan_mx_kernel
     int slice;               // entries per block slice (FILTER)
     int cap;
     unsigned long long* dbg_times;   // tuning aid (nullable): per wave {start, end} wall-clock ticks (100 MHz)
@@ -91,6 +93,7 @@ struct ThresholdArgs {
     const float* blockmax;   // nullable: per-block max |y| of the bootstrap scan
     int n_blockmax;
     void* mq_frag;           // nullable: B-fragment table of scan_mq_kernel, (B rounded up to 4) x 256 f16
+    int rank2;               // > 0: also estimate tau2 = the rank2-th smallest minimum (two-class candidate slices)
     PrepArgs prep;           // the per-query preparation runs here too (one launch less on the sampled path)
 };
 
@@ -99,6 +102,7 @@ struct SelectArgs {
     const int2* cand_rt;
     int64_t cand_stride;     // elements between queries
     const int* bcount;       // nullable: per-block slice counts (B x PSH_MAX_BLOCKS) -> compaction first
+    const int* bcount2;      // nullable: per-block counts of the entries at the BACK of the slices (second class)
     int nblk, slice;
     int key_cap;             // distance keys that fit in LDS (set by the launcher)
     int* total;              // nullable: B, number of candidates ranked

@@ -120,7 +120,7 @@ __device__ __forceinline__ void prep_query(const PrepArgs& a, int b) {
         q.thr_base = __uint_as_float(PSH_INF_BITS);   // rejects nothing until the threshold kernel sets it
         q.mx_scale = 0.0f;                            // the matrix-core filter is off until the threshold kernel arms it
         q.mx_thr = __uint_as_float(PSH_INF_BITS);
-        q.pad = 0;
+        q.tau2_bits = PSH_INF_BITS;                   // = tau until the threshold kernel estimates it
         a.qstate[b] = q;
         a.total[b] = 0;
         if (a.status) a.status[b] = PSH_STATUS_OK_;
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
     _Float16* a1 = ah;                                                    // y^
     _Float16* a2 = ah + PSH_MX_NHALF;                                     // (y~^2)^
     int npend = 0;
-    if (threadIdx.x == 0) { *next_unit = 0; lcount[0] = 0; }
+    if (threadIdx.x == 0) { *next_unit = 0; lcount[0] = 0; lcount[1] = 0; }
     {   // the tail slots no segment ever writes must hold finite values (0 * NaN poisons a row)
         unsigned* z = reinterpret_cast<unsigned*>(ah);
         for (int i = lane; i < PSH_MX_NHALF; i += 64) z[i] = 0u;          // 2 arrays x NHALF halves = NHALF dwords
@@ -766,6 +766,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
     typedef const __attribute__((address_space(4))) QueryState* const_qsp;
     const const_qsp qs = (const_qsp)a.qstate;
     const float tau = __uint_as_float(qs[0].tau_bits);
+    const float tau2 = a.bcount2 ? __uint_as_float(qs[0].tau2_bits) : tau;   // no second class without its counters
     const float scale = qs[0].mx_scale;
     const float thr = qs[0].mx_thr;
     // (if the threshold kernel could not arm the filter -- absurd magnitudes -- scale is 0 and
@@ -804,9 +805,12 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
         wave_lds_fence();
         if (lane < npend) {
             const u32x4 e = pend[lane];
-            const int pos = atomicAdd(&lcount[0], 1);
+            // below tau2 (where the k-th smallest is expected, times two): front of the slice; the rest of
+            // what tau admits: back of the slice, read only if the front lists hold fewer than k
+            const bool front = __uint_as_float(e[0]) < tau2;
+            const int pos = atomicAdd(&lcount[front ? 0 : 1], 1);
             if (pos < a.slice) {
-                const int64_t o = (int64_t)blockIdx.x * a.slice + pos;
+                const int64_t o = (int64_t)blockIdx.x * a.slice + (front ? pos : a.slice - 1 - pos);
                 a.cand_d[o] = dist_from_acc(__uint_as_float(e[0]), xn);
                 a.cand_rt[o] = make_int2((int)e[1], (int)e[2]);
             }
@@ -905,7 +909,10 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
     while (u < u_hi) u = process(st, u);
     if (npend > 0) flush();
     __syncthreads();
-    if (threadIdx.x == 0) a.bcount[blockIdx.x] = lcount[0];
+    if (threadIdx.x == 0) {
+        a.bcount[blockIdx.x] = lcount[0];
+        if (a.bcount2) a.bcount2[blockIdx.x] = lcount[1];
+    }
 }
 
 // ----------------------------------------------------------------------------------
@@ -1621,8 +1628,10 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a
 struct SelectShared {
     unsigned hist[1 << PSH_RB];
     uint64_t prefix, kmin, kmax;
+    uint64_t prefix_b;                 // radix_select64(rank_b): first-pass bucket of a second rank (an estimate)
     int remaining, done, nsel, cnt, overflow;
     int offs[PSH_MAX_BLOCKS + 1];
+    int cnt_front[PSH_MAX_BLOCKS];     // two-class slices: entries at the front of each slice
 };
 
 // min / max of the live 64-bit keys over the block (kmin > kmax when nothing is live)
@@ -1665,7 +1674,7 @@ template <typename KeyFn, typename LiveFn>
 __device__ inline void radix_select64(KeyFn key_of, LiveFn live, int n, int rank, int sh_floor,
                                       SelectShared* sm, uint64_t* out_prefix, int* out_sh, bool* out_exact,
                                       int* out_remaining, bool have_minmax = false, uint64_t kmin_in = 0,
-                                      uint64_t kmax_in = 0, int good_enough_sh = -1) {
+                                      uint64_t kmax_in = 0, int good_enough_sh = -1, int rank_b = 0) {
     const int tid = (int)threadIdx.x;
     constexpr unsigned NB = 1u << PSH_RB;
     uint64_t kmin = kmin_in, kmax = kmax_in;
@@ -1722,6 +1731,16 @@ __device__ inline void radix_select64(KeyFn key_of, LiveFn live, int n, int rank
                 if (tid >= off) inc += v;
             }
             unsigned cum = inc - sl;
+            if (first && rank_b > 0 && cum < (unsigned)rank_b && inc >= (unsigned)rank_b) {   // the second rank's bucket
+                unsigned c2 = cum;
+                int bucket_b = PER * tid;
+#pragma unroll
+                for (int q = 0; q < PER; ++q) {
+                    if (c2 < (unsigned)rank_b && c2 + h[q] >= (unsigned)rank_b) bucket_b = PER * tid + q;
+                    c2 += h[q];
+                }
+                sm->prefix_b = prefix | ((uint64_t)(unsigned)bucket_b << sh) | ((sh > 0) ? ((1ull << sh) - 1ull) : 0ull);   // upper edge
+            }
             if (cum < (unsigned)rem && inc >= (unsigned)rem) {      // exactly one lane
                 int bucket = PER * tid;
                 unsigned before = cum, hb = 0;
@@ -1761,7 +1780,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
     const float* v = a.minbuf + (int64_t)b * a.min_stride;
     const int n = a.n_entries;
     __shared__ unsigned s_maxbits;                         // largest |value| among the sampled data and this query
-    if (tid == 0) { prep_query(a.prep, b); s_maxbits = 0u; }   // ||x||, sum of squares, state reset
+    if (tid == 0) { prep_query(a.prep, b); s_maxbits = 0u; sm.prefix_b = ~0ull; }   // ||x||, sum of squares, state reset
     __syncthreads();                                       // (block-scope visibility of qstate[b] for thread 0 below)
     if (a.blockmax) {
         unsigned mb = 0u;                                  // non-negative floats order as their bit patterns
@@ -1787,7 +1806,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
     // tau only has to bound the k-th smallest minimum from above: once the digits examined pin it to
     // 2^15 ulps (0.4 %) the bucket's upper edge serves -- usually one pass instead of three
     radix_select64([&](int i) { return (uint64_t)(in_lds ? tkeys[i] : __float_as_uint(v[i])) << 32; },
-                   [](int) { return true; }, n, a.k, 32, &sm, &prefix, &sh, &exact, &rem, false, 0, 0, 32 + 15);
+                   [](int) { return true; }, n, a.k, 32, &sm, &prefix, &sh, &exact, &rem, false, 0, 0, 32 + 15, a.rank2);
     if (tid == 0) {
         // every sampled value whose bits >> (sh-32) are <= the prefix's is among the k
         // smallest: the largest float with that truncated prefix bounds them all
@@ -1797,6 +1816,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
             if (tau0 < __uint_as_float(PSH_INF_BITS) && tau0 > 0.0f) {
                 QueryState* qs = a.qstate + b;
                 qs->tau_bits = __float_as_uint(tau0);
+                qs->tau2_bits = __float_as_uint(tau0);
                 // bound-then-verify filter (see approx16): with S = nx + ny - 2c the real
                 // value of a window's sum, a window the exact fp32 chain would admit
                 // (acc < tau) satisfies  ny - 2c < tau(1+23u) - nx, and the computed
@@ -1832,6 +1852,16 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
                 }
             }
         }
+    }
+    if (a.rank2 > 0 && a.rank2 < a.k && tid == 0) {
+        // tau2: where the k-th smallest acc of the WHOLE ensemble is expected, with a 2x margin -- the
+        // rank2-th smallest sampled minimum (rank2 = 2 k * sampled rows / rows), read off the first
+        // histogram pass of the selection above (its bucket's upper edge).  Only an estimate: the scan
+        // admits with tau as before but files what is below tau2 separately, and the selection falls back
+        // to everything when fewer than k candidates are below tau2.
+        QueryState* qs = a.qstate + b;
+        const unsigned hi2 = (unsigned)(sm.prefix_b >> 32), t1 = qs->tau_bits;
+        qs->tau2_bits = (hi2 < t1) ? hi2 : t1;           // positive floats: bit order = value order
     }
     if (a.mq_frag) {
         // this query's share of scan_mq_kernel's B-fragment table: group b / 4, K-step s, lane
@@ -1881,28 +1911,39 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
     if (slices) {
         // ---- the scan left one slice per block: offs[] = exclusive prefix of their sizes
         const int* bc = a.bcount + (int64_t)b * PSH_MAX_BLOCKS;
+        const int* bc2 = a.bcount2 ? a.bcount2 + (int64_t)b * PSH_MAX_BLOCKS : nullptr;
         if (tid == 0) { sm.overflow = 0; sm.offs[0] = 0; }
         __syncthreads();
-        for (int i = tid; i < a.nblk; i += PSH_SELECT_THREADS) {
-            int c = bc[i];
-            if (c > a.slice) { c = a.slice; sm.overflow = 1; }
-            sm.offs[i + 1] = c;
-        }
-        __syncthreads();
-        for (int off = 1; off < a.nblk; off <<= 1) {            // inclusive scan of offs[1..nblk]
-            int v[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int i = tid + e * PSH_SELECT_THREADS + 1;
-                v[e] = (i <= a.nblk && i - off >= 1) ? sm.offs[i - off] : 0;
+        // two classes per slice (scan_mx_kernel): acc < tau2 at the front, [tau2, tau) at the back.  tau2 is
+        // where the k-th smallest was EXPECTED (x2): when the front lists alone hold k candidates -- the
+        // normal case, ~2k of them instead of ~17k -- the back lists are never read
+        for (int pass = 0; pass < 2; ++pass) {
+            const bool with_back = pass == 1;
+            for (int i = tid; i < a.nblk; i += PSH_SELECT_THREADS) {
+                const int cf = bc[i], cb = bc2 ? bc2[i] : 0;
+                if (cf + cb > a.slice) sm.overflow = 1;              // the two ends met: entries were lost or overwritten
+                if (bc2) sm.cnt_front[i] = cf < a.slice ? cf : a.slice;
+                int c = cf + (with_back ? cb : 0);
+                if (c > a.slice) c = a.slice;
+                sm.offs[i + 1] = c;
             }
             __syncthreads();
+            for (int off = 1; off < a.nblk; off <<= 1) {            // inclusive scan of offs[1..nblk]
+                int v[2];
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int i = tid + e * PSH_SELECT_THREADS + 1;
-                if (i <= a.nblk) sm.offs[i] += v[e];
+                for (int e = 0; e < 2; ++e) {
+                    const int i = tid + e * PSH_SELECT_THREADS + 1;
+                    v[e] = (i <= a.nblk && i - off >= 1) ? sm.offs[i - off] : 0;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int i = tid + e * PSH_SELECT_THREADS + 1;
+                    if (i <= a.nblk) sm.offs[i] += v[e];
+                }
+                __syncthreads();
             }
-            __syncthreads();
+            if (!bc2 || sm.offs[a.nblk] >= a.k) break;                // (uniform) enough candidates without the back lists
         }
         n = sm.offs[a.nblk];
         if (tid == 0 && sm.overflow && a.status) a.status[b] = PSH_STATUS_OVERFLOW_;
@@ -1911,6 +1952,12 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
     }
     mark();                                              // 1: slice prefix done
     if (tid == 0 && a.total) a.total[b] = n;
+    // entry j of slice sl: front entries first, then (two-class slices, fallback only) the back ones
+    const bool two_class = slices && a.bcount2 != nullptr;
+    auto slot = [&](int sl, int j) -> int64_t {
+        if (two_class) { const int cf = sm.cnt_front[sl]; if (j >= cf) return (int64_t)sl * a.slice + (a.slice - 1 - (j - cf)); }
+        return (int64_t)sl * a.slice + j;
+    };
     // candidate e lives at src(e): identity for flat inputs, slice lookup (binary search of
     // the owning block in LDS) otherwise -- no compaction pass over global memory
     auto src = [&](int e) -> int64_t {
@@ -1920,7 +1967,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
             const int mid = (lo + hi) >> 1;
             if (sm.offs[mid] <= e) lo = mid; else hi = mid;
         }
-        return (int64_t)lo * a.slice + (e - sm.offs[lo]);
+        return slot(lo, e - sm.offs[lo]);
     };
     // walk the candidates as (e, src) pairs without a search: a group of threads per slice
     // (flat inputs: e == src).  Four independent loads in flight per thread.
@@ -1930,8 +1977,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
             const int q = tid % tps, sstep = PSH_SELECT_THREADS / tps;
             for (int sl = tid / tps; sl < a.nblk; sl += sstep) {
                 const int e0 = sm.offs[sl], cnt = sm.offs[sl + 1] - e0;
-                const int64_t s0 = (int64_t)sl * a.slice;
-                for (int j = q; j < cnt; j += tps) body(e0 + j, s0 + j);
+                for (int j = q; j < cnt; j += tps) body(e0 + j, slot(sl, j));
             }
         } else {
             for (int e = tid; e < n; e += PSH_SELECT_THREADS) body(e, src(e));
@@ -1946,11 +1992,10 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
             const int q = tid % tps, sstep = PSH_SELECT_THREADS / tps;
             for (int sl = tid / tps; sl < a.nblk; sl += sstep) {
                 const int e0 = sm.offs[sl], cnt = sm.offs[sl + 1] - e0;
-                const float* sp = cd + (int64_t)sl * a.slice;
                 for (int j = q; j < cnt; j += 4 * tps) {
                     float v[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] = (j + u * tps < cnt) ? sp[j + u * tps] : 0.0f;
+                    for (int u = 0; u < 4; ++u) v[u] = (j + u * tps < cnt) ? cd[slot(sl, j + u * tps)] : 0.0f;
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
                         if (j + u * tps < cnt) {
@@ -2421,7 +2466,7 @@ hipError_t launch_threshold(const ThresholdArgs& a0, int B, hipStream_t s) {
 hipError_t launch_select(const SelectArgs& a0, int B, hipStream_t s) {
     SelectArgs a = a0;
     // LDS: the k items being sorted + as many staged distance keys as fit next to them
-    const size_t lds_budget = 136 * 1024;      // of 160 KB; SelectShared (static) takes ~16 KB
+    const size_t lds_budget = 128 * 1024;      // of 160 KB; SelectShared (static) takes ~25 KB
     const size_t items_bytes = (size_t)a.kpad * sizeof(uint64_t);
     int64_t key_cap = items_bytes < lds_budget ? (int64_t)((lds_budget - items_bytes) / sizeof(unsigned)) : 0;
     const int64_t n_max = a.bcount ? (int64_t)a.nblk * a.slice : (int64_t)a.n_fixed;
