@@ -64,17 +64,23 @@ struct Workspace {
 // k * R / rows windows.
 //   per-wave mode: one minimum per 1024-window segment, 1/16 of the rows (more, up to a
 //                  quarter, until there are >= 8k of them);
+//   half-segment mode (per_wave = 2; the single-query matrix-core scan, whose two-class slices keep the
+//                  selection cheap whatever tau admits): two minima per segment, half the rows -- the
+//                  bootstrap is a latency-bound launch and one segment per wave is one round trip less;
 //   per-lane mode: one minimum per 16 windows, for ensembles too small for the above;
 //   rows == 0    : sample too thin to be useful -> exhaustive path.
 struct BootPlan { int64_t rows; int per_wave; int64_t entries; };
-BootPlan boot_plan(int64_t R, int64_t Tp, int k) {
+BootPlan boot_plan(int64_t R, int64_t Tp, int k, bool halves = false) {
     BootPlan bp{0, 0, 0};
     const int64_t nseg = (Tp + PSH_SEG - 1) / PSH_SEG;
     const int64_t quarter = R / 4;
     int64_t rows = R / 16;
     const int64_t need_rows = (8 * (int64_t)k + nseg - 1) / nseg;      // >= 8k segment minima
     if (rows < need_rows) rows = need_rows;
-    if (rows >= 1 && rows <= quarter) { bp.rows = rows; bp.per_wave = 1; bp.entries = rows * nseg; return bp; }
+    if (rows >= 1 && rows <= quarter) {
+        if (halves && rows >= 2) { bp.rows = (rows + 1) / 2; bp.per_wave = 2; bp.entries = bp.rows * nseg * 2; return bp; }
+        bp.rows = rows; bp.per_wave = 1; bp.entries = rows * nseg; return bp;
+    }
     const int64_t lanes_per_row = (Tp + PSH_L - 1) / PSH_L;             // real minima per row
     rows = (32 * (int64_t)k + lanes_per_row - 1) / lanes_per_row;
     if (rows > quarter) rows = quarter;
@@ -82,7 +88,11 @@ BootPlan boot_plan(int64_t R, int64_t Tp, int k) {
     bp.rows = rows; bp.per_wave = 0; bp.entries = rows * nseg * 64;
     return bp;
 }
-int64_t boot_entries(int64_t R, int64_t Tp, int k) { return boot_plan(R, Tp, k).entries; }
+// workspace sizing: the larger of the two per-segment variants (half-segment mode rounds the rows up)
+int64_t boot_entries(int64_t R, int64_t Tp, int k) {
+    const int64_t a = boot_plan(R, Tp, k, false).entries, b = boot_plan(R, Tp, k, true).entries;
+    return a > b ? a : b;
+}
 
 // fixed part + cap * 12 bytes per query (the block slices / window slots)
 size_t fixed_bytes(int B, int kpad, int64_t min_stride) {
@@ -439,7 +449,14 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     // small problems (everything fits the candidate buffer), one-window rows (their
     // numerator uses another reduction order, handled by the exhaustive kernel only) or
     // a sample too thin to be useful: exhaustive path
-    const BootPlan bp = boot_plan(p.R, p.Tp, k);
+    // the cheap test of the full scan runs on the matrix cores where that is implemented
+    // (PSH_FILTER=valu keeps it on the vector ALUs: comparison runs, tools/)
+    bool use_mx = !p.ker && scan_mx_supported(p.W, p.B);
+    bool use_mq = !p.ker && scan_mq_supported(p.W, p.B);      // batched queries: 4 queries x 8 shifts per MFMA
+    if (const char* e = getenv("PSH_FILTER")) { if (!strcmp(e, "valu")) use_mx = use_mq = false; }
+    // (half-segment mode measured for the single-query scan: bootstrap 17.4 -> 12.3 us, but tau admits twice as
+    // much and the scan's exact rechecks cost 4.3 us more -- 135.7 vs 134.3 us per step; left off)
+    const BootPlan bp = boot_plan(p.R, p.Tp, k, false);
     const int64_t n_sample = bp.rows;
     if (p.R * ((p.Tp + PSH_SEG - 1) / PSH_SEG) * PSH_SEG + k <= (int64_t)w.cap || p.Tp == 1 || n_sample == 0)
         return run_exhaustive(device, s, dataset, queries, qnorm, p, w, out_d, out_idx, out_status, profile);
@@ -456,18 +473,13 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
 
     Plan plan_s;
     rc = plan_scan(device, p, n_sample, &plan_s); if (rc) return rc;
-    // the cheap test of the full scan runs on the matrix cores where that is implemented
-    // (PSH_FILTER=valu keeps it on the vector ALUs: comparison runs, tools/)
-    bool use_mx = !p.ker && scan_mx_supported(p.W, p.B);
-    bool use_mq = !p.ker && scan_mq_supported(p.W, p.B);      // batched queries: 4 queries x 8 shifts per MFMA
-    if (const char* e = getenv("PSH_FILTER")) { if (!strcmp(e, "valu")) use_mx = use_mq = false; }
     ScanArgs sa = make_scan_args(dataset, queries, p, w, plan_s, row0, stride, n_sample);
     sa.boot_per_wave = bp.per_wave;
     sa.blockmax = (use_mx || use_mq) ? w.blockmax : nullptr;
     int n_blockmax = plan_s.grid;
     // (a single query is better served by the exact bootstrap: 8192 segments are a latency-bound launch either
     // way -- 20.8 vs 18.7 us measured -- and the exact minima admit 9 % fewer candidates)
-    if (use_mq && bp.per_wave && boot_mq_supported(p.W)) {
+    if (use_mq && bp.per_wave == 1 && boot_mq_supported(p.W)) {
         // segment minima as matrix-core upper bounds (boot_mq_kernel) instead of exact chains
         int ncu = 0;
         HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));

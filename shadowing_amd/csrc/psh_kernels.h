@@ -62,7 +62,7 @@ struct ScanArgs {
     QueryState* qstate;
     float* minbuf;           // B x min_stride          (BOOT)
     int64_t min_stride;
-    int boot_per_wave;       // BOOT: 1 = one minimum per wave-segment, 0 = one per lane
+    int boot_per_wave;       // BOOT: 1 = one minimum per wave-segment, 2 = one per half segment, 0 = one per lane
     float* cand_d;           // B x cap: FILTER: one slice of `slice` entries per block;
     int2* cand_rt;           //          ALL: slot = unit * 1024 + 16 * lane + i
     int* bcount;             // B x PSH_MAX_BLOCKS: entries each block appended (FILTER)

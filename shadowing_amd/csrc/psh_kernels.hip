@@ -600,7 +600,11 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
 #pragma unroll
                     for (int i = 0; i < PSH_L; ++i) m = (i < nvalid) ? fminf(m, acc[i]) : m;
                 }
-                if (a.boot_per_wave) {
+                if (a.boot_per_wave == 2) {                 // one minimum per half segment (lanes 0-31 / 32-63)
+#pragma unroll
+                    for (int off = 16; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+                    if ((lane & 31) == 0) a.minbuf[(int64_t)b * a.min_stride + 2 * (int64_t)rs + (lane >> 5)] = m;
+                } else if (a.boot_per_wave) {
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
                     if (lane == 0) a.minbuf[(int64_t)b * a.min_stride + (int64_t)rs] = m;
