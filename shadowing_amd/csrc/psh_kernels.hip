@@ -1800,17 +1800,37 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
     if (n < a.k) return;                                   // tau stays +inf (host avoids this)
     const bool in_lds = a.keys_in_lds != 0;
     if (in_lds) {
+        // the keys' min / max fall out of the staging pass (the selection would otherwise re-read all of them)
+        unsigned kmin32 = 0xffffffffu, kmax32 = 0u;
+        if (tid == 0) { sm.kmin = ~0ull; sm.kmax = 0ull; }
+        __syncthreads();
 #pragma unroll 4
-        for (int i = tid; i < n; i += PSH_SELECT_THREADS) tkeys[i] = __float_as_uint(v[i]);
+        for (int i = tid; i < n; i += PSH_SELECT_THREADS) {
+            const unsigned kb = __float_as_uint(v[i]);
+            tkeys[i] = kb;
+            kmin32 = kb < kmin32 ? kb : kmin32;
+            kmax32 = kb > kmax32 ? kb : kmax32;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned l2 = __shfl_xor(kmin32, off, 64), h2 = __shfl_xor(kmax32, off, 64);
+            kmin32 = l2 < kmin32 ? l2 : kmin32;
+            kmax32 = h2 > kmax32 ? h2 : kmax32;
+        }
+        if ((tid & 63) == 0) {
+            atomicMin((unsigned long long*)&sm.kmin, (unsigned long long)kmin32 << 32);
+            atomicMax((unsigned long long*)&sm.kmax, (unsigned long long)kmax32 << 32);
+        }
         __syncthreads();
     }
+    const uint64_t kmin64 = in_lds ? sm.kmin : 0ull, kmax64 = in_lds ? sm.kmax : 0ull;
     uint64_t prefix;
     int sh, rem;
     bool exact;
     // tau only has to bound the k-th smallest minimum from above: once the digits examined pin it to
     // 2^15 ulps (0.4 %) the bucket's upper edge serves -- usually one pass instead of three
     radix_select64([&](int i) { return (uint64_t)(in_lds ? tkeys[i] : __float_as_uint(v[i])) << 32; },
-                   [](int) { return true; }, n, a.k, 32, &sm, &prefix, &sh, &exact, &rem, false, 0, 0, 32 + 15, a.rank2);
+                   [](int) { return true; }, n, a.k, 32, &sm, &prefix, &sh, &exact, &rem, in_lds, kmin64, kmax64, 32 + 15, a.rank2);
     if (tid == 0) {
         // every sampled value whose bits >> (sh-32) are <= the prefix's is among the k
         // smallest: the largest float with that truncated prefix bounds them all
