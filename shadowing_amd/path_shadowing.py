@@ -33,7 +33,7 @@ from tqdm import tqdm
 from . import _native
 from .averaging import DiscreteProba, Softmax, Uniform
 from .path_distance import PathDistance, RelativeMSE
-from .path_embedding import (ArrayType, ContextManagerBase, Identity, PathEmbedding,
+from .path_embedding import (ArrayType, ContextManagerBase, Identity, ImputationContext, PathEmbedding,
                              PredictionContext)
 
 
@@ -113,20 +113,30 @@ class PathShadowing:
           "identity": Identity + RelativeMSE + PredictionContext -- windows read in place;
           "linear"  : any other PathEmbedding whose forward is the stock conv1d (Foveal,
                       PathEmbedding(kernel)) + RelativeMSE + PredictionContext, one-window
-                      queries, kernel small enough for LDS -- psh_scan_topk_embedded."""
-        if not (type(self.distance) is RelativeMSE and type(self.context) is PredictionContext
-                and x.shape[1] == 1 and y.ndim == 3 and y.shape[1] == 1
+                      queries, kernel small enough for LDS -- psh_scan_topk_embedded;
+          "padded"  : a stock embedding (Identity included) + RelativeMSE + ImputationContext((l, c, r)):
+                      the context's zero taps over the gap are part of the scanning kernel -- the same
+                      entry point with the padded (d, l+c+r) kernel and no trailing horizon."""
+        if not (type(self.distance) is RelativeMSE and x.shape[1] == 1 and y.ndim == 3 and y.shape[1] == 1
                 and x.dtype == torch.float32 and y.dtype == torch.float32 and k <= _native.PSH_MAX_K):
             return None
         emb = self.embedding
+        stock = (isinstance(emb, PathEmbedding) and type(emb).forward is PathEmbedding.forward
+                 and type(emb).adjust_to_context is PathEmbedding.adjust_to_context
+                 and emb.kernel.ndim == 3 and emb.kernel.shape[1] == 1 and emb.kernel.dtype == torch.float32
+                 and emb.kernel.shape[-1] == x.shape[-1])
+        if type(self.context) is ImputationContext:
+            p = self.context.portion
+            if (stock and p is not None and len(p) == 3 and min(p) > 0 and p[0] + p[2] == x.shape[-1]
+                    and _native.embedding_supported(emb.kernel.shape[0], sum(p))):
+                return "padded"
+            return None
+        if type(self.context) is not PredictionContext:
+            return None
         if type(emb) is Identity:
             ok = x.shape[-1] == emb.kernel.shape[0] and x.shape[-1] <= _native.PSH_MAX_W
             return "identity" if ok else None
-        if (isinstance(emb, PathEmbedding) and type(emb).forward is PathEmbedding.forward
-                and type(emb).adjust_to_context is PathEmbedding.adjust_to_context
-                and emb.kernel.ndim == 3 and emb.kernel.shape[1] == 1 and emb.kernel.dtype == torch.float32
-                and emb.kernel.shape[-1] == x.shape[-1]
-                and _native.embedding_supported(emb.kernel.shape[0], emb.kernel.shape[-1])):
+        if stock and _native.embedding_supported(emb.kernel.shape[0], emb.kernel.shape[-1]):
             return "linear"
         return None
 
@@ -162,12 +172,18 @@ class PathShadowing:
         if k > n_windows:
             # the reference fails inside torch.topk (ref :165) with the same exception type
             raise RuntimeError("selected index k out of range")
-        if self._native_kind(x, y, k) == "linear":
+        kind = self._native_kind(x, y, k)
+        if kind in ("linear", "padded"):
             # the (tiny) query embedding stays the module's own conv1d (ref :140); the scan
-            # over the ensemble takes the unpadded kernel and the horizon as an integer
+            # over the ensemble takes the unpadded kernel and the horizon as an integer --
+            # or, for an ImputationContext, the kernel with the gap's zero taps and no horizon
             ker = self.embedding.kernel
             hx = self.embedding(x.to(ker.device))[:, 0, :].contiguous().to(dev)
-            ker2 = ker[:, 0, :].contiguous().to(dev)
+            if kind == "padded":
+                ker2 = self.context.pad_context(ker)[:, 0, :].contiguous().to(dev)
+                h = 0
+            else:
+                ker2 = ker[:, 0, :].contiguous().to(dev)
 
             def scan(sel, exhaustive):
                 q = hx if sel is None else hx[sel].contiguous()

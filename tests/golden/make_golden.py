@@ -75,10 +75,10 @@ def main():
         np.savez_compressed(HERE / f"{name}.npz", **out)
         print(f"{name}: d{d.shape} idx{idx.shape} paths{paths.shape} ref {dt:.2f}s")
 
-    def run_embedded(name, emb, ds, q, h, k, n_splits, store_dataset, meta=None):
+    def run_embedded(name, emb, ds, q, h, k, n_splits, store_dataset, meta=None, ctx=None):
         """A PathEmbedding with a (d,1,K) kernel in front of RelativeMSE: besides the outputs,
         the fixture keeps the kernel and the reference's embedded queries hx = embedding(x)."""
-        obj = ref.PathShadowing(emb, ref.RelativeMSE(), ds, ref.PredictionContext(horizon=h))
+        obj = ref.PathShadowing(emb, ref.RelativeMSE(), ds, ctx if ctx is not None else ref.PredictionContext(horizon=h))
         t0 = time.time()
         d, paths, idx = obj.shadow(q, k=k, n_splits=n_splits, cuda=False)
         dt = time.time() - t0
@@ -87,6 +87,9 @@ def main():
         out = dict(queries=q2, kernel=emb.kernel[:, 0, :].numpy(), hx=hx.numpy(), hxnorm=hx.norm(dim=-1).numpy(),
                    d=d, idx=idx, paths=paths, h=-1 if h is None else h, k=k, n_splits=n_splits,
                    dataset_sha256=syn.sha256(ds), dataset_shape=np.array(ds.shape))
+        if ctx is not None:      # the context's zero taps are part of the scanning kernel (no trailing horizon)
+            out["kernel_padded"] = ctx.pad_context(emb.kernel)[:, 0, :].numpy()
+            out["portion"] = np.array(ctx.portion)
         if store_dataset:
             out["dataset"] = ds
         else:   # generated ensemble, large k: keep the head of the gathered paths only
@@ -116,6 +119,11 @@ def main():
         wav = ref.PathEmbedding(torch.tensor(syn.wavelet_bank(5, 252))[:, None, :])
         run_embedded("wavelet_W252_rolling", wav, syn.dataset(48, 1500, 41), syn.rolling_queries(4, 252, 42),
                      20, 128, 2, True)
+        # ImputationContext: l known samples, a gap of c to impute, r known samples (path_embedding.py:59-88)
+        run_embedded("imputation_identity_8_5_12", ref.Identity(20), syn.dataset(60, 500, 43), syn.gbm_log_returns((3, 20), 44),
+                     None, 40, 2, True, ctx=ref.ImputationContext((8, 5, 12)))
+        run_embedded("imputation_user_kernel_6_9_7", ref.PathEmbedding(torch.randn(4, 1, 13, generator=g)), syn.dataset(50, 300, 45),
+                     syn.gbm_log_returns((2, 13), 46), None, 25, 1, True, ctx=ref.ImputationContext((6, 9, 7)))
         if args.big:
             # the tutorial's shape (k = 8192, horizon 252) on a generated ensemble
             run_embedded("foveal_tutorial_R1024", fov, syn.dataset(1024, 2048, 39), syn.gbm_log_returns((2, 126), 40),

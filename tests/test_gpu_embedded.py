@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import EMBEDDED_GOLDENS, assert_exact, assert_matches_reference, bits, load_golden, rows3
+from _util import EMBEDDED_GOLDENS, IMPUTATION_GOLDENS, assert_exact, assert_matches_reference, bits, load_golden, rows3
 from shadowing_amd import synthetic as syn
 
 pytestmark = pytest.mark.gpu
@@ -188,3 +188,26 @@ def test_sharded_class_with_linear_embedding_over_rccl(hip_device, oracle_mod, t
         parts.append(o.local_scan(torch.tensor(hx).to(hip_device), k)[:2])
     md, mi = _native.merge_topk(torch.cat([p[0] for p in parts], 1), torch.cat([p[1] for p in parts], 1), k)
     assert_exact(md.cpu().numpy(), mi.cpu().numpy(), od, oidx, "4 logical shards")
+
+
+@pytest.mark.parametrize("name", IMPUTATION_GOLDENS)
+def test_path_shadowing_with_an_imputation_context_runs_native(hip_device, name):
+    """PathShadowing(embedding, RelativeMSE, ds, ImputationContext((l, c, r))).shadow(cuda=True) through the
+    embedded scan (padded kernel): the reference's shadow(cuda=False) output, paths included."""
+    from shadowing import Identity, ImputationContext, PathEmbedding, PathShadowing, RelativeMSE
+    g = load_golden(name)
+    K = g["kernel"].shape[1]
+    emb = Identity(K) if name.startswith("imputation_identity") else PathEmbedding(torch.tensor(g["kernel"])[:, None, :])
+    obj = PathShadowing(emb, RelativeMSE(), g["dataset"], ImputationContext(tuple(int(v) for v in g["portion"])))
+    d, paths, idx = obj.shadow(g["queries"], k=g["k"], n_splits=g["n_splits"], cuda=True)
+    assert obj.last_path == "hip"
+    assert_matches_reference(d, idx, g, None, what=name)
+    ds = rows3(g["dataset"])
+    L = g["kernel_padded"].shape[1]
+    for b in range(d.shape[0]):
+        for i in range(d.shape[1]):
+            r, t = idx[b, i]
+            assert np.array_equal(paths[b, i, 0], ds[r, 0, t:t + L])
+    # the in-context / out-context split of the gathered paths (what predict_from_paths consumes)
+    left, gap, right = (int(v) for v in g["portion"])
+    assert obj.context.select_out_context(paths).shape[-1] == gap

@@ -181,7 +181,12 @@ def test_native_dispatch_rules():
     assert kind(Squared(torch.randn(3, 1, 10))) is None
     assert kind(Padded(torch.randn(3, 1, 10))) is None
     assert kind(sa.Identity(20), dist=L1()) is None
-    assert kind(sa.Identity(20), ctx=sa.ImputationContext((8, 4, 8))) is None
+    assert kind(sa.Identity(20), ctx=sa.ImputationContext((8, 4, 8))) is None          # l + r != window length
+    assert kind(sa.Identity(20), ctx=sa.ImputationContext((8, 5, 12))) == "padded"
+    assert kind(sa.PathEmbedding(torch.randn(4, 1, 13)), ctx=sa.ImputationContext((6, 9, 7))) == "padded"
+    assert kind(sa.Identity(20), ctx=sa.ImputationContext((8, 250, 12))) is None       # padded kernel beyond 256 taps
+    assert kind(sa.Identity(20), ctx=sa.ImputationContext(None)) is None
+    assert kind(Squared(torch.randn(3, 1, 10)), ctx=sa.ImputationContext((4, 3, 6))) is None
     assert kind(sa.Identity(20), y=torch.zeros((4, 2, 600))) is None        # two channels
     assert kind(sa.Identity(20), k=_native.PSH_MAX_K + 1) is None
     assert kind(sa.Identity(20), x=torch.zeros((2, 1, 20), dtype=torch.float64)) is None

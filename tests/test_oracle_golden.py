@@ -6,7 +6,7 @@ order among exact ties, gathered paths identical."""
 import numpy as np
 import pytest
 
-from _util import (BIG_GOLDENS, EMBEDDED_GOLDENS, SMALL_GOLDENS, assert_matches_reference, bits, canonical,
+from _util import (BIG_GOLDENS, EMBEDDED_GOLDENS, IMPUTATION_GOLDENS, SMALL_GOLDENS, assert_matches_reference, bits, canonical,
                    load_golden, rows3)
 
 
@@ -130,3 +130,16 @@ def test_embedded_oracle_is_k_minimal_against_brute_force(oracle_mod):
         order = np.lexsort((np.tile(np.arange(Tp), full.shape[0]), np.repeat(np.arange(full.shape[0]), Tp), full.ravel()))[:k]
         assert np.array_equal(bits(full.ravel()[order]), bits(d[b]))
         assert np.array_equal(np.stack([order // Tp, order % Tp], -1).astype(np.int32), idx[b])
+
+
+@pytest.mark.parametrize("name", IMPUTATION_GOLDENS)
+def test_embedded_oracle_reproduces_reference_with_an_imputation_context(oracle_mod, name):
+    """ImputationContext((l, c, r)) (path_embedding.py:59-88): pad_context puts c zero taps into the middle
+    of the kernel; the scan is the embedded scan with that padded kernel and no trailing horizon."""
+    g = load_golden(name)
+    ds = rows3(g["dataset"])
+    d, idx = oracle_mod.scan_topk_embedded(ds, g["kernel_padded"], g["hx"], g["k"], h=0)
+    all_dist = [oracle_mod.all_distances_embedded(ds, g["kernel_padded"], q, 0) for q in g["hx"]]
+    assert_matches_reference(d, idx, g, all_dist, what=name)
+    ref_paths = oracle_mod.gather_paths(ds, g["idx"], g["kernel_padded"].shape[1])[:, :, None, :]
+    assert np.array_equal(ref_paths, g["paths"])
