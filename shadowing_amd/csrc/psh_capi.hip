@@ -545,6 +545,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     SelectArgs se = make_select_args(p, w, out_d, out_idx, out_status, true, nblk, 0);
     se.unsorted_ok = (profile && (profile->flags & PSH_FLAG_UNSORTED)) ? 1 : 0;
     se.bcount2 = rank2 > 0 ? w.bcount2 : nullptr;
+    if (rank2 > 0) { se.dataset = dataset; se.queries = queries; se.T = p.T; se.r_offset = p.r_offset; se.W = p.W; }
     if (const char* e = getenv("PSH_DBG_SELECT_PTR")) se.dbg_times = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning aid
     HIP_TRY(launch_select(se, B, s));
     rc = tm.mark(); if (rc) return rc;                                       // 5

@@ -20,7 +20,7 @@
 
 namespace psh {
 
-struct QueryState {   // one per query, device, 32 bytes
+struct QueryState {   // one per query, device, 48 bytes
     float xn;             // ||x||
     unsigned tau_bits;    // admission threshold on acc (exclusive), float bits
     int n_valid;          // valid entries in out_d/out_idx after the last select
@@ -30,7 +30,10 @@ struct QueryState {   // one per query, device, 32 bytes
     float mx_thr;         //   reject iff  t^ > mx_thr  (t^ = sum y~^2 - 2 sum x~ y~ on the scaled f16 copies)
     unsigned tau2_bits;   // ESTIMATE of the k-th smallest acc with a 2x margin (<= tau): candidates below it go to the
                           //   front of a block's slice, the rest of the admitted ones to its back (see select_kernel)
+    float mx_thr2;        // the matrix-core rejection threshold that goes with tau2 (<= mx_thr)
+    int pad[3];
 };
+#define PSH_UNVERIFIED_BITS 0xffffffffu   // cand_d of a back-list entry whose exact distance was not computed by the scan
 
 #define PSH_MAX_BLOCKS 2048          // upper bound of the scan grid
 #define PSH_MAX_B_PER_LAUNCH 1024    // per-block LDS append counters: one int per query
@@ -114,6 +117,12 @@ struct SelectArgs {
     int k, kpad;
     int skip_negative_rows;  // merge: entries with r < 0 are padding
     int unsorted_ok;         // the k selected may be written in arbitrary order (a merge follows)
+    // two-class slices, fallback only: back-list entries may carry PSH_UNVERIFIED_BITS; the selection then
+    // computes their exact distance itself (single query, Identity scan)
+    const float* dataset;    // R x T
+    const float* queries;    // B x W
+    int64_t T, r_offset;
+    int W;
     float* out_d;
     int32_t* out_idx;
     int2* sel_rt;            // B x kpad scratch

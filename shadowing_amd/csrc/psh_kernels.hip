@@ -121,6 +121,8 @@ __device__ __forceinline__ void prep_query(const PrepArgs& a, int b) {
         q.mx_scale = 0.0f;                            // the matrix-core filter is off until the threshold kernel arms it
         q.mx_thr = __uint_as_float(PSH_INF_BITS);
         q.tau2_bits = PSH_INF_BITS;                   // = tau until the threshold kernel estimates it
+        q.mx_thr2 = __uint_as_float(PSH_INF_BITS);
+        q.pad[0] = q.pad[1] = q.pad[2] = 0;
         a.qstate[b] = q;
         a.total[b] = 0;
         if (a.status) a.status[b] = PSH_STATUS_OK_;
@@ -773,6 +775,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
     const float tau2 = a.bcount2 ? __uint_as_float(qs[0].tau2_bits) : tau;   // no second class without its counters
     const float scale = qs[0].mx_scale;
     const float thr = qs[0].mx_thr;
+    const float thr2 = a.bcount2 ? qs[0].mx_thr2 : thr;                      // <= thr: what cannot be below tau2
     // (if the threshold kernel could not arm the filter -- absurd magnitudes -- scale is 0 and
     // thr +inf: nothing is rejected, every window goes through exact_one: slow, still exact)
 
@@ -811,11 +814,14 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
             const u32x4 e = pend[lane];
             // below tau2 (where the k-th smallest is expected, times two): front of the slice; the rest of
             // what tau admits: back of the slice, read only if the front lists hold fewer than k
-            const bool front = __uint_as_float(e[0]) < tau2;
+            // (a window the cheap test could only place above tau2 arrives unverified -- marker instead of
+            // its acc: the exact chain is spent on it only if the selection ever has to read the back lists)
+            const bool verified = e[0] != PSH_UNVERIFIED_BITS;
+            const bool front = verified && __uint_as_float(e[0]) < tau2;
             const int pos = atomicAdd(&lcount[front ? 0 : 1], 1);
             if (pos < a.slice) {
                 const int64_t o = (int64_t)blockIdx.x * a.slice + (front ? pos : a.slice - 1 - pos);
-                a.cand_d[o] = dist_from_acc(__uint_as_float(e[0]), xn);
+                a.cand_d[o] = verified ? dist_from_acc(__uint_as_float(e[0]), xn) : __uint_as_float(PSH_UNVERIFIED_BITS);
                 a.cand_rt[o] = make_int2((int)e[1], (int)e[2]);
             }
         }
@@ -887,17 +893,25 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) keep = keep || !(acc[r] > thr);
             if (__any(keep)) {                             // about one segment in four
-                unsigned hm = 0u;                          // bit r: window of accumulator r survives
+                unsigned hm = 0u, hm2 = 0u;                // bit r: window of accumulator r survives tau / tau2
 #pragma unroll
-                for (int r = 0; r < 16; ++r) hm |= !(acc[r] > thr) ? (1u << r) : 0u;
+                for (int r = 0; r < 16; ++r) {
+                    hm |= !(acc[r] > thr) ? (1u << r) : 0u;
+                    hm2 |= !(acc[r] > thr2) ? (1u << r) : 0u;
+                }
 #pragma unroll 1
                 for (int r = 0; r < 16; ++r) {
                     const int p = 32 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + m;      // C layout: row -> window
-                    bool hit = (((hm >> r) & 1u) != 0u) && (seg_start + p < a.Tp);
+                    const bool hit = (((hm >> r) & 1u) != 0u) && (seg_start + p < a.Tp);
                     if (!__ballot(hit)) continue;
-                    float v = 0.0f;
-                    if (hit) { if constexpr (WT > 0) v = exact_one<(WT > 0 ? WT : 20)>(tile, p, x); else v = exact_one_rt(tile, p, x, W); }
-                    push(hit && (v < tau), v, seg_start + p);
+                    // the exact chain only where the window may still be below tau2; the others are admitted
+                    // unverified (they can only matter if the front lists end up short of k)
+                    const bool may2 = hit && (((hm2 >> r) & 1u) != 0u);
+                    float v = __uint_as_float(PSH_UNVERIFIED_BITS);
+                    if (__ballot(may2)) {
+                        if (may2) { if constexpr (WT > 0) v = exact_one<(WT > 0 ? WT : 20)>(tile, p, x); else v = exact_one_rt(tile, p, x, W); }
+                    }
+                    push(hit && (!may2 || v < tau), v, seg_start + p);
                 }
             }
         }
@@ -1871,6 +1885,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
                     if ((double)Tf < T) Tf = __uint_as_float(Tf >= 0.0f ? __float_as_uint(Tf) + 1u : __float_as_uint(Tf) - 1u);
                     if (sane && Tf == Tf && fabsf(Tf) < __uint_as_float(PSH_INF_BITS)) {
                         qs->mx_thr = Tf;
+                        qs->mx_thr2 = Tf;
                         qs->mx_scale = sc;
                     }
                 }
@@ -1886,6 +1901,19 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
         QueryState* qs = a.qstate + b;
         const unsigned hi2 = (unsigned)(sm.prefix_b >> 32), t1 = qs->tau_bits;
         qs->tau2_bits = (hi2 < t1) ? hi2 : t1;           // positive floats: bit order = value order
+        if (qs->mx_scale > 0.0f && hi2 < t1) {
+            // the rejection threshold for tau2: same bound, same rounding towards "keep" as mx_thr
+            const double sc = (double)qs->mx_scale;
+            const float* xq = a.prep.queries + (int64_t)b * a.prep.W;
+            double nxs = 0.0;
+            for (int j = 0; j < a.prep.W; ++j) { const double v = (double)xq[j] * sc; nxs += v * v; }
+            const double am = 1.0 / 512.0, bm = 1.0 / 262144.0;
+            const double taus = (double)__uint_as_float(hi2) * sc * sc;
+            const double T2 = taus * (1.0 + 1.0 / 131072.0) * (1.0 + 2.0 * am) - nxs * (1.0 - 3.0 * am) * (1.0 - 1e-12) + bm;
+            float Tf = (float)T2;
+            if ((double)Tf < T2) Tf = __uint_as_float(Tf >= 0.0f ? __float_as_uint(Tf) + 1u : __float_as_uint(Tf) - 1u);
+            if (Tf == Tf && Tf < qs->mx_thr) qs->mx_thr2 = Tf;
+        }
     }
     if (a.mq_frag) {
         // this query's share of scan_mq_kernel's B-fragment table: group b / 4, K-step s, lane
@@ -1968,6 +1996,29 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
                 __syncthreads();
             }
             if (!bc2 || sm.offs[a.nblk] >= a.k) break;                // (uniform) enough candidates without the back lists
+            if (pass == 0 && a.dataset) {
+                // the back lists are needed after all: their unverified entries get their exact distance now
+                // (the scan's arithmetic: sequential fp32 chain, correctly rounded sqrt and division)
+                float* cdw = const_cast<float*>(cd);
+                const float xn = a.qstate[b].xn;
+                const float* xq = a.queries + (int64_t)b * a.W;
+                const int tps2 = (a.nblk >= PSH_SELECT_THREADS) ? 1 : PSH_SELECT_THREADS / a.nblk;
+                for (int sl = tid / tps2; sl < a.nblk; sl += PSH_SELECT_THREADS / tps2) {
+                    int cb = bc2[sl];
+                    if (cb > a.slice) cb = a.slice;
+                    for (int j = tid % tps2; j < cb; j += tps2) {
+                        const int64_t o = (int64_t)sl * a.slice + (a.slice - 1 - j);
+                        if (__float_as_uint(cd[o]) != PSH_UNVERIFIED_BITS) continue;
+                        const int2 rt = crt[o];
+                        const float* y = a.dataset + ((int64_t)rt.x - a.r_offset) * a.T + rt.y;
+                        float acc = 0.0f;
+                        for (int jj = 0; jj < a.W; ++jj) { const float D = __fsub_rn(xq[jj], y[jj]); acc = __builtin_fmaf(D, D, acc); }
+                        cdw[o] = dist_from_acc(acc, xn);
+                    }
+                }
+                __threadfence();          // the staging below re-reads these slots from other threads: no stale L1 lines
+                __syncthreads();
+            }
         }
         n = sm.offs[a.nblk];
         if (tid == 0 && sm.overflow && a.status) a.status[b] = PSH_STATUS_OVERFLOW_;
