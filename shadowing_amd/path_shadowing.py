@@ -98,8 +98,13 @@ class PathShadowing:
         try:
             from scatspectra import TimeSeriesDataset  # type: ignore
         except Exception as e:  # noqa: BLE001
-            raise ImportError("loading a dataset from a path needs the `scatspectra` package "
-                              "(pass the array itself instead)") from e
+            # without the un-vendored package: a directory of the reference's own batch files
+            # (scripts/batch_generations.py: batchNNNN.npy) is read directly
+            if isinstance(dataset, Path) and dataset.is_dir():
+                from . import ingest
+                return ingest.load_batches(dataset)[0]
+            raise ImportError("loading a dataset from a path needs the `scatspectra` package, or a directory of "
+                              "batchNNNN.npy files (pass the array itself instead)") from e
         if isinstance(dataset, Path):
             dataset = TimeSeriesDataset(dpath=dataset, R=None).load()
         if isinstance(dataset, TimeSeriesDataset):
