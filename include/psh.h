@@ -182,6 +182,14 @@ int psh_merge_topk_gathered(int device, void* stream,
                             const float* d_gathered, const int32_t* idx_gathered,
                             int G, int64_t rank_stride, int64_t rank_stride_idx, int B, int k_in, int k,
                             float* out_d, int32_t* out_idx, void* workspace, size_t workspace_bytes);
+/* The same when every list arrives SORTED by (d, r, t) (what psh_scan_topk returns) and list g holds
+ * smaller rows than list g+1 (ranks own ascending row blocks): no selection, no sort -- each entry's
+ * merged position is its own position plus a binary-search count per other list.  No workspace.
+ * Requires G <= 64 and G * k_in <= 32768 (the distance keys sit in LDS); PSH_ERR_UNSUPPORTED otherwise. */
+int psh_merge_sorted_gathered(int device, void* stream,
+                              const float* d_gathered, const int32_t* idx_gathered,
+                              int G, int64_t rank_stride, int64_t rank_stride_idx, int B, int k_in, int k,
+                              float* out_d, int32_t* out_idx);
 int psh_merge_topk(int device, void* stream,
                    const float* d_lists, const int32_t* idx_lists, int B, int n_in, int k,
                    float* out_d, int32_t* out_idx, void* workspace, size_t workspace_bytes);

@@ -37,7 +37,7 @@ class PshProfile(C.Structure):
 EXPORTS = ("psh_version", "psh_strerror", "psh_last_hip_error", "psh_workspace_bytes", "psh_query_norm",
            "psh_scan_topk", "psh_scan_topk_exhaustive", "psh_scan_topk_embedded",
            "psh_scan_topk_embedded_exhaustive", "psh_merge_workspace_bytes", "psh_merge_topk",
-           "psh_merge_topk_gathered", "psh_gather_paths")
+           "psh_merge_topk_gathered", "psh_merge_sorted_gathered", "psh_gather_paths")
 
 _lib = None
 
@@ -91,6 +91,8 @@ def load() -> C.CDLL:
     L.psh_merge_topk.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, C.c_size_t]
     L.psh_merge_topk_gathered.restype = i32
     L.psh_merge_topk_gathered.argtypes = [i32, vp, vp, vp, i32, i64, i64, i32, i32, i32, vp, vp, vp, C.c_size_t]
+    L.psh_merge_sorted_gathered.restype = i32
+    L.psh_merge_sorted_gathered.argtypes = [i32, vp, vp, vp, i32, i64, i64, i32, i32, i32, vp, vp]
     L.psh_gather_paths.restype = i32
     L.psh_gather_paths.argtypes = [i32, vp, vp, i64, i64, i64, i64, vp, i64, i32, vp]
     _lib = L
@@ -318,6 +320,27 @@ def merge_topk_gathered(gathered: torch.Tensor, G: int, B: int, k_in: int, k: in
                                           G, 3 * B * k_in, (3 * B * k_in) // 2, B, k_in, k,
                                           out_d.data_ptr(), out_idx.data_ptr(),
                                           ws.data_ptr(), ws.numel()), "psh_merge_topk_gathered")
+    return out_d, out_idx
+
+
+def merge_sorted_supported(G: int, k_in: int) -> bool:
+    return G <= 64 and G * k_in <= 32768
+
+
+def merge_sorted_gathered(gathered: torch.Tensor, G: int, B: int, k_in: int, k: int):
+    """merge_topk_gathered for lists that are SORTED by (d, r, t), rank g owning smaller rows than rank g+1
+    (psh_merge_sorted_gathered: positions by binary search, no selection, no sort)."""
+    g = _dev_tensor(gathered, torch.int32, "gathered")
+    if tuple(g.shape) != (G, 3 * B * k_in):
+        raise ValueError("gathered must be (G, 3*B*k_in) int32")
+    if (B * k_in) % 2:
+        raise ValueError("B*k_in must be even for the in-place gathered merge")
+    out_d = torch.empty((B, k), dtype=torch.float32, device=g.device)
+    out_idx = torch.empty((B, k, 2), dtype=torch.int32, device=g.device)
+    base = g.data_ptr()
+    _check(load().psh_merge_sorted_gathered(g.device.index, _stream_ptr(g.device), base, base + 4 * B * k_in,
+                                            G, 3 * B * k_in, (3 * B * k_in) // 2, B, k_in, k,
+                                            out_d.data_ptr(), out_idx.data_ptr()), "psh_merge_sorted_gathered")
     return out_d, out_idx
 
 

@@ -653,6 +653,20 @@ int psh_merge_topk_gathered(int device, void* stream, const float* d_gathered, c
     return PSH_OK;
 }
 
+int psh_merge_sorted_gathered(int device, void* stream, const float* d_gathered, const int32_t* idx_gathered,
+                              int G, int64_t rank_stride, int64_t rank_stride_idx, int B, int k_in, int k,
+                              float* out_d, int32_t* out_idx) {
+    if (!d_gathered || !idx_gathered || !out_d || !out_idx || G <= 0 || B <= 0 || k_in <= 0 || k <= 0) return PSH_ERR_ARG;
+    if (rank_stride < (int64_t)B * k_in || rank_stride_idx < (int64_t)B * k_in) return PSH_ERR_ARG;
+    if (((uintptr_t)idx_gathered & 7u) != 0) return PSH_ERR_ARG;
+    if (G > 64 || (int64_t)G * k_in * 4 > 128 * 1024 || (int64_t)k > (int64_t)G * k_in + PSH_MAX_K) return PSH_ERR_UNSUPPORTED;
+    DeviceGuard g(device);
+    if (!g.ok) { snprintf(g_hip_err, sizeof(g_hip_err), "hipSetDevice(%d) failed", device); return PSH_ERR_HIP; }
+    MergeSortedArgs m{d_gathered, (const int2*)idx_gathered, rank_stride, rank_stride_idx, G, k_in, k, out_d, out_idx};
+    HIP_TRY(launch_merge_sorted(m, B, (hipStream_t)stream));
+    return PSH_OK;
+}
+
 int psh_gather_paths(int device, void* stream, const float* dataset, int64_t R, int64_t C, int64_t T, int64_t r_offset,
                      const int32_t* idx, int64_t n, int len, float* out) {
     if (!dataset || !idx || !out || R <= 0 || C <= 0 || T <= 0 || n < 0 || len <= 0) return PSH_ERR_ARG;

@@ -131,6 +131,15 @@ struct SelectArgs {
     unsigned long long* dbg_times;   // tuning aid (nullable): phase boundaries of block 0 in wall-clock ticks (100 MHz)
 };
 
+struct MergeSortedArgs {   // k best of G lists, each sorted by (d, r, t), list g holding smaller rows than list g+1
+    const float* d;          // list g of query b: d + g * stride_d + b * k_in
+    const int2* rt;          //                    rt + g * stride_rt + b * k_in
+    int64_t stride_d, stride_rt;
+    int G, k_in, k;
+    float* out_d;            // B x k
+    int32_t* out_idx;        // B x k x 2
+};
+
 struct ReseedArgs {      // exhaustive path: running best -> cand[b][offset .. offset + k)
     const float* out_d;
     const int32_t* out_idx;
@@ -166,6 +175,7 @@ hipError_t scan_blocks_per_cu(int W, bool aligned, bool embedded, size_t shmem, 
 hipError_t launch_threshold(const ThresholdArgs& a, int B, hipStream_t s);
 hipError_t launch_select(const SelectArgs& a, int B, hipStream_t s);
 hipError_t launch_reseed(const ReseedArgs& a, int B, hipStream_t s);
+hipError_t launch_merge_sorted(const MergeSortedArgs& a, int B, hipStream_t s);   // needs G * k_in * 4 bytes of LDS
 hipError_t launch_gather(const GatherArgs& a, hipStream_t s);
 
 }  // namespace psh

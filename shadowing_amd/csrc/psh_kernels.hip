@@ -2339,6 +2339,71 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
     mark();                                              // 6: written
 }
 
+// ----------------------------------------------------------------------------------
+// merge of per-shard results that arrive SORTED (the cross-GPU merge after the all-gather)
+// ----------------------------------------------------------------------------------
+// G lists of k_in entries, each ascending by (d, r, t), shard g holding smaller rows than shard g+1
+// (padding: d = +inf, r = -1, at the end).  No selection pass, no sort: an entry's position in the
+// merged order is its own position plus, per other list, the number of entries that precede it --
+// a binary search on the distance bits; equal distances across lists are ordered by the list index,
+// which IS the (r, t) order because shards are ascending row blocks.  Only entries that can be among
+// the k best take part: with c = ceil(1.25 k / G), everything above P = max_g list_g[c] is out (at
+// least G (c + 1) >= k entries are <= P).  One block per query; the distance keys sit in LDS.
+__global__ __launch_bounds__(PSH_SELECT_THREADS) void merge_sorted_kernel(MergeSortedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned mkeys[];     // G x k_in distance bits (non-negative floats: bit order)
+    __shared__ int ncut[64];                                              // per list: entries <= P
+    __shared__ unsigned pivot;
+    const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
+    const int G = a.G, kin = a.k_in;
+    for (int e = tid; e < G * kin; e += PSH_SELECT_THREADS) {
+        const int g = e / kin, j = e - g * kin;
+        mkeys[e] = __float_as_uint(a.d[(int64_t)g * a.stride_d + (int64_t)b * kin + j]);
+    }
+    if (tid == 0) pivot = 0u;
+    __syncthreads();
+    int c = (5 * a.k + 4 * G - 1) / (4 * G);           // 1.25 k / G: G (c + 1) >= k entries are <= P
+    if (c > kin - 1) c = kin - 1;
+    if (tid < G) atomicMax(&pivot, mkeys[tid * kin + c]);
+    __syncthreads();
+    const unsigned P = pivot;
+    if (tid < G) {                                      // upper bound of P in list tid
+        const unsigned* L = mkeys + tid * kin;
+        int lo = 0, hi = kin;                           // L[lo-1] <= P < L[hi]
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (L[mid] <= P) lo = mid + 1; else hi = mid; }
+        ncut[tid] = lo;
+    }
+    __syncthreads();
+    // candidates: list g, positions [0, ncut[g]); flattened over (g, j) with a running offset
+    int total = 0;
+    for (int g = 0; g < G; ++g) total += ncut[g];
+    for (int e = tid; e < total; e += PSH_SELECT_THREADS) {
+        int g = 0, j = e;
+        while (j >= ncut[g]) { j -= ncut[g]; ++g; }
+        const unsigned mine = mkeys[g * kin + j];
+        int rank = j;
+        for (int v = 0; v < G; ++v) {
+            if (v == g) continue;
+            const unsigned* L = mkeys + v * kin;
+            int lo = 0, hi = ncut[v];                   // entries beyond the cut are > P >= mine
+            if (v < g) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (L[mid] <= mine) lo = mid + 1; else hi = mid; } }
+            else       { while (lo < hi) { const int mid = (lo + hi) >> 1; if (L[mid] < mine) lo = mid + 1; else hi = mid; } }
+            rank += lo;
+        }
+        if (rank < a.k) {
+            const int2 rt = a.rt[(int64_t)g * a.stride_rt + (int64_t)b * kin + j];
+            a.out_d[(int64_t)b * a.k + rank] = __uint_as_float(mine);
+            a.out_idx[((int64_t)b * a.k + rank) * 2 + 0] = rt.x;
+            a.out_idx[((int64_t)b * a.k + rank) * 2 + 1] = rt.y;
+        }
+    }
+    // fewer than k entries in all (k larger than the lists together): pad
+    for (int i = G * kin + tid; i < a.k; i += PSH_SELECT_THREADS) {
+        a.out_d[(int64_t)b * a.k + i] = __uint_as_float(PSH_INF_BITS);
+        a.out_idx[((int64_t)b * a.k + i) * 2 + 0] = -1;
+        a.out_idx[((int64_t)b * a.k + i) * 2 + 1] = -1;
+    }
+}
+
 // exhaustive path: the running best goes behind the next chunk's window slots
 __global__ void reseed_kernel(ReseedArgs a) {
     const int b = (int)blockIdx.y;
@@ -2553,6 +2618,15 @@ hipError_t launch_select(const SelectArgs& a0, int B, hipStream_t s) {
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(select_kernel, dim3(B), dim3(PSH_SELECT_THREADS), shmem, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_merge_sorted(const MergeSortedArgs& a, int B, hipStream_t s) {
+    const size_t shmem = (size_t)a.G * a.k_in * sizeof(unsigned);
+    if (shmem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)merge_sorted_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(merge_sorted_kernel, dim3(B), dim3(PSH_SELECT_THREADS), shmem, s, a);
     return hipGetLastError();
 }
 hipError_t launch_reseed(const ReseedArgs& a, int B, hipStream_t s) {

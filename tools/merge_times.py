@@ -14,7 +14,7 @@ for G in (1, 2, 4, 8):
     for g in range(G):
         ds = torch.as_tensor(syn.dataset(rows, 2048, 10 + g)[:, 0, :]).to(dev)
         out = (gathered[g, :B * k].view(torch.float32).view(B, k), gathered[g, B * k:].view(B, k, 2))
-        _native.scan_topk(ds, q, k, h=20, r_offset=g * rows, out=out, unsorted=True)
+        _native.scan_topk(ds, q, k, h=20, r_offset=g * rows, out=out)
     torch.cuda.synchronize()
     for _ in range(5):
         _native.merge_topk_gathered(gathered, G, B, k, k)
@@ -24,4 +24,12 @@ for G in (1, 2, 4, 8):
     for _ in range(50):
         _native.merge_topk_gathered(gathered, G, B, k, k)
     e1.record(); torch.cuda.synchronize()
-    print(f"G={G}: merge of {G * k} candidates -> {k}: {e0.elapsed_time(e1) / 50 * 1e3:.1f} us per call (incl. 3 small allocations)")
+    t_general = e0.elapsed_time(e1) / 50 * 1e3
+    a1, i1 = _native.merge_topk_gathered(gathered, G, B, k, k)
+    a2, i2 = _native.merge_sorted_gathered(gathered, G, B, k, k)
+    assert torch.equal(a1.view(torch.int32), a2.view(torch.int32)) and torch.equal(i1, i2)
+    e0.record()
+    for _ in range(50):
+        _native.merge_sorted_gathered(gathered, G, B, k, k)
+    e1.record(); torch.cuda.synchronize()
+    print(f"G={G}: {G * k} candidates -> {k}: general merge {t_general:.1f} us, sorted-lists merge {e0.elapsed_time(e1) / 50 * 1e3:.1f} us per call")
