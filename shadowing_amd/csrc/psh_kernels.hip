@@ -10,22 +10,27 @@
 //   path_shadowing.py:43-58    flat index -> (row, t)
 //
 // Design (DESIGN.md has the long form):
-//   * one WAVE (64 lanes) owns a segment of 1024 consecutive windows of one row:
-//     it streams the 4 KB (+ W-1 halo) with coalesced 16-byte loads, stages them
-//     in a wave-private, bank-conflict-free LDS tile, and every lane walks 16
-//     consecutive windows with a 16-register sliding window, so each dataset
-//     element is fetched from HBM once and from LDS ~1.3 times.
-//   * the per-window chain is kept in the reference's exact order (bit-exact
-//     distances are what make indices bit-exact) -- no tree/shuffle reduction.
-//   * selection never ranks on anything but the exact value.  An admission threshold
-//     tau (a provable upper bound of the k-th smallest acc: the k-th smallest over ANY
-//     subset of the windows bounds the global one) keeps all but ~1e4 of the 1e8
-//     windows out of the candidate list; it comes from a bootstrap pass over 1/16 of the
-//     rows.  Survivors are appended to per-block slices with an LDS cursor -- no global
-//     atomics anywhere (device-scope atomics on one line cost ~25 ns each on this
-//     8-XCD part; 5e4 of them were 5x the whole scan).  A one-block radix select +
-//     bitonic sort then orders the survivors by (d, r, t).
-//   * no MFMA: the work is a streaming scan, not a contraction.
+//   * one WAVE (64 lanes) owns a segment of 1024 consecutive windows of one row: it streams
+//     the 4 KB (+ W-1 halo) with coalesced non-temporal 16-byte loads and stages them in
+//     wave-private LDS (no block barrier in any scan loop); each dataset element is fetched
+//     from HBM once.
+//   * ranking only ever sees the reference's exact value: the per-window chain is kept in the
+//     reference's order (bit-exact distances are what make indices bit-exact) -- no
+//     tree/shuffle reduction.
+//   * exact fp32 is 41 VALU operations per 4 bytes -- more than the vector ALUs issue at
+//     8 TB/s -- so the scans are bound-then-verify: a cheap quantity with a RIGOROUS error
+//     bound rejects what cannot be admitted, the ~1e-4 survivors get the exact chain.  The
+//     cheap quantity is a banded f16 product on the matrix cores (scan_mx_kernel, one query;
+//     scan_mq_kernel / boot_mq_kernel, batches) or an fp32 correlation + prefix sums on the
+//     VALU (scan_kernel, every other window length; PSH_FILTER=valu).
+//   * an admission threshold tau (a provable upper bound of the k-th smallest acc: the k-th
+//     smallest over ANY subset of the windows bounds the global one) keeps all but ~1e4 of
+//     the 1e8 windows out of the candidate lists; it comes from a bootstrap pass over 1/16
+//     of the rows.  Survivors are appended to per-block slices with LDS cursors -- no global
+//     atomics anywhere (device-scope atomics on one line cost ~25 ns each on this 8-XCD
+//     part; 5e4 of them were 5x the whole scan).  A one-block radix select then picks the
+//     k best and orders them by (d, r, t).
+//   * the embedded scan (embed_scan_kernel) runs the same pipeline behind a linear embedding.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
