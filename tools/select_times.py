@@ -9,7 +9,7 @@ ws = _native.Workspace(dev)
 buf = torch.zeros(64, dtype=torch.int64, device=dev)
 os.environ["PSH_DBG_SELECT_PTR"] = str(buf.data_ptr())
 for rep in range(3):
-    *_, prof = _native.scan_topk(ds, q, 1024, h=20, workspace=ws, profile=True)
+    *_, prof = _native.scan_topk(ds, q, int(sys.argv[1]) if len(sys.argv) > 1 else 1024, h=20, workspace=ws, profile=True)
 t = buf.cpu().numpy()[:8].astype(np.float64) * 0.01  # us
 names = ["slice prefix", "load keys", "min/max + radix select", "assign slots", "fetch (r,t)", "sort", "write out"]
 print("select_ms", prof["select_ms"], "candidates", prof["n_candidates"])
