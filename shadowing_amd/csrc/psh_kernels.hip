@@ -1658,20 +1658,18 @@ struct SelectShared {
 };
 
 // min / max of the live 64-bit keys over the block (kmin > kmax when nothing is live)
-template <typename KeyFn, typename LiveFn>
-__device__ inline void block_minmax64(KeyFn key_of, LiveFn live, int n, SelectShared* sm,
-                                      uint64_t* out_min, uint64_t* out_max) {
+// (`walk(body)` calls body(key) once per live candidate, every thread its share)
+template <typename WalkFn>
+__device__ inline void block_minmax64(WalkFn walk, SelectShared* sm, uint64_t* out_min, uint64_t* out_max) {
     const int tid = (int)threadIdx.x;
     __syncthreads();
     if (tid == 0) { sm->kmin = ~0ull; sm->kmax = 0ull; }
     __syncthreads();
     uint64_t lo = ~0ull, hi = 0ull;
-    for (int i = tid; i < n; i += PSH_SELECT_THREADS) {
-        if (!live(i)) continue;
-        const uint64_t k = key_of(i);
+    walk([&](uint64_t k) {
         lo = k < lo ? k : lo;
         hi = k > hi ? k : hi;
-    }
+    });
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const uint64_t l2 = __shfl_xor(lo, off, 64), h2 = __shfl_xor(hi, off, 64);
@@ -1693,15 +1691,16 @@ __device__ inline void block_minmax64(KeyFn key_of, LiveFn live, int n, SelectSh
 // (key >> sh) <= (prefix >> sh) are exactly the `rank` smallest -- unless keys tie down to
 // sh_floor (*exact false): then more may match and *remaining of the ones equal to
 // prefix at sh_floor are still wanted.
-template <typename KeyFn, typename LiveFn>
-__device__ inline void radix_select64(KeyFn key_of, LiveFn live, int n, int rank, int sh_floor,
-                                      SelectShared* sm, uint64_t* out_prefix, int* out_sh, bool* out_exact,
-                                      int* out_remaining, bool have_minmax = false, uint64_t kmin_in = 0,
-                                      uint64_t kmax_in = 0, int good_enough_sh = -1, int rank_b = 0) {
+// The candidates are visited through `walk(body)` (body(key) once per live candidate).
+template <typename WalkFn>
+__device__ inline void radix_select64_walk(WalkFn walk, int rank, int sh_floor,
+                                           SelectShared* sm, uint64_t* out_prefix, int* out_sh, bool* out_exact,
+                                           int* out_remaining, bool have_minmax = false, uint64_t kmin_in = 0,
+                                           uint64_t kmax_in = 0, int good_enough_sh = -1, int rank_b = 0) {
     const int tid = (int)threadIdx.x;
     constexpr unsigned NB = 1u << PSH_RB;
     uint64_t kmin = kmin_in, kmax = kmax_in;
-    if (!have_minmax) block_minmax64(key_of, live, n, sm, &kmin, &kmax);
+    if (!have_minmax) block_minmax64(walk, sm, &kmin, &kmax);
     const uint64_t diff = (kmin ^ kmax) >> sh_floor;
     if (kmin > kmax || diff == 0ull) {       // nothing live, or every key equal above the floor
         *out_prefix = (kmin > kmax) ? 0ull : ((kmin >> sh_floor) << sh_floor);
@@ -1731,12 +1730,10 @@ __device__ inline void radix_select64(KeyFn key_of, LiveFn live, int n, int rank
         const uint64_t prefix = sm->prefix;
         const int shp = sh + bits;
         const unsigned dmask = (1u << bits) - 1u;
-        for (int i = tid; i < n; i += PSH_SELECT_THREADS) {
-            if (!live(i)) continue;
-            const uint64_t key = key_of(i);
+        walk([&](uint64_t key) {
             const bool match = first || shp >= 64 || ((key >> shp) == (prefix >> shp));
             if (match) atomicAdd(&sm->hist[(unsigned)(key >> sh) & dmask], 1u);
-        }
+        });
         __syncthreads();
         if (tid < 64) {
             // bucket holding the rank: wave-wide prefix over the counters, NB/64 per lane
@@ -1791,6 +1788,20 @@ __device__ inline void radix_select64(KeyFn key_of, LiveFn live, int n, int rank
     *out_exact = sm->done != 0;
     *out_remaining = sm->remaining;
     __syncthreads();
+}
+
+// the same over an index range: candidate i (live(i)) has key key_of(i)
+template <typename KeyFn, typename LiveFn>
+__device__ inline void radix_select64(KeyFn key_of, LiveFn live, int n, int rank, int sh_floor,
+                                      SelectShared* sm, uint64_t* out_prefix, int* out_sh, bool* out_exact,
+                                      int* out_remaining, bool have_minmax = false, uint64_t kmin_in = 0,
+                                      uint64_t kmax_in = 0, int good_enough_sh = -1, int rank_b = 0) {
+    radix_select64_walk([&](auto&& body) {
+                            for (int i = (int)threadIdx.x; i < n; i += PSH_SELECT_THREADS)
+                                if (live(i)) body(key_of(i));
+                        },
+                        rank, sh_floor, sm, out_prefix, out_sh, out_exact, out_remaining, have_minmax, kmin_in, kmax_in,
+                        good_enough_sh, rank_b);
 }
 
 // bootstrap threshold: tau = k-th smallest of the sampled minima (+ margin).  The sample
@@ -2141,8 +2152,17 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
     if (need > 0 && need < n_real) {
         bool exact;
         int rem;
-        radix_select64([&](int e) { return (uint64_t)dkey(e) << 32; }, live, n, need, 32,
-                       &sm, &d_prefix, &d_sh, &exact, &rem, have_mm, kmin64, kmax64);
+        if (!in_lds && slices && !skip_neg) {
+            // more candidates than LDS holds keys for: walk the slices (no per-key search for the owning
+            // block, independent loads) instead of indexing candidate e through src(e)
+            radix_select64_walk([&](auto&& body) {
+                                    for_each_cand([&](int, int64_t sidx) { body((uint64_t)__float_as_uint(cd[sidx]) << 32); });
+                                },
+                                need, 32, &sm, &d_prefix, &d_sh, &exact, &rem);
+        } else {
+            radix_select64([&](int e) { return (uint64_t)dkey(e) << 32; }, live, n, need, 32,
+                           &sm, &d_prefix, &d_sh, &exact, &rem, have_mm, kmin64, kmax64);
+        }
         if (!exact) {
             // the k-th distance VALUE is shared by more candidates than fit: the canonical
             // order keeps the smallest (r, t) among those ties
