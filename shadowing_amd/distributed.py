@@ -146,8 +146,10 @@ class ShardedPathShadowing:
         if self._linear:
             # the query embedding is the module's own conv1d (reference path_shadowing.py:140), on
             # the module's device; what travels to the scan is (B, d)
+            from .path_shadowing import single_thread
             kdev = self.embedding.kernel.device
-            queries = self.embedding(queries.to(kdev, dtype=torch.float32)[:, None, :])[:, 0, :]
+            with single_thread():
+                queries = self.embedding(queries.to(kdev, dtype=torch.float32)[:, None, :])[:, 0, :]
         q = queries.to(self.device, dtype=torch.float32).contiguous()
         B = q.shape[0]
         G = self.world_size

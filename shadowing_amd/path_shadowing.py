@@ -23,6 +23,7 @@ the generic torch formulation on the host.
 """
 from __future__ import annotations
 
+import contextlib
 from pathlib import Path
 from typing import Callable
 
@@ -35,6 +36,19 @@ from .averaging import DiscreteProba, Softmax, Uniform
 from .path_distance import PathDistance, RelativeMSE
 from .path_embedding import (ArrayType, ContextManagerBase, Identity, ImputationContext, PathEmbedding,
                              PredictionContext)
+
+
+@contextlib.contextmanager
+def single_thread():
+    """The (tiny) query embedding on the host with ONE intra-op thread: the result is the same bits (checked
+    on every fixture), but an 8..256-thread OpenMP team woken for 34 x 126 multiply-adds stalls for up to
+    200 ms every few dozen calls (measured: p99 160 ms against a 0.17 ms median; 0.8 ms worst case with one)."""
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        yield
+    finally:
+        torch.set_num_threads(n)
 
 
 def _dim_array(x: ArrayType) -> ArrayType:
@@ -183,7 +197,9 @@ class PathShadowing:
             # over the ensemble takes the unpadded kernel and the horizon as an integer --
             # or, for an ImputationContext, the kernel with the gap's zero taps and no horizon
             ker = self.embedding.kernel
-            hx = self.embedding(x.to(ker.device))[:, 0, :].contiguous().to(dev)
+            with single_thread():
+                hx = self.embedding(x.to(ker.device))[:, 0, :].contiguous()
+            hx = hx.to(dev)
             if kind == "padded":
                 ker2 = self.context.pad_context(ker)[:, 0, :].contiguous().to(dev)
                 h = 0
