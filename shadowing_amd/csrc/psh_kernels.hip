@@ -426,7 +426,8 @@ __device__ __forceinline__ void pend_flush(const u32x4* pend, int npend, int* lc
         const int b = (int)e[3];
         const int pos = atomicAdd(&lcount[b], 1);      // LDS: this block's cursor for query b
         if (pos < a.slice) {
-            const int64_t o = (int64_t)b * a.cap + (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * a.slice + pos;
+            // (2-D grids: blockIdx.y picks a chunk of queries, so the blocks of one column never write the same query)
+            const int64_t o = (int64_t)b * a.cap + (int64_t)blockIdx.x * a.slice + pos;
             a.cand_d[o] = dist_from_acc(__uint_as_float(e[0]), a.qstate[b].xn);
             a.cand_rt[o] = make_int2((int)e[1], (int)e[2]);
         }
@@ -1200,9 +1201,8 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
     }
     if (npend > 0) pend_flush(pend, npend, lcount, a, lane);
     __syncthreads();
-    const int blk = (int)(blockIdx.y * gridDim.x + blockIdx.x);
-    for (int q = (int)threadIdx.x; q < a.B; q += PSH_MQ_THREADS)
-        a.bcount[(int64_t)q * PSH_MAX_BLOCKS + blk] = lcount[q];
+    for (int q = q0 + (int)threadIdx.x; q < q0 + nq; q += PSH_MQ_THREADS)          // this block's queries only
+        a.bcount[(int64_t)q * PSH_MAX_BLOCKS + blockIdx.x] = lcount[q];
 }
 
 // ----------------------------------------------------------------------------------
