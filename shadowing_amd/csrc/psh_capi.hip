@@ -233,6 +233,7 @@ ScanArgs make_scan_args(const float* dataset, const float* queries, const Proble
     a.ker = p.ker;
     a.hx = p.ker ? queries : nullptr;
     a.emb_d = p.emb_d;
+    if (const char* e = getenv("PSH_EMBED")) a.emb_dense = !strcmp(e, "dense") ? 1 : 0;   // A/B aid: skip the suffix-rows fast path
     a.B = p.B;
     a.n_qgroups = plan.n_qgroups;
     a.q_per_group = plan.q_per_group;

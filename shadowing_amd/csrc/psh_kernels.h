@@ -81,6 +81,7 @@ struct ScanArgs {
     const float* ker;        // emb_d x W row-major
     const float* hx;         // B x emb_d
     int emb_d;
+    int emb_dense;           // embedded scan: always the dense chains, even when the kernel has suffix rows (tests, PSH_EMBED=dense)
 };
 
 #define PSH_EMB_MAX_D 128            // embedding rows handled natively

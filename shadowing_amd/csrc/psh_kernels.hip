@@ -1524,6 +1524,64 @@ __device__ __forceinline__ void emit16(const ScanArgs& a, int b, const float (&a
     }
 }
 
+// ---- suffix rows (Foveal, reference path_embedding.py:142-172) -------------------------
+// A Foveal kernel row is c_i on the LAST n_i taps and zero elsewhere (n_i = 1, 1, .., 2, .., 115
+// for max_context 126): 865 fma per window through the dense chain above, but only 115 DISTINCT
+// partial sums -- row i is c_i times the running sum of the window's newest n_i samples.  The
+// kernel recognises the general form of that structure by itself, from the matrix it was given:
+//     every row is one constant on  U & [a_i, K)  -- U the union of all supports --
+// (an ImputationContext's gap only removes taps from U, so padded kernels qualify too), and then
+// scans bound-then-verify like the Identity path:
+//   cheap  : S <- running sum over the taps of U, newest sample first, ONE pass for all rows;
+//            when the pass reaches a_i:  e_i = hx_i - c_i S;  acc^ += e_i^2   (~120 VALU ops/window)
+//   bound  : both the cheap h^_i = c_i S and the exact chain's h_i carry at most
+//            n_i u |c_i| sum|y| of rounding error (u = 2^-24, any summation order), so
+//            |h^_i - h_i| <= 2 u |c_i| n_i^2 ymax  and, in the embedding space,
+//            sqrt(acc) >= sqrt(acc^) - ymax * cerr   with cerr = 2u sqrt(sum_i (c_i (n_i+1)^2)^2)
+//            (ymax = max |y| over the segment);  the sums of d squares add (d + 3) u relative
+//   verify : a window survives unless  acc^ > (sqrt(tau)(1 + 2^-15) + ymax cerr)^2 (1 + 2^-14);
+//            survivors (a few per million) get the exact dense chain, and only exact values are
+//            ever ranked.  The bootstrap uses the same bound the other way round (upper bounds).
+// Non-finite data needs no special path: NaN fails the '>' and is kept, an infinite ymax makes
+// the threshold infinite (everything is verified exactly).
+#define PSH_NEST_BG 2                // queries sharing one pass of running sums (register budget: 128 VGPRs)
+#define PSH_NEST_MAX_K 256           // support masks are 4 x 64 bits, 16 blocks of 16 taps
+struct NestHdr { int ok; int nops; float cerr; int n_empty; unsigned blk[16]; };   // blk: active taps | closing taps << 16
+
+// The running sums of a lane's 16 windows.  The window registers are addressed by DATA index:
+// y[base + m] lives in slot m & 15, so at tap j (PH = j & 15) window w reads slot (w + PH) & 15,
+// and the sample that enters for tap j - 1 replaces the one that leaves, in slot (PH - 1) & 15:
+// walking the taps downwards in blocks of 16 makes every register index a compile-time constant.
+// Slots s and s + 8 share a 64-bit register pair (W2[s & 7]), windows w and w + 8 likewise
+// (S2[w]): the two windows of a pair always read the two slots of one pair, in order or swapped,
+// which is what v_pk_add_f32's op_sel expresses -- 8 packed adds per tap.  Entering samples
+// arrive four at a time (aligned 16-byte LDS reads, one per 4 taps, issued 4 taps ahead) in two
+// alternating quads: group G = (j - 1) >> 2 sits in Q[G & 1].
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int PH>
+__device__ __forceinline__ void nest_add(f32x2 (&S2)[8], const f32x2 (&W2)[8]) {
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        if (((w + PH) & 15) < 8)
+            asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(S2[w]) : "v"(W2[(w + PH) & 7]));
+        else
+            asm volatile("v_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "+v"(S2[w]) : "v"(W2[(w + PH) & 7]));
+    }
+}
+
+template <int PH>
+__device__ __forceinline__ void nest_shift(f32x2 (&W2)[8], f32x4 (&Q)[2], const float* tile, int base, int j) {
+    constexpr int GP = (PH % 4 == 0) ? (((PH >> 2) + 3) & 1) : ((PH >> 2) & 1);
+    constexpr int SE = (PH + 15) & 15;                         // slot of the entering sample
+    W2[SE & 7][SE >> 3] = Q[GP][(PH + 3) & 3];
+    if (PH % 4 == 0) {                                         // group G - 1 for the four taps after the next three
+        int jq = j - 8;
+        jq = jq < 0 ? 0 : jq;                                  // (a clamped quad is never consumed)
+        Q[GP ^ 1] = *reinterpret_cast<const f32x4*>(tile + lds_pad(base + jq));
+    }
+}
+
 template <bool ALIGNED, int MODE>
 __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1539,6 +1597,12 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a
     float* kerL = reinterpret_cast<float*>(pend0 + (size_t)NW * PSH_PEND);   // d x Kp, rows zero padded
     int2* rng = reinterpret_cast<int2*>(kerL + (size_t)d * Kp);              // per row: {first tap & ~3, taps to visit}
     int npend = 0;
+    // suffix-rows fast path (BOOT / FILTER): header, rows in closing order, analysis scratch
+    NestHdr* nh = reinterpret_cast<NestHdr*>(rng + ((d + 1) & ~1));          // 16-byte aligned
+    int4* prog = reinterpret_cast<int4*>(nh + 1);                            // d x {closing tap a_i, row, c bits, n_i}
+    unsigned long long* rmask = reinterpret_cast<unsigned long long*>(prog + d);   // d x 4 support masks, then U
+    int* sl = reinterpret_cast<int*>(rmask + (size_t)4 * (d + 1)) + (size_t)wave_in_block * 192;   // wave-private: 64 survivors,
+    float* Dl = reinterpret_cast<float*>(sl + 64);                                                     //   128 row differences
 
     if (threadIdx.x == 0) *next_unit = 0;
     if (MODE == PSH_MODE_FILTER)
@@ -1558,7 +1622,81 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a
         lo &= ~3;
         rng[threadIdx.x] = make_int2(lo, hi - lo);
     }
+    if (threadIdx.x == 0) {
+        nh->ok = (MODE != PSH_MODE_ALL && K <= PSH_NEST_MAX_K && !a.emb_dense) ? 1 : 0;
+        nh->nops = d; nh->cerr = 0.0f; nh->n_empty = 0;
+        for (int q = 0; q < 16; ++q) nh->blk[q] = 0u;
+        for (int q = 0; q < 4; ++q) rmask[4 * d + q] = 0ull;
+    }
     __syncthreads();
+    if (MODE != PSH_MODE_ALL && K <= PSH_NEST_MAX_K) {       // every block repeats the (tiny) analysis of the matrix
+        const int tid = (int)threadIdx.x;
+        unsigned long long m[4] = {0ull, 0ull, 0ull, 0ull};
+        int n = 0, lowest = 1 << 20;                         // empty rows close before the first tap
+        float c = 0.0f;
+        if (tid < d) {                                       // support mask, size, constant of row tid
+            const float* row = kerL + (size_t)tid * Kp;
+            bool okc = true;
+            for (int j = K - 1; j >= 0; --j) {
+                const float v = row[j];
+                if (v != 0.0f) {                             // (NaN included: it then fails v == v)
+                    if (n == 0) c = v;
+                    okc = okc && (v == v) && (__float_as_uint(v) == __float_as_uint(c));
+                    m[j >> 6] |= 1ull << (j & 63);
+                    lowest = j;
+                    ++n;
+                }
+            }
+            okc = okc && (fabsf(c) <= 3.0e38f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                rmask[4 * tid + q] = m[q];
+                if (m[q]) atomicOr(&rmask[4 * d + q], m[q]);
+            }
+            prog[tid] = make_int4(lowest, tid, (int)__float_as_uint(c), n);   // (unsorted: read back below)
+            if (!okc) atomicAnd(&nh->ok, 0);
+        }
+        __syncthreads();
+        int rk = 0;
+        if (tid < d) {                                       // the row must be all of U from its lowest tap up; rank by closing tap
+            bool oks = true;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int lo_bit = lowest - 64 * q;          // taps of word q at or above `lowest`
+                const unsigned long long keep = lo_bit <= 0 ? ~0ull : (lo_bit >= 64 ? 0ull : (~0ull << lo_bit));
+                oks = oks && (m[q] == (rmask[4 * d + q] & keep));
+            }
+            if (n == 0) oks = true;
+            if (!oks) atomicAnd(&nh->ok, 0);
+            for (int i2 = 0; i2 < d; ++i2) { const int l2 = prog[i2].x; rk += (l2 > lowest || (l2 == lowest && i2 < tid)) ? 1 : 0; }
+        }
+        __syncthreads();
+        if (tid < d) {
+            prog[rk] = make_int4(lowest, tid, (int)__float_as_uint(c), n);
+            if (n == 0) atomicAdd(&nh->n_empty, 1);
+            else atomicOr(&nh->blk[lowest >> 4], 0x10000u << (lowest & 15));
+        }
+        if (tid < 16) {
+            const unsigned long long uw = rmask[4 * d + (tid >> 2)];
+            atomicOr(&nh->blk[tid], (unsigned)((uw >> (16 * (tid & 3))) & 0xffffull));
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float e2 = 0.0f;
+            for (int i = 0; i < d; ++i) {
+                const int4 o = prog[i];
+                const float n1 = (float)(o.w + 1);
+                const float t = fabsf(__uint_as_float((unsigned)o.z)) * n1 * n1;
+                e2 = __builtin_fmaf(t, t, e2);
+            }
+            nh->cerr = 1.05f * 2.0f * 5.9604645e-8f * __builtin_sqrtf(e2);   // 2u sqrt(sum (c_i (n_i+1)^2)^2), margin for its own rounding
+            if (!(e2 < 3.0e38f)) nh->ok = 0;
+        }
+        __syncthreads();
+    }
+    const bool nested = (MODE != PSH_MODE_ALL) && (__builtin_amdgcn_readfirstlane(nh->ok) != 0);
+    const int n_empty = __builtin_amdgcn_readfirstlane(nh->n_empty);
+    const float cerr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(nh->cerr)));
 
     const int nfloat = PSH_SEG + K - 1;
     const unsigned n_rs = (unsigned)a.n_rows * (unsigned)a.nseg;
@@ -1585,9 +1723,19 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a
             pend_flush(pend, npend, lcount, a, lane);
             npend = 0;
         }
+        float ymax = 0.0f;
         {
             Stage st;
             stage_load<ALIGNED>(st, a.dataset + row * a.T, a.T, seg_start, nfloat, lane);
+            if (MODE != PSH_MODE_ALL && nested) {            // max |y| of everything this segment reads (NaN ignored: see above)
+#pragma unroll
+                for (int q = 0; q < PSH_NSTAGE; ++q) {
+                    if (q < PSH_NSTAGE - 1 || lane + 64 * q < ((nfloat + 3) >> 2)) {
+                        ymax = fmaxf(ymax, fmaxf(fmaxf(fabsf(st.v[q][0]), fabsf(st.v[q][1])),
+                                                 fmaxf(fabsf(st.v[q][2]), fabsf(st.v[q][3]))));
+                    }
+                }
+            }
             stage_store(st, tile, nfloat, lane);
         }
         wave_lds_fence();
@@ -1599,6 +1747,206 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a
         const int q_begin = (int)qgi * a.q_per_group;
         const int q_end = (q_begin + a.q_per_group) < a.B ? (q_begin + a.q_per_group) : a.B;
 
+        if (MODE != PSH_MODE_ALL && nested) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, off, 64));
+            const float err = ymax * cerr;                    // radius of the cheap embedding around the exact one
+            const int base = PSH_L * lane;
+            int ns = 0;                                       // survivors waiting in sl (wave-uniform)
+            // Exact verification of the listed survivors (window index | query << 12), rows across the lanes:
+            // lane (el, l) runs the chains of the l-th shortest and then the l-th longest row of survivor el
+            // (equal work per lane), 64 / ceil(d/2) survivors per pass; one lane per survivor then adds the d
+            // squares in row order.  A row's taps need no matrix: c_i on U & [a_i, K), zero elsewhere (the zero
+            // taps the dense chain visits are visited too: fma(0, y, .) matters for non-finite y).
+            auto verify_list = [&]() {
+                wave_lds_fence();
+                const int H = (d + 1) >> 1, EPP = 64 / H;
+                const int el = lane / H, l = lane - el * H;
+                const int4 oA = prog[l];
+                const int sB = d - 1 - l;
+                const bool hasB = sB > l;
+                const int4 oB = prog[hasB ? sB : l];
+                const int2 gA = rng[oA.y], gB = rng[oB.y];
+                const float cA = __uint_as_float((unsigned)oA.z), cB = __uint_as_float((unsigned)oB.z);
+#pragma unroll 1
+                for (int e0 = 0; e0 < ns; e0 += EPP) {
+                    const bool lv = el < EPP && e0 + el < ns;
+                    const int ent = lv ? sl[e0 + el] : 0;
+                    const int pwin = ent & 4095, b = ent >> 12;
+                    const int nA4 = lv ? ((gA.y + 3) & ~3) : 0, nB4 = (lv && hasB) ? ((gB.y + 3) & ~3) : 0;
+                    auto chain = [&](int lo, int n4, int ath, float c) -> float {
+                        int lm = n4;
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) { const int o2 = __shfl_xor(lm, off, 64); lm = o2 > lm ? o2 : lm; }
+                        lm = __builtin_amdgcn_readfirstlane(lm);
+                        float hy = 0.0f;
+#pragma unroll 1
+                        for (int it = 0; it < lm; it += 4) {             // lo, n4 are multiples of 4: a group is all or nothing
+                            const bool act = it < n4;
+                            const int j0 = act ? lo + it : 0;
+                            float y[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) y[q] = tile[lds_pad(pwin + j0 + q)];
+                            const unsigned ub = nh->blk[(j0 >> 4) & 15] >> (j0 & 15);
+                            float t = hy;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const bool on = (j0 + q >= ath) && (((ub >> q) & 1u) != 0u);
+                                t = __builtin_fmaf(on ? c : 0.0f, y[q], t);
+                            }
+                            hy = act ? t : hy;
+                        }
+                        return hy;
+                    };
+                    const float hyA = chain(gA.x, nA4, oA.x, cA);
+                    const float hyB = chain(gB.x, nB4, oB.x, cB);
+                    if (lv) {
+                        const float* hxb = a.hx + (int64_t)b * d;
+                        Dl[el * d + oA.y] = __fsub_rn(hxb[oA.y], hyA);
+                        if (hasB) Dl[el * d + oB.y] = __fsub_rn(hxb[oB.y], hyB);
+                    }
+                    wave_lds_fence();
+                    float ea = __uint_as_float(PSH_INF_BITS);
+                    bool hit = false;
+                    if (lv && l == 0) {
+                        ea = 0.0f;
+                        for (int i = 0; i < d; ++i) { const float D = Dl[el * d + i]; ea = __builtin_fmaf(D, D, ea); }
+                        hit = ea < __uint_as_float(a.qstate[b].tau_bits);
+                    }
+                    const unsigned long long mask = __ballot(hit);
+                    wave_lds_fence();                        // Dl is rewritten by the next pass
+                    if (!mask) continue;
+                    const int nh2 = __popcll(mask);
+                    if (npend + nh2 > PSH_PEND) {
+                        pend_flush(pend, npend, lcount, a, lane);
+                        npend = 0;
+                        wave_lds_fence();
+                    }
+                    if (hit) {
+                        const int slot = npend + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                        pend[slot] = u32x4{__float_as_uint(ea), (unsigned)r_global, (unsigned)(seg_start + pwin), (unsigned)b};
+                    }
+                    npend += nh2;
+                }
+                wave_lds_fence();                            // sl is refilled afterwards
+            };
+            for (int b0 = q_begin; b0 < q_end; b0 += PSH_NEST_BG) {
+                const int nq = (q_end - b0) < PSH_NEST_BG ? (q_end - b0) : PSH_NEST_BG;
+                f32x2 acc[PSH_NEST_BG][8], S[8], win[8];          // element x: window w / slot s, element y: w + 8 / s + 8
+                f32x4 Q[2];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) { S[w] = f32x2{0.f, 0.f}; win[w] = f32x2{0.f, 0.f}; }
+#pragma unroll
+                for (int g = 0; g < PSH_NEST_BG; ++g)
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) acc[g][w] = f32x2{0.f, 0.f};
+                Q[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                Q[1] = Q[0];
+                // rows in closing order; the next one's constants are fetched while the taps before it run
+                int pc = 0;
+                int4 opn = prog[0];
+                int next_row = __builtin_amdgcn_readfirstlane(opn.y);
+                float next_nc = -__uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(opn.z));
+                float hxn[PSH_NEST_BG];
+#pragma unroll
+                for (int g = 0; g < PSH_NEST_BG; ++g) hxn[g] = (g < nq) ? hxk[(int64_t)(b0 + g) * d + next_row] : 0.0f;
+                auto close_row = [&]() {                     // e = hx - c S;  acc += e^2  for the row at the head of the list
+                    const f32x2 nc2 = f32x2{next_nc, next_nc};
+#pragma unroll
+                    for (int g = 0; g < PSH_NEST_BG; ++g) {
+                        if (g < nq) {                        // wave-uniform
+                            const f32x2 hx2 = f32x2{hxn[g], hxn[g]};
+#pragma unroll
+                            for (int w = 0; w < 8; ++w) {
+                                const f32x2 e = __builtin_elementwise_fma(nc2, S[w], hx2);
+                                acc[g][w] = __builtin_elementwise_fma(e, e, acc[g][w]);
+                            }
+                        }
+                    }
+                    ++pc;
+                    const int pn = pc < d ? pc : d - 1;
+                    opn = prog[pn];
+                    next_row = __builtin_amdgcn_readfirstlane(opn.y);
+                    next_nc = -__uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(opn.z));
+#pragma unroll
+                    for (int g = 0; g < PSH_NEST_BG; ++g) hxn[g] = (g < nq) ? hxk[(int64_t)(b0 + g) * d + next_row] : 0.0f;
+                };
+                for (int e0 = 0; e0 < n_empty; ++e0) close_row();            // all-zero rows: h = 0
+                {
+                    // window of tap jtop = 16 q + 15 >= K - 1: slot 15 <- y[base + jtop], slots 0..14 <- the 15 samples above
+                    const int qb = (K - 1) >> 4;
+                    const f32x4 v3 = *reinterpret_cast<const f32x4*>(tile + lds_pad(base + 16 * qb + 12));
+                    win[7][1] = v3[3];
+#pragma unroll
+                    for (int sq = 0; sq < 4; ++sq) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(tile + lds_pad(base + 16 * qb + 16 + 4 * sq));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (4 * sq + e < 15) win[(4 * sq + e) & 7][(4 * sq + e) >> 3] = v[e];
+                    }
+                    Q[1] = v3;                                                   // group 4 qb + 3 (taps 15..13 take its samples 2..0)
+                    Q[0] = *reinterpret_cast<const f32x4*>(tile + lds_pad(base + 16 * qb + 8));   // group 4 qb + 2
+#pragma unroll 1
+                    for (int jb = 16 * qb; jb >= 0 && pc < d; jb -= 16) {
+                        const unsigned bm = (unsigned)__builtin_amdgcn_readfirstlane((int)nh->blk[jb >> 4]);
+#define PSH_NEST_TAP(PH)                                                                        \
+                        if (bm & (1u << (PH))) nest_add<PH>(S, win);                            \
+                        nest_shift<PH>(win, Q, tile, base, jb + (PH));                          \
+                        if (bm & (0x10000u << (PH))) {                                          \
+                            do close_row(); while (pc < d && __builtin_amdgcn_readfirstlane(opn.x) == jb + (PH)); \
+                        }
+                        PSH_NEST_TAP(15) PSH_NEST_TAP(14) PSH_NEST_TAP(13) PSH_NEST_TAP(12)
+                        PSH_NEST_TAP(11) PSH_NEST_TAP(10) PSH_NEST_TAP(9) PSH_NEST_TAP(8)
+                        PSH_NEST_TAP(7) PSH_NEST_TAP(6) PSH_NEST_TAP(5) PSH_NEST_TAP(4)
+                        PSH_NEST_TAP(3) PSH_NEST_TAP(2) PSH_NEST_TAP(1) PSH_NEST_TAP(0)
+#undef PSH_NEST_TAP
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < PSH_NEST_BG; ++g) {
+                    const int b = b0 + g;
+                    if (g >= nq) continue;
+                    if (MODE == PSH_MODE_BOOT) {
+                        // upper bound of the exact acc of the lane's (wave's) best window
+                        float m = __uint_as_float(PSH_INF_BITS);
+#pragma unroll
+                        for (int w = 0; w < PSH_L; ++w) m = (w < nvalid) ? fminf(m, acc[g][w & 7][w >> 3]) : m;
+                        if (a.boot_per_wave) {
+#pragma unroll
+                            for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+                        }
+                        const float su = __builtin_sqrtf(m) * (1.0f + 1.0f / 32768.0f) + err;
+                        const float ub = su * su * (1.0f + 1.0f / 16384.0f);
+                        if (a.boot_per_wave) {
+                            if (lane == 0) a.minbuf[(int64_t)b * a.min_stride + (int64_t)rs] = ub;
+                        } else {
+                            a.minbuf[(int64_t)b * a.min_stride + (int64_t)rs * 64 + lane] = ub;
+                        }
+                    } else {
+                        const float tau = __uint_as_float(qstate_k[b].tau_bits);
+                        const float st = __builtin_sqrtf(tau) * (1.0f + 1.0f / 32768.0f) + err;
+                        const float thr = st * st * (1.0f + 1.0f / 16384.0f);
+                        unsigned hm = 0u;
+#pragma unroll
+                        for (int w = 0; w < PSH_L; ++w) hm |= ((w < nvalid) && !(acc[g][w & 7][w >> 3] > thr)) ? (1u << w) : 0u;
+                        // survivors go to the wave's list; the whole wave verifies them together (verify_list)
+                        while (__any(hm != 0u)) {
+                            const bool has = hm != 0u;
+                            const int w = has ? (int)__builtin_ctz(hm) : 0;
+                            hm &= hm - 1u;
+                            const unsigned long long sm = __ballot(has);
+                            const int ne = __popcll(sm);
+                            if (ns + ne > 64) { verify_list(); ns = 0; }
+                            if (has) sl[ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u))] =
+                                (base + w) | (b << 12);
+                            ns += ne;
+                        }
+                    }
+                }
+            }
+            if (MODE == PSH_MODE_FILTER && ns > 0) { verify_list(); ns = 0; }   // before the tile is overwritten
+        } else
         for (int b0 = q_begin; b0 < q_end; b0 += PSH_EMB_BG) {
             float acc[PSH_EMB_BG][PSH_L];
 #pragma unroll
@@ -2559,7 +2907,10 @@ size_t scan_shmem_bytes(int tile_floats, int B, int emb_d, int W) {
     size_t n = (size_t)tile_floats * (PSH_SCAN_THREADS / 64) * sizeof(float)      // wave-private tiles
                + (size_t)(((B + 3) & ~3) + 4) * sizeof(int)                         // per-query append cursors + work cursor
                + (size_t)(PSH_SCAN_THREADS / 64) * PSH_PEND * 16;                   // wave-private pending admissions
-    if (emb_d > 0) n += (size_t)emb_d * ((W + 3) & ~3) * sizeof(float) + (size_t)emb_d * sizeof(int2);   // kernel matrix, tap spans
+    if (emb_d > 0) n += (size_t)emb_d * ((W + 3) & ~3) * sizeof(float) + (size_t)emb_d * sizeof(int2)    // kernel matrix, tap spans
+                      + sizeof(NestHdr) + (size_t)emb_d * 16                                             // suffix-rows fast path: closing order
+                      + (size_t)(emb_d + 1) * 32 + 8                                                      //   and support masks
+                      + (size_t)(PSH_SCAN_THREADS / 64) * 192 * 4;                                        //   verification scratch
     return n;
 }
 

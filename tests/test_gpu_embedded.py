@@ -55,6 +55,9 @@ EMB_CASES = [  # R, T, d, K, h, k, B, kind
     (6, 2100, 0, 64, 20, 1, 1, "foveal"),          # k = 1
     (2048, 512, 0, 40, 20, 777, 7, "foveal"),      # sampled path, 3 accumulator groups (B = 7)
     (1500, 900, 4, 20, 5, 300, 4, "gaps"),         # rows with leading/trailing/interior zero taps, one all-zero row
+    (2048, 700, 100, 80, 5, 300, 3, "suffix"),     # suffix rows, d > 64 (one survivor per verification pass)
+    (1024, 1500, 20, 250, 9, 500, 5, "suffix"),    # 16 tap blocks, three accumulator groups
+    (4096, 600, 9, 33, 0, 2000, 2, "suffix"),      # many survivors per segment
 ]
 
 
@@ -67,6 +70,20 @@ def _case_inputs(R, T, d, K, B, kind, seed):
         ker = rng.standard_normal((d, K)).astype(np.float32)
         if kind == "gaps":
             ker[0, :9] = 0; ker[1, 11:] = 0; ker[2, 5:13] = 0; ker[3, :] = 0
+    if kind == "suffix":
+        # the structure the fast path recognises, in its general form: every row one constant on U & [a_i, K) --
+        # U with a gap (an ImputationContext's zero taps), negative constants, duplicates, an all-zero row, d > 64
+        U = np.ones(K, bool)
+        U[K // 3: K // 3 + 7] = False
+        U[:3] = False
+        ker = np.zeros((d, K), np.float32)
+        starts = rng.integers(3, K, d)
+        starts[:4] = [K - 1, K - 1, 3, K // 3 + 2]           # a start inside the gap too
+        for i in range(d):
+            ker[i, starts[i]:] = np.float32(rng.standard_normal() or 1.0)
+        ker[:, ~U] = 0
+        ker[5, :] = 0
+        ker[7] = ker[6]
     x = syn.gbm_log_returns((B, K), seed + 1)
     hx = torch.nn.functional.conv1d(torch.tensor(x)[:, None, :], torch.tensor(ker)[:, None, :])[:, :, 0].numpy()
     return ds, ker, hx
@@ -87,6 +104,26 @@ def test_embedded_exhaustive_path_equals_oracle(hip_device, oracle_mod, R, T, d,
     dd, idx, status, _ = hip_scan_embedded(hip_device, ds, ker, hx, k, h, exhaustive=True)
     od, oidx = oracle_mod.scan_topk_embedded(ds, ker, hx, k, h=h)
     assert_exact(dd, idx, od, oidx, "embedded exhaustive")
+
+
+@pytest.mark.parametrize("kind,d,K", [("foveal", 0, 126), ("suffix", 40, 60)])
+def test_suffix_rows_fast_path_equals_the_dense_chains(hip_device, monkeypatch, kind, d, K):
+    """Foveal-like kernels take the bound-then-verify pass over running sums; PSH_EMBED=dense forces the dense
+    chains.  Same bits either way -- also with non-finite samples in the ensemble (NaN is kept by the cheap test,
+    an infinite segment maximum disarms it)."""
+    ds, ker, hx = _case_inputs(2048, 1024, d, K, 3, kind, 31)
+    ds = ds.copy()
+    ds[5, 0, 100] = np.nan
+    ds[700, 0, 513] = np.inf
+    ds[701, 0, 17] = -np.inf
+    ds[1500, 0, 900:903] = 3.0e38
+    fast = hip_scan_embedded(hip_device, ds, ker, hx, 512, 20, profile=True)
+    monkeypatch.setenv("PSH_EMBED", "dense")
+    dense = hip_scan_embedded(hip_device, ds, ker, hx, 512, 20, profile=True)
+    assert np.all(fast[2] == 0) and np.all(dense[2] == 0)
+    assert_exact(fast[0], fast[1], dense[0], dense[1], "suffix rows vs dense")
+    # the bootstrap of the fast path hands over upper bounds (a 1e-4 relative margin): a few more candidates
+    assert dense[3]["n_candidates"] <= fast[3]["n_candidates"] <= 1.05 * dense[3]["n_candidates"] + 8
 
 
 def test_embedded_sampled_path_is_taken(hip_device):

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--which", nargs="+", default=["tutorial", "testing"])
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--rows", type=int, default=0, help="override R of the testing workload")
+    ap.add_argument("--k", type=int, default=0, help="override k (k = 8: hardly any survivor, the cheap pass alone)")
     ap.add_argument("--generic", action="store_true", help="also time the generic torch path on the device")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -40,6 +41,8 @@ def main():
             "testing": dict(R=args.rows or 131072, T=4096, B=1, k=10000, h=252)}
     for name in args.which:
         c = cfgs[name]
+        if args.k:
+            c["k"] = args.k
         g = torch.Generator(device=dev).manual_seed(1)
         ds = torch.randn((c["R"], 1, c["T"]), generator=g, device=dev) * 0.0126      # testing.ipynb uses torch.randn
         x = torch.tensor(syn.gbm_log_returns((c["B"], 126), 2))
