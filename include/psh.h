@@ -48,8 +48,9 @@ extern "C" {
 
 /* per-query status words written to `out_status` (device) by psh_scan_topk */
 #define PSH_STATUS_OK        0
-#define PSH_STATUS_OVERFLOW  1     /* candidate buffer overflowed: results of that query are
-                                      INVALID, rerun it with psh_scan_topk_exhaustive */
+#define PSH_STATUS_OVERFLOW  1     /* candidate buffer overflowed -- or (embedded scan) fewer than k windows
+                                      lay below the sampled estimate of the k-th distance: results of that
+                                      query are INVALID, rerun it with the _exhaustive entry point */
 
 /*
  * Optional instrumentation of psh_scan_topk / psh_scan_topk_exhaustive.
@@ -152,6 +153,10 @@ int psh_scan_topk_exhaustive(int device, void* stream,
  * to ~1e-6 relative (tested at 1e-5) with indices equal outside near-ties; agreement
  * with the oracle's restatement of the order above is bit-exact.  Requires d <= 128 and
  * d * roundup4(K) <= 8192 (the kernel matrix lives in LDS), finite data.
+ * Kernels whose rows are one constant each on a common support from some tap onwards
+ * (Foveal, also with an ImputationContext's gap; recognised on the device, K <= 256) are
+ * scanned bound-then-verify over shared running sums -- same results, ~5x faster; the
+ * environment variable PSH_EMBED=dense forces the dense chains (A/B tests).
  */
 int psh_scan_topk_embedded(int device, void* stream,
                            const float* dataset, int64_t R, int64_t T, int64_t r_offset,

@@ -499,7 +499,11 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     // single query on the matrix cores: candidates are filed in two classes around an ESTIMATE of the k-th
     // smallest acc (the rank2-th smallest sampled minimum ~ 2k windows of the whole ensemble below it)
     int rank2 = 0;
-    if (use_mx) {
+    if (use_mx || p.ker) {
+        // The embedded scan ADMITS below this estimate (tau2 <= tau): a candidate costs it an exact d x K chain, and
+        // the provable tau of a 1/16 sample lets ~16 k of them through.  Everything with acc < tau2 is found, so when
+        // at least k windows are, the result is the exact top-k; when fewer are (the sample was not representative)
+        // the selection raises the query's status and the caller takes the exhaustive path, as for an overflow.
         const int64_t r2 = (2 * (int64_t)k * n_sample + p.R - 1) / p.R + 8;
         rank2 = (r2 < k && r2 <= bp.entries) ? (int)r2 : 0;
     }
@@ -512,7 +516,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     rc = plan_scan(device, p, p.R, &plan_f); if (rc) return rc;
     ScanArgs fa = make_scan_args(dataset, queries, p, w, plan_f, 0, 1, p.R);
     fa.use_mx = use_mx ? 1 : 0;
-    fa.bcount2 = rank2 > 0 ? w.bcount2 : nullptr;
+    fa.bcount2 = (use_mx && rank2 > 0) ? w.bcount2 : nullptr;
     if (use_mx) {
         // scan_mx_kernel reads the fp32 tile only window by window (no sliding refills past the segment):
         // SEG + W - 1 values rounded up to whole float4 stores, padded layout -- every byte counts, the
@@ -548,8 +552,8 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
 
     SelectArgs se = make_select_args(p, w, out_d, out_idx, out_status, true, nblk, 0);
     se.unsorted_ok = (profile && (profile->flags & PSH_FLAG_UNSORTED)) ? 1 : 0;
-    se.bcount2 = rank2 > 0 ? w.bcount2 : nullptr;
-    if (rank2 > 0) { se.dataset = dataset; se.queries = queries; se.T = p.T; se.r_offset = p.r_offset; se.W = p.W; }
+    se.bcount2 = (use_mx && rank2 > 0) ? w.bcount2 : nullptr;
+    if (use_mx && rank2 > 0) { se.dataset = dataset; se.queries = queries; se.T = p.T; se.r_offset = p.r_offset; se.W = p.W; }
     if (const char* e = getenv("PSH_DBG_SELECT_PTR")) se.dbg_times = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning aid
     HIP_TRY(launch_select(se, B, s));
     rc = tm.mark(); if (rc) return rc;                                       // 5

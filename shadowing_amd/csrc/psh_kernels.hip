@@ -1546,7 +1546,7 @@ __device__ __forceinline__ void emit16(const ScanArgs& a, int b, const float (&a
 // the threshold infinite (everything is verified exactly).
 #define PSH_NEST_BG 2                // queries sharing one pass of running sums (register budget: 128 VGPRs)
 #define PSH_NEST_MAX_K 256           // support masks are 4 x 64 bits, 16 blocks of 16 taps
-struct NestHdr { int ok; int nops; float cerr; int n_empty; unsigned blk[16]; };   // blk: active taps | closing taps << 16
+struct NestHdr { int ok; int nops; float cerr; int n_empty; unsigned blk[16]; int ncl[PSH_NEST_MAX_K]; };   // blk: active taps | closing taps << 16; ncl: rows closing at a tap
 
 // The running sums of a lane's 16 windows.  The window registers are addressed by DATA index:
 // y[base + m] lives in slot m & 15, so at tap j (PH = j & 15) window w reads slot (w + PH) & 15,
@@ -1575,6 +1575,7 @@ __device__ __forceinline__ void nest_shift(f32x2 (&W2)[8], f32x4 (&Q)[2], const 
     constexpr int GP = (PH % 4 == 0) ? (((PH >> 2) + 3) & 1) : ((PH >> 2) & 1);
     constexpr int SE = (PH + 15) & 15;                         // slot of the entering sample
     W2[SE & 7][SE >> 3] = Q[GP][(PH + 3) & 3];
+    asm volatile("" : "+v"(W2[SE & 7]));                      // materialise the pair now: one v_mov into its half, not a re-assembly per use
     if (PH % 4 == 0) {                                         // group G - 1 for the four taps after the next three
         int jq = j - 8;
         jq = jq < 0 ? 0 : jq;                                  // (a clamped quad is never consumed)
@@ -1626,6 +1627,9 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a
         nh->ok = (MODE != PSH_MODE_ALL && K <= PSH_NEST_MAX_K && !a.emb_dense) ? 1 : 0;
         nh->nops = d; nh->cerr = 0.0f; nh->n_empty = 0;
         for (int q = 0; q < 16; ++q) nh->blk[q] = 0u;
+    }
+    if ((int)threadIdx.x < PSH_NEST_MAX_K) nh->ncl[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
         for (int q = 0; q < 4; ++q) rmask[4 * d + q] = 0ull;
     }
     __syncthreads();
@@ -1674,7 +1678,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a
         if (tid < d) {
             prog[rk] = make_int4(lowest, tid, (int)__float_as_uint(c), n);
             if (n == 0) atomicAdd(&nh->n_empty, 1);
-            else atomicOr(&nh->blk[lowest >> 4], 0x10000u << (lowest & 15));
+            else { atomicOr(&nh->blk[lowest >> 4], 0x10000u << (lowest & 15)); atomicAdd(&nh->ncl[lowest], 1); }
         }
         if (tid < 16) {
             const unsigned long long uw = rmask[4 * d + (tid >> 2)];
@@ -1697,6 +1701,18 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a
     const bool nested = (MODE != PSH_MODE_ALL) && (__builtin_amdgcn_readfirstlane(nh->ok) != 0);
     const int n_empty = __builtin_amdgcn_readfirstlane(nh->n_empty);
     const float cerr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(nh->cerr)));
+    // rows in closing order, one per lane (two registers: d <= 128): what a closing row needs comes by v_readlane
+    int ctab[2] = {0, 0}, rtab[2] = {0, 0};                  // -c_i bits, row index
+    if (nested) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (lane + 64 * q < d) {
+                const int4 o = prog[lane + 64 * q];
+                ctab[q] = (int)(__float_as_uint(__uint_as_float((unsigned)o.z)) ^ 0x80000000u);
+                rtab[q] = o.y;
+            }
+        }
+    }
 
     const int nfloat = PSH_SEG + K - 1;
     const unsigned n_rs = (unsigned)a.n_rows * (unsigned)a.nseg;
@@ -1811,7 +1827,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a
                     if (lv && l == 0) {
                         ea = 0.0f;
                         for (int i = 0; i < d; ++i) { const float D = Dl[el * d + i]; ea = __builtin_fmaf(D, D, ea); }
-                        hit = ea < __uint_as_float(a.qstate[b].tau_bits);
+                        hit = ea < __uint_as_float(a.qstate[b].tau2_bits);
                     }
                     const unsigned long long mask = __ballot(hit);
                     wave_lds_fence();                        // Dl is rewritten by the next pass
@@ -1843,20 +1859,26 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a
                     for (int w = 0; w < 8; ++w) acc[g][w] = f32x2{0.f, 0.f};
                 Q[0] = f32x4{0.f, 0.f, 0.f, 0.f};
                 Q[1] = Q[0];
-                // rows in closing order; the next one's constants are fetched while the taps before it run
+                // the group's embedded queries, permuted into closing order across the lanes
                 int pc = 0;
-                int4 opn = prog[0];
-                int next_row = __builtin_amdgcn_readfirstlane(opn.y);
-                float next_nc = -__uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(opn.z));
-                float hxn[PSH_NEST_BG];
+                int hxt[PSH_NEST_BG][2];
 #pragma unroll
-                for (int g = 0; g < PSH_NEST_BG; ++g) hxn[g] = (g < nq) ? hxk[(int64_t)(b0 + g) * d + next_row] : 0.0f;
+                for (int g = 0; g < PSH_NEST_BG; ++g)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        hxt[g][q] = (g < nq && lane + 64 * q < d) ? (int)__float_as_uint(a.hx[(int64_t)(b0 + g) * d + rtab[q]]) : 0;
                 auto close_row = [&]() {                     // e = hx - c S;  acc += e^2  for the row at the head of the list
-                    const f32x2 nc2 = f32x2{next_nc, next_nc};
+                    const int sl2 = pc & 63;
+                    const bool lo64 = pc < 64;
+                    const int c0 = __builtin_amdgcn_readlane(ctab[0], sl2), c1 = __builtin_amdgcn_readlane(ctab[1], sl2);
+                    const float nc = __uint_as_float((unsigned)(lo64 ? c0 : c1));
+                    const f32x2 nc2 = f32x2{nc, nc};
 #pragma unroll
                     for (int g = 0; g < PSH_NEST_BG; ++g) {
                         if (g < nq) {                        // wave-uniform
-                            const f32x2 hx2 = f32x2{hxn[g], hxn[g]};
+                            const int h0 = __builtin_amdgcn_readlane(hxt[g][0], sl2), h1 = __builtin_amdgcn_readlane(hxt[g][1], sl2);
+                            const float hv = __uint_as_float((unsigned)(lo64 ? h0 : h1));
+                            const f32x2 hx2 = f32x2{hv, hv};
 #pragma unroll
                             for (int w = 0; w < 8; ++w) {
                                 const f32x2 e = __builtin_elementwise_fma(nc2, S[w], hx2);
@@ -1865,12 +1887,6 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a
                         }
                     }
                     ++pc;
-                    const int pn = pc < d ? pc : d - 1;
-                    opn = prog[pn];
-                    next_row = __builtin_amdgcn_readfirstlane(opn.y);
-                    next_nc = -__uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(opn.z));
-#pragma unroll
-                    for (int g = 0; g < PSH_NEST_BG; ++g) hxn[g] = (g < nq) ? hxk[(int64_t)(b0 + g) * d + next_row] : 0.0f;
                 };
                 for (int e0 = 0; e0 < n_empty; ++e0) close_row();            // all-zero rows: h = 0
                 {
@@ -1894,7 +1910,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a
                         if (bm & (1u << (PH))) nest_add<PH>(S, win);                            \
                         nest_shift<PH>(win, Q, tile, base, jb + (PH));                          \
                         if (bm & (0x10000u << (PH))) {                                          \
-                            do close_row(); while (pc < d && __builtin_amdgcn_readfirstlane(opn.x) == jb + (PH)); \
+                            for (int cl = __builtin_amdgcn_readfirstlane(nh->ncl[jb + (PH)]); cl > 0; --cl) close_row(); \
                         }
                         PSH_NEST_TAP(15) PSH_NEST_TAP(14) PSH_NEST_TAP(13) PSH_NEST_TAP(12)
                         PSH_NEST_TAP(11) PSH_NEST_TAP(10) PSH_NEST_TAP(9) PSH_NEST_TAP(8)
@@ -1924,7 +1940,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a
                             a.minbuf[(int64_t)b * a.min_stride + (int64_t)rs * 64 + lane] = ub;
                         }
                     } else {
-                        const float tau = __uint_as_float(qstate_k[b].tau_bits);
+                        const float tau = __uint_as_float(qstate_k[b].tau2_bits);
                         const float st = __builtin_sqrtf(tau) * (1.0f + 1.0f / 32768.0f) + err;
                         const float thr = st * st * (1.0f + 1.0f / 16384.0f);
                         unsigned hm = 0u;
@@ -1976,7 +1992,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a
             for (int g = 0; g < PSH_EMB_BG; ++g) {
                 const int b = b0 + g;
                 if (b < q_end) {
-                    const float tau = (MODE == PSH_MODE_FILTER) ? __uint_as_float(qstate_k[b].tau_bits) : 0.0f;
+                    const float tau = (MODE == PSH_MODE_FILTER) ? __uint_as_float(qstate_k[b].tau2_bits) : 0.0f;   // see below: the estimate, when there is one
                     const float xn = (MODE == PSH_MODE_ALL) ? qstate_k[b].xn : 0.0f;
                     emit16<MODE>(a, b, acc[g], nvalid, lane, rs, r_global, t_lane, tau, xn, pend, npend, lcount);
                 }
@@ -2386,7 +2402,9 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
             }
         }
         n = sm.offs[a.nblk];
-        if (tid == 0 && sm.overflow && a.status) a.status[b] = PSH_STATUS_OVERFLOW_;
+        // (n < k: the scan admitted below an ESTIMATE of the k-th smallest acc -- the embedded scan does, see
+        //  psh_capi.hip -- and the estimate fell short: same recovery as an overflow, the exhaustive path)
+        if (tid == 0 && (sm.overflow || n < a.k) && a.status) a.status[b] = PSH_STATUS_OVERFLOW_;
     } else {
         n = a.n_fixed;
     }

@@ -126,6 +126,37 @@ def test_suffix_rows_fast_path_equals_the_dense_chains(hip_device, monkeypatch, 
     assert dense[3]["n_candidates"] <= fast[3]["n_candidates"] <= 1.05 * dense[3]["n_candidates"] + 8
 
 
+def test_estimated_threshold_that_falls_short_raises_the_status(hip_device, oracle_mod):
+    """The embedded scan admits below an ESTIMATE of the k-th smallest distance taken from the sampled rows.  Here the
+    sample lies: near-copies of the query sit in the sampled rows only, so fewer than k windows of the whole ensemble
+    are below the estimate.  The selection must say so (status != 0) and the exhaustive path must then return the
+    exact answer -- what PathShadowing does with such a status."""
+    R, T, K, k, h = 2048, 640, 40, 1000, 0
+    ds, ker, hx = _case_inputs(R, T, 0, K, 1, "foveal", 77)
+    _, _, _, prof = hip_scan_embedded(hip_device, ds, ker, hx, k, h, profile=True)
+    n_s = prof["n_sample_rows"]
+    assert prof["path"] == 0 and 0 < n_s < R
+    stride = R // n_s
+    x = syn.gbm_log_returns((1, K), 78)[0]
+    ds = ds.copy()
+    rng = np.random.default_rng(5)
+    rank2 = (2 * k * n_s + R - 1) // R + 8
+    assert rank2 < k
+    planted = 0
+    for i in range(n_s):                                     # one near-copy per 64-sample stretch of every sampled row
+        r = stride // 2 + i * stride
+        for t in range(0, T - K - 64, 64):
+            if planted < rank2 + 40:
+                ds[r, 0, t:t + K] = x * (1 + 1e-3 * rng.standard_normal(K)).astype(np.float32)
+                planted += 1
+    assert rank2 < planted < k
+    dd, idx, status, _ = hip_scan_embedded(hip_device, ds, ker, hx, k, h)
+    assert status[0] != 0, "the estimate fell short and nobody noticed"
+    dd, idx, status, _ = hip_scan_embedded(hip_device, ds, ker, hx, k, h, exhaustive=True)
+    od, oidx = oracle_mod.scan_topk_embedded(ds, ker, hx, k, h=h)
+    assert_exact(dd, idx, od, oidx, "exhaustive after a short estimate")
+
+
 def test_embedded_sampled_path_is_taken(hip_device):
     ds, ker, hx = _case_inputs(2048, 2048, 0, 126, 2, "foveal", 5)
     _, _, status, prof = hip_scan_embedded(hip_device, ds, ker, hx, 1024, 252, profile=True)
