@@ -34,8 +34,8 @@ from tqdm import tqdm
 from . import _native
 from .averaging import DiscreteProba, Softmax, Uniform
 from .path_distance import PathDistance, RelativeMSE
-from .path_embedding import (ArrayType, ContextManagerBase, Identity, ImputationContext, PathEmbedding,
-                             PredictionContext)
+from .path_embedding import (ArrayType, ContextManagerBase, CrossChannelContext, Identity, ImputationContext,
+                             PathEmbedding, PredictionContext)
 
 
 @contextlib.contextmanager
@@ -103,6 +103,7 @@ class PathShadowing:
         self.distance = distance
         self.context = context or PredictionContext(horizon=None)
         self._resident = None       # (key, device tensor (R, C, T)) -- the ensemble in HBM
+        self._scan_rows = None      # (key, device tensor (R, T)): channel 0 of a multi-channel ensemble
         self._workspace = None
         self.last_profile = None
 
@@ -135,8 +136,14 @@ class PathShadowing:
                       queries, kernel small enough for LDS -- psh_scan_topk_embedded;
           "padded"  : a stock embedding (Identity included) + RelativeMSE + ImputationContext((l, c, r)):
                       the context's zero taps over the gap are part of the scanning kernel -- the same
-                      entry point with the padded (d, l+c+r) kernel and no trailing horizon."""
-        if not (type(self.distance) is RelativeMSE and x.shape[1] == 1 and y.ndim == 3 and y.shape[1] == 1
+                      entry point with the padded (d, l+c+r) kernel and no trailing horizon.
+        A CrossChannelContext(oc) (ensemble of 1 + oc channels, query on the first) pads the kernel with zero
+        taps on the other channels: the scan is the "identity" / "linear" one over channel 0, the gathered paths
+        keep every channel."""
+        n_ch = 1
+        if type(self.context) is CrossChannelContext and isinstance(self.context.out_context_channels, int):
+            n_ch = 1 + self.context.out_context_channels
+        if not (type(self.distance) is RelativeMSE and x.shape[1] == 1 and y.ndim == 3 and y.shape[1] == n_ch
                 and x.dtype == torch.float32 and y.dtype == torch.float32 and k <= _native.PSH_MAX_K):
             return None
         emb = self.embedding
@@ -150,7 +157,9 @@ class PathShadowing:
                     and _native.embedding_supported(emb.kernel.shape[0], sum(p))):
                 return "padded"
             return None
-        if type(self.context) is not PredictionContext:
+        if type(self.context) not in (PredictionContext, CrossChannelContext):
+            return None
+        if type(self.context) is CrossChannelContext and n_ch < 2:
             return None
         if type(emb) is Identity:
             ok = x.shape[-1] == emb.kernel.shape[0] and x.shape[-1] <= _native.PSH_MAX_W
@@ -178,12 +187,24 @@ class PathShadowing:
         key = (y.data_ptr(), tuple(y.shape), y._version, device)
         if self._resident is None or self._resident[0] != key:
             self._resident = (key, y.contiguous().to(device, non_blocking=False))
+            self._scan_rows = None
         return self._resident[1]
+
+    def _scan_rows_of(self, ds: torch.Tensor) -> torch.Tensor:
+        """(R, T) rows the scan reads: the ensemble itself, or -- several channels, CrossChannelContext -- a
+        contiguous copy of channel 0 kept beside it."""
+        if ds.shape[1] == 1:
+            return ds[:, 0, :]
+        key = (ds.data_ptr(), tuple(ds.shape), ds._version)
+        if self._scan_rows is None or self._scan_rows[0] != key:
+            self._scan_rows = (key, ds[:, 0, :].contiguous())
+        return self._scan_rows[1]
 
     def _native_scan(self, x: torch.Tensor, y: torch.Tensor, k: int):
         dev = self._hip_device()
         _native.load()
         ds = self._resident_dataset(y, dev)
+        rows = self._scan_rows_of(ds)
         h = self.context.get_out_times()
         if self._workspace is None or self._workspace.device != dev:
             self._workspace = _native.Workspace(dev)
@@ -208,14 +229,14 @@ class PathShadowing:
 
             def scan(sel, exhaustive):
                 q = hx if sel is None else hx[sel].contiguous()
-                return _native.scan_topk_embedded(ds[:, 0, :], ker2, q, k, h=h, workspace=self._workspace,
+                return _native.scan_topk_embedded(rows, ker2, q, k, h=h, workspace=self._workspace,
                                                   exhaustive=exhaustive)
         else:
             xq = x[:, 0, :].contiguous().to(dev)
 
             def scan(sel, exhaustive):
                 q = xq if sel is None else xq[sel].contiguous()
-                return _native.scan_topk(ds[:, 0, :], q, k, h=h, workspace=self._workspace, exhaustive=exhaustive)
+                return _native.scan_topk(rows, q, k, h=h, workspace=self._workspace, exhaustive=exhaustive)
         d, idx, status = scan(None, False)
         bad = torch.nonzero(status != _native.PSH_STATUS_OK).flatten()
         if bad.numel():

@@ -16,6 +16,8 @@ SMALL_GOLDENS = ["cfg1_h20", "cfg1_hNone", "multiquery_splits", "remainder_split
 BIG_GOLDENS = ["cfg2_R32768", "cfg3_rolling_R2048"]
 # ImputationContext((l, c, r)): the gap's zero taps are part of the scanning kernel ("kernel_padded")
 IMPUTATION_GOLDENS = ["imputation_identity_8_5_12", "imputation_user_kernel_6_9_7"]
+# CrossChannelContext(oc): ensemble of 1 + oc channels, the scan reads channel 0, the gathered paths keep all
+CROSS_GOLDENS = ["crosschannel_identity_C2", "crosschannel_foveal_C3"]
 # linear embeddings (Foveal / user kernels) in front of RelativeMSE: psh_scan_topk_embedded
 EMBEDDED_GOLDENS = ["foveal_tutorial_small", "foveal_a2_hNone", "user_kernel_d5_K23", "foveal_ragged_B7",
                     "foveal_tutorial_R1024", "wavelet_W252_rolling"]

@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--big", action="store_true", help="also the cfg-2 / cfg-3 sized cases (~2 min)")
     ap.add_argument("--embedded", action="store_true",
                     help="ONLY the linear-embedding cases (Foveal / user kernels); the Identity fixtures are left alone")
+    ap.add_argument("--cross", action="store_true",
+                    help="ONLY the CrossChannelContext cases (multi-channel ensemble, scan on channel 0)")
     args = ap.parse_args()
 
     ref = load_reference()
@@ -99,6 +101,29 @@ def main():
         out["meta"] = json.dumps(m)
         np.savez_compressed(HERE / f"{name}.npz", **out)
         print(f"{name}: kernel{tuple(emb.kernel.shape)} d{d.shape} idx{idx.shape} paths{paths.shape} ref {dt:.2f}s")
+
+    def run_cross(name, emb, ds, q, oc, k, n_splits):
+        """CrossChannelContext(oc) (path_embedding.py:91-114): the ensemble has 1 + oc channels, the query only the
+        first; pad_context gives the scanning kernel zero taps on the other channels."""
+        obj = ref.PathShadowing(emb, ref.RelativeMSE(), ds, ref.CrossChannelContext(oc))
+        t0 = time.time()
+        d, paths, idx = obj.shadow(q, k=k, n_splits=n_splits, cuda=False)
+        dt = time.time() - t0
+        hx = emb(torch.tensor(q))[:, 0, :]
+        out = dict(queries=q, kernel=emb.kernel[:, 0, :].numpy(), hx=hx.numpy(), d=d, idx=idx, paths=paths, h=-1, k=k,
+                   n_splits=n_splits, out_context_channels=oc, dataset=ds, dataset_sha256=syn.sha256(ds),
+                   dataset_shape=np.array(ds.shape),
+                   meta=json.dumps(dict(reference_seconds=round(dt, 3), numpy=np.__version__, torch=torch.__version__)))
+        np.savez_compressed(HERE / f"{name}.npz", **out)
+        print(f"{name}: dataset{ds.shape} d{d.shape} idx{idx.shape} paths{paths.shape} ref {dt:.2f}s")
+
+    if args.cross:
+        def multi(R, T, C, seed):
+            return np.ascontiguousarray(np.concatenate([syn.dataset(R, T, seed + c) for c in range(C)], axis=1))
+        run_cross("crosschannel_identity_C2", ref.Identity(20), multi(70, 400, 2, 50), syn.gbm_log_returns((3, 1, 20), 52), 1, 48, 2)
+        run_cross("crosschannel_foveal_C3", ref.Foveal(alpha=2.0, beta=0.5, max_context=32), multi(40, 300, 3, 53),
+                  syn.gbm_log_returns((2, 1, 32), 56), 2, 30, 1)
+        return
 
     if args.embedded:
         # the tutorial's embedding (tutorial.ipynb cell 8): Foveal(1.15, 0.9, 126)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import EMBEDDED_GOLDENS, IMPUTATION_GOLDENS, assert_exact, assert_matches_reference, bits, load_golden, rows3
+from _util import CROSS_GOLDENS, EMBEDDED_GOLDENS, IMPUTATION_GOLDENS, assert_exact, assert_matches_reference, bits, load_golden, rows3
 from shadowing_amd import synthetic as syn
 
 pytestmark = pytest.mark.gpu
@@ -279,3 +279,27 @@ def test_path_shadowing_with_an_imputation_context_runs_native(hip_device, name)
     # the in-context / out-context split of the gathered paths (what predict_from_paths consumes)
     left, gap, right = (int(v) for v in g["portion"])
     assert obj.context.select_out_context(paths).shape[-1] == gap
+
+
+@pytest.mark.parametrize("name", CROSS_GOLDENS)
+def test_path_shadowing_with_a_cross_channel_context_runs_native(hip_device, name):
+    """PathShadowing(embedding, RelativeMSE, ds (R, 1 + oc, T), CrossChannelContext(oc)).shadow(cuda=True): the scan
+    runs over channel 0 (the context's zero taps on the other channels contribute nothing), the gathered paths keep
+    every channel -- the reference's shadow(cuda=False) output."""
+    from shadowing import CrossChannelContext, Foveal, Identity, PathShadowing, RelativeMSE
+    g = load_golden(name)
+    emb = Identity(20) if name.startswith("crosschannel_identity") else Foveal(alpha=2.0, beta=0.5, max_context=32)
+    oc = int(g["out_context_channels"])
+    obj = PathShadowing(emb, RelativeMSE(), g["dataset"], CrossChannelContext(oc))
+    d, paths, idx = obj.shadow(g["queries"], k=g["k"], n_splits=g["n_splits"], cuda=True)
+    assert obj.last_path == "hip"
+    assert_matches_reference(d, idx, g, None, what=name)
+    W = g["queries"].shape[-1]
+    assert paths.shape == g["paths"].shape
+    for b in range(d.shape[0]):
+        for i in range(d.shape[1]):
+            r, t = idx[b, i]
+            assert np.array_equal(paths[b, i], g["dataset"][r, :, t:t + W])
+    assert obj.context.select_out_context(paths).shape[-2] == oc
+    d2, _, idx2 = obj.shadow(g["queries"], k=g["k"], cuda=True)          # second call: resident ensemble + channel-0 copy reused
+    assert np.array_equal(bits(d), bits(d2)) and np.array_equal(idx, idx2)

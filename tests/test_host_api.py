@@ -188,5 +188,9 @@ def test_native_dispatch_rules():
     assert kind(sa.Identity(20), ctx=sa.ImputationContext(None)) is None
     assert kind(Squared(torch.randn(3, 1, 10)), ctx=sa.ImputationContext((4, 3, 6))) is None
     assert kind(sa.Identity(20), y=torch.zeros((4, 2, 600))) is None        # two channels
+    assert kind(sa.Identity(20), ctx=sa.CrossChannelContext(1), y=torch.zeros((4, 2, 600))) == "identity"
+    assert kind(sa.Foveal(2.0, 0.5, 20), ctx=sa.CrossChannelContext(2), y=torch.zeros((4, 3, 600))) == "linear"
+    assert kind(sa.Identity(20), ctx=sa.CrossChannelContext(2), y=torch.zeros((4, 2, 600))) is None   # channel count off
+    assert kind(Squared(torch.randn(3, 1, 20)), ctx=sa.CrossChannelContext(1), y=torch.zeros((4, 2, 600))) is None
     assert kind(sa.Identity(20), k=_native.PSH_MAX_K + 1) is None
     assert kind(sa.Identity(20), x=torch.zeros((2, 1, 20), dtype=torch.float64)) is None

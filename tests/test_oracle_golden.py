@@ -6,7 +6,7 @@ order among exact ties, gathered paths identical."""
 import numpy as np
 import pytest
 
-from _util import (BIG_GOLDENS, EMBEDDED_GOLDENS, IMPUTATION_GOLDENS, SMALL_GOLDENS, assert_matches_reference, bits, canonical,
+from _util import (BIG_GOLDENS, CROSS_GOLDENS, EMBEDDED_GOLDENS, IMPUTATION_GOLDENS, SMALL_GOLDENS, assert_matches_reference, bits, canonical,
                    load_golden, rows3)
 
 
@@ -143,3 +143,39 @@ def test_embedded_oracle_reproduces_reference_with_an_imputation_context(oracle_
     assert_matches_reference(d, idx, g, all_dist, what=name)
     ref_paths = oracle_mod.gather_paths(ds, g["idx"], g["kernel_padded"].shape[1])[:, :, None, :]
     assert np.array_equal(ref_paths, g["paths"])
+
+
+@pytest.mark.parametrize("name", CROSS_GOLDENS)
+def test_oracle_reproduces_reference_with_a_cross_channel_context(oracle_mod, name):
+    """CrossChannelContext(oc) (path_embedding.py:91-114): pad_context gives the scanning kernel zero taps on the
+    oc extra channels, so the scan is the one over channel 0 (h = 0); the gathered paths keep every channel."""
+    g = load_golden(name)
+    ds = g["dataset"]
+    ch0 = np.ascontiguousarray(ds[:, 0:1, :])
+    if name.startswith("crosschannel_identity"):
+        d, idx = oracle_mod.scan_topk(ch0, g["queries"][:, 0, :], g["k"], h=0)
+        all_dist = [oracle_mod.all_distances(ch0, q, 0) for q in g["queries"][:, 0, :]]
+    else:
+        d, idx = oracle_mod.scan_topk_embedded(ch0, g["kernel"], g["hx"], g["k"], h=0)
+        all_dist = [oracle_mod.all_distances_embedded(ch0, g["kernel"], q, 0) for q in g["hx"]]
+    assert_matches_reference(d, idx, g, all_dist, what=name)
+    W = g["queries"].shape[-1]
+    for b in range(d.shape[0]):
+        for i in range(d.shape[1]):
+            r, t = g["idx"][b, i]
+            assert np.array_equal(g["paths"][b, i], ds[r, :, t:t + W])
+
+
+@pytest.mark.parametrize("name", CROSS_GOLDENS)
+def test_host_path_with_a_cross_channel_context_matches_reference(name):
+    """cuda=False: the generic torch formulation (what the reference itself runs) through this package's classes."""
+    import torch
+    from shadowing import CrossChannelContext, Foveal, Identity, PathShadowing, RelativeMSE
+    g = load_golden(name)
+    emb = Identity(20) if name.startswith("crosschannel_identity") else Foveal(alpha=2.0, beta=0.5, max_context=32)
+    assert np.array_equal(emb.kernel[:, 0, :].numpy(), g["kernel"])
+    obj = PathShadowing(emb, RelativeMSE(), g["dataset"], CrossChannelContext(int(g["out_context_channels"])))
+    d, paths, idx = obj.shadow(g["queries"], k=g["k"], n_splits=g["n_splits"], cuda=False)
+    assert np.array_equal(bits(np.sort(d, 1)), bits(np.sort(g["d"], 1)))
+    assert paths.shape == g["paths"].shape
+    assert obj.context.select_out_context(paths).shape[-2] == int(g["out_context_channels"])
