@@ -32,7 +32,7 @@ import torch
 from tqdm import tqdm
 
 from . import _native
-from .averaging import DiscreteProba, Softmax, Uniform
+from .averaging import HAVE_SCATSPECTRA, DiscreteProba, Softmax, Uniform
 from .path_distance import PathDistance, RelativeMSE
 from .path_embedding import (ArrayType, ContextManagerBase, CrossChannelContext, Identity, ImputationContext,
                              PathEmbedding, PredictionContext)
@@ -102,6 +102,8 @@ class PathShadowing:
         self.embedding = embedding
         self.distance = distance
         self.context = context or PredictionContext(horizon=None)
+        self._host = None           # (key, float32 torch wrapper of a numpy ensemble)
+        self._host_gen = 0
         self._resident = None       # (key, device tensor (R, C, T)) -- the ensemble in HBM
         self._scan_rows = None      # (key, device tensor (R, T)): channel 0 of a multi-channel ensemble
         self._workspace = None
@@ -125,6 +127,31 @@ class PathShadowing:
         if isinstance(dataset, TimeSeriesDataset):
             dataset = dataset.load()
         return dataset
+
+    def _dataset_tensor(self) -> torch.Tensor:
+        """The ensemble as a float32 (R, C, T) torch tensor.  The reference converts (copies) the whole array on
+        every call (ref :205: 0.5 GB per call at R = 32768); here a numpy ensemble is wrapped once, without a copy
+        when it already is contiguous float32, and the wrapper -- hence the copy resident in HBM, which is keyed
+        on it -- is kept while the array is the same object with the same contents.  "Same contents" is checked
+        on a strided sample of 4096 values, enough to notice an in-place refresh of the ensemble; after a surgical
+        in-place edit call `refresh()`."""
+        ds = self.dataset
+        if isinstance(ds, torch.Tensor):
+            return _dim_array(ds)
+        arr = np.asarray(ds)
+        flat = arr.reshape(-1)
+        probe = flat[:: max(1, flat.size // 4096)][:4096]
+        key = (id(ds), arr.shape, arr.dtype.str, arr.__array_interface__["data"][0],
+               float(np.sum(probe, dtype=np.float64)), float(np.sum(np.abs(probe), dtype=np.float64)))
+        if self._host is None or self._host[0] != key:
+            self._host = (key, torch.as_tensor(np.ascontiguousarray(_dim_array(arr), dtype=np.float32)))
+            self._host_gen += 1                       # the HBM copy is keyed on this too
+        return self._host[1]
+
+    def refresh(self) -> None:
+        """Forget the cached views of `dataset` (host wrapper, HBM copy): call after editing it in place."""
+        self._host = self._resident = self._scan_rows = None
+        self._host_gen += 1
 
     # ------------------------------------------------------------------ native path
     def _native_kind(self, x: torch.Tensor, y: torch.Tensor, k: int) -> str | None:
@@ -184,7 +211,7 @@ class PathShadowing:
         host storage (the reference re-uploads every split on every call, ref :154-155)."""
         if y.is_cuda:
             return y.contiguous()
-        key = (y.data_ptr(), tuple(y.shape), y._version, device)
+        key = (y.data_ptr(), tuple(y.shape), y._version, device, self._host_gen)
         if self._resident is None or self._resident[0] != key:
             self._resident = (key, y.contiguous().to(device, non_blocking=False))
             self._scan_rows = None
@@ -311,7 +338,7 @@ class PathShadowing:
         if ksize != 0 and ksize != x_context.shape[-1]:
             raise Exception("The embedding kernel should be of the same size as the context.")
         x = _torch(_dim_array(x_context))
-        y = _torch(_dim_array(self.dataset))
+        y = self._dataset_tensor()
         length = x.shape[-1] + self.context.get_out_times()
 
         if cuda and self._native_ok(x, y, k):
@@ -346,14 +373,55 @@ class PathShadowing:
         values = to_predict(future)
         return proba.avg(values, axis=1), proba.std(values, axis=1)
 
+    def _predict_on_device(self, x: torch.Tensor, y: torch.Tensor, k: int, to_predict: Callable,
+                           proba_name: str, eta: float | None):
+        """shadow() + predict_from_paths() without leaving the GPU: the k paths of every query (74 MB for the
+        tutorial's call) stay in HBM, `to_predict` runs on the device tensor of their out-context, the weighted
+        moments are reduced there, and only the (B, ...) results travel.  Returns None when this cannot be done
+        faithfully -- `to_predict` does not take torch tensors (a numpy-only callable), or the averaging classes
+        are the real scatspectra ones, whose arithmetic is not restated here -- and the caller takes the host path."""
+        if HAVE_SCATSPECTRA or proba_name not in ("uniform", "softmax"):
+            return None
+        d, idx, ds = self._native_scan(x, y, k)
+        paths = _native.gather_paths(ds, idx, x.shape[-1] + self.context.get_out_times())
+        try:
+            values = to_predict(self.context.select_out_context(paths))
+        except Exception:  # noqa: BLE001 -- a callable written for numpy arrays
+            return None
+        if not (isinstance(values, torch.Tensor) and values.is_cuda and values.dim() >= 2 and values.shape[:2] == d.shape):
+            return None
+        self.last_path = "hip"
+        v = values.to(torch.float64)
+        if proba_name == "uniform" or eta is None:        # the stand-in classes of averaging.py, same formulas
+            w = torch.full(d.shape, 1.0 / d.shape[1], dtype=torch.float64, device=d.device)
+        else:
+            z = -(d.to(torch.float64) ** 2) / (2.0 * float(eta) ** 2)
+            w = torch.exp(z - z.max(dim=1, keepdim=True).values)
+            w = w / w.sum(dim=1, keepdim=True)
+        w = w.reshape(w.shape + (1,) * (v.dim() - 2))
+        mean = (w * v).sum(dim=1)
+        std = torch.sqrt((w * (v - mean.unsqueeze(1)) ** 2).sum(dim=1))
+        return self._to_host(mean, std)
+
     def predict(self, x_context: ArrayType, k: int, to_predict: Callable, eta: float | None = None,
                 proba_name: str = "softmax", n_dataset_splits: int = 1, n_context_splits: int = 1,
                 cuda: bool = False) -> tuple[np.ndarray, np.ndarray]:
-        """shadow() + predict_from_paths() over `n_context_splits` batches of queries (ref :256-301)."""
+        """shadow() + predict_from_paths() over `n_context_splits` batches of queries (ref :256-301).
+        With cuda=True on a natively scanned configuration the whole chain runs on the device when `to_predict`
+        accepts torch tensors (`shadowing.realized_variance` does): see _predict_on_device."""
         x = _torch(_dim_array(x_context))
         n = x.shape[0]
+        y = None
         means, stds = [], []
         for rows in tqdm(torch.arange(n).split(n // n_context_splits)):
+            if cuda:
+                y = self._dataset_tensor() if y is None else y
+                if self._native_ok(x[rows, ...], y, k):
+                    got = self._predict_on_device(x[rows, ...], y, k, to_predict, proba_name, eta)
+                    if got is not None:
+                        means.append(got[0])
+                        stds.append(got[1])
+                        continue
             d, paths, _ = self.shadow(x[rows, ...], k, n_dataset_splits, cuda)
             m, s = self.predict_from_paths(d, paths, to_predict, proba_name, eta)
             means.append(m)

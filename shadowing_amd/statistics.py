@@ -1,13 +1,20 @@
-"""Host helper used by the README / tutorial snippets of the reference
-(shadowing/statistics.py:5-16): annualised realized variance per maturity."""
+"""Helper used by the README / tutorial snippets of the reference
+(shadowing/statistics.py:5-16): annualised realized variance per maturity.  Takes numpy arrays like the
+reference's, and torch tensors on any device (so that `predict(..., cuda=True)` can evaluate it where the
+shadowing paths already are)."""
 from __future__ import annotations
 
 import numpy as np
+import torch
 
 
-def realized_variance(x: np.ndarray, Ts, vol: bool = False) -> np.ndarray:
+def realized_variance(x, Ts, vol: bool = False):
     """x: (..., T) log-returns; Ts: iterable of maturities (in samples).
     Returns (..., len(Ts)): mean(x^2[..., :T]) * 252 (its square root if vol)."""
+    if isinstance(x, torch.Tensor):
+        x2 = x ** 2
+        out = torch.stack([x2[..., :int(T)].mean(-1) for T in Ts], dim=-1) * 252
+        return out ** 0.5 if vol else out
     x = np.asarray(x)
     out = np.stack([(x[..., :T] ** 2).mean(-1) * 252 for T in Ts], axis=-1)
     return np.sqrt(out) if vol else out

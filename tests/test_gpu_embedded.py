@@ -303,3 +303,32 @@ def test_path_shadowing_with_a_cross_channel_context_runs_native(hip_device, nam
     assert obj.context.select_out_context(paths).shape[-2] == oc
     d2, _, idx2 = obj.shadow(g["queries"], k=g["k"], cuda=True)          # second call: resident ensemble + channel-0 copy reused
     assert np.array_equal(bits(d), bits(d2)) and np.array_equal(idx, idx2)
+
+
+@pytest.mark.parametrize("proba,eta", [("softmax", 0.1), ("uniform", None)])
+def test_predict_runs_on_the_device_and_matches_the_host_chain(hip_device, monkeypatch, proba, eta):
+    """predict(cuda=True) with a torch-capable `to_predict` (shadowing.realized_variance): scan, gather, statistic
+    and weighted moments all on the GPU.  Same numbers as shadow() + predict_from_paths() on the host (float64
+    moments: 1e-9); a numpy-only callable silently takes the host chain."""
+    import shadowing
+    from shadowing import Foveal, PathShadowing, PredictionContext, RelativeMSE, realized_variance
+    ds = syn.dataset(1024, 900, 61)
+    x = syn.gbm_log_returns((5, 40), 62)
+    obj = PathShadowing(Foveal(alpha=1.4, beta=0.9, max_context=40), RelativeMSE(), ds, PredictionContext(horizon=30))
+    Ts = [2, 7, 30]
+    to_predict = lambda p: realized_variance(p, Ts=Ts, vol=False)[:, :, 0, :]     # noqa: E731
+    seen = []
+    real = obj._predict_on_device
+    monkeypatch.setattr(obj, "_predict_on_device", lambda *a: seen.append(real(*a)) or seen[-1])
+    m, s = obj.predict(x, k=256, to_predict=to_predict, eta=eta, proba_name=proba, n_context_splits=2, cuda=True)
+    assert len(seen) == 3 and all(v is not None for v in seen)          # 5 queries in splits of 2: device chain each time
+    d, paths, _ = obj.shadow(x, k=256, cuda=True)
+    m0, s0 = obj.predict_from_paths(d, paths, to_predict, proba, eta)
+    assert m.shape == m0.shape == (5, 3)
+    np.testing.assert_allclose(m, m0, rtol=2e-6)                         # float32 statistic, float64 moments
+    np.testing.assert_allclose(s, s0, rtol=2e-5, atol=1e-12)
+    seen.clear()
+    host_only = lambda p: np.asarray(realized_variance(np.asarray(p), Ts=Ts, vol=False))[:, :, 0, :]   # noqa: E731
+    m1, s1 = obj.predict(x, k=256, to_predict=host_only, eta=eta, proba_name=proba, cuda=True)
+    assert seen == [None]
+    np.testing.assert_allclose(m1, m0, rtol=1e-12)

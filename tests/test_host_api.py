@@ -194,3 +194,34 @@ def test_native_dispatch_rules():
     assert kind(Squared(torch.randn(3, 1, 20)), ctx=sa.CrossChannelContext(1), y=torch.zeros((4, 2, 600))) is None
     assert kind(sa.Identity(20), k=_native.PSH_MAX_K + 1) is None
     assert kind(sa.Identity(20), x=torch.zeros((2, 1, 20), dtype=torch.float64)) is None
+
+
+def test_numpy_ensemble_is_wrapped_once_and_edits_are_noticed():
+    """shadow() does not copy a contiguous float32 ensemble per call (the reference does, ref :205); the cached
+    wrapper follows the array's contents: a refreshed ensemble is seen, refresh() forces it."""
+    ds = syn.dataset(32, 300, 3)
+    obj = sa.PathShadowing(sa.Identity(10), sa.RelativeMSE(), ds, sa.PredictionContext(5))
+    y1 = obj._dataset_tensor()
+    assert y1.data_ptr() == ds.__array_interface__["data"][0]              # no copy
+    assert obj._dataset_tensor() is y1
+    q = syn.gbm_log_returns((1, 10), 4)
+    d1, _, i1 = obj.shadow(q, k=5)
+    ds[:] = syn.dataset(32, 300, 9)                                        # in-place refresh of the whole ensemble
+    y2 = obj._dataset_tensor()
+    assert y2 is not y1 and obj._host_gen == 2
+    d2, _, i2 = obj.shadow(q, k=5)
+    ref = sa.PathShadowing(sa.Identity(10), sa.RelativeMSE(), ds.copy(), sa.PredictionContext(5)).shadow(q, k=5)
+    assert np.array_equal(d2, ref[0]) and np.array_equal(i2, ref[2]) and not np.array_equal(d1, d2)
+    obj.refresh()
+    assert obj._dataset_tensor() is not y2
+    f64 = sa.PathShadowing(sa.Identity(10), sa.RelativeMSE(), ds.astype(np.float64), sa.PredictionContext(5))
+    assert f64._dataset_tensor().dtype == torch.float32 and np.array_equal(f64.shadow(q, k=5)[0], d2)
+
+
+def test_realized_variance_takes_torch_tensors():
+    x = syn.gbm_log_returns((3, 4, 30), 5)
+    for vol in (False, True):
+        a = sa.realized_variance(x, [2, 7, 30], vol=vol)
+        b = sa.realized_variance(torch.tensor(x), [2, 7, 30], vol=vol)
+        assert isinstance(b, torch.Tensor) and b.shape == (3, 4, 3)
+        np.testing.assert_allclose(b.numpy(), a, rtol=1e-6)

@@ -69,11 +69,24 @@ def main():
             d, paths, idx = obj.shadow(x.numpy(), k=c["k"], cuda=True)
         api_ms = (time.perf_counter() - t0) / 5 * 1e3
         assert obj.last_path == "hip"
+        # the reference's own timed call (testing.ipynb:95-104): predict() = scan + gather + statistic + weighted moments
+        from shadowing_amd.statistics import realized_variance
+        to_predict = lambda p: realized_variance(p, Ts=[2, 7, 252], vol=False)     # noqa: E731
+        obj.predict(x.numpy(), k=c["k"], to_predict=to_predict, eta=0.1, cuda=True)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            obj.predict(x.numpy(), k=c["k"], to_predict=to_predict, eta=0.1, cuda=True)
+        predict_ms = (time.perf_counter() - t0) / 5 * 1e3
+        host_tp = lambda p: realized_variance(np.asarray(p), Ts=[2, 7, 252], vol=False)   # noqa: E731
+        t0 = time.perf_counter()
+        obj.predict(x.numpy(), k=c["k"], to_predict=host_tp, eta=0.1, cuda=True)
+        predict_host_ms = (time.perf_counter() - t0) * 1e3
         line = dict(workload=name, config=c, embedding="Foveal(1.15,0.9,126) d=34", ms_per_call=round(ms, 4),
                     windows=windows, query_windows_per_s=windows * c["B"] / (ms * 1e-3),
                     nonzero_taps=taps, gfma_per_s=windows * taps * ((c["B"] + 2) // 3) / (ms * 1e-3) / 1e9,
                     stages_ms={k: round(v, 4) for k, v in stages.items() if k.endswith("_ms")},
                     n_candidates=stages["n_candidates"], shadow_api_ms=round(api_ms, 3),
+                    predict_api_ms=round(predict_ms, 3), predict_api_host_statistic_ms=round(predict_host_ms, 3),
                     reference_published="2.65 s per predict() call (testing.ipynb:90, unnamed NVIDIA GPU, H2D included)"
                     if name == "testing" else None)
         if args.generic:
