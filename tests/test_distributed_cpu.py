@@ -49,6 +49,19 @@ def _worker(rank, world, port, R, T, W, h, k, B, tmp):
         q = syn.rolling_queries(B, W, 6)
         d, paths, idx = obj.shadow(q, k)
         np.savez(os.path.join(tmp, f"rank{rank}.npz"), d=d, paths=paths, idx=idx)
+        # pipelined form: batch i+1 begins (local scan + start of its all-gather) before batch i is finished
+        qs = [torch.tensor(syn.rolling_queries(B, W, 60 + i)) for i in range(3)]
+        serial = [obj.scan(qi, k) for qi in qs]
+        outs, pend = [], None
+        for qi in qs:
+            nxt = obj.scan_begin(qi, k)
+            if pend is not None:
+                outs.append(pend.finish())
+            pend = nxt
+        outs.append(pend.finish())
+        assert pend.finish() is outs[-1]                                   # finishing twice is harmless
+        for a, b in zip(serial, outs):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     finally:
         dist.destroy_process_group()
 
