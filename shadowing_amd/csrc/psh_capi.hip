@@ -317,7 +317,8 @@ int run_exhaustive(int device, hipStream_t s, const float* dataset, const float*
                    const Problem& p, const Workspace& w, float* out_d, int32_t* out_idx, int32_t* out_status,
                    psh_profile* prof) {
     const int64_t nseg = (p.Tp + PSH_SEG - 1) / PSH_SEG;
-    const int64_t slots_per_row = nseg * PSH_SEG;
+    const bool rows_path = p.Tp == 1 && !p.ker && getenv("PSH_ROWS") == nullptr;   // one-window rows: a slot per row (rows_kernel)
+    const int64_t slots_per_row = rows_path ? 1 : nseg * PSH_SEG;
     if ((int64_t)w.cap < (int64_t)p.k + slots_per_row) return PSH_ERR_WORKSPACE;
     const bool stages = prof && prof->mode == PSH_PROFILE_STAGES;
     const bool events = prof && prof->mode == PSH_PROFILE_EVENTS && prof->ev_scan_begin && prof->ev_scan_end;
@@ -341,7 +342,15 @@ int run_exhaustive(int device, hipStream_t s, const float* dataset, const float*
         ReseedArgs ra{out_d, out_idx, w.qstate, w.cand_d, w.cand_rt, (int64_t)w.cap, n_slots, p.k};
         HIP_TRY(launch_reseed(ra, p.B, s));
         ScanArgs sa = make_scan_args(dataset, queries, p, w, plan, r0, 1, nr);
-        HIP_TRY(launch_scan(sa, PSH_MODE_ALL, p.aligned, plan.grid, s));
+        if (rows_path) {
+            int ncu = 0;
+            HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+            int64_t gb = (nr + 127) / 128;
+            if (gb > 8 * (int64_t)ncu) gb = 8 * (int64_t)ncu;
+            HIP_TRY(launch_rows(sa, PSH_MODE_ALL, (int)(gb < 1 ? 1 : gb), s));
+        } else {
+            HIP_TRY(launch_scan(sa, PSH_MODE_ALL, p.aligned, plan.grid, s));
+        }
         SelectArgs se = make_select_args(p, w, out_d, out_idx, nullptr, false, 0, n_slots + p.k);
         HIP_TRY(launch_select(se, p.B, s));
     }
@@ -457,9 +466,23 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     if (const char* e = getenv("PSH_FILTER")) { if (!strcmp(e, "valu")) use_mx = use_mq = false; }
     // (half-segment mode measured for the single-query scan: bootstrap 17.4 -> 12.3 us, but tau admits twice as
     // much and the scan's exact rechecks cost 4.3 us more -- 135.7 vs 134.3 us per step; left off)
-    const BootPlan bp = boot_plan(p.R, p.Tp, k, false);
+    BootPlan bp = boot_plan(p.R, p.Tp, k, false);
+    // one-window rows (T == W + h; PathDistance.forward_topk's N pre-embedded points): rows_kernel, a row per lane.
+    // Its bootstrap takes one exact value per sampled row.
+    const bool rows_path = p.Tp == 1 && !p.ker && getenv("PSH_ROWS") == nullptr;
+    if (rows_path) {
+        int frac = 16;
+        if (const char* e = getenv("PSH_ROWS_FRAC")) { const int v = atoi(e); if (v >= 2) frac = v; }   // tuning aid
+        int64_t ns = p.R / frac > 8 * (int64_t)k ? p.R / frac : 8 * (int64_t)k;
+        if (ns > p.R / 2) ns = p.R / 2;
+        if (ns > w.min_stride) ns = w.min_stride;
+        bp.rows = ns >= 2 * (int64_t)k ? ns : 0;
+        bp.per_wave = 1;
+        bp.entries = bp.rows;
+        use_mx = use_mq = false;
+    }
     const int64_t n_sample = bp.rows;
-    if (p.R * ((p.Tp + PSH_SEG - 1) / PSH_SEG) * PSH_SEG + k <= (int64_t)w.cap || p.Tp == 1 || n_sample == 0)
+    if (p.R * ((p.Tp + PSH_SEG - 1) / PSH_SEG) * PSH_SEG + k <= (int64_t)w.cap || (p.Tp == 1 && !rows_path) || n_sample == 0)
         return run_exhaustive(device, s, dataset, queries, qnorm, p, w, out_d, out_idx, out_status, profile);
     const int64_t stride = p.R / n_sample;
     const int64_t row0 = stride / 2;
@@ -491,6 +514,12 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
         if (gx < 1) gx = 1;
         n_blockmax = (int)gx * chunks;
         HIP_TRY(launch_boot_mq(sa, p.aligned, (int)gx, s));
+    } else if (rows_path) {
+        int ncu = 0;
+        HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+        int64_t gb = (n_sample + 127) / 128;
+        if (gb > 8 * (int64_t)ncu) gb = 8 * (int64_t)ncu;
+        HIP_TRY(launch_rows(sa, PSH_MODE_BOOT, (int)(gb < 1 ? 1 : gb), s));
     } else {
         HIP_TRY(launch_scan(sa, PSH_MODE_BOOT, p.aligned, plan_s.grid, s));
     }
@@ -544,6 +573,15 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
         fa.mq_frag = w.mq_frag;
         fa.slice = w.cap / nblk;
         HIP_TRY(launch_scan_mq(fa, p.aligned, (int)gx, s));
+    } else if (rows_path) {
+        int ncu = 0;
+        HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+        int64_t gb = (p.R + 127) / 128;
+        if (gb > 8 * (int64_t)ncu) gb = 8 * (int64_t)ncu;
+        if (gb > PSH_MAX_BLOCKS) gb = PSH_MAX_BLOCKS;
+        nblk = (int)(gb < 1 ? 1 : gb);
+        fa.slice = w.cap / nblk;
+        HIP_TRY(launch_rows(fa, PSH_MODE_FILTER, nblk, s));
     } else {
         HIP_TRY(launch_scan(fa, PSH_MODE_FILTER, p.aligned, plan_f.grid, s));
     }

@@ -2009,6 +2009,117 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a
 }
 
 // ----------------------------------------------------------------------------------
+// one-window rows (T == W + h): the ensemble is N points of W samples -- what
+// PathDistance.forward_topk scans (a pre-embedded y, reference path_distance.py:10-49), and
+// shadow() on paths exactly one window long.  The reference's numerator is then a
+// CONTIGUOUS reduce (8-lane order: sumsq8), one per row, and a wave takes 64 rows at a time,
+// a row per lane:
+//   FILTER : the 64 rows are 64*T contiguous floats -- coalesced 16-byte loads, scattered into
+//            LDS at an odd row stride (every lane then walks its own row without bank
+//            conflicts); admits acc < tau into the block's slice like the other scans
+//   BOOT   : the sampled rows are `row_stride` apart: every lane reads its own row from
+//            memory; one exact acc per sampled row -> minbuf
+// HBM-bound for a handful of queries (2.3 W VALU operations per row and query against 4 T bytes).
+// ----------------------------------------------------------------------------------
+#define PSH_ROWS_THREADS 128
+
+template <int MODE>
+__global__ __launch_bounds__(PSH_ROWS_THREADS) void rows_kernel(ScanArgs a, int aligned16) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr int NW = PSH_ROWS_THREADS / 64;
+    const int ds = a.tile_floats;                            // LDS floats per row, odd
+    float* tile = smem + (size_t)wave * 64 * ds;
+    int* lcount = reinterpret_cast<int*>(smem + (size_t)NW * 64 * ds);
+    u32x4* pend = reinterpret_cast<u32x4*>(lcount + ((a.B + 3) & ~3)) + (size_t)wave * PSH_PEND;
+    int npend = 0;
+    if (MODE == PSH_MODE_FILTER) {
+        for (int q = (int)threadIdx.x; q < a.B; q += PSH_ROWS_THREADS) lcount[q] = 0;
+        __syncthreads();
+    }
+    const int W = a.W;
+    const int64_t T = a.T;
+    const int n_chunks = (a.n_rows + 63) >> 6;
+    const int c_lo = (int)(((int64_t)n_chunks * blockIdx.x) / gridDim.x);
+    const int c_hi = (int)(((int64_t)n_chunks * (blockIdx.x + 1)) / gridDim.x);
+    const const_f32p qk = (const_f32p)a.queries;
+    typedef const __attribute__((address_space(4))) QueryState* const_qsp;
+    const const_qsp qstate_k = (const_qsp)a.qstate;
+    const bool staged = (MODE != PSH_MODE_BOOT) && a.row_stride == 1;
+
+    for (int c = c_lo + wave; c < c_hi; c += NW) {
+        const int i = 64 * c + lane;                         // this lane's row of the launch
+        const bool valid = i < a.n_rows;
+        const int64_t row = a.row0 + (int64_t)(valid ? i : a.n_rows - 1) * a.row_stride;
+        const float* yrow = a.dataset + row * T;
+        if (MODE == PSH_MODE_FILTER && npend > 0) { pend_flush(pend, npend, lcount, a, lane); npend = 0; }
+        if (staged) {
+            const int nr = (a.n_rows - 64 * c) < 64 ? (a.n_rows - 64 * c) : 64;
+            const int64_t nfl = (int64_t)nr * T;
+            const float* src = a.dataset + (a.row0 + (int64_t)64 * c) * T;
+            const unsigned magic = (unsigned)((1ull << 32) / (unsigned long long)T);
+            for (int64_t e4 = lane; 4 * e4 < nfl; e4 += 64) {
+                float v[4];
+                if (aligned16 && 4 * e4 + 3 < nfl) {
+                    const f32x4 q4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + e4);
+                    v[0] = q4[0]; v[1] = q4[1]; v[2] = q4[2]; v[3] = q4[3];
+                } else {
+#pragma unroll
+                    for (int k2 = 0; k2 < 4; ++k2) v[k2] = (4 * e4 + k2 < nfl) ? src[4 * e4 + k2] : 0.0f;
+                }
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    const unsigned e = (unsigned)(4 * e4 + k2);
+                    const unsigned r = fast_div(e, magic, (unsigned)T);
+                    const unsigned col = e - r * (unsigned)T;
+                    if (col < (unsigned)W && (int64_t)e < nfl) tile[r * ds + col] = v[k2];
+                }
+            }
+            wave_lds_fence();
+        }
+        for (int b = 0; b < a.B; ++b) {
+            const const_f32p x = qk + (int64_t)b * W;
+            float acc;
+            if (staged) acc = sumsq8([&](int j) { return __fsub_rn(x[j], tile[lane * ds + j]); }, W);
+            else        acc = sumsq8([&](int j) { return __fsub_rn(x[j], yrow[j]); }, W);
+            if (MODE == PSH_MODE_BOOT) {
+                if (valid) a.minbuf[(int64_t)b * a.min_stride + i] = acc;
+            } else if (MODE == PSH_MODE_ALL) {               // exhaustive path: one slot per row of the chunk
+                if (valid) {
+                    a.cand_d[(int64_t)b * a.cap + i] = dist_from_acc(acc, qstate_k[b].xn);
+                    a.cand_rt[(int64_t)b * a.cap + i] = make_int2((int)(row + a.r_offset), 0);
+                }
+            } else {
+                const float tau = __uint_as_float(qstate_k[b].tau_bits);
+                const bool hit = valid && (acc < tau);
+                const unsigned long long mask = __ballot(hit);
+                if (!mask) continue;
+                const int nh = __popcll(mask);
+                if (npend + nh > PSH_PEND) {
+                    pend_flush(pend, npend, lcount, a, lane);
+                    npend = 0;
+                    wave_lds_fence();
+                }
+                if (hit) {
+                    const int slot = npend + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                 __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    pend[slot] = u32x4{__float_as_uint(acc), (unsigned)(int)(row + a.r_offset), 0u, (unsigned)b};
+                }
+                npend += nh;
+            }
+        }
+        if (staged) wave_lds_fence();                        // all lanes done with the tile before it is overwritten
+    }
+    if (MODE == PSH_MODE_FILTER) {
+        if (npend > 0) pend_flush(pend, npend, lcount, a, lane);
+        __syncthreads();
+        for (int q = (int)threadIdx.x; q < a.B; q += PSH_ROWS_THREADS)
+            a.bcount[(int64_t)q * PSH_MAX_BLOCKS + blockIdx.x] = lcount[q];
+    }
+}
+
+// ----------------------------------------------------------------------------------
 // one-block selection machinery (threshold of the bootstrap sample, final top-k, merge)
 // ----------------------------------------------------------------------------------
 #define PSH_RB 11                          // radix-select digit width: 2048 counters per pass
@@ -3100,6 +3211,33 @@ hipError_t launch_reseed(const ReseedArgs& a, int B, hipStream_t s) {
     hipLaunchKernelGGL(reseed_kernel, dim3((a.k + 255) / 256, B), dim3(256), 0, s, a);
     return hipGetLastError();
 }
+size_t rows_shmem_bytes(int W, int B) {
+    const int ds = W | 1;
+    return (size_t)(PSH_ROWS_THREADS / 64) * 64 * ds * sizeof(float) + (size_t)((B + 3) & ~3) * sizeof(int)
+           + (size_t)(PSH_ROWS_THREADS / 64) * PSH_PEND * 16;
+}
+
+// one-window rows: a.n_rows rows from a.row0 at a.row_stride, `grid` blocks (<= PSH_MAX_BLOCKS)
+hipError_t launch_rows(ScanArgs a, int mode, int grid, hipStream_t s) {
+    a.tile_floats = a.W | 1;
+    const size_t shmem = rows_shmem_bytes(a.W, a.B);
+    const int aligned16 = (((uintptr_t)a.dataset & 15u) == 0 && ((a.T * a.row0) % 4) == 0 && (a.T % 4 == 0 || a.row_stride == 1)) ? 1 : 0;
+    if (mode == PSH_MODE_BOOT) {
+        hipError_t e = hipFuncSetAttribute((const void*)rows_kernel<PSH_MODE_BOOT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((rows_kernel<PSH_MODE_BOOT>), dim3(grid), dim3(PSH_ROWS_THREADS), shmem, s, a, aligned16);
+    } else if (mode == PSH_MODE_ALL) {
+        hipError_t e = hipFuncSetAttribute((const void*)rows_kernel<PSH_MODE_ALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((rows_kernel<PSH_MODE_ALL>), dim3(grid), dim3(PSH_ROWS_THREADS), shmem, s, a, aligned16);
+    } else {
+        hipError_t e = hipFuncSetAttribute((const void*)rows_kernel<PSH_MODE_FILTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((rows_kernel<PSH_MODE_FILTER>), dim3(grid), dim3(PSH_ROWS_THREADS), shmem, s, a, aligned16);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_gather(const GatherArgs& a, hipStream_t s) {
     const int64_t total = a.n * a.C * a.len;
     if (total <= 0) return hipSuccess;

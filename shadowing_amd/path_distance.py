@@ -63,3 +63,34 @@ class RelativeMSE(PathDistance):
 
     def forward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         return torch.linalg.vector_norm(x - y, dim=-1) / torch.linalg.vector_norm(x, dim=-1)
+
+    def forward_topk(self, x: torch.Tensor, y: torch.Tensor, k: int, n_splits: int = 1
+                     ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """On a HIP device (the reference's forward_topk follows its tensors' device, path_distance.py:27-29)
+        the k smallest are found by the scan kernels: the N = prod(y.shape[:-1]) pre-embedded points are N
+        "paths" of d samples holding ONE window each, and for one-window paths the reference's distance is the
+        contiguous reduce this very function evaluates (8-lane order) -- psh_scan_topk with W = T = d
+        returns the same bits as the reference's CPU forward_topk (tests/golden/forward_topk_*.npz), ties in
+        canonical index order.  Anything the kernels do not take (subclasses, other dtypes, d > 256, k > N)
+        runs the generic formulation above."""
+        if type(self) is RelativeMSE and x.is_cuda and y.is_cuda and x.dim() == 2 and y.dim() >= 2:
+            from . import _native
+            n = 1
+            for s in y.shape[:-1]:
+                n *= s
+            d = y.shape[-1]
+            if (x.dtype == torch.float32 and y.dtype == torch.float32 and x.shape[-1] == d and 1 <= d <= _native.PSH_MAX_W
+                    and 1 <= k <= min(n, _native.PSH_MAX_K) and n < 2 ** 31):
+                rows = y.reshape(n, d)
+                dist, idx, status = _native.scan_topk(rows, x.contiguous(), k, h=0)
+                bad = torch.nonzero(status != _native.PSH_STATUS_OK).flatten()
+                if bad.numel():
+                    d2, i2, _ = _native.scan_topk(rows, x[bad].contiguous(), k, h=0, exhaustive=True)
+                    dist[bad], idx[bad] = d2, i2
+                flat = idx[..., 0].to(torch.int64)                 # the point's flat position; its window index is 0
+                coords = []
+                for s in reversed(y.shape[:-1]):
+                    coords.append(flat % s)
+                    flat = flat // s
+                return dist, torch.stack(coords[::-1], dim=-1)
+        return super().forward_topk(x, y, k, n_splits)

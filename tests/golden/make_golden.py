@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--big", action="store_true", help="also the cfg-2 / cfg-3 sized cases (~2 min)")
     ap.add_argument("--embedded", action="store_true",
                     help="ONLY the linear-embedding cases (Foveal / user kernels); the Identity fixtures are left alone")
+    ap.add_argument("--topk", action="store_true", help="ONLY the PathDistance.forward_topk cases")
     ap.add_argument("--cross", action="store_true",
                     help="ONLY the CrossChannelContext cases (multi-channel ensemble, scan on channel 0)")
     args = ap.parse_args()
@@ -116,6 +117,19 @@ def main():
                    meta=json.dumps(dict(reference_seconds=round(dt, 3), numpy=np.__version__, torch=torch.__version__)))
         np.savez_compressed(HERE / f"{name}.npz", **out)
         print(f"{name}: dataset{ds.shape} d{d.shape} idx{idx.shape} paths{paths.shape} ref {dt:.2f}s")
+
+    if args.topk:
+        # PathDistance.forward_topk (path_distance.py:10-49) on a pre-embedded y (B2, T2, d)
+        g = torch.Generator().manual_seed(70)
+        for name, (B1, B2, T2, d, k, ns) in {"forward_topk_d34": (3, 40, 30, 34, 50, 2), "forward_topk_d5": (2, 100, 7, 5, 20, 4),
+                                             "forward_topk_d126": (2, 30, 20, 126, 10, 1)}.items():
+            x = torch.randn(B1, d, generator=g) * 0.02
+            y = torch.randn(B2, T2, d, generator=g) * 0.02
+            dr, ir = ref.RelativeMSE().forward_topk(x, y, k, n_splits=ns)
+            np.savez_compressed(HERE / f"{name}.npz", x=x.numpy(), y=y.numpy(), d=dr.numpy(), idx=ir.numpy(), k=k, n_splits=ns,
+                                meta=json.dumps(dict(numpy=np.__version__, torch=torch.__version__)))
+            print(f"{name}: x{tuple(x.shape)} y{tuple(y.shape)} d{tuple(dr.shape)} idx{tuple(ir.shape)} {ir.dtype}")
+        return
 
     if args.cross:
         def multi(R, T, C, seed):

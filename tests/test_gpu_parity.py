@@ -419,3 +419,31 @@ def test_merge_of_sorted_gathered_lists(hip_device, oracle_mod, G, k_in, k, B):
     real = gi.cpu().numpy()[..., 0] >= 0
     assert np.array_equal(md.cpu().numpy()[real].view(np.uint32), gd.cpu().numpy()[real].view(np.uint32))
     assert np.array_equal(mi.cpu().numpy()[real], gi.cpu().numpy()[real])
+
+
+@pytest.mark.parametrize("name", ["forward_topk_d34", "forward_topk_d5", "forward_topk_d126"])
+def test_forward_topk_on_the_device_matches_reference_golden(hip_device, name):
+    """RelativeMSE.forward_topk with device tensors runs the scan kernels (N one-window paths): the reference's
+    CPU output bit for bit, int64 indices into y's leading dims."""
+    from pathlib import Path
+    import shadowing_amd as sa
+    z = np.load(Path(__file__).resolve().parent / "golden" / f"{name}.npz")
+    x, y, k = torch.tensor(z["x"]).to(hip_device), torch.tensor(z["y"]).to(hip_device), int(z["k"])
+    d, idx = sa.RelativeMSE().forward_topk(x, y, k, n_splits=int(z["n_splits"]))
+    assert d.is_cuda and idx.dtype == torch.int64 and tuple(idx.shape) == z["idx"].shape
+    assert np.array_equal(d.cpu().numpy().view(np.uint32), np.sort(z["d"], 1).view(np.uint32))
+    for b in range(x.shape[0]):
+        assert {tuple(v) for v in idx[b].cpu().numpy()} == {tuple(v) for v in z["idx"][b]}
+
+
+def test_forward_topk_on_the_device_large(hip_device, oracle_mod):
+    """A pre-embedded ensemble of 2^18 points (4-D y): sampled path sizes, against the oracle."""
+    g = np.random.default_rng(8)
+    y = (g.standard_normal((64, 128, 32, 34)) * 0.02).astype(np.float32)
+    x = (g.standard_normal((3, 34)) * 0.02).astype(np.float32)
+    import shadowing_amd as sa
+    d, idx = sa.RelativeMSE().forward_topk(torch.tensor(x).to(hip_device), torch.tensor(y).to(hip_device), 200)
+    od, oi = oracle_mod.scan_topk(y.reshape(-1, 1, 34), x, 200, h=0)
+    assert np.array_equal(d.cpu().numpy().view(np.uint32), od.view(np.uint32))
+    flat = (idx[..., 0] * 128 + idx[..., 1]) * 32 + idx[..., 2]
+    assert np.array_equal(flat.cpu().numpy(), oi[..., 0])

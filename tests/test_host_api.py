@@ -1,6 +1,8 @@
 """Host-side mirror of the reference's plugin surface: names,
 signatures, return types, error behaviour -- and the reference's own three test cells
 (testing.ipynb: forward_topk prefix consistency, shadow() self-consistency)."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 import torch
@@ -225,3 +227,22 @@ def test_realized_variance_takes_torch_tensors():
         b = sa.realized_variance(torch.tensor(x), [2, 7, 30], vol=vol)
         assert isinstance(b, torch.Tensor) and b.shape == (3, 4, 3)
         np.testing.assert_allclose(b.numpy(), a, rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["forward_topk_d34", "forward_topk_d5", "forward_topk_d126"])
+def test_forward_topk_matches_reference_golden(name, oracle_mod):
+    """The generic forward_topk (flat top-k + decoded indices instead of the reference's host-side
+    itertools.product table) against the reference's own output; and the observation the HIP path rests on: the
+    same numbers come out of the scan over N one-window paths (oracle, T' = 1: contiguous 8-lane reduce)."""
+    z = np.load(Path(__file__).resolve().parent / "golden" / f"{name}.npz")
+    x, y, k = torch.tensor(z["x"]), torch.tensor(z["y"]), int(z["k"])
+    d, idx = sa.RelativeMSE().forward_topk(x, y, k, n_splits=int(z["n_splits"]))
+    assert idx.dtype == torch.int64 and idx.shape == z["idx"].shape
+    assert np.array_equal(d.numpy().view(np.uint32), z["d"].view(np.uint32))
+    for b in range(x.shape[0]):
+        assert {tuple(v) for v in idx[b].numpy()} == {tuple(v) for v in z["idx"][b]}
+    od, oi = oracle_mod.scan_topk(z["y"].reshape(-1, 1, y.shape[-1]).copy(), z["x"], k, h=0)
+    assert np.array_equal(od.view(np.uint32), np.sort(z["d"], 1).view(np.uint32)) and oi[..., 1].max() == 0
+    T2 = y.shape[1]
+    for b in range(x.shape[0]):
+        assert {(int(f) // T2, int(f) % T2) for f in oi[b, :, 0]} == {tuple(v) for v in z["idx"][b]}
