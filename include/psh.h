@@ -117,7 +117,7 @@ int psh_query_norm(int device, void* stream, const float* queries, int B, int W,
  *
  * Requires R*(T-W-h+1) >= k (the reference raises for k larger than a split,
  * path_shadowing.py:165) and r_offset + R, T < 2^31.
-  * One-window rows (T == W + h, e.g. N pre-embedded points of PathDistance.forward_topk with
+ * One-window rows (T == W + h, e.g. N pre-embedded points of PathDistance.forward_topk with
  * W = T = d): the reference's numerator is then the contiguous 8-lane reduce, and the scan
  * runs a row per lane (rows_kernel) instead of a segment per wave.
  */
