@@ -175,21 +175,25 @@ int check_problem(const float* dataset, int64_t R, int64_t T, int64_t r_offset, 
     return PSH_OK;
 }
 
-struct Plan { int grid; int n_qgroups; int q_per_group; int tile_floats; };
+struct Plan { int grid; int n_qgroups; int q_per_group; int tile_floats; int wide; };
 
 int plan_scan(int device, const Problem& p, int64_t n_rows, Plan* plan) {
     const int tile_floats = tile_floats_for(p.W);
-    const size_t shmem = scan_shmem_bytes(tile_floats, p.B, p.emb_d, p.W);
+    // embedded scan of a batch: 512-thread blocks whose waves carry 12 (suffix rows: 6) queries per evaluation of the
+    // embedding (256 VGPRs, one block per CU)
+    const bool wide = p.ker && p.B >= PSH_EMB_WIDE_MIN_B && getenv("PSH_EMBED_NARROW") == nullptr;
+    const int threads = wide ? 512 : PSH_SCAN_THREADS;
+    const size_t shmem = scan_shmem_bytes(tile_floats, p.B, p.emb_d, p.W, threads);
     if (shmem > 160 * 1024) return PSH_ERR_UNSUPPORTED;
-    int bpc = 0, ncu = 0;
-    HIP_TRY(scan_blocks_per_cu(p.W, p.aligned, p.ker != nullptr, shmem, &bpc));
+    int bpc = 1, ncu = 0;
+    if (!wide) HIP_TRY(scan_blocks_per_cu(p.W, p.aligned, p.ker != nullptr, shmem, &bpc));
     HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
     if (const char* e = getenv("PSH_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) bpc = v; }   // tuning aid
     if (bpc < 1) bpc = 1;
     if (bpc > 8) bpc = 8;
     const int nseg = (int)((p.Tp + PSH_SEG - 1) / PSH_SEG);
     const int64_t n_rs = n_rows * nseg;
-    const int64_t waves = (int64_t)bpc * ncu * (PSH_SCAN_THREADS / 64);
+    const int64_t waves = (int64_t)bpc * ncu * (threads / 64);
     // not enough (row, segment) units to fill the chip: also split the queries
     int n_qgroups = 1;
     if (n_rs < waves && p.B > 1) {
@@ -200,7 +204,7 @@ int plan_scan(int device, const Problem& p, int64_t n_rows, Plan* plan) {
     n_qgroups = (p.B + q_per_group - 1) / q_per_group;
     const int64_t units = n_rs * n_qgroups;
     if (units >= (1ll << 31)) return PSH_ERR_UNSUPPORTED;
-    int64_t grid = (units + (PSH_SCAN_THREADS / 64) - 1) / (PSH_SCAN_THREADS / 64);
+    int64_t grid = (units + (threads / 64) - 1) / (threads / 64);
     if (grid > (int64_t)bpc * ncu) grid = (int64_t)bpc * ncu;
     if (grid > PSH_MAX_BLOCKS) grid = PSH_MAX_BLOCKS;
     if (grid < 1) grid = 1;
@@ -208,6 +212,7 @@ int plan_scan(int device, const Problem& p, int64_t n_rows, Plan* plan) {
     plan->n_qgroups = n_qgroups;
     plan->q_per_group = q_per_group;
     plan->tile_floats = tile_floats;
+    plan->wide = wide ? 1 : 0;
     return PSH_OK;
 }
 
@@ -233,6 +238,7 @@ ScanArgs make_scan_args(const float* dataset, const float* queries, const Proble
     a.ker = p.ker;
     a.hx = p.ker ? queries : nullptr;
     a.emb_d = p.emb_d;
+    a.emb_wide = plan.wide;
     if (const char* e = getenv("PSH_EMBED")) a.emb_dense = !strcmp(e, "dense") ? 1 : 0;   // A/B aid: skip the suffix-rows fast path
     a.B = p.B;
     a.n_qgroups = plan.n_qgroups;

@@ -81,6 +81,7 @@ struct ScanArgs {
     const float* ker;        // emb_d x W row-major
     const float* hx;         // B x emb_d
     int emb_d;
+    int emb_wide;            // embedded scan: the 512-thread instantiation (launchers, plan)
     int emb_dense;           // embedded scan: always the dense chains, even when the kernel has suffix rows (tests, PSH_EMBED=dense)
 };
 
@@ -164,7 +165,8 @@ struct GatherArgs {
 hipError_t launch_prep(const PrepArgs& a, hipStream_t s);
 hipError_t launch_qnorm(const float* q, int B, int W, float* out, hipStream_t s);
 hipError_t launch_scan(const ScanArgs& a, int mode, bool aligned, int grid, hipStream_t s);
-size_t scan_shmem_bytes(int tile_floats, int B, int emb_d, int W);
+size_t scan_shmem_bytes(int tile_floats, int B, int emb_d, int W, int threads = PSH_SCAN_THREADS);
+#define PSH_EMB_WIDE_MIN_B 7          // embedded scan, this many queries and more: 512-thread blocks carrying 10 (6) queries per pass
 size_t scan_mx_shmem_bytes(int tile_floats, int B);
 bool scan_mx_supported(int W, int B);
 bool scan_mq_supported(int W, int B);          // batched queries on the matrix cores

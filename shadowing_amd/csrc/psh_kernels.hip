@@ -1583,12 +1583,15 @@ __device__ __forceinline__ void nest_shift(f32x2 (&W2)[8], f32x4 (&Q)[2], const 
     }
 }
 
-template <bool ALIGNED, int MODE>
-__global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a) {
+// THREADS / BG / NBG: 1024 threads (4 waves per SIMD, 128 VGPRs) with 3 (dense) or 2 (suffix rows) queries per evaluation of
+// the embedding, or -- batches of 7 and more -- 512 threads (2 waves per SIMD, 256 VGPRs) with 10 or 6: the embedding is the
+// cost, and a wave that carries 4x the accumulators evaluates it 4x less often.
+template <bool ALIGNED, int MODE, int THREADS, int BG, int NBG>
+__global__ __launch_bounds__(THREADS) void embed_scan_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = lane_id();
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    constexpr int NW = PSH_SCAN_THREADS / 64;
+    constexpr int NW = THREADS / 64;
     float* tile = smem + (size_t)wave_in_block * a.tile_floats;
     int* lcount = reinterpret_cast<int*>(smem + (size_t)NW * a.tile_floats);
     int* next_unit = lcount + ((a.B + 3) & ~3);
@@ -1607,8 +1610,8 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a
 
     if (threadIdx.x == 0) *next_unit = 0;
     if (MODE == PSH_MODE_FILTER)
-        for (int q = (int)threadIdx.x; q < a.B; q += PSH_SCAN_THREADS) lcount[q] = 0;
-    for (int e = (int)threadIdx.x; e < d * Kp; e += PSH_SCAN_THREADS) {
+        for (int q = (int)threadIdx.x; q < a.B; q += THREADS) lcount[q] = 0;
+    for (int e = (int)threadIdx.x; e < d * Kp; e += THREADS) {
         const int i = e / Kp, j = e - i * Kp;
         kerL[e] = j < K ? a.ker[(int64_t)i * K + j] : 0.0f;
     }
@@ -1847,23 +1850,23 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a
                 }
                 wave_lds_fence();                            // sl is refilled afterwards
             };
-            for (int b0 = q_begin; b0 < q_end; b0 += PSH_NEST_BG) {
-                const int nq = (q_end - b0) < PSH_NEST_BG ? (q_end - b0) : PSH_NEST_BG;
-                f32x2 acc[PSH_NEST_BG][8], S[8], win[8];          // element x: window w / slot s, element y: w + 8 / s + 8
+            for (int b0 = q_begin; b0 < q_end; b0 += NBG) {
+                const int nq = (q_end - b0) < NBG ? (q_end - b0) : NBG;
+                f32x2 acc[NBG][8], S[8], win[8];          // element x: window w / slot s, element y: w + 8 / s + 8
                 f32x4 Q[2];
 #pragma unroll
                 for (int w = 0; w < 8; ++w) { S[w] = f32x2{0.f, 0.f}; win[w] = f32x2{0.f, 0.f}; }
 #pragma unroll
-                for (int g = 0; g < PSH_NEST_BG; ++g)
+                for (int g = 0; g < NBG; ++g)
 #pragma unroll
                     for (int w = 0; w < 8; ++w) acc[g][w] = f32x2{0.f, 0.f};
                 Q[0] = f32x4{0.f, 0.f, 0.f, 0.f};
                 Q[1] = Q[0];
                 // the group's embedded queries, permuted into closing order across the lanes
                 int pc = 0;
-                int hxt[PSH_NEST_BG][2];
+                int hxt[NBG][2];
 #pragma unroll
-                for (int g = 0; g < PSH_NEST_BG; ++g)
+                for (int g = 0; g < NBG; ++g)
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
                         hxt[g][q] = (g < nq && lane + 64 * q < d) ? (int)__float_as_uint(a.hx[(int64_t)(b0 + g) * d + rtab[q]]) : 0;
@@ -1874,7 +1877,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a
                     const float nc = __uint_as_float((unsigned)(lo64 ? c0 : c1));
                     const f32x2 nc2 = f32x2{nc, nc};
 #pragma unroll
-                    for (int g = 0; g < PSH_NEST_BG; ++g) {
+                    for (int g = 0; g < NBG; ++g) {
                         if (g < nq) {                        // wave-uniform
                             const int h0 = __builtin_amdgcn_readlane(hxt[g][0], sl2), h1 = __builtin_amdgcn_readlane(hxt[g][1], sl2);
                             const float hv = __uint_as_float((unsigned)(lo64 ? h0 : h1));
@@ -1920,7 +1923,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a
                     }
                 }
 #pragma unroll
-                for (int g = 0; g < PSH_NEST_BG; ++g) {
+                for (int g = 0; g < NBG; ++g) {
                     const int b = b0 + g;
                     if (g >= nq) continue;
                     if (MODE == PSH_MODE_BOOT) {
@@ -1963,10 +1966,10 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a
             }
             if (MODE == PSH_MODE_FILTER && ns > 0) { verify_list(); ns = 0; }   // before the tile is overwritten
         } else
-        for (int b0 = q_begin; b0 < q_end; b0 += PSH_EMB_BG) {
-            float acc[PSH_EMB_BG][PSH_L];
+        for (int b0 = q_begin; b0 < q_end; b0 += BG) {
+            float acc[BG][PSH_L];
 #pragma unroll
-            for (int g = 0; g < PSH_EMB_BG; ++g)
+            for (int g = 0; g < BG; ++g)
 #pragma unroll
                 for (int w = 0; w < PSH_L; ++w) acc[g][w] = 0.0f;
 #pragma unroll 1
@@ -1977,7 +1980,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a
                 float c[PSH_L];
                 correlate16(tile, PSH_L * lane + jlo, kerL + (size_t)i * Kp + jlo, n, c);
 #pragma unroll
-                for (int g = 0; g < PSH_EMB_BG; ++g) {
+                for (int g = 0; g < BG; ++g) {
                     if (b0 + g < q_end) {                    // wave-uniform
                         const float hxv = hxk[(int64_t)(b0 + g) * d + i];
 #pragma unroll
@@ -1989,7 +1992,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a
                 }
             }
 #pragma unroll
-            for (int g = 0; g < PSH_EMB_BG; ++g) {
+            for (int g = 0; g < BG; ++g) {
                 const int b = b0 + g;
                 if (b < q_end) {
                     const float tau = (MODE == PSH_MODE_FILTER) ? __uint_as_float(qstate_k[b].tau2_bits) : 0.0f;   // see below: the estimate, when there is one
@@ -2003,7 +2006,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void embed_scan_kernel(ScanArgs a
     if (MODE == PSH_MODE_FILTER) {
         if (npend > 0) pend_flush(pend, npend, lcount, a, lane);
         __syncthreads();
-        for (int q = (int)threadIdx.x; q < a.B; q += PSH_SCAN_THREADS)
+        for (int q = (int)threadIdx.x; q < a.B; q += THREADS)
             a.bcount[(int64_t)q * PSH_MAX_BLOCKS + blockIdx.x] = lcount[q];
     }
 }
@@ -3032,14 +3035,15 @@ static hipError_t launch_scan_mode(const ScanArgs& a, int mode, int grid, size_t
     return hipGetLastError();
 }
 
-size_t scan_shmem_bytes(int tile_floats, int B, int emb_d, int W) {
-    size_t n = (size_t)tile_floats * (PSH_SCAN_THREADS / 64) * sizeof(float)      // wave-private tiles
+size_t scan_shmem_bytes(int tile_floats, int B, int emb_d, int W, int threads) {
+    const int nw = threads / 64;
+    size_t n = (size_t)tile_floats * nw * sizeof(float)                              // wave-private tiles
                + (size_t)(((B + 3) & ~3) + 4) * sizeof(int)                         // per-query append cursors + work cursor
-               + (size_t)(PSH_SCAN_THREADS / 64) * PSH_PEND * 16;                   // wave-private pending admissions
+               + (size_t)nw * PSH_PEND * 16;                                        // wave-private pending admissions
     if (emb_d > 0) n += (size_t)emb_d * ((W + 3) & ~3) * sizeof(float) + (size_t)emb_d * sizeof(int2)    // kernel matrix, tap spans
                       + sizeof(NestHdr) + (size_t)emb_d * 16                                             // suffix-rows fast path: closing order
                       + (size_t)(emb_d + 1) * 32 + 8                                                      //   and support masks
-                      + (size_t)(PSH_SCAN_THREADS / 64) * 192 * 4;                                        //   verification scratch
+                      + (size_t)nw * 192 * 4;                                                             //   verification scratch
     return n;
 }
 
@@ -3107,14 +3111,26 @@ hipError_t launch_scan_mq(const ScanArgs& a, bool aligned, int grid_x, hipStream
                    : launch_big_lds(scan_mq_kernel<0, false>, grid, PSH_MQ_THREADS, shmem, s, a);
 }
 
+#define PSH_EMB_WIDE_THREADS 512
+#define PSH_EMB_WIDE_BG 10
+#define PSH_EMB_WIDE_NBG 6
+
 template <bool ALIGNED, int MODE>
 static hipError_t launch_embed_mode(const ScanArgs& a, int grid, size_t shmem, hipStream_t s) {
+    if (a.emb_wide) {
+        hipError_t e = hipFuncSetAttribute((const void*)embed_scan_kernel<ALIGNED, MODE, PSH_EMB_WIDE_THREADS, PSH_EMB_WIDE_BG, PSH_EMB_WIDE_NBG>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((embed_scan_kernel<ALIGNED, MODE, PSH_EMB_WIDE_THREADS, PSH_EMB_WIDE_BG, PSH_EMB_WIDE_NBG>), dim3(grid),
+                           dim3(PSH_EMB_WIDE_THREADS), shmem, s, a);
+        return hipGetLastError();
+    }
     if (shmem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)embed_scan_kernel<ALIGNED, MODE>,
+        hipError_t e = hipFuncSetAttribute((const void*)embed_scan_kernel<ALIGNED, MODE, PSH_SCAN_THREADS, PSH_EMB_BG, PSH_NEST_BG>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((embed_scan_kernel<ALIGNED, MODE>), dim3(grid), dim3(PSH_SCAN_THREADS), shmem, s, a);
+    hipLaunchKernelGGL((embed_scan_kernel<ALIGNED, MODE, PSH_SCAN_THREADS, PSH_EMB_BG, PSH_NEST_BG>), dim3(grid), dim3(PSH_SCAN_THREADS), shmem, s, a);
     return hipGetLastError();
 }
 
@@ -3128,7 +3144,7 @@ static hipError_t launch_embed(const ScanArgs& a, int mode, int grid, size_t shm
 }
 
 hipError_t launch_scan(const ScanArgs& a, int mode, bool aligned, int grid, hipStream_t s) {
-    const size_t shmem = scan_shmem_bytes(a.tile_floats, a.B, a.ker ? a.emb_d : 0, a.W);
+    const size_t shmem = scan_shmem_bytes(a.tile_floats, a.B, a.ker ? a.emb_d : 0, a.W, (a.ker && a.emb_wide) ? PSH_EMB_WIDE_THREADS : PSH_SCAN_THREADS);
     if (a.ker) return aligned ? launch_embed<true>(a, mode, grid, shmem, s) : launch_embed<false>(a, mode, grid, shmem, s);
     if (a.use_mx && mode == PSH_MODE_FILTER && scan_mx_supported(a.W, a.B))
         return aligned ? launch_scan_mx<true>(a, grid, s) : launch_scan_mx<false>(a, grid, s);
@@ -3144,8 +3160,8 @@ hipError_t scan_blocks_per_cu(int W, bool aligned, bool embedded, size_t shmem, 
     int n = 0;
     hipError_t e;
     if (embedded) {
-        e = aligned ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, embed_scan_kernel<true, PSH_MODE_FILTER>, PSH_SCAN_THREADS, shmem)
-                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, embed_scan_kernel<false, PSH_MODE_FILTER>, PSH_SCAN_THREADS, shmem);
+        e = aligned ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, embed_scan_kernel<true, PSH_MODE_FILTER, PSH_SCAN_THREADS, PSH_EMB_BG, PSH_NEST_BG>, PSH_SCAN_THREADS, shmem)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, embed_scan_kernel<false, PSH_MODE_FILTER, PSH_SCAN_THREADS, PSH_EMB_BG, PSH_NEST_BG>, PSH_SCAN_THREADS, shmem);
     } else if (W == 20) {
         e = aligned ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, scan_kernel<20, true, PSH_MODE_FILTER>, PSH_SCAN_THREADS, shmem)
                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, scan_kernel<20, false, PSH_MODE_FILTER>, PSH_SCAN_THREADS, shmem);

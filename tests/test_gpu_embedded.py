@@ -58,6 +58,9 @@ EMB_CASES = [  # R, T, d, K, h, k, B, kind
     (2048, 700, 100, 80, 5, 300, 3, "suffix"),     # suffix rows, d > 64 (one survivor per verification pass)
     (1024, 1500, 20, 250, 9, 500, 5, "suffix"),    # 16 tap blocks, three accumulator groups
     (4096, 600, 9, 33, 0, 2000, 2, "suffix"),      # many survivors per segment
+    (1500, 1100, 6, 23, 20, 128, 9, "dense"),      # 7+ queries: the 512-thread instantiation, 10 queries per pass
+    (700, 2100, 11, 60, 5, 300, 23, "dense"),      #   three passes (10 + 10 + 3)
+    (2048, 700, 30, 80, 5, 300, 13, "suffix"),     #   suffix rows, 6 queries per pass
 ]
 
 

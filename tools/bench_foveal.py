@@ -39,10 +39,39 @@ def main():
     ker = emb.kernel[:, 0, :].contiguous().to(dev)
     cfgs = {"tutorial": dict(R=2048, T=4096, B=6, k=8192, h=252),
             "testing": dict(R=args.rows or 131072, T=4096, B=1, k=10000, h=252)}
+    cfgs["wavelet"] = dict(R=args.rows or 32768, T=4096, B=16, k=1024, h=20)     # BASELINE.json configs[4], one GPU's shard
     for name in args.which:
         c = cfgs[name]
         if args.k:
             c["k"] = args.k
+        if name == "wavelet":
+            # "wavelet conv, W=252 replacing Identity, batched queries": the linear stage of a scattering embedding
+            # (synthetic.wavelet_bank), 16 rolling query dates; no suffix structure, so the dense chains
+            wk = torch.tensor(syn.wavelet_bank(5, 252))
+            g = torch.Generator(device=dev).manual_seed(1)
+            ds = torch.randn((c["R"], 1, c["T"]), generator=g, device=dev) * 0.0126
+            xq = torch.tensor(syn.rolling_queries(c["B"], 252, 2))
+            hxw = torch.nn.functional.conv1d(xq[:, None, :], wk[:, None, :])[:, :, 0].contiguous().to(dev)
+            kw = wk.contiguous().to(dev)
+            ws = _native.Workspace(dev)
+            out = _native.scan_topk_embedded(ds[:, 0, :], kw, hxw, c["k"], h=c["h"], workspace=ws, profile=True)
+            assert int(out[2].max()) == 0, "overflow"
+            for _ in range(2):
+                _native.scan_topk_embedded(ds[:, 0, :], kw, hxw, c["k"], h=c["h"], workspace=ws)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nst = max(2, args.steps // 4)
+            for _ in range(nst):
+                _native.scan_topk_embedded(ds[:, 0, :], kw, hxw, c["k"], h=c["h"], workspace=ws)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / nst * 1e3
+            windows = c["R"] * (c["T"] - 252 - c["h"] + 1)
+            print(json.dumps(dict(workload="wavelet (BASELINE.json configs[4], per GPU)", config=c,
+                                  embedding=f"wavelet_bank(5, 252): d={wk.shape[0]}, {int((wk != 0).sum())} non-zero taps",
+                                  ms_per_call=round(ms, 3), windows=windows, query_windows_per_s=windows * c["B"] / (ms * 1e-3),
+                                  stages_ms={k2: round(v, 4) for k2, v in out[3].items() if k2.endswith("_ms")},
+                                  n_candidates=out[3]["n_candidates"])))
+            continue
         g = torch.Generator(device=dev).manual_seed(1)
         ds = torch.randn((c["R"], 1, c["T"]), generator=g, device=dev) * 0.0126      # testing.ipynb uses torch.randn
         x = torch.tensor(syn.gbm_log_returns((c["B"], 126), 2))
