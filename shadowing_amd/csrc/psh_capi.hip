@@ -477,9 +477,9 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     // Its bootstrap takes one exact value per sampled row.
     const bool rows_path = p.Tp == 1 && !p.ker && getenv("PSH_ROWS") == nullptr;
     if (rows_path) {
-        int frac = 16;
+        int frac = 64;
         if (const char* e = getenv("PSH_ROWS_FRAC")) { const int v = atoi(e); if (v >= 2) frac = v; }   // tuning aid
-        int64_t ns = p.R / frac > 8 * (int64_t)k ? p.R / frac : 8 * (int64_t)k;
+        int64_t ns = p.R / frac > 16 * (int64_t)k ? p.R / frac : 16 * (int64_t)k;
         if (ns > p.R / 2) ns = p.R / 2;
         if (ns > w.min_stride) ns = w.min_stride;
         bp.rows = ns >= 2 * (int64_t)k ? ns : 0;
@@ -540,6 +540,11 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
         // at least k windows are, the result is the exact top-k; when fewer are (the sample was not representative)
         // the selection raises the query's status and the caller takes the exhaustive path, as for an overflow.
         const int64_t r2 = (2 * (int64_t)k * n_sample + p.R - 1) / p.R + 8;
+        rank2 = (r2 < k && r2 <= bp.entries) ? (int)r2 : 0;
+    } else if (rows_path) {
+        // one-window rows: a 1/64 sample (the threshold kernel is otherwise the longest stage), so a wider margin: the
+        // estimate sits where ~3k points are expected (a 6-sigma shortfall before fewer than k are below it)
+        const int64_t r2 = (3 * (int64_t)k * n_sample + p.R - 1) / p.R + 16;
         rank2 = (r2 < k && r2 <= bp.entries) ? (int)r2 : 0;
     }
     ThresholdArgs ta{w.minbuf, w.min_stride, (int)bp.entries, w.qstate, k, 0,

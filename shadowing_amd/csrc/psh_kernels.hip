@@ -2094,7 +2094,7 @@ __global__ __launch_bounds__(PSH_ROWS_THREADS) void rows_kernel(ScanArgs a, int 
                     a.cand_rt[(int64_t)b * a.cap + i] = make_int2((int)(row + a.r_offset), 0);
                 }
             } else {
-                const float tau = __uint_as_float(qstate_k[b].tau_bits);
+                const float tau = __uint_as_float(qstate_k[b].tau2_bits);   // the estimate when there is one (psh_capi.hip), else tau
                 const bool hit = valid && (acc < tau);
                 const unsigned long long mask = __ballot(hit);
                 if (!mask) continue;

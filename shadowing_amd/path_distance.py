@@ -82,10 +82,13 @@ class RelativeMSE(PathDistance):
             if (x.dtype == torch.float32 and y.dtype == torch.float32 and x.shape[-1] == d and 1 <= d <= _native.PSH_MAX_W
                     and 1 <= k <= min(n, _native.PSH_MAX_K) and n < 2 ** 31):
                 rows = y.reshape(n, d)
-                dist, idx, status = _native.scan_topk(rows, x.contiguous(), k, h=0)
-                bad = torch.nonzero(status != _native.PSH_STATUS_OK).flatten()
-                if bad.numel():
-                    d2, i2, _ = _native.scan_topk(rows, x[bad].contiguous(), k, h=0, exhaustive=True)
+                ws = getattr(self, "_workspace", None)             # scratch kept between calls
+                if ws is None or ws.device != y.device:
+                    ws = self._workspace = _native.Workspace(y.device)
+                dist, idx, status = _native.scan_topk(rows, x.contiguous(), k, h=0, workspace=ws)
+                if bool(status.any()):                             # one host sync; rare: ties en masse / a short estimate
+                    bad = torch.nonzero(status != _native.PSH_STATUS_OK).flatten()
+                    d2, i2, _ = _native.scan_topk(rows, x[bad].contiguous(), k, h=0, workspace=ws, exhaustive=True)
                     dist[bad], idx[bad] = d2, i2
                 flat = idx[..., 0].to(torch.int64)                 # the point's flat position; its window index is 0
                 coords = []
