@@ -2,7 +2,7 @@
 stage timings.  (Not part of the product or the test suite.)"""
 import sys, time
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np, torch
 import oracle
 from shadowing_amd import _native, synthetic as syn

@@ -1,7 +1,7 @@
 """Randomised parity stress: HIP scan vs the CPU oracle over odd shapes (development aid)."""
 import sys, time
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np, torch
 import oracle
 from shadowing_amd import _native, synthetic as syn

@@ -3,7 +3,7 @@ outliers the bootstrap sample never saw, queries far smaller / larger than the d
 fp32 scales, planted near-matches, heavy tails.  HIP scan vs the CPU oracle, bit for bit."""
 import sys, time
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np, torch
 import oracle
 from shadowing_amd import _native, synthetic as syn
