@@ -70,19 +70,22 @@ struct Workspace {
 //   per-lane mode: one minimum per 16 windows, for ensembles too small for the above;
 //   rows == 0    : sample too thin to be useful -> exhaustive path.
 struct BootPlan { int64_t rows; int per_wave; int64_t entries; };
-BootPlan boot_plan(int64_t R, int64_t Tp, int k, bool halves = false) {
+// `estimate`: the scan admits below the sampled ESTIMATE of the k-th distance (embedded scan), so the sample only has
+// to carry that estimate's rank (~2k * sampled fraction) comfortably -- 2k minima instead of the 8k that keep the
+// provable k-th smallest tight.  (Never more entries than the plain plan: the workspace is sized for that one.)
+BootPlan boot_plan(int64_t R, int64_t Tp, int k, bool halves = false, bool estimate = false) {
     BootPlan bp{0, 0, 0};
     const int64_t nseg = (Tp + PSH_SEG - 1) / PSH_SEG;
     const int64_t quarter = R / 4;
     int64_t rows = R / 16;
-    const int64_t need_rows = (8 * (int64_t)k + nseg - 1) / nseg;      // >= 8k segment minima
+    const int64_t need_rows = ((estimate ? 2 : 8) * (int64_t)k + nseg - 1) / nseg;      // >= 8k (2k) segment minima
     if (rows < need_rows) rows = need_rows;
     if (rows >= 1 && rows <= quarter) {
         if (halves && rows >= 2) { bp.rows = (rows + 1) / 2; bp.per_wave = 2; bp.entries = bp.rows * nseg * 2; return bp; }
         bp.rows = rows; bp.per_wave = 1; bp.entries = rows * nseg; return bp;
     }
     const int64_t lanes_per_row = (Tp + PSH_L - 1) / PSH_L;             // real minima per row
-    rows = (32 * (int64_t)k + lanes_per_row - 1) / lanes_per_row;
+    rows = ((estimate ? 8 : 32) * (int64_t)k + lanes_per_row - 1) / lanes_per_row;
     if (rows > quarter) rows = quarter;
     if (rows < 1 || rows * lanes_per_row < 4 * (int64_t)k) return bp;
     bp.rows = rows; bp.per_wave = 0; bp.entries = rows * nseg * 64;
@@ -472,7 +475,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     if (const char* e = getenv("PSH_FILTER")) { if (!strcmp(e, "valu")) use_mx = use_mq = false; }
     // (half-segment mode measured for the single-query scan: bootstrap 17.4 -> 12.3 us, but tau admits twice as
     // much and the scan's exact rechecks cost 4.3 us more -- 135.7 vs 134.3 us per step; left off)
-    BootPlan bp = boot_plan(p.R, p.Tp, k, false);
+    BootPlan bp = boot_plan(p.R, p.Tp, k, false, p.ker != nullptr);
     // one-window rows (T == W + h; PathDistance.forward_topk's N pre-embedded points): rows_kernel, a row per lane.
     // Its bootstrap takes one exact value per sampled row.
     const bool rows_path = p.Tp == 1 && !p.ker && getenv("PSH_ROWS") == nullptr;
