@@ -280,6 +280,7 @@ SelectArgs make_select_args(const Problem& p, const Workspace& w, float* out_d, 
     s.out_d = out_d;
     s.out_idx = out_idx;
     s.sel_rt = w.sel_rt;
+    s.sort_scratch = reinterpret_cast<uint64_t*>(w.cand_rt);   // (r, t) of the selected are in sel_rt by the time the ordering runs
     s.status = status;
     s.qstate = w.qstate;
     return s;

@@ -2441,6 +2441,14 @@ __device__ __forceinline__ bool item_less(uint64_t x, uint64_t y, const int2* rt
     return (unsigned)a.y < (unsigned)b.y;
 }
 
+// the lower-bound comparison of the merge sort by ranking: distance bits alone -- the (almost always empty) range of
+// equal distances is then stepped over with item_less -- except for PADDING items (d = 0xffffffff, kpad - k of them,
+// made distinct by their low word, ordered by it): there the whole 64-bit key is the order, and stepping over
+// thousands of "equal" padding entries one by one was 1 ms per level at k = 10000
+__device__ __forceinline__ bool sort_key_less(uint64_t sib, uint64_t mine) {
+    return ((unsigned)(mine >> 32) == 0xffffffffu) ? (sib < mine) : ((unsigned)(sib >> 32) < (unsigned)(mine >> 32));
+}
+
 __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t items[];   // kpad entries, then key_cap u32 keys
     __shared__ SelectShared sm;
@@ -2858,12 +2866,12 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
                 for (int step = len >> 1; step > 0; step >>= 1)
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        if (i < per && (unsigned)(sib[i][lo[i] + step - 1] >> 32) < (unsigned)(mine[i] >> 32)) lo[i] += step;
+                        if (i < per && sort_key_less(sib[i][lo[i] + step - 1], mine[i])) lo[i] += step;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     if (i < per) {
                         const int e = tid + i * PSH_SELECT_THREADS;
-                        if ((unsigned)(sib[i][lo[i]] >> 32) < (unsigned)(mine[i] >> 32)) lo[i] += 1;
+                        if (sort_key_less(sib[i][lo[i]], mine[i])) lo[i] += 1;
                         while (lo[i] < len && (unsigned)(sib[i][lo[i]] >> 32) == (unsigned)(mine[i] >> 32)
                                && item_less(sib[i][lo[i]], mine[i], sel_rt)) lo[i] += 1;
                         dst[(size_t)((e >> sh) >> 1) * 2 * len + (e & (len - 1)) + lo[i]] = mine[i];
@@ -2874,6 +2882,65 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
             }
             if (src != items) {
                 for (int e = tid; e < a.kpad; e += PSH_SELECT_THREADS) items[e] = src[e];
+            }
+            need_network = false;
+        } else if (a.sort_scratch) {
+            // kpad = 16384 (the reference test's k = 10000): the items fill the LDS, so the second buffer of the same
+            // merge sort by ranking is GLOBAL scratch (this query's candidate slots, consumed by now): every level
+            // searches in LDS, writes the merged order to the scratch and copies it back (128 KB, coalesced, L2) --
+            // ~9 us per level against the bitonic network's 105 barrier-separated sweeps.
+            uint64_t* G = a.sort_scratch + (int64_t)b * a.cand_stride;
+            const int per = a.kpad / PSH_SELECT_THREADS;            // 16
+            for (int i = 0; i < per; ++i) {
+                const int e = (i * (PSH_SELECT_THREADS / 64) + (tid >> 6)) * 64 + (tid & 63);
+                uint64_t mine = items[e];
+                if ((unsigned)(mine >> 32) == 0xffffffffu) mine = 0xffffffff00000000ull | (unsigned)e;   // padding: distinct, last
+                const unsigned myd = (unsigned)(mine >> 32);
+                int wrank = 0;
+#pragma unroll 16
+                for (int j = 0; j < 64; ++j) {
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mine, j);
+                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)myd, j);
+                    wrank += (hi < myd) ? 1 : 0;
+                    if (__any(hi == myd && j != (tid & 63)))
+                        wrank += (hi == myd && item_less(((uint64_t)hi << 32) | lo, mine, sel_rt)) ? 1 : 0;
+                }
+                G[(e & ~63) + wrank] = mine;
+            }
+            __threadfence_block();       // the block's waves share one vL1D: workgroup scope orders the scratch traffic (an agent-scope fence writes back the L2: ~1 ms per level)
+            __syncthreads();
+            for (int e = tid; e < a.kpad; e += PSH_SELECT_THREADS) items[e] = G[e];
+            __syncthreads();
+            for (int len = 64; len < a.kpad; len <<= 1) {
+                const int sh = 31 - __builtin_clz((unsigned)len);
+                for (int i0 = 0; i0 < per; i0 += 8) {
+                    uint64_t mine[8];
+                    int lo[8];
+                    const uint64_t* sib[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int e = tid + (i0 + i) * PSH_SELECT_THREADS;
+                        mine[i] = items[e];
+                        sib[i] = items + (size_t)((e >> sh) ^ 1) * len;
+                        lo[i] = 0;
+                    }
+                    for (int step = len >> 1; step > 0; step >>= 1)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            if (sort_key_less(sib[i][lo[i] + step - 1], mine[i])) lo[i] += step;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int e = tid + (i0 + i) * PSH_SELECT_THREADS;
+                        if (sort_key_less(sib[i][lo[i]], mine[i])) lo[i] += 1;
+                        while (lo[i] < len && (unsigned)(sib[i][lo[i]] >> 32) == (unsigned)(mine[i] >> 32)
+                               && item_less(sib[i][lo[i]], mine[i], sel_rt)) lo[i] += 1;
+                        G[(size_t)((e >> sh) >> 1) * 2 * len + (e & (len - 1)) + lo[i]] = mine[i];
+                    }
+                }
+                __threadfence_block();       // the block's waves share one vL1D: workgroup scope orders the scratch traffic (an agent-scope fence writes back the L2: ~1 ms per level)
+                __syncthreads();
+                for (int e = tid; e < a.kpad; e += PSH_SELECT_THREADS) items[e] = G[e];
+                __syncthreads();
             }
             need_network = false;
         }
@@ -3205,6 +3272,8 @@ hipError_t launch_select(const SelectArgs& a0, int B, hipStream_t s) {
     // kpad > 1024: the ordering stage wants a second kpad-item buffer behind the items (merge sort by ranking)
     int64_t area = key_cap;
     a.sort_buf_ok = (a.kpad > PSH_SELECT_THREADS && a.kpad <= 8 * PSH_SELECT_THREADS && 2 * items_bytes <= lds_budget) ? 1 : 0;
+    // beyond that (kpad = 16384): the second buffer is the query's own candidate slots, if the caller says they are free by then
+    if (a.sort_buf_ok || a.kpad <= 8 * PSH_SELECT_THREADS || (int64_t)a.cand_stride < (int64_t)a.kpad) a.sort_scratch = nullptr;
     if (a.sort_buf_ok && area < 2 * (int64_t)a.kpad) area = 2 * (int64_t)a.kpad;
     const size_t shmem = items_bytes + (size_t)area * sizeof(unsigned);
     if (shmem > 48 * 1024) {

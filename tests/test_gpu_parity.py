@@ -57,6 +57,9 @@ CASES = [  # R, T, W, h, k, B
     (24, 900, 256, 10, 20, 1),        # PSH_MAX_W
     (6, 2100, 20, 20, 1, 1),          # k = 1
     (2048, 512, 20, 20, 777, 4),
+    (4096, 1024, 20, 20, 5000, 2),    # kpad = 8192: merge sort by ranking, both buffers in LDS
+    (4096, 1024, 20, 20, 10000, 2),   # kpad = 16384 (the reference test's k): second buffer in global scratch
+    (2048, 2048, 20, 0, 16384, 1),    # PSH_MAX_K
 ]
 
 
@@ -447,3 +450,16 @@ def test_forward_topk_on_the_device_large(hip_device, oracle_mod):
     assert np.array_equal(d.cpu().numpy().view(np.uint32), od.view(np.uint32))
     flat = (idx[..., 0] * 128 + idx[..., 1]) * 32 + idx[..., 2]
     assert np.array_equal(flat.cpu().numpy(), oi[..., 0])
+
+
+def test_large_k_ordering_with_duplicated_paths(hip_device, oracle_mod):
+    """k = 12000 over an ensemble whose rows repeat 8 times: every distance value occurs 8 times, so the ordering
+    stage (kpad = 16384, merge sort by ranking through global scratch) leans on the (r, t) tie-break everywhere."""
+    base = syn.dataset(256, 1024, 91)
+    ds = np.ascontiguousarray(np.tile(base, (8, 1, 1)))
+    q = syn.gbm_log_returns((1, 20), 92)
+    d, idx, status, _ = hip_scan(hip_device, ds, q, 12000, 20)
+    if status[0] != 0:
+        d, idx, _, _ = hip_scan(hip_device, ds, q, 12000, 20, exhaustive=True)
+    od, oidx = oracle_mod.scan_topk(ds, q, 12000, h=20)
+    assert_exact(d, idx, od, oidx, "large k, 8-fold ties")
