@@ -182,7 +182,7 @@ hipError_t launch_select(const SelectArgs& a, int B, hipStream_t s);
 hipError_t launch_reseed(const ReseedArgs& a, int B, hipStream_t s);
 hipError_t launch_merge_sorted(const MergeSortedArgs& a, int B, hipStream_t s);   // needs G * k_in * 4 bytes of LDS
 hipError_t launch_rows(ScanArgs a, int mode, int grid, hipStream_t s);     // one-window rows (T == W + h): BOOT / FILTER
-size_t rows_shmem_bytes(int W, int B);
+size_t rows_shmem_bytes(int ds, int B);
 hipError_t launch_gather(const GatherArgs& a, hipStream_t s);
 
 }  // namespace psh

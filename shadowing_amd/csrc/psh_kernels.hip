@@ -2026,8 +2026,18 @@ __global__ __launch_bounds__(THREADS) void embed_scan_kernel(ScanArgs a) {
 // ----------------------------------------------------------------------------------
 #define PSH_ROWS_THREADS 128
 
+// staging of the 64 rows of a chunk (FILTER / ALL), chosen by the launcher:
+//   PSH_ROWS_FLAT  : gcd(T, 64) <= 2 -- the chunk is copied as it lies (16-byte LDS writes, no index arithmetic); a lane
+//                    then walks its row at stride T with at most a 2-way bank conflict
+//   PSH_ROWS_QUADS : T % 4 == 0 -- one row/column split per float4 (rows start on float4 boundaries), odd LDS row stride
+//   PSH_ROWS_SPLIT : anything else (long rows with a horizon tail, unaligned ensembles): one split per element, only
+//                    the first W samples of a row are kept
+#define PSH_ROWS_SPLIT 0
+#define PSH_ROWS_FLAT 1
+#define PSH_ROWS_QUADS 2
+
 template <int MODE>
-__global__ __launch_bounds__(PSH_ROWS_THREADS) void rows_kernel(ScanArgs a, int aligned16) {
+__global__ __launch_bounds__(PSH_ROWS_THREADS) void rows_kernel(ScanArgs a, int aligned16, int staging) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -2061,6 +2071,27 @@ __global__ __launch_bounds__(PSH_ROWS_THREADS) void rows_kernel(ScanArgs a, int 
             const int nr = (a.n_rows - 64 * c) < 64 ? (a.n_rows - 64 * c) : 64;
             const int64_t nfl = (int64_t)nr * T;
             const float* src = a.dataset + (a.row0 + (int64_t)64 * c) * T;
+            if (staging == PSH_ROWS_FLAT) {
+                for (int64_t e4 = lane; 4 * e4 < nfl; e4 += 64) {
+                    if (4 * e4 + 3 < nfl) {
+                        *reinterpret_cast<f32x4*>(tile + 4 * e4) = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + e4);
+                    } else {
+                        for (int k2 = 0; 4 * e4 + k2 < nfl; ++k2) tile[4 * e4 + k2] = src[4 * e4 + k2];
+                    }
+                }
+            } else if (staging == PSH_ROWS_QUADS) {
+                const unsigned T4 = (unsigned)(T >> 2);
+                const unsigned magic4 = (unsigned)((1ull << 32) / (unsigned long long)T4);
+                for (int64_t e4 = lane; 4 * e4 < nfl; e4 += 64) {
+                    const f32x4 q4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + e4);
+                    const unsigned r = fast_div((unsigned)e4, magic4, T4);
+                    const unsigned c = 4u * ((unsigned)e4 - r * T4);
+                    if (c < (unsigned)W) {
+                        float* dstp = tile + r * ds + c;
+                        dstp[0] = q4[0]; dstp[1] = q4[1]; dstp[2] = q4[2]; dstp[3] = q4[3];   // (columns >= W of the last quad: unused slots of the row)
+                    }
+                }
+            } else {
             const unsigned magic = (unsigned)((1ull << 32) / (unsigned long long)T);
             for (int64_t e4 = lane; 4 * e4 < nfl; e4 += 64) {
                 float v[4];
@@ -2078,6 +2109,7 @@ __global__ __launch_bounds__(PSH_ROWS_THREADS) void rows_kernel(ScanArgs a, int 
                     const unsigned col = e - r * (unsigned)T;
                     if (col < (unsigned)W && (int64_t)e < nfl) tile[r * ds + col] = v[k2];
                 }
+            }
             }
             wave_lds_fence();
         }
@@ -3296,29 +3328,35 @@ hipError_t launch_reseed(const ReseedArgs& a, int B, hipStream_t s) {
     hipLaunchKernelGGL(reseed_kernel, dim3((a.k + 255) / 256, B), dim3(256), 0, s, a);
     return hipGetLastError();
 }
-size_t rows_shmem_bytes(int W, int B) {
-    const int ds = W | 1;
-    return (size_t)(PSH_ROWS_THREADS / 64) * 64 * ds * sizeof(float) + (size_t)((B + 3) & ~3) * sizeof(int)
+size_t rows_shmem_bytes(int ds, int B) {      // ds: LDS floats per row
+    return (size_t)(PSH_ROWS_THREADS / 64) * 64 * (ds + 1) * sizeof(float) + (size_t)((B + 3) & ~3) * sizeof(int)
            + (size_t)(PSH_ROWS_THREADS / 64) * PSH_PEND * 16;
 }
 
 // one-window rows: a.n_rows rows from a.row0 at a.row_stride, `grid` blocks (<= PSH_MAX_BLOCKS)
 hipError_t launch_rows(ScanArgs a, int mode, int grid, hipStream_t s) {
-    a.tile_floats = a.W | 1;
-    const size_t shmem = rows_shmem_bytes(a.W, a.B);
     const int aligned16 = (((uintptr_t)a.dataset & 15u) == 0 && ((a.T * a.row0) % 4) == 0 && (a.T % 4 == 0 || a.row_stride == 1)) ? 1 : 0;
+    int staging = PSH_ROWS_SPLIT;
+    int ds = a.W | 1;
+    if (aligned16 && a.row_stride == 1 && a.T <= a.W + 12) {
+        const int64_t g = a.T & -a.T;                           // largest power of two dividing T
+        if (g <= 2) { staging = PSH_ROWS_FLAT; ds = (int)a.T; }
+        else { staging = PSH_ROWS_QUADS; ds = (int)((a.W + 3) & ~3) | 1; }
+    }
+    a.tile_floats = ds;
+    const size_t shmem = rows_shmem_bytes(ds, a.B);
     if (mode == PSH_MODE_BOOT) {
         hipError_t e = hipFuncSetAttribute((const void*)rows_kernel<PSH_MODE_BOOT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((rows_kernel<PSH_MODE_BOOT>), dim3(grid), dim3(PSH_ROWS_THREADS), shmem, s, a, aligned16);
+        hipLaunchKernelGGL((rows_kernel<PSH_MODE_BOOT>), dim3(grid), dim3(PSH_ROWS_THREADS), shmem, s, a, aligned16, staging);
     } else if (mode == PSH_MODE_ALL) {
         hipError_t e = hipFuncSetAttribute((const void*)rows_kernel<PSH_MODE_ALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((rows_kernel<PSH_MODE_ALL>), dim3(grid), dim3(PSH_ROWS_THREADS), shmem, s, a, aligned16);
+        hipLaunchKernelGGL((rows_kernel<PSH_MODE_ALL>), dim3(grid), dim3(PSH_ROWS_THREADS), shmem, s, a, aligned16, staging);
     } else {
         hipError_t e = hipFuncSetAttribute((const void*)rows_kernel<PSH_MODE_FILTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((rows_kernel<PSH_MODE_FILTER>), dim3(grid), dim3(PSH_ROWS_THREADS), shmem, s, a, aligned16);
+        hipLaunchKernelGGL((rows_kernel<PSH_MODE_FILTER>), dim3(grid), dim3(PSH_ROWS_THREADS), shmem, s, a, aligned16, staging);
     }
     return hipGetLastError();
 }
