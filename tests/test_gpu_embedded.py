@@ -335,3 +335,42 @@ def test_predict_runs_on_the_device_and_matches_the_host_chain(hip_device, monke
     m1, s1 = obj.predict(x, k=256, to_predict=host_only, eta=eta, proba_name=proba, cuda=True)
     assert seen == [None]
     np.testing.assert_allclose(m1, m0, rtol=1e-12)
+
+
+def test_reference_test_cell_1_forward_topk_prefix_consistency_on_the_device(hip_device):
+    """testing.ipynb:43-53 at its own sizes, device tensors: top-32 (32 splits) == the first 32 of top-64 (64 splits),
+    torch.equal on distances and indices -- through the scan kernels (rows_kernel)."""
+    import shadowing_amd as sa
+    torch.manual_seed(0)
+    dist = sa.RelativeMSE()
+    x, y = torch.randn(8, 34).to(hip_device), torch.randn(128, 512, 34).to(hip_device)
+    d32, i32 = dist.forward_topk(x, y, 32, 32)
+    d64, i64 = dist.forward_topk(x, y, 64, 64)
+    assert torch.equal(d32, d64[:, :32]) and torch.equal(i32, i64[:, :32])
+    assert i32.dtype == torch.int64 and i32.shape == (8, 32, 2) and d32.is_cuda
+    for b in range(8):                                       # the indices point at the distances they claim
+        r, t = i32[b, :, 0], i32[b, :, 1]
+        again = dist(x[b][None, :].cpu(), y[r, t].cpu())
+        np.testing.assert_allclose(again.numpy(), d32[b].cpu().numpy(), rtol=1e-6)
+
+
+def test_reference_test_cell_2_shadow_self_consistency_on_the_device(hip_device):
+    """testing.ipynb:62-78 at its own sizes with cuda=True: Foveal(1.15, 0.9, 126), x_context (8,1,126), dataset
+    (32,1,4096), horizon 252, k = 1024; re-embedding the returned paths' in-context part reproduces the returned
+    distances (the reference asserts rtol 1e-2; here 1e-5), rows ascending."""
+    import shadowing_amd as sa
+    torch.manual_seed(1)
+    emb = sa.Foveal(alpha=1.15, beta=0.9, max_context=126)
+    ctx = sa.PredictionContext(horizon=252)
+    ds = torch.randn(32, 1, 4096).numpy()
+    x = torch.randn(8, 1, 126).numpy()
+    obj = sa.PathShadowing(emb, sa.RelativeMSE(), ds, ctx)
+    d, paths, idx = obj.shadow(x, k=1024, cuda=True)
+    assert obj.last_path == "hip" and paths.shape == (8, 1024, 1, 378) and idx.shape == (8, 1024, 2)
+    hx = emb(torch.tensor(x))[:, 0, :]
+    hp = emb(torch.tensor(ctx.select_in_context(paths)).reshape(-1, 1, 126))[:, 0, :].reshape(8, 1024, -1)
+    again = sa.RelativeMSE()(hx[:, None, :], hp).numpy()
+    np.testing.assert_allclose(again, d, rtol=1e-5)
+    assert np.all(np.diff(d, axis=1) >= 0)
+    d_host, _, idx_host = obj.shadow(x, k=1024, cuda=False)   # and the reference's formulation on the host agrees
+    np.testing.assert_allclose(d, d_host, rtol=1e-5)
