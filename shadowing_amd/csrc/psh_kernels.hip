@@ -354,6 +354,26 @@ __device__ inline float acc_single_window(const float* tile, int lane, const_f32
     return sumsq8([&](int j) { return __fsub_rn(x[j], tile[lds_pad(base + j)]); }, W);
 }
 
+// minimum of the 16 accumulators of an MFMA tile in 8 v_min3_f32.  (fminf() makes the compiler quiet possible signalling
+// NaNs first -- two v_max x, x per tile in the hottest loop of the batched scan; v_min3 returns the non-NaN operands'
+// minimum just the same: a NaN accumulator is ignored, which is what the callers want -- its window can never be admitted.)
+__device__ __forceinline__ float min3f(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ float tile_min16(const f32x16_t& t) {
+    float m = min3f(t[0], t[1], t[2]);
+    m = min3f(m, t[3], t[4]);
+    m = min3f(m, t[5], t[6]);
+    m = min3f(m, t[7], t[8]);
+    m = min3f(m, t[9], t[10]);
+    m = min3f(m, t[11], t[12]);
+    m = min3f(m, t[13], t[14]);
+    return min3f(m, t[15], t[15]);
+}
+
 __device__ __forceinline__ float min16(const float (&a)[PSH_L]) {
     float m = fminf(fminf(a[0], a[1]), a[2]);
 #pragma unroll
@@ -1138,13 +1158,10 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
             float mn[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float m2 = fminf(fminf(acc[g][0], acc[g][1]), acc[g][2]);
-#pragma unroll
-                for (int i = 3; i + 1 < 16; i += 2) m2 = fminf(fminf(m2, acc[g][i]), acc[g][i + 1]);
-                mn[g] = fminf(m2, acc[g][15]);
+                mn[g] = tile_min16(acc[g]);
             }
             // values are finite here unless keep_all (then thr = +inf keeps NaN too)
-            if (!__any(!(fminf(fminf(mn[0], mn[1]), fminf(mn[2], mn[3])) > thr))) continue;
+            if (!__any(!(min3f(min3f(mn[0], mn[1], mn[2]), mn[3], mn[3]) > thr))) continue;
             // survivors are only QUEUED here (window, query): a lane-by-lane exact chain would run ~140
             // instructions for the one or two lanes that hold a survivor; the queue is drained 64 at a time
             const bool lane_ok = ql < nq;
