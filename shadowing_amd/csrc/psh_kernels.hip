@@ -782,6 +782,8 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
     _Float16* a1 = ah;                                                    // y^
     _Float16* a2 = ah + PSH_MX_NHALF;                                     // (y~^2)^
     int npend = 0;
+    const int gw_dbg = (int)blockIdx.x * NW + wave_in_block;
+    if (a.dbg_times && lane == 0) a.dbg_times[2 * gw_dbg] = wall_clock64();   // tuning aid (tools/wave_times.py)
     if (threadIdx.x == 0) { *next_unit = 0; lcount[0] = 0; lcount[1] = 0; }
     {   // the tail slots no segment ever writes must hold finite values (0 * NaN poisons a row)
         unsigned* z = reinterpret_cast<unsigned*>(ah);
@@ -951,6 +953,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
     unsigned u = grab();
     if (u < u_hi) load_unit(st, u);
     while (u < u_hi) u = process(st, u);
+    if (a.dbg_times && lane == 0) a.dbg_times[2 * gw_dbg + 1] = wall_clock64();
     if (npend > 0) flush();
     __syncthreads();
     if (threadIdx.x == 0) {
