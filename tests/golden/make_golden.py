@@ -163,6 +163,10 @@ def main():
                      None, 40, 2, True, ctx=ref.ImputationContext((8, 5, 12)))
         run_embedded("imputation_user_kernel_6_9_7", ref.PathEmbedding(torch.randn(4, 1, 13, generator=g)), syn.dataset(50, 300, 45),
                      syn.gbm_log_returns((2, 13), 46), None, 25, 1, True, ctx=ref.ImputationContext((6, 9, 7)))
+        # Foveal + ImputationContext on an ensemble large enough for the sampled path (the suffix-rows scan with a gap)
+        run_embedded("imputation_foveal_18_6_12", ref.Foveal(alpha=1.3, beta=0.8, max_context=30), syn.dataset(600, 700, 47),
+                     syn.gbm_log_returns((3, 30), 48), None, 200, 2, False, dict(gen="dataset(600,700,47)"),
+                     ctx=ref.ImputationContext((18, 6, 12)))
         if args.big:
             # the tutorial's shape (k = 8192, horizon 252) on a generated ensemble
             run_embedded("foveal_tutorial_R1024", fov, syn.dataset(1024, 2048, 39), syn.gbm_log_returns((2, 126), 40),

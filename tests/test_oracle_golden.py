@@ -27,7 +27,7 @@ def test_oracle_reproduces_reference(oracle_mod, name):
     W = g["W"]
     h = g["h"] or 0
     ref_paths = oracle_mod.gather_paths(ds, g["idx"], W + h)[:, :, None, :]
-    assert np.array_equal(ref_paths, g["paths"])
+    assert np.array_equal(ref_paths[:, :g["paths"].shape[1]], g["paths"])      # (generated ensembles keep the first 32 paths only)
 
 
 @pytest.mark.parametrize("name", SMALL_GOLDENS)
@@ -103,7 +103,7 @@ def test_embedded_oracle_reproduces_reference(oracle_mod, name):
     n = g["paths"].shape[1]
     K = g["kernel"].shape[1]
     ref_paths = oracle_mod.gather_paths(ds, g["idx"][:, :n], K + h)[:, :, None, :]
-    assert np.array_equal(ref_paths, g["paths"])
+    assert np.array_equal(ref_paths[:, :g["paths"].shape[1]], g["paths"])      # (generated ensembles keep the first 32 paths only)
 
 
 def test_embedded_oracle_with_identity_kernel_is_the_plain_scan(oracle_mod):
@@ -142,7 +142,7 @@ def test_embedded_oracle_reproduces_reference_with_an_imputation_context(oracle_
     all_dist = [oracle_mod.all_distances_embedded(ds, g["kernel_padded"], q, 0) for q in g["hx"]]
     assert_matches_reference(d, idx, g, all_dist, what=name)
     ref_paths = oracle_mod.gather_paths(ds, g["idx"], g["kernel_padded"].shape[1])[:, :, None, :]
-    assert np.array_equal(ref_paths, g["paths"])
+    assert np.array_equal(ref_paths[:, :g["paths"].shape[1]], g["paths"])      # (generated ensembles keep the first 32 paths only)
 
 
 @pytest.mark.parametrize("name", CROSS_GOLDENS)
