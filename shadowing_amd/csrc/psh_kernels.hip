@@ -1603,6 +1603,79 @@ __device__ __forceinline__ void nest_shift(f32x2 (&W2)[8], f32x4 (&Q)[2], const 
     }
 }
 
+// correlate16 on packed fp32: the 16 chains of a lane as 8 register pairs (windows w and w + 8), the window slots
+// paired the same way (slot s with s + 8, as in nest_add), so one tap is 8 v_pk_fma_f32 -- each half an IEEE fma of its
+// own: the same bits as 16 v_fmac_f32, at half the issue slots.  The tap comes straight out of the 16-byte LDS read
+// (op_sel picks its half of the pair), the window pair is read in order or swapped.
+template <int JJ, int Q>
+__device__ __forceinline__ void corr16_pk(const f32x4& tp, const f32x2 (&W2)[8], f32x2 (&C2)[8]) {
+    const f32x2 tpair = (Q < 2) ? f32x2{tp[0], tp[1]} : f32x2{tp[2], tp[3]};
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const bool swapped = ((w + JJ) & 15) >= 8;
+        if ((Q & 1) == 0) {
+            if (!swapped) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(C2[w]) : "v"(tpair), "v"(W2[(w + JJ) & 7]));
+            else          asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1]" : "+v"(C2[w]) : "v"(tpair), "v"(W2[(w + JJ) & 7]));
+        } else {
+            if (!swapped) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(C2[w]) : "v"(tpair), "v"(W2[(w + JJ) & 7]));
+            else          asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(C2[w]) : "v"(tpair), "v"(W2[(w + JJ) & 7]));
+        }
+    }
+}
+
+template <int G4>
+__device__ __forceinline__ void corr16_pk_group(const f32x4& tp, const f32x4& nx, f32x2 (&W2)[8], f32x2 (&C2)[8]) {
+    corr16_pk<4 * G4 + 0, 0>(tp, W2, C2);
+    W2[(4 * G4 + 0) & 7][(4 * G4 + 0) >> 3] = nx[0];
+    asm volatile("" : "+v"(W2[(4 * G4 + 0) & 7]));
+    corr16_pk<4 * G4 + 1, 1>(tp, W2, C2);
+    W2[(4 * G4 + 1) & 7][(4 * G4 + 1) >> 3] = nx[1];
+    asm volatile("" : "+v"(W2[(4 * G4 + 1) & 7]));
+    corr16_pk<4 * G4 + 2, 2>(tp, W2, C2);
+    W2[(4 * G4 + 2) & 7][(4 * G4 + 2) >> 3] = nx[2];
+    asm volatile("" : "+v"(W2[(4 * G4 + 2) & 7]));
+    corr16_pk<4 * G4 + 3, 3>(tp, W2, C2);
+    W2[(4 * G4 + 3) & 7][(4 * G4 + 3) >> 3] = nx[3];
+    asm volatile("" : "+v"(W2[(4 * G4 + 3) & 7]));
+}
+
+// c_w = sum_{j < n} taps[j] * tile[base + w + j], windows w and w + 8 in C2[w] -- same contract as correlate16
+__device__ __forceinline__ void correlate16_pk(const float* tile, int base, const float* taps, int n, f32x2 (&C2)[8]) {
+    f32x2 W2[8];
+#pragma unroll
+    for (int q = 0; q < PSH_L / 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(tile + lds_pad(base + 4 * q));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) W2[(4 * q + e) & 7][(4 * q + e) >> 3] = v[e];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) C2[i] = f32x2{0.0f, 0.0f};
+#pragma unroll 1
+    for (int jb = 0; jb < n; jb += PSH_L) {
+        const int rem = n - jb;                              // wave-uniform
+        if (0 < rem) {
+            const f32x4 nx = *reinterpret_cast<const f32x4*>(tile + lds_pad(base + jb + PSH_L + 0));
+            const f32x4 tp = *reinterpret_cast<const f32x4*>(taps + jb + 0);
+            corr16_pk_group<0>(tp, nx, W2, C2);
+        }
+        if (4 < rem) {
+            const f32x4 nx = *reinterpret_cast<const f32x4*>(tile + lds_pad(base + jb + PSH_L + 4));
+            const f32x4 tp = *reinterpret_cast<const f32x4*>(taps + jb + 4);
+            corr16_pk_group<1>(tp, nx, W2, C2);
+        }
+        if (8 < rem) {
+            const f32x4 nx = *reinterpret_cast<const f32x4*>(tile + lds_pad(base + jb + PSH_L + 8));
+            const f32x4 tp = *reinterpret_cast<const f32x4*>(taps + jb + 8);
+            corr16_pk_group<2>(tp, nx, W2, C2);
+        }
+        if (12 < rem) {
+            const f32x4 nx = *reinterpret_cast<const f32x4*>(tile + lds_pad(base + jb + PSH_L + 12));
+            const f32x4 tp = *reinterpret_cast<const f32x4*>(taps + jb + 12);
+            corr16_pk_group<3>(tp, nx, W2, C2);
+        }
+    }
+}
+
 // THREADS / BG / NBG: 1024 threads (4 waves per SIMD, 128 VGPRs) with 3 (dense) or 2 (suffix rows) queries per evaluation of
 // the embedding, or -- batches of 7 and more -- 512 threads (2 waves per SIMD, 256 VGPRs) with 10 or 6: the embedding is the
 // cost, and a wave that carries 4x the accumulators evaluates it 4x less often.
@@ -1987,30 +2060,36 @@ __global__ __launch_bounds__(THREADS) void embed_scan_kernel(ScanArgs a) {
             if (MODE == PSH_MODE_FILTER && ns > 0) { verify_list(); ns = 0; }   // before the tile is overwritten
         } else
         for (int b0 = q_begin; b0 < q_end; b0 += BG) {
-            float acc[BG][PSH_L];
+            f32x2 acc2[BG][8];
 #pragma unroll
             for (int g = 0; g < BG; ++g)
 #pragma unroll
-                for (int w = 0; w < PSH_L; ++w) acc[g][w] = 0.0f;
+                for (int w = 0; w < 8; ++w) acc2[g][w] = f32x2{0.0f, 0.0f};
 #pragma unroll 1
             for (int i = 0; i < d; ++i) {
                 const int2 rg = rng[i];
                 const int jlo = __builtin_amdgcn_readfirstlane(rg.x);
                 const int n = __builtin_amdgcn_readfirstlane(rg.y);
-                float c[PSH_L];
-                correlate16(tile, PSH_L * lane + jlo, kerL + (size_t)i * Kp + jlo, n, c);
+                f32x2 c2[8];                                 // windows w (x) and w + 8 (y)
+                correlate16_pk(tile, PSH_L * lane + jlo, kerL + (size_t)i * Kp + jlo, n, c2);
 #pragma unroll
                 for (int g = 0; g < BG; ++g) {
                     if (b0 + g < q_end) {                    // wave-uniform
                         const float hxv = hxk[(int64_t)(b0 + g) * d + i];
+                        const f32x2 hx2 = f32x2{hxv, hxv};
 #pragma unroll
-                        for (int w = 0; w < PSH_L; ++w) {
-                            const float D = __fsub_rn(hxv, c[w]);
-                            acc[g][w] = __builtin_fmaf(D, D, acc[g][w]);
+                        for (int w = 0; w < 8; ++w) {        // D = hx - c (one rounding), acc = fma(D, D, acc): per half, IEEE
+                            const f32x2 D = hx2 - c2[w];
+                            acc2[g][w] = __builtin_elementwise_fma(D, D, acc2[g][w]);
                         }
                     }
                 }
             }
+            float acc[BG][PSH_L];
+#pragma unroll
+            for (int g = 0; g < BG; ++g)
+#pragma unroll
+                for (int w = 0; w < PSH_L; ++w) acc[g][w] = acc2[g][w & 7][w >> 3];
 #pragma unroll
             for (int g = 0; g < BG; ++g) {
                 const int b = b0 + g;
