@@ -23,4 +23,11 @@ for f in $(find $OUT/prof_stats -name "*kernel_stats.csv"); do cp $f $OUT/kernel
 cd $R
 timeout 300 python bench.py --steps 20 --warmup 3 --queries 512 --no-cpu-baseline > $OUT/bench_n1_q512.json 2>> $OUT/bench.err
 PSH_FILTER=valu timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_n1_valu_filter.json 2>> $OUT/bench.err
+# the widened rows of the scope table: the reference's Foveal workloads, configs[4] (wavelet), forward_topk
+timeout 600 python tools/bench_foveal.py --steps 20 --generic --which tutorial testing wavelet 2>> $OUT/bench.err | grep "^{" > $OUT/bench_foveal.jsonl
+timeout 300 python tools/bench_forward_topk.py 2>> $OUT/bench.err | grep "^{" > $OUT/bench_forward_topk.jsonl
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_foveal -o fov -- python $R/tools/bench_foveal.py --steps 20 --which tutorial testing > $OUT/bench_foveal_prof.log 2>&1
+for f in $(find $OUT/prof_foveal -name "*kernel_stats.csv"); do head -8 $f > $OUT/foveal_kernel_stats.csv; done
+cd $R
 tail -c 600 $OUT/pmc_summary.txt; head -8 $OUT/kernel_stats.csv; cat $OUT/bench_n1.json
