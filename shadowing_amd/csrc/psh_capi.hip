@@ -184,7 +184,9 @@ int plan_scan(int device, const Problem& p, int64_t n_rows, Plan* plan) {
     const int tile_floats = tile_floats_for(p.W);
     // embedded scan of a batch: 512-thread blocks whose waves carry 12 (suffix rows: 6) queries per evaluation of the
     // embedding (256 VGPRs, one block per CU)
-    const bool wide = p.ker && p.B >= PSH_EMB_WIDE_MIN_B && getenv("PSH_EMBED_NARROW") == nullptr;
+    int wide_min = PSH_EMB_WIDE_MIN_B;
+    if (const char* e = getenv("PSH_EMBED_WIDE_MIN_B")) { const int v = atoi(e); if (v >= 1) wide_min = v; }   // tuning aid
+    const bool wide = p.ker && p.B >= wide_min && getenv("PSH_EMBED_NARROW") == nullptr;
     const int threads = wide ? 512 : PSH_SCAN_THREADS;
     const size_t shmem = scan_shmem_bytes(tile_floats, p.B, p.emb_d, p.W, threads);
     if (shmem > 160 * 1024) return PSH_ERR_UNSUPPORTED;
