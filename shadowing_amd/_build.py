@@ -11,8 +11,8 @@ CSRC = PKG / "csrc"
 LIBDIR = PKG / "lib"
 LIB = LIBDIR / "libpsh_hip.so"
 INCLUDE = PKG.parent / "include"
-SOURCES = [CSRC / "psh_kernels.hip", CSRC / "psh_capi.hip"]
-DEPS = SOURCES + [CSRC / "psh_kernels.h", INCLUDE / "psh.h"]
+SOURCES = [CSRC / "psh_scan.hip", CSRC / "psh_embed.hip", CSRC / "psh_select.hip", CSRC / "psh_capi.hip"]
+DEPS = SOURCES + [CSRC / "psh_kernels.h", CSRC / "psh_device.h", INCLUDE / "psh.h"]
 
 # -ffp-contract=off: nothing may be fused or re-associated that the source does not
 # spell out -- bit-exact distances are what make the returned indices bit-exact.
@@ -38,12 +38,31 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not is_stale():
         return LIB
     LIBDIR.mkdir(exist_ok=True)
-    cmd = [hipcc_path(), *HIPCC_FLAGS, f"-I{INCLUDE}", f"-I{CSRC}", *map(str, SOURCES), "-o", str(LIB)]
+    hipcc = hipcc_path()
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    objdir = LIBDIR / "obj"
+    objdir.mkdir(exist_ok=True)
+
+    def compile_one(srcfile: Path) -> Path:
+        obj = objdir / (srcfile.stem + ".o")
+        cmd = [hipcc, *flags, f"-I{INCLUDE}", f"-I{CSRC}", "-c", str(srcfile), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {srcfile.name}:\n{res.stdout}\n{res.stderr}")
+        return obj
+
+    # the translation units are independent: compile them side by side, then link
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *map(str, objs), "-o", str(LIB)]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed:\n{res.stdout}\n{res.stderr}")
+        raise RuntimeError(f"hipcc link failed:\n{res.stdout}\n{res.stderr}")
     return LIB
 
 

@@ -1,5 +1,5 @@
 // psh_kernels.h -- argument blocks and launch entry points shared by the kernels
-// (psh_kernels.hip) and the C ABI (psh_capi.hip).  Internal; the public header is
+// (psh_scan.hip, psh_embed.hip, psh_select.hip) and the C ABI (psh_capi.hip).  Internal; the public header is
 // include/psh.h.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -166,6 +166,8 @@ struct GatherArgs {
 hipError_t launch_prep(const PrepArgs& a, hipStream_t s);
 hipError_t launch_qnorm(const float* q, int B, int W, float* out, hipStream_t s);
 hipError_t launch_scan(const ScanArgs& a, int mode, bool aligned, int grid, hipStream_t s);
+hipError_t launch_embed_scan(const ScanArgs& a, int mode, bool aligned, int grid, hipStream_t s);   // psh_embed.hip; launch_scan routes a.ker != nullptr here
+hipError_t embed_blocks_per_cu(bool aligned, size_t shmem, int* out);
 size_t scan_shmem_bytes(int tile_floats, int B, int emb_d, int W, int threads = PSH_SCAN_THREADS);
 #define PSH_EMB_WIDE_MIN_B 7          // embedded scan, this many queries and more: 512-thread blocks carrying 10 (6) queries per pass
 size_t scan_mx_shmem_bytes(int tile_floats, int B);

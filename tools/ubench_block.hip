@@ -1,6 +1,6 @@
 // Isolated timing of the scan's hot blocks (no HBM traffic): how many SIMD cycles does one
 // 1024-window segment cost in accumulate16<20> (exact) and approx16<20> (cheap test)?
-#include "../shadowing_amd/csrc/psh_kernels.hip"
+#include "../shadowing_amd/csrc/psh_device.h"
 #include <stdio.h>
 using namespace psh;
 template <int VARIANT>
