@@ -88,6 +88,10 @@ def cpu_baseline(ds: np.ndarray, q: np.ndarray, k: int, h: int) -> dict:
 
 def main():
     args = parse()
+    # stdout carries ONE line, the JSON: anything a native library prints there (RCCL writes a five-line version banner
+    # to stdout when a communicator goes away) is sent to stderr instead
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -261,7 +265,7 @@ def main():
             "stages_ms": stages,
             "parity_vs_reference_golden": parity,
         }
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_pg:
         dist.destroy_process_group()
 
