@@ -463,3 +463,25 @@ def test_large_k_ordering_with_duplicated_paths(hip_device, oracle_mod):
         d, idx, _, _ = hip_scan(hip_device, ds, q, 12000, 20, exhaustive=True)
     od, oidx = oracle_mod.scan_topk(ds, q, 12000, h=20)
     assert_exact(d, idx, od, oidx, "large k, 8-fold ties")
+
+
+@pytest.mark.parametrize("R,W,h,k,B", [
+    (5000, 20, 3, 100, 2),      # T = 23: flat staging (odd row length)
+    (3000, 32, 0, 64, 1),       # T = 32: one row/column split per float4, odd LDS row stride
+    (4097, 33, 7, 300, 3),      # T = 40, W = 33: quads with unused tail columns; ragged last chunk
+    (2000, 256, 0, 50, 1),      # PSH_MAX_W: 132 KB of LDS per block
+    (6000, 5, 100, 200, 2),     # T = 105 >> W: per-element split, only the first W samples kept
+    (70000, 34, 0, 1000, 9),    # the sampled path at size, 9 queries
+    (1000, 7, 0, 900, 1),       # k close to N / 1: bootstrap too thin -> exhaustive, one slot per row
+])
+def test_one_window_rows_equal_oracle(hip_device, oracle_mod, R, W, h, k, B):
+    """Paths exactly one window long (T == W + h): rows_kernel (a row per lane; BOOT / FILTER / ALL and its three
+    staging modes) against the oracle's contiguous 8-lane reduce -- what forward_topk and shadow() on such paths run."""
+    ds = syn.dataset(R, W + h, 300 + R)
+    q = syn.gbm_log_returns((B, W), 400 + W)
+    d, idx, status, _ = hip_scan(hip_device, ds, q, k, h)
+    if np.any(status != 0):
+        d, idx, _, _ = hip_scan(hip_device, ds, q, k, h, exhaustive=True)
+    od, oidx = oracle_mod.scan_topk(ds, q, k, h=h)
+    assert_exact(d, idx, od, oidx, f"one-window rows R={R} W={W} h={h} k={k} B={B}")
+    assert np.all(idx[..., 1] == 0)
