@@ -540,20 +540,24 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     // single query on the matrix cores: candidates are filed in two classes around an ESTIMATE of the k-th
     // smallest acc (the rank2-th smallest sampled minimum ~ 2k windows of the whole ensemble below it)
     int rank2 = 0;
-    if (use_mx || p.ker) {
-        // The embedded scan ADMITS below this estimate (tau2 <= tau): a candidate costs it an exact d x K chain, and
-        // the provable tau of a 1/16 sample lets ~16 k of them through.  Everything with acc < tau2 is found, so when
-        // at least k windows are, the result is the exact top-k; when fewer are (the sample was not representative)
-        // the selection raises the query's status and the caller takes the exhaustive path, as for an overflow.
+    int k_thr = k;             // the rank the threshold kernel selects exactly
+    if (use_mx) {
         const int64_t r2 = (2 * (int64_t)k * n_sample + p.R - 1) / p.R + 8;
         rank2 = (r2 < k && r2 <= bp.entries) ? (int)r2 : 0;
-    } else if (rows_path) {
-        // one-window rows: a 1/64 sample (the threshold kernel is otherwise the longest stage), so a wider margin: the
-        // estimate sits where ~3k points are expected (a 6-sigma shortfall before fewer than k are below it)
-        const int64_t r2 = (3 * (int64_t)k * n_sample + p.R - 1) / p.R + 16;
-        rank2 = (r2 < k && r2 <= bp.entries) ? (int)r2 : 0;
+    } else if (p.ker || rows_path) {
+        // The embedded scan (and the scan of one-window rows) ADMITS below an estimate: a candidate costs it an exact
+        // d x K chain, and the provable tau of a 1/16 sample lets ~16 k of them through.  The estimate is the r2-th
+        // smallest sampled minimum, r2 ~ 1.5 k x the sampled fraction (3 k for the thin 1/64 sample of one-window
+        // rows) + 16: ~1.5 k (3 k) windows of the whole ensemble lie below it, k only after a 4..14 sigma shortfall.
+        // Everything with acc below it is found, so when at least k windows are, the result is the exact top-k; when
+        // fewer are, the selection raises the query's status and the caller takes the exhaustive path, as for an
+        // overflow.  The threshold kernel selects THIS rank exactly (tau = tau2 = the estimate): read off a bucket edge
+        // of the rank-k selection it came out 1.5x too generous, and 25 k candidates per query miss the selection's
+        // LDS-resident path (16384 keys) that 12 k take.
+        const int64_t r2 = ((p.ker ? 3 : 6) * (int64_t)k * n_sample + 2 * p.R - 1) / (2 * p.R) + 16;
+        if (r2 < k && r2 <= bp.entries) k_thr = (int)r2;
     }
-    ThresholdArgs ta{w.minbuf, w.min_stride, (int)bp.entries, w.qstate, k, 0,
+    ThresholdArgs ta{w.minbuf, w.min_stride, (int)bp.entries, w.qstate, k_thr, 0,
                      (use_mx || use_mq) ? w.blockmax : nullptr, n_blockmax, use_mq ? w.mq_frag : nullptr, rank2, pa};
     HIP_TRY(launch_threshold(ta, B, s));
     rc = tm.mark(); if (rc) return rc;                                       // 3

@@ -336,12 +336,32 @@ __device__ __forceinline__ bool item_less(uint64_t x, uint64_t y, const int2* rt
     return (unsigned)a.y < (unsigned)b.y;
 }
 
-// the lower-bound comparison of the merge sort by ranking: distance bits alone -- the (almost always empty) range of
-// equal distances is then stepped over with item_less -- except for PADDING items (d = 0xffffffff, kpad - k of them,
-// made distinct by their low word, ordered by it): there the whole 64-bit key is the order, and stepping over
-// thousands of "equal" padding entries one by one was 1 ms per level at k = 10000
-__device__ __forceinline__ bool sort_key_less(uint64_t sib, uint64_t mine) {
-    return ((unsigned)(mine >> 32) == 0xffffffffu) ? (sib < mine) : ((unsigned)(sib >> 32) < (unsigned)(mine >> 32));
+// the distance word of item `idx` of a run (little endian: the high dword of the 64-bit key) -- the searches of the merge
+// sort by ranking are bound by LDS throughput (16 waves x ~100 random probes per level), so they read 4 bytes a probe, not 8
+__device__ __forceinline__ unsigned run_dist(const uint64_t* run, int idx) {
+    return reinterpret_cast<const unsigned*>(run)[2 * idx + 1];
+}
+__device__ __forceinline__ unsigned run_low(const uint64_t* run, int idx) {
+    return reinterpret_cast<const unsigned*>(run)[2 * idx];
+}
+// first position of run[0, len) whose key is not below `mine` in the order of item_less, given `lo` from the lower bound
+// on the distance word: padding (d = 0xffffffff, kpad - k entries, distinct low words in ascending order) takes a second
+// lower bound on the low word -- stepping over thousands of "equal" padding keys one by one was 1 ms per level at
+// k = 10000 -- anything else steps over the (almost always empty) range of equal distances with the full comparison
+__device__ __forceinline__ int finish_rank(const uint64_t* run, int len, int lo, uint64_t mine, const int2* sel_rt) {
+    const unsigned myd = (unsigned)(mine >> 32);
+    if (lo < len && run_dist(run, lo) < myd) lo += 1;
+    if (myd == 0xffffffffu) {
+        int n = len - lo;                                  // the padding tail of the run
+        const unsigned mylow = (unsigned)mine;
+        while (n > 0) {
+            const int half = n >> 1;
+            if (run_low(run, lo + half) < mylow) { lo += half + 1; n -= half + 1; } else n = half;
+        }
+        return lo;
+    }
+    while (lo < len && run_dist(run, lo) == myd && item_less(run[lo], mine, sel_rt)) lo += 1;
+    return lo;
 }
 
 __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a) {
@@ -761,14 +781,12 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
                 for (int step = len >> 1; step > 0; step >>= 1)
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        if (i < per && sort_key_less(sib[i][lo[i] + step - 1], mine[i])) lo[i] += step;
+                        if (i < per && run_dist(sib[i], lo[i] + step - 1) < (unsigned)(mine[i] >> 32)) lo[i] += step;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     if (i < per) {
                         const int e = tid + i * PSH_SELECT_THREADS;
-                        if (sort_key_less(sib[i][lo[i]], mine[i])) lo[i] += 1;
-                        while (lo[i] < len && (unsigned)(sib[i][lo[i]] >> 32) == (unsigned)(mine[i] >> 32)
-                               && item_less(sib[i][lo[i]], mine[i], sel_rt)) lo[i] += 1;
+                        lo[i] = finish_rank(sib[i], len, lo[i], mine[i], sel_rt);
                         dst[(size_t)((e >> sh) >> 1) * 2 * len + (e & (len - 1)) + lo[i]] = mine[i];
                     }
                 }
@@ -822,13 +840,11 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
                     for (int step = len >> 1; step > 0; step >>= 1)
 #pragma unroll
                         for (int i = 0; i < 8; ++i)
-                            if (sort_key_less(sib[i][lo[i] + step - 1], mine[i])) lo[i] += step;
+                            if (run_dist(sib[i], lo[i] + step - 1) < (unsigned)(mine[i] >> 32)) lo[i] += step;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const int e = tid + (i0 + i) * PSH_SELECT_THREADS;
-                        if (sort_key_less(sib[i][lo[i]], mine[i])) lo[i] += 1;
-                        while (lo[i] < len && (unsigned)(sib[i][lo[i]] >> 32) == (unsigned)(mine[i] >> 32)
-                               && item_less(sib[i][lo[i]], mine[i], sel_rt)) lo[i] += 1;
+                        lo[i] = finish_rank(sib[i], len, lo[i], mine[i], sel_rt);
                         G[(size_t)((e >> sh) >> 1) * 2 * len + (e & (len - 1)) + lo[i]] = mine[i];
                     }
                 }
