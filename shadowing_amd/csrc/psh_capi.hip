@@ -77,7 +77,7 @@ BootPlan boot_plan(int64_t R, int64_t Tp, int k, bool halves = false, bool estim
     BootPlan bp{0, 0, 0};
     const int64_t nseg = (Tp + PSH_SEG - 1) / PSH_SEG;
     const int64_t quarter = R / 4;
-    int64_t rows = R / 16;
+    int64_t rows = estimate ? R / 32 : R / 16;
     const int64_t need_rows = ((estimate ? 2 : 8) * (int64_t)k + nseg - 1) / nseg;      // >= 8k (2k) segment minima
     if (rows < need_rows) rows = need_rows;
     if (rows >= 1 && rows <= quarter) {
@@ -85,7 +85,7 @@ BootPlan boot_plan(int64_t R, int64_t Tp, int k, bool halves = false, bool estim
         bp.rows = rows; bp.per_wave = 1; bp.entries = rows * nseg; return bp;
     }
     const int64_t lanes_per_row = (Tp + PSH_L - 1) / PSH_L;             // real minima per row
-    rows = ((estimate ? 8 : 32) * (int64_t)k + lanes_per_row - 1) / lanes_per_row;
+    rows = ((estimate ? 4 : 32) * (int64_t)k + lanes_per_row - 1) / lanes_per_row;
     if (rows > quarter) rows = quarter;
     if (rows < 1 || rows * lanes_per_row < 4 * (int64_t)k) return bp;
     bp.rows = rows; bp.per_wave = 0; bp.entries = rows * nseg * 64;
