@@ -6,8 +6,9 @@ PathShadowing scan (query prep -> sample -> threshold -> sliding-window scan ->
 select; for N > 1 also the RCCL all-gather of the per-shard top-k and the merge)
 with the trajectory ensemble already resident in HBM.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: spawns its N ranks itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --sweep 1,2,4,8                      (one line per N, weak-scaling efficiency on stderr)
 
 Workload (BASELINE.json configs[1], the one the metric is quoted on):
   R = 32768 trajectories per GPU x T = 4096, W = 20, horizon 20, k = 1024, one query;
@@ -56,7 +57,61 @@ def parse():
     ap.add_argument("--no-parity", action="store_true", help="skip the golden-vector check of the first result")
     ap.add_argument("--force-sharded", action="store_true",
                     help="exercise the multi-GPU code path (process group, all-gather, merge) even with one rank")
+    ap.add_argument("--filter", choices=("mx", "valu"), default="mx",
+                    help="rejection test of the scan: matrix cores (default) or vector ALUs (PSH_FLAG_FILTER_VALU; comparison runs)")
+    ap.add_argument("--no-fuse", action="store_true", help="the separate bootstrap / threshold / scan / select launches")
+    ap.add_argument("--sweep", type=str, default=None,
+                    help="comma-separated GPU counts: run each in turn, print one JSON line per N (stdout) and the "
+                         "weak-scaling efficiency against the first (stderr)")
     return ap.parse_args()
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n: int, argv: list[str]) -> int:
+    """`python bench.py --gpus N` without a launcher: run the N ranks through torch.distributed.run (one process per
+    GPU, RCCL over xGMI), exactly as the driver's own command line does.  Rank 0's JSON line passes through."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(Path(__file__).resolve())] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def sweep(counts: list[int], argv: list[str]) -> int:
+    """N = counts[0], counts[1], ... back to back; stdout: one JSON line per N; stderr: ms/step and weak-scaling
+    efficiency (value_N / (N/N0 * value_N0)) per N."""
+    import subprocess
+    rest = []
+    skip = False
+    for a in argv:                                       # drop --sweep X / --gpus X from the forwarded arguments
+        if skip:
+            skip = False
+        elif a in ("--sweep", "--gpus"):
+            skip = True
+        elif not a.startswith(("--sweep=", "--gpus=")):
+            rest.append(a)
+    lines = []
+    for n in counts:
+        res = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--gpus", str(n)] + rest, capture_output=True, text=True)
+        line = next((ln for ln in res.stdout.splitlines() if ln.startswith("{")), None)
+        if res.returncode != 0 or line is None:
+            sys.stderr.write(f"[sweep] N={n}: failed (rc {res.returncode})\n{res.stderr[-2000:]}\n")
+            return 1
+        print(line, flush=True)
+        lines.append(json.loads(line))
+    base = lines[0]
+    for j in lines:
+        eff = j["value"] / (base["value"] * j["n_gpus"] / base["n_gpus"])
+        sys.stderr.write(f"[sweep] n_gpus={j['n_gpus']} rccl_world_size={j.get('rccl_world_size')} ms_per_step={j['ms_per_step']:.4f} "
+                         f"value={j['value']:.4g} {j['unit']} weak_scaling_efficiency={eff:.3f}\n")
+    return 0
 
 
 def cpu_baseline(ds: np.ndarray, q: np.ndarray, k: int, h: int) -> dict:
@@ -80,14 +135,45 @@ def cpu_baseline(ds: np.ndarray, q: np.ndarray, k: int, h: int) -> dict:
             break
     best, med = min(times), sorted(times)[len(times) // 2]
     windows = rows * (T - W - h + 1) * nq
-    return {"value": windows / med, "unit": "windows/s", "cores": cores, "kind": "port",
-            "sample": f"{rows} of {R} rows x {nq} query of the same workload, {len(times)} passes in "
-                      f"{sum(times):.1f} s, median {med:.3f} s (best {best:.3f} s), oracle/psh_oracle.c, "
-                      f"OpenMP over rows, gcc -O3 -mavx2 -mfma"}
+    out = {"value": windows / med, "unit": "windows/s", "cores": cores, "kind": "port",
+           "sample": f"{rows} of {R} rows x {nq} query of the same workload, {len(times)} passes in "
+                     f"{sum(times):.1f} s, median {med:.3f} s (best {best:.3f} s), oracle/psh_oracle.c, "
+                     f"OpenMP over rows, gcc -O3 -mavx2 -mfma"}
+    out["torch_formulation"] = torch_cpu_baseline(ds, q, k, h)
+    return out
+
+
+def torch_cpu_baseline(ds: np.ndarray, q: np.ndarray, k: int, h: int) -> dict:
+    """SURVEY 8d's second CPU figure: the torch expression of the same math -- what the reference executes with
+    cuda=False (conv1d with the one-hot kernel, broadcast norm, topk, running merge; here the package's own
+    generic path, PathShadowing._generic_scan) -- on a bounded row sample, all of torch's intra-op threads."""
+    import shadowing_amd as sa
+    R, _, T = ds.shape
+    W = q.shape[-1]
+    rows = min(R, 2048)
+    obj = sa.PathShadowing(sa.Identity(W), sa.RelativeMSE(), ds[:rows], sa.PredictionContext(h))
+    x = torch.tensor(q[:1])[:, None, :]
+    y = torch.as_tensor(ds[:rows])
+    kk = min(k, rows * (T - W - h + 1))
+    obj._generic_scan(x, y, kk, 16, False)                 # warm-up
+    times = []
+    t_start = time.perf_counter()
+    while time.perf_counter() - t_start < 5.0 and len(times) < 20:
+        t0 = time.perf_counter()
+        obj._generic_scan(x, y, kk, 16, False)
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(rows * (T - W - h + 1) / med, 1), "unit": "windows/s", "threads": torch.get_num_threads(),
+            "sample": f"{rows} of {R} rows x 1 query, 16 splits, {len(times)} passes, median {med:.3f} s; "
+                      f"shadowing_amd.PathShadowing._generic_scan (the reference's formulation in torch ops), cuda=False"}
 
 
 def main():
     args = parse()
+    if args.sweep:
+        raise SystemExit(sweep([int(c) for c in args.sweep.split(",")], sys.argv[1:]))
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     # stdout carries ONE line, the JSON: anything a native library prints there (RCCL writes a five-line version banner
     # to stdout when a communicator goes away) is sent to stderr instead
     json_fd = os.dup(1)
@@ -96,9 +182,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("for --gpus N > 1 launch with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -116,6 +203,7 @@ def main():
 
     R, T, W, h, k, B = args.rows_per_gpu, args.T, args.W, args.horizon, args.k, args.queries
     Tp = T - W - h + 1
+    flags = (_native.FLAG_FILTER_VALU if args.filter == "valu" else 0) | (_native.FLAG_NO_FUSE if args.no_fuse else 0)
     # per-rank block of the ensemble: block g is dataset(R, T, seed=g); rank 0's block at
     # the default sizes is exactly the dataset of tests/golden/cfg2_R32768.npz
     ds_host = syn.dataset(R, T, seed=rank)
@@ -149,7 +237,7 @@ def main():
             pending.append(nxt)
             return out
         ev = ev_pairs[i] if i is not None else None
-        d, idx, st = _native.scan_topk(ds[:, 0, :], q, k, h=h, workspace=ws, scan_events=ev)
+        d, idx, st = _native.scan_topk(ds[:, 0, :], q, k, h=h, workspace=ws, scan_events=ev, flags=flags)
         statuses.append(st)
         return d, idx
 
@@ -172,6 +260,18 @@ def main():
                           and {tuple(v) for v in i0.cpu().numpy()[0]} == {tuple(v) for v in g["idx"][0]})
             if not parity:
                 raise SystemExit("PARITY FAILURE against tests/golden/cfg2_R32768.npz")
+    parity_oracle = None
+    if world == 1 and not args.no_parity and B > 1:
+        # a batch: the first result of the run against the CPU oracle on a subset of the queries spread over the
+        # query chunks of the batched scan (first, around the chunk boundary, last)
+        import oracle
+        oracle.build()
+        sel = sorted({0, min(111, B - 1), min(112, B - 1), B // 2, B - 1})
+        od, oi = oracle.scan_topk(ds_host, q_host[sel], k, h=h)
+        got_d, got_i = d0.cpu().numpy()[sel], i0.cpu().numpy()[sel]
+        parity_oracle = bool(np.array_equal(got_d.view(np.uint32), od.view(np.uint32)) and np.array_equal(got_i, oi))
+        if not parity_oracle:
+            raise SystemExit(f"PARITY FAILURE against the oracle on queries {sel}")
 
     for _ in range(args.warmup):
         step()
@@ -202,7 +302,7 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
 
     # ---- roofline of the dominant kernel: algorithmic bytes / live-measured duration
-    mx = (W <= (33 if B == 1 else 25) and os.environ.get("PSH_FILTER") != "valu")
+    mx = (W <= (33 if B == 1 else 25) and args.filter != "valu")
     wt = "20" if W == 20 else "0"
     kernel_name = (("psh::scan_mx_kernel<%s,true>" if B == 1 else "psh::scan_mq_kernel<%s,true>") % wt
                    + " (full scan: f16 matrix-core rejection test + exact fp32 recheck)" if mx
@@ -213,23 +313,28 @@ def main():
         scan_ms = [a.elapsed_time(b) for a, b in ev_pairs]
         avg_ms = float(np.mean(scan_ms))
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, the guide's gfx950 correction): they
+        # cannot be collected inside this run (PMC passes are their own rocprofv3 runs, tools/profile_round.sh), so the
+        # figure is READ from the committed summary of those passes and labelled as such
         traffic = None
+        traffic_source = None
         tfile = REPO / "profiles" / "hbm_traffic.json"
         if tfile.exists():
             try:
                 tj = json.loads(tfile.read_text())
                 if tj.get("workload") == f"R={R},T={T},W={W},h={h},k={k},B={B}":
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)"
             except Exception:   # noqa: BLE001
                 traffic = None
         roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                    "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                    "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg_bytes,
                     "avg_launch_ms": round(avg_ms, 5), "min_launch_ms": round(float(np.min(scan_ms)), 5),
                     "launches_timed": len(scan_ms)}
     else:
         # per-GPU kernel timing is taken from one instrumented local scan on rank 0
-        _, _, _, prof = _native.scan_topk(ds[:, 0, :], q, k, h=h, workspace=ws, profile=True)
+        _, _, _, prof = _native.scan_topk(ds[:, 0, :], q, k, h=h, workspace=ws, profile=True, flags=flags | _native.FLAG_NO_FUSE)
         achieved = alg_bytes / (prof["scan_ms"] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
@@ -239,7 +344,7 @@ def main():
     stages = None
     cpu = None
     if rank == 0 and world == 1:
-        _, _, _, stages = _native.scan_topk(ds[:, 0, :], q, k, h=h, workspace=ws, profile=True)
+        _, _, _, stages = _native.scan_topk(ds[:, 0, :], q, k, h=h, workspace=ws, profile=True, flags=flags | _native.FLAG_NO_FUSE)
         stages = {key: (round(val, 5) if isinstance(val, float) else val) for key, val in stages.items()}
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(ds_host, q_host, k, h)
@@ -248,7 +353,8 @@ def main():
     if rank == 0:
         out = {
             "metric": "windows scanned/sec (k-nearest-path scan, Identity + RelativeMSE, W=20, k=1024)",
-            "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 1), "unit": "windows/s", "n_gpus": world,
+            "rccl_world_size": dist.get_world_size() if use_pg else None, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: single query, R=32768 paths/GPU x T=4096, W=20, horizon=20, k=1024"
@@ -264,6 +370,7 @@ def main():
             "achieved_hbm_GBps_whole_step": round(world * alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
             "stages_ms": stages,
             "parity_vs_reference_golden": parity,
+            "parity_vs_oracle_query_subset": parity_oracle,
         }
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_pg:

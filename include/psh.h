@@ -14,7 +14,8 @@
  * Conventions
  *   - plain C types only; every pointer marked "device" is HBM on `device`.
  *   - the caller owns every buffer (torch tensors -> data_ptr()); the library
- *     allocates nothing persistent and keeps no global state.
+ *     allocates nothing persistent, keeps no global state and reads no
+ *     environment variable.
  *   - every call only ENQUEUES work on `stream` (a hipStream_t, NULL = the
  *     default stream) and returns; the caller synchronises.
  *   - return value: PSH_OK or a negative PSH_ERR_*; nothing throws or aborts.
@@ -67,6 +68,16 @@ extern "C" {
  * orders them after the all-gather anyway; saves the ordering stage of the selection kernel).
  * Honoured by psh_scan_topk on the sampled path only. */
 #define PSH_FLAG_UNSORTED 1
+/* A/B switches of the test-suite and the tools (results are identical either way):
+ *   FILTER_VALU   the rejection test of the Identity scan on the vector ALUs instead of the matrix cores
+ *   EMBED_DENSE   psh_scan_topk_embedded: dense fma chains even when the kernel has suffix rows
+ *   ROWS_GENERIC  one-window rows (T == W + h) through the generic exhaustive path instead of rows_kernel
+ *   NO_FUSE       psh_scan_topk: the separate bootstrap / threshold / scan / select launches instead of the
+ *                 single fused launch */
+#define PSH_FLAG_FILTER_VALU  2
+#define PSH_FLAG_EMBED_DENSE  4
+#define PSH_FLAG_ROWS_GENERIC 8
+#define PSH_FLAG_NO_FUSE      16
 typedef struct psh_profile {
     int   mode;           /* in */
     int   flags;          /* in: PSH_FLAG_* */
@@ -154,13 +165,17 @@ int psh_scan_topk_exhaustive(int device, void* stream,
  * Everything else as psh_scan_topk (same workspace: psh_workspace_bytes with W = K).
  * The reference evaluates these sums in library-chosen orders, so agreement with IT is
  * to ~1e-6 relative (tested at 1e-5) with indices equal outside near-ties; agreement
- * with the oracle's restatement of the order above is bit-exact.  Requires d <= 128 and
- * d * roundup4(K) <= 8192 (the kernel matrix lives in LDS), finite data.
+ * with the oracle's restatement of the order above is bit-exact.  Requires d <= 128, K <= PSH_MAX_W and a
+ * kernel matrix that fits LDS beside the wave tiles (psh_embedded_supported: up to 64 x 256, or 39 x 252 --
+ * Foveal(1.15, 0.9, 252)), finite data, and MORE than one window per row:
+ * T == K + h returns PSH_ERR_UNSUPPORTED -- that layout is scanned as R pre-embedded points, psh_embed_rows
+ * followed by psh_scan_topk (below).
  * Kernels whose rows are one constant each on a common support from some tap onwards
  * (Foveal, also with an ImputationContext's gap; recognised on the device, K <= 256) are
- * scanned bound-then-verify over shared running sums -- same results, ~5x faster; the
- * environment variable PSH_EMBED=dense forces the dense chains (A/B tests).
+ * scanned bound-then-verify over shared running sums -- same results, ~5x faster;
+ * PSH_FLAG_EMBED_DENSE forces the dense chains (A/B tests).
  */
+int psh_embedded_supported(int d, int K);   /* 1 when a d x K kernel fits the embedded scan (LDS), else 0 */
 int psh_scan_topk_embedded(int device, void* stream,
                            const float* dataset, int64_t R, int64_t T, int64_t r_offset,
                            const float* kernel, int d, int K,
@@ -173,6 +188,18 @@ int psh_scan_topk_embedded_exhaustive(int device, void* stream,
                            const float* hx, const float* hxnorm, int B, int h, int k,
                            float* out_d, int32_t* out_idx, int32_t* out_status,
                            void* workspace, size_t workspace_bytes, psh_profile* profile);
+
+/*
+ * One-window rows behind a linear embedding (T == K + h).  The reference's embedded view (S, 1, d) is then
+ * contiguous and RelativeMSE reduces over d in the 8-lane order (path_embedding.py:129-132, path_distance.py:65),
+ * exactly what psh_scan_topk computes for rows ONE window long.  So:
+ *     psh_embed_rows(dataset R x T, kernel d x K)  ->  out R x d:  out[r][i] = sum_j kernel[i][j] * y[r][j]
+ *                                                                  (fma chain over increasing j)
+ *     psh_scan_topk(dataset = out, R, T = d, queries = hx (B x d), W = d, h = 0)      (t is 0 in every index)
+ * out: device, R x d float32, caller-owned.
+ */
+int psh_embed_rows(int device, void* stream, const float* dataset, int64_t R, int64_t T,
+                   const float* kernel, int d, int K, float* out);
 
 /*
  * Merge G sorted-or-not candidate lists per query into the k best by (d, r, t):

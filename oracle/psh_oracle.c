@@ -240,6 +240,21 @@ int psh_oracle_scan_topk(const float* dataset, int64_t R, int64_t T, int64_t r_o
  * ker: d x K row-major (unpadded; the context's zero taps are the integer h).
  * hx: B x d embedded queries.  hxnorm: B or NULL (-> psh_oracle_qnorm(hx, d)).
  */
+/* One window per row (T == K + h): the embedded view (S, 1, d) is contiguous and the
+ * numerator is reduced in the 8-lane order of psh_oracle_sumsq8 over the d coordinates,
+ * as for the Identity embedding (acc_single_window_row). */
+static inline float embedded_acc_one_window(const float* y, const float* ker, int d, int K, const float* hx) {
+    float D[4096];
+    if (d > 4096) return NAN;
+    for (int i = 0; i < d; ++i) {
+        const float* kr = ker + (int64_t)i * K;
+        float e = 0.0f;
+        for (int j = 0; j < K; ++j) e = fmaf(kr[j], y[j], e);
+        D[i] = hx[i] - e;
+    }
+    return psh_oracle_sumsq8(D, d);
+}
+
 static inline float embedded_acc(const float* y, const float* ker, int d, int K, const float* hx) {
     float acc = 0.0f;
     for (int i = 0; i < d; ++i) {
@@ -286,7 +301,7 @@ int psh_oracle_scan_topk_embedded(const float* dataset, int64_t R, int64_t T, in
                 const float* y = dataset + r * T;
                 for (int64_t t = 0; t < Tp; ++t) {
                     cand_t c;
-                    c.d = sqrtf(embedded_acc(y + t, ker, d, K, x)) / xn;
+                    c.d = sqrtf(Tp == 1 ? embedded_acc_one_window(y, ker, d, K, x) : embedded_acc(y + t, ker, d, K, x)) / xn;
                     c.r = (int32_t)(r_offset + r);
                     c.t = (int32_t)t;
                     if (hp.n < k) { if (c.d == c.d) heap_offer(&hp, c); }
@@ -326,7 +341,8 @@ int psh_oracle_all_distances_embedded(const float* dataset, int64_t R, int64_t T
 #pragma omp parallel for schedule(static)
     for (int64_t r = 0; r < R; ++r)
         for (int64_t t = 0; t < Tp; ++t)
-            out[r * Tp + t] = sqrtf(embedded_acc(dataset + r * T + t, ker, d, K, hx)) / xn;
+            out[r * Tp + t] = sqrtf(Tp == 1 ? embedded_acc_one_window(dataset + r * T, ker, d, K, hx)
+                                            : embedded_acc(dataset + r * T + t, ker, d, K, hx)) / xn;
     return 0;
 }
 

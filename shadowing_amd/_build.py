@@ -17,6 +17,7 @@ DEPS = SOURCES + [CSRC / "psh_kernels.h", CSRC / "psh_device.h", INCLUDE / "psh.
 # -ffp-contract=off: nothing may be fused or re-associated that the source does not
 # spell out -- bit-exact distances are what make the returned indices bit-exact.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
+LINK_LIBS: list[str] = []
 
 
 def hipcc_path() -> str:
@@ -26,21 +27,44 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (looked at $HIPCC, PATH and /opt/rocm/bin/hipcc)")
 
 
-def is_stale() -> bool:
-    if not LIB.exists():
+TUNING_LIB = LIBDIR / "libpsh_hip_tuning.so"     # -DPSH_TUNING: geometry overrides + device time stamps for tools/
+
+
+def source_hash() -> str:
+    """SHA-256 over the sources the library is built from (file names + contents): what `is_stale` compares --
+    modification times do not survive the copy to the GPU box, contents do."""
+    import hashlib
+    h = hashlib.sha256()
+    for p in DEPS:
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()
+
+
+def _stamp(lib: Path) -> Path:
+    return lib.with_suffix(lib.suffix + ".srchash")
+
+
+def is_stale(lib: Path | None = None) -> bool:
+    """True when `lib` is missing or was built from other sources than the ones in the tree."""
+    lib = lib or LIB
+    stamp = _stamp(lib)
+    if not lib.exists() or not stamp.exists():
         return True
-    t = LIB.stat().st_mtime
-    return any(p.stat().st_mtime > t for p in DEPS)
+    return stamp.read_text().strip() != source_hash()
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile the HIP kernels + C ABI into shadowing_amd/lib/libpsh_hip.so."""
-    if not force and not is_stale():
-        return LIB
+def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> Path:
+    """Compile the HIP kernels + C ABI into shadowing_amd/lib/libpsh_hip.so (tuning=True: the instrumented
+    libpsh_hip_tuning.so the scripts under tools/ load through PSH_LIB)."""
+    lib = TUNING_LIB if tuning else LIB
+    if not force and not is_stale(lib):
+        return lib
     LIBDIR.mkdir(exist_ok=True)
     hipcc = hipcc_path()
-    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
-    objdir = LIBDIR / "obj"
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + (["-DPSH_TUNING"] if tuning else [])
+    objdir = LIBDIR / ("obj_tuning" if tuning else "obj")
     objdir.mkdir(exist_ok=True)
 
     def compile_one(srcfile: Path) -> Path:
@@ -57,14 +81,16 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
         objs = list(pool.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *map(str, objs), "-o", str(LIB)]
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *map(str, objs), *LINK_LIBS, "-o", str(lib)]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"hipcc link failed:\n{res.stdout}\n{res.stderr}")
-    return LIB
+    _stamp(lib).write_text(source_hash() + "\n")
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force=True, verbose=True, tuning="--tuning" in sys.argv))

@@ -16,6 +16,8 @@ from . import _build
 PSH_OK = 0
 PSH_STATUS_OK, PSH_STATUS_OVERFLOW = 0, 1
 PSH_MAX_W, PSH_MAX_K, PSH_MAX_B_PER_LAUNCH = 256, 16384, 1024
+# psh_profile.flags (include/psh.h)
+FLAG_UNSORTED, FLAG_FILTER_VALU, FLAG_EMBED_DENSE, FLAG_ROWS_GENERIC, FLAG_NO_FUSE = 1, 2, 4, 8, 16
 
 
 class NativeLibraryError(RuntimeError):
@@ -37,7 +39,8 @@ class PshProfile(C.Structure):
 EXPORTS = ("psh_version", "psh_strerror", "psh_last_hip_error", "psh_workspace_bytes", "psh_query_norm",
            "psh_scan_topk", "psh_scan_topk_exhaustive", "psh_scan_topk_embedded",
            "psh_scan_topk_embedded_exhaustive", "psh_merge_workspace_bytes", "psh_merge_topk",
-           "psh_merge_topk_gathered", "psh_merge_sorted_gathered", "psh_gather_paths")
+           "psh_merge_topk_gathered", "psh_merge_sorted_gathered", "psh_gather_paths", "psh_embed_rows",
+           "psh_embedded_supported")
 
 _lib = None
 
@@ -60,6 +63,10 @@ def load() -> C.CDLL:
         raise NativeLibraryError(
             f"{path} is missing: build it with `python -m shadowing_amd._build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for cuda=True.")
+    if path == _build.LIB and _build.is_stale():
+        raise NativeLibraryError(
+            f"{path} was built from other sources than the ones in shadowing_amd/csrc (content hash differs): "
+            "rebuild it with `python -m shadowing_amd._build`")
     try:
         L = C.CDLL(str(path))
     except OSError as e:  # pragma: no cover
@@ -93,6 +100,10 @@ def load() -> C.CDLL:
     L.psh_merge_topk_gathered.argtypes = [i32, vp, vp, vp, i32, i64, i64, i32, i32, i32, vp, vp, vp, C.c_size_t]
     L.psh_merge_sorted_gathered.restype = i32
     L.psh_merge_sorted_gathered.argtypes = [i32, vp, vp, vp, i32, i64, i64, i32, i32, i32, vp, vp]
+    L.psh_embedded_supported.restype = i32
+    L.psh_embedded_supported.argtypes = [i32, i32]
+    L.psh_embed_rows.restype = i32
+    L.psh_embed_rows.argtypes = [i32, vp, vp, i64, i64, vp, i32, i32, vp]
     L.psh_gather_paths.restype = i32
     L.psh_gather_paths.argtypes = [i32, vp, vp, i64, i64, i64, i64, vp, i64, i32, vp]
     _lib = L
@@ -157,7 +168,7 @@ def query_norm(queries: torch.Tensor) -> torch.Tensor:
 def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, r_offset: int = 0,
               qnorm: torch.Tensor | None = None, workspace: Workspace | None = None,
               exhaustive: bool = False, profile: bool = False, extra_workspace_factor: float = 1.0,
-              scan_events: tuple | None = None, out: tuple | None = None, unsorted: bool = False):
+              scan_events: tuple | None = None, out: tuple | None = None, unsorted: bool = False, flags: int = 0):
     """Enqueue the scan on the current stream.
 
     dataset (R, T) float32 device, queries (B, W) float32 device.  Returns
@@ -168,7 +179,7 @@ def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, 
     once beforehand so that the handle exists) are re-recorded on the current stream
     right around the dominant scan kernel, without any synchronisation.
     `unsorted=True`: the k best come back in arbitrary order (PSH_FLAG_UNSORTED; for callers that
-    merge afterwards).
+    merge afterwards).  `flags`: further PSH_FLAG_* bits (A/B switches of tests and tools).
     """
     ds = _dev_tensor(dataset, torch.float32, "dataset")
     q = _dev_tensor(queries, torch.float32, "queries")
@@ -186,7 +197,7 @@ def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, 
         parts = [scan_topk(ds, q[i:i + PSH_MAX_B_PER_LAUNCH].contiguous(), k, h=h, r_offset=r_offset,
                            qnorm=None if qnorm is None else qnorm[i:i + PSH_MAX_B_PER_LAUNCH].contiguous(),
                            workspace=workspace, exhaustive=exhaustive, extra_workspace_factor=extra_workspace_factor,
-                           unsorted=unsorted)
+                           unsorted=unsorted, flags=flags)
                  for i in range(0, B, PSH_MAX_B_PER_LAUNCH)]
         return tuple(torch.cat([p[j] for p in parts], dim=0) for j in range(3))
     nbytes = int(workspace_bytes(R, T, B, W, h, k) * extra_workspace_factor)
@@ -210,10 +221,12 @@ def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, 
         prof.ev_scan_begin = scan_events[0].cuda_event
         prof.ev_scan_end = scan_events[1].cuda_event
     if unsorted and not exhaustive:
+        flags |= FLAG_UNSORTED
+    if flags:
         if prof is None:
             prof = PshProfile()
             prof.mode = 1                 # no events given: nothing is recorded, nothing is synchronised
-        prof.flags = 1                    # PSH_FLAG_UNSORTED
+        prof.flags = flags
     fn = load().psh_scan_topk_exhaustive if exhaustive else load().psh_scan_topk
     rc = fn(dev.index, _stream_ptr(dev), ds.data_ptr(), R, T, r_offset, q.data_ptr(),
             None if qnorm is None else qnorm.data_ptr(), B, W, h, k,
@@ -225,17 +238,19 @@ def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, 
     return out_d, out_idx, status
 
 
-PSH_EMB_MAX_D, PSH_EMB_MAX_TAPS = 128, 8192
+PSH_EMB_MAX_D = 128
 
 
 def embedding_supported(d: int, K: int) -> bool:
-    """Whether psh_scan_topk_embedded takes a (d, K) kernel (it lives in LDS)."""
-    return 0 < d <= PSH_EMB_MAX_D and 0 < K <= PSH_MAX_W and d * ((K + 3) // 4 * 4) <= PSH_EMB_MAX_TAPS
+    """Whether psh_scan_topk_embedded takes a (d, K) kernel (it lives in LDS beside the wave tiles)."""
+    if not (0 < d <= PSH_EMB_MAX_D and 0 < K <= PSH_MAX_W):
+        return False
+    return bool(load().psh_embedded_supported(int(d), int(K)))
 
 
 def scan_topk_embedded(dataset: torch.Tensor, kernel: torch.Tensor, hx: torch.Tensor, k: int, h: int = 0,
                        r_offset: int = 0, hxnorm: torch.Tensor | None = None, workspace: Workspace | None = None,
-                       exhaustive: bool = False, profile: bool = False, out: tuple | None = None):
+                       exhaustive: bool = False, profile: bool = False, out: tuple | None = None, flags: int = 0):
     """The scan behind a linear embedding: kernel (d, K) float32 device (unpadded), hx (B, d)
     embedded queries.  Same returns and conventions as scan_topk."""
     ds = _dev_tensor(dataset, torch.float32, "dataset")
@@ -254,7 +269,7 @@ def scan_topk_embedded(dataset: torch.Tensor, kernel: torch.Tensor, hx: torch.Te
     if B > PSH_MAX_B_PER_LAUNCH and not profile:
         parts = [scan_topk_embedded(ds, ker, q[i:i + PSH_MAX_B_PER_LAUNCH].contiguous(), k, h=h, r_offset=r_offset,
                                     hxnorm=None if hxnorm is None else hxnorm[i:i + PSH_MAX_B_PER_LAUNCH].contiguous(),
-                                    workspace=workspace, exhaustive=exhaustive)
+                                    workspace=workspace, exhaustive=exhaustive, flags=flags)
                  for i in range(0, B, PSH_MAX_B_PER_LAUNCH)]
         return tuple(torch.cat([p[j] for p in parts], dim=0) for j in range(3))
     ws = (workspace or Workspace(dev)).get(workspace_bytes(R, T, B, K, h, k))
@@ -271,6 +286,11 @@ def scan_topk_embedded(dataset: torch.Tensor, kernel: torch.Tensor, hx: torch.Te
     if profile:
         prof = PshProfile()
         prof.mode = 0
+    if flags:
+        if prof is None:
+            prof = PshProfile()
+            prof.mode = 1
+        prof.flags = flags
     name = "psh_scan_topk_embedded_exhaustive" if exhaustive else "psh_scan_topk_embedded"
     rc = getattr(load(), name)(dev.index, _stream_ptr(dev), ds.data_ptr(), R, T, r_offset, ker.data_ptr(), d, K,
                                q.data_ptr(), None if hxnorm is None else hxnorm.data_ptr(), B, h, k,
@@ -280,6 +300,18 @@ def scan_topk_embedded(dataset: torch.Tensor, kernel: torch.Tensor, hx: torch.Te
     if profile:
         return out_d, out_idx, status, prof.as_dict()
     return out_d, out_idx, status
+
+
+def embed_rows(dataset: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:
+    """(R, d): the embedding of the FIRST window of every row (one-window rows behind a linear embedding)."""
+    ds = _dev_tensor(dataset, torch.float32, "dataset")
+    ker = _dev_tensor(kernel, torch.float32, "kernel")
+    R, T = ds.shape
+    d, K = ker.shape
+    out = torch.empty((R, d), dtype=torch.float32, device=ds.device)
+    _check(load().psh_embed_rows(ds.device.index, _stream_ptr(ds.device), ds.data_ptr(), R, T, ker.data_ptr(), d, K,
+                                 out.data_ptr()), "psh_embed_rows")
+    return out
 
 
 def merge_topk(d_lists: torch.Tensor, idx_lists: torch.Tensor, k: int):

@@ -154,6 +154,8 @@ struct Problem {
     const float* ker;     // embedded scan: emb_d x W kernel matrix (device), else nullptr
     int emb_d;
     int qlen;             // floats per query vector handed over: W, or emb_d (pre-embedded queries)
+    bool emb_dense;       // PSH_FLAG_EMBED_DENSE
+    bool rows_generic;    // PSH_FLAG_ROWS_GENERIC
 };
 
 int check_problem(const float* dataset, int64_t R, int64_t T, int64_t r_offset, const float* queries,
@@ -175,25 +177,47 @@ int check_problem(const float* dataset, int64_t R, int64_t T, int64_t r_offset, 
     p->ker = emb_d > 0 ? ker : nullptr;
     p->emb_d = emb_d;
     p->qlen = emb_d > 0 ? emb_d : W;
+    p->emb_dense = false;
+    p->rows_generic = false;
     return PSH_OK;
 }
 
 struct Plan { int grid; int n_qgroups; int q_per_group; int tile_floats; int wide; };
 
+// Launch-geometry overrides and device-side time stamps for the scripts under tools/: compiled into the
+// tuning build only (-DPSH_TUNING, `python -m shadowing_amd._build --tuning`).  The product library reads no
+// environment variable and takes no pointer from anywhere but its arguments.
+struct Tuning { int wide_min; bool narrow; int bpc; int rows_frac; unsigned long long* dbg_times; unsigned long long* dbg_select; };
+inline Tuning tuning() {
+    Tuning t{PSH_EMB_WIDE_MIN_B, false, 0, 64, nullptr, nullptr};
+#ifdef PSH_TUNING
+    if (const char* e = getenv("PSH_EMBED_WIDE_MIN_B")) { const int v = atoi(e); if (v >= 1) t.wide_min = v; }
+    t.narrow = getenv("PSH_EMBED_NARROW") != nullptr;
+    if (const char* e = getenv("PSH_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) t.bpc = v; }
+    if (const char* e = getenv("PSH_ROWS_FRAC")) { const int v = atoi(e); if (v >= 2) t.rows_frac = v; }
+    if (const char* e = getenv("PSH_DBG_TIMES_PTR")) t.dbg_times = (unsigned long long*)strtoull(e, nullptr, 0);
+    if (const char* e = getenv("PSH_DBG_SELECT_PTR")) t.dbg_select = (unsigned long long*)strtoull(e, nullptr, 0);
+#endif
+    return t;
+}
+inline int flags_of(const psh_profile* prof) { return prof ? prof->flags : 0; }
+
 int plan_scan(int device, const Problem& p, int64_t n_rows, Plan* plan) {
     const int tile_floats = tile_floats_for(p.W);
     // embedded scan of a batch: 512-thread blocks whose waves carry 12 (suffix rows: 6) queries per evaluation of the
     // embedding (256 VGPRs, one block per CU)
-    int wide_min = PSH_EMB_WIDE_MIN_B;
-    if (const char* e = getenv("PSH_EMBED_WIDE_MIN_B")) { const int v = atoi(e); if (v >= 1) wide_min = v; }   // tuning aid
-    const bool wide = p.ker && p.B >= wide_min && getenv("PSH_EMBED_NARROW") == nullptr;
+    const Tuning tn = tuning();
+    bool wide = p.ker && p.B >= tn.wide_min && !tn.narrow;
+    // a kernel matrix too large to sit in LDS beside sixteen wave tiles (Foveal(1.15, 0.9, 252): 39 x 252) runs the
+    // 8-wave instantiation whatever the batch size
+    if (p.ker && !wide && scan_shmem_bytes(tile_floats, p.B, p.emb_d, p.W, PSH_SCAN_THREADS) > PSH_LDS_BYTES) wide = true;
     const int threads = wide ? 512 : PSH_SCAN_THREADS;
     const size_t shmem = scan_shmem_bytes(tile_floats, p.B, p.emb_d, p.W, threads);
-    if (shmem > 160 * 1024) return PSH_ERR_UNSUPPORTED;
+    if (shmem > PSH_LDS_BYTES) return PSH_ERR_UNSUPPORTED;
     int bpc = 1, ncu = 0;
     if (!wide) HIP_TRY(scan_blocks_per_cu(p.W, p.aligned, p.ker != nullptr, shmem, &bpc));
     HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
-    if (const char* e = getenv("PSH_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) bpc = v; }   // tuning aid
+    if (tn.bpc > 0) bpc = tn.bpc;
     if (bpc < 1) bpc = 1;
     if (bpc > 8) bpc = 8;
     const int nseg = (int)((p.Tp + PSH_SEG - 1) / PSH_SEG);
@@ -244,7 +268,7 @@ ScanArgs make_scan_args(const float* dataset, const float* queries, const Proble
     a.hx = p.ker ? queries : nullptr;
     a.emb_d = p.emb_d;
     a.emb_wide = plan.wide;
-    if (const char* e = getenv("PSH_EMBED")) a.emb_dense = !strcmp(e, "dense") ? 1 : 0;   // A/B aid: skip the suffix-rows fast path
+    a.emb_dense = p.emb_dense ? 1 : 0;                  // PSH_FLAG_EMBED_DENSE: skip the suffix-rows fast path (A/B tests)
     a.B = p.B;
     a.n_qgroups = plan.n_qgroups;
     a.q_per_group = plan.q_per_group;
@@ -329,7 +353,7 @@ int run_exhaustive(int device, hipStream_t s, const float* dataset, const float*
                    const Problem& p, const Workspace& w, float* out_d, int32_t* out_idx, int32_t* out_status,
                    psh_profile* prof) {
     const int64_t nseg = (p.Tp + PSH_SEG - 1) / PSH_SEG;
-    const bool rows_path = p.Tp == 1 && !p.ker && getenv("PSH_ROWS") == nullptr;   // one-window rows: a slot per row (rows_kernel)
+    const bool rows_path = p.Tp == 1 && !p.ker && !p.rows_generic;   // one-window rows: a slot per row (rows_kernel)
     const int64_t slots_per_row = rows_path ? 1 : nseg * PSH_SEG;
     if ((int64_t)w.cap < (int64_t)p.k + slots_per_row) return PSH_ERR_WORKSPACE;
     const bool stages = prof && prof->mode == PSH_PROFILE_STAGES;
@@ -425,6 +449,8 @@ static int scan_exhaustive_impl(int device, void* stream, const float* dataset, 
     Problem p;
     int rc = check_problem(dataset, R, T, r_offset, queries, B, W, h, k, out_d, out_idx, &p, ker, emb_d);
     if (rc) return rc;
+    p.emb_dense = (flags_of(profile) & PSH_FLAG_EMBED_DENSE) != 0;
+    p.rows_generic = (flags_of(profile) & PSH_FLAG_ROWS_GENERIC) != 0;
     Workspace w;
     rc = carve(workspace, workspace_bytes, B, k, boot_entries(p.R, p.Tp, k), &w);
     if (rc) return rc;
@@ -447,6 +473,7 @@ int psh_scan_topk_embedded_exhaustive(int device, void* stream, const float* dat
                                       float* out_d, int32_t* out_idx, int32_t* out_status,
                                       void* workspace, size_t workspace_bytes, psh_profile* profile) {
     if (!kernel || d <= 0) return PSH_ERR_ARG;
+    if (T == (int64_t)K + h) return PSH_ERR_UNSUPPORTED;     // one-window rows: psh_embed_rows + psh_scan_topk (see psh.h)
     return scan_exhaustive_impl(device, stream, dataset, R, T, r_offset, hx, hxnorm, B, K, h, k, kernel, d,
                                 out_d, out_idx, out_status, workspace, workspace_bytes, profile);
 }
@@ -460,6 +487,8 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     int rc = check_problem(dataset, R, T, r_offset, queries, B, W, h, k, out_d, out_idx, &p, ker, emb_d);
     if (rc) return rc;
     if (!out_status) return PSH_ERR_ARG;
+    p.emb_dense = (flags_of(profile) & PSH_FLAG_EMBED_DENSE) != 0;
+    p.rows_generic = (flags_of(profile) & PSH_FLAG_ROWS_GENERIC) != 0;
     Workspace w;
     rc = carve(workspace, workspace_bytes, B, k, boot_entries(p.R, p.Tp, k), &w);
     if (rc) return rc;
@@ -472,19 +501,18 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     // numerator uses another reduction order, handled by the exhaustive kernel only) or
     // a sample too thin to be useful: exhaustive path
     // the cheap test of the full scan runs on the matrix cores where that is implemented
-    // (PSH_FILTER=valu keeps it on the vector ALUs: comparison runs, tools/)
+    // (PSH_FLAG_FILTER_VALU keeps it on the vector ALUs: comparison runs, tools/)
     bool use_mx = !p.ker && scan_mx_supported(p.W, p.B);
     bool use_mq = !p.ker && scan_mq_supported(p.W, p.B);      // batched queries: 4 queries x 8 shifts per MFMA
-    if (const char* e = getenv("PSH_FILTER")) { if (!strcmp(e, "valu")) use_mx = use_mq = false; }
+    if (flags_of(profile) & PSH_FLAG_FILTER_VALU) use_mx = use_mq = false;
     // (half-segment mode measured for the single-query scan: bootstrap 17.4 -> 12.3 us, but tau admits twice as
     // much and the scan's exact rechecks cost 4.3 us more -- 135.7 vs 134.3 us per step; left off)
     BootPlan bp = boot_plan(p.R, p.Tp, k, false, p.ker != nullptr);
     // one-window rows (T == W + h; PathDistance.forward_topk's N pre-embedded points): rows_kernel, a row per lane.
     // Its bootstrap takes one exact value per sampled row.
-    const bool rows_path = p.Tp == 1 && !p.ker && getenv("PSH_ROWS") == nullptr;
+    const bool rows_path = p.Tp == 1 && !p.ker && !p.rows_generic;
     if (rows_path) {
-        int frac = 64;
-        if (const char* e = getenv("PSH_ROWS_FRAC")) { const int v = atoi(e); if (v >= 2) frac = v; }   // tuning aid
+        const int frac = tuning().rows_frac;
         int64_t ns = p.R / frac > 16 * (int64_t)k ? p.R / frac : 16 * (int64_t)k;
         if (ns > p.R / 2) ns = p.R / 2;
         if (ns > w.min_stride) ns = w.min_stride;
@@ -574,7 +602,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
         const int logical = PSH_SEG + p.W + 3;
         fa.tile_floats = (logical + ((logical >> 6) << 2) + 4 + 3) & ~3;
     }
-    if (const char* e = getenv("PSH_DBG_TIMES_PTR")) fa.dbg_times = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning aid
+    fa.dbg_times = tuning().dbg_times;
     if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_begin, s));
     int nblk = plan_f.grid;
     if (use_mq) {
@@ -610,10 +638,10 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     rc = tm.mark(); if (rc) return rc;                                       // 4
 
     SelectArgs se = make_select_args(p, w, out_d, out_idx, out_status, true, nblk, 0);
-    se.unsorted_ok = (profile && (profile->flags & PSH_FLAG_UNSORTED)) ? 1 : 0;
+    se.unsorted_ok = (flags_of(profile) & PSH_FLAG_UNSORTED) ? 1 : 0;
     se.bcount2 = (use_mx && rank2 > 0) ? w.bcount2 : nullptr;
     if (use_mx && rank2 > 0) { se.dataset = dataset; se.queries = queries; se.T = p.T; se.r_offset = p.r_offset; se.W = p.W; }
-    if (const char* e = getenv("PSH_DBG_SELECT_PTR")) se.dbg_times = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning aid
+    se.dbg_times = tuning().dbg_select;
     HIP_TRY(launch_select(se, B, s));
     rc = tm.mark(); if (rc) return rc;                                       // 5
 
@@ -648,6 +676,7 @@ int psh_scan_topk_embedded(int device, void* stream, const float* dataset, int64
                            float* out_d, int32_t* out_idx, int32_t* out_status,
                            void* workspace, size_t workspace_bytes, psh_profile* profile) {
     if (!kernel || d <= 0) return PSH_ERR_ARG;
+    if (T == (int64_t)K + h) return PSH_ERR_UNSUPPORTED;     // one-window rows: psh_embed_rows + psh_scan_topk (see psh.h)
     return scan_topk_impl(device, stream, dataset, R, T, r_offset, hx, hxnorm, B, K, h, k, kernel, d,
                           out_d, out_idx, out_status, workspace, workspace_bytes, profile);
 }
@@ -731,6 +760,21 @@ int psh_merge_sorted_gathered(int device, void* stream, const float* d_gathered,
     if (!g.ok) { snprintf(g_hip_err, sizeof(g_hip_err), "hipSetDevice(%d) failed", device); return PSH_ERR_HIP; }
     MergeSortedArgs m{d_gathered, (const int2*)idx_gathered, rank_stride, rank_stride_idx, G, k_in, k, out_d, out_idx};
     HIP_TRY(launch_merge_sorted(m, B, (hipStream_t)stream));
+    return PSH_OK;
+}
+
+int psh_embedded_supported(int d, int K) {
+    if (d <= 0 || K <= 0 || d > PSH_EMB_MAX_D || K > PSH_MAX_W || (int64_t)d * ((K + 3) & ~3) > PSH_EMB_MAX_TAPS) return 0;
+    return scan_shmem_bytes(tile_floats_for(K), PSH_MAX_B_PER_LAUNCH, d, K, 512) <= PSH_LDS_BYTES ? 1 : 0;
+}
+
+int psh_embed_rows(int device, void* stream, const float* dataset, int64_t R, int64_t T,
+                   const float* kernel, int d, int K, float* out) {
+    if (!dataset || !kernel || !out || R <= 0 || T <= 0 || d <= 0 || K <= 0 || K > T) return PSH_ERR_ARG;
+    if (d > PSH_EMB_MAX_D || (int64_t)d * ((K + 3) & ~3) > PSH_EMB_MAX_TAPS) return PSH_ERR_UNSUPPORTED;
+    DeviceGuard g(device);
+    if (!g.ok) { snprintf(g_hip_err, sizeof(g_hip_err), "hipSetDevice(%d) failed", device); return PSH_ERR_HIP; }
+    HIP_TRY(launch_embed_rows(dataset, R, T, kernel, d, K, out, (hipStream_t)stream));
     return PSH_OK;
 }
 

@@ -838,6 +838,42 @@ hipError_t embed_blocks_per_cu(bool aligned, size_t shmem, int* out) {
     return e;
 }
 
+// ----------------------------------------------------------------------------------
+// embedding of the FIRST window of every row: out[r][i] = sum_j ker[i][j] * y[r][j], fma chain over increasing j
+// (all K taps, zeros included: the oracle's embedded_acc_one_window).  One-window rows behind a linear embedding
+// (T == K + h) are embedded once with this and then scanned as N pre-embedded points by rows_kernel, whose numerator is
+// the contiguous 8-lane reduce the reference uses for that layout (path_embedding.py:129-132, path_distance.py:65).
+// ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict__ dataset, int64_t R, int64_t T,
+                                                         const float* __restrict__ ker, int d, int K, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float kerS[];          // d x K
+    for (int e = (int)threadIdx.x; e < d * K; e += 256) kerS[e] = ker[e];
+    __syncthreads();
+    const int64_t n = R * (int64_t)d;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / d;
+        const int i = (int)(e - r * d);
+        const float* y = dataset + r * T;
+        const float* kr = kerS + (size_t)i * K;
+        float acc = 0.0f;
+        for (int j = 0; j < K; ++j) acc = __builtin_fmaf(kr[j], y[j], acc);
+        out[e] = acc;
+    }
+}
+
+hipError_t launch_embed_rows(const float* dataset, int64_t R, int64_t T, const float* ker, int d, int K, float* out, hipStream_t s) {
+    const size_t shmem = (size_t)d * K * sizeof(float);
+    if (shmem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)embed_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    int64_t grid = (R * d + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(embed_rows_kernel, dim3((unsigned)grid), dim3(256), shmem, s, dataset, R, T, ker, d, K, out);
+    return hipGetLastError();
+}
+
 size_t rows_shmem_bytes(int ds, int B) {      // ds: LDS floats per row
     return (size_t)(PSH_ROWS_THREADS / 64) * 64 * (ds + 1) * sizeof(float) + (size_t)((B + 3) & ~3) * sizeof(int)
            + (size_t)(PSH_ROWS_THREADS / 64) * PSH_PEND * 16;

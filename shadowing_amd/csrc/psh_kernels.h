@@ -86,7 +86,9 @@ struct ScanArgs {
 };
 
 #define PSH_EMB_MAX_D 128            // embedding rows handled natively
-#define PSH_EMB_MAX_TAPS 8192        // emb_d * roundup4(K) floats of LDS for the kernel matrix
+#define PSH_EMB_MAX_TAPS 16384       // emb_d * roundup4(K) floats of LDS for the kernel matrix (what fits is decided by
+                                     // the launch plan: psh_embedded_supported)
+#define PSH_LDS_BYTES (160 * 1024)   // LDS per CU (gfx950)
 
 struct ThresholdArgs {
     const float* minbuf;
@@ -186,5 +188,6 @@ hipError_t launch_merge_sorted(const MergeSortedArgs& a, int B, hipStream_t s); 
 hipError_t launch_rows(ScanArgs a, int mode, int grid, hipStream_t s);     // one-window rows (T == W + h): BOOT / FILTER
 size_t rows_shmem_bytes(int ds, int B);
 hipError_t launch_gather(const GatherArgs& a, hipStream_t s);
+hipError_t launch_embed_rows(const float* dataset, int64_t R, int64_t T, const float* ker, int d, int K, float* out, hipStream_t s);
 
 }  // namespace psh

@@ -85,9 +85,6 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
     };
 
     if (a.dbg_times && lane == 0) a.dbg_times[2 * gw] = wall_clock64();
-#ifdef PSH_PHASE_TIMING
-    unsigned long long ph[5] = {0, 0, 0, 0, 0};
-#endif
     Stage st;
     unsigned u = grab();
     // unit -> (query group, row index, segment)
@@ -109,11 +106,6 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
         const int64_t row = a.row0 + (int64_t)ri * a.row_stride;
         const int seg_start = (int)sg * PSH_SEG;
 
-#ifdef PSH_PHASE_TIMING
-        const unsigned long long tp0 = __builtin_readcyclecounter();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long tp1 = __builtin_readcyclecounter();
-#endif
         stage_store(st, tile, nfloat, lane);
         if (MODE == PSH_MODE_BOOT && a.blockmax) {
             const int nq = (nfloat + 3) >> 2;
@@ -124,10 +116,6 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
                                  fmaxf(fabsf(st.v[q][2]), fabsf(st.v[q][3])));
         }
         wave_lds_fence();
-#ifdef PSH_PHASE_TIMING
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const unsigned long long tp2 = __builtin_readcyclecounter();
-#endif
         if (MODE == PSH_MODE_FILTER && npend > 0) {   // last iteration's admissions, ahead of the prefetch
             pend_flush(pend, npend, lcount, a, lane);
             npend = 0;
@@ -136,11 +124,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
         {   // prefetch the next unit of this wave while this one is computed.  (Spreading
             // these five loads over the arithmetic through a hook was tried: +6 % time --
             // the extra live ranges cost a spill at the 128-VGPR cap.)
-#if defined(PSH_ABL) && (PSH_ABL == 1)
-            if (false) {                                   // ablation 1: no HBM traffic after the first segment
-#else
             if (un < u_hi) {
-#endif
                 unsigned rsn, rin, sgn, qgn;
                 decode(un, rsn, rin, sgn, qgn);
                 const int64_t rown = a.row0 + (int64_t)rin * a.row_stride;
@@ -148,9 +132,6 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
             }
         }
 
-#ifdef PSH_PHASE_TIMING
-        const unsigned long long tp3 = __builtin_readcyclecounter();
-#endif
         const int t_lane = seg_start + PSH_L * lane;           // first window of this lane
         int nvalid = a.Tp - t_lane;                             // admissible windows of this lane
         nvalid = nvalid < 0 ? 0 : (nvalid > PSH_L ? PSH_L : nvalid);
@@ -175,13 +156,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
                 float xv[WX];                              // the query taps as VGPRs (see corr8)
 #pragma unroll
                 for (int j = 0; j < WX; ++j) { xv[j] = x[j]; asm volatile("" : "+v"(xv[j])); }
-#if defined(PSH_ABL) && (PSH_ABL == 2)
-                NY = tile[lds_pad(PSH_L * lane)];                          // ablation 2: no arithmetic
-#pragma unroll
-                for (int i = 0; i < PSH_L; ++i) acc[i] = 1e30f;
-#else
                 approx16<WX>(tile, lane, xv, acc, NY);     // acc[] holds t_i = ny_i - 2 c_i here
-#endif
                 if (MODE == PSH_MODE_BOOT) {
                     // acc_i <= (nx + t_i + 2^-17 (nx + NY)) (1 + 2^-19): add nx (1 + 2^-16) + 2^-16 NY, both rounded
                     // up generously; the query state is not set up yet (that happens in the threshold kernel)
@@ -272,17 +247,8 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
             }
         }
         wave_lds_fence();  // all lanes done with the tile before it is overwritten
-#ifdef PSH_PHASE_TIMING
-        {
-            const unsigned long long tp4 = __builtin_readcyclecounter();
-            ph[0] += tp1 - tp0; ph[1] += tp2 - tp1; ph[2] += tp3 - tp2; ph[3] += tp4 - tp3; ph[4] += 1;
-        }
-#endif
         u = un;
     }
-#ifdef PSH_PHASE_TIMING
-    if (a.dbg_times && lane == 0) for (int i = 0; i < 5; ++i) a.dbg_times[2 * 8192 + 5 * gw + i] = ph[i];
-#endif
     if (a.dbg_times && lane == 0) a.dbg_times[2 * gw + 1] = wall_clock64();
     if (MODE == PSH_MODE_FILTER) {
         if (npend > 0) pend_flush(pend, npend, lcount, a, lane);

@@ -95,6 +95,7 @@ class ShardedPathShadowing:
             ds = ds[:, None, :]
         if ds.dim() != 3 or ds.shape[1] != 1:
             raise ValueError("local_dataset must be (R_local, 1, T) or (R_local, T)")
+        self._n_global = None       # windows of the whole ensemble (summed over the ranks on first use)
         if local_topk is None:   # production: resident in this rank's HBM
             if device is None:
                 if not torch.cuda.is_available():
@@ -114,13 +115,35 @@ class ShardedPathShadowing:
     def world_size(self) -> int:
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
+    def n_windows_global(self) -> int:
+        """Admissible windows of the whole (sharded) ensemble: one all-reduce, once."""
+        if self._n_global is None:
+            h = self.context.get_out_times()
+            R_local, _, T = self.dataset.shape
+            n = R_local * max(T - self.embedding.kernel.shape[-1] - h + 1, 0)
+            if self.world_size > 1:
+                t = torch.tensor([n], dtype=torch.int64, device=self.device)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                n = int(t.item())
+            self._n_global = n
+        return self._n_global
+
     def local_scan(self, q: torch.Tensor, k: int, out=None, check: bool = True, unsorted: bool = False):
         """This rank's candidates: (d (B,k), idx (B,k,2), status) with global row numbers,
         padded with (+inf, -1) when the shard holds fewer than k windows."""
         h = self.context.get_out_times()
         R_local, _, T = self.dataset.shape
-        n_local = R_local * (T - self.embedding.kernel.shape[-1] - h + 1)
+        n_local = R_local * max(T - self.embedding.kernel.shape[-1] - h + 1, 0)
         k_local = min(k, n_local)
+        if k_local == 0:                            # an empty shard (fewer rows than ranks): pure padding
+            B = q.shape[0]
+            d = torch.full((B, k), float("inf"), dtype=torch.float32, device=self.device)
+            idx = torch.full((B, k, 2), -1, dtype=torch.int32, device=self.device)
+            if out is not None:
+                out[0].copy_(d)
+                out[1].copy_(idx)
+                d, idx = out
+            return d, idx, torch.zeros((B,), dtype=torch.int32, device=self.device)
         if self._local_topk is not None:            # CPU test path (oracle injected)
             d, idx = self._local_topk(self.dataset[:, 0, :], q, k_local, h, self.row_offset)
             status = None
@@ -161,6 +184,9 @@ class ShardedPathShadowing:
         q = queries.to(self.device, dtype=torch.float32).contiguous()
         B = q.shape[0]
         G = self.world_size
+        if k > self.n_windows_global():
+            # the reference fails inside torch.topk with this exception type (path_shadowing.py:165)
+            raise RuntimeError("selected index k out of range")
         exchange = G > 1 or self.always_exchange
         native = self._local_topk is None and self._merge is None
         if native and (B * k) % 2 == 0:

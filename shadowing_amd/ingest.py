@@ -82,6 +82,9 @@ def load_batches(dirpath, device: torch.device | str | None = None, shard: tuple
     stage = [torch.empty((min(chunk_rows, max(n, 1)), C, T), dtype=torch.float32, pin_memory=True) for _ in range(2)]
     done = [torch.cuda.Event(), torch.cuda.Event()]
     side = torch.cuda.Stream(device=dev)
+    # `out` may be a block the caching allocator recycled from work still queued on the current stream: the copies
+    # on the side stream start after it
+    side.wait_stream(torch.cuda.current_stream(dev))
     for i, a in enumerate(range(lo, hi, chunk_rows)):
         b = min(hi, a + chunk_rows)
         buf = stage[i & 1]

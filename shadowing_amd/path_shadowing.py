@@ -24,6 +24,8 @@ the generic torch formulation on the host.
 from __future__ import annotations
 
 import contextlib
+import warnings
+import weakref
 from pathlib import Path
 from typing import Callable
 
@@ -95,19 +97,31 @@ class PathShadowing:
     """
 
     def __init__(self, embedding: PathEmbedding, distance: PathDistance,
-                 dataset, context: ContextManagerBase | None = None):
+                 dataset, context: ContextManagerBase | None = None, cache: bool | str = "auto"):
+        """`cache` governs the copy of the ensemble kept in HBM for cuda=True (the reference re-reads and
+        re-uploads `dataset` on every call, ref :205, :154-155):
+          "auto" (default)  kept only when staleness is detectable or impossible: a torch tensor (CUDA: used in
+                            place; CPU: keyed on its version counter, which in-place torch ops bump) or a
+                            read-only numpy array; a WRITEABLE numpy array is uploaded on every call, exactly
+                            as the reference does, so an in-place edit is never missed;
+          True              kept for any dataset until `refresh()` -- the caller promises to call it after
+                            editing the array in place (8.5 ms per call saved at R = 32768 x T = 4096);
+          False             never kept."""
         if isinstance(dataset, Path) or hasattr(dataset, "load"):
             dataset = self._load_with_scatspectra(dataset)
+        if cache not in (True, False, "auto"):
+            raise ValueError('cache must be True, False or "auto"')
         self.dataset = dataset
         self.embedding = embedding
         self.distance = distance
         self.context = context or PredictionContext(horizon=None)
-        self._host = None           # (key, float32 torch wrapper of a numpy ensemble)
-        self._host_gen = 0
-        self._resident = None       # (key, device tensor (R, C, T)) -- the ensemble in HBM
+        self.cache = cache
+        self._resident = None       # (key, device tensor (R, C, T), weakref to the host tensor) -- the ensemble in HBM
         self._scan_rows = None      # (key, device tensor (R, T)): channel 0 of a multi-channel ensemble
+        self._gen = 0               # bumped by refresh()
         self._workspace = None
         self.last_profile = None
+        self.last_path = None       # "hip" / "torch": which implementation served the last shadow() / predict()
 
     @staticmethod
     def _load_with_scatspectra(dataset):
@@ -129,29 +143,36 @@ class PathShadowing:
         return dataset
 
     def _dataset_tensor(self) -> torch.Tensor:
-        """The ensemble as a float32 (R, C, T) torch tensor.  The reference converts (copies) the whole array on
-        every call (ref :205: 0.5 GB per call at R = 32768); here a numpy ensemble is wrapped once, without a copy
-        when it already is contiguous float32, and the wrapper -- hence the copy resident in HBM, which is keyed
-        on it -- is kept while the array is the same object with the same contents.  "Same contents" is checked
-        on a strided sample of 4096 values, enough to notice an in-place refresh of the ensemble; after a surgical
-        in-place edit call `refresh()`."""
+        """The ensemble as a float32 (R, C, T) torch tensor, read afresh on every call like the reference
+        (ref :205) -- nothing converted is kept on the host.  A contiguous float32 numpy array is wrapped
+        without a copy (the reference copies 0.5 GB per call at R = 32768); any other dtype / layout is
+        converted per call."""
         ds = self.dataset
         if isinstance(ds, torch.Tensor):
             return _dim_array(ds)
-        arr = np.asarray(ds)
-        flat = arr.reshape(-1)
-        probe = flat[:: max(1, flat.size // 4096)][:4096]
-        key = (id(ds), arr.shape, arr.dtype.str, arr.__array_interface__["data"][0],
-               float(np.sum(probe, dtype=np.float64)), float(np.sum(np.abs(probe), dtype=np.float64)))
-        if self._host is None or self._host[0] != key:
-            self._host = (key, torch.as_tensor(np.ascontiguousarray(_dim_array(arr), dtype=np.float32)))
-            self._host_gen += 1                       # the HBM copy is keyed on this too
-        return self._host[1]
+        arr = _dim_array(np.asarray(ds))
+        if arr.dtype == np.float32 and arr.flags.c_contiguous:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", UserWarning)   # a read-only array is wrapped as is: nothing here writes to it
+                return torch.as_tensor(arr)
+        return torch.as_tensor(np.ascontiguousarray(arr, dtype=np.float32))
 
     def refresh(self) -> None:
-        """Forget the cached views of `dataset` (host wrapper, HBM copy): call after editing it in place."""
-        self._host = self._resident = self._scan_rows = None
-        self._host_gen += 1
+        """Forget the copy of `dataset` resident in HBM: call after editing the array in place when the object
+        was built with cache=True (with cache="auto" a writeable numpy array is re-read on every call anyway)."""
+        self._resident = self._scan_rows = None
+        self._gen += 1
+
+    def _may_keep_resident(self) -> bool:
+        if self.cache is True:
+            return True
+        if self.cache is False:
+            return False
+        ds = self.dataset
+        if isinstance(ds, torch.Tensor):
+            return True                               # keyed on the tensor's version counter
+        arr = np.asarray(ds)
+        return not arr.flags.writeable
 
     # ------------------------------------------------------------------ native path
     def _native_kind(self, x: torch.Tensor, y: torch.Tensor, k: int) -> str | None:
@@ -211,9 +232,21 @@ class PathShadowing:
         host storage (the reference re-uploads every split on every call, ref :154-155)."""
         if y.is_cuda:
             return y.contiguous()
-        key = (y.data_ptr(), tuple(y.shape), y._version, device, self._host_gen)
-        if self._resident is None or self._resident[0] != key:
-            self._resident = (key, y.contiguous().to(device, non_blocking=False))
+        if not self._may_keep_resident():
+            self._resident = self._scan_rows = None
+            return y.contiguous().to(device, non_blocking=False)
+        # keyed on the host storage AND the identity of what owns it: for a torch dataset the tensor object itself
+        # (a weak reference: an address the allocator reuses for another tensor is not a match), for a numpy
+        # dataset the array object
+        owner = self.dataset
+        key = (y.data_ptr(), tuple(y.shape), y._version if isinstance(owner, torch.Tensor) else 0, device, self._gen)
+        hit = (self._resident is not None and self._resident[0] == key and self._resident[2]() is owner)
+        if not hit:
+            try:
+                ref = weakref.ref(owner)
+            except TypeError:                         # (a list: no weak references; cache=True only)
+                ref = (lambda o=owner: o)
+            self._resident = (key, y.contiguous().to(device, non_blocking=False), ref)
             self._scan_rows = None
         return self._resident[1]
 
@@ -223,8 +256,8 @@ class PathShadowing:
         if ds.shape[1] == 1:
             return ds[:, 0, :]
         key = (ds.data_ptr(), tuple(ds.shape), ds._version)
-        if self._scan_rows is None or self._scan_rows[0] != key:
-            self._scan_rows = (key, ds[:, 0, :].contiguous())
+        if self._scan_rows is None or self._scan_rows[0] != key or self._scan_rows[2]() is not ds:
+            self._scan_rows = (key, ds[:, 0, :].contiguous(), weakref.ref(ds))
         return self._scan_rows[1]
 
     def _native_scan(self, x: torch.Tensor, y: torch.Tensor, k: int):
@@ -254,10 +287,20 @@ class PathShadowing:
             else:
                 ker2 = ker[:, 0, :].contiguous().to(dev)
 
-            def scan(sel, exhaustive):
-                q = hx if sel is None else hx[sel].contiguous()
-                return _native.scan_topk_embedded(rows, ker2, q, k, h=h, workspace=self._workspace,
-                                                  exhaustive=exhaustive)
+            if rows.shape[-1] == ker2.shape[-1] + h:
+                # ONE window per row: the reference's embedded view (S, 1, d) is contiguous and its distance the
+                # 8-lane reduce over d (ref path_embedding.py:129-132, path_distance.py:65) -- embed every row once,
+                # then scan R pre-embedded points (rows one window long): psh_embed_rows + psh_scan_topk
+                points = _native.embed_rows(rows.contiguous(), ker2)
+
+                def scan(sel, exhaustive):
+                    q = hx if sel is None else hx[sel].contiguous()
+                    return _native.scan_topk(points, q, k, h=0, workspace=self._workspace, exhaustive=exhaustive)
+            else:
+                def scan(sel, exhaustive):
+                    q = hx if sel is None else hx[sel].contiguous()
+                    return _native.scan_topk_embedded(rows, ker2, q, k, h=h, workspace=self._workspace,
+                                                      exhaustive=exhaustive)
         else:
             xq = x[:, 0, :].contiguous().to(dev)
 
@@ -375,53 +418,48 @@ class PathShadowing:
 
     def _predict_on_device(self, x: torch.Tensor, y: torch.Tensor, k: int, to_predict: Callable,
                            proba_name: str, eta: float | None):
-        """shadow() + predict_from_paths() without leaving the GPU: the k paths of every query (74 MB for the
-        tutorial's call) stay in HBM, `to_predict` runs on the device tensor of their out-context, the weighted
-        moments are reduced there, and only the (B, ...) results travel.  Returns None when this cannot be done
-        faithfully -- `to_predict` does not take torch tensors (a numpy-only callable), or the averaging classes
-        are the real scatspectra ones, whose arithmetic is not restated here -- and the caller takes the host path."""
-        if HAVE_SCATSPECTRA or proba_name not in ("uniform", "softmax"):
-            return None
+        """shadow() + predict_from_paths() with the PATHS kept on the GPU: the k paths of every query (74 MB for
+        the tutorial's call) stay in HBM and `to_predict` is evaluated there on the device tensor of their
+        out-context; what crosses PCIe are the (B, k) distances and the (B, k, ...) statistic -- a few hundred KB.
+        The averaging itself is the installed DiscreteProba's own `avg` / `std` on those host arrays (ref :245-252):
+        scatspectra's classes when that package is importable, the stand-ins of averaging.py otherwise -- no
+        formula of theirs is restated here.  Only called when the caller opted in (see predict())."""
         d, idx, ds = self._native_scan(x, y, k)
         paths = _native.gather_paths(ds, idx, x.shape[-1] + self.context.get_out_times())
-        try:
-            values = to_predict(self.context.select_out_context(paths))
-        except Exception:  # noqa: BLE001 -- a callable written for numpy arrays
-            return None
-        if not (isinstance(values, torch.Tensor) and values.is_cuda and values.dim() >= 2 and values.shape[:2] == d.shape):
-            return None
+        values = to_predict(self.context.select_out_context(paths))
+        if not (isinstance(values, torch.Tensor) and values.dim() >= 2 and tuple(values.shape[:2]) == tuple(d.shape)):
+            raise TypeError("device_predict: to_predict must map the (B, k, C, h) torch tensor of out-context paths to a "
+                            f"torch tensor (B, k, ...); got {type(values).__name__}"
+                            f"{tuple(getattr(values, 'shape', ()))}")
         self.last_path = "hip"
-        v = values.to(torch.float64)
-        if proba_name == "uniform" or eta is None:        # the stand-in classes of averaging.py, same formulas
-            w = torch.full(d.shape, 1.0 / d.shape[1], dtype=torch.float64, device=d.device)
-        else:
-            z = -(d.to(torch.float64) ** 2) / (2.0 * float(eta) ** 2)
-            w = torch.exp(z - z.max(dim=1, keepdim=True).values)
-            w = w / w.sum(dim=1, keepdim=True)
-        w = w.reshape(w.shape + (1,) * (v.dim() - 2))
-        mean = (w * v).sum(dim=1)
-        std = torch.sqrt((w * (v - mean.unsqueeze(1)) ** 2).sum(dim=1))
-        return self._to_host(mean, std)
+        d_host, v_host = self._to_host(d, values.contiguous()) if values.is_cuda else (d.cpu().numpy(), values.numpy())
+        proba = self.init_averaging_proba(proba_name, d_host[:, :, None], eta)
+        return proba.avg(v_host, axis=1), proba.std(v_host, axis=1)
 
     def predict(self, x_context: ArrayType, k: int, to_predict: Callable, eta: float | None = None,
                 proba_name: str = "softmax", n_dataset_splits: int = 1, n_context_splits: int = 1,
-                cuda: bool = False) -> tuple[np.ndarray, np.ndarray]:
+                cuda: bool = False, device_predict: bool | None = None) -> tuple[np.ndarray, np.ndarray]:
         """shadow() + predict_from_paths() over `n_context_splits` batches of queries (ref :256-301).
-        With cuda=True on a natively scanned configuration the whole chain runs on the device when `to_predict`
-        accepts torch tensors (`shadowing.realized_variance` does): see _predict_on_device."""
+
+        `to_predict` receives what the reference hands it: the numpy array of out-context paths.  OPT-IN, with
+        cuda=True on a natively scanned configuration: `device_predict=True` -- or a callable that declares
+        `to_predict.accepts_torch = True`, as `shadowing.realized_variance` does -- evaluates `to_predict` on the
+        device tensor instead, so the paths never leave HBM (_predict_on_device).  A numpy-style callable is NOT
+        silently given tensors: `x.std(-1)` is Bessel-corrected in torch and not in numpy."""
         x = _torch(_dim_array(x_context))
         n = x.shape[0]
         y = None
+        if device_predict is None:
+            device_predict = bool(getattr(to_predict, "accepts_torch", False))
         means, stds = [], []
         for rows in tqdm(torch.arange(n).split(n // n_context_splits)):
-            if cuda:
+            if cuda and device_predict:
                 y = self._dataset_tensor() if y is None else y
                 if self._native_ok(x[rows, ...], y, k):
                     got = self._predict_on_device(x[rows, ...], y, k, to_predict, proba_name, eta)
-                    if got is not None:
-                        means.append(got[0])
-                        stds.append(got[1])
-                        continue
+                    means.append(got[0])
+                    stds.append(got[1])
+                    continue
             d, paths, _ = self.shadow(x[rows, ...], k, n_dataset_splits, cuda)
             m, s = self.predict_from_paths(d, paths, to_predict, proba_name, eta)
             means.append(m)

@@ -18,3 +18,9 @@ def realized_variance(x, Ts, vol: bool = False):
     x = np.asarray(x)
     out = np.stack([(x[..., :T] ** 2).mean(-1) * 252 for T in Ts], axis=-1)
     return np.sqrt(out) if vol else out
+
+
+# PathShadowing.predict(cuda=True) may evaluate this statistic on the device tensor of the shadowing paths: both
+# branches above compute the same quantity (mean of squares; no ddof / median conventions that differ between the
+# two libraries)
+realized_variance.accepts_torch = True

@@ -47,6 +47,10 @@ def main():
     ap.add_argument("--embedded", action="store_true",
                     help="ONLY the linear-embedding cases (Foveal / user kernels); the Identity fixtures are left alone")
     ap.add_argument("--topk", action="store_true", help="ONLY the PathDistance.forward_topk cases")
+    ap.add_argument("--batched", action="store_true",
+                    help="ONLY the configs[2]-shaped cases with more queries than one query chunk of the batched scan")
+    ap.add_argument("--edge", action="store_true",
+                    help="ONLY the embedded one-window-per-row cases (T == K + h)")
     ap.add_argument("--cross", action="store_true",
                     help="ONLY the CrossChannelContext cases (multi-channel ensemble, scan on channel 0)")
     args = ap.parse_args()
@@ -117,6 +121,26 @@ def main():
                    meta=json.dumps(dict(reference_seconds=round(dt, 3), numpy=np.__version__, torch=torch.__version__)))
         np.savez_compressed(HERE / f"{name}.npz", **out)
         print(f"{name}: dataset{ds.shape} d{d.shape} idx{idx.shape} paths{paths.shape} ref {dt:.2f}s")
+
+    if args.batched:
+        # BASELINE.json configs[2] in small: more rolling query dates than one query chunk (112) of the batched scan
+        run("cfg3_rolling_B128_R256", syn.dataset(256, 1024, 60), syn.rolling_queries(128, 20, 61), 20, 20, 64, 4, False,
+            dict(gen="dataset(256,1024,60)", qgen="rolling_queries(128,20,61)"))
+        run("cfg3_rolling_B130_R1024", syn.dataset(1024, 1024, 62), syn.rolling_queries(130, 20, 63), 20, 20, 100, 16, False,
+            dict(gen="dataset(1024,1024,62)", qgen="rolling_queries(130,20,63)"))
+        return
+
+    if args.edge:
+        # one window per row behind a linear embedding (T == K + h): conv1d's output collapses to (S, 1, d) and
+        # RelativeMSE's norm becomes the contiguous reduce over d (path_embedding.py:129-132, path_distance.py:65)
+        g = torch.Generator().manual_seed(80)
+        run_embedded("foveal_one_window_rows", ref.Foveal(alpha=1.3, beta=0.8, max_context=30), syn.dataset(400, 37, 81),
+                     syn.gbm_log_returns((3, 30), 82), 7, 50, 1, True)
+        run_embedded("user_kernel_d20_one_window_rows", ref.PathEmbedding(torch.randn(20, 1, 16, generator=g)),
+                     syn.dataset(300, 16, 83), syn.gbm_log_returns((2, 16), 84), None, 40, 2, True)
+        run_embedded("user_kernel_d9_one_window_rows", ref.PathEmbedding(torch.randn(9, 1, 12, generator=g)),
+                     syn.dataset(200, 15, 85), syn.gbm_log_returns((2, 12), 86), 3, 30, 1, True)
+        return
 
     if args.topk:
         # PathDistance.forward_topk (path_distance.py:10-49) on a pre-embedded y (B2, T2, d)

@@ -62,11 +62,19 @@ def _worker(rank, world, port, R, T, W, h, k, B, tmp):
         assert pend.finish() is outs[-1]                                   # finishing twice is harmless
         for a, b in zip(serial, outs):
             assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        # k beyond the windows of the WHOLE ensemble: the reference's exception type, on every rank alike
+        n_all = R * (T - W - h + 1)
+        assert obj.n_windows_global() == n_all
+        try:
+            obj.scan(qs[0], n_all + 1)
+            raise AssertionError("k > number of windows must raise")
+        except RuntimeError:
+            pass
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("R,k", [(37, 50), (5, 300)])   # uneven shards; a shard with fewer than k windows
+@pytest.mark.parametrize("R,k", [(37, 50), (5, 300), (1, 50)])   # uneven shards; a shard with fewer than k windows; an EMPTY shard
 def test_two_rank_gloo_matches_single_process(tmp_path, oracle_mod, R, k):
     T, W, h, B = 160, 20, 20, 3
     port = 29500 + (os.getpid() % 2000) + (R % 7)

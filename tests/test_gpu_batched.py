@@ -1,0 +1,165 @@
+"""BASELINE.json configs[2] -- many query dates sharing one pass over the ensemble -- at sizes that run the
+batched scan's query chunks for real (scan_mq_kernel / boot_mq_kernel take PSH_MQ_CHUNK = 112 queries per
+blockIdx.y; one launch carries at most PSH_MAX_B_PER_LAUNCH = 1024), and the seam itself:
+PathShadowing.batched_distance(cuda=True) / shadow(cuda=True) against the reference's own outputs."""
+import numpy as np
+import pytest
+import torch
+
+from _util import SMALL_GOLDENS, assert_exact, assert_matches_reference, bits, load_golden, rows3
+from shadowing_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+BATCHED_GOLDENS = ["cfg3_rolling_B128_R256", "cfg3_rolling_B130_R1024"]
+
+
+def hip_scan(dev, ds, q, k, h, **kw):
+    from shadowing_amd import _native
+    ds_t = torch.as_tensor(np.ascontiguousarray(rows3(ds)[:, 0, :])).to(dev)
+    q_t = torch.as_tensor(np.ascontiguousarray(np.atleast_2d(q), dtype=np.float32)).to(dev)
+    out = _native.scan_topk(ds_t, q_t, k, h=h, **kw)
+    torch.cuda.synchronize(dev)
+    return out[0].cpu().numpy(), out[1].cpu().numpy(), out[2].cpu().numpy(), out[3:] and out[3]
+
+
+def resolve(dev, ds, q, k, h, d, idx, status):
+    bad = np.nonzero(status)[0]
+    if bad.size:
+        d2, idx2, _, _ = hip_scan(dev, ds, q[bad], k, h, exhaustive=True)
+        d[bad], idx[bad] = d2, idx2
+    return d, idx
+
+
+@pytest.mark.parametrize("name", BATCHED_GOLDENS)
+def test_more_queries_than_one_chunk_match_the_reference(hip_device, oracle_mod, name):
+    """128 / 130 rolling query dates (two query chunks, the second one ragged): the reference's CPU output."""
+    g = load_golden(name)
+    d, idx, status, prof = hip_scan(hip_device, g["dataset"], g["queries"], g["k"], g["h"], profile=True)
+    assert prof["path"] == 0, "the sampled path (bootstrap -> threshold -> batched scan -> select) must be the one tested"
+    d, idx = resolve(hip_device, g["dataset"], g["queries"], g["k"], g["h"], d, idx, status)
+    assert_matches_reference(d, idx, g, None, what=name)
+    od, oidx = oracle_mod.scan_topk(g["dataset"], g["queries"], g["k"], h=g["h"])
+    assert_exact(d, idx, od, oidx, name + " vs oracle")
+
+
+@pytest.mark.parametrize("B,R,T,k", [(113, 2048, 1024, 64), (225, 2048, 1024, 100), (512, 2048, 2048, 256),
+                                     (1100, 1536, 1024, 64)])
+def test_query_chunks_equal_oracle_seeded(hip_device, oracle_mod, B, R, T, k):
+    """B = 113 (one query into the second chunk), 225 (a full + a one-query chunk... of three), 512 (configs[2]'s
+    batch), 1100 (the host splits at PSH_MAX_B_PER_LAUNCH = 1024): every query bit-exact against the oracle."""
+    ds = syn.dataset(R, T, 2000 + B)
+    q = syn.rolling_queries(B, 20, 2100 + B)
+    d, idx, status, _ = hip_scan(hip_device, ds, q, k, 20)
+    assert status.shape == (B,)
+    d, idx = resolve(hip_device, ds, q, k, 20, d, idx, status)
+    od, oidx = oracle_mod.scan_topk(ds, q, k, h=20)
+    assert_exact(d, idx, od, oidx, f"B={B}")
+
+
+def test_query_chunks_with_independent_queries_and_runtime_window_length(hip_device, oracle_mod):
+    """Independent draws instead of rolling windows (no shared samples between neighbours), W = 17 (run-time
+    window length), B = 130."""
+    ds = syn.dataset(1024, 1500, 2300)
+    q = syn.gbm_log_returns((130, 17), 2301)
+    q[7] *= 30.0                                              # one loud query in the common f16 scale
+    q[120] = ds[5, 0, 200:217]                                # one exact window of the data
+    d, idx, status, prof = hip_scan(hip_device, ds, q, 77, 5, profile=True)
+    assert prof["path"] == 0
+    d, idx = resolve(hip_device, ds, q, 77, 5, d, idx, status)
+    od, oidx = oracle_mod.scan_topk(ds, q, 77, h=5)
+    assert_exact(d, idx, od, oidx, "independent queries")
+
+
+def test_configs2_full_size_properties(hip_device, oracle_mod):
+    """BASELINE configs[2] at its size: 512 rolling query dates x R = 32768 x T = 4096, k = 1024.  Size-independent
+    properties for every query (rows sorted, indices admissible and distinct, each returned distance re-derived
+    on the host in the reference's order for sampled rows) and the full oracle scan for a few queries spread over
+    the chunks (first, last of chunk 0, first of chunk 1, the ragged last chunk)."""
+    g = load_golden("cfg2_R32768")                           # the ensemble of configs[1]/[2] (SHA-256 checked)
+    ds, h, W, k = g["dataset"], g["h"], g["W"], g["k"]
+    B = 512
+    q = syn.rolling_queries(B, W, syn.QUERY_SEED)
+    d, idx, status, _ = hip_scan(hip_device, ds, q, k, h)
+    assert not status.any()
+    assert np.all(np.diff(d, axis=1) >= 0)
+    assert idx[..., 0].min() >= 0 and idx[..., 0].max() < ds.shape[0]
+    assert idx[..., 1].min() >= 0 and idx[..., 1].max() <= ds.shape[-1] - W - h
+    flat = idx[..., 0].astype(np.int64) * ds.shape[-1] + idx[..., 1]
+    assert all(len(np.unique(flat[b])) == k for b in range(B))
+    xn = oracle_mod.qnorm(q)
+    for b in range(0, B, 7):
+        for j in (0, 1, 511, 1023):
+            r, t = idx[b, j]
+            acc = np.float32(0)
+            for i in range(W):
+                D = np.float32(q[b, i] - ds[r, 0, t + i])
+                acc = np.float32(np.float64(D) * np.float64(D) + np.float64(acc))
+            assert bits(np.float32(np.sqrt(acc)) / xn[b]) == bits(d[b, j]), (b, j)
+    for b in (0, 111, 112, 300, 511):
+        od, oidx = oracle_mod.scan_topk(ds, q[b:b + 1], k, h=h)
+        assert_exact(d[b:b + 1], idx[b:b + 1], od, oidx, f"configs[2] query {b}")
+
+
+# ---- the seam: batched_distance / shadow through the reference's API ------------------------------
+@pytest.mark.parametrize("name", ["cfg1_h20", "cfg1_hNone", "multiquery_splits", "remainder_split_W12", "oddW33_h11",
+                                  "W7_h0", "self_match", "single_window_rows", "cfg3_rolling_B128_R256"])
+def test_batched_distance_cuda_matches_the_reference(hip_device, name):
+    """PathShadowing.batched_distance(x, y, k, n_splits, cuda=True) (ref path_shadowing.py:97-179): CPU torch
+    tensors, distances (B, k) float32 and indices (B, k, 2) int32 -- the reference's own output."""
+    import shadowing_amd as sa
+    g = load_golden(name)
+    ds = rows3(g["dataset"])
+    obj = sa.PathShadowing(sa.Identity(g["W"]), sa.RelativeMSE(), ds, sa.PredictionContext(horizon=g["h"]))
+    x = torch.tensor(g["queries"])[:, None, :]
+    d, idx = obj.batched_distance(x, torch.tensor(ds), g["k"], g["n_splits"], cuda=True)
+    assert isinstance(d, torch.Tensor) and not d.is_cuda and d.dtype == torch.float32 and tuple(d.shape) == g["d"].shape
+    assert not idx.is_cuda and idx.dtype == torch.int32 and tuple(idx.shape) == g["idx"].shape
+    assert_matches_reference(d.numpy(), idx.numpy(), g, None, what=name)
+
+
+@pytest.mark.parametrize("name", SMALL_GOLDENS + ["cfg3_rolling_B128_R256"])
+def test_shadow_cuda_identity_matches_the_reference_with_paths(hip_device, oracle_mod, name):
+    """PathShadowing(Identity, RelativeMSE).shadow(cuda=True) (ref :181-218): distances, indices AND the gathered
+    paths (B, k, C, W + h) against the reference's shadow(cuda=False) output."""
+    import shadowing_amd as sa
+    g = load_golden(name)
+    ds = g["dataset"]
+    obj = sa.PathShadowing(sa.Identity(g["W"]), sa.RelativeMSE(), ds, sa.PredictionContext(horizon=g["h"]))
+    d, paths, idx = obj.shadow(g["queries"] if g["queries"].shape[0] > 1 else g["queries"][0], k=g["k"],
+                               n_splits=g["n_splits"], cuda=True)
+    assert obj.last_path == "hip"
+    assert d.dtype == np.float32 and idx.dtype == np.int32 and paths.dtype == np.float32
+    assert paths.shape[:2] == g["d"].shape and paths.shape[2:] == (1, g["W"] + (g["h"] or 0))
+    assert_matches_reference(d, idx, g, None, what=name)
+    h = g["h"] or 0
+    assert np.array_equal(paths[:, :, 0, :], oracle_mod.gather_paths(rows3(ds), idx, g["W"] + h))
+    # where the order is determined (no exact ties) the paths ARE the reference's, position by position
+    if name not in ("duplicated_paths", "zero_query"):
+        same = np.all(idx == g["idx"], axis=-1)
+        n = g["paths"].shape[1]
+        assert np.array_equal(paths[:, :n][same[:, :n]], g["paths"][same[:, :n]])
+        assert same.mean() > 0.99
+
+
+def test_resident_copy_follows_edits_of_the_ensemble(hip_device):
+    """cuda=True: a writeable numpy ensemble is re-read on every call (an in-place edit of one row is seen, as in the
+    reference); a torch ensemble stays resident and is re-uploaded when its version counter moves; cache=True keeps
+    the HBM copy until refresh()."""
+    import shadowing_amd as sa
+    q = syn.gbm_log_returns((1, 20), 3100)
+    mk = lambda data, **kw: sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), data, sa.PredictionContext(5), **kw)
+    ds = syn.dataset(512, 600, 3101)
+    for data in (ds.copy(), ds.astype(np.float64), torch.tensor(ds)):
+        obj = mk(data)
+        d1, _, i1 = obj.shadow(q, k=8, cuda=True)
+        data[100, 0, 300:320] = torch.tensor(q[0]) if isinstance(data, torch.Tensor) else q[0]
+        d2, _, i2 = obj.shadow(q, k=8, cuda=True)
+        assert d1[0, 0] > 0 and d2[0, 0] == 0 and tuple(i2[0, 0]) == (100, 300)
+    kept = mk(ds.copy(), cache=True)
+    d1, _, _ = kept.shadow(q, k=8, cuda=True)
+    kept.dataset[100, 0, 300:320] = q[0]
+    assert kept.shadow(q, k=8, cuda=True)[0][0, 0] == d1[0, 0]           # by contract: stale until refresh()
+    kept.refresh()
+    assert kept.shadow(q, k=8, cuda=True)[0][0, 0] == 0
+    assert kept._resident is not None and mk(ds.copy())._resident is None

@@ -110,8 +110,8 @@ def test_embedded_exhaustive_path_equals_oracle(hip_device, oracle_mod, R, T, d,
 
 
 @pytest.mark.parametrize("kind,d,K", [("foveal", 0, 126), ("suffix", 40, 60)])
-def test_suffix_rows_fast_path_equals_the_dense_chains(hip_device, monkeypatch, kind, d, K):
-    """Foveal-like kernels take the bound-then-verify pass over running sums; PSH_EMBED=dense forces the dense
+def test_suffix_rows_fast_path_equals_the_dense_chains(hip_device, kind, d, K):
+    """Foveal-like kernels take the bound-then-verify pass over running sums; PSH_FLAG_EMBED_DENSE forces the dense
     chains.  Same bits either way -- also with non-finite samples in the ensemble (NaN is kept by the cheap test,
     an infinite segment maximum disarms it)."""
     ds, ker, hx = _case_inputs(2048, 1024, d, K, 3, kind, 31)
@@ -121,8 +121,8 @@ def test_suffix_rows_fast_path_equals_the_dense_chains(hip_device, monkeypatch, 
     ds[701, 0, 17] = -np.inf
     ds[1500, 0, 900:903] = 3.0e38
     fast = hip_scan_embedded(hip_device, ds, ker, hx, 512, 20, profile=True)
-    monkeypatch.setenv("PSH_EMBED", "dense")
-    dense = hip_scan_embedded(hip_device, ds, ker, hx, 512, 20, profile=True)
+    from shadowing_amd import _native
+    dense = hip_scan_embedded(hip_device, ds, ker, hx, 512, 20, profile=True, flags=_native.FLAG_EMBED_DENSE)
     assert np.all(fast[2] == 0) and np.all(dense[2] == 0)
     assert_exact(fast[0], fast[1], dense[0], dense[1], "suffix rows vs dense")
     # the bootstrap of the fast path hands over upper bounds (a 1e-4 relative margin): a few more candidates
@@ -178,13 +178,64 @@ def test_identity_kernel_through_the_embedded_scan_is_the_plain_scan(hip_device,
 def test_embedded_argument_errors(hip_device):
     from shadowing_amd import _native
     ds = torch.zeros((8, 600), device=hip_device)
-    hx = torch.ones((1, 64), device=hip_device)
+    hx = torch.ones((1, 128), device=hip_device)
     with pytest.raises(_native.NativeLibraryError):          # d * K over the LDS limit -> unsupported
-        _native.scan_topk_embedded(ds, torch.ones((64, 256), device=hip_device), hx, 4)
-    assert not _native.embedding_supported(64, 256) and _native.embedding_supported(34, 126)
+        _native.scan_topk_embedded(ds, torch.ones((128, 256), device=hip_device), hx, 4)
+    assert not _native.embedding_supported(128, 256) and _native.embedding_supported(34, 126)
+    assert _native.embedding_supported(64, 256) and _native.embedding_supported(39, 252)
+    with pytest.raises(_native.NativeLibraryError):          # one window per row: psh_embed_rows + psh_scan_topk instead
+        _native.scan_topk_embedded(ds, torch.ones((4, 600), device=hip_device)[:, :256].contiguous()[:, :200].contiguous(),
+                                   torch.ones((1, 4), device=hip_device), 4, h=400)
     with pytest.raises(ValueError):                           # k larger than the number of windows
         _native.scan_topk_embedded(ds, torch.ones((4, 500), device=hip_device)[:, :200].contiguous(),
                                    torch.ones((1, 4), device=hip_device), 8 * 401 + 1)
+
+
+@pytest.mark.parametrize("name", ["user_kernel_d20_one_window_rows", "user_kernel_d9_one_window_rows", "foveal_one_window_rows"])
+def test_one_window_rows_behind_a_linear_embedding(hip_device, oracle_mod, name):
+    """T == K + h: psh_embed_rows + psh_scan_topk over the R embedded points (rows_kernel: the 8-lane reduce over d
+    the reference uses for that layout) -- bit for bit the oracle; the reference itself bit for bit where its conv1d's
+    own tap order is the plain chain (the user kernels), 1e-6 with identical indices on the Foveal fixture; and the
+    same through PathShadowing.shadow(cuda=True)."""
+    from shadowing_amd import _native
+    import shadowing_amd as sa
+    g = load_golden(name)
+    ds = rows3(g["dataset"])
+    h = g["h"] or 0
+    ds_t = torch.as_tensor(np.ascontiguousarray(ds[:, 0, :])).to(hip_device)
+    ker_t = torch.as_tensor(g["kernel"]).to(hip_device)
+    points = _native.embed_rows(ds_t, ker_t)
+    d, idx, status = _native.scan_topk(points, torch.as_tensor(g["hx"]).to(hip_device), g["k"], h=0)
+    torch.cuda.synchronize()
+    assert not status.cpu().numpy().any()
+    od, oidx = oracle_mod.scan_topk_embedded(ds, g["kernel"], g["hx"], g["k"], h=h)
+    assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, name + " vs oracle")
+    obj = sa.PathShadowing(sa.PathEmbedding(torch.tensor(g["kernel"])[:, None, :]), sa.RelativeMSE(), g["dataset"],
+                           sa.PredictionContext(horizon=g["h"]))
+    d2, paths, idx2 = obj.shadow(g["queries"], k=g["k"], cuda=True)
+    assert obj.last_path == "hip"
+    assert_exact(d2, idx2, od, oidx, name + " through PathShadowing")
+    if name.startswith("user_kernel"):
+        assert_matches_reference(d2, idx2, g, None, what=name)
+    else:
+        np.testing.assert_allclose(d2, np.sort(g["d"], 1), rtol=1e-6, atol=0)
+    assert np.array_equal(paths[:, :, 0, :], oracle_mod.gather_paths(ds, idx2, g["kernel"].shape[1] + h))
+
+
+def test_kernel_matrix_larger_than_sixteen_tiles_allow(hip_device, oracle_mod):
+    """Foveal(1.15, 0.9, 252) -- 39 x 252 taps, 39 KB of LDS: runs the 8-wave instantiation of the embedded scan for
+    any batch size (it used to fall back to the generic torch path)."""
+    import shadowing_amd as sa
+    fov = sa.Foveal(alpha=1.15, beta=0.9, max_context=252)
+    assert tuple(fov.kernel.shape) == (39, 1, 252)
+    ds = syn.dataset(1024, 2048, 88)
+    x = syn.gbm_log_returns((2, 252), 89)
+    obj = sa.PathShadowing(fov, sa.RelativeMSE(), ds, sa.PredictionContext(horizon=20))
+    d, _, idx = obj.shadow(x, k=300, cuda=True)
+    assert obj.last_path == "hip"
+    hx = fov(torch.tensor(x)[:, None, :])[:, 0, :].numpy()
+    od, oidx = oracle_mod.scan_topk_embedded(ds, fov.kernel[:, 0, :].numpy(), hx, 300, h=20)
+    assert_exact(d, idx, od, oidx, "Foveal max_context 252")
 
 
 # ---- through the reference's own API -----------------------------------------------------------------
@@ -308,33 +359,60 @@ def test_path_shadowing_with_a_cross_channel_context_runs_native(hip_device, nam
     assert np.array_equal(bits(d), bits(d2)) and np.array_equal(idx, idx2)
 
 
-@pytest.mark.parametrize("proba,eta", [("softmax", 0.1), ("uniform", None)])
-def test_predict_runs_on_the_device_and_matches_the_host_chain(hip_device, monkeypatch, proba, eta):
-    """predict(cuda=True) with a torch-capable `to_predict` (shadowing.realized_variance): scan, gather, statistic
-    and weighted moments all on the GPU.  Same numbers as shadow() + predict_from_paths() on the host (float64
-    moments: 1e-9); a numpy-only callable silently takes the host chain."""
+class _KnownProba:
+    """An injected DiscreteProba whose arithmetic is known: weights 1/(1 + rank) normalised, avg = sum w x,
+    std = max |x - avg| (deliberately NOT a weighted variance: nothing on the device may assume one)."""
+
+    def __init__(self, distances):
+        self.n = distances.shape[1]
+        w = 1.0 / (1.0 + np.arange(self.n, dtype=np.float64))
+        self.w = w / w.sum()
+
+    def avg(self, x, axis=1):
+        assert isinstance(x, np.ndarray) and axis == 1
+        return np.tensordot(self.w, np.moveaxis(np.asarray(x, np.float64), 1, 0), axes=1)
+
+    def std(self, x, axis=1):
+        return np.abs(np.asarray(x, np.float64) - np.expand_dims(self.avg(x), 1)).max(axis=1)
+
+
+@pytest.mark.parametrize("proba,eta", [("softmax", 0.1), ("uniform", None), ("known", None)])
+def test_predict_keeps_the_paths_on_the_device_when_asked_to(hip_device, monkeypatch, proba, eta):
+    """predict(cuda=True, device_predict=True): scan, gather and `to_predict` on the GPU, the averaging by the
+    installed DiscreteProba's own avg / std on the (B, k, ...) statistic -- here also an injected class with known
+    arithmetic.  Same numbers as shadow() + predict_from_paths() on the host.  Without the opt-in (and without the
+    `accepts_torch` marker) a callable is handed numpy arrays, as in the reference."""
     import shadowing
     from shadowing import Foveal, PathShadowing, PredictionContext, RelativeMSE, realized_variance
     ds = syn.dataset(1024, 900, 61)
     x = syn.gbm_log_returns((5, 40), 62)
     obj = PathShadowing(Foveal(alpha=1.4, beta=0.9, max_context=40), RelativeMSE(), ds, PredictionContext(horizon=30))
+    if proba == "known":
+        monkeypatch.setattr(PathShadowing, "init_averaging_proba", staticmethod(lambda name, d, eta: _KnownProba(d)))
     Ts = [2, 7, 30]
-    to_predict = lambda p: realized_variance(p, Ts=Ts, vol=False)[:, :, 0, :]     # noqa: E731
-    seen = []
-    real = obj._predict_on_device
-    monkeypatch.setattr(obj, "_predict_on_device", lambda *a: seen.append(real(*a)) or seen[-1])
-    m, s = obj.predict(x, k=256, to_predict=to_predict, eta=eta, proba_name=proba, n_context_splits=2, cuda=True)
-    assert len(seen) == 3 and all(v is not None for v in seen)          # 5 queries in splits of 2: device chain each time
+    kinds = []
+
+    def to_predict(p):
+        kinds.append(type(p))
+        return realized_variance(p, Ts=Ts, vol=False)[:, :, 0, :]
+
+    m, s = obj.predict(x, k=256, to_predict=to_predict, eta=eta, proba_name=proba, n_context_splits=2, cuda=True,
+                       device_predict=True)
+    assert obj.last_path == "hip" and kinds and all(t is torch.Tensor for t in kinds)
     d, paths, _ = obj.shadow(x, k=256, cuda=True)
-    m0, s0 = obj.predict_from_paths(d, paths, to_predict, proba, eta)
-    assert m.shape == m0.shape == (5, 3)
-    np.testing.assert_allclose(m, m0, rtol=2e-6)                         # float32 statistic, float64 moments
+    m0, s0 = obj.predict_from_paths(d, paths, lambda p: np.asarray(to_predict(p)), proba, eta)
+    np.testing.assert_allclose(m, m0, rtol=2e-6)                         # float32 statistic on either side
     np.testing.assert_allclose(s, s0, rtol=2e-5, atol=1e-12)
-    seen.clear()
-    host_only = lambda p: np.asarray(realized_variance(np.asarray(p), Ts=Ts, vol=False))[:, :, 0, :]   # noqa: E731
-    m1, s1 = obj.predict(x, k=256, to_predict=host_only, eta=eta, proba_name=proba, cuda=True)
-    assert seen == [None]
+    # no opt-in: numpy in, as the reference does -- a torch-incompatible callable works, and gets no tensor
+    kinds.clear()
+    m1, s1 = obj.predict(x, k=256, to_predict=to_predict, eta=eta, proba_name=proba, cuda=True)
+    assert kinds and all(t is np.ndarray for t in kinds)
     np.testing.assert_allclose(m1, m0, rtol=1e-12)
+    # the marker on shadowing.realized_variance opts in by itself
+    assert getattr(realized_variance, "accepts_torch", False)
+    # and a callable that does not return a tensor under device_predict is an error, not a silent fallback
+    with pytest.raises(TypeError):
+        obj.predict(x, k=16, to_predict=lambda p: 1.0, cuda=True, device_predict=True)
 
 
 def test_reference_test_cell_1_forward_topk_prefix_consistency_on_the_device(hip_device):

@@ -282,12 +282,12 @@ def test_matrix_core_filter_is_exact_on_adversarial_data(hip_device, oracle_mod,
     assert_exact(d, idx, od, oidx, kind)
 
 
-def test_matrix_core_and_valu_filters_admit_the_same_windows(hip_device, monkeypatch):
+def test_matrix_core_and_valu_filters_admit_the_same_windows(hip_device):
     ds = syn.dataset(8192, 4096, 77)
     q = syn.single_query(20, 78)
+    from shadowing_amd import _native
     d1, i1, s1, p1 = hip_scan(hip_device, ds, q, 1024, 20, profile=True)
-    monkeypatch.setenv("PSH_FILTER", "valu")
-    d2, i2, s2, p2 = hip_scan(hip_device, ds, q, 1024, 20, profile=True)
+    d2, i2, s2, p2 = hip_scan(hip_device, ds, q, 1024, 20, profile=True, flags=_native.FLAG_FILTER_VALU)
     assert s1[0] == 0 and s2[0] == 0
     assert_exact(d1, i1, d2, i2, "mx vs valu filter")
     # same tau; the matrix-core scan files its candidates in two classes and reports the first (below the
@@ -296,10 +296,8 @@ def test_matrix_core_and_valu_filters_admit_the_same_windows(hip_device, monkeyp
 
     # batched queries: the matrix-core bootstrap bounds tau from above (a little looser), the result is the same
     q4 = syn.rolling_queries(6, 20, 79)
-    monkeypatch.delenv("PSH_FILTER")
     d3, i3, s3, p3 = hip_scan(hip_device, ds, q4, 1024, 20, profile=True)
-    monkeypatch.setenv("PSH_FILTER", "valu")
-    d4, i4, s4, p4 = hip_scan(hip_device, ds, q4, 1024, 20, profile=True)
+    d4, i4, s4, p4 = hip_scan(hip_device, ds, q4, 1024, 20, profile=True, flags=_native.FLAG_FILTER_VALU)
     assert not s3.any() and not s4.any()
     assert_exact(d3, i3, d4, i4, "mq vs valu filter")
     assert p4["n_candidates"] <= p3["n_candidates"] <= 1.5 * p4["n_candidates"]

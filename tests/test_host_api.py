@@ -165,7 +165,8 @@ def test_native_dispatch_rules():
     assert kind(sa.Identity(20)) == "identity"
     assert kind(sa.Foveal(1.15, 0.9, 126), ctx=sa.PredictionContext(252)) == "linear"
     assert kind(sa.PathEmbedding(torch.randn(5, 1, 23))) == "linear"
-    assert kind(sa.PathEmbedding(torch.randn(64, 1, 256))) is None          # 64 x 256 taps do not fit LDS
+    assert kind(sa.PathEmbedding(torch.randn(128, 1, 256))) is None         # 128 x 256 taps do not fit LDS
+    assert kind(sa.Foveal(1.15, 0.9, 252)) == "linear"                      # 39 x 252: the 8-wave instantiation
     assert _native.embedding_supported(32, 256) and not _native.embedding_supported(129, 4)
 
     class Squared(sa.PathEmbedding):
@@ -198,26 +199,36 @@ def test_native_dispatch_rules():
     assert kind(sa.Identity(20), x=torch.zeros((2, 1, 20), dtype=torch.float64)) is None
 
 
-def test_numpy_ensemble_is_wrapped_once_and_edits_are_noticed():
-    """shadow() does not copy a contiguous float32 ensemble per call (the reference does, ref :205); the cached
-    wrapper follows the array's contents: a refreshed ensemble is seen, refresh() forces it."""
-    ds = syn.dataset(32, 300, 3)
-    obj = sa.PathShadowing(sa.Identity(10), sa.RelativeMSE(), ds, sa.PredictionContext(5))
-    y1 = obj._dataset_tensor()
-    assert y1.data_ptr() == ds.__array_interface__["data"][0]              # no copy
-    assert obj._dataset_tensor() is y1
+def test_host_path_rereads_the_ensemble_on_every_call():
+    """cuda=False reads `dataset` afresh on every call, as the reference does (ref :205): nothing converted is kept,
+    so an in-place edit of ONE row -- float32 (wrapped without a copy) or float64 (converted per call) -- is seen."""
     q = syn.gbm_log_returns((1, 10), 4)
-    d1, _, i1 = obj.shadow(q, k=5)
-    ds[:] = syn.dataset(32, 300, 9)                                        # in-place refresh of the whole ensemble
-    y2 = obj._dataset_tensor()
-    assert y2 is not y1 and obj._host_gen == 2
-    d2, _, i2 = obj.shadow(q, k=5)
-    ref = sa.PathShadowing(sa.Identity(10), sa.RelativeMSE(), ds.copy(), sa.PredictionContext(5)).shadow(q, k=5)
-    assert np.array_equal(d2, ref[0]) and np.array_equal(i2, ref[2]) and not np.array_equal(d1, d2)
-    obj.refresh()
-    assert obj._dataset_tensor() is not y2
-    f64 = sa.PathShadowing(sa.Identity(10), sa.RelativeMSE(), ds.astype(np.float64), sa.PredictionContext(5))
-    assert f64._dataset_tensor().dtype == torch.float32 and np.array_equal(f64.shadow(q, k=5)[0], d2)
+    for dtype in (np.float32, np.float64):
+        ds = syn.dataset(64, 300, 3).astype(dtype)
+        obj = sa.PathShadowing(sa.Identity(10), sa.RelativeMSE(), ds, sa.PredictionContext(5))
+        if dtype == np.float32:
+            assert obj._dataset_tensor().data_ptr() == ds.__array_interface__["data"][0]      # no copy
+        d1, _, i1 = obj.shadow(q, k=5)
+        ds[40, 0, 100:110] = q[0]                                          # a surgical edit: one window of one row
+        d2, _, i2 = obj.shadow(q, k=5)
+        assert d2[0, 0] == 0.0 and tuple(i2[0, 0]) == (40, 100) and d1[0, 0] > 0.0
+    assert obj._dataset_tensor().dtype == torch.float32
+
+
+def test_resident_copy_policy():
+    """What may stay in HBM between calls (cache="auto"): a torch tensor (version counter) or a read-only array;
+    a writeable numpy array never; cache=True keeps anything until refresh(); cache=False nothing."""
+    ds = syn.dataset(8, 100, 5)
+    mk = lambda data, **kw: sa.PathShadowing(sa.Identity(10), sa.RelativeMSE(), data, sa.PredictionContext(5), **kw)
+    assert not mk(ds)._may_keep_resident()
+    ro = ds.copy(); ro.flags.writeable = False
+    assert mk(ro)._may_keep_resident() and mk(torch.tensor(ds))._may_keep_resident()
+    assert mk(ds, cache=True)._may_keep_resident() and not mk(ro, cache=False)._may_keep_resident()
+    with pytest.raises(ValueError):
+        mk(ds, cache="yes")
+    obj = mk(ro)
+    assert obj.last_path is None                                           # readable before the first call
+    assert obj._dataset_tensor().data_ptr() == ro.__array_interface__["data"][0]     # read-only arrays are wrapped too
 
 
 def test_realized_variance_takes_torch_tensors():

@@ -22,7 +22,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_st
 for f in $(find $OUT/prof_stats -name "*kernel_stats.csv"); do cp $f $OUT/kernel_stats.csv; done
 cd $R
 timeout 300 python bench.py --steps 20 --warmup 3 --queries 512 --no-cpu-baseline > $OUT/bench_n1_q512.json 2>> $OUT/bench.err
-PSH_FILTER=valu timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_n1_valu_filter.json 2>> $OUT/bench.err
+timeout 300 python bench.py --filter valu --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_n1_valu_filter.json 2>> $OUT/bench.err
 # the widened rows of the scope table: the reference's Foveal workloads, configs[4] (wavelet), forward_topk
 timeout 600 python tools/bench_foveal.py --steps 20 --generic --which tutorial testing wavelet 2>> $OUT/bench.err | grep "^{" > $OUT/bench_foveal.jsonl
 timeout 300 python tools/bench_forward_topk.py 2>> $OUT/bench.err | grep "^{" > $OUT/bench_forward_topk.jsonl

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Randomised A/B of the embedded scan on the GPU: the suffix-rows fast path against the dense chains
-(PSH_EMBED=dense), bit for bit, over random Foveal-like kernels (with and without an imputation gap), ensemble
+(PSH_FLAG_EMBED_DENSE), bit for bit, over random Foveal-like kernels (with and without an imputation gap), ensemble
 shapes (ragged segments, unaligned rows), k, horizons and batch sizes (both block-size instantiations)."""
 import os
 import sys
@@ -44,11 +44,8 @@ for case in range(n_cases):
     dsd, kd, hd = torch.tensor(ds[:, 0, :]).to(dev), torch.tensor(ker).to(dev), hx.to(dev)
     outs = []
     for mode in ("fast", "dense"):
-        if mode == "dense":
-            os.environ["PSH_EMBED"] = "dense"
-        else:
-            os.environ.pop("PSH_EMBED", None)
-        d, idx, st = _native.scan_topk_embedded(dsd, kd, hd, k, h=h)
+        fl = _native.FLAG_EMBED_DENSE if mode == "dense" else 0
+        d, idx, st = _native.scan_topk_embedded(dsd, kd, hd, k, h=h, flags=fl)
         if int(st.max()) != 0:
             d, idx, _ = _native.scan_topk_embedded(dsd, kd, hd, k, h=h, exhaustive=True)
         torch.cuda.synchronize()

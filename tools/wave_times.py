@@ -2,6 +2,8 @@ import os, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import numpy as np, torch
+from shadowing_amd import _build
+os.environ["PSH_LIB"] = str(_build.build(tuning=True))   # the instrumented build (-DPSH_TUNING): env overrides, time stamps
 from shadowing_amd import _native, synthetic as syn
 dev = torch.device("cuda", 0)
 ds = torch.as_tensor(syn.dataset(32768, 4096, 0)[:, 0, :].copy()).to(dev); q = torch.as_tensor(syn.single_query(20, 1)[None]).to(dev)
