@@ -217,7 +217,11 @@ def main():
         sharded = ShardedPathShadowing(sa.Identity(W), sa.RelativeMSE(), ds, rank * R, sa.PredictionContext(h), device=dev,
                                        always_exchange=args.force_sharded)
 
-    ev_pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # HIP events around the dominant kernel on every EV_EVERY-th timed step: an event record is a barrier packet of its own
+    # on the stream (~5 us for the pair, measured: 112 vs 101 us per step with a pair on every step), so bracketing every
+    # launch would tax the very step time the metric is
+    EV_EVERY = 4
+    ev_pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range((args.steps + EV_EVERY - 1) // EV_EVERY)]
     for a, b in ev_pairs:   # materialise the hipEvent handles
         a.record(); b.record()
     torch.cuda.synchronize()
@@ -236,7 +240,7 @@ def main():
             out = pending.pop().finish() if pending else None
             pending.append(nxt)
             return out
-        ev = ev_pairs[i] if i is not None else None
+        ev = ev_pairs[i // EV_EVERY] if (i is not None and i % EV_EVERY == 0) else None
         d, idx, st = _native.scan_topk(ds[:, 0, :], q, k, h=h, workspace=ws, scan_events=ev, flags=flags)
         statuses.append(st)
         return d, idx
@@ -304,7 +308,14 @@ def main():
     # ---- roofline of the dominant kernel: algorithmic bytes / live-measured duration
     mx = (W <= (33 if B == 1 else 25) and args.filter != "valu")
     wt = "20" if W == 20 else "0"
-    kernel_name = (("psh::scan_mx_kernel<%s,true>" if B == 1 else "psh::scan_mq_kernel<%s,true>") % wt
+    fused = mx and B == 1 and not args.no_fuse and sharded is None
+    if sharded is None:   # which path served the call (no synchronisation: the launch plan's answer)
+        info = {}
+        _native.scan_topk(ds[:, 0, :], q, k, h=h, workspace=ws, flags=flags, info=info)
+        fused = info.get("path") == 2
+    kernel_name = ("psh::scan_fused_kernel<%s,true> (the WHOLE step in one launch: bootstrap, threshold, f16 matrix-core "
+                   "rejection test + exact fp32 recheck over the ensemble, distributed selection)" % wt if fused else
+                   ("psh::scan_mx_kernel<%s,true>" if B == 1 else "psh::scan_mq_kernel<%s,true>") % wt
                    + " (full scan: f16 matrix-core rejection test + exact fp32 recheck)" if mx
                    else "psh::scan_kernel<%s,true,1> (full scan, VALU rejection test)" % wt)
     alg_bytes = R * T * 4 + B * W * 4 + B * k * 12          # one read of the ensemble + query + result
@@ -322,7 +333,7 @@ def main():
         if tfile.exists():
             try:
                 tj = json.loads(tfile.read_text())
-                if tj.get("workload") == f"R={R},T={T},W={W},h={h},k={k},B={B}":
+                if tj.get("workload") == f"R={R},T={T},W={W},h={h},k={k},B={B}" and ("scan_fused" in tj.get("kernel", "")) == fused:
                     traffic = tj.get("hbm_bytes_per_launch")
                     traffic_source = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)"
             except Exception:   # noqa: BLE001
@@ -331,7 +342,7 @@ def main():
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg_bytes,
                     "avg_launch_ms": round(avg_ms, 5), "min_launch_ms": round(float(np.min(scan_ms)), 5),
-                    "launches_timed": len(scan_ms)}
+                    "launches_timed": len(scan_ms), "launches_timed_every": EV_EVERY}
     else:
         # per-GPU kernel timing is taken from one instrumented local scan on rank 0
         _, _, _, prof = _native.scan_topk(ds[:, 0, :], q, k, h=h, workspace=ws, profile=True, flags=flags | _native.FLAG_NO_FUSE)

@@ -52,6 +52,9 @@ extern "C" {
 #define PSH_STATUS_OVERFLOW  1     /* candidate buffer overflowed -- or (embedded scan) fewer than k windows
                                       lay below the sampled estimate of the k-th distance: results of that
                                       query are INVALID, rerun it with the _exhaustive entry point */
+#define PSH_STATUS_RETRY     2     /* the fused single-launch scan gave up (estimate short of k, a block with too many
+                                      candidates, a block that was not resident, a workspace never initialised):
+                                      results are INVALID, rerun the call with PSH_FLAG_NO_FUSE */
 
 /*
  * Optional instrumentation of psh_scan_topk / psh_scan_topk_exhaustive.
@@ -62,6 +65,7 @@ extern "C" {
  *        dominant kernel (the full sliding-window scan), so that a benchmark can time
  *        that kernel live inside its own timed loop.
  */
+/* (PSH_PROFILE_STAGES implies the separate launches; PSH_PROFILE_EVENTS brackets the fused launch when that runs) */
 #define PSH_PROFILE_STAGES 0
 #define PSH_PROFILE_EVENTS 1
 /* flags: the k best of every query are returned in ARBITRARY order (the sharded scan merges and
@@ -89,7 +93,7 @@ typedef struct psh_profile {
     float scan_ms;        /* the full sliding-window scan + filter (HBM-bound kernel) */
     float select_ms;      /* radix select + bitonic sort of the survivors   */
     float total_ms;
-    int   path;           /* 0 = sampled threshold path, 1 = exhaustive path */
+    int   path;           /* 0 = sampled threshold path, 1 = exhaustive path, 2 = sampled path as ONE fused launch */
     int   n_sample_rows;
     int   grid_blocks;    /* blocks of the scan kernel */
     int   n_candidates;   /* PSH_PROFILE_STAGES: largest per-query candidate count the scan admitted */
@@ -104,6 +108,14 @@ const char* psh_last_hip_error(void);   /* text of the last failing HIP call on 
  * this problem (a larger workspace is used as a larger candidate buffer).
  */
 int psh_workspace_bytes(int64_t R, int64_t T, int B, int W, int h, int k, size_t* out_bytes);
+/*
+ * Arm the fused single-launch scan for this workspace: psh_scan_topk with ONE query (W <= 33) then runs bootstrap,
+ * threshold, scan and selection in one launch whose blocks exchange data through a header at the start of the
+ * workspace.  Call once after allocating the workspace (and again after a PSH_STATUS_RETRY caused by a time-out);
+ * a workspace that was never initialised is detected on the device and the call reports PSH_STATUS_RETRY.
+ * The header keeps an epoch across launches: one workspace serves ONE stream at a time.
+ */
+int psh_workspace_init(int device, void* stream, void* workspace, size_t workspace_bytes);
 
 /*
  * ||x||_2 of each query in the reduction order of the reference's

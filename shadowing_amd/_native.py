@@ -14,7 +14,7 @@ import torch
 from . import _build
 
 PSH_OK = 0
-PSH_STATUS_OK, PSH_STATUS_OVERFLOW = 0, 1
+PSH_STATUS_OK, PSH_STATUS_OVERFLOW, PSH_STATUS_RETRY = 0, 1, 2
 PSH_MAX_W, PSH_MAX_K, PSH_MAX_B_PER_LAUNCH = 256, 16384, 1024
 # psh_profile.flags (include/psh.h)
 FLAG_UNSORTED, FLAG_FILTER_VALU, FLAG_EMBED_DENSE, FLAG_ROWS_GENERIC, FLAG_NO_FUSE = 1, 2, 4, 8, 16
@@ -40,7 +40,7 @@ EXPORTS = ("psh_version", "psh_strerror", "psh_last_hip_error", "psh_workspace_b
            "psh_scan_topk", "psh_scan_topk_exhaustive", "psh_scan_topk_embedded",
            "psh_scan_topk_embedded_exhaustive", "psh_merge_workspace_bytes", "psh_merge_topk",
            "psh_merge_topk_gathered", "psh_merge_sorted_gathered", "psh_gather_paths", "psh_embed_rows",
-           "psh_embedded_supported")
+           "psh_embedded_supported", "psh_workspace_init")
 
 _lib = None
 
@@ -78,6 +78,8 @@ def load() -> C.CDLL:
     L.psh_last_hip_error.restype = C.c_char_p
     L.psh_workspace_bytes.restype = i32
     L.psh_workspace_bytes.argtypes = [i64, i64, i32, i32, i32, i32, C.POINTER(C.c_size_t)]
+    L.psh_workspace_init.restype = i32
+    L.psh_workspace_init.argtypes = [i32, vp, vp, C.c_size_t]
     L.psh_query_norm.restype = i32
     L.psh_query_norm.argtypes = [i32, vp, vp, i32, i32, vp]
     scan_args = [i32, vp, vp, i64, i64, i64, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, C.c_size_t,
@@ -144,7 +146,9 @@ def workspace_bytes(R: int, T: int, B: int, W: int, h: int, k: int) -> int:
 
 
 class Workspace:
-    """Caller-owned scratch of the scan (a torch uint8 tensor), grown on demand."""
+    """Caller-owned scratch of the scan (a torch uint8 tensor), grown on demand.  A fresh buffer is armed for the
+    fused single-launch scan (psh_workspace_init, enqueued on the current stream).  The header at its start keeps an
+    epoch from launch to launch: one Workspace serves one stream at a time."""
 
     def __init__(self, device: torch.device):
         self.device = device
@@ -153,7 +157,15 @@ class Workspace:
     def get(self, nbytes: int) -> torch.Tensor:
         if self.buf is None or self.buf.numel() < nbytes:
             self.buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self.arm()
         return self.buf
+
+    def arm(self) -> None:
+        """(Re-)initialise the fused scan's header: after allocation, and after a PSH_STATUS_RETRY (a time-out inside
+        the fused launch disarms the header on the device)."""
+        if self.buf is not None:
+            _check(load().psh_workspace_init(self.device.index, _stream_ptr(self.device), self.buf.data_ptr(),
+                                             self.buf.numel()), "psh_workspace_init")
 
 
 def query_norm(queries: torch.Tensor) -> torch.Tensor:
@@ -168,7 +180,8 @@ def query_norm(queries: torch.Tensor) -> torch.Tensor:
 def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, r_offset: int = 0,
               qnorm: torch.Tensor | None = None, workspace: Workspace | None = None,
               exhaustive: bool = False, profile: bool = False, extra_workspace_factor: float = 1.0,
-              scan_events: tuple | None = None, out: tuple | None = None, unsorted: bool = False, flags: int = 0):
+              scan_events: tuple | None = None, out: tuple | None = None, unsorted: bool = False, flags: int = 0,
+              info: dict | None = None):
     """Enqueue the scan on the current stream.
 
     dataset (R, T) float32 device, queries (B, W) float32 device.  Returns
@@ -180,6 +193,8 @@ def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, 
     right around the dominant scan kernel, without any synchronisation.
     `unsorted=True`: the k best come back in arbitrary order (PSH_FLAG_UNSORTED; for callers that
     merge afterwards).  `flags`: further PSH_FLAG_* bits (A/B switches of tests and tools).
+    `info`: a dict that receives the launch plan's facts (path: 0 separate launches, 1 exhaustive, 2 fused; ...)
+    without any synchronisation.
     """
     ds = _dev_tensor(dataset, torch.float32, "dataset")
     q = _dev_tensor(queries, torch.float32, "queries")
@@ -222,7 +237,7 @@ def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, 
         prof.ev_scan_end = scan_events[1].cuda_event
     if unsorted and not exhaustive:
         flags |= FLAG_UNSORTED
-    if flags:
+    if flags or info is not None:
         if prof is None:
             prof = PshProfile()
             prof.mode = 1                 # no events given: nothing is recorded, nothing is synchronised
@@ -233,9 +248,33 @@ def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, 
             out_d.data_ptr(), out_idx.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(),
             C.byref(prof) if prof is not None else None)
     _check(rc, "psh_scan_topk_exhaustive" if exhaustive else "psh_scan_topk")
+    if info is not None:
+        info.update(path=prof.path, n_sample_rows=prof.n_sample_rows, grid_blocks=prof.grid_blocks)
     if profile:
         return out_d, out_idx, status, prof.as_dict()
     return out_d, out_idx, status
+
+
+def scan_topk_checked(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, r_offset: int = 0,
+                      workspace: Workspace | None = None, out: tuple | None = None, unsorted: bool = False, flags: int = 0):
+    """scan_topk + the status protocol of include/psh.h, with ONE host synchronisation in the normal case:
+    PSH_STATUS_RETRY (the fused launch gave up) -> the same call through the separate launches (PSH_FLAG_NO_FUSE);
+    PSH_STATUS_OVERFLOW (candidate slices overflowed: ties en masse) -> those queries through the exhaustive path.
+    Returns (d, idx) device tensors holding valid results for every query."""
+    ws = workspace or Workspace(dataset.device)
+    d, idx, status = scan_topk(dataset, queries, k, h=h, r_offset=r_offset, workspace=ws, out=out, unsorted=unsorted, flags=flags)
+    st = status.cpu()
+    if bool((st == PSH_STATUS_RETRY).any()):
+        ws.arm()
+        d, idx, status = scan_topk(dataset, queries, k, h=h, r_offset=r_offset, workspace=ws, out=out, unsorted=unsorted,
+                                   flags=flags | FLAG_NO_FUSE)
+        st = status.cpu()
+    bad = torch.nonzero(st != PSH_STATUS_OK).flatten().to(dataset.device)
+    if bad.numel():
+        d2, i2, _ = scan_topk(dataset, queries[bad].contiguous(), k, h=h, r_offset=r_offset, workspace=ws, exhaustive=True)
+        d[bad] = d2
+        idx[bad] = i2
+    return d, idx
 
 
 PSH_EMB_MAX_D = 128

@@ -44,6 +44,7 @@ inline int tile_floats_for(int W) {
 }
 
 struct Workspace {
+    FusedHdr* fused;      // state of the fused single-launch scan: ALWAYS the first PSH_FUSED_BYTES of the workspace
     QueryState* qstate;
     int* total;
     float* minbuf;
@@ -99,7 +100,7 @@ int64_t boot_entries(int64_t R, int64_t Tp, int k) {
 
 // fixed part + cap * 12 bytes per query (the block slices / window slots)
 size_t fixed_bytes(int B, int kpad, int64_t min_stride) {
-    size_t o = 0;
+    size_t o = PSH_FUSED_BYTES;
     o += align_up(sizeof(QueryState) * (size_t)B, 256);
     o += align_up(sizeof(int) * (size_t)B, 256);
     o += align_up(sizeof(float) * (size_t)B * (size_t)min_stride, 256);
@@ -121,6 +122,7 @@ int carve(void* ws, size_t bytes, int B, int k, int64_t min_stride, Workspace* o
     if (cap <= 0) return PSH_ERR_WORKSPACE;
     char* p = (char*)ws;
     if (((uintptr_t)p & 255u) != 0) return PSH_ERR_ARG;   // torch allocations are >= 512-byte aligned
+    out->fused = (FusedHdr*)p;    p += PSH_FUSED_BYTES;
     out->qstate = (QueryState*)p; p += align_up(sizeof(QueryState) * (size_t)B, 256);
     out->total = (int*)p;         p += align_up(sizeof(int) * (size_t)B, 256);
     out->minbuf = (float*)p;      p += align_up(sizeof(float) * (size_t)B * (size_t)min_stride, 256);
@@ -433,6 +435,15 @@ int psh_workspace_bytes(int64_t R, int64_t T, int B, int W, int h, int k, size_t
     return PSH_OK;
 }
 
+int psh_workspace_init(int device, void* stream, void* workspace, size_t workspace_bytes) {
+    if (!workspace || ((uintptr_t)workspace & 255u) != 0) return PSH_ERR_ARG;
+    if (workspace_bytes < PSH_FUSED_BYTES) return PSH_ERR_WORKSPACE;
+    DeviceGuard g(device);
+    if (!g.ok) { snprintf(g_hip_err, sizeof(g_hip_err), "hipSetDevice(%d) failed", device); return PSH_ERR_HIP; }
+    HIP_TRY(launch_fused_init((FusedHdr*)workspace, (hipStream_t)stream));
+    return PSH_OK;
+}
+
 int psh_query_norm(int device, void* stream, const float* queries, int B, int W, float* out_qnorm) {
     if (!queries || !out_qnorm || B <= 0 || W <= 0) return PSH_ERR_ARG;
     DeviceGuard g(device);
@@ -529,6 +540,54 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
 
     const bool stages = profile && profile->mode == PSH_PROFILE_STAGES;
     const bool events = profile && profile->mode == PSH_PROFILE_EVENTS && profile->ev_scan_begin && profile->ev_scan_end;
+
+    // ---- the whole step as ONE launch (psh_fused.hip): a single query on the matrix-core scan whose bootstrap sample is
+    // one minimum per (row, segment) unit and fits the exchange area.  Anything that goes wrong inside raises
+    // PSH_STATUS_RETRY in out_status and the caller reruns with PSH_FLAG_NO_FUSE.
+    if (use_mx && !rows_path && !stages && !(flags_of(profile) & PSH_FLAG_NO_FUSE) && scan_fused_supported(p.W)) {
+        Plan plan_f;
+        rc = plan_scan(device, p, p.R, &plan_f); if (rc) return rc;
+        // its own sample: only an ESTIMATE of the k-th smallest acc is needed (what is admitted is verified exactly, and
+        // "at least k admitted" proves the result complete), so at most PSH_FUSED_MAX_UNITS (row, segment) units -- one
+        // minimum each -- spread over at most a quarter of the ensemble
+        const int64_t nseg = (p.Tp + PSH_SEG - 1) / PSH_SEG;
+        int64_t rows_f = PSH_FUSED_MAX_UNITS / nseg;
+        if (rows_f > p.R / 4) rows_f = p.R / 4;
+        const int64_t units_f = rows_f * nseg;
+        // the admission level: the rank-th smallest sampled minimum -- ~2k windows of the whole ensemble expected below it
+        // (~3k when that rank is small and therefore noisy)
+        int64_t r2 = rows_f > 0 ? (2 * (int64_t)k * rows_f + p.R - 1) / p.R : 0;
+        r2 += r2 < 64 ? r2 / 2 + 16 : 8;
+        // (~2.5 k candidates are expected: they must fit the blocks' front lists with room to spare)
+        if (plan_f.grid <= PSH_FUSED_MAX_BLOCKS && rows_f >= 1 && units_f >= 256 && r2 <= units_f / 2 &&
+            5 * (int64_t)k <= (int64_t)plan_f.grid * PSH_FUSED_FRONT) {
+            const int64_t stride_f = p.R / rows_f, row0_f = stride_f / 2;
+            ScanArgs fa = make_scan_args(dataset, queries, p, w, plan_f, 0, 1, p.R);
+            const int logical = PSH_SEG + p.W + 3;
+            fa.tile_floats = (logical + ((logical >> 6) << 2) + 4 + 3) & ~3;
+            if (scan_fused_shmem_bytes(fa.tile_floats) <= PSH_LDS_BYTES) {
+                FusedArgs fu;
+                memset(&fu, 0, sizeof(fu));
+                fu.hdr = w.fused;
+                fu.boot_units = (int)units_f;
+                fu.boot_row0 = row0_f;
+                fu.boot_row_stride = stride_f;
+                fu.rank = (int)r2;
+                fu.qnorm_in = qnorm;
+                fu.out_d = out_d;
+                fu.out_idx = out_idx;
+                fu.status = out_status;
+                fu.total = w.total;
+                fu.spin_ticks = 200000;                    // 2 ms at the 100 MHz wall clock: a block that is not resident
+                fa.dbg_times = tuning().dbg_times;
+                if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_begin, s));
+                HIP_TRY(launch_scan_fused(fa, fu, p.aligned, plan_f.grid, s));
+                if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_end, s));
+                if (profile) { profile->path = 2; profile->n_sample_rows = (int)rows_f; profile->grid_blocks = plan_f.grid; }
+                return PSH_OK;
+            }
+        }
+    }
     Timer tm(stages, s);
     rc = tm.init(); if (rc) return rc;
     rc = tm.mark(); if (rc) return rc;                                       // 0

@@ -390,6 +390,22 @@ __device__ __forceinline__ void stage_store(const Stage& st, float* tile, int nf
     }
 }
 
+// ---- matrix-core rejection test: f16 staging layout (scan_mx_kernel, scan_mq_kernel, scan_fused_kernel) ---------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define PSH_MX_SLOTS 144                      // 16-byte slots per f16 array: 32*31 + 64 values, whole groups of 16 slots
+#define PSH_MX_NHALF (PSH_MX_SLOTS * 8)
+#define PSH_MX_PEND 64                        // >= 64: one ballot can admit a whole wave
+
+// logical f16 index -> LDS index.  A-fragment reads of the 32 rows sit 64 bytes apart
+// (4 slots): rotating the slot inside its group of 16 by the group number spreads 16
+// consecutive rows over 16 distinct slots without any padding.
+__device__ __forceinline__ int mx_half(int idx) {
+    const int slot = idx >> 3;
+    return (((slot & ~15) | ((slot + (slot >> 4)) & 15)) << 3) | (idx & 7);
+}
+
 // ---- deferred candidate append -----------------------------------------------------
 // vmcnt retires in order: a global store issued by the (rare) admission path would be
 // YOUNGER than the prefetch of the next segment, so anything that later waits for that

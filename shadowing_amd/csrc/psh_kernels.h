@@ -17,6 +17,7 @@
 
 #define PSH_STATUS_OK_ 0
 #define PSH_STATUS_OVERFLOW_ 1
+#define PSH_STATUS_RETRY_ 2
 
 namespace psh {
 
@@ -37,6 +38,40 @@ struct QueryState {   // one per query, device, 48 bytes
 
 #define PSH_MAX_BLOCKS 2048          // upper bound of the scan grid
 #define PSH_MAX_B_PER_LAUNCH 1024    // per-block LDS append counters: one int per query
+
+// ---- the fused single-launch scan (psh_fused.hip): state at the START of the caller's workspace -----------------
+// One launch runs bootstrap -> threshold -> scan -> selection; its blocks hand data to each other through 8-byte
+// {tag, value} granules and write-through stores in this header (MI355X: per-XCD L2s are not coherent, so every
+// shared word is an agent-scope access).  Tags derive from `epoch`, which lives HERE (not in a kernel argument: it
+// survives graph replay) and is advanced by the launch itself; psh_workspace_init writes magic + epoch once.
+#define PSH_FUSED_MAGIC 0x5053484655534544ull
+#define PSH_FUSED_MAX_BLOCKS 256     // blocks of the fused launch (one per CU)
+#define PSH_FUSED_MAX_UNITS 4096     // bootstrap minima exchanged (one 16-byte load per thread of a block reads them all)
+#define PSH_FUSED_FRONT 64           // candidates a block may hand to the distributed selection (~8 expected)
+struct FusedHdr {
+    unsigned long long magic;
+    unsigned epoch;
+    unsigned pad[13];
+    unsigned long long blk[PSH_FUSED_MAX_BLOCKS];            // end-of-scan record of a block: tag << 32 | overflow << 31 | count
+    unsigned long long blk2[PSH_FUSED_MAX_BLOCKS];           //   and tag << 32 | the tau2 bits it admitted with (must agree everywhere)
+    unsigned long long aflag[PSH_FUSED_MAX_BLOCKS];          // bootstrap: tag << 32 | 1 once the block's minima are written
+    unsigned minima[PSH_FUSED_MAX_UNITS];                    // bootstrap: float bits of a (row, segment) minimum
+    unsigned long long cand[PSH_FUSED_MAX_BLOCKS * PSH_FUSED_FRONT * 2];   // {r << 32 | d bits, t}
+};
+#define PSH_FUSED_BYTES ((sizeof(psh::FusedHdr) + 255) / 256 * 256)
+
+struct FusedArgs {
+    FusedHdr* hdr;
+    int boot_units;                  // sampled (row, segment) units: row = boot_row0 + (u / nseg) * boot_row_stride
+    int64_t boot_row0, boot_row_stride;
+    int rank;                        // the estimate tau2 = the rank-th smallest sampled minimum (~2k windows of the ensemble below it)
+    const float* qnorm_in;           // nullable
+    float* out_d;
+    int32_t* out_idx;
+    int* status;
+    int* total;
+    long long spin_ticks;            // give-up time of a poll in wall-clock ticks (100 MHz)
+};
 
 struct PrepArgs {
     const float* queries;
@@ -188,6 +223,10 @@ hipError_t launch_merge_sorted(const MergeSortedArgs& a, int B, hipStream_t s); 
 hipError_t launch_rows(ScanArgs a, int mode, int grid, hipStream_t s);     // one-window rows (T == W + h): BOOT / FILTER
 size_t rows_shmem_bytes(int ds, int B);
 hipError_t launch_gather(const GatherArgs& a, hipStream_t s);
+bool scan_fused_supported(int W);
+size_t scan_fused_shmem_bytes(int tile_floats);
+hipError_t launch_scan_fused(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, hipStream_t s);
+hipError_t launch_fused_init(FusedHdr* hdr, hipStream_t s);
 hipError_t launch_embed_rows(const float* dataset, int64_t R, int64_t T, const float* ker, int d, int K, float* out, hipStream_t s);
 
 }  // namespace psh

@@ -300,20 +300,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_kernel(ScanArgs a) {
 // rightly rejected when its t^ comes out +inf, and is kept for the exact recheck when it
 // comes out NaN (inf * 0 from the zero part of the band, inf - inf): both are correct.
 // ----------------------------------------------------------------------------------
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-#define PSH_MX_SLOTS 144                      // 16-byte slots per f16 array: 32*31 + 64 values, whole groups of 16 slots
-#define PSH_MX_NHALF (PSH_MX_SLOTS * 8)
-#define PSH_MX_PEND 64                        // >= 64: one ballot can admit a whole wave
-
-// logical f16 index -> LDS index.  A-fragment reads of the 32 rows sit 64 bytes apart
-// (4 slots): rotating the slot inside its group of 16 by the group number spreads 16
-// consecutive rows over 16 distinct slots without any padding.
-__device__ __forceinline__ int mx_half(int idx) {
-    const int slot = idx >> 3;
-    return (((slot & ~15) | ((slot + (slot >> 4)) & 15)) << 3) | (idx & 7);
-}
+// (f16x8 / f16x4 / f32x16, PSH_MX_SLOTS / NHALF / PEND and mx_half(): psh_device.h -- shared with psh_fused.hip)
 
 template <int WT, bool ALIGNED>
 __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {

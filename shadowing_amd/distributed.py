@@ -41,6 +41,9 @@ def _native_local_topk(ds2d: torch.Tensor, q: torch.Tensor, k: int, h: int, r_of
                                      exhaustive=exhaustive, unsorted=unsorted)
         return _native.scan_topk_embedded(ds2d, ker, qq, k, h=h, r_offset=r_offset, workspace=workspace, out=out_,
                                           exhaustive=exhaustive)
+    if check and ker is None:    # one host sync: the status protocol (fused launch gave up -> separate launches; overflow -> exact)
+        d, idx = _native.scan_topk_checked(ds2d, q, k, h=h, r_offset=r_offset, workspace=workspace, out=out, unsorted=unsorted)
+        return d, idx, torch.zeros((q.shape[0],), dtype=torch.int32, device=q.device)
     d, idx, status = run(q, False, out)
     if check:    # one host sync: a query whose candidate slices overflowed is redone exactly
         bad = torch.nonzero(status != _native.PSH_STATUS_OK).flatten()

@@ -85,11 +85,7 @@ class RelativeMSE(PathDistance):
                 ws = getattr(self, "_workspace", None)             # scratch kept between calls
                 if ws is None or ws.device != y.device:
                     ws = self._workspace = _native.Workspace(y.device)
-                dist, idx, status = _native.scan_topk(rows, x.contiguous(), k, h=0, workspace=ws)
-                if bool(status.any()):                             # one host sync; rare: ties en masse / a short estimate
-                    bad = torch.nonzero(status != _native.PSH_STATUS_OK).flatten()
-                    d2, i2, _ = _native.scan_topk(rows, x[bad].contiguous(), k, h=0, workspace=ws, exhaustive=True)
-                    dist[bad], idx[bad] = d2, i2
+                dist, idx = _native.scan_topk_checked(rows, x.contiguous(), k, h=0, workspace=ws)   # one host sync
                 flat = idx[..., 0].to(torch.int64)                 # the point's flat position; its window index is 0
                 coords = []
                 for s in reversed(y.shape[:-1]):

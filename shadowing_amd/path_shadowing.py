@@ -293,9 +293,8 @@ class PathShadowing:
                 # then scan R pre-embedded points (rows one window long): psh_embed_rows + psh_scan_topk
                 points = _native.embed_rows(rows.contiguous(), ker2)
 
-                def scan(sel, exhaustive):
-                    q = hx if sel is None else hx[sel].contiguous()
-                    return _native.scan_topk(points, q, k, h=0, workspace=self._workspace, exhaustive=exhaustive)
+                d, idx = _native.scan_topk_checked(points, hx, k, h=0, workspace=self._workspace)
+                return d, idx, ds
             else:
                 def scan(sel, exhaustive):
                     q = hx if sel is None else hx[sel].contiguous()
@@ -303,10 +302,8 @@ class PathShadowing:
                                                       exhaustive=exhaustive)
         else:
             xq = x[:, 0, :].contiguous().to(dev)
-
-            def scan(sel, exhaustive):
-                q = xq if sel is None else xq[sel].contiguous()
-                return _native.scan_topk(rows, q, k, h=h, workspace=self._workspace, exhaustive=exhaustive)
+            d, idx = _native.scan_topk_checked(rows, xq, k, h=h, workspace=self._workspace)
+            return d, idx, ds
         d, idx, status = scan(None, False)
         bad = torch.nonzero(status != _native.PSH_STATUS_OK).flatten()
         if bad.numel():

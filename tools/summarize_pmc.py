@@ -9,7 +9,7 @@ import os
 import sys
 
 out = sys.argv[1]
-KEEP = ("scan_kernel", "scan_mx_kernel", "scan_mq_kernel", "boot_mq_kernel", "embed_scan_kernel", "select", "threshold")
+KEEP = ("scan_fused_kernel", "scan_kernel", "scan_mx_kernel", "scan_mq_kernel", "boot_mq_kernel", "embed_scan_kernel", "select", "threshold")
 means = {}
 for path in sorted(glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
     acc = collections.defaultdict(list)
@@ -26,14 +26,14 @@ for path in sorted(glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collecti
 if "--traffic" in sys.argv:
     dst = sys.argv[sys.argv.index("--traffic") + 1]
     # the dominant kernel: the full scan (FILTER instantiation <..,1> of scan_kernel, or scan_mx_kernel)
-    cands = [kn for (kn, cn) in means if cn == "FETCH_SIZE" and ("scan_mx_kernel" in kn or "scan_kernel<20, true, 1>" in kn
+    cands = [kn for (kn, cn) in means if cn == "FETCH_SIZE" and ("scan_fused_kernel" in kn or "scan_mx_kernel" in kn or "scan_kernel<20, true, 1>" in kn
                                                                   or "scan_kernel<20,true,1>" in kn)]
     if cands:
         kn = max(cands, key=lambda k: means[(k, "FETCH_SIZE")])
         fetch = means[(kn, "FETCH_SIZE")]
         write = means.get((kn, "WRITE_SIZE"), 0.0)
         R, T, W, h, k, B = 32768, 4096, 20, 20, 1024, 1
-        j = {"workload": f"R={R},T={T},W={W},h={h},k={k},B={B}", "kernel": kn, "round": 1,
+        j = {"workload": f"R={R},T={T},W={W},h={h},k={k},B={B}", "kernel": kn, "round": 2,
              "FETCH_SIZE_KiB_per_launch": round(fetch, 1), "WRITE_SIZE_KiB_per_launch": round(write, 1),
              "correction": "gfx950 rocprofv3 FETCH_SIZE counts 64 B per 128-B request on wide coalesced streams: read bytes = "
                            "2 x FETCH_SIZE x 1024 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE taken as is",
