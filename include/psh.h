@@ -43,6 +43,7 @@ extern "C" {
 #define PSH_ERR_UNSUPPORTED   -2   /* W > PSH_MAX_W, k > PSH_MAX_K, index would overflow int32 */
 #define PSH_ERR_WORKSPACE     -3   /* workspace too small (see psh_workspace_bytes) */
 #define PSH_ERR_HIP           -4   /* a HIP runtime call failed (psh_last_hip_error) */
+#define PSH_ERR_COMM          -5   /* RCCL could not be opened or a collective call failed (psh_last_comm_error) */
 
 #define PSH_MAX_W      256         /* longest query window handled natively */
 #define PSH_MAX_K      16384       /* largest k handled natively */
@@ -82,6 +83,10 @@ extern "C" {
 #define PSH_FLAG_EMBED_DENSE  4
 #define PSH_FLAG_ROWS_GENERIC 8
 #define PSH_FLAG_NO_FUSE      16
+/* RESERVE_CUS: the scan leaves a few compute units free (grid = CUs - 4): set by callers that run a collective and a
+ * merge on a side stream beside the NEXT scan -- the fused launch otherwise owns every CU of the chip, and work on
+ * another stream would wait for it (or make its last block wait). */
+#define PSH_FLAG_RESERVE_CUS  32
 typedef struct psh_profile {
     int   mode;           /* in */
     int   flags;          /* in: PSH_FLAG_* */
@@ -240,6 +245,41 @@ int psh_merge_sorted_gathered(int device, void* stream,
 int psh_merge_topk(int device, void* stream,
                    const float* d_lists, const int32_t* idx_lists, int B, int n_in, int k,
                    float* out_d, int32_t* out_idx, void* workspace, size_t workspace_bytes);
+
+/*
+ * ---- multi-GPU: the exchange of the row-sharded scan (the reference has no multi-GPU path) ------------
+ * One process per GPU.  Rank g keeps rows [lo_g, hi_g) resident, scans them with r_offset = lo_g (psh_scan_topk),
+ * and the per-rank top-k lists meet in ONE all-gather of B*k*12 bytes per rank (RCCL over xGMI), after which every
+ * rank merges the G sorted lists with the same (d, r, t) order -- results identical for any G.
+ * RCCL is opened at run time from `librccl_path` (NULL: "librccl.so"); hand over the library the process already
+ * uses (PyTorch-ROCm's torch/lib/librccl.so) so that there is one RCCL in the process.
+ *   psh_comm_unique_id   rank 0 creates the 128-byte id; the caller broadcasts it by its own means
+ *   psh_comm_create      collective over the `world` ranks (ncclCommInitRank)
+ *   psh_exchange_merge   enqueues, without synchronising the host:
+ *                          compute stream: record ev_scan_done            (the local scan wrote `send` before it)
+ *                          side stream   : wait ev_scan_done; all-gather send -> gathered; merge -> out_d / out_idx;
+ *                                          record ev_merged
+ *                        so the collective and the merge run beside whatever the compute stream does next (the scan
+ *                        of the next query batch); the consumer of out_d / out_idx waits for ev_merged.
+ *     send      device, 3*B*k int32: the (B,k) float32 distances (bit patterns), then the (B,k,2) int32 indices --
+ *               psh_scan_topk writes straight into it (out_d = send, out_idx = send + B*k)
+ *     gathered  device, G x 3*B*k int32 (the all-gather's receive buffer, caller-owned)
+ *     merge_workspace  psh_merge_workspace_bytes(B, k); only used when the sorted merge does not apply (G > 64 or
+ *               G*k > 32768)
+ *     ev_scan_done, ev_merged   hipEvent_t created by the caller
+ *   Requires B*k even.  Buffers must stay alive until ev_merged has completed.
+ */
+#define PSH_COMM_ID_BYTES 128
+typedef struct psh_comm psh_comm;
+const char* psh_last_comm_error(void);
+int psh_comm_unique_id(const char* librccl_path, void* out_id);
+int psh_comm_create(const char* librccl_path, int device, int world, int rank, const void* id, psh_comm** out);
+int psh_comm_destroy(psh_comm* comm);
+int psh_comm_world(const psh_comm* comm);
+int psh_exchange_merge(psh_comm* comm, void* compute_stream, void* side_stream,
+                       const int32_t* send, int32_t* gathered, int B, int k,
+                       float* out_d, int32_t* out_idx, void* merge_workspace, size_t merge_workspace_bytes,
+                       void* ev_scan_done, void* ev_merged);
 
 /*
  * Path gather of shadow() (path_shadowing.py:211-216):

@@ -11,13 +11,14 @@ CSRC = PKG / "csrc"
 LIBDIR = PKG / "lib"
 LIB = LIBDIR / "libpsh_hip.so"
 INCLUDE = PKG.parent / "include"
-SOURCES = [CSRC / "psh_scan.hip", CSRC / "psh_fused.hip", CSRC / "psh_embed.hip", CSRC / "psh_select.hip", CSRC / "psh_capi.hip"]
+SOURCES = [CSRC / "psh_scan.hip", CSRC / "psh_fused.hip", CSRC / "psh_embed.hip", CSRC / "psh_select.hip", CSRC / "psh_capi.hip",
+           CSRC / "psh_comm.hip"]
 DEPS = SOURCES + [CSRC / "psh_kernels.h", CSRC / "psh_device.h", INCLUDE / "psh.h"]
 
 # -ffp-contract=off: nothing may be fused or re-associated that the source does not
 # spell out -- bit-exact distances are what make the returned indices bit-exact.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
-LINK_LIBS: list[str] = []
+LINK_LIBS: list[str] = ["-ldl"]      # psh_comm.hip opens RCCL at run time (dlopen): no link-time dependency on it
 
 
 def hipcc_path() -> str:

@@ -17,7 +17,7 @@ PSH_OK = 0
 PSH_STATUS_OK, PSH_STATUS_OVERFLOW, PSH_STATUS_RETRY = 0, 1, 2
 PSH_MAX_W, PSH_MAX_K, PSH_MAX_B_PER_LAUNCH = 256, 16384, 1024
 # psh_profile.flags (include/psh.h)
-FLAG_UNSORTED, FLAG_FILTER_VALU, FLAG_EMBED_DENSE, FLAG_ROWS_GENERIC, FLAG_NO_FUSE = 1, 2, 4, 8, 16
+FLAG_UNSORTED, FLAG_FILTER_VALU, FLAG_EMBED_DENSE, FLAG_ROWS_GENERIC, FLAG_NO_FUSE, FLAG_RESERVE_CUS = 1, 2, 4, 8, 16, 32
 
 
 class NativeLibraryError(RuntimeError):
@@ -40,7 +40,8 @@ EXPORTS = ("psh_version", "psh_strerror", "psh_last_hip_error", "psh_workspace_b
            "psh_scan_topk", "psh_scan_topk_exhaustive", "psh_scan_topk_embedded",
            "psh_scan_topk_embedded_exhaustive", "psh_merge_workspace_bytes", "psh_merge_topk",
            "psh_merge_topk_gathered", "psh_merge_sorted_gathered", "psh_gather_paths", "psh_embed_rows",
-           "psh_embedded_supported", "psh_workspace_init")
+           "psh_embedded_supported", "psh_workspace_init", "psh_last_comm_error", "psh_comm_unique_id", "psh_comm_create",
+           "psh_comm_destroy", "psh_comm_world", "psh_exchange_merge")
 
 _lib = None
 
@@ -78,6 +79,17 @@ def load() -> C.CDLL:
     L.psh_last_hip_error.restype = C.c_char_p
     L.psh_workspace_bytes.restype = i32
     L.psh_workspace_bytes.argtypes = [i64, i64, i32, i32, i32, i32, C.POINTER(C.c_size_t)]
+    L.psh_last_comm_error.restype = C.c_char_p
+    L.psh_comm_unique_id.restype = i32
+    L.psh_comm_unique_id.argtypes = [C.c_char_p, vp]
+    L.psh_comm_create.restype = i32
+    L.psh_comm_create.argtypes = [C.c_char_p, i32, i32, i32, vp, C.POINTER(vp)]
+    L.psh_comm_destroy.restype = i32
+    L.psh_comm_destroy.argtypes = [vp]
+    L.psh_comm_world.restype = i32
+    L.psh_comm_world.argtypes = [vp]
+    L.psh_exchange_merge.restype = i32
+    L.psh_exchange_merge.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, C.c_size_t, vp, vp]
     L.psh_workspace_init.restype = i32
     L.psh_workspace_init.argtypes = [i32, vp, vp, C.c_size_t]
     L.psh_query_norm.restype = i32
@@ -119,6 +131,8 @@ def _check(rc: int, what: str):
     msg = L.psh_strerror(rc).decode()
     if rc == -4:
         msg += ": " + L.psh_last_hip_error().decode()
+    if rc == -5:
+        msg += ": " + L.psh_last_comm_error().decode()
     if rc == -1:
         raise ValueError(f"{what}: {msg}")
     raise NativeLibraryError(f"{what}: {msg} (code {rc})")
@@ -353,6 +367,52 @@ def embed_rows(dataset: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# ---- multi-GPU exchange under the C ABI (psh_comm.hip) ----------------------------------------------------------
+PSH_COMM_ID_BYTES = 128
+
+
+def rccl_library_path() -> str:
+    """The RCCL this process already uses: the one bundled with PyTorch-ROCm (torch/lib/librccl.so)."""
+    import os
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return cand if os.path.exists(cand) else "librccl.so"
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(PSH_COMM_ID_BYTES)
+    _check(load().psh_comm_unique_id(rccl_library_path().encode(), buf), "psh_comm_unique_id")
+    return buf.raw
+
+
+class Comm:
+    """An RCCL communicator owned by libpsh_hip.so (psh_comm_create): one per rank, created collectively."""
+
+    def __init__(self, device: torch.device, world: int, rank: int, unique_id: bytes):
+        self.device, self.world, self.rank = device, world, rank
+        h = C.c_void_p()
+        _check(load().psh_comm_create(rccl_library_path().encode(), device.index, world, rank, unique_id, C.byref(h)),
+               "psh_comm_create")
+        self._h = h
+
+    def close(self):
+        if self._h:
+            load().psh_comm_destroy(self._h)
+            self._h = None
+
+    def exchange_merge(self, send: torch.Tensor, gathered: torch.Tensor, B: int, k: int, out_d: torch.Tensor,
+                       out_idx: torch.Tensor, merge_ws: torch.Tensor | None, side: "torch.cuda.Stream",
+                       ev_scan_done: "torch.cuda.Event", ev_merged: "torch.cuda.Event"):
+        """psh_exchange_merge: all-gather + merge on `side`, behind ONE event on the current stream; nothing is
+        synchronised.  The events must have been recorded once (their handles exist)."""
+        _dev_tensor(send, torch.int32, "send")
+        _dev_tensor(gathered, torch.int32, "gathered")
+        rc = load().psh_exchange_merge(self._h, _stream_ptr(self.device), side.cuda_stream, send.data_ptr(), gathered.data_ptr(),
+                                       B, k, out_d.data_ptr(), out_idx.data_ptr(),
+                                       None if merge_ws is None else merge_ws.data_ptr(), 0 if merge_ws is None else merge_ws.numel(),
+                                       ev_scan_done.cuda_event, ev_merged.cuda_event)
+        _check(rc, "psh_exchange_merge")
+
+
 def merge_topk(d_lists: torch.Tensor, idx_lists: torch.Tensor, k: int):
     """k best by (d, r, t) out of (B, n) candidates; entries with r < 0 are padding."""
     d = _dev_tensor(d_lists, torch.float32, "d_lists")
@@ -392,6 +452,12 @@ def merge_topk_gathered(gathered: torch.Tensor, G: int, B: int, k_in: int, k: in
                                           out_d.data_ptr(), out_idx.data_ptr(),
                                           ws.data_ptr(), ws.numel()), "psh_merge_topk_gathered")
     return out_d, out_idx
+
+
+def merge_workspace_bytes(B: int, k: int) -> int:
+    need = C.c_size_t(0)
+    _check(load().psh_merge_workspace_bytes(B, k, C.byref(need)), "psh_merge_workspace_bytes")
+    return int(need.value)
 
 
 def merge_sorted_supported(G: int, k_in: int) -> bool:

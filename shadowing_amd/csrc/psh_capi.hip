@@ -185,6 +185,7 @@ int check_problem(const float* dataset, int64_t R, int64_t T, int64_t r_offset, 
 }
 
 struct Plan { int grid; int n_qgroups; int q_per_group; int tile_floats; int wide; };
+#define PSH_RESERVED_CUS 4           // PSH_FLAG_RESERVE_CUS: compute units a scan leaves to the side stream (collective, merge)
 
 // Launch-geometry overrides and device-side time stamps for the scripts under tools/: compiled into the
 // tuning build only (-DPSH_TUNING, `python -m shadowing_amd._build --tuning`).  The product library reads no
@@ -419,6 +420,7 @@ const char* psh_strerror(int code) {
         case PSH_ERR_UNSUPPORTED: return "unsupported size (W > PSH_MAX_W, k > PSH_MAX_K, or int32 index overflow)";
         case PSH_ERR_WORKSPACE: return "workspace too small (see psh_workspace_bytes)";
         case PSH_ERR_HIP: return "HIP runtime error (see psh_last_hip_error)";
+        case PSH_ERR_COMM: return "RCCL error (see psh_last_comm_error)";
         default: return "unknown error";
     }
 }
@@ -547,6 +549,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     if (use_mx && !rows_path && !stages && !(flags_of(profile) & PSH_FLAG_NO_FUSE) && scan_fused_supported(p.W)) {
         Plan plan_f;
         rc = plan_scan(device, p, p.R, &plan_f); if (rc) return rc;
+        if ((flags_of(profile) & PSH_FLAG_RESERVE_CUS) && plan_f.grid > 2 * PSH_RESERVED_CUS) plan_f.grid -= PSH_RESERVED_CUS;
         // its own sample: only an ESTIMATE of the k-th smallest acc is needed (what is admitted is verified exactly, and
         // "at least k admitted" proves the result complete), so at most PSH_FUSED_MAX_UNITS (row, segment) units -- one
         // minimum each -- spread over at most a quarter of the ensemble
@@ -578,7 +581,9 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
                 fu.out_idx = out_idx;
                 fu.status = out_status;
                 fu.total = w.total;
-                fu.spin_ticks = 200000;                    // 2 ms at the 100 MHz wall clock: a block that is not resident
+                // give-up time of a poll at the 100 MHz wall clock: 2 ms (a block that is not resident); 20 ms when a
+                // collective shares the chip (its workgroups may hold a few CUs until the peers arrive)
+                fu.spin_ticks = (flags_of(profile) & PSH_FLAG_RESERVE_CUS) ? 2000000 : 200000;
                 fa.dbg_times = tuning().dbg_times;
                 if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_begin, s));
                 HIP_TRY(launch_scan_fused(fa, fu, p.aligned, plan_f.grid, s));

@@ -32,17 +32,18 @@ def shard_rows(R: int, world_size: int, rank: int) -> tuple[int, int]:
 
 
 def _native_local_topk(ds2d: torch.Tensor, q: torch.Tensor, k: int, h: int, r_offset: int, workspace,
-                       out=None, check: bool = True, ker: torch.Tensor | None = None, unsorted: bool = False):
+                       out=None, check: bool = True, ker: torch.Tensor | None = None, unsorted: bool = False, flags: int = 0):
     """q: the query windows (B, W), or -- with `ker` (d, K), a linear embedding -- the embedded
     queries (B, d)."""
     def run(qq, exhaustive, out_):
         if ker is None:
             return _native.scan_topk(ds2d, qq, k, h=h, r_offset=r_offset, workspace=workspace, out=out_,
-                                     exhaustive=exhaustive, unsorted=unsorted)
+                                     exhaustive=exhaustive, unsorted=unsorted, flags=flags)
         return _native.scan_topk_embedded(ds2d, ker, qq, k, h=h, r_offset=r_offset, workspace=workspace, out=out_,
                                           exhaustive=exhaustive)
     if check and ker is None:    # one host sync: the status protocol (fused launch gave up -> separate launches; overflow -> exact)
-        d, idx = _native.scan_topk_checked(ds2d, q, k, h=h, r_offset=r_offset, workspace=workspace, out=out, unsorted=unsorted)
+        d, idx = _native.scan_topk_checked(ds2d, q, k, h=h, r_offset=r_offset, workspace=workspace, out=out, unsorted=unsorted,
+                                           flags=flags)
         return d, idx, torch.zeros((q.shape[0],), dtype=torch.int32, device=q.device)
     d, idx, status = run(q, False, out)
     if check:    # one host sync: a query whose candidate slices overflowed is redone exactly
@@ -69,7 +70,8 @@ class ShardedPathShadowing:
 
     def __init__(self, embedding: Identity, distance: RelativeMSE, local_dataset, row_offset: int,
                  context: PredictionContext | None = None, group=None, device: torch.device | None = None,
-                 local_topk: Callable | None = None, merge: Callable | None = None, always_exchange: bool = False):
+                 local_topk: Callable | None = None, merge: Callable | None = None, always_exchange: bool = False,
+                 exchange: str = "auto"):
         if type(distance) is not RelativeMSE:
             raise TypeError("the sharded scan implements RelativeMSE only")
         if type(embedding) is Identity:
@@ -88,6 +90,17 @@ class ShardedPathShadowing:
             raise TypeError("the sharded scan implements PredictionContext only")
         self.group = group
         self.always_exchange = always_exchange      # run the all-gather + merge even with one rank (tests)
+        # who runs the collective: "library" = libpsh_hip.so itself (psh_exchange_merge: RCCL all-gather + merge on a
+        # side stream behind one event, one C call per step); "torch" = torch.distributed's all_gather_into_tensor
+        # (asynchronous) and the merge on the compute stream; "auto" = the library on a HIP device, torch otherwise
+        if exchange not in ("auto", "library", "torch"):
+            raise ValueError('exchange must be "auto", "library" or "torch"')
+        self.exchange = exchange
+        self.fuse = True            # False: the local scan as separate launches (PSH_FLAG_NO_FUSE)
+        self._comm = None
+        self._side = None
+        self._events = None
+        self._ev_next = 0
         self.row_offset = int(row_offset)
         self._local_topk = local_topk
         self._merge = merge
@@ -131,7 +144,36 @@ class ShardedPathShadowing:
             self._n_global = n
         return self._n_global
 
-    def local_scan(self, q: torch.Tensor, k: int, out=None, check: bool = True, unsorted: bool = False):
+    def _library_exchange(self):
+        """The communicator owned by libpsh_hip.so, created collectively on first use (the 128-byte id travels through
+        the torch.distributed group that is there anyway), its side stream and a ring of pre-recorded events (an event
+        record is a packet on the stream: none is spent per step beyond the two the hand-over needs)."""
+        if self._comm is None:
+            G = self.world_size
+            rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+            box = [_native.comm_unique_id() if rank == 0 else None]
+            if G > 1:
+                dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                                           group=self.group)
+            self._comm = _native.Comm(self.device, G, rank, box[0])
+            self._side = torch.cuda.Stream(device=self.device)
+            self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(8)]
+            for a, b in self._events:              # materialise the hipEvent handles
+                a.record(); b.record()
+        return self._comm
+
+    def _use_library(self, B: int, k: int) -> bool:
+        if self.exchange == "torch" or self._local_topk is not None or self._merge is not None or not self.device.type == "cuda":
+            return False
+        return (B * k) % 2 == 0
+
+    def close(self):
+        if self._comm is not None:
+            torch.cuda.synchronize(self.device)
+            self._comm.close()
+            self._comm = None
+
+    def local_scan(self, q: torch.Tensor, k: int, out=None, check: bool = True, unsorted: bool = False, flags: int = 0):
         """This rank's candidates: (d (B,k), idx (B,k,2), status) with global row numbers,
         padded with (+inf, -1) when the shard holds fewer than k windows."""
         h = self.context.get_out_times()
@@ -153,7 +195,7 @@ class ShardedPathShadowing:
         else:
             d, idx, status = _native_local_topk(self.dataset[:, 0, :], q, k_local, h, self.row_offset, self._workspace,
                                                 out=out if k_local == k else None, check=check, ker=self._ker,
-                                                unsorted=unsorted)
+                                                unsorted=unsorted, flags=flags)
         if k_local < k:
             B = q.shape[0]
             d = torch.cat([d, d.new_full((B, k - k_local), float("inf"))], dim=1)
@@ -199,12 +241,31 @@ class ShardedPathShadowing:
             # selection, no sort, 15 us at G = 8 against 36 us for the general merge); lists too long for
             # its LDS go to the general merge, which orders anyway -- the local selection then skips its own
             sorted_merge = _native.merge_sorted_supported(G, k)
-            d, idx, self.last_status = self.local_scan(q, k, out=out, check=check, unsorted=exchange and not sorted_merge)
+            library = exchange and self._use_library(B, k)
+            comm = self._library_exchange() if library else None
+            d, idx, self.last_status = self.local_scan(q, k, out=out, check=check, unsorted=exchange and not sorted_merge,
+                                                       flags=(_native.FLAG_RESERVE_CUS if library else 0)
+                                                       | (0 if self.fuse else _native.FLAG_NO_FUSE))
             if d.data_ptr() != out[0].data_ptr():     # shard smaller than k: padded copies were made
                 out[0].copy_(d)
                 out[1].copy_(idx)
             if not exchange:
                 return PendingScan(self, None, None, (d, idx), B, k)
+            if library:
+                # ONE C call: record an event on this stream, and on the side stream behind it the RCCL all-gather and
+                # the merge; the next batch's scan starts on this stream right away
+                gathered = torch.empty((G, 3 * B * k), dtype=torch.int32, device=self.device)
+                out_d = torch.empty((B, k), dtype=torch.float32, device=self.device)
+                out_idx = torch.empty((B, k, 2), dtype=torch.int32, device=self.device)
+                merge_ws = None
+                if not sorted_merge:
+                    merge_ws = torch.empty(_native.merge_workspace_bytes(B, k), dtype=torch.uint8, device=self.device)
+                for t in (send, gathered, out_d, out_idx) + ((merge_ws,) if merge_ws is not None else ()):
+                    t.record_stream(self._side)        # allocated on this stream, used on the side stream
+                ev_a, ev_b = self._events[self._ev_next % len(self._events)]
+                self._ev_next += 1
+                comm.exchange_merge(send, gathered, B, k, out_d, out_idx, merge_ws, self._side, ev_a, ev_b)
+                return PendingScan(self, None, (send, gathered, "library", ev_b, merge_ws), (out_d, out_idx), B, k)
             gathered = torch.empty((G, 3 * B * k), dtype=torch.int32, device=self.device)
             work = dist.all_gather_into_tensor(gathered.view(-1), send, group=self.group, async_op=True)
             return PendingScan(self, work, (send, gathered, "sorted" if sorted_merge else "general"), None, B, k)
@@ -251,6 +312,11 @@ class PendingScan:
     def finish(self):
         """(d (B,k), idx (B,k,2)) on the device, identical on all ranks.  Waits for the collective on the
         compute STREAM (no host synchronisation with the RCCL backend) and merges the gathered lists."""
+        if self._buffers is not None and self._buffers[2] == "library":
+            # the merged lists are written by the side stream: whoever consumes them on this stream waits for the event
+            torch.cuda.current_stream(self._owner.device).wait_event(self._buffers[3])
+            self._buffers = None
+            return self._result
         if self._result is None:
             o, B, k = self._owner, self._B, self._k
             G = o.world_size

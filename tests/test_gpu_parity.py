@@ -210,24 +210,47 @@ def test_merge_of_gathered_lists_in_place(hip_device, oracle_mod):
     assert_exact(md.cpu().numpy(), mi.cpu().numpy(), od, oidx, "gathered merge")
 
 
-def test_sharded_class_with_rccl_process_group(hip_device, oracle_mod, tmp_path):
-    """ShardedPathShadowing end to end over a real RCCL process group (one rank: the
-    all-gather and the merge still run)."""
+@pytest.mark.parametrize("exchange", ["library", "torch"])
+def test_sharded_class_with_rccl_process_group(hip_device, oracle_mod, tmp_path, exchange):
+    """ShardedPathShadowing end to end over RCCL (one rank: the all-gather and the merge still run) -- with the
+    collective issued by libpsh_hip.so itself (psh_exchange_merge: side stream, one event hand-over) and by
+    torch.distributed; then three query batches pipelined (batch i+1 scanned before batch i is finished)."""
     import torch.distributed as dist
     import shadowing_amd as sa
     from shadowing_amd.distributed import ShardedPathShadowing
     dist.init_process_group("nccl", init_method=f"file://{tmp_path}/pg", rank=0, world_size=1, device_id=hip_device)
+    obj = None
     try:
         R, T, W, h, k, B = 600, 900, 20, 20, 128, 3
         ds = syn.dataset(R, T, 23)
         q = syn.rolling_queries(B, W, 24)
         obj = ShardedPathShadowing(sa.Identity(W), sa.RelativeMSE(), ds, 0, sa.PredictionContext(h),
-                                   device=hip_device, always_exchange=True)
+                                   device=hip_device, always_exchange=True, exchange=exchange)
         d, paths, idx = obj.shadow(q, k)
         od, opaths, oidx = oracle_mod.shadow(ds, q, k, h)
         assert_exact(d, idx, od, oidx, "sharded class")
         assert np.array_equal(paths, opaths)
+        assert (obj._comm is not None) == (exchange == "library")
+        # a larger shard (the fused single-query launch with reserved CUs), pipelined
+        big = syn.dataset(8192, 2048, 25)
+        obj2 = ShardedPathShadowing(sa.Identity(W), sa.RelativeMSE(), big, 0, sa.PredictionContext(h),
+                                    device=hip_device, always_exchange=True, exchange=exchange)
+        qs = [torch.tensor(syn.gbm_log_returns((1, W), 26 + i)) for i in range(4)]
+        outs, pend = [], None
+        for qi in qs:
+            nxt = obj2.scan_begin(qi, 256)
+            if pend is not None:
+                outs.append(pend.finish())
+            pend = nxt
+        outs.append(pend.finish())
+        torch.cuda.synchronize()
+        for qi, (dd, ii) in zip(qs, outs):
+            od2, oi2 = oracle_mod.scan_topk(big, qi.numpy(), 256, h=h)
+            assert_exact(dd.cpu().numpy(), ii.cpu().numpy(), od2, oi2, "pipelined batch")
+        obj2.close()
     finally:
+        if obj is not None:
+            obj.close()
         dist.destroy_process_group()
 
 
