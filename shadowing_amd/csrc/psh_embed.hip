@@ -649,6 +649,7 @@ __global__ __launch_bounds__(THREADS) void embed_scan_kernel(ScanArgs a) {
 // HBM-bound for a handful of queries (2.3 W VALU operations per row and query against 4 T bytes).
 // ----------------------------------------------------------------------------------
 #define PSH_ROWS_THREADS 128
+#define PSH_ROWS_NB 10               // 16-byte loads a lane keeps in flight while a chunk of 64 rows is staged
 
 // staging of the 64 rows of a chunk (FILTER / ALL), chosen by the launcher:
 //   PSH_ROWS_FLAT  : gcd(T, 64) <= 2 -- the chunk is copied as it lies (16-byte LDS writes, no index arithmetic); a lane
@@ -695,24 +696,47 @@ __global__ __launch_bounds__(PSH_ROWS_THREADS) void rows_kernel(ScanArgs a, int 
             const int nr = (a.n_rows - 64 * c) < 64 ? (a.n_rows - 64 * c) : 64;
             const int64_t nfl = (int64_t)nr * T;
             const float* src = a.dataset + (a.row0 + (int64_t)64 * c) * T;
+            // PSH_ROWS_NB 16-byte loads of a lane are in flight TOGETHER before the first of them is stored (a plain
+            // "load, store, next" loop waits for every load in turn: one KB in flight per wave, 4.8 TB/s; rows of 34
+            // floats are 9 loads per lane -- one batch)
+            const int64_t n4 = nfl >> 2;                     // whole float4s of the chunk
+            const f32x4* src4 = reinterpret_cast<const f32x4*>(src);
             if (staging == PSH_ROWS_FLAT) {
-                for (int64_t e4 = lane; 4 * e4 < nfl; e4 += 64) {
-                    if (4 * e4 + 3 < nfl) {
-                        *reinterpret_cast<f32x4*>(tile + 4 * e4) = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + e4);
-                    } else {
-                        for (int k2 = 0; 4 * e4 + k2 < nfl; ++k2) tile[4 * e4 + k2] = src[4 * e4 + k2];
+                for (int64_t b4 = 0; b4 < n4; b4 += 64 * PSH_ROWS_NB) {
+                    f32x4 v[PSH_ROWS_NB];
+#pragma unroll
+                    for (int u2 = 0; u2 < PSH_ROWS_NB; ++u2) {     // unconditional (clamped): a predicated load is a branch with its own wait
+                        const int64_t e4 = b4 + lane + 64 * u2;
+                        v[u2] = __builtin_nontemporal_load(src4 + (e4 < n4 ? e4 : n4 - 1));
+                    }
+#pragma unroll
+                    for (int u2 = 0; u2 < PSH_ROWS_NB; ++u2) {
+                        const int64_t e4 = b4 + lane + 64 * u2;
+                        if (e4 < n4) *reinterpret_cast<f32x4*>(tile + 4 * e4) = v[u2];
                     }
                 }
+                if (lane < (int)(nfl & 3)) tile[4 * n4 + lane] = src[4 * n4 + lane];      // the last < 4 floats of a ragged chunk
             } else if (staging == PSH_ROWS_QUADS) {
                 const unsigned T4 = (unsigned)(T >> 2);
                 const unsigned magic4 = (unsigned)((1ull << 32) / (unsigned long long)T4);
-                for (int64_t e4 = lane; 4 * e4 < nfl; e4 += 64) {
-                    const f32x4 q4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + e4);
-                    const unsigned r = fast_div((unsigned)e4, magic4, T4);
-                    const unsigned c = 4u * ((unsigned)e4 - r * T4);
-                    if (c < (unsigned)W) {
-                        float* dstp = tile + r * ds + c;
-                        dstp[0] = q4[0]; dstp[1] = q4[1]; dstp[2] = q4[2]; dstp[3] = q4[3];   // (columns >= W of the last quad: unused slots of the row)
+                for (int64_t b4 = 0; b4 < n4; b4 += 64 * PSH_ROWS_NB) {
+                    f32x4 v[PSH_ROWS_NB];
+#pragma unroll
+                    for (int u2 = 0; u2 < PSH_ROWS_NB; ++u2) {     // unconditional (clamped): a predicated load is a branch with its own wait
+                        const int64_t e4 = b4 + lane + 64 * u2;
+                        v[u2] = __builtin_nontemporal_load(src4 + (e4 < n4 ? e4 : n4 - 1));
+                    }
+#pragma unroll
+                    for (int u2 = 0; u2 < PSH_ROWS_NB; ++u2) {
+                        const int64_t e4 = b4 + lane + 64 * u2;
+                        if (e4 < n4) {
+                            const unsigned r = fast_div((unsigned)e4, magic4, T4);
+                            const unsigned c2 = 4u * ((unsigned)e4 - r * T4);
+                            if (c2 < (unsigned)W) {
+                                float* dstp = tile + r * ds + c2;
+                                dstp[0] = v[u2][0]; dstp[1] = v[u2][1]; dstp[2] = v[u2][2]; dstp[3] = v[u2][3];   // (columns >= W of the last quad: unused slots of the row)
+                            }
+                        }
                     }
                 }
             } else {
@@ -720,7 +744,7 @@ __global__ __launch_bounds__(PSH_ROWS_THREADS) void rows_kernel(ScanArgs a, int 
             for (int64_t e4 = lane; 4 * e4 < nfl; e4 += 64) {
                 float v[4];
                 if (aligned16 && 4 * e4 + 3 < nfl) {
-                    const f32x4 q4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + e4);
+                    const f32x4 q4 = __builtin_nontemporal_load(src4 + e4);
                     v[0] = q4[0]; v[1] = q4[1]; v[2] = q4[2]; v[3] = q4[3];
                 } else {
 #pragma unroll
