@@ -283,8 +283,8 @@ def scan_topk_checked(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: i
         d, idx, status = scan_topk(dataset, queries, k, h=h, r_offset=r_offset, workspace=ws, out=out, unsorted=unsorted,
                                    flags=flags | FLAG_NO_FUSE)
         st = status.cpu()
-    bad = torch.nonzero(st != PSH_STATUS_OK).flatten().to(dataset.device)
-    if bad.numel():
+    if bool((st != PSH_STATUS_OK).any()):      # (nothing is uploaded in the normal case)
+        bad = torch.nonzero(st != PSH_STATUS_OK).flatten().to(dataset.device)
         d2, i2, _ = scan_topk(dataset, queries[bad].contiguous(), k, h=h, r_offset=r_offset, workspace=ws, exhaustive=True)
         d[bad] = d2
         idx[bad] = i2

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One call on the GPU box: PMC passes (own runs, no trace options) -> HBM traffic json, then the
 # bench line (which reads that json), then rocprofv3 kernel stats of the same bench command.
-# Results under gpurun_out/round/; the summaries are copied to profiles/ afterwards.
+# Results under gpurun_out/round/; the summaries are copied to profiles/ afterwards (tools/refresh_profiles.sh rNN).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/round
@@ -16,18 +16,26 @@ done
 python $R/tools/summarize_pmc.py $OUT --traffic $OUT/hbm_traffic.json > $OUT/pmc_summary.txt 2>&1
 cp $OUT/hbm_traffic.json $R/profiles/hbm_traffic.json 2>/dev/null
 cd $R
+# the headline line: configs[1], the whole step as one fused launch (with the CPU baselines)
 timeout 600 python bench.py --steps ${STEPS:-200} --warmup 20 > $OUT/bench_n1.json 2> $OUT/bench.err
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o scan -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_prof.log 2>&1
 for f in $(find $OUT/prof_stats -name "*kernel_stats.csv"); do cp $f $OUT/kernel_stats.csv; done
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_nofuse -o scan -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-fuse > $OUT/bench_prof_nofuse.log 2>&1
+for f in $(find $OUT/prof_stats_nofuse -name "*kernel_stats.csv"); do cp $f $OUT/kernel_stats_nofuse.csv; done
 cd $R
+timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-fuse > $OUT/bench_n1_separate_launches.json 2>> $OUT/bench.err
 timeout 300 python bench.py --steps 20 --warmup 3 --queries 512 --no-cpu-baseline > $OUT/bench_n1_q512.json 2>> $OUT/bench.err
 timeout 300 python bench.py --filter valu --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_n1_valu_filter.json 2>> $OUT/bench.err
+timeout 300 python bench.py --gpus 1 --force-sharded --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_n1_forced_exchange.json 2>> $OUT/bench.err
+timeout 300 python tools/fused_times.py > $OUT/fused_phase_times.txt 2>> $OUT/bench.err
 # the widened rows of the scope table: the reference's Foveal workloads, configs[4] (wavelet), forward_topk
 timeout 600 python tools/bench_foveal.py --steps 20 --generic --which tutorial testing wavelet 2>> $OUT/bench.err | grep "^{" > $OUT/bench_foveal.jsonl
 timeout 300 python tools/bench_forward_topk.py 2>> $OUT/bench.err | grep "^{" > $OUT/bench_forward_topk.jsonl
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_foveal -o fov -- python $R/tools/bench_foveal.py --steps 20 --which tutorial testing > $OUT/bench_foveal_prof.log 2>&1
 for f in $(find $OUT/prof_foveal -name "*kernel_stats.csv"); do head -8 $f > $OUT/foveal_kernel_stats.csv; done
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_rows -o rows -- python $R/tools/bench_forward_topk.py > $OUT/bench_rows_prof.log 2>&1
+for f in $(find $OUT/prof_rows -name "*kernel_stats.csv"); do grep "Name\|rows_kernel\|threshold\|select" $f > $OUT/forward_topk_kernel_stats.csv; done
 cd $R
 tail -c 600 $OUT/pmc_summary.txt; head -8 $OUT/kernel_stats.csv; cat $OUT/bench_n1.json
