@@ -83,6 +83,11 @@ extern "C" {
 #define PSH_FLAG_EMBED_DENSE  4
 #define PSH_FLAG_ROWS_GENERIC 8
 #define PSH_FLAG_NO_FUSE      16
+/* EMBED_MX: psh_scan_topk_embedded with a DENSE kernel (no suffix structure: a wavelet bank, a user kernel; d <= 12):
+ * the rejection test as a split-precision banded product on the matrix cores (embed_mx_kernel), exact dense chains for the
+ * survivors -- same results as without the flag.  (The library cannot look at the kernel matrix without a device
+ * synchronisation, so the caller says which it is: Foveal-like kernels are faster WITHOUT the flag, on the suffix-rows path.) */
+#define PSH_FLAG_EMBED_MX     64
 /* RESERVE_CUS: the scan leaves a few compute units free (grid = CUs - 4): set by callers that run a collective and a
  * merge on a side stream beside the NEXT scan -- the fused launch otherwise owns every CU of the chip, and work on
  * another stream would wait for it (or make its last block wait). */

@@ -158,6 +158,7 @@ struct Problem {
     int qlen;             // floats per query vector handed over: W, or emb_d (pre-embedded queries)
     bool emb_dense;       // PSH_FLAG_EMBED_DENSE
     bool rows_generic;    // PSH_FLAG_ROWS_GENERIC
+    bool emx;             // PSH_FLAG_EMBED_MX and the kernel fits: embed_mx_kernel (BOOT / FILTER)
 };
 
 int check_problem(const float* dataset, int64_t R, int64_t T, int64_t r_offset, const float* queries,
@@ -181,6 +182,7 @@ int check_problem(const float* dataset, int64_t R, int64_t T, int64_t r_offset, 
     p->qlen = emb_d > 0 ? emb_d : W;
     p->emb_dense = false;
     p->rows_generic = false;
+    p->emx = false;
     return PSH_OK;
 }
 
@@ -210,6 +212,33 @@ int plan_scan(int device, const Problem& p, int64_t n_rows, Plan* plan) {
     // embedded scan of a batch: 512-thread blocks whose waves carry 12 (suffix rows: 6) queries per evaluation of the
     // embedding (256 VGPRs, one block per CU)
     const Tuning tn = tuning();
+    if (p.emx) {
+        // embed_mx_kernel: 4 waves (one per SIMD), one block per CU
+        int ncu = 0;
+        HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+        const int nseg = (int)((p.Tp + PSH_SEG - 1) / PSH_SEG);
+        const int64_t n_rs = n_rows * nseg;
+        const int64_t waves = (int64_t)ncu * 4;
+        int n_qgroups = 1;
+        if (n_rs < waves && p.B > 1) {
+            int64_t g = (waves + n_rs - 1) / n_rs;
+            n_qgroups = (int)(g < p.B ? g : p.B);
+        }
+        const int q_per_group = (p.B + n_qgroups - 1) / n_qgroups;
+        n_qgroups = (p.B + q_per_group - 1) / q_per_group;
+        const int64_t units = n_rs * n_qgroups;
+        if (units >= (1ll << 31)) return PSH_ERR_UNSUPPORTED;
+        int64_t grid = (units + 3) / 4;
+        if (grid > ncu) grid = ncu;
+        if (grid > PSH_MAX_BLOCKS) grid = PSH_MAX_BLOCKS;
+        if (grid < 1) grid = 1;
+        plan->grid = (int)grid;
+        plan->n_qgroups = n_qgroups;
+        plan->q_per_group = q_per_group;
+        plan->tile_floats = tile_floats;
+        plan->wide = 0;
+        return PSH_OK;
+    }
     bool wide = p.ker && p.B >= tn.wide_min && !tn.narrow;
     // a kernel matrix too large to sit in LDS beside sixteen wave tiles (Foveal(1.15, 0.9, 252): 39 x 252) runs the
     // 8-wave instantiation whatever the batch size
@@ -272,6 +301,7 @@ ScanArgs make_scan_args(const float* dataset, const float* queries, const Proble
     a.emb_d = p.emb_d;
     a.emb_wide = plan.wide;
     a.emb_dense = p.emb_dense ? 1 : 0;                  // PSH_FLAG_EMBED_DENSE: skip the suffix-rows fast path (A/B tests)
+    a.emb_mx = p.emx ? 1 : 0;
     a.B = p.B;
     a.n_qgroups = plan.n_qgroups;
     a.q_per_group = plan.q_per_group;
@@ -353,8 +383,10 @@ struct Timer {   // optional per-stage HIP events
 };
 
 int run_exhaustive(int device, hipStream_t s, const float* dataset, const float* queries, const float* qnorm,
-                   const Problem& p, const Workspace& w, float* out_d, int32_t* out_idx, int32_t* out_status,
+                   const Problem& p_in, const Workspace& w, float* out_d, int32_t* out_idx, int32_t* out_status,
                    psh_profile* prof) {
+    Problem p = p_in;
+    p.emx = false;                 // every window is ranked here: the dense chains of embed_scan_kernel, no rejection test
     const int64_t nseg = (p.Tp + PSH_SEG - 1) / PSH_SEG;
     const bool rows_path = p.Tp == 1 && !p.ker && !p.rows_generic;   // one-window rows: a slot per row (rows_kernel)
     const int64_t slots_per_row = rows_path ? 1 : nseg * PSH_SEG;
@@ -502,6 +534,8 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     if (!out_status) return PSH_ERR_ARG;
     p.emb_dense = (flags_of(profile) & PSH_FLAG_EMBED_DENSE) != 0;
     p.rows_generic = (flags_of(profile) & PSH_FLAG_ROWS_GENERIC) != 0;
+    p.emx = p.ker && (flags_of(profile) & PSH_FLAG_EMBED_MX) && !p.emb_dense && p.Tp > 1 &&
+            embed_mx_supported(p.emb_d, p.W, p.B, tile_floats_for(p.W));
     Workspace w;
     rc = carve(workspace, workspace_bytes, B, k, boot_entries(p.R, p.Tp, k), &w);
     if (rc) return rc;
@@ -520,7 +554,11 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     if (flags_of(profile) & PSH_FLAG_FILTER_VALU) use_mx = use_mq = false;
     // (half-segment mode measured for the single-query scan: bootstrap 17.4 -> 12.3 us, but tau admits twice as
     // much and the scan's exact rechecks cost 4.3 us more -- 135.7 vs 134.3 us per step; left off)
-    BootPlan bp = boot_plan(p.R, p.Tp, k, false, p.ker != nullptr);
+    // (the matrix-core embedded scan samples one minimum per HALF segment; a sample too thin for that plan is taken by
+    // embed_scan_kernel instead -- the full scan still runs on the matrix cores)
+    BootPlan bp = boot_plan(p.R, p.Tp, k, p.emx, p.ker != nullptr);
+    const bool boot_emx = p.emx && bp.per_wave == 2;
+    if (p.emx && !boot_emx) bp = boot_plan(p.R, p.Tp, k, false, true);
     // one-window rows (T == W + h; PathDistance.forward_topk's N pre-embedded points): rows_kernel, a row per lane.
     // Its bootstrap takes one exact value per sampled row.
     const bool rows_path = p.Tp == 1 && !p.ker && !p.rows_generic;
@@ -603,6 +641,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     rc = plan_scan(device, p, n_sample, &plan_s); if (rc) return rc;
     ScanArgs sa = make_scan_args(dataset, queries, p, w, plan_s, row0, stride, n_sample);
     sa.boot_per_wave = bp.per_wave;
+    sa.emb_mx = boot_emx ? 1 : 0;
     sa.blockmax = (use_mx || use_mq) ? w.blockmax : nullptr;
     int n_blockmax = plan_s.grid;
     // (a single query is better served by the exact bootstrap: 8192 segments are a latency-bound launch either

@@ -849,6 +849,8 @@ static hipError_t launch_embed(const ScanArgs& a, int mode, int grid, size_t shm
 }
 
 hipError_t launch_embed_scan(const ScanArgs& a, int mode, bool aligned, int grid, hipStream_t s) {
+    if (a.emb_mx && (mode == PSH_MODE_FILTER || (mode == PSH_MODE_BOOT && a.boot_per_wave == 2)))
+        return launch_embed_mx(a, mode, aligned, grid, s);                   // psh_embed_mx.hip: dense kernel, matrix cores
     const size_t shmem = scan_shmem_bytes(a.tile_floats, a.B, a.emb_d, a.W, a.emb_wide ? PSH_EMB_WIDE_THREADS : PSH_SCAN_THREADS);
     return aligned ? launch_embed<true>(a, mode, grid, shmem, s) : launch_embed<false>(a, mode, grid, shmem, s);
 }

@@ -1,0 +1,435 @@
+// psh_embed_mx.hip -- the embedded scan for DENSE linear embeddings (wavelet banks, user kernels) with its rejection test on
+// the matrix cores: psh_scan_topk_embedded + PSH_FLAG_EMBED_MX, BOOT and FILTER stages (the exhaustive stage stays with
+// embed_scan_kernel).  Reference: path_embedding.py:117-132 (conv1d with a (d,1,K) kernel) feeding path_distance.py:62-65.
+//
+// Per window  H_i = sum_j ker[i][j] y[t+j]  (i < d)  is a Toeplitz product: (1024 windows x K taps) . (K x d).  On the vector
+// ALUs it is d*K fma per window and 4 bytes (2772 for the 11 x 252 bank of BASELINE configs[4]): 10.8 ms per 16 queries.
+// Here it runs on v_mfma_f32_16x16x32_f16, laid out so that NO operand needs an unaligned read and every lane ends up
+// with ALL d values of its windows:
+//   A  row m = the samples from window 16 m on (64 rows per segment, taken 32 at a time: two M tiles per half segment):
+//      fragment = 8 consecutive halves at 16 m + 32 ks + 8 kq -- an aligned 16-byte LDS read of the segment's f16 copy;
+//   B  one N tile PER KERNEL ROW i, its 16 columns the 16 shifts s:  B[k][s] = ker_i[k - s]  -> fragment = 8 consecutive
+//      taps at 32 ks + 8 kq - s: two aligned 8-byte reads of the copy of the row shifted by (-s) mod 4 (4 copies, hi and lo);
+//   C  tile (M tile, i), column s (the lane), row (the register): H_i of window 16 m + s.  K' = K + 15 taps in 32-tap steps.
+// A half segment (512 windows) keeps 2 x 12 tiles x 4 = 96 accumulator registers per lane -- all of them VGPRs the epilogue
+// can read (a whole segment's 192 spill: the vector ALUs cannot take AGPR operands).
+// f16 alone is too coarse (its 2^-11 per tap let ~2 % of the windows through, r01): data and kernel are SPLIT,
+// v = hi + lo (22 bits), and three products are accumulated, hi.hi + lo.hi + hi.lo (lo.lo ~ 2^-22 is dropped): per output
+//   |C_i - S H_i| <= eps * sum_j |k~_ij| |y~_j|,   eps = 3 * 2^-22 (splits, dropped term) + 3 K' * 2^-24 (fp32 accumulation
+//   of 3 K' exact products, any order) -- doubled below for whatever the unit does inside -- plus 2^-6 absolute (subnormal
+//   lo parts), S = the two power-of-two scales that put max|y| of the segment and max|ker| into [256, 512).
+// In the embedding space that is a ball of radius  R = ymax * eps * sqrt(sum_i ||ker_i||_1^2): a window survives unless
+//   acc^ > (sqrt(tau)(1 + 2^-15) + R)^2 (1 + 2^-14),  acc^ = sum_i (hx_i - H^_i)^2 = ||hx||^2 + sum_i H^_i^2 - 2 sum_i hx_i H^_i
+// (13 VALU operations per window and query, the query's 12 coordinates in SGPRs); survivors -- true candidates plus a
+// fraction of a percent -- get the exact dense chains in the oracle's order (embedded_acc), and only those values are ranked:
+// results are bit-identical to embed_scan_kernel's.  The bootstrap uses the bound the other way round (upper bounds).
+// 1296 16x16x32 MFMAs per segment (8.6 us per SIMD) against ~15 000 VALU instructions for the dense chains.
+#include "psh_device.h"
+
+namespace psh {
+
+#define PSH_EMX_THREADS 256                  // 4 waves, one per SIMD: 12 accumulator tiles = 192 registers per lane
+#define PSH_EMX_MAX_D 12
+#define PSH_EMX_PADL 16                      // zero taps in front of a kernel row (shifts reach 15 taps back)
+#define PSH_EMX_QCAP 128                     // survivors (window | query << 12) queued per wave before exact verification
+#define PSH_EMX_EPS_REL (2.0f * (3.0f / 4194304.0f))          // 2 x 3 * 2^-22; the accumulation part is added per K (below)
+
+struct EmxDims {
+    int KS;        // 32-tap steps: ceil((K + 15) / 32)
+    int CS;        // halves per shifted copy of a kernel row (zero padded on both sides), copies on different banks
+    int nhalf;     // halves of a segment's f16 copy: 1024 + 32 KS
+};
+__host__ __device__ inline EmxDims emx_dims(int K) {
+    EmxDims d;
+    d.KS = (K + 15 + 31) / 32;
+    int cs = 32 * d.KS + PSH_EMX_PADL + 8;   // the last fragment ends at 32 (KS - 1) + 24 + PADL + 7
+    cs = ((cs - 32 + 127) & ~127) + 32;      // = 32 mod 128 halves: the four copies a wave reads start 16 banks apart
+    d.CS = cs;
+    d.nhalf = 1024 + 32 * d.KS;
+    return d;
+}
+
+__host__ __device__ inline size_t emx_shmem_bytes(int K, int d, int B, int tile_floats) {
+    const EmxDims m = emx_dims(K);
+    size_t n = (size_t)PSH_EMX_MAX_D * 4 * m.CS * sizeof(_Float16) * 2;              // B operand: 12 rows x 4 shifted copies, hi and lo
+    n += (size_t)d * K * sizeof(float);                                               // the fp32 kernel (exact verification)
+    n = (n + 15) & ~(size_t)15;
+    n += (size_t)(PSH_EMX_THREADS / 64) * ((size_t)2 * m.nhalf * sizeof(_Float16) + (size_t)tile_floats * sizeof(float)
+                                           + (size_t)PSH_PEND * 16 + (size_t)PSH_EMX_QCAP * 4 + 64 * 4);
+    n += (size_t)(((B + 3) & ~3) + 8) * sizeof(int) + 64;
+    return n;
+}
+
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+
+// NG: groups of 4 kernel rows computed (ceil(d / 4)); a compile-time constant so that the product loop has NO branch around
+// its MFMAs -- with one, the accumulators are shuffled between AGPRs and VGPRs at every merge (96 + 96 moves per K step).
+template <bool ALIGNED, int MODE, int NG>
+__global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NW = PSH_EMX_THREADS / 64;
+    const int lane = lane_id();
+    const int tid = (int)threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int K = a.W, d = a.emb_d;
+    const EmxDims dm = emx_dims(K);
+    // ---- LDS carve
+    _Float16* bh = reinterpret_cast<_Float16*>(smem);                                  // [12][4][CS] hi
+    _Float16* bl = bh + (size_t)PSH_EMX_MAX_D * 4 * dm.CS;                              // [12][4][CS] lo
+    float* kerF = reinterpret_cast<float*>(bl + (size_t)PSH_EMX_MAX_D * 4 * dm.CS);     // d x K fp32
+    char* pw = reinterpret_cast<char*>(kerF) + (((size_t)d * K * 4 + 15) & ~(size_t)15);
+    const size_t per_wave = (size_t)2 * dm.nhalf * 2 + (size_t)a.tile_floats * 4 + (size_t)PSH_PEND * 16 + (size_t)PSH_EMX_QCAP * 4 + 64 * 4;
+    char* mine = pw + (size_t)wave * per_wave;
+    _Float16* yh = reinterpret_cast<_Float16*>(mine);
+    _Float16* yl = yh + dm.nhalf;
+    float* tile = reinterpret_cast<float*>(yl + dm.nhalf);
+    u32x4* pend = reinterpret_cast<u32x4*>(tile + a.tile_floats);
+    unsigned* sq = reinterpret_cast<unsigned*>(pend + PSH_PEND);
+    float* Dl = reinterpret_cast<float*>(sq + PSH_EMX_QCAP);                            // 4 survivors x 16 row differences
+    int* lcount = reinterpret_cast<int*>(pw + (size_t)NW * per_wave);
+    int* ctl = lcount + ((a.B + 3) & ~3);                                               // [0] work cursor, [1] max|ker| bits, [2..3] cerr^2 (float bits)
+    int npend = 0, nsq = 0;
+
+    // ---- per-block set-up: kernel scale, the shifted hi/lo copies of every row, the radius constant
+    if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; }
+    if (MODE == PSH_MODE_FILTER)
+        for (int q = tid; q < a.B; q += PSH_EMX_THREADS) lcount[q] = 0;
+    for (int e = tid; e < d * K; e += PSH_EMX_THREADS) kerF[e] = a.ker[e];
+    {
+        unsigned* z = reinterpret_cast<unsigned*>(yh);
+        for (int i = lane; i < dm.nhalf; i += 64) z[i] = 0u;                            // 2 arrays x nhalf halves = nhalf dwords
+    }
+    __syncthreads();
+    {
+        unsigned mb = 0u;
+        for (int e = tid; e < d * K; e += PSH_EMX_THREADS) mb = max(mb, __float_as_uint(fabsf(kerF[e])));
+        if (mb) atomicMax(reinterpret_cast<unsigned*>(&ctl[1]), mb);
+        if (tid < d) {                                                                  // ||ker_i||_1^2 summed over the rows
+            float l1 = 0.0f;
+            for (int j = 0; j < K; ++j) l1 += fabsf(kerF[tid * K + j]);
+            atomicAdd(reinterpret_cast<float*>(&ctl[2]), l1 * l1 * 1.0001f);
+        }
+    }
+    __syncthreads();
+    const unsigned kmb = (unsigned)ctl[1];
+    const int ek = kmb >= 0x00800000u ? 9 - ((int)((kmb >> 23) & 255u) - 126) : 0;      // max|ker| 2^ek in [256, 512)
+    const int ekc = ek > 100 ? 100 : (ek < -100 ? -100 : ek);
+    const float sk = __uint_as_float((unsigned)(127 + ekc) << 23);
+    for (int e = tid; e < PSH_EMX_MAX_D * 4 * dm.CS; e += PSH_EMX_THREADS) {
+        // copy c of row i:  copy[x] = L_i[x + c],  L_i[x] = ker_i[x - PADL] (zero outside [0, K))
+        const int i = e / (4 * dm.CS), rem = e - i * 4 * dm.CS, c = rem / dm.CS, x2 = rem - c * dm.CS;
+        const int j = x2 + c - PSH_EMX_PADL;
+        float v = (i < d && j >= 0 && j < K) ? kerF[i * K + j] * sk : 0.0f;
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        bh[e] = hi;
+        bl[e] = lo;
+    }
+    __syncthreads();
+    // eps: splits and the dropped lo.lo term (3 * 2^-22) + fp32 accumulation of 3 K' products (3 * 32 KS * 2^-24), doubled
+    const float eps = PSH_EMX_EPS_REL + 2.0f * (float)(3 * 32 * dm.KS) / 16777216.0f;
+    const float cerr = eps * __builtin_sqrtf(__uint_as_float((unsigned)ctl[2])) * 1.001f;
+
+    const int nfloat = PSH_SEG + K - 1;
+    const unsigned n_rs = (unsigned)a.n_rows * (unsigned)a.nseg;
+    const unsigned n_units = n_rs * (unsigned)a.n_qgroups;
+    const unsigned u_lo = (unsigned)(((unsigned long long)n_units * blockIdx.x) / gridDim.x);
+    const unsigned u_hi = (unsigned)(((unsigned long long)n_units * (blockIdx.x + 1)) / gridDim.x);
+    const const_f32p hxk = (const_f32p)a.hx;
+    typedef const __attribute__((address_space(4))) QueryState* const_qsp;
+    const const_qsp qstate_k = (const_qsp)a.qstate;
+    const int scol = lane & 15, kq = lane >> 4;                                         // column = shift s (and A row), K quarter
+
+    // exact verification of the queued survivors: lane (e, i) runs row i of survivor e (4 per pass), the oracle's order:
+    // hy_i = fma chain over all K taps, D_i = hx_i - hy_i, acc = fma chain over i
+    auto verify = [&](int seg_start, int r_global) {
+        wave_lds_fence();
+        const int el = lane >> 4, il = lane & 15;
+#pragma unroll 1
+        for (int e0 = 0; e0 < nsq; e0 += 4) {
+            const bool lv = e0 + el < nsq;
+            const unsigned ent = lv ? sq[e0 + el] : 0u;
+            const int pwin = (int)(ent & 4095u), b = (int)(ent >> 12);
+            float hy = 0.0f;
+            if (lv && il < d) {
+                const float* kr = kerF + il * K;
+                for (int j = 0; j < K; ++j) hy = __builtin_fmaf(kr[j], tile[lds_pad(pwin + j)], hy);
+                Dl[el * 16 + il] = __fsub_rn(a.hx[(int64_t)b * d + il], hy);
+            }
+            wave_lds_fence();
+            float ea = 0.0f;
+            bool hit = false;
+            if (lv && il == 0) {
+                for (int i = 0; i < d; ++i) { const float D = Dl[el * 16 + i]; ea = __builtin_fmaf(D, D, ea); }
+                hit = ea < __uint_as_float(a.qstate[b].tau2_bits);
+            }
+            const unsigned long long mask = __ballot(hit);
+            wave_lds_fence();                                // Dl is rewritten by the next pass
+            if (!mask) continue;
+            const int nh = __popcll(mask);
+            if (npend + nh > PSH_PEND) {
+                pend_flush(pend, npend, lcount, a, lane);
+                npend = 0;
+                wave_lds_fence();
+            }
+            if (hit) {
+                const int slot = npend + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                pend[slot] = u32x4{__float_as_uint(ea), (unsigned)r_global, (unsigned)(seg_start + pwin), (unsigned)b};
+            }
+            npend += nh;
+        }
+        nsq = 0;
+        wave_lds_fence();
+    };
+
+    auto grab = [&]() -> unsigned {
+        int v0 = 0;
+        if (lane == 0) v0 = atomicAdd(&ctl[0], 1);
+        return u_lo + (unsigned)__builtin_amdgcn_readfirstlane(v0);
+    };
+    auto load_unit = [&](Stage& sx, unsigned uu) {
+        const unsigned qg2 = fast_div(uu, a.magic_nrs, n_rs);
+        const unsigned rs2 = uu - qg2 * n_rs;
+        const unsigned ri2 = fast_div(rs2, a.magic_nseg, (unsigned)a.nseg);
+        const unsigned sg2 = rs2 - ri2 * (unsigned)a.nseg;
+        stage_load<ALIGNED>(sx, a.dataset + (a.row0 + (int64_t)ri2 * a.row_stride) * a.T, a.T, (int)sg2 * PSH_SEG, nfloat, lane);
+    };
+    // one segment in flight from HBM besides the one being worked on (one wave per SIMD: nothing else hides the latency)
+    Stage st;
+    unsigned u = grab();
+    if (u < u_hi) load_unit(st, u);
+    while (u < u_hi) {
+        const unsigned qgi = fast_div(u, a.magic_nrs, n_rs);
+        const unsigned rs = u - qgi * n_rs;
+        const unsigned ri = fast_div(rs, a.magic_nseg, (unsigned)a.nseg);
+        const unsigned sg = rs - ri * (unsigned)a.nseg;
+        const int64_t row = a.row0 + (int64_t)ri * a.row_stride;
+        const int seg_start = (int)sg * PSH_SEG;
+        const int r_global = (int)(row + a.r_offset);
+
+        // ---- the segment: fp32 tile (verification), scale, hi/lo f16 copies
+        float ymax = 0.0f;
+        int ey;
+        unsigned un;
+        {
+            const int nq = (nfloat + 3) >> 2;
+#pragma unroll
+            for (int q = 0; q < PSH_NSTAGE; ++q)
+                if (q < PSH_NSTAGE - 1 || lane + 64 * q < nq)
+                    ymax = fmaxf(ymax, fmaxf(fmaxf(fabsf(st.v[q][0]), fabsf(st.v[q][1])), fmaxf(fabsf(st.v[q][2]), fabsf(st.v[q][3]))));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, off, 64));
+            const unsigned yb = __float_as_uint(ymax);
+            ey = yb >= 0x00800000u ? 9 - ((int)((yb >> 23) & 255u) - 126) : 0;          // ymax 2^ey in [256, 512)
+            ey = ey > 100 ? 100 : (ey < -100 ? -100 : ey);
+            const float sy = __uint_as_float((unsigned)(127 + ey) << 23);
+            if (MODE == PSH_MODE_FILTER) stage_store(st, tile, nfloat, lane);
+#pragma unroll
+            for (int q = 0; q < PSH_NSTAGE; ++q) {
+                const int m = lane + 64 * q;
+                if (q < PSH_NSTAGE - 1 || m < nq) {
+                    const f32x4 v = st.v[q] * sy;
+                    const f16x4v hi = __builtin_convertvector(v, f16x4v);
+                    const f32x4 res = v - __builtin_convertvector(hi, f32x4);
+                    *reinterpret_cast<f16x4v*>(yh + 4 * m) = hi;
+                    *reinterpret_cast<f16x4v*>(yl + 4 * m) = __builtin_convertvector(res, f16x4v);
+                }
+            }
+            if (MODE == PSH_MODE_FILTER && npend > 0) {   // stores ahead of the prefetch: vmcnt retires in order
+                pend_flush(pend, npend, lcount, a, lane);
+                npend = 0;
+            }
+            un = grab();
+            if (un < u_hi) load_unit(st, un);
+        }
+        wave_lds_fence();
+
+        const float inv = __uint_as_float((unsigned)(127 - ey - ekc) << 23);
+        const float Rad = ymax * cerr + 1.0e-30f;
+        const int q_begin = (int)qgi * a.q_per_group;
+        const int q_end = (q_begin + a.q_per_group) < a.B ? (q_begin + a.q_per_group) : a.B;
+#pragma unroll 1
+        for (int hf = 0; hf < 2; ++hf) {
+            // ---- the banded product of a half segment: 2 M tiles x 12 kernel rows x KS steps x 3 products
+            f32x4 C[2][4 * NG];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4 * NG; ++i) C[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            {
+                const int cpy = (-scol) & 3;                                            // the copy whose fragment is 8-byte aligned for this shift
+                const _Float16* bhc = bh + (size_t)cpy * dm.CS + (PSH_EMX_PADL - scol - cpy) + 8 * kq;
+                const _Float16* blc = bl + (size_t)cpy * dm.CS + (PSH_EMX_PADL - scol - cpy) + 8 * kq;
+                const _Float16* ya = yh + 16 * (32 * hf + scol) + 8 * kq;               // A row of M tile 0: m = 32 hf + (lane & 15)
+                const _Float16* yb2 = yl + 16 * (32 * hf + scol) + 8 * kq;
+                // B fragments of a group of 4 rows: hi and lo, two 8-byte reads each
+                auto load_b = [&](f16x4v (&fb)[4][4], int g, int ks) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const _Float16* ph = bhc + (size_t)(4 * g + r4) * 4 * dm.CS + 32 * ks;
+                        const _Float16* pl = blc + (size_t)(4 * g + r4) * 4 * dm.CS + 32 * ks;
+                        fb[r4][0] = *reinterpret_cast<const f16x4v*>(ph);
+                        fb[r4][1] = *reinterpret_cast<const f16x4v*>(ph + 4);
+                        fb[r4][2] = *reinterpret_cast<const f16x4v*>(pl);
+                        fb[r4][3] = *reinterpret_cast<const f16x4v*>(pl + 4);
+                    }
+                };
+                // the 24 MFMAs of a group: the three products of a tile are 8 instructions apart (no back-to-back dependence)
+                auto mma_group = [&](const f16x4v (&fb)[4][4], int g, const f16x8& ah0, const f16x8& ah1, const f16x8& al0, const f16x8& al1) {
+                    f16x8 bhf[4], blf[4];
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        // (a concatenation of register pairs, not eight element moves: built element by element the fragments cost
+                        //  ~5700 VALU instructions per segment, 1.5 ms of a 3.5 ms scan)
+                        bhf[r4] = __builtin_shufflevector(fb[r4][0], fb[r4][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                        blf[r4] = __builtin_shufflevector(fb[r4][2], fb[r4][3], 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        C[0][4 * g + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bhf[r4], C[0][4 * g + r4], 0, 0, 0);
+                        C[1][4 * g + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bhf[r4], C[1][4 * g + r4], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        C[0][4 * g + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bhf[r4], C[0][4 * g + r4], 0, 0, 0);
+                        C[1][4 * g + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bhf[r4], C[1][4 * g + r4], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        C[0][4 * g + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, blf[r4], C[0][4 * g + r4], 0, 0, 0);
+                        C[1][4 * g + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, blf[r4], C[1][4 * g + r4], 0, 0, 0);
+                    }
+                };
+#pragma unroll 1
+                for (int ks = 0; ks < dm.KS; ++ks) {
+                    const f16x8 ah0 = *reinterpret_cast<const f16x8*>(ya + 32 * ks), ah1 = *reinterpret_cast<const f16x8*>(ya + 256 + 32 * ks);
+                    const f16x8 al0 = *reinterpret_cast<const f16x8*>(yb2 + 32 * ks), al1 = *reinterpret_cast<const f16x8*>(yb2 + 256 + 32 * ks);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {                                      // (rows >= d of the last group: zero copies)
+                        f16x4v fb[4][4];
+                        load_b(fb, g, ks);
+                        mma_group(fb, g, ah0, ah1, al0, al1);
+                    }
+                }
+            }
+            // ---- back to the data's units; ||H||^2 per window.  Slot (mt, r) of the lane: window 16 (32 hf + 16 mt + 4 kq + r) + scol
+            float nh[8];
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) nh[sl] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4 * NG; ++i) {                                         // (rows >= d: zero copies of the kernel -> exact zeros)
+#pragma unroll
+                for (int sl = 0; sl < 8; ++sl) { C[sl >> 2][i][sl & 3] *= inv; nh[sl] = __builtin_fmaf(C[sl >> 2][i][sl & 3], C[sl >> 2][i][sl & 3], nh[sl]); }
+            }
+            unsigned vmask = 0u;                                                        // bit sl: the slot's window is admissible
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) {
+                const int p = 16 * (32 * hf + 16 * (sl >> 2) + 4 * kq + (sl & 3)) + scol;
+                vmask |= (seg_start + p < a.Tp) ? (1u << sl) : 0u;
+            }
+            // the query's coordinates and level come through the scalar cache, one query AHEAD of their use (one wave per SIMD:
+            // nothing else would hide the load)
+            float hnx[4 * NG];
+            unsigned taunx = 0u;
+            auto fetch_query = [&](int bq) {
+#pragma unroll
+                for (int i = 0; i < 4 * NG; ++i) hnx[i] = hxk[(int64_t)bq * d + (i < d ? i : 0)];
+                if (MODE == PSH_MODE_FILTER) taunx = qstate_k[bq].tau2_bits;
+            };
+            if (q_begin < q_end) fetch_query(q_begin);
+#pragma unroll 1
+            for (int b = q_begin; b < q_end; ++b) {
+                float hxs[4 * NG];
+                float nx = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4 * NG; ++i) {
+                    hxs[i] = i < d ? hnx[i] : 0.0f;
+                    asm volatile("" : "+v"(hxs[i]));                                    // a VGPR copy: an fma with an SGPR operand issues at ~0.6 of the rate (ubench_dot2)
+                    nx = __builtin_fmaf(hxs[i], hxs[i], nx);
+                }
+                const unsigned tau_bits = taunx;
+                if (b + 1 < q_end) fetch_query(b + 1);
+                // acc^ = nx + nh - 2 sum_i hx_i H_i
+                float accv[8];
+                float mn = __uint_as_float(PSH_INF_BITS);
+#pragma unroll
+                for (int sl = 0; sl < 8; ++sl) {
+                    float c = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 4 * NG; ++i) c = __builtin_fmaf(hxs[i], C[sl >> 2][i][sl & 3], c);
+                    float v = __builtin_fmaf(-2.0f, c, nh[sl] + nx);
+                    v = v > 0.0f ? v : 0.0f;                                            // (cancellation can leave a tiny negative)
+                    accv[sl] = v;
+                    mn = ((vmask >> sl) & 1u) ? fminf(mn, v) : mn;
+                }
+                if (MODE == PSH_MODE_BOOT) {
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off, 64));
+                    // one minimum per HALF segment (the launch plan's boot_per_wave == 2): an upper bound of the exact acc of
+                    // the half's best window
+                    const float su = __builtin_sqrtf(mn) * (1.0f + 1.0f / 32768.0f) + Rad;
+                    const float ub = su * su * (1.0f + 1.0f / 16384.0f);
+                    if (lane == 0) a.minbuf[(int64_t)b * a.min_stride + 2 * (int64_t)rs + hf] = ub;
+                } else {
+                    const float tau = __uint_as_float(tau_bits);
+                    const float st2 = __builtin_sqrtf(tau) * (1.0f + 1.0f / 32768.0f) + Rad;
+                    const float thr = st2 * st2 * (1.0f + 1.0f / 16384.0f);
+                    if (!__any(!(mn > thr))) continue;                                  // the common case: nothing of this query here
+                    unsigned hm = 0u;
+#pragma unroll
+                    for (int sl = 0; sl < 8; ++sl) hm |= (((vmask >> sl) & 1u) && !(accv[sl] > thr)) ? (1u << sl) : 0u;
+                    while (__any(hm != 0u)) {
+                        const bool has = hm != 0u;
+                        const int sl = has ? (int)__builtin_ctz(hm) : 0;
+                        hm &= hm - 1u;
+                        const unsigned long long sm = __ballot(has);
+                        const int ne = __popcll(sm);
+                        if (nsq + ne > PSH_EMX_QCAP) verify(seg_start, r_global);
+                        if (has) {
+                            const int p = 16 * (32 * hf + 16 * (sl >> 2) + 4 * kq + (sl & 3)) + scol;
+                            sq[nsq + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u))] =
+                                (unsigned)p | ((unsigned)b << 12);
+                        }
+                        nsq += ne;
+                    }
+                }
+            }
+        }
+        if (MODE == PSH_MODE_FILTER && nsq > 0) verify(seg_start, r_global);           // before the tile is overwritten
+        wave_lds_fence();
+        u = un;
+    }
+    if (MODE == PSH_MODE_FILTER) {
+        if (npend > 0) pend_flush(pend, npend, lcount, a, lane);
+        __syncthreads();
+        for (int q = tid; q < a.B; q += PSH_EMX_THREADS) a.bcount[(int64_t)q * PSH_MAX_BLOCKS + blockIdx.x] = lcount[q];
+    }
+}
+
+bool embed_mx_supported(int d, int K, int B, int tile_floats) {
+    return d >= 1 && d <= PSH_EMX_MAX_D && K >= 1 && K <= 256 && emx_shmem_bytes(K, d, B, tile_floats) <= PSH_LDS_BYTES;
+}
+
+template <bool ALIGNED, int MODE, int NG>
+static hipError_t launch_emx_ng(const ScanArgs& a, int grid, hipStream_t s) {
+    const size_t shmem = emx_shmem_bytes(a.W, a.emb_d, a.B, a.tile_floats);
+    hipError_t e = hipFuncSetAttribute((const void*)embed_mx_kernel<ALIGNED, MODE, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((embed_mx_kernel<ALIGNED, MODE, NG>), dim3(grid), dim3(PSH_EMX_THREADS), shmem, s, a);
+    return hipGetLastError();
+}
+
+template <bool ALIGNED, int MODE>
+static hipError_t launch_emx(const ScanArgs& a, int grid, hipStream_t s) {
+    const int ng = (a.emb_d + 3) >> 2;
+    return ng == 1 ? launch_emx_ng<ALIGNED, MODE, 1>(a, grid, s) : ng == 2 ? launch_emx_ng<ALIGNED, MODE, 2>(a, grid, s)
+                                                                          : launch_emx_ng<ALIGNED, MODE, 3>(a, grid, s);
+}
+
+hipError_t launch_embed_mx(const ScanArgs& a, int mode, bool aligned, int grid, hipStream_t s) {
+    if (mode == PSH_MODE_BOOT) return aligned ? launch_emx<true, PSH_MODE_BOOT>(a, grid, s) : launch_emx<false, PSH_MODE_BOOT>(a, grid, s);
+    return aligned ? launch_emx<true, PSH_MODE_FILTER>(a, grid, s) : launch_emx<false, PSH_MODE_FILTER>(a, grid, s);
+}
+
+}  // namespace psh

@@ -118,6 +118,7 @@ struct ScanArgs {
     int emb_d;
     int emb_wide;            // embedded scan: the 512-thread instantiation (launchers, plan)
     int emb_dense;           // embedded scan: always the dense chains, even when the kernel has suffix rows (tests, PSH_EMBED=dense)
+    int emb_mx;              // embedded scan: the dense kernel's rejection test on the matrix cores (embed_mx_kernel: BOOT / FILTER)
 };
 
 #define PSH_EMB_MAX_D 128            // embedding rows handled natively
@@ -205,6 +206,8 @@ hipError_t launch_qnorm(const float* q, int B, int W, float* out, hipStream_t s)
 hipError_t launch_scan(const ScanArgs& a, int mode, bool aligned, int grid, hipStream_t s);
 hipError_t launch_embed_scan(const ScanArgs& a, int mode, bool aligned, int grid, hipStream_t s);   // psh_embed.hip; launch_scan routes a.ker != nullptr here
 hipError_t embed_blocks_per_cu(bool aligned, size_t shmem, int* out);
+bool embed_mx_supported(int d, int K, int B, int tile_floats);          // psh_embed_mx.hip: dense kernels, rejection test on the matrix cores
+hipError_t launch_embed_mx(const ScanArgs& a, int mode, bool aligned, int grid, hipStream_t s);   // BOOT (half-segment minima) / FILTER
 size_t scan_shmem_bytes(int tile_floats, int B, int emb_d, int W, int threads = PSH_SCAN_THREADS);
 #define PSH_EMB_WIDE_MIN_B 7          // embedded scan, this many queries and more: 512-thread blocks carrying 10 (6) queries per pass
 size_t scan_mx_shmem_bytes(int tile_floats, int B);

@@ -40,7 +40,7 @@ def _native_local_topk(ds2d: torch.Tensor, q: torch.Tensor, k: int, h: int, r_of
             return _native.scan_topk(ds2d, qq, k, h=h, r_offset=r_offset, workspace=workspace, out=out_,
                                      exhaustive=exhaustive, unsorted=unsorted, flags=flags)
         return _native.scan_topk_embedded(ds2d, ker, qq, k, h=h, r_offset=r_offset, workspace=workspace, out=out_,
-                                          exhaustive=exhaustive)
+                                          exhaustive=exhaustive, flags=flags & _native.FLAG_EMBED_MX)
     if check and ker is None:    # one host sync: the status protocol (fused launch gave up -> separate launches; overflow -> exact)
         d, idx = _native.scan_topk_checked(ds2d, q, k, h=h, r_offset=r_offset, workspace=workspace, out=out, unsorted=unsorted,
                                            flags=flags)
@@ -122,6 +122,8 @@ class ShardedPathShadowing:
             self._workspace = _native.Workspace(device)
             if self._linear:
                 self._ker = embedding.kernel[:, 0, :].to(device=device, dtype=torch.float32).contiguous()
+                from .path_embedding import Foveal
+                self._emb_flags = 0 if isinstance(embedding, Foveal) else _native.FLAG_EMBED_MX
         else:
             self._workspace = None
         self.dataset = ds.contiguous()
@@ -245,7 +247,7 @@ class ShardedPathShadowing:
             comm = self._library_exchange() if library else None
             d, idx, self.last_status = self.local_scan(q, k, out=out, check=check, unsorted=exchange and not sorted_merge,
                                                        flags=(_native.FLAG_RESERVE_CUS if library else 0)
-                                                       | (0 if self.fuse else _native.FLAG_NO_FUSE))
+                                                       | (0 if self.fuse else _native.FLAG_NO_FUSE) | getattr(self, "_emb_flags", 0))
             if d.data_ptr() != out[0].data_ptr():     # shard smaller than k: padded copies were made
                 out[0].copy_(d)
                 out[1].copy_(idx)
@@ -269,7 +271,7 @@ class ShardedPathShadowing:
             gathered = torch.empty((G, 3 * B * k), dtype=torch.int32, device=self.device)
             work = dist.all_gather_into_tensor(gathered.view(-1), send, group=self.group, async_op=True)
             return PendingScan(self, work, (send, gathered, "sorted" if sorted_merge else "general"), None, B, k)
-        d, idx, self.last_status = self.local_scan(q, k, check=check)
+        d, idx, self.last_status = self.local_scan(q, k, check=check, flags=getattr(self, "_emb_flags", 0))
         if not exchange:
             return PendingScan(self, None, None, (d, idx), B, k)
         # generic form (CPU tests, odd B*k): pack (d, r, t) as 3 x int32, one all-gather

@@ -36,7 +36,7 @@ from tqdm import tqdm
 from . import _native
 from .averaging import HAVE_SCATSPECTRA, DiscreteProba, Softmax, Uniform
 from .path_distance import PathDistance, RelativeMSE
-from .path_embedding import (ArrayType, ContextManagerBase, CrossChannelContext, Identity, ImputationContext,
+from .path_embedding import (ArrayType, ContextManagerBase, CrossChannelContext, Foveal, Identity, ImputationContext,
                              PathEmbedding, PredictionContext)
 
 
@@ -296,10 +296,14 @@ class PathShadowing:
                 d, idx = _native.scan_topk_checked(points, hx, k, h=0, workspace=self._workspace)
                 return d, idx, ds
             else:
+                # a kernel without Foveal's suffix structure (a filter bank, a user kernel): the rejection test on the
+                # matrix cores (the library cannot look at the matrix without a synchronisation: the caller says which it is)
+                fl = 0 if isinstance(self.embedding, Foveal) else _native.FLAG_EMBED_MX
+
                 def scan(sel, exhaustive):
                     q = hx if sel is None else hx[sel].contiguous()
                     return _native.scan_topk_embedded(rows, ker2, q, k, h=h, workspace=self._workspace,
-                                                      exhaustive=exhaustive)
+                                                      exhaustive=exhaustive, flags=fl)
         else:
             xq = x[:, 0, :].contiguous().to(dev)
             d, idx = _native.scan_topk_checked(rows, xq, k, h=h, workspace=self._workspace)

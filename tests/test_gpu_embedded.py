@@ -238,6 +238,58 @@ def test_kernel_matrix_larger_than_sixteen_tiles_allow(hip_device, oracle_mod):
     assert_exact(d, idx, od, oidx, "Foveal max_context 252")
 
 
+@pytest.mark.parametrize("R,T,d,K,h,k,B,kind", [
+    (2048, 2048, 11, 252, 20, 200, 3, "wavelet"),     # BASELINE configs[4]'s bank: three row groups, nine 32-tap steps
+    (4096, 1024, 5, 23, 7, 100, 2, "dense"),          # two row groups (rows 5..7 zero), one step
+    (3000, 1100, 12, 64, 3, 300, 5, "dense"),         # d = 12: every tile used; ragged last segment
+    (5000, 515, 1, 7, 0, 50, 1, "dense"),             # one row; unaligned rows (T % 4 != 0)
+    (4096, 4096, 11, 252, 20, 1024, 16, "wavelet"),   # configs[4]'s query batch
+    (1500, 1200, 9, 256, 0, 64, 2, "dense"),          # PSH_MAX_W taps
+    (20000, 300, 4, 16, 5, 400, 1, "dense"),          # short rows: one segment each, mostly inadmissible windows
+])
+def test_dense_kernel_on_the_matrix_cores_equals_oracle(hip_device, oracle_mod, R, T, d, K, h, k, B, kind):
+    """PSH_FLAG_EMBED_MX (embed_mx_kernel: hi/lo f16 banded product as the rejection test, exact dense chains for the
+    survivors): bit for bit the oracle, and the same candidates decide as without the flag."""
+    from shadowing_amd import _native
+    ds = syn.dataset(R, T, 500 + R)
+    if kind == "wavelet":
+        ker = syn.wavelet_bank((d - 1) // 2, K)
+    else:
+        ker = (np.random.default_rng(600 + d).standard_normal((d, K)) * 0.3).astype(np.float32)
+        ker[:, ::3] *= 1e-3                                   # a wide dynamic range inside the rows: the lo parts matter
+    x = syn.gbm_log_returns((B, K), 700 + K)
+    hx = torch.nn.functional.conv1d(torch.tensor(x)[:, None, :], torch.tensor(ker)[:, None, :])[:, :, 0].numpy()
+    dd, idx, status, prof = hip_scan_embedded(hip_device, ds, ker, hx, k, h, profile=True, flags=_native.FLAG_EMBED_MX)
+    if status.any():
+        bad = np.nonzero(status)[0]
+        d2, i2, _, _ = hip_scan_embedded(hip_device, ds, ker, hx[bad], k, h, exhaustive=True)
+        dd[bad], idx[bad] = d2, i2
+    od, oidx = oracle_mod.scan_topk_embedded(ds, ker, hx, k, h=h)
+    assert_exact(dd, idx, od, oidx, f"embed_mx {(R, T, d, K, h, k, B, kind)}")
+    if prof["path"] == 0 and not status.any():
+        assert prof["n_candidates"] >= k              # (its bootstrap samples half segments: another estimate than the plain scan's)
+
+
+def test_dense_kernel_on_the_matrix_cores_with_awkward_magnitudes(hip_device, oracle_mod):
+    """Scales far from one (data 1e-9, kernel 1e+6), a kernel row of zeros, one loud row in the ensemble: the per-segment
+    and per-kernel power-of-two scales keep the split exact where it has to be."""
+    from shadowing_amd import _native
+    R, T, d, K, h, k, B = 3000, 1024, 7, 40, 4, 150, 3
+    ds = (syn.dataset(R, T, 801) * np.float32(1e-9)).astype(np.float32)
+    ds[77] *= np.float32(1e4)
+    ker = (np.random.default_rng(802).standard_normal((d, K)) * 1e6).astype(np.float32)
+    ker[3] = 0.0
+    x = (syn.gbm_log_returns((B, K), 803) * np.float32(1e-9)).astype(np.float32)
+    hx = torch.nn.functional.conv1d(torch.tensor(x)[:, None, :], torch.tensor(ker)[:, None, :])[:, :, 0].numpy()
+    dd, idx, status, _ = hip_scan_embedded(hip_device, ds, ker, hx, k, h, flags=_native.FLAG_EMBED_MX)
+    if status.any():
+        bad = np.nonzero(status)[0]
+        d2, i2, _, _ = hip_scan_embedded(hip_device, ds, ker, hx[bad], k, h, exhaustive=True)
+        dd[bad], idx[bad] = d2, i2
+    od, oidx = oracle_mod.scan_topk_embedded(ds, ker, hx, k, h=h)
+    assert_exact(dd, idx, od, oidx, "embed_mx, awkward magnitudes")
+
+
 # ---- through the reference's own API -----------------------------------------------------------------
 @pytest.mark.parametrize("name", ["foveal_tutorial_small", "user_kernel_d5_K23", "foveal_ragged_B7"])
 def test_path_shadowing_with_linear_embedding_runs_native(hip_device, name):

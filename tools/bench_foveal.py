@@ -54,21 +54,26 @@ def main():
             hxw = torch.nn.functional.conv1d(xq[:, None, :], wk[:, None, :])[:, :, 0].contiguous().to(dev)
             kw = wk.contiguous().to(dev)
             ws = _native.Workspace(dev)
-            out = _native.scan_topk_embedded(ds[:, 0, :], kw, hxw, c["k"], h=c["h"], workspace=ws, profile=True)
+            mxf = _native.FLAG_EMBED_MX            # a dense kernel: rejection test on the matrix cores (what PathShadowing passes)
+            out = _native.scan_topk_embedded(ds[:, 0, :], kw, hxw, c["k"], h=c["h"], workspace=ws, profile=True, flags=mxf)
             assert int(out[2].max()) == 0, "overflow"
-            for _ in range(2):
-                _native.scan_topk_embedded(ds[:, 0, :], kw, hxw, c["k"], h=c["h"], workspace=ws)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
             nst = max(2, args.steps // 4)
-            for _ in range(nst):
-                _native.scan_topk_embedded(ds[:, 0, :], kw, hxw, c["k"], h=c["h"], workspace=ws)
-            torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) / nst * 1e3
+            ms_by = {}
+            for label, fl in (("matrix_cores", mxf), ("valu_dense_chains", 0)):
+                for _ in range(2):
+                    _native.scan_topk_embedded(ds[:, 0, :], kw, hxw, c["k"], h=c["h"], workspace=ws, flags=fl)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(nst):
+                    _native.scan_topk_embedded(ds[:, 0, :], kw, hxw, c["k"], h=c["h"], workspace=ws, flags=fl)
+                torch.cuda.synchronize()
+                ms_by[label] = (time.perf_counter() - t0) / nst * 1e3
+            ms = ms_by["matrix_cores"]
             windows = c["R"] * (c["T"] - 252 - c["h"] + 1)
             print(json.dumps(dict(workload="wavelet (BASELINE.json configs[4], per GPU)", config=c,
                                   embedding=f"wavelet_bank(5, 252): d={wk.shape[0]}, {int((wk != 0).sum())} non-zero taps",
-                                  ms_per_call=round(ms, 3), windows=windows, query_windows_per_s=windows * c["B"] / (ms * 1e-3),
+                                  ms_per_call=round(ms, 3), ms_per_call_valu_dense_chains=round(ms_by["valu_dense_chains"], 3),
+                                  windows=windows, query_windows_per_s=windows * c["B"] / (ms * 1e-3),
                                   stages_ms={k2: round(v, 4) for k2, v in out[3].items() if k2.endswith("_ms")},
                                   n_candidates=out[3]["n_candidates"])))
             continue
