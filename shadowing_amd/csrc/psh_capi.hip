@@ -213,12 +213,12 @@ int plan_scan(int device, const Problem& p, int64_t n_rows, Plan* plan) {
     // embedding (256 VGPRs, one block per CU)
     const Tuning tn = tuning();
     if (p.emx) {
-        // embed_mx_kernel: 4 waves (one per SIMD), one block per CU
+        // embed_mx_kernel: 8 waves (two per SIMD), one block per CU
         int ncu = 0;
         HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
         const int nseg = (int)((p.Tp + PSH_SEG - 1) / PSH_SEG);
         const int64_t n_rs = n_rows * nseg;
-        const int64_t waves = (int64_t)ncu * 4;
+        const int64_t waves = (int64_t)ncu * 8;
         int n_qgroups = 1;
         if (n_rs < waves && p.B > 1) {
             int64_t g = (waves + n_rs - 1) / n_rs;
@@ -228,7 +228,7 @@ int plan_scan(int device, const Problem& p, int64_t n_rows, Plan* plan) {
         n_qgroups = (p.B + q_per_group - 1) / q_per_group;
         const int64_t units = n_rs * n_qgroups;
         if (units >= (1ll << 31)) return PSH_ERR_UNSUPPORTED;
-        int64_t grid = (units + 3) / 4;
+        int64_t grid = (units + 7) / 8;
         if (grid > ncu) grid = ncu;
         if (grid > PSH_MAX_BLOCKS) grid = PSH_MAX_BLOCKS;
         if (grid < 1) grid = 1;

@@ -28,7 +28,8 @@
 
 namespace psh {
 
-#define PSH_EMX_THREADS 256                  // 4 waves, one per SIMD: 12 accumulator tiles = 192 registers per lane
+#define PSH_EMX_THREADS 512                  // 8 waves, two per SIMD: one wave's epilogue / conversion runs beside the other's MFMAs
+#define PSH_EMX_TILE 0                       // fp32 copy of the segment in LDS for the exact verification (0: the survivors' windows are re-read from global memory)
 #define PSH_EMX_MAX_D 12
 #define PSH_EMX_PADL 16                      // zero taps in front of a kernel row (shifts reach 15 taps back)
 #define PSH_EMX_QCAP 128                     // survivors (window | query << 12) queued per wave before exact verification
@@ -43,9 +44,10 @@ __host__ __device__ inline EmxDims emx_dims(int K) {
     EmxDims d;
     d.KS = (K + 15 + 31) / 32;
     int cs = 32 * d.KS + PSH_EMX_PADL + 8;   // the last fragment ends at 32 (KS - 1) + 24 + PADL + 7
-    cs = ((cs - 32 + 127) & ~127) + 32;      // = 32 mod 128 halves: the four copies a wave reads start 16 banks apart
+    if ((cs & 31) == 0) cs += 8;             // (measured: a bank-aligned stride, 32 mod 128 halves, and padded A rows change nothing)
     d.CS = cs;
     d.nhalf = 1024 + 32 * d.KS;
+
     return d;
 }
 
@@ -54,12 +56,14 @@ __host__ __device__ inline size_t emx_shmem_bytes(int K, int d, int B, int tile_
     size_t n = (size_t)PSH_EMX_MAX_D * 4 * m.CS * sizeof(_Float16) * 2;              // B operand: 12 rows x 4 shifted copies, hi and lo
     n += (size_t)d * K * sizeof(float);                                               // the fp32 kernel (exact verification)
     n = (n + 15) & ~(size_t)15;
-    n += (size_t)(PSH_EMX_THREADS / 64) * ((size_t)2 * m.nhalf * sizeof(_Float16) + (size_t)tile_floats * sizeof(float)
+    n += (size_t)(PSH_EMX_THREADS / 64) * ((size_t)2 * m.nhalf * sizeof(_Float16) + (size_t)(PSH_EMX_TILE ? tile_floats : 0) * sizeof(float)
                                            + (size_t)PSH_PEND * 16 + (size_t)PSH_EMX_QCAP * 4 + 64 * 4);
     n += (size_t)(((B + 3) & ~3) + 8) * sizeof(int) + 64;
     return n;
 }
 
+// logical half index -> padded LDS index (8 halves of padding per 256)
+__device__ __forceinline__ int emx_pad(int p) { return p; }
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
 
@@ -79,12 +83,13 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
     _Float16* bl = bh + (size_t)PSH_EMX_MAX_D * 4 * dm.CS;                              // [12][4][CS] lo
     float* kerF = reinterpret_cast<float*>(bl + (size_t)PSH_EMX_MAX_D * 4 * dm.CS);     // d x K fp32
     char* pw = reinterpret_cast<char*>(kerF) + (((size_t)d * K * 4 + 15) & ~(size_t)15);
-    const size_t per_wave = (size_t)2 * dm.nhalf * 2 + (size_t)a.tile_floats * 4 + (size_t)PSH_PEND * 16 + (size_t)PSH_EMX_QCAP * 4 + 64 * 4;
+    const int tile_fl = PSH_EMX_TILE ? a.tile_floats : 0;
+    const size_t per_wave = (size_t)2 * dm.nhalf * 2 + (size_t)tile_fl * 4 + (size_t)PSH_PEND * 16 + (size_t)PSH_EMX_QCAP * 4 + 64 * 4;
     char* mine = pw + (size_t)wave * per_wave;
     _Float16* yh = reinterpret_cast<_Float16*>(mine);
     _Float16* yl = yh + dm.nhalf;
     float* tile = reinterpret_cast<float*>(yl + dm.nhalf);
-    u32x4* pend = reinterpret_cast<u32x4*>(tile + a.tile_floats);
+    u32x4* pend = reinterpret_cast<u32x4*>(tile + tile_fl);
     unsigned* sq = reinterpret_cast<unsigned*>(pend + PSH_PEND);
     float* Dl = reinterpret_cast<float*>(sq + PSH_EMX_QCAP);                            // 4 survivors x 16 row differences
     int* lcount = reinterpret_cast<int*>(pw + (size_t)NW * per_wave);
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
 
     // exact verification of the queued survivors: lane (e, i) runs row i of survivor e (4 per pass), the oracle's order:
     // hy_i = fma chain over all K taps, D_i = hx_i - hy_i, acc = fma chain over i
-    auto verify = [&](int seg_start, int r_global) {
+    auto verify = [&](int seg_start, int r_global, const float* yrow) {
         wave_lds_fence();
         const int el = lane >> 4, il = lane & 15;
 #pragma unroll 1
@@ -154,7 +159,8 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
             float hy = 0.0f;
             if (lv && il < d) {
                 const float* kr = kerF + il * K;
-                for (int j = 0; j < K; ++j) hy = __builtin_fmaf(kr[j], tile[lds_pad(pwin + j)], hy);
+                if (PSH_EMX_TILE) { for (int j = 0; j < K; ++j) hy = __builtin_fmaf(kr[j], tile[lds_pad(pwin + j)], hy); }
+                else { const float* yw = yrow + seg_start + pwin; for (int j = 0; j < K; ++j) hy = __builtin_fmaf(kr[j], yw[j], hy); }
                 Dl[el * 16 + il] = __fsub_rn(a.hx[(int64_t)b * d + il], hy);
             }
             wave_lds_fence();
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
             ey = yb >= 0x00800000u ? 9 - ((int)((yb >> 23) & 255u) - 126) : 0;          // ymax 2^ey in [256, 512)
             ey = ey > 100 ? 100 : (ey < -100 ? -100 : ey);
             const float sy = __uint_as_float((unsigned)(127 + ey) << 23);
-            if (MODE == PSH_MODE_FILTER) stage_store(st, tile, nfloat, lane);
+            if (MODE == PSH_MODE_FILTER && PSH_EMX_TILE) stage_store(st, tile, nfloat, lane);
 #pragma unroll
             for (int q = 0; q < PSH_NSTAGE; ++q) {
                 const int m = lane + 64 * q;
@@ -232,8 +238,8 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                     const f32x4 v = st.v[q] * sy;
                     const f16x4v hi = __builtin_convertvector(v, f16x4v);
                     const f32x4 res = v - __builtin_convertvector(hi, f32x4);
-                    *reinterpret_cast<f16x4v*>(yh + 4 * m) = hi;
-                    *reinterpret_cast<f16x4v*>(yl + 4 * m) = __builtin_convertvector(res, f16x4v);
+                    *reinterpret_cast<f16x4v*>(yh + emx_pad(4 * m)) = hi;
+                    *reinterpret_cast<f16x4v*>(yl + emx_pad(4 * m)) = __builtin_convertvector(res, f16x4v);
                 }
             }
             if (MODE == PSH_MODE_FILTER && npend > 0) {   // stores ahead of the prefetch: vmcnt retires in order
@@ -261,8 +267,7 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                 const int cpy = (-scol) & 3;                                            // the copy whose fragment is 8-byte aligned for this shift
                 const _Float16* bhc = bh + (size_t)cpy * dm.CS + (PSH_EMX_PADL - scol - cpy) + 8 * kq;
                 const _Float16* blc = bl + (size_t)cpy * dm.CS + (PSH_EMX_PADL - scol - cpy) + 8 * kq;
-                const _Float16* ya = yh + 16 * (32 * hf + scol) + 8 * kq;               // A row of M tile 0: m = 32 hf + (lane & 15)
-                const _Float16* yb2 = yl + 16 * (32 * hf + scol) + 8 * kq;
+                const int arow = 16 * (32 * hf + scol) + 8 * kq;                        // A row of M tile 0: m = 32 hf + (lane & 15)
                 // B fragments of a group of 4 rows: hi and lo, two 8-byte reads each
                 auto load_b = [&](f16x4v (&fb)[4][4], int g, int ks) {
 #pragma unroll
@@ -303,8 +308,9 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                 };
 #pragma unroll 1
                 for (int ks = 0; ks < dm.KS; ++ks) {
-                    const f16x8 ah0 = *reinterpret_cast<const f16x8*>(ya + 32 * ks), ah1 = *reinterpret_cast<const f16x8*>(ya + 256 + 32 * ks);
-                    const f16x8 al0 = *reinterpret_cast<const f16x8*>(yb2 + 32 * ks), al1 = *reinterpret_cast<const f16x8*>(yb2 + 256 + 32 * ks);
+                    const int p0 = emx_pad(arow + 32 * ks), p1 = emx_pad(arow + 256 + 32 * ks);
+                    const f16x8 ah0 = *reinterpret_cast<const f16x8*>(yh + p0), ah1 = *reinterpret_cast<const f16x8*>(yh + p1);
+                    const f16x8 al0 = *reinterpret_cast<const f16x8*>(yl + p0), al1 = *reinterpret_cast<const f16x8*>(yl + p1);
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {                                      // (rows >= d of the last group: zero copies)
                         f16x4v fb[4][4];
@@ -322,11 +328,10 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
 #pragma unroll
                 for (int sl = 0; sl < 8; ++sl) { C[sl >> 2][i][sl & 3] *= inv; nh[sl] = __builtin_fmaf(C[sl >> 2][i][sl & 3], C[sl >> 2][i][sl & 3], nh[sl]); }
             }
-            unsigned vmask = 0u;                                                        // bit sl: the slot's window is admissible
 #pragma unroll
-            for (int sl = 0; sl < 8; ++sl) {
+            for (int sl = 0; sl < 8; ++sl) {                                            // an inadmissible window never wins, never survives
                 const int p = 16 * (32 * hf + 16 * (sl >> 2) + 4 * kq + (sl & 3)) + scol;
-                vmask |= (seg_start + p < a.Tp) ? (1u << sl) : 0u;
+                nh[sl] = (seg_start + p < a.Tp) ? nh[sl] : __uint_as_float(PSH_INF_BITS);
             }
             // the query's coordinates and level come through the scalar cache, one query AHEAD of their use (one wave per SIMD:
             // nothing else would hide the load)
@@ -350,42 +355,43 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                 }
                 const unsigned tau_bits = taunx;
                 if (b + 1 < q_end) fetch_query(b + 1);
-                // acc^ = nx + nh - 2 sum_i hx_i H_i
-                float accv[8];
-                float mn = __uint_as_float(PSH_INF_BITS);
-#pragma unroll
-                for (int sl = 0; sl < 8; ++sl) {
+                // acc^ - nx = nh - 2 sum_i hx_i H_i  (nh of an inadmissible window is +inf: it never wins a minimum, never survives);
+                // 13 operations per window and query -- the minimum alone is kept, the rare wave that holds a survivor goes
+                // through its slots again
+                auto vslot = [&](int sl) -> float {
                     float c = 0.0f;
 #pragma unroll
                     for (int i = 0; i < 4 * NG; ++i) c = __builtin_fmaf(hxs[i], C[sl >> 2][i][sl & 3], c);
-                    float v = __builtin_fmaf(-2.0f, c, nh[sl] + nx);
-                    v = v > 0.0f ? v : 0.0f;                                            // (cancellation can leave a tiny negative)
-                    accv[sl] = v;
-                    mn = ((vmask >> sl) & 1u) ? fminf(mn, v) : mn;
-                }
+                    return __builtin_fmaf(-2.0f, c, nh[sl]);
+                };
+                float mn = vslot(0);
+#pragma unroll
+                for (int sl = 1; sl < 8; ++sl) mn = fminf(mn, vslot(sl));
                 if (MODE == PSH_MODE_BOOT) {
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off, 64));
                     // one minimum per HALF segment (the launch plan's boot_per_wave == 2): an upper bound of the exact acc of
                     // the half's best window
-                    const float su = __builtin_sqrtf(mn) * (1.0f + 1.0f / 32768.0f) + Rad;
+                    float m2 = mn + nx;
+                    m2 = m2 > 0.0f ? m2 : 0.0f;                                         // (cancellation can leave a tiny negative)
+                    const float su = __builtin_sqrtf(m2) * (1.0f + 1.0f / 32768.0f) + Rad;
                     const float ub = su * su * (1.0f + 1.0f / 16384.0f);
                     if (lane == 0) a.minbuf[(int64_t)b * a.min_stride + 2 * (int64_t)rs + hf] = ub;
                 } else {
                     const float tau = __uint_as_float(tau_bits);
                     const float st2 = __builtin_sqrtf(tau) * (1.0f + 1.0f / 32768.0f) + Rad;
-                    const float thr = st2 * st2 * (1.0f + 1.0f / 16384.0f);
+                    const float thr = st2 * st2 * (1.0f + 1.0f / 16384.0f) - nx * (1.0f - 1.0f / 4194304.0f);   // compared with acc^ - nx (rounded towards "keep")
                     if (!__any(!(mn > thr))) continue;                                  // the common case: nothing of this query here
                     unsigned hm = 0u;
 #pragma unroll
-                    for (int sl = 0; sl < 8; ++sl) hm |= (((vmask >> sl) & 1u) && !(accv[sl] > thr)) ? (1u << sl) : 0u;
+                    for (int sl = 0; sl < 8; ++sl) hm |= !(vslot(sl) > thr) ? (1u << sl) : 0u;
                     while (__any(hm != 0u)) {
                         const bool has = hm != 0u;
                         const int sl = has ? (int)__builtin_ctz(hm) : 0;
                         hm &= hm - 1u;
                         const unsigned long long sm = __ballot(has);
                         const int ne = __popcll(sm);
-                        if (nsq + ne > PSH_EMX_QCAP) verify(seg_start, r_global);
+                        if (nsq + ne > PSH_EMX_QCAP) verify(seg_start, r_global, a.dataset + row * a.T);
                         if (has) {
                             const int p = 16 * (32 * hf + 16 * (sl >> 2) + 4 * kq + (sl & 3)) + scol;
                             sq[nsq + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u))] =
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                 }
             }
         }
-        if (MODE == PSH_MODE_FILTER && nsq > 0) verify(seg_start, r_global);           // before the tile is overwritten
+        if (MODE == PSH_MODE_FILTER && nsq > 0) verify(seg_start, r_global, a.dataset + row * a.T);   // before the tile is overwritten
         wave_lds_fence();
         u = un;
     }
