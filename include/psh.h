@@ -88,6 +88,9 @@ extern "C" {
  * survivors -- same results as without the flag.  (The library cannot look at the kernel matrix without a device
  * synchronisation, so the caller says which it is: Foveal-like kernels are faster WITHOUT the flag, on the suffix-rows path.) */
 #define PSH_FLAG_EMBED_MX     64
+/* EMBED_TAPS: psh_scan_topk_embedded on a suffix-rows kernel whose supports form ONE interval (Foveal): the running sums
+ * by walking the taps, as for kernels with a gap, instead of differences of prefix sums (A/B tests; same results). */
+#define PSH_FLAG_EMBED_TAPS   128
 /* RESERVE_CUS: the scan leaves a few compute units free (grid = CUs - 4): set by callers that run a collective and a
  * merge on a side stream beside the NEXT scan -- the fused launch otherwise owns every CU of the chip, and work on
  * another stream would wait for it (or make its last block wait). */
@@ -194,7 +197,9 @@ int psh_scan_topk_exhaustive(int device, void* stream,
  * followed by psh_scan_topk (below).
  * Kernels whose rows are one constant each on a common support from some tap onwards
  * (Foveal, also with an ImputationContext's gap; recognised on the device, K <= 256) are
- * scanned bound-then-verify over shared running sums -- same results, ~5x faster;
+ * scanned bound-then-verify over shared running sums -- same results, ~5x faster; when the
+ * common support is one interval (Foveal itself) the running sums are differences of prefix sums
+ * of the segment -- another ~2x (PSH_FLAG_EMBED_TAPS: the tap walk instead).
  * PSH_FLAG_EMBED_DENSE forces the dense chains (A/B tests).
  */
 int psh_embedded_supported(int d, int K);   /* 1 when a d x K kernel fits the embedded scan (LDS), else 0 */

@@ -158,6 +158,7 @@ struct Problem {
     int qlen;             // floats per query vector handed over: W, or emb_d (pre-embedded queries)
     bool emb_dense;       // PSH_FLAG_EMBED_DENSE
     bool rows_generic;    // PSH_FLAG_ROWS_GENERIC
+    bool emb_taps;        // PSH_FLAG_EMBED_TAPS
     bool emx;             // PSH_FLAG_EMBED_MX and the kernel fits: embed_mx_kernel (BOOT / FILTER)
 };
 
@@ -182,6 +183,7 @@ int check_problem(const float* dataset, int64_t R, int64_t T, int64_t r_offset, 
     p->qlen = emb_d > 0 ? emb_d : W;
     p->emb_dense = false;
     p->rows_generic = false;
+    p->emb_taps = false;
     p->emx = false;
     return PSH_OK;
 }
@@ -302,6 +304,7 @@ ScanArgs make_scan_args(const float* dataset, const float* queries, const Proble
     a.emb_wide = plan.wide;
     a.emb_dense = p.emb_dense ? 1 : 0;                  // PSH_FLAG_EMBED_DENSE: skip the suffix-rows fast path (A/B tests)
     a.emb_mx = p.emx ? 1 : 0;
+    a.emb_taps = p.emb_taps ? 1 : 0;
     a.B = p.B;
     a.n_qgroups = plan.n_qgroups;
     a.q_per_group = plan.q_per_group;
@@ -534,6 +537,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     if (!out_status) return PSH_ERR_ARG;
     p.emb_dense = (flags_of(profile) & PSH_FLAG_EMBED_DENSE) != 0;
     p.rows_generic = (flags_of(profile) & PSH_FLAG_ROWS_GENERIC) != 0;
+    p.emb_taps = (flags_of(profile) & PSH_FLAG_EMBED_TAPS) != 0;
     p.emx = p.ker && (flags_of(profile) & PSH_FLAG_EMBED_MX) && !p.emb_dense && p.Tp > 1 &&
             embed_mx_supported(p.emb_d, p.W, p.B, tile_floats_for(p.W));
     Workspace w;

@@ -118,6 +118,7 @@ struct ScanArgs {
     int emb_d;
     int emb_wide;            // embedded scan: the 512-thread instantiation (launchers, plan)
     int emb_dense;           // embedded scan: always the dense chains, even when the kernel has suffix rows (tests, PSH_EMBED=dense)
+    int emb_taps;            // embedded scan, suffix rows: walk the taps even when the support is one interval (PSH_FLAG_EMBED_TAPS)
     int emb_mx;              // embedded scan: the dense kernel's rejection test on the matrix cores (embed_mx_kernel: BOOT / FILTER)
 };
 

@@ -125,8 +125,14 @@ def test_suffix_rows_fast_path_equals_the_dense_chains(hip_device, kind, d, K):
     dense = hip_scan_embedded(hip_device, ds, ker, hx, 512, 20, profile=True, flags=_native.FLAG_EMBED_DENSE)
     assert np.all(fast[2] == 0) and np.all(dense[2] == 0)
     assert_exact(fast[0], fast[1], dense[0], dense[1], "suffix rows vs dense")
-    # the bootstrap of the fast path hands over upper bounds (a 1e-4 relative margin): a few more candidates
-    assert dense[3]["n_candidates"] <= fast[3]["n_candidates"] <= 1.05 * dense[3]["n_candidates"] + 8
+    # the bootstrap of the fast path hands over upper bounds (a 1e-4 relative margin): a few more candidates -- when the
+    # sampled minima are taken over the same groups of windows (the tap walk: 16 consecutive windows per lane, like the dense
+    # chains; the prefix-sum variant of Foveal groups 16 windows 64 apart, another estimate of the same level)
+    taps = hip_scan_embedded(hip_device, ds, ker, hx, 512, 20, profile=True, flags=_native.FLAG_EMBED_TAPS)
+    assert np.all(taps[2] == 0)
+    assert_exact(taps[0], taps[1], dense[0], dense[1], "suffix rows (tap walk) vs dense")
+    assert dense[3]["n_candidates"] <= taps[3]["n_candidates"] <= 1.05 * dense[3]["n_candidates"] + 8
+    assert 512 <= fast[3]["n_candidates"] <= 1.3 * dense[3]["n_candidates"] + 8
 
 
 def test_estimated_threshold_that_falls_short_raises_the_status(hip_device, oracle_mod):
@@ -146,9 +152,9 @@ def test_estimated_threshold_that_falls_short_raises_the_status(hip_device, orac
     rank2 = (3 * k * n_s + 2 * R - 1) // (2 * R) + 16            # the rank of the estimate (psh_capi.hip)
     assert rank2 < k
     planted = 0
-    for i in range(n_s):                                     # one near-copy per 64-sample stretch of every sampled row
-        r = stride // 2 + i * stride
-        for t in range(0, T - K - 64, 64):
+    for i in range(n_s):                                     # one near-copy per 65-sample stretch of every sampled row: each
+        r = stride // 2 + i * stride                         # in a group of its own, whether a lane's 16 windows are consecutive
+        for t in range(0, T - K - 64, 65):                   # (tap walk, dense chains) or 64 apart (prefix sums)
             if planted < rank2 + 40:
                 ds[r, 0, t:t + K] = x * (1 + 1e-3 * rng.standard_normal(K)).astype(np.float32)
                 planted += 1
