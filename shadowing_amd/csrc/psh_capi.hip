@@ -45,6 +45,7 @@ inline int tile_floats_for(int W) {
 
 struct Workspace {
     FusedHdr* fused;      // state of the fused single-launch scan: ALWAYS the first PSH_FUSED_BYTES of the workspace
+    EmbedPlan* eplan;     // embedded scan: what embed_plan_kernel found in the kernel matrix (PSH_PLAN_BYTES)
     QueryState* qstate;
     int* total;
     float* minbuf;
@@ -100,7 +101,7 @@ int64_t boot_entries(int64_t R, int64_t Tp, int k) {
 
 // fixed part + cap * 12 bytes per query (the block slices / window slots)
 size_t fixed_bytes(int B, int kpad, int64_t min_stride) {
-    size_t o = PSH_FUSED_BYTES;
+    size_t o = PSH_FUSED_BYTES + PSH_PLAN_BYTES;
     o += align_up(sizeof(QueryState) * (size_t)B, 256);
     o += align_up(sizeof(int) * (size_t)B, 256);
     o += align_up(sizeof(float) * (size_t)B * (size_t)min_stride, 256);
@@ -123,6 +124,7 @@ int carve(void* ws, size_t bytes, int B, int k, int64_t min_stride, Workspace* o
     char* p = (char*)ws;
     if (((uintptr_t)p & 255u) != 0) return PSH_ERR_ARG;   // torch allocations are >= 512-byte aligned
     out->fused = (FusedHdr*)p;    p += PSH_FUSED_BYTES;
+    out->eplan = (EmbedPlan*)p;   p += PSH_PLAN_BYTES;
     out->qstate = (QueryState*)p; p += align_up(sizeof(QueryState) * (size_t)B, 256);
     out->total = (int*)p;         p += align_up(sizeof(int) * (size_t)B, 256);
     out->minbuf = (float*)p;      p += align_up(sizeof(float) * (size_t)B * (size_t)min_stride, 256);
@@ -159,6 +161,7 @@ struct Problem {
     bool emb_dense;       // PSH_FLAG_EMBED_DENSE
     bool rows_generic;    // PSH_FLAG_ROWS_GENERIC
     bool emb_taps;        // PSH_FLAG_EMBED_TAPS
+    const EmbedPlan* eplan;   // embedded scan, sampled path: the plan region of the workspace when embed_plan_kernel runs, else nullptr
     bool emx;             // PSH_FLAG_EMBED_MX and the kernel fits: embed_mx_kernel (BOOT / FILTER)
 };
 
@@ -184,6 +187,7 @@ int check_problem(const float* dataset, int64_t R, int64_t T, int64_t r_offset, 
     p->emb_dense = false;
     p->rows_generic = false;
     p->emb_taps = false;
+    p->eplan = nullptr;
     p->emx = false;
     return PSH_OK;
 }
@@ -305,6 +309,7 @@ ScanArgs make_scan_args(const float* dataset, const float* queries, const Proble
     a.emb_dense = p.emb_dense ? 1 : 0;                  // PSH_FLAG_EMBED_DENSE: skip the suffix-rows fast path (A/B tests)
     a.emb_mx = p.emx ? 1 : 0;
     a.emb_taps = p.emb_taps ? 1 : 0;
+    a.plan = p.eplan;
     a.B = p.B;
     a.n_qgroups = plan.n_qgroups;
     a.q_per_group = plan.q_per_group;
@@ -390,6 +395,7 @@ int run_exhaustive(int device, hipStream_t s, const float* dataset, const float*
                    psh_profile* prof) {
     Problem p = p_in;
     p.emx = false;                 // every window is ranked here: the dense chains of embed_scan_kernel, no rejection test
+    p.eplan = nullptr;
     const int64_t nseg = (p.Tp + PSH_SEG - 1) / PSH_SEG;
     const bool rows_path = p.Tp == 1 && !p.ker && !p.rows_generic;   // one-window rows: a slot per row (rows_kernel)
     const int64_t slots_per_row = rows_path ? 1 : nseg * PSH_SEG;
@@ -547,6 +553,11 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     DeviceGuard g(device);
     if (!g.ok) { snprintf(g_hip_err, sizeof(g_hip_err), "hipSetDevice(%d) failed", device); return PSH_ERR_HIP; }
     hipStream_t s = (hipStream_t)stream;
+    // a linear embedding that may be Foveal-like on one interval: the matrix is looked at on the device (one small launch),
+    // and of the two kernels launched per stage the one the structure belongs to does the work (psh_embed_px.hip)
+    const bool want_plan = p.ker && !p.emb_dense && !p.emb_taps && !p.emx && p.Tp > 1 &&
+                           embed_px_supported(tile_floats_for(p.W), p.B, p.emb_d, p.W, false) &&
+                           embed_px_supported(tile_floats_for(p.W), p.B, p.emb_d, p.W, true);
 
     // small problems (everything fits the candidate buffer), one-window rows (their
     // numerator uses another reduction order, handled by the exhaustive kernel only) or
@@ -581,6 +592,10 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
         return run_exhaustive(device, s, dataset, queries, qnorm, p, w, out_d, out_idx, out_status, profile);
     const int64_t stride = p.R / n_sample;
     const int64_t row0 = stride / 2;
+    if (want_plan) {
+        HIP_TRY(launch_embed_plan(p.ker, p.emb_d, p.W, w.eplan, s));
+        p.eplan = w.eplan;
+    }
 
     const bool stages = profile && profile->mode == PSH_PROFILE_STAGES;
     const bool events = profile && profile->mode == PSH_PROFILE_EVENTS && profile->ev_scan_begin && profile->ev_scan_end;

@@ -91,8 +91,7 @@ __device__ __forceinline__ void correlate16(const float* tile, int base, const f
 // the threshold infinite (everything is verified exactly).
 #define PSH_NEST_BG 2                // queries sharing one pass of running sums (register budget: 128 VGPRs)
 #define PSH_NEST_MAX_K 256           // support masks are 4 x 64 bits, 16 blocks of 16 taps
-struct NestHdr { int ok; int nops; float cerr; int n_empty; unsigned blk[16]; int ncl[PSH_NEST_MAX_K];   // blk: active taps | closing taps << 16; ncl: rows closing at a tap
-                 int contig; int ktop; float cerr_p; int ngroups; float cerr_y; int pad[3]; };                                          // prefix variant: U == [amin, ktop), 2u ||c||_2, merged rows, u sqrt(sum (c_i (n_i+2)^2)^2)
+struct NestHdr { int ok; int nops; float cerr; int n_empty; unsigned blk[16]; int ncl[PSH_NEST_MAX_K]; };   // blk: active taps | closing taps << 16; ncl: rows closing at a tap
 
 // The running sums of a lane's 16 windows.  The window registers are addressed by DATA index:
 // y[base + m] lives in slot m & 15, so at tap j (PH = j & 15) window w reads slot (w + PH) & 15,
@@ -104,60 +103,6 @@ struct NestHdr { int ok; int nops; float cerr; int n_empty; unsigned blk[16]; in
 // arrive four at a time (aligned 16-byte LDS reads, one per 4 taps, issued 4 taps ahead) in two
 // alternating quads: group G = (j - 1) >> 2 sits in Q[G & 1].
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// ---- suffix rows over a CONTIGUOUS support (Foveal itself): prefix sums instead of the tap walk ----------------------------
-// Row i is c_i on [a_i, ktop): its running sum is a difference of two prefix sums of the segment,
-//     S_i(t) = E[t + ktop] - E[t + a_i],   E[m] = y_0 + .. + y_{m-1},
-// so the cheap embedding costs d LDS reads and 3 d packed-able operations per window instead of one packed add per tap
-// and window (ktop - amin = 115 taps against d = 34 rows for Foveal(1.15, 0.9, 126)).  E is summed in DOUBLE (a scan over
-// the staged registers, exact to ~2^-42 ymax) and rounded ONCE to fp32, so an entry is off by at most u |E| and
-//     |S^_i - S_i| <= 2 u Pmax + u n_i ymax (+ 2^-31 ymax),   Pmax = max |E| over the segment
-// -- with the exact chain's own n_i^2 u |c_i| ymax the radius of the cheap embedding around the exact one becomes
-//     ymax * u sqrt(sum_i (c_i (n_i + 1)^2)^2)  +  Pmax * 2 u ||c||_2      (both with the 1.05 margin; cerr / 2 and cerr_p)
-// -- smaller than the tap walk's (whose running sums round at every tap).  Non-finite data: an infinite Pmax makes the
-// threshold infinite, a NaN in E makes every comparison fail -- either way the windows are verified exactly.
-// Exclusive prefix sums of the staged segment (element 4 (lane + 64 q) + r of Stage) -> dst[0 .. 4 nq); returns max |E|.
-// inc += (inc of the lane `ctrl` names, 0.0 where there is none): one step of the wave scan, on the DPP path of the VALU
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_add(double inc) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(inc), CTRL, ROW_MASK, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(inc), CTRL, ROW_MASK, 0xf, true);
-    return inc + __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ float prefix_store(const Stage& st, float* dst, int nfloat, int lane) {
-    const int nq = (nfloat + 3) >> 2;
-    double carry = 0.0;
-    float pmax = 0.0f;
-#pragma unroll
-    for (int q = 0; q < PSH_NSTAGE; ++q) {
-        const int m = lane + 64 * q;
-        const bool on = q < PSH_NSTAGE - 1 || m < nq;      // (group nq, all zeros, carries E[nfloat] when nfloat % 4 == 0)
-        const double d0 = on ? (double)st.v[q][0] : 0.0;
-        const double d1 = d0 + (on ? (double)st.v[q][1] : 0.0);
-        const double d2 = d1 + (on ? (double)st.v[q][2] : 0.0);
-        const double d3 = d2 + (on ? (double)st.v[q][3] : 0.0);
-        // inclusive scan of the lane totals: within the rows of 16 lanes (row_shr 1, 2, 4, 8), then across them
-        // (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3)
-        double inc = d3;
-        inc = dpp_add<0x111, 0xf>(inc);
-        inc = dpp_add<0x112, 0xf>(inc);
-        inc = dpp_add<0x114, 0xf>(inc);
-        inc = dpp_add<0x118, 0xf>(inc);
-        inc = dpp_add<0x142, 0xa>(inc);
-        inc = dpp_add<0x143, 0xc>(inc);
-        const double x = carry + (inc - d3);                 // (the lane's own total taken off again: ~2^-53 of |inc|)
-        const f32x4 E = f32x4{(float)x, (float)(x + d0), (float)(x + d1), (float)(x + d2)};
-        carry += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(inc), 63), __builtin_amdgcn_readlane(__double2loint(inc), 63));
-        if (on || m == nq) {
-            *reinterpret_cast<f32x4*>(dst + 4 * m) = E;
-            pmax = fmaxf(pmax, fmaxf(fmaxf(fabsf(E[0]), fabsf(E[1])), fmaxf(fabsf(E[2]), fabsf(E[3]))));
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, off, 64));
-    return pmax;
-}
 
 template <int PH>
 __device__ __forceinline__ void nest_add(f32x2 (&S2)[8], const f32x2 (&W2)[8]) {
@@ -261,6 +206,8 @@ __device__ __forceinline__ void correlate16_pk(const float* tile, int base, cons
 // cost, and a wave that carries 4x the accumulators evaluates it 4x less often.
 template <bool ALIGNED, int MODE, int THREADS, int BG, int NBG>
 __global__ __launch_bounds__(THREADS) void embed_scan_kernel(ScanArgs a) {
+    // supports that form one interval: embed_px_kernel (psh_embed_px.hip), launched beside this one, does the stage
+    if (MODE != PSH_MODE_ALL && a.plan != nullptr && __builtin_amdgcn_readfirstlane(a.plan->contig) != 0) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = lane_id();
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -371,56 +318,12 @@ __global__ __launch_bounds__(THREADS) void embed_scan_kernel(ScanArgs a) {
             }
             nh->cerr = 1.05f * 2.0f * 5.9604645e-8f * __builtin_sqrtf(e2);   // 2u sqrt(sum (c_i (n_i+1)^2)^2), margin for its own rounding
             if (!(e2 < 3.0e38f)) nh->ok = 0;
-            // prefix variant: the union of the supports is one interval [amin, ktop)
-            int lowU = -1, topU = 0, nU = 0;
-            float c2s = 0.0f;
-            for (int j = 0; j < K; ++j)
-                if ((rmask[4 * d + (j >> 6)] >> (j & 63)) & 1ull) { if (lowU < 0) lowU = j; topU = j + 1; ++nU; }
-            for (int i = 0; i < d; ++i) { const float c = __uint_as_float((unsigned)prog[i].z); c2s = __builtin_fmaf(c, c, c2s); }
-            nh->contig = (nU > 0 && topU - lowU == nU && !a.emb_taps) ? 1 : 0;
-            nh->ktop = topU;
-            nh->cerr_p = 1.05f * 2.0f * 5.9604645e-8f * __builtin_sqrtf(c2s);
-            if (!(c2s < 3.0e38f)) nh->contig = 0;
-            float e2p = 0.0f;
-            for (int i = 0; i < d; ++i) {
-                const float n2 = (float)(prog[i].w + 2);
-                const float t = fabsf(__uint_as_float((unsigned)prog[i].z)) * n2 * n2;
-                e2p = __builtin_fmaf(t, t, e2p);
-            }
-            nh->cerr_y = 1.05f * 5.9604645e-8f * __builtin_sqrtf(e2p);
-            // the prefix variant's table: IDENTICAL rows (same first tap, same constant -- Foveal's short scales repeat: 34
-            // rows, 27 distinct) are merged, up to 4 to a group: sum_j (hx_j - c S)^2 = m (mean hx - c S)^2 + V, so the group
-            // costs one row with c' = sqrt(m) c and h' = sqrt(m) mean hx (V >= 0 is dropped by the rejection test and added
-            // back by the bootstrap).  Entry: {c' bits, byte offset of E[a_i] (E[ktop] for an empty row: S = 0), the members'
-            // row indices (a byte each), m}.  (The support masks are dead by now: the table takes their place.)
-            int4* gt = reinterpret_cast<int4*>(rmask);
-            int G = 0;
-            for (int i = 0; i < d; ++i) {
-                const int4 o = prog[i];
-                const int off = 4 * (o.w > 0 ? o.x : topU);
-                int g = -1;
-                for (int j = 0; j < G && g < 0; ++j)
-                    if (gt[j].x == o.z && gt[j].y == off && gt[j].w < 4) g = j;
-                if (g < 0) { gt[G] = make_int4(o.z, off, o.y, 1); ++G; }
-                else { gt[g].z |= o.y << (8 * gt[g].w); gt[g].w += 1; }
-            }
-            for (int j = 0; j < G; ++j) {
-                const int m = gt[j].w;
-                const float rm = m == 1 ? 1.0f : (m == 2 ? 1.41421356f : (m == 3 ? 1.7320508f : 2.0f));
-                gt[j].x = (int)__float_as_uint(__fmul_rn(__uint_as_float((unsigned)gt[j].x), rm));
-            }
-            nh->ngroups = G;
         }
         __syncthreads();
     }
     const bool nested = (MODE != PSH_MODE_ALL) && (__builtin_amdgcn_readfirstlane(nh->ok) != 0);
     const int n_empty = __builtin_amdgcn_readfirstlane(nh->n_empty);
     const float cerr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(nh->cerr)));
-    const bool prefix = nested && (__builtin_amdgcn_readfirstlane(nh->contig) != 0);
-    const int ktop = __builtin_amdgcn_readfirstlane(nh->ktop);
-    const float cerr_p = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(nh->cerr_p)));
-    const float cerr_y = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(nh->cerr_y)));
-    const int ngroups = __builtin_amdgcn_readfirstlane(nh->ngroups);
     // rows in closing order, one per lane (two registers: d <= 128): what a closing row needs comes by v_readlane
     int ctab[2] = {0, 0}, rtab[2] = {0, 0};                  // -c_i bits, row index
     if (nested) {
@@ -459,7 +362,7 @@ __global__ __launch_bounds__(THREADS) void embed_scan_kernel(ScanArgs a) {
             pend_flush(pend, npend, lcount, a, lane);
             npend = 0;
         }
-        float ymax = 0.0f, pmax = 0.0f;
+        float ymax = 0.0f;
         {
             Stage st;
             stage_load<ALIGNED>(st, a.dataset + row * a.T, a.T, seg_start, nfloat, lane);
@@ -472,8 +375,7 @@ __global__ __launch_bounds__(THREADS) void embed_scan_kernel(ScanArgs a) {
                     }
                 }
             }
-            if (MODE != PSH_MODE_ALL && prefix) pmax = prefix_store(st, tile, nfloat, lane);   // the tile holds E, not y
-            else stage_store(st, tile, nfloat, lane);
+            stage_store(st, tile, nfloat, lane);
         }
         wave_lds_fence();
 
@@ -487,17 +389,15 @@ __global__ __launch_bounds__(THREADS) void embed_scan_kernel(ScanArgs a) {
         if (MODE != PSH_MODE_ALL && nested) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, off, 64));
-            // radius of the cheap embedding around the exact one
-            const float err = prefix ? __builtin_fmaf(ymax, cerr_y, pmax * cerr_p) : ymax * cerr;
+            const float err = ymax * cerr;                    // radius of the cheap embedding around the exact one
             const int base = PSH_L * lane;
-            const float* yrow_g = a.dataset + row * a.T + seg_start;   // the segment in global memory (prefix variant: the tile holds E)
             int ns = 0;                                       // survivors waiting in sl (wave-uniform)
             // Exact verification of the listed survivors (window index | query << 12), rows across the lanes:
             // lane (el, l) runs the chains of the l-th shortest and then the l-th longest row of survivor el
             // (equal work per lane), 64 / ceil(d/2) survivors per pass; one lane per survivor then adds the d
             // squares in row order.  A row's taps need no matrix: c_i on U & [a_i, K), zero elsewhere (the zero
             // taps the dense chain visits are visited too: fma(0, y, .) matters for non-finite y).
-            auto verify_list = [&](const float* yg) {        // yg: the segment in global memory, or nullptr: the fp32 tile
+            auto verify_list = [&]() {
                 wave_lds_fence();
                 const int H = (d + 1) >> 1, EPP = 64 / H;
                 const int el = lane / H, l = lane - el * H;
@@ -524,13 +424,8 @@ __global__ __launch_bounds__(THREADS) void embed_scan_kernel(ScanArgs a) {
                             const bool act = it < n4;
                             const int j0 = act ? lo + it : 0;
                             float y[4];
-                            if (yg) {
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) y[q] = (j0 + q < K) ? yg[pwin + j0 + q] : 0.0f;
-                            } else {
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) y[q] = tile[lds_pad(pwin + j0 + q)];
-                            }
+                            for (int q = 0; q < 4; ++q) y[q] = tile[lds_pad(pwin + j0 + q)];
                             const unsigned ub = nh->blk[(j0 >> 4) & 15] >> (j0 & 15);
                             float t = hy;
 #pragma unroll
@@ -575,139 +470,6 @@ __global__ __launch_bounds__(THREADS) void embed_scan_kernel(ScanArgs a) {
                 }
                 wave_lds_fence();                            // sl is refilled afterwards
             };
-            if (prefix) {
-                // window w of the lane: lane + 64 w -- every LDS read is 64 consecutive floats, and a register PAIR holds two
-                // windows 64 apart (ds_read2st64_b32), ready for the packed operations
-                float Pk[PSH_L];
-#pragma unroll
-                for (int w = 0; w < PSH_L; ++w) Pk[w] = tile[lane + 64 * w + ktop];
-                for (int b0 = q_begin; b0 < q_end; b0 += NBG) {
-                    const int nq = (q_end - b0) < NBG ? (q_end - b0) : NBG;
-                    f32x2 acc[NBG][8];
-#pragma unroll
-                    for (int g = 0; g < NBG; ++g)
-#pragma unroll
-                        for (int w = 0; w < 8; ++w) acc[g][w] = f32x2{0.f, 0.f};
-                    // the groups' h' = sqrt(m) mean hx across the lanes, V = sum of the within-group scatter, ||hx||^2
-                    int hgt[NBG][2];
-                    float Vq[NBG], errq[NBG];
-                    const int4* gtab = reinterpret_cast<const int4*>(rmask);
-#pragma unroll
-                    for (int g = 0; g < NBG; ++g) {
-                        float vs = 0.0f, sq = 0.0f;
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            hgt[g][q] = 0;
-                            if (g < nq && lane + 64 * q < ngroups) {
-                                const int4 ge = gtab[lane + 64 * q];
-                                const float* hxb = a.hx + (int64_t)(b0 + g) * d;
-                                float hj[4], sum = 0.0f;
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    hj[j] = j < ge.w ? hxb[(ge.z >> (8 * j)) & 255] : 0.0f;
-                                    sum += hj[j];
-                                    sq = __builtin_fmaf(hj[j], hj[j], sq);
-                                }
-                                const float mean = sum / (float)ge.w;
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) { const float dv = j < ge.w ? hj[j] - mean : 0.0f; vs = __builtin_fmaf(dv, dv, vs); }
-                                const float rs = ge.w == 1 ? 1.0f : (ge.w == 2 ? 0.70710678f : (ge.w == 3 ? 0.57735027f : 0.5f));
-                                hgt[g][q] = (int)__float_as_uint(sum * rs);
-                            }
-                        }
-#pragma unroll
-                        for (int off = 32; off > 0; off >>= 1) { vs += __shfl_xor(vs, off, 64); sq += __shfl_xor(sq, off, 64); }
-                        Vq[g] = vs * (1.0f + 1.0f / 256.0f);
-                        // rounding of h' and c': at most 6 u ||hx|| more between the cheap embedding and the exact one
-                        errq[g] = __builtin_fmaf(6.0f * 5.9604645e-8f * 1.001f, __builtin_sqrtf(sq), err);
-                    }
-                    // a row: its first tap and constant come out of the block's table (one broadcast LDS read, fetched a row
-                    // ahead), the query's coordinate out of the lane that holds it
-                    const int2* ptab = reinterpret_cast<const int2*>(gtab);          // {c' bits, byte offset of E[a_i]} of entry 0
-                    const char* tile_b = reinterpret_cast<const char*>(tile + lane);
-                    int2 o_next = ptab[0];
-                    auto row_step = [&](int i, const float (&hv)[NBG]) {
-                        const int2 o = o_next;
-                        o_next = ptab[2 * (i + 1)];          // (one entry past the table: never used)
-                        const float c = __uint_as_float((unsigned)o.x);
-                        const f32x2 c2 = f32x2{c, c};
-                        const float* pa = reinterpret_cast<const float*>(tile_b + o.y);
-                        f32x2 S[8];                          // -S_i of the window pair: e = hx - c S = fma(c, -S, hx)
-#pragma unroll
-                        for (int w = 0; w < 8; ++w) S[w] = f32x2{pa[128 * w], pa[128 * w + 64]} - f32x2{Pk[2 * w], Pk[2 * w + 1]};
-#pragma unroll
-                        for (int g = 0; g < NBG; ++g) {
-                            if (g < nq) {                    // wave-uniform
-                                const f32x2 hx2 = f32x2{hv[g], hv[g]};
-                                f32x2 e[8];
-#pragma unroll
-                                for (int w = 0; w < 8; ++w) e[w] = __builtin_elementwise_fma(c2, S[w], hx2);
-#pragma unroll
-                                for (int w = 0; w < 8; ++w) acc[g][w] = __builtin_elementwise_fma(e[w], e[w], acc[g][w]);
-                            }
-                        }
-                    };
-                    const int g_lo = ngroups < 64 ? ngroups : 64;
-#pragma unroll 1
-                    for (int i = 0; i < g_lo; ++i) {
-                        float hv[NBG];
-#pragma unroll
-                        for (int g = 0; g < NBG; ++g) hv[g] = __uint_as_float((unsigned)__builtin_amdgcn_readlane(hgt[g][0], i));
-                        row_step(i, hv);
-                    }
-#pragma unroll 1
-                    for (int i = 64; i < ngroups; ++i) {
-                        float hv[NBG];
-#pragma unroll
-                        for (int g = 0; g < NBG; ++g) hv[g] = __uint_as_float((unsigned)__builtin_amdgcn_readlane(hgt[g][1], i - 64));
-                        row_step(i, hv);
-                    }
-                    unsigned vmask = 0u;                     // admissible windows of the lane
-#pragma unroll
-                    for (int w = 0; w < PSH_L; ++w) vmask |= (seg_start + lane + 64 * w < a.Tp) ? (1u << w) : 0u;
-#pragma unroll
-                    for (int g = 0; g < NBG; ++g) {
-                        const int b = b0 + g;
-                        if (g >= nq) continue;
-                        if (MODE == PSH_MODE_BOOT) {
-                            float m = __uint_as_float(PSH_INF_BITS);
-#pragma unroll
-                            for (int w = 0; w < PSH_L; ++w) m = ((vmask >> w) & 1u) ? fminf(m, acc[g][w >> 1][w & 1]) : m;
-                            if (a.boot_per_wave) {
-#pragma unroll
-                                for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
-                            }
-                            const float su = __builtin_sqrtf(m + Vq[g]) * (1.0f + 1.0f / 32768.0f) + errq[g];
-                            const float ub = su * su * (1.0f + 1.0f / 16384.0f);
-                            if (a.boot_per_wave) {
-                                if (lane == 0) a.minbuf[(int64_t)b * a.min_stride + (int64_t)rs] = ub;
-                            } else {
-                                a.minbuf[(int64_t)b * a.min_stride + (int64_t)rs * 64 + lane] = ub;
-                            }
-                        } else {
-                            const float tau = __uint_as_float(qstate_k[b].tau2_bits);
-                            const float st = __builtin_sqrtf(tau) * (1.0f + 1.0f / 32768.0f) + errq[g];
-                            const float thr = st * st * (1.0f + 1.0f / 16384.0f);
-                            unsigned hm = 0u;
-#pragma unroll
-                            for (int w = 0; w < PSH_L; ++w) hm |= !(acc[g][w >> 1][w & 1] > thr) ? (1u << w) : 0u;
-                            hm &= vmask;
-                            while (__any(hm != 0u)) {
-                                const bool has = hm != 0u;
-                                const int w = has ? (int)__builtin_ctz(hm) : 0;
-                                hm &= hm - 1u;
-                                const unsigned long long sm = __ballot(has);
-                                const int ne = __popcll(sm);
-                                if (ns + ne > 64) { verify_list(yrow_g); ns = 0; }
-                                if (has) sl[ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u))] =
-                                    (lane + 64 * w) | (b << 12);
-                                ns += ne;
-                            }
-                        }
-                    }
-                }
-                if (MODE == PSH_MODE_FILTER && ns > 0) { verify_list(yrow_g); ns = 0; }
-            } else {
             for (int b0 = q_begin; b0 < q_end; b0 += NBG) {
                 const int nq = (q_end - b0) < NBG ? (q_end - b0) : NBG;
                 f32x2 acc[NBG][8], S[8], win[8];          // element x: window w / slot s, element y: w + 8 / s + 8
@@ -814,7 +576,7 @@ __global__ __launch_bounds__(THREADS) void embed_scan_kernel(ScanArgs a) {
                             hm &= hm - 1u;
                             const unsigned long long sm = __ballot(has);
                             const int ne = __popcll(sm);
-                            if (ns + ne > 64) { verify_list(nullptr); ns = 0; }
+                            if (ns + ne > 64) { verify_list(); ns = 0; }
                             if (has) sl[ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u))] =
                                 (base + w) | (b << 12);
                             ns += ne;
@@ -822,8 +584,7 @@ __global__ __launch_bounds__(THREADS) void embed_scan_kernel(ScanArgs a) {
                     }
                 }
             }
-            if (MODE == PSH_MODE_FILTER && ns > 0) { verify_list(nullptr); ns = 0; }   // before the tile is overwritten
-            }
+            if (MODE == PSH_MODE_FILTER && ns > 0) { verify_list(); ns = 0; }   // before the tile is overwritten
         } else
         for (int b0 = q_begin; b0 < q_end; b0 += BG) {
             f32x2 acc2[BG][8];
@@ -1092,6 +853,10 @@ static hipError_t launch_embed(const ScanArgs& a, int mode, int grid, size_t shm
 hipError_t launch_embed_scan(const ScanArgs& a, int mode, bool aligned, int grid, hipStream_t s) {
     if (a.emb_mx && (mode == PSH_MODE_FILTER || (mode == PSH_MODE_BOOT && a.boot_per_wave == 2)))
         return launch_embed_mx(a, mode, aligned, grid, s);                   // psh_embed_mx.hip: dense kernel, matrix cores
+    if (a.plan != nullptr && mode != PSH_MODE_ALL) {                         // psh_embed_px.hip: one of the two returns at once
+        const hipError_t e = launch_embed_px(a, mode, aligned, grid, s);
+        if (e != hipSuccess) return e;
+    }
     const size_t shmem = scan_shmem_bytes(a.tile_floats, a.B, a.emb_d, a.W, a.emb_wide ? PSH_EMB_WIDE_THREADS : PSH_SCAN_THREADS);
     return aligned ? launch_embed<true>(a, mode, grid, shmem, s) : launch_embed<false>(a, mode, grid, shmem, s);
 }

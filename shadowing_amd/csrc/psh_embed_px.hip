@@ -1,0 +1,527 @@
+// psh_embed_px.hip -- the embedded scan for suffix-rows kernels whose supports form ONE interval (Foveal itself:
+// reference path_embedding.py:142-172), BOOT and FILTER stages: the running sums of the rows as differences of PREFIX
+// SUMS of the segment.  Part of libpsh_hip.so; the general suffix-rows pass (tap walk, kernels with a gap) and the dense
+// chains are embed_scan_kernel's (psh_embed.hip), which this kernel replaces when the structure is there.
+//
+// Row i of such a kernel is one constant c_i on the taps [a_i, ktop) and zero elsewhere, so for window t
+//     h_i(t) = c_i S_i(t),   S_i(t) = E[t + ktop] - E[t + a_i],   E[m] = y_0 + .. + y_{m-1}   (of the segment's samples)
+// and the cheap embedding costs ONE LDS read and three packed-able operations per row, window and query
+//     S = Pk - E[t + a_i];  e = hx_i - c_i S;  acc^ += e^2
+// instead of one packed add per TAP and window (115 taps against 34 rows -- 27 distinct -- for Foveal(1.15, 0.9, 126)).
+//   * E is summed in DOUBLE by a scan over the staged registers (4 samples per lane serially, the lane totals through six
+//     DPP steps, the five 256-sample blocks chained through a scalar) -- exact to ~2^-42 ymax -- and rounded ONCE to fp32:
+//     an entry is off by at most u |E|, so  |S^_i - S_i| <= 2 u Pmax + u n_i ymax (+ 2^-31 ymax),  Pmax = max |E|.
+//   * IDENTICAL rows (same a_i, same c_i: Foveal's short scales repeat) are merged, up to 4 to a group:
+//     sum_j (hx_j - c S)^2 = m (mean hx - c S)^2 + V  -- one row with c' = sqrt(m) c and h' = sqrt(m) mean hx; V >= 0 is
+//     dropped by the rejection test (conservative) and added back by the bootstrap's upper bounds.
+//   * Window w of a lane is  lane + 64 w : every LDS read is 64 consecutive floats (no bank conflict) and a register PAIR
+//     holds two windows 64 apart (ds_read2st64_b32), ready for v_pk_add_f32 / v_pk_fma_f32.
+// Bound-then-verify like the tap walk (psh_embed.hip): with the exact chain's own n_i^2 u |c_i| ymax, the rounding of c'
+// and h' (<= 2 u n_i |c_i| ymax, 6 u ||hx||) the cheap embedding lies within
+//     Rad = ymax * u sqrt(sum_i (c_i (n_i + 2)^2)^2) + Pmax * 2 u ||c||_2 + 6 u ||hx||_2          (each with a 5 % margin)
+// of the exact one; a window survives unless  acc^ > (sqrt(tau)(1 + 2^-15) + Rad)^2 (1 + 2^-14);  survivors get the exact
+// dense chain in the oracle's order (oracle/psh_oracle.c: embedded_acc), their samples re-read from global memory (the
+// tile holds E), and only exact values are ever ranked: results are bit-identical to the tap walk's and the dense chains'.
+// Non-finite data: an infinite Pmax / ymax makes the threshold infinite, a NaN in E fails every '>' -- either way the
+// windows are verified exactly.
+//
+// The structure is recognised ON THE DEVICE (embed_plan_kernel, one small launch per call: the library cannot look at the
+// matrix without a synchronisation): the plan it leaves in the workspace says which of the two kernels launched for a
+// stage does the work -- the other one returns at once.
+#include "psh_device.h"
+
+namespace psh {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ---- the plan: one block looks at the d x K matrix -----------------------------------------------------------------------
+__global__ __launch_bounds__(128) void embed_plan_kernel(const float* __restrict__ ker, int d, int K, EmbedPlan* plan) {
+    __shared__ int s_ok;
+    __shared__ unsigned long long s_U[4];
+    __shared__ int4 s_row[PSH_EMB_MAX_D];                    // {first tap, row, c bits, taps}
+    __shared__ int4 s_prog[PSH_EMB_MAX_D];                   // the same, longest support last
+    const int tid = (int)threadIdx.x;
+    if (tid == 0) { s_ok = (d <= PSH_EMB_MAX_D && K <= 256) ? 1 : 0; s_U[0] = s_U[1] = s_U[2] = s_U[3] = 0ull; }
+    __syncthreads();
+    if (!s_ok) { if (tid == 0) { plan->contig = 0; plan->ngroups = 0; } return; }
+    unsigned long long m[4] = {0ull, 0ull, 0ull, 0ull};
+    int n = 0, lowest = 1 << 20;
+    float c = 0.0f;
+    if (tid < d) {                                           // support mask, size, constant of row tid
+        const float* row = ker + (size_t)tid * K;
+        bool okc = true;
+        for (int j = K - 1; j >= 0; --j) {
+            const float v = row[j];
+            if (v != 0.0f) {                                 // (NaN included: it then fails v == v)
+                if (n == 0) c = v;
+                okc = okc && (v == v) && (__float_as_uint(v) == __float_as_uint(c));
+                m[j >> 6] |= 1ull << (j & 63);
+                lowest = j;
+                ++n;
+            }
+        }
+        okc = okc && (fabsf(c) <= 3.0e38f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (m[q]) atomicOr(&s_U[q], m[q]);
+        s_row[tid] = make_int4(lowest, tid, (int)__float_as_uint(c), n);
+        if (!okc) atomicAnd(&s_ok, 0);
+    }
+    __syncthreads();
+    if (tid < d) {                                           // the row must be all of U from its first tap up
+        bool oks = true;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int lo_bit = lowest - 64 * q;
+            const unsigned long long keep = lo_bit <= 0 ? ~0ull : (lo_bit >= 64 ? 0ull : (~0ull << lo_bit));
+            oks = oks && (m[q] == (s_U[q] & keep));
+        }
+        if (n == 0) oks = true;
+        if (!oks) atomicAnd(&s_ok, 0);
+        int rk = 0;                                          // short supports first (the verification pairs row l with row d-1-l)
+        for (int i2 = 0; i2 < d; ++i2) { const int l2 = s_row[i2].x; rk += (l2 > lowest || (l2 == lowest && i2 < tid)) ? 1 : 0; }
+        s_prog[rk] = make_int4(lowest, tid, (int)__float_as_uint(c), n);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int lowU = -1, topU = 0, nU = 0;
+        for (int j = 0; j < K; ++j)
+            if ((s_U[j >> 6] >> (j & 63)) & 1ull) { if (lowU < 0) lowU = j; topU = j + 1; ++nU; }
+        float e2p = 0.0f, c2s = 0.0f;
+        for (int i = 0; i < d; ++i) {
+            const float ci = __uint_as_float((unsigned)s_prog[i].z);
+            const float n2 = (float)(s_prog[i].w + 2);
+            const float t = fabsf(ci) * n2 * n2;
+            e2p = __builtin_fmaf(t, t, e2p);
+            c2s = __builtin_fmaf(ci, ci, c2s);
+        }
+        const bool ok = s_ok != 0 && nU > 0 && topU - lowU == nU && e2p < 3.0e38f && c2s < 3.0e38f;
+        // merged rows: {c' bits, byte offset of E[a_i] (E[ktop] for an empty row: S = 0), the members' rows (a byte each), m}
+        int G = 0;
+        for (int i = 0; i < d; ++i) {
+            const int4 o = s_prog[i];
+            plan->prog[i] = o;
+            const int off = 4 * (o.w > 0 ? o.x : topU);
+            int g = -1;
+            for (int j = 0; j < G && g < 0; ++j)
+                if (plan->gtab[j].x == o.z && plan->gtab[j].y == off && plan->gtab[j].w < 4) g = j;
+            if (g < 0) { plan->gtab[G] = make_int4(o.z, off, o.y, 1); ++G; }
+            else { int4 ge = plan->gtab[g]; ge.z |= o.y << (8 * ge.w); ge.w += 1; plan->gtab[g] = ge; }
+        }
+        for (int j = 0; j < G; ++j) {
+            int4 ge = plan->gtab[j];
+            const float rm = ge.w == 1 ? 1.0f : (ge.w == 2 ? 1.41421356f : (ge.w == 3 ? 1.7320508f : 2.0f));
+            ge.x = (int)__float_as_uint(__fmul_rn(__uint_as_float((unsigned)ge.x), rm));
+            plan->gtab[j] = ge;
+        }
+        plan->gtab[G] = make_int4(0, 0, 0, 0);
+        plan->ktop = topU;
+        plan->ngroups = G;
+        plan->d = d;
+        plan->cerr_y = 1.05f * 5.9604645e-8f * __builtin_sqrtf(e2p);
+        plan->cerr_p = 1.05f * 2.0f * 5.9604645e-8f * __builtin_sqrtf(c2s);
+        __threadfence();
+        plan->contig = ok ? 1 : 0;
+    }
+}
+
+hipError_t launch_embed_plan(const float* ker, int d, int K, EmbedPlan* plan, hipStream_t s) {
+    hipLaunchKernelGGL(embed_plan_kernel, dim3(1), dim3(128), 0, s, ker, d, K, plan);
+    return hipGetLastError();
+}
+
+// inc += (inc of the lane CTRL names, 0.0 where there is none): one step of the wave scan, on the DPP path of the VALU
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double inc) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(inc), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(inc), CTRL, ROW_MASK, 0xf, true);
+    return inc + __hiloint2double(hi, lo);
+}
+
+// Exclusive prefix sums of the staged segment (element 4 (lane + 64 q) + r of Stage) -> dst[0 .. 4 nq]; returns max |E|.
+__device__ __forceinline__ float prefix_store(const Stage& st, float* dst, int nfloat, int lane) {
+    const int nq = (nfloat + 3) >> 2;
+    double carry = 0.0;
+    float pmax = 0.0f;
+#pragma unroll
+    for (int q = 0; q < PSH_NSTAGE; ++q) {
+        const int m = lane + 64 * q;
+        const bool on = q < PSH_NSTAGE - 1 || m < nq;      // (group nq, all zeros, carries E[nfloat] when nfloat % 4 == 0)
+        const double d0 = on ? (double)st.v[q][0] : 0.0;
+        const double d1 = d0 + (on ? (double)st.v[q][1] : 0.0);
+        const double d2 = d1 + (on ? (double)st.v[q][2] : 0.0);
+        const double d3 = d2 + (on ? (double)st.v[q][3] : 0.0);
+        // inclusive scan of the lane totals: within the rows of 16 lanes (row_shr 1, 2, 4, 8), then across them
+        // (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3)
+        double inc = d3;
+        inc = dpp_add<0x111, 0xf>(inc);
+        inc = dpp_add<0x112, 0xf>(inc);
+        inc = dpp_add<0x114, 0xf>(inc);
+        inc = dpp_add<0x118, 0xf>(inc);
+        inc = dpp_add<0x142, 0xa>(inc);
+        inc = dpp_add<0x143, 0xc>(inc);
+        const double x = carry + (inc - d3);                 // (the lane's own total taken off again: ~2^-53 of |inc|)
+        const f32x4 E = f32x4{(float)x, (float)(x + d0), (float)(x + d1), (float)(x + d2)};
+        carry += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(inc), 63), __builtin_amdgcn_readlane(__double2loint(inc), 63));
+        if (on || m == nq) {
+            *reinterpret_cast<f32x4*>(dst + 4 * m) = E;
+            pmax = fmaxf(pmax, fmaxf(fmaxf(fabsf(E[0]), fabsf(E[1])), fmaxf(fabsf(E[2]), fabsf(E[3]))));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, off, 64));
+    return pmax;
+}
+
+__host__ __device__ inline size_t px_shmem_bytes(int tile_floats, int B, int d, int threads) {
+    const int nw = threads / 64;
+    return (size_t)tile_floats * nw * sizeof(float)                                  // wave-private tiles (E)
+           + (size_t)(((B + 3) & ~3) + 4) * sizeof(int)                             // per-query append cursors + work cursor
+           + (size_t)nw * PSH_PEND * 16                                             // wave-private pending admissions
+           + (size_t)d * 16 + (size_t)(d + 1) * 16                                  // rows (verification), merged rows
+           + (size_t)nw * 192 * 4;                                                  // verification scratch
+}
+
+// THREADS / NBG: 1024 threads (4 waves per SIMD, 128 VGPRs) with 2 queries per pass over the rows, or -- batches of 7 and
+// more -- 512 threads (256 VGPRs) with 6.
+template <bool ALIGNED, int MODE, int THREADS, int NBG>
+__global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
+    const EmbedPlan* __restrict__ plan = a.plan;
+    if (__builtin_amdgcn_readfirstlane(plan->contig) == 0) return;      // not this kernel's structure: embed_scan_kernel works
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = lane_id();
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr int NW = THREADS / 64;
+    float* tile = smem + (size_t)wave_in_block * a.tile_floats;
+    int* lcount = reinterpret_cast<int*>(smem + (size_t)NW * a.tile_floats);
+    int* next_unit = lcount + ((a.B + 3) & ~3);
+    u32x4* pend0 = reinterpret_cast<u32x4*>(lcount + ((a.B + 3) & ~3) + 4);
+    u32x4* pend = pend0 + (size_t)wave_in_block * PSH_PEND;
+    const int K = a.W, d = a.emb_d;
+    int4* prog = reinterpret_cast<int4*>(pend0 + (size_t)NW * PSH_PEND);     // d x {first tap a_i, row, c bits, n_i}
+    int4* gtab = prog + d;                                                   // ngroups (+1) merged rows
+    int* sl = reinterpret_cast<int*>(gtab + d + 1) + (size_t)wave_in_block * 192;   // wave-private: 64 survivors,
+    float* Dl = reinterpret_cast<float*>(sl + 64);                                   //   128 row differences
+    int npend = 0;
+
+    const int ktop = __builtin_amdgcn_readfirstlane(plan->ktop);
+    const int ngroups = __builtin_amdgcn_readfirstlane(plan->ngroups);
+    const float cerr_y = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(plan->cerr_y)));
+    const float cerr_p = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(plan->cerr_p)));
+    if (threadIdx.x == 0) *next_unit = 0;
+    if (MODE == PSH_MODE_FILTER)
+        for (int q = (int)threadIdx.x; q < a.B; q += THREADS) lcount[q] = 0;
+    for (int i = (int)threadIdx.x; i < d; i += THREADS) prog[i] = plan->prog[i];
+    for (int i = (int)threadIdx.x; i <= ngroups; i += THREADS) gtab[i] = plan->gtab[i];
+    for (int p = lane; p < a.tile_floats; p += 64) tile[p] = 0.0f;
+    __syncthreads();
+
+    const int nfloat = PSH_SEG + K - 1;
+    const unsigned n_rs = (unsigned)a.n_rows * (unsigned)a.nseg;
+    const unsigned n_units = n_rs * (unsigned)a.n_qgroups;
+    const unsigned u_lo = (unsigned)(((unsigned long long)n_units * blockIdx.x) / gridDim.x);
+    const unsigned u_hi = (unsigned)(((unsigned long long)n_units * (blockIdx.x + 1)) / gridDim.x);
+    typedef const __attribute__((address_space(4))) QueryState* const_qsp;
+    const const_qsp qstate_k = (const_qsp)a.qstate;
+
+    // the query group's merged coordinates h' = sqrt(m) mean hx across the lanes (group g in lane g), V = the scatter inside
+    // the groups, 6 u ||hx||: kept across units while the group stays the same (the whole kernel when B <= NBG)
+    int hgt[NBG][2];
+    float Vq[NBG], hnq[NBG];
+    int hgt_b0 = -1;
+#pragma unroll
+    for (int g = 0; g < NBG; ++g) { hgt[g][0] = hgt[g][1] = 0; Vq[g] = hnq[g] = 0.0f; }
+
+    for (;;) {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(next_unit, 1);
+        const unsigned u = u_lo + (unsigned)__builtin_amdgcn_readfirstlane(v);
+        if (u >= u_hi) break;
+        const unsigned qgi = fast_div(u, a.magic_nrs, n_rs);
+        const unsigned rs = u - qgi * n_rs;
+        const unsigned ri = fast_div(rs, a.magic_nseg, (unsigned)a.nseg);
+        const unsigned sg = rs - ri * (unsigned)a.nseg;
+        const int64_t row = a.row0 + (int64_t)ri * a.row_stride;
+        const int seg_start = (int)sg * PSH_SEG;
+
+        if (MODE == PSH_MODE_FILTER && npend > 0) {   // stores ahead of the loads: vmcnt retires in order
+            pend_flush(pend, npend, lcount, a, lane);
+            npend = 0;
+        }
+        float ymax = 0.0f, pmax;
+        {
+            Stage st;
+            stage_load<ALIGNED>(st, a.dataset + row * a.T, a.T, seg_start, nfloat, lane);
+#pragma unroll
+            for (int q = 0; q < PSH_NSTAGE; ++q) {          // max |y| of everything this segment reads (NaN ignored)
+                if (q < PSH_NSTAGE - 1 || lane + 64 * q < ((nfloat + 3) >> 2)) {
+                    ymax = fmaxf(ymax, fmaxf(fmaxf(fabsf(st.v[q][0]), fabsf(st.v[q][1])),
+                                             fmaxf(fabsf(st.v[q][2]), fabsf(st.v[q][3]))));
+                }
+            }
+            pmax = prefix_store(st, tile, nfloat, lane);     // the tile holds E, not y
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, off, 64));
+        const float err = __builtin_fmaf(ymax, cerr_y, pmax * cerr_p);
+
+        const int r_global = (int)(row + a.r_offset);
+        const int q_begin = (int)qgi * a.q_per_group;
+        const int q_end = (q_begin + a.q_per_group) < a.B ? (q_begin + a.q_per_group) : a.B;
+        const float* yrow_g = a.dataset + row * a.T + seg_start;   // the segment in global memory
+        int ns = 0;                                          // survivors waiting in sl (wave-uniform)
+
+        // Exact verification of the listed survivors (window index | query << 12), rows across the lanes: lane (el, l)
+        // runs the chains of row l and then of row d-1-l of survivor el (short and long support: equal work per lane),
+        // 64 / ceil(d/2) survivors per pass; one lane per survivor then adds the d squares in row order.  A row's taps need
+        // no matrix: c_i on [a_i, ktop), zero elsewhere -- the zero taps the dense chain visits inside its span of
+        // 4-tap groups are visited too (fma(0, y, .) matters for non-finite y).
+        auto verify_list = [&]() {
+            wave_lds_fence();
+            const int H = (d + 1) >> 1, EPP = 64 / H;
+            const int el = lane / H, l = lane - el * H;
+            const int4 oA = prog[l];
+            const int sB = d - 1 - l;
+            const bool hasB = sB > l;
+            const int4 oB = prog[hasB ? sB : l];
+            // the dense chain's span: from the first tap rounded down to a multiple of 4 to the last non-zero tap
+            const int loA = oA.w > 0 ? (oA.x & ~3) : 0, loB = oB.w > 0 ? (oB.x & ~3) : 0;
+            const int nA = oA.w > 0 ? ktop - loA : 0, nB = oB.w > 0 ? ktop - loB : 0;
+            const float cA = __uint_as_float((unsigned)oA.z), cB = __uint_as_float((unsigned)oB.z);
+#pragma unroll 1
+            for (int e0 = 0; e0 < ns; e0 += EPP) {
+                const bool lv = el < EPP && e0 + el < ns;
+                const int ent = lv ? sl[e0 + el] : 0;
+                const int pwin = ent & 4095, b = ent >> 12;
+                const int nA4 = lv ? ((nA + 3) & ~3) : 0, nB4 = (lv && hasB) ? ((nB + 3) & ~3) : 0;
+                auto chain = [&](int lo, int n4, int ath, float c) -> float {
+                    int lm = n4;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) { const int o2 = __shfl_xor(lm, off, 64); lm = o2 > lm ? o2 : lm; }
+                    lm = __builtin_amdgcn_readfirstlane(lm);
+                    float hy = 0.0f;
+#pragma unroll 1
+                    for (int it = 0; it < lm; it += 4) {     // lo, n4 are multiples of 4: a group is all or nothing
+                        const bool act = it < n4;
+                        const int j0 = act ? lo + it : 0;
+                        float t = hy;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float y = (j0 + q < K) ? yrow_g[pwin + j0 + q] : 0.0f;
+                            const bool on = (j0 + q >= ath) && (j0 + q < ktop);
+                            t = __builtin_fmaf(on ? c : 0.0f, y, t);
+                        }
+                        hy = act ? t : hy;
+                    }
+                    return hy;
+                };
+                const float hyA = chain(loA, nA4, oA.x, cA);
+                const float hyB = chain(loB, nB4, oB.x, cB);
+                if (lv) {
+                    const float* hxb = a.hx + (int64_t)b * d;
+                    Dl[el * d + oA.y] = __fsub_rn(hxb[oA.y], hyA);
+                    if (hasB) Dl[el * d + oB.y] = __fsub_rn(hxb[oB.y], hyB);
+                }
+                wave_lds_fence();
+                float ea = __uint_as_float(PSH_INF_BITS);
+                bool hit = false;
+                if (lv && l == 0) {
+                    ea = 0.0f;
+                    for (int i = 0; i < d; ++i) { const float D = Dl[el * d + i]; ea = __builtin_fmaf(D, D, ea); }
+                    hit = ea < __uint_as_float(a.qstate[b].tau2_bits);
+                }
+                const unsigned long long mask = __ballot(hit);
+                wave_lds_fence();                            // Dl is rewritten by the next pass
+                if (!mask) continue;
+                const int nh2 = __popcll(mask);
+                if (npend + nh2 > PSH_PEND) {
+                    pend_flush(pend, npend, lcount, a, lane);
+                    npend = 0;
+                    wave_lds_fence();
+                }
+                if (hit) {
+                    const int slot = npend + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                 __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    pend[slot] = u32x4{__float_as_uint(ea), (unsigned)r_global, (unsigned)(seg_start + pwin), (unsigned)b};
+                }
+                npend += nh2;
+            }
+            wave_lds_fence();                                // sl is refilled afterwards
+        };
+
+        float Pk[PSH_L];                                     // E[t + ktop] of the lane's windows t = lane + 64 w
+#pragma unroll
+        for (int w = 0; w < PSH_L; ++w) Pk[w] = tile[lane + 64 * w + ktop];
+        // admissible windows of the lane: seg_start + lane + 64 w < Tp
+        int nv = (a.Tp - seg_start - lane + 63) >> 6;
+        nv = nv < 0 ? 0 : (nv > PSH_L ? PSH_L : nv);
+        const unsigned vmask = (1u << nv) - 1u;
+
+        for (int b0 = q_begin; b0 < q_end; b0 += NBG) {
+            const int nq = (q_end - b0) < NBG ? (q_end - b0) : NBG;
+            if (b0 != hgt_b0) {                              // wave-uniform
+                hgt_b0 = b0;
+#pragma unroll
+                for (int g = 0; g < NBG; ++g) {
+                    float vs = 0.0f, sq = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        hgt[g][q] = 0;
+                        if (g < nq && lane + 64 * q < ngroups) {
+                            const int4 ge = gtab[lane + 64 * q];
+                            const float* hxb = a.hx + (int64_t)(b0 + g) * d;
+                            float hj[4], sum = 0.0f;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                hj[j] = j < ge.w ? hxb[(ge.z >> (8 * j)) & 255] : 0.0f;
+                                sum += hj[j];
+                                sq = __builtin_fmaf(hj[j], hj[j], sq);
+                            }
+                            const float mean = sum / (float)ge.w;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { const float dv = j < ge.w ? hj[j] - mean : 0.0f; vs = __builtin_fmaf(dv, dv, vs); }
+                            const float rsm = ge.w == 1 ? 1.0f : (ge.w == 2 ? 0.70710678f : (ge.w == 3 ? 0.57735027f : 0.5f));
+                            hgt[g][q] = (int)__float_as_uint(sum * rsm);
+                        }
+                    }
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) { vs += __shfl_xor(vs, off, 64); sq += __shfl_xor(sq, off, 64); }
+                    Vq[g] = vs * (1.0f + 1.0f / 256.0f);
+                    hnq[g] = 6.0f * 5.9604645e-8f * 1.001f * __builtin_sqrtf(sq);
+                }
+            }
+            f32x2 acc[NBG][8];
+#pragma unroll
+            for (int g = 0; g < NBG; ++g)
+#pragma unroll
+                for (int w = 0; w < 8; ++w) acc[g][w] = f32x2{0.f, 0.f};
+            // a (merged) row: its constant and first tap come out of the block's table (one broadcast LDS read, fetched a
+            // row ahead), the query's coordinate out of the lane that holds it
+            const int2* ptab = reinterpret_cast<const int2*>(gtab);              // {c' bits, byte offset of E[a_i]} of entry 0
+            const char* tile_b = reinterpret_cast<const char*>(tile + lane);
+            int2 o_next = ptab[0];
+            auto row_step = [&](int i, const float (&hv)[NBG]) {
+                const int2 o = o_next;
+                o_next = ptab[2 * (i + 1)];                  // (entry ngroups: a blank one)
+                const float c = __uint_as_float((unsigned)o.x);
+                const f32x2 c2 = f32x2{c, c};
+                const float* pa = reinterpret_cast<const float*>(tile_b + o.y);
+                f32x2 S[8];                                  // -S_i of the window pair: e = hx - c S = fma(c, -S, hx)
+#pragma unroll
+                for (int w = 0; w < 8; ++w) S[w] = f32x2{pa[128 * w], pa[128 * w + 64]} - f32x2{Pk[2 * w], Pk[2 * w + 1]};
+#pragma unroll
+                for (int g = 0; g < NBG; ++g) {
+                    if (g < nq) {                            // wave-uniform
+                        const f32x2 hx2 = f32x2{hv[g], hv[g]};
+                        f32x2 e[8];
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) e[w] = __builtin_elementwise_fma(c2, S[w], hx2);
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) acc[g][w] = __builtin_elementwise_fma(e[w], e[w], acc[g][w]);
+                    }
+                }
+            };
+            const int g_lo = ngroups < 64 ? ngroups : 64;
+#pragma unroll 1
+            for (int i = 0; i < g_lo; ++i) {
+                float hv[NBG];
+#pragma unroll
+                for (int g = 0; g < NBG; ++g) hv[g] = __uint_as_float((unsigned)__builtin_amdgcn_readlane(hgt[g][0], i));
+                row_step(i, hv);
+            }
+#pragma unroll 1
+            for (int i = 64; i < ngroups; ++i) {
+                float hv[NBG];
+#pragma unroll
+                for (int g = 0; g < NBG; ++g) hv[g] = __uint_as_float((unsigned)__builtin_amdgcn_readlane(hgt[g][1], i - 64));
+                row_step(i, hv);
+            }
+#pragma unroll
+            for (int g = 0; g < NBG; ++g) {
+                const int b = b0 + g;
+                if (g >= nq) continue;
+                const float errq = err + hnq[g];
+                if (MODE == PSH_MODE_BOOT) {
+                    // upper bound of the exact acc of the lane's (wave's) best window
+                    float m = __uint_as_float(PSH_INF_BITS);
+#pragma unroll
+                    for (int w = 0; w < PSH_L; ++w) m = ((vmask >> w) & 1u) ? fminf(m, acc[g][w >> 1][w & 1]) : m;
+                    if (a.boot_per_wave) {
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+                    }
+                    const float su = __builtin_sqrtf(m + Vq[g]) * (1.0f + 1.0f / 32768.0f) + errq;
+                    const float ub = su * su * (1.0f + 1.0f / 16384.0f);
+                    if (a.boot_per_wave) {
+                        if (lane == 0) a.minbuf[(int64_t)b * a.min_stride + (int64_t)rs] = ub;
+                    } else {
+                        a.minbuf[(int64_t)b * a.min_stride + (int64_t)rs * 64 + lane] = ub;
+                    }
+                } else {
+                    const float tau = __uint_as_float(qstate_k[b].tau2_bits);
+                    const float st = __builtin_sqrtf(tau) * (1.0f + 1.0f / 32768.0f) + errq;
+                    const float thr = st * st * (1.0f + 1.0f / 16384.0f);
+                    unsigned hm = 0u;
+#pragma unroll
+                    for (int w = 0; w < PSH_L; ++w) hm |= !(acc[g][w >> 1][w & 1] > thr) ? (1u << w) : 0u;
+                    hm &= vmask;
+                    // survivors go to the wave's list; the whole wave verifies them together (verify_list)
+                    while (__any(hm != 0u)) {
+                        const bool has = hm != 0u;
+                        const int w = has ? (int)__builtin_ctz(hm) : 0;
+                        hm &= hm - 1u;
+                        const unsigned long long sm = __ballot(has);
+                        const int ne = __popcll(sm);
+                        if (ns + ne > 64) { verify_list(); ns = 0; }
+                        if (has) sl[ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u))] =
+                            (lane + 64 * w) | (b << 12);
+                        ns += ne;
+                    }
+                }
+            }
+        }
+        if (MODE == PSH_MODE_FILTER && ns > 0) { verify_list(); ns = 0; }
+        wave_lds_fence();  // all lanes done with the tile before it is overwritten
+    }
+    if (MODE == PSH_MODE_FILTER) {
+        if (npend > 0) pend_flush(pend, npend, lcount, a, lane);
+        __syncthreads();
+        for (int q = (int)threadIdx.x; q < a.B; q += THREADS)
+            a.bcount[(int64_t)q * PSH_MAX_BLOCKS + blockIdx.x] = lcount[q];
+    }
+}
+
+#define PSH_PX_WIDE_THREADS 512
+#define PSH_PX_WIDE_NBG 6
+#define PSH_PX_NBG 2
+
+bool embed_px_supported(int tile_floats, int B, int d, int K, bool wide) {
+    return d >= 1 && d <= PSH_EMB_MAX_D && K >= 1 && K <= 256 &&
+           px_shmem_bytes(tile_floats, B, d, wide ? PSH_PX_WIDE_THREADS : PSH_SCAN_THREADS) <= PSH_LDS_BYTES;
+}
+
+template <bool ALIGNED, int MODE>
+static hipError_t launch_px_mode(const ScanArgs& a, int grid, hipStream_t s) {
+    if (a.emb_wide) {
+        const size_t shmem = px_shmem_bytes(a.tile_floats, a.B, a.emb_d, PSH_PX_WIDE_THREADS);
+        hipError_t e = hipFuncSetAttribute((const void*)embed_px_kernel<ALIGNED, MODE, PSH_PX_WIDE_THREADS, PSH_PX_WIDE_NBG>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((embed_px_kernel<ALIGNED, MODE, PSH_PX_WIDE_THREADS, PSH_PX_WIDE_NBG>), dim3(grid), dim3(PSH_PX_WIDE_THREADS), shmem, s, a);
+        return hipGetLastError();
+    }
+    const size_t shmem = px_shmem_bytes(a.tile_floats, a.B, a.emb_d, PSH_SCAN_THREADS);
+    hipError_t e = hipFuncSetAttribute((const void*)embed_px_kernel<ALIGNED, MODE, PSH_SCAN_THREADS, PSH_PX_NBG>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((embed_px_kernel<ALIGNED, MODE, PSH_SCAN_THREADS, PSH_PX_NBG>), dim3(grid), dim3(PSH_SCAN_THREADS), shmem, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_embed_px(const ScanArgs& a, int mode, bool aligned, int grid, hipStream_t s) {
+    if (mode == PSH_MODE_BOOT) return aligned ? launch_px_mode<true, PSH_MODE_BOOT>(a, grid, s) : launch_px_mode<false, PSH_MODE_BOOT>(a, grid, s);
+    return aligned ? launch_px_mode<true, PSH_MODE_FILTER>(a, grid, s) : launch_px_mode<false, PSH_MODE_FILTER>(a, grid, s);
+}
+
+}  // namespace psh

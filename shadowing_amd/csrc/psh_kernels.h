@@ -120,9 +120,23 @@ struct ScanArgs {
     int emb_dense;           // embedded scan: always the dense chains, even when the kernel has suffix rows (tests, PSH_EMBED=dense)
     int emb_taps;            // embedded scan, suffix rows: walk the taps even when the support is one interval (PSH_FLAG_EMBED_TAPS)
     int emb_mx;              // embedded scan: the dense kernel's rejection test on the matrix cores (embed_mx_kernel: BOOT / FILTER)
+    const struct EmbedPlan* plan;   // embedded scan, BOOT / FILTER: what embed_plan_kernel found in the matrix (nullable: dense chains / tap walk decided in the kernel)
 };
 
 #define PSH_EMB_MAX_D 128            // embedding rows handled natively
+// What embed_plan_kernel (psh_embed_px.hip) leaves in the workspace for the two kernels launched per stage:
+// contig != 0 -- every row is one constant on [a_i, ktop), one interval for all: embed_px_kernel (prefix sums) does the
+// work and embed_scan_kernel returns at once; contig == 0 -- the other way round.
+struct EmbedPlan {
+    int contig, ktop, ngroups, d;
+    float cerr_y, cerr_p;
+    int pad[2];
+    int4 prog[PSH_EMB_MAX_D];        // rows, short supports first: {first tap a_i, row, c_i bits, taps n_i}
+    int4 gtab[PSH_EMB_MAX_D + 1];    // merged rows: {c' bits, byte offset of E[a_i], member rows (a byte each), members}
+};
+#define PSH_PLAN_BYTES 8192
+static_assert(sizeof(EmbedPlan) <= PSH_PLAN_BYTES, "plan region");
+
 #define PSH_EMB_MAX_TAPS 16384       // emb_d * roundup4(K) floats of LDS for the kernel matrix (what fits is decided by
                                      // the launch plan: psh_embedded_supported)
 #define PSH_LDS_BYTES (160 * 1024)   // LDS per CU (gfx950)
@@ -209,6 +223,9 @@ hipError_t launch_embed_scan(const ScanArgs& a, int mode, bool aligned, int grid
 hipError_t embed_blocks_per_cu(bool aligned, size_t shmem, int* out);
 bool embed_mx_supported(int d, int K, int B, int tile_floats);          // psh_embed_mx.hip: dense kernels, rejection test on the matrix cores
 hipError_t launch_embed_mx(const ScanArgs& a, int mode, bool aligned, int grid, hipStream_t s);   // BOOT (half-segment minima) / FILTER
+hipError_t launch_embed_plan(const float* ker, int d, int K, EmbedPlan* plan, hipStream_t s);     // psh_embed_px.hip: the structure of the matrix
+bool embed_px_supported(int tile_floats, int B, int d, int K, bool wide);
+hipError_t launch_embed_px(const ScanArgs& a, int mode, bool aligned, int grid, hipStream_t s);   // BOOT / FILTER; returns at once unless plan->contig
 size_t scan_shmem_bytes(int tile_floats, int B, int emb_d, int W, int threads = PSH_SCAN_THREADS);
 #define PSH_EMB_WIDE_MIN_B 7          // embedded scan, this many queries and more: 512-thread blocks carrying 10 (6) queries per pass
 size_t scan_mx_shmem_bytes(int tile_floats, int B);

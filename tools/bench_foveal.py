@@ -93,6 +93,15 @@ def main():
             _native.scan_topk_embedded(ds[:, 0, :], ker, hx, c["k"], h=c["h"], workspace=ws)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / args.steps * 1e3
+        # the same scan walking the taps (what kernels with a gap in their support take): PSH_FLAG_EMBED_TAPS
+        for _ in range(2):
+            _native.scan_topk_embedded(ds[:, 0, :], ker, hx, c["k"], h=c["h"], workspace=ws, flags=_native.FLAG_EMBED_TAPS)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(max(2, args.steps // 2)):
+            _native.scan_topk_embedded(ds[:, 0, :], ker, hx, c["k"], h=c["h"], workspace=ws, flags=_native.FLAG_EMBED_TAPS)
+        torch.cuda.synchronize()
+        ms_taps = (time.perf_counter() - t0) / max(2, args.steps // 2) * 1e3
         windows = c["R"] * (c["T"] - 126 - c["h"] + 1)
         taps = int((emb.kernel != 0).sum())
         # through the reference API, dataset already a device tensor (resident)
@@ -116,6 +125,7 @@ def main():
         obj.predict(x.numpy(), k=c["k"], to_predict=host_tp, eta=0.1, cuda=True)
         predict_host_ms = (time.perf_counter() - t0) * 1e3
         line = dict(workload=name, config=c, embedding="Foveal(1.15,0.9,126) d=34", ms_per_call=round(ms, 4),
+                    ms_per_call_tap_walk=round(ms_taps, 4),
                     windows=windows, query_windows_per_s=windows * c["B"] / (ms * 1e-3),
                     nonzero_taps=taps, gfma_per_s=windows * taps * ((c["B"] + 2) // 3) / (ms * 1e-3) / 1e9,
                     stages_ms={k: round(v, 4) for k, v in stages.items() if k.endswith("_ms")},
