@@ -28,6 +28,8 @@
 // The structure is recognised ON THE DEVICE (embed_plan_kernel, one small launch per call: the library cannot look at the
 // matrix without a synchronisation): the plan it leaves in the workspace says which of the two kernels launched for a
 // stage does the work -- the other one returns at once.
+#include <type_traits>
+
 #include "psh_device.h"
 
 namespace psh {
@@ -35,39 +37,79 @@ namespace psh {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---- the plan: one block looks at the d x K matrix -----------------------------------------------------------------------
-__global__ __launch_bounds__(128) void embed_plan_kernel(const float* __restrict__ ker, int d, int K, EmbedPlan* plan) {
-    __shared__ int s_ok;
+// (everything in LDS, rows across the threads: the launch is in front of every sampled call, ~10 us)
+#define PSH_PLAN_THREADS 256
+__global__ __launch_bounds__(PSH_PLAN_THREADS) void embed_plan_kernel(const float* __restrict__ ker, int d, int K, EmbedPlan* plan) {
+    extern __shared__ __attribute__((aligned(16))) float s_ker[];        // d x K
+    __shared__ int s_ok, s_ngroups;
     __shared__ unsigned long long s_U[4];
     __shared__ int4 s_row[PSH_EMB_MAX_D];                    // {first tap, row, c bits, taps}
     __shared__ int4 s_prog[PSH_EMB_MAX_D];                   // the same, longest support last
+    __shared__ int s_rep[PSH_EMB_MAX_D];                     // rank among the identical rows before it
+    __shared__ float s_e2[PSH_EMB_MAX_D], s_c2[PSH_EMB_MAX_D];
     const int tid = (int)threadIdx.x;
-    if (tid == 0) { s_ok = (d <= PSH_EMB_MAX_D && K <= 256) ? 1 : 0; s_U[0] = s_U[1] = s_U[2] = s_U[3] = 0ull; }
+    if (d > PSH_EMB_MAX_D || K > 256) { if (tid == 0) { plan->contig = 0; plan->ngroups = 0; } return; }
+    for (int e = tid; e < d * K; e += PSH_PLAN_THREADS) s_ker[e] = ker[e];
+    if (tid == 0) { s_ok = 1; s_ngroups = 0; s_U[0] = s_U[1] = s_U[2] = s_U[3] = 0ull; }
     __syncthreads();
-    if (!s_ok) { if (tid == 0) { plan->contig = 0; plan->ngroups = 0; } return; }
+    // support mask, size, constant of every row: a wave per row, the taps across its lanes (64 per ballot)
+    __shared__ unsigned long long s_m[PSH_EMB_MAX_D][4];
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int r = wv; r < d; r += PSH_PLAN_THREADS / 64) {
+            const float* row = s_ker + (size_t)r * K;
+            unsigned long long mm[4];
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v[q] = (64 * q + lane < K) ? row[64 * q + lane] : 0.0f;
+                mm[q] = __ballot(v[q] != 0.0f);              // (NaN included: it then fails the comparison with c below)
+            }
+            int nn = 0, low = 1 << 20, top = -1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (mm[q]) {
+                    if (low == (1 << 20)) low = 64 * q + (int)__builtin_ctzll(mm[q]);
+                    top = 64 * q + 63 - (int)__builtin_clzll(mm[q]);
+                    nn += (int)__popcll(mm[q]);
+                }
+            unsigned cb = 0u;                                // the constant: the value of the last non-zero tap
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (top >= 64 * q && top < 64 * q + 64) cb = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v[q]), top & 63);
+            bool bad = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bad = bad || (v[q] != 0.0f && __float_as_uint(v[q]) != cb) || (v[q] != v[q]);
+            const bool okc = !__any(bad) && (fabsf(__uint_as_float(cb)) <= 3.0e38f);
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { s_m[r][q] = mm[q]; if (mm[q]) atomicOr(&s_U[q], mm[q]); }
+                s_row[r] = make_int4(low, r, (int)cb, nn);
+                if (!okc) atomicAnd(&s_ok, 0);
+            }
+        }
+    }
+    __syncthreads();
     unsigned long long m[4] = {0ull, 0ull, 0ull, 0ull};
     int n = 0, lowest = 1 << 20;
     float c = 0.0f;
-    if (tid < d) {                                           // support mask, size, constant of row tid
-        const float* row = ker + (size_t)tid * K;
-        bool okc = true;
-        for (int j = K - 1; j >= 0; --j) {
-            const float v = row[j];
-            if (v != 0.0f) {                                 // (NaN included: it then fails v == v)
-                if (n == 0) c = v;
-                okc = okc && (v == v) && (__float_as_uint(v) == __float_as_uint(c));
-                m[j >> 6] |= 1ull << (j & 63);
-                lowest = j;
-                ++n;
-            }
-        }
-        okc = okc && (fabsf(c) <= 3.0e38f);
+    if (tid < d) {
+        const int4 o = s_row[tid];
+        lowest = o.x; n = o.w; c = __uint_as_float((unsigned)o.z);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (m[q]) atomicOr(&s_U[q], m[q]);
-        s_row[tid] = make_int4(lowest, tid, (int)__float_as_uint(c), n);
-        if (!okc) atomicAnd(&s_ok, 0);
+        for (int q = 0; q < 4; ++q) m[q] = s_m[tid][q];
     }
-    __syncthreads();
+    // the union of the supports: one interval [lowU, topU)?
+    int lowU = -1, topU = 0, nU = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned long long uw = s_U[q];
+        if (uw) {
+            if (lowU < 0) lowU = 64 * q + (int)__builtin_ctzll(uw);
+            topU = 64 * q + 64 - (int)__builtin_clzll(uw);
+            nU += (int)__popcll(uw);
+        }
+    }
     if (tid < d) {                                           // the row must be all of U from its first tap up
         bool oks = true;
 #pragma unroll
@@ -83,50 +125,58 @@ __global__ __launch_bounds__(128) void embed_plan_kernel(const float* __restrict
         s_prog[rk] = make_int4(lowest, tid, (int)__float_as_uint(c), n);
     }
     __syncthreads();
+    // merged rows: identical rows (same constant, same first tap) in groups of up to 4, a group where its first row stands
+    int4 me = make_int4(0, 0, 0, 0);
+    int off = 0, rep = 0;
+    if (tid < d) {
+        me = s_prog[tid];
+        off = 4 * (me.w > 0 ? me.x : topU);                  // byte offset of E[a_i] (E[ktop] for an empty row: S = 0)
+        for (int j = 0; j < tid; ++j) { const int4 o = s_prog[j]; rep += (o.z == me.z && 4 * (o.w > 0 ? o.x : topU) == off) ? 1 : 0; }
+        s_rep[tid] = rep;
+        const float n2 = (float)(me.w + 2);
+        const float t = fabsf(__uint_as_float((unsigned)me.z)) * n2 * n2;
+        s_e2[tid] = t * t;
+        s_c2[tid] = __uint_as_float((unsigned)me.z) * __uint_as_float((unsigned)me.z);
+    }
+    __syncthreads();
+    if (tid < d && (rep & 3) == 0) {                         // a group starts here: its index = the starts before it
+        int g = 0;
+        for (int j = 0; j < tid; ++j) g += (s_rep[j] & 3) == 0 ? 1 : 0;
+        int members = me.y, cnt = 1;
+        for (int j = tid + 1; j < d; ++j) {
+            const int4 o = s_prog[j];
+            if (o.z == me.z && 4 * (o.w > 0 ? o.x : topU) == off && s_rep[j] > rep && s_rep[j] < rep + 4) { members |= o.y << (8 * (s_rep[j] - rep)); ++cnt; }
+        }
+        const float rm = cnt == 1 ? 1.0f : (cnt == 2 ? 1.41421356f : (cnt == 3 ? 1.7320508f : 2.0f));
+        plan->gtab[g] = make_int4((int)__float_as_uint(__fmul_rn(__uint_as_float((unsigned)me.z), rm)), off, members, cnt);
+        atomicAdd(&s_ngroups, 1);
+    }
+    if (tid < d) plan->prog[tid] = me;
+    __syncthreads();
     if (tid == 0) {
-        int lowU = -1, topU = 0, nU = 0;
-        for (int j = 0; j < K; ++j)
-            if ((s_U[j >> 6] >> (j & 63)) & 1ull) { if (lowU < 0) lowU = j; topU = j + 1; ++nU; }
         float e2p = 0.0f, c2s = 0.0f;
-        for (int i = 0; i < d; ++i) {
-            const float ci = __uint_as_float((unsigned)s_prog[i].z);
-            const float n2 = (float)(s_prog[i].w + 2);
-            const float t = fabsf(ci) * n2 * n2;
-            e2p = __builtin_fmaf(t, t, e2p);
-            c2s = __builtin_fmaf(ci, ci, c2s);
-        }
-        const bool ok = s_ok != 0 && nU > 0 && topU - lowU == nU && e2p < 3.0e38f && c2s < 3.0e38f;
-        // merged rows: {c' bits, byte offset of E[a_i] (E[ktop] for an empty row: S = 0), the members' rows (a byte each), m}
-        int G = 0;
-        for (int i = 0; i < d; ++i) {
-            const int4 o = s_prog[i];
-            plan->prog[i] = o;
-            const int off = 4 * (o.w > 0 ? o.x : topU);
-            int g = -1;
-            for (int j = 0; j < G && g < 0; ++j)
-                if (plan->gtab[j].x == o.z && plan->gtab[j].y == off && plan->gtab[j].w < 4) g = j;
-            if (g < 0) { plan->gtab[G] = make_int4(o.z, off, o.y, 1); ++G; }
-            else { int4 ge = plan->gtab[g]; ge.z |= o.y << (8 * ge.w); ge.w += 1; plan->gtab[g] = ge; }
-        }
-        for (int j = 0; j < G; ++j) {
-            int4 ge = plan->gtab[j];
-            const float rm = ge.w == 1 ? 1.0f : (ge.w == 2 ? 1.41421356f : (ge.w == 3 ? 1.7320508f : 2.0f));
-            ge.x = (int)__float_as_uint(__fmul_rn(__uint_as_float((unsigned)ge.x), rm));
-            plan->gtab[j] = ge;
-        }
+        for (int i = 0; i < d; ++i) { e2p += s_e2[i]; c2s += s_c2[i]; }
+        e2p *= 1.0001f; c2s *= 1.0001f;                      // (the order of this sum does not matter to the margin)
+        const int G = s_ngroups;
+        // (at most 64 merged rows: a lane of the scan per row; larger kernels keep the tap walk)
+        const bool ok = s_ok != 0 && nU > 0 && topU - lowU == nU && e2p < 3.0e38f && c2s < 3.0e38f && G <= 64;
         plan->gtab[G] = make_int4(0, 0, 0, 0);
         plan->ktop = topU;
         plan->ngroups = G;
         plan->d = d;
         plan->cerr_y = 1.05f * 5.9604645e-8f * __builtin_sqrtf(e2p);
         plan->cerr_p = 1.05f * 2.0f * 5.9604645e-8f * __builtin_sqrtf(c2s);
-        __threadfence();
         plan->contig = ok ? 1 : 0;
     }
 }
 
 hipError_t launch_embed_plan(const float* ker, int d, int K, EmbedPlan* plan, hipStream_t s) {
-    hipLaunchKernelGGL(embed_plan_kernel, dim3(1), dim3(128), 0, s, ker, d, K, plan);
+    const size_t shmem = (size_t)d * K * sizeof(float);
+    if (shmem > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute((const void*)embed_plan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(embed_plan_kernel, dim3(1), dim3(PSH_PLAN_THREADS), shmem, s, ker, d, K, plan);
     return hipGetLastError();
 }
 
@@ -178,7 +228,7 @@ __host__ __device__ inline size_t px_shmem_bytes(int tile_floats, int B, int d, 
     return (size_t)tile_floats * nw * sizeof(float)                                  // wave-private tiles (E)
            + (size_t)(((B + 3) & ~3) + 4) * sizeof(int)                             // per-query append cursors + work cursor
            + (size_t)nw * PSH_PEND * 16                                             // wave-private pending admissions
-           + (size_t)d * 16 + (size_t)(d + 1) * 16                                  // rows (verification), merged rows
+           + (size_t)d * 16 + (size_t)(d + 1) * 16 + (size_t)(d + 4) * 16           // rows (verification), merged rows, their {c', c', offset}
            + (size_t)nw * 192 * 4;                                                  // verification scratch
 }
 
@@ -200,7 +250,8 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
     const int K = a.W, d = a.emb_d;
     int4* prog = reinterpret_cast<int4*>(pend0 + (size_t)NW * PSH_PEND);     // d x {first tap a_i, row, c bits, n_i}
     int4* gtab = prog + d;                                                   // ngroups (+1) merged rows
-    int* sl = reinterpret_cast<int*>(gtab + d + 1) + (size_t)wave_in_block * 192;   // wave-private: 64 survivors,
+    int4* rtab = gtab + d + 1;                                               // ngroups (+3) x {c' bits twice, byte offset of E[a_i], -}
+    int* sl = reinterpret_cast<int*>(rtab + d + 4) + (size_t)wave_in_block * 192;   // wave-private: 64 survivors,
     float* Dl = reinterpret_cast<float*>(sl + 64);                                   //   128 row differences
     int npend = 0;
 
@@ -212,7 +263,11 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
     if (MODE == PSH_MODE_FILTER)
         for (int q = (int)threadIdx.x; q < a.B; q += THREADS) lcount[q] = 0;
     for (int i = (int)threadIdx.x; i < d; i += THREADS) prog[i] = plan->prog[i];
-    for (int i = (int)threadIdx.x; i <= ngroups; i += THREADS) gtab[i] = plan->gtab[i];
+    for (int i = (int)threadIdx.x; i <= ngroups + 2; i += THREADS) {
+        const int4 ge = i <= ngroups ? plan->gtab[i] : make_int4(0, 0, 0, 0);
+        if (i <= ngroups) gtab[i] = ge;
+        rtab[i] = make_int4(ge.x, ge.x, ge.y, 0);
+    }
     for (int p = lane; p < a.tile_floats; p += 64) tile[p] = 0.0f;
     __syncthreads();
 
@@ -226,11 +281,11 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
 
     // the query group's merged coordinates h' = sqrt(m) mean hx across the lanes (group g in lane g), V = the scatter inside
     // the groups, 6 u ||hx||: kept across units while the group stays the same (the whole kernel when B <= NBG)
-    int hgt[NBG][2];
+    int hgt[NBG];
     float Vq[NBG], hnq[NBG];
     int hgt_b0 = -1;
 #pragma unroll
-    for (int g = 0; g < NBG; ++g) { hgt[g][0] = hgt[g][1] = 0; Vq[g] = hnq[g] = 0.0f; }
+    for (int g = 0; g < NBG; ++g) { hgt[g] = 0; Vq[g] = hnq[g] = 0.0f; }
 
     for (;;) {
         int v = 0;
@@ -365,25 +420,22 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
 #pragma unroll
                 for (int g = 0; g < NBG; ++g) {
                     float vs = 0.0f, sq = 0.0f;
+                    hgt[g] = 0;
+                    if (g < nq && lane < ngroups) {
+                        const int4 ge = gtab[lane];
+                        const float* hxb = a.hx + (int64_t)(b0 + g) * d;
+                        float hj[4], sum = 0.0f;
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        hgt[g][q] = 0;
-                        if (g < nq && lane + 64 * q < ngroups) {
-                            const int4 ge = gtab[lane + 64 * q];
-                            const float* hxb = a.hx + (int64_t)(b0 + g) * d;
-                            float hj[4], sum = 0.0f;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                hj[j] = j < ge.w ? hxb[(ge.z >> (8 * j)) & 255] : 0.0f;
-                                sum += hj[j];
-                                sq = __builtin_fmaf(hj[j], hj[j], sq);
-                            }
-                            const float mean = sum / (float)ge.w;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) { const float dv = j < ge.w ? hj[j] - mean : 0.0f; vs = __builtin_fmaf(dv, dv, vs); }
-                            const float rsm = ge.w == 1 ? 1.0f : (ge.w == 2 ? 0.70710678f : (ge.w == 3 ? 0.57735027f : 0.5f));
-                            hgt[g][q] = (int)__float_as_uint(sum * rsm);
+                        for (int j = 0; j < 4; ++j) {
+                            hj[j] = j < ge.w ? hxb[(ge.z >> (8 * j)) & 255] : 0.0f;
+                            sum += hj[j];
+                            sq = __builtin_fmaf(hj[j], hj[j], sq);
                         }
+                        const float mean = sum / (float)ge.w;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { const float dv = j < ge.w ? hj[j] - mean : 0.0f; vs = __builtin_fmaf(dv, dv, vs); }
+                        const float rsm = ge.w == 1 ? 1.0f : (ge.w == 2 ? 0.70710678f : (ge.w == 3 ? 0.57735027f : 0.5f));
+                        hgt[g] = (int)__float_as_uint(sum * rsm);
                     }
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) { vs += __shfl_xor(vs, off, 64); sq += __shfl_xor(sq, off, 64); }
@@ -396,46 +448,54 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
             for (int g = 0; g < NBG; ++g)
 #pragma unroll
                 for (int w = 0; w < 8; ++w) acc[g][w] = f32x2{0.f, 0.f};
-            // a (merged) row: its constant and first tap come out of the block's table (one broadcast LDS read, fetched a
-            // row ahead), the query's coordinate out of the lane that holds it
-            const int2* ptab = reinterpret_cast<const int2*>(gtab);              // {c' bits, byte offset of E[a_i]} of entry 0
+            // a (merged) row: its constant (as a pair) and first tap come out of the block's table -- one broadcast LDS read,
+            // fetched a row ahead into the OTHER of two register sets (the loop takes two rows a turn) --, the query's
+            // coordinate out of the lane that holds it
             const char* tile_b = reinterpret_cast<const char*>(tile + lane);
-            int2 o_next = ptab[0];
-            auto row_step = [&](int i, const float (&hv)[NBG]) {
-                const int2 o = o_next;
-                o_next = ptab[2 * (i + 1)];                  // (entry ngroups: a blank one)
-                const float c = __uint_as_float((unsigned)o.x);
-                const f32x2 c2 = f32x2{c, c};
-                const float* pa = reinterpret_cast<const float*>(tile_b + o.y);
-                f32x2 S[8];                                  // -S_i of the window pair: e = hx - c S = fma(c, -S, hx)
+            // (NQ, the queries of this pass, is a compile-time constant of the loop: no branch inside a row)
+            auto rows = [&](auto nq_c) {
+                constexpr int NQ = decltype(nq_c)::value;
+                auto row_step = [&](const int4& o, int i) {
+                    const f32x2 c2 = f32x2{__uint_as_float((unsigned)o.x), __uint_as_float((unsigned)o.y)};
+                    const float* pa = reinterpret_cast<const float*>(tile_b + o.z);
+                    f32x2 S[8];                              // -S_i of the window pair: e = hx - c S = fma(c, -S, hx)
 #pragma unroll
-                for (int w = 0; w < 8; ++w) S[w] = f32x2{pa[128 * w], pa[128 * w + 64]} - f32x2{Pk[2 * w], Pk[2 * w + 1]};
+                    for (int w = 0; w < 8; ++w) S[w] = f32x2{pa[128 * w], pa[128 * w + 64]} - f32x2{Pk[2 * w], Pk[2 * w + 1]};
 #pragma unroll
-                for (int g = 0; g < NBG; ++g) {
-                    if (g < nq) {                            // wave-uniform
-                        const f32x2 hx2 = f32x2{hv[g], hv[g]};
+                    for (int g = 0; g < NQ; ++g) {
+                        const float hv = __uint_as_float((unsigned)__builtin_amdgcn_readlane(hgt[g], i));
+                        const f32x2 hx2 = f32x2{hv, hv};
                         f32x2 e[8];
 #pragma unroll
                         for (int w = 0; w < 8; ++w) e[w] = __builtin_elementwise_fma(c2, S[w], hx2);
 #pragma unroll
                         for (int w = 0; w < 8; ++w) acc[g][w] = __builtin_elementwise_fma(e[w], e[w], acc[g][w]);
                     }
+                };
+                // (fetching a row's E values while the row before it is computed -- two register sets, 768 threads for the
+                //  registers -- measured slower, 1.92 against 1.57 ms: four waves per SIMD hide the LDS latency better)
+                int4 oa = rtab[0];
+                int i = 0;
+#pragma unroll 1
+                for (; i + 1 < ngroups; i += 2) {
+                    const int4 ob = rtab[i + 1];
+                    row_step(oa, i);
+                    oa = rtab[i + 2];                        // (up to entry ngroups + 1: blank)
+                    row_step(ob, i + 1);
                 }
+                if (i < ngroups) row_step(oa, i);
             };
-            const int g_lo = ngroups < 64 ? ngroups : 64;
-#pragma unroll 1
-            for (int i = 0; i < g_lo; ++i) {
-                float hv[NBG];
-#pragma unroll
-                for (int g = 0; g < NBG; ++g) hv[g] = __uint_as_float((unsigned)__builtin_amdgcn_readlane(hgt[g][0], i));
-                row_step(i, hv);
-            }
-#pragma unroll 1
-            for (int i = 64; i < ngroups; ++i) {
-                float hv[NBG];
-#pragma unroll
-                for (int g = 0; g < NBG; ++g) hv[g] = __uint_as_float((unsigned)__builtin_amdgcn_readlane(hgt[g][1], i - 64));
-                row_step(i, hv);
+            if constexpr (NBG == 2) {
+                if (nq == 2) rows(std::integral_constant<int, 2>{}); else rows(std::integral_constant<int, 1>{});
+            } else {
+                switch (nq) {
+                    case 1: rows(std::integral_constant<int, 1>{}); break;
+                    case 2: rows(std::integral_constant<int, 2>{}); break;
+                    case 3: rows(std::integral_constant<int, 3>{}); break;
+                    case 4: rows(std::integral_constant<int, 4>{}); break;
+                    case 5: rows(std::integral_constant<int, 5>{}); break;
+                    default: rows(std::integral_constant<int, NBG>{}); break;
+                }
             }
 #pragma unroll
             for (int g = 0; g < NBG; ++g) {
@@ -462,10 +522,22 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
                     const float tau = __uint_as_float(qstate_k[b].tau2_bits);
                     const float st = __builtin_sqrtf(tau) * (1.0f + 1.0f / 32768.0f) + errq;
                     const float thr = st * st * (1.0f + 1.0f / 16384.0f);
-                    unsigned hm = 0u;
+                    // the common case -- nothing of the lane's 16 windows at or below the threshold (or NaN) -- costs a
+                    // minimum and two comparisons, not 16
+                    // (fminf drops a NaN; the sum of the non-negative values keeps it)
+                    float mn = acc[g][0][0];
+                    f32x2 sm2 = acc[g][0];
 #pragma unroll
-                    for (int w = 0; w < PSH_L; ++w) hm |= !(acc[g][w >> 1][w & 1] > thr) ? (1u << w) : 0u;
-                    hm &= vmask;
+                    for (int w = 1; w < PSH_L; ++w) mn = fminf(mn, acc[g][w >> 1][w & 1]);
+#pragma unroll
+                    for (int w = 1; w < 8; ++w) sm2 += acc[g][w];
+                    const float sm1 = sm2[0] + sm2[1];
+                    unsigned hm = 0u;
+                    if (__any(!(mn > thr) || !(sm1 == sm1))) {
+#pragma unroll
+                        for (int w = 0; w < PSH_L; ++w) hm |= !(acc[g][w >> 1][w & 1] > thr) ? (1u << w) : 0u;
+                        hm &= vmask;
+                    }
                     // survivors go to the wave's list; the whole wave verifies them together (verify_list)
                     while (__any(hm != 0u)) {
                         const bool has = hm != 0u;
@@ -495,10 +567,11 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
 #define PSH_PX_WIDE_THREADS 512
 #define PSH_PX_WIDE_NBG 6
 #define PSH_PX_NBG 2
+#define PSH_PX_THREADS 1024
 
 bool embed_px_supported(int tile_floats, int B, int d, int K, bool wide) {
     return d >= 1 && d <= PSH_EMB_MAX_D && K >= 1 && K <= 256 &&
-           px_shmem_bytes(tile_floats, B, d, wide ? PSH_PX_WIDE_THREADS : PSH_SCAN_THREADS) <= PSH_LDS_BYTES;
+           px_shmem_bytes(tile_floats, B, d, wide ? PSH_PX_WIDE_THREADS : PSH_PX_THREADS) <= PSH_LDS_BYTES;
 }
 
 template <bool ALIGNED, int MODE>
@@ -511,11 +584,11 @@ static hipError_t launch_px_mode(const ScanArgs& a, int grid, hipStream_t s) {
         hipLaunchKernelGGL((embed_px_kernel<ALIGNED, MODE, PSH_PX_WIDE_THREADS, PSH_PX_WIDE_NBG>), dim3(grid), dim3(PSH_PX_WIDE_THREADS), shmem, s, a);
         return hipGetLastError();
     }
-    const size_t shmem = px_shmem_bytes(a.tile_floats, a.B, a.emb_d, PSH_SCAN_THREADS);
-    hipError_t e = hipFuncSetAttribute((const void*)embed_px_kernel<ALIGNED, MODE, PSH_SCAN_THREADS, PSH_PX_NBG>,
+    const size_t shmem = px_shmem_bytes(a.tile_floats, a.B, a.emb_d, PSH_PX_THREADS);
+    hipError_t e = hipFuncSetAttribute((const void*)embed_px_kernel<ALIGNED, MODE, PSH_PX_THREADS, PSH_PX_NBG>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((embed_px_kernel<ALIGNED, MODE, PSH_SCAN_THREADS, PSH_PX_NBG>), dim3(grid), dim3(PSH_SCAN_THREADS), shmem, s, a);
+    hipLaunchKernelGGL((embed_px_kernel<ALIGNED, MODE, PSH_PX_THREADS, PSH_PX_NBG>), dim3(grid), dim3(PSH_PX_THREADS), shmem, s, a);
     return hipGetLastError();
 }
 

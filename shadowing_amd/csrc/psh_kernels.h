@@ -174,6 +174,8 @@ struct SelectArgs {
     int unsorted_ok;         // the k selected may be written in arbitrary order (a merge follows)
     int sort_buf_ok;         // set by the launcher: LDS holds a second kpad-item buffer behind the items (merge sort by ranking)
     uint64_t* sort_scratch;  // kpad = 16384: global second buffer of that sort, query b at + b * cand_stride (8-byte units); nullable
+    int rank_sort;           // set by the launcher (kpad >= 4096, scratch at hand): the selected items go to the scratch unordered and
+                             // chunk_sort_kernel / chunk_merge_kernel -- kpad / 1024 blocks per query instead of this one -- order them, write the results
     // two-class slices, fallback only: back-list entries may carry PSH_UNVERIFIED_BITS; the selection then
     // computes their exact distance itself (single query, Identity scan)
     const float* dataset;    // R x T

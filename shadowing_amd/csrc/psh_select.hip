@@ -650,6 +650,20 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
     // wave (shuffles, no barrier), only the wider ones go through LDS
     if (a.unsorted_ok) {
         // the caller merges and orders later: the selected items stay where the collection put them
+    } else if (a.rank_sort) {
+        // the ordering is chunk_sort_kernel / chunk_merge_kernel.s (many blocks instead of this one): hand over the items
+        uint64_t* G = a.sort_scratch + (int64_t)b * a.cand_stride;
+        for (int e = tid; e < a.kpad; e += PSH_SELECT_THREADS) {
+            uint64_t it = items[e];
+            // padding: distance words of its own above every real one (non-negative floats up to +inf), in slot order
+            if ((unsigned)(it >> 32) == 0xffffffffu) it = ((uint64_t)(0x7f800001u + (unsigned)e) << 32) | (unsigned)e;
+            G[e] = it;
+        }
+        if (tid == 0) {
+            G[a.kpad] = (uint64_t)(unsigned)(sm.nsel < need ? sm.nsel : need);
+            if (a.qstate) a.qstate[b].n_valid = sm.nsel < need ? sm.nsel : need;
+        }
+        return;
     } else if (a.kpad <= PSH_SELECT_THREADS) {
         // one item per thread.  Pass 0 orders the 64-bit items as plain integers (distance
         // bits, then slot): exact unless two selected candidates share a distance value;
@@ -892,6 +906,113 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
 }
 
 // ----------------------------------------------------------------------------------
+// ordering of a large selection (kpad >= 4096: the tutorial's k = 8192, the reference test's k = 10000) on MANY compute
+// units: select_kernel -- one block per query -- leaves its kpad selected items unordered in global scratch (padding
+// with distance words of its own, above every real one), and two small launches order them by (d, r, t):
+//   chunk_sort_kernel   a block per 1024 items: every wave orders its 64 by counting, every item then finds its place
+//                       among the block's 16 runs with 15 binary searches (6 LDS probes each)
+//   chunk_merge_kernel  a block per 1024 items again: all distance words in LDS, every item adds to its place in its own
+//                       chunk the number of items below it in each other chunk (10 probes each) and writes the result
+// ~270 LDS probes per item instead of the in-block merge sort's log2(kpad / 64) levels through one block's LDS and
+// global scratch (240 us at kpad = 16384; counting all pairs on all CUs was tried too: 4 VALU operations per pair,
+// 90 us).  Equal distance values are met by the full comparison (finish_rank) wherever a search lands on one.
+// ----------------------------------------------------------------------------------
+#define PSH_CHUNK 1024
+// first position of the ascending run whose distance word is not below myd (len a power of two)
+__device__ __forceinline__ int lower_bound_dw(const unsigned* run, int len, unsigned myd) {
+    int lo = 0;
+    for (int step = len >> 1; step > 0; step >>= 1)
+        if (run[lo + step - 1] < myd) lo += step;
+    if (run[lo] < myd) lo += 1;
+    return lo;
+}
+
+__global__ __launch_bounds__(PSH_CHUNK) void chunk_sort_kernel(SelectArgs a) {
+    __shared__ uint64_t runs[PSH_CHUNK];
+    const int b = (int)blockIdx.y, tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
+    uint64_t* G = a.sort_scratch + (int64_t)b * a.cand_stride + (size_t)blockIdx.x * PSH_CHUNK;
+    const int2* sel_rt = a.sel_rt + (int64_t)b * a.kpad;
+    const uint64_t mine = G[tid];
+    const unsigned myd = (unsigned)(mine >> 32);
+    // position inside the wave's run: the lanes holding a smaller item
+    int wrank = 0;
+#pragma unroll 16
+    for (int j = 0; j < 64; ++j) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mine, j);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)myd, j);
+        wrank += (hi < myd) ? 1 : 0;
+        if (__any(hi == myd && j != lane))                                   // an equal distance value: (r, t) decides
+            wrank += (hi == myd && j != lane && item_less(((uint64_t)hi << 32) | lo, mine, sel_rt)) ? 1 : 0;
+    }
+    runs[(tid & ~63) + wrank] = mine;
+    __syncthreads();
+    // place among the 16 runs: all searches advance together (6 rounds of independent LDS probes)
+    int pos[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) pos[c] = 0;
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1)
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (run_dist(runs + 64 * c, pos[c] + step - 1) < myd) pos[c] += step;
+    int rank = wrank;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+        if (c != w) rank += finish_rank(runs + 64 * c, 64, pos[c], mine, sel_rt);
+    G[rank] = mine;
+}
+
+__global__ __launch_bounds__(PSH_CHUNK) void chunk_merge_kernel(SelectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned dw[];      // the distance words of the query's kpad items, chunk by chunk
+    const int b = (int)blockIdx.y, tid = (int)threadIdx.x, me = (int)blockIdx.x;
+    const uint64_t* G = a.sort_scratch + (int64_t)b * a.cand_stride;
+    const int2* sel_rt = a.sel_rt + (int64_t)b * a.kpad;
+    {
+        const u32x4* src = reinterpret_cast<const u32x4*>(G);          // two items per 16 bytes
+        for (int i = tid; i < a.kpad / 2; i += PSH_CHUNK) {
+            const u32x4 v = src[i];
+            dw[2 * i] = v[1];
+            dw[2 * i + 1] = v[3];
+        }
+    }
+    __syncthreads();
+    const uint64_t mine = G[(size_t)me * PSH_CHUNK + tid];
+    const unsigned myd = (unsigned)(mine >> 32), mylo = (unsigned)mine;
+    const int nch = a.kpad / PSH_CHUNK;
+    int rank = tid;
+    for (int c0 = 0; c0 < nch; c0 += 8) {                    // eight searches advance together
+        int lo[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lo[i] = 0;
+        for (int step = PSH_CHUNK >> 1; step > 0; step >>= 1)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = c0 + i < nch ? c0 + i : me;
+                if (dw[c * PSH_CHUNK + lo[i] + step - 1] < myd) lo[i] += step;
+            }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = c0 + i;
+            if (c >= nch || c == me) continue;
+            int l = lo[i];
+            if (dw[c * PSH_CHUNK + l] < myd) l += 1;
+            // equal distance values (rare): the full comparison decides
+            while (l < PSH_CHUNK && dw[c * PSH_CHUNK + l] == myd && item_less(G[(size_t)c * PSH_CHUNK + l], mine, sel_rt)) l += 1;
+            rank += l;
+        }
+    }
+    const int nsel = (int)(unsigned)G[a.kpad];
+    if (rank < a.k) {
+        float d = __uint_as_float(PSH_INF_BITS);
+        int2 rt = make_int2(-1, -1);
+        if (rank < nsel && myd <= 0x7f800000u) { d = __uint_as_float(myd); rt = sel_rt[mylo]; }
+        a.out_d[(int64_t)b * a.k + rank] = d;
+        a.out_idx[((int64_t)b * a.k + rank) * 2 + 0] = rt.x;
+        a.out_idx[((int64_t)b * a.k + rank) * 2 + 1] = rt.y;
+    }
+}
+
+// ----------------------------------------------------------------------------------
 // merge of per-shard results that arrive SORTED (the cross-GPU merge after the all-gather)
 // ----------------------------------------------------------------------------------
 // G lists of k_in entries, each ascending by (d, r, t), shard g holding smaller rows than shard g+1
@@ -1016,9 +1137,11 @@ hipError_t launch_select(const SelectArgs& a0, int B, hipStream_t s) {
     a.key_cap = (int)key_cap;
     // kpad > 1024: the ordering stage wants a second kpad-item buffer behind the items (merge sort by ranking)
     int64_t area = key_cap;
-    a.sort_buf_ok = (a.kpad > PSH_SELECT_THREADS && a.kpad <= 8 * PSH_SELECT_THREADS && 2 * items_bytes <= lds_budget) ? 1 : 0;
+    // large selections are ordered by chunk_sort_kernel / chunk_merge_kernel when the caller.s scratch can take the items
+    a.rank_sort = (!a.unsorted_ok && a.kpad >= 4096 && a.kpad <= 32768 && a.sort_scratch != nullptr && (int64_t)a.cand_stride > (int64_t)a.kpad) ? 1 : 0;
+    a.sort_buf_ok = (!a.rank_sort && a.kpad > PSH_SELECT_THREADS && a.kpad <= 8 * PSH_SELECT_THREADS && 2 * items_bytes <= lds_budget) ? 1 : 0;
     // beyond that (kpad = 16384): the second buffer is the query's own candidate slots, if the caller says they are free by then
-    if (a.sort_buf_ok || a.kpad <= 8 * PSH_SELECT_THREADS || (int64_t)a.cand_stride < (int64_t)a.kpad) a.sort_scratch = nullptr;
+    if (!a.rank_sort && (a.sort_buf_ok || a.kpad <= 8 * PSH_SELECT_THREADS || (int64_t)a.cand_stride < (int64_t)a.kpad)) a.sort_scratch = nullptr;
     if (a.sort_buf_ok && area < 2 * (int64_t)a.kpad) area = 2 * (int64_t)a.kpad;
     const size_t shmem = items_bytes + (size_t)area * sizeof(unsigned);
     if (shmem > 48 * 1024) {
@@ -1026,6 +1149,15 @@ hipError_t launch_select(const SelectArgs& a0, int B, hipStream_t s) {
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(select_kernel, dim3(B), dim3(PSH_SELECT_THREADS), shmem, s, a);
+    if (a.rank_sort) {
+        const size_t ms_shmem = (size_t)a.kpad * sizeof(unsigned);
+        if (ms_shmem > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)chunk_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ms_shmem);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(chunk_sort_kernel, dim3(a.kpad / PSH_CHUNK, B), dim3(PSH_CHUNK), 0, s, a);
+        hipLaunchKernelGGL(chunk_merge_kernel, dim3(a.kpad / PSH_CHUNK, B), dim3(PSH_CHUNK), ms_shmem, s, a);
+    }
     return hipGetLastError();
 }
 hipError_t launch_merge_sorted(const MergeSortedArgs& a, int B, hipStream_t s) {
