@@ -203,6 +203,10 @@ int psh_scan_topk_exhaustive(int device, void* stream,
  * PSH_FLAG_EMBED_DENSE forces the dense chains (A/B tests).
  */
 int psh_embedded_supported(int d, int K);   /* 1 when a d x K kernel fits the embedded scan (LDS), else 0 */
+/* Diagnostics: byte offset, inside the workspace, of what the last sampled psh_scan_topk_embedded call found in its kernel
+ * matrix -- four int32 {one_interval, ktop, merged_rows, d}: one_interval != 0 says the prefix-sum scan did the work
+ * (tests and tools read it after synchronising the stream). */
+size_t psh_embed_plan_offset(void);
 int psh_scan_topk_embedded(int device, void* stream,
                            const float* dataset, int64_t R, int64_t T, int64_t r_offset,
                            const float* kernel, int d, int K,

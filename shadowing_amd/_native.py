@@ -40,7 +40,7 @@ EXPORTS = ("psh_version", "psh_strerror", "psh_last_hip_error", "psh_workspace_b
            "psh_scan_topk", "psh_scan_topk_exhaustive", "psh_scan_topk_embedded",
            "psh_scan_topk_embedded_exhaustive", "psh_merge_workspace_bytes", "psh_merge_topk",
            "psh_merge_topk_gathered", "psh_merge_sorted_gathered", "psh_gather_paths", "psh_embed_rows",
-           "psh_embedded_supported", "psh_workspace_init", "psh_last_comm_error", "psh_comm_unique_id", "psh_comm_create",
+           "psh_embedded_supported", "psh_embed_plan_offset", "psh_workspace_init", "psh_last_comm_error", "psh_comm_unique_id", "psh_comm_create",
            "psh_comm_destroy", "psh_comm_world", "psh_exchange_merge")
 
 _lib = None
@@ -114,6 +114,8 @@ def load() -> C.CDLL:
     L.psh_merge_topk_gathered.argtypes = [i32, vp, vp, vp, i32, i64, i64, i32, i32, i32, vp, vp, vp, C.c_size_t]
     L.psh_merge_sorted_gathered.restype = i32
     L.psh_merge_sorted_gathered.argtypes = [i32, vp, vp, vp, i32, i64, i64, i32, i32, i32, vp, vp]
+    L.psh_embed_plan_offset.restype = C.c_size_t
+    L.psh_embed_plan_offset.argtypes = []
     L.psh_embedded_supported.restype = i32
     L.psh_embedded_supported.argtypes = [i32, i32]
     L.psh_embed_rows.restype = i32
@@ -292,6 +294,13 @@ def scan_topk_checked(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: i
 
 
 PSH_EMB_MAX_D = 128
+
+
+def embed_plan(workspace: "Workspace") -> dict:
+    """What the last sampled scan_topk_embedded call on `workspace` found in its kernel matrix (synchronises)."""
+    off = int(load().psh_embed_plan_offset())
+    v = workspace.buf[off:off + 16].view(torch.int32).cpu().tolist()
+    return {"one_interval": bool(v[0]), "ktop": v[1], "merged_rows": v[2], "d": v[3]}
 
 
 def embedding_supported(d: int, K: int) -> bool:

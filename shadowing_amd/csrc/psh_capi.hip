@@ -885,6 +885,8 @@ int psh_merge_sorted_gathered(int device, void* stream, const float* d_gathered,
     return PSH_OK;
 }
 
+size_t psh_embed_plan_offset(void) { return PSH_FUSED_BYTES; }
+
 int psh_embedded_supported(int d, int K) {
     if (d <= 0 || K <= 0 || d > PSH_EMB_MAX_D || K > PSH_MAX_W || (int64_t)d * ((K + 3) & ~3) > PSH_EMB_MAX_TAPS) return 0;
     return scan_shmem_bytes(tile_floats_for(K), PSH_MAX_B_PER_LAUNCH, d, K, 512) <= PSH_LDS_BYTES ? 1 : 0;

@@ -135,6 +135,75 @@ def test_suffix_rows_fast_path_equals_the_dense_chains(hip_device, kind, d, K):
     assert 512 <= fast[3]["n_candidates"] <= 1.3 * dense[3]["n_candidates"] + 8
 
 
+def _interval_kernel(rng, d, K, top, dup=0, empty=False):
+    """Rows of one constant on [a_i, top): the structure the prefix-sum scan takes (psh_embed_px.hip) -- `dup` copies of one
+    row (merged four to a group), negative constants, an optional all-zero row, zero taps above `top`."""
+    ker = np.zeros((d, K), np.float32)
+    starts = rng.integers(0, top, d)
+    starts[0] = 0
+    if d > 1:
+        starts[1] = top - 1
+    for i in range(d):
+        ker[i, starts[i]:top] = np.float32(rng.standard_normal() or 1.0)
+    for i in range(dup):
+        ker[2 + i] = ker[2]
+    if empty:
+        ker[d - 1] = 0
+    return ker
+
+
+PX_CASES = [  # R, T, d, K, top, dup, empty, h, k, B : what it exercises
+    (2048, 700, 12, 61, 61, 7, True, 5, 300, 3),      # K % 4 == 1 (the last prefix entry has a group of its own), 7 copies of a row, an empty row
+    (2048, 701, 9, 33, 30, 0, False, 0, 500, 2),      # T % 4 != 0: unaligned rows; zero taps above the interval
+    (1024, 1500, 20, 256, 256, 3, False, 9, 400, 5),  # K = 256: the longest window
+    (2048, 640, 70, 48, 48, 12, False, 5, 300, 9),    # 70 rows, 12 of them identical: 61 merged rows; 7+ queries (512 threads, 6 a pass)
+    (1500, 900, 1, 20, 20, 0, False, 5, 300, 1),      # one row
+]
+
+
+@pytest.mark.parametrize("R,T,d,K,top,dup,empty,h,k,B", PX_CASES)
+def test_prefix_sum_scan_equals_oracle_and_tap_walk(hip_device, oracle_mod, R, T, d, K, top, dup, empty, h, k, B):
+    from shadowing_amd import _native
+    rng = np.random.default_rng(1000 + d + K)
+    ker = _interval_kernel(rng, d, K, top, dup, empty)
+    ds = syn.dataset(R, T, 500 + K)
+    x = syn.gbm_log_returns((B, K), 501 + K)
+    hx = torch.nn.functional.conv1d(torch.tensor(x)[:, None, :], torch.tensor(ker)[:, None, :])[:, :, 0].numpy()
+    ws = _native.Workspace(hip_device)
+    dd, idx, status, prof = hip_scan_embedded(hip_device, ds, ker, hx, k, h, profile=True, workspace=ws)
+    plan = _native.embed_plan(ws)
+    assert prof["path"] == 0 and plan["one_interval"] and plan["ktop"] == top and plan["d"] == d
+    assert plan["merged_rows"] <= d - max(0, dup - (dup + 3) // 4)
+    assert np.all(status == 0)
+    od, oidx = oracle_mod.scan_topk_embedded(ds, ker, hx, k, h=h)
+    assert_exact(dd, idx, od, oidx, "prefix sums vs oracle")
+    td, tidx, tstatus, _ = hip_scan_embedded(hip_device, ds, ker, hx, k, h, flags=_native.FLAG_EMBED_TAPS)
+    assert np.all(tstatus == 0)
+    assert_exact(dd, idx, td, tidx, "prefix sums vs tap walk")
+
+
+def test_kernels_the_prefix_sum_scan_does_not_take(hip_device, oracle_mod):
+    """A gap in the common support (ImputationContext), more than 64 distinct rows, a row that is not one constant: the
+    plan says so on the device and the tap walk / the dense chains do the work -- same results."""
+    from shadowing_amd import _native
+    rng = np.random.default_rng(77)
+    R, T, K, h, k, B = 2048, 700, 80, 5, 300, 2
+    ds = syn.dataset(R, T, 78)
+    x = syn.gbm_log_returns((B, K), 79)
+    many = _interval_kernel(rng, 100, K, K)                       # ~70 distinct starts: more than 64 merged rows
+    gap = _interval_kernel(rng, 10, K, K); gap[:, 30:37] = 0
+    ragged = _interval_kernel(rng, 10, K, K); ragged[4, K - 2] *= 2
+    for name, ker in (("many", many), ("gap", gap), ("ragged", ragged)):
+        hx = torch.nn.functional.conv1d(torch.tensor(x)[:, None, :], torch.tensor(ker)[:, None, :])[:, :, 0].numpy()
+        ws = _native.Workspace(hip_device)
+        dd, idx, status, prof = hip_scan_embedded(hip_device, ds, ker, hx, k, h, profile=True, workspace=ws)
+        plan = _native.embed_plan(ws)
+        assert prof["path"] == 0 and not plan["one_interval"], (name, plan)
+        assert np.all(status == 0)
+        od, oidx = oracle_mod.scan_topk_embedded(ds, ker, hx, k, h=h)
+        assert_exact(dd, idx, od, oidx, name)
+
+
 def test_estimated_threshold_that_falls_short_raises_the_status(hip_device, oracle_mod):
     """The embedded scan admits below an ESTIMATE of the k-th smallest distance taken from the sampled rows.  Here the
     sample lies: near-copies of the query sit in the sampled rows only, so fewer than k windows of the whole ensemble
