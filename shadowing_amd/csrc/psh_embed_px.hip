@@ -332,7 +332,12 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
         // 64 / ceil(d/2) survivors per pass; one lane per survivor then adds the d squares in row order.  A row's taps need
         // no matrix: c_i on [a_i, ktop), zero elsewhere -- the zero taps the dense chain visits inside its span of
         // 4-tap groups are visited too (fma(0, y, .) matters for non-finite y).
-        auto verify_list = [&]() {
+        // `staged` (the call at the end of a unit, when E is no longer needed): the survivors' windows are first copied
+        // into the wave's tile, as many as fit, with all their loads in flight together -- the chains then run at LDS
+        // latency.  Mid-unit (a full list) the chains read global memory, 16 taps' worth of loads at a time.  (A load per
+        // step of the chain made every step a round trip: most of the tutorial's scan, whose 6 x 14 k survivors outnumber
+        // its segments ten to one.)
+        auto verify_list = [&](bool staged) {
             wave_lds_fence();
             const int H = (d + 1) >> 1, EPP = 64 / H;
             const int el = lane / H, l = lane - el * H;
@@ -344,30 +349,81 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
             const int loA = oA.w > 0 ? (oA.x & ~3) : 0, loB = oB.w > 0 ? (oB.x & ~3) : 0;
             const int nA = oA.w > 0 ? ktop - loA : 0, nB = oB.w > 0 ? ktop - loB : 0;
             const float cA = __uint_as_float((unsigned)oA.z), cB = __uint_as_float((unsigned)oB.z);
+            const int Kst = (K + 3) & ~3;
+            int nst = (a.tile_floats / Kst) / EPP * EPP;      // windows per staging batch: whole passes
+            if (nst < EPP) staged = false;
+            if (!staged) nst = 64;
+            const int nq4 = (Kst + 63) >> 6;
 #pragma unroll 1
-            for (int e0 = 0; e0 < ns; e0 += EPP) {
-                const bool lv = el < EPP && e0 + el < ns;
+            for (int s0 = 0; s0 < ns; s0 += nst) {
+            const int s1 = (s0 + nst) < ns ? (s0 + nst) : ns;
+            if (staged) {
+                wave_lds_fence();                            // the batch before this one has been read
+#pragma unroll 1
+                for (int sb = s0; sb < s1; sb += 4) {
+                    float v[4][4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int su = (sb + u) < s1 ? (sb + u) : (s1 - 1);
+                        const float* yw = yrow_g + (sl[su] & 4095);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            int j = lane + 64 * q;
+                            j = j < K ? j : K - 1;
+                            if (q < nq4) v[u][q] = yw[j];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int j = lane + 64 * q;
+                            if (q < nq4 && sb + u < s1 && j < Kst) tile[(sb + u - s0) * Kst + j] = j < K ? v[u][q] : 0.0f;
+                        }
+                }
+                wave_lds_fence();
+            }
+#pragma unroll 1
+            for (int e0 = s0; e0 < s1; e0 += EPP) {
+                const bool lv = el < EPP && e0 + el < s1;
                 const int ent = lv ? sl[e0 + el] : 0;
                 const int pwin = ent & 4095, b = ent >> 12;
                 const int nA4 = lv ? ((nA + 3) & ~3) : 0, nB4 = (lv && hasB) ? ((nB + 3) & ~3) : 0;
+                const float* ys = tile + (lv ? (e0 - s0 + el) * Kst : 0);       // the staged window
                 auto chain = [&](int lo, int n4, int ath, float c) -> float {
                     int lm = n4;
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) { const int o2 = __shfl_xor(lm, off, 64); lm = o2 > lm ? o2 : lm; }
                     lm = __builtin_amdgcn_readfirstlane(lm);
                     float hy = 0.0f;
+                    const float* yw = yrow_g + pwin;
 #pragma unroll 1
-                    for (int it = 0; it < lm; it += 4) {     // lo, n4 are multiples of 4: a group is all or nothing
-                        const bool act = it < n4;
-                        const int j0 = act ? lo + it : 0;
-                        float t = hy;
+                    for (int it = 0; it < lm; it += 16) {
+                        float yb[16];
+                        if (staged) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float y = (j0 + q < K) ? yrow_g[pwin + j0 + q] : 0.0f;
-                            const bool on = (j0 + q >= ath) && (j0 + q < ktop);
-                            t = __builtin_fmaf(on ? c : 0.0f, y, t);
+                            for (int q = 0; q < 16; q += 4) {        // lo + it is a multiple of 4; the batch is padded to Kst
+                                int j = lo + it + q;
+                                j = j < Kst ? j : Kst - 4;
+                                const f32x4 v4 = *reinterpret_cast<const f32x4*>(ys + j);
+                                yb[q] = v4[0]; yb[q + 1] = v4[1]; yb[q + 2] = v4[2]; yb[q + 3] = v4[3];
+                            }
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) {
+                                int j = lo + it + q;
+                                j = j < K ? j : K - 1;
+                                yb[q] = yw[j];
+                            }
                         }
-                        hy = act ? t : hy;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {           // lo, n4 are multiples of 4: a group of 4 taps is all or nothing
+                            const int j = lo + it + q;
+                            const bool on = (j >= ath) && (j < ktop);
+                            const float y = j < K ? yb[q] : 0.0f;
+                            const float t = __builtin_fmaf(on ? c : 0.0f, y, hy);
+                            hy = (it + q < n4) ? t : hy;
+                        }
                     }
                     return hy;
                 };
@@ -401,6 +457,7 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
                     pend[slot] = u32x4{__float_as_uint(ea), (unsigned)r_global, (unsigned)(seg_start + pwin), (unsigned)b};
                 }
                 npend += nh2;
+            }
             }
             wave_lds_fence();                                // sl is refilled afterwards
         };
@@ -545,7 +602,7 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
                         hm &= hm - 1u;
                         const unsigned long long sm = __ballot(has);
                         const int ne = __popcll(sm);
-                        if (ns + ne > 64) { verify_list(); ns = 0; }
+                        if (ns + ne > 64) { verify_list(false); ns = 0; }
                         if (has) sl[ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u))] =
                             (lane + 64 * w) | (b << 12);
                         ns += ne;
@@ -553,7 +610,7 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
                 }
             }
         }
-        if (MODE == PSH_MODE_FILTER && ns > 0) { verify_list(); ns = 0; }
+        if (MODE == PSH_MODE_FILTER && ns > 0) { verify_list(true); ns = 0; }   // (E is done with: the tile stages the windows)
         wave_lds_fence();  // all lanes done with the tile before it is overwritten
     }
     if (MODE == PSH_MODE_FILTER) {

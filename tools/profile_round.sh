@@ -37,5 +37,17 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_fo
 for f in $(find $OUT/prof_foveal -name "*kernel_stats.csv"); do head -8 $f > $OUT/foveal_kernel_stats.csv; done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_rows -o rows -- python $R/tools/bench_forward_topk.py > $OUT/bench_rows_prof.log 2>&1
 for f in $(find $OUT/prof_rows -name "*kernel_stats.csv"); do grep "Name\|rows_kernel\|threshold\|select" $f > $OUT/forward_topk_kernel_stats.csv; done
+# the embedded scans alone: the reference's timed workload (prefix-sum scan), configs[4] (matrix cores): kernel stats + counters
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_fovt -o f -- python $R/tools/fov_prof.py 0 > $OUT/fov_prof.log 2>&1
+for f in $(find $OUT/prof_fovt -name "*kernel_stats.csv"); do grep "Name\|psh::" $f > $OUT/foveal_testing_kernel_stats.csv; done
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_emx -o f -- python $R/tools/emx_prof.py 16 > $OUT/emx_prof.log 2>&1
+for f in $(find $OUT/prof_emx -name "*kernel_stats.csv"); do grep "Name\|psh::" $f > $OUT/wavelet_kernel_stats.csv; done
+j=0
+for CTRS in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVES" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA SQ_ACTIVE_INST_MISC"; do
+  j=$((j+1))
+  timeout 300 rocprofv3 --pmc $CTRS --output-format csv -d $OUT/emb/pmc_f$j -o p -- python $R/tools/fov_prof.py 0 > $OUT/pmc_f$j.log 2>&1
+  timeout 300 rocprofv3 --pmc $CTRS --output-format csv -d $OUT/emb/pmc_w$j -o p -- python $R/tools/emx_prof.py 16 > $OUT/pmc_w$j.log 2>&1
+done
+python $R/tools/summarize_pmc.py $OUT/emb | grep -E "^==|embed_px_kernel<true, 1|embed_mx_kernel<true, 1" > $OUT/embedded_pmc_summary.txt 2>&1
 cd $R
 tail -c 600 $OUT/pmc_summary.txt; head -8 $OUT/kernel_stats.csv; cat $OUT/bench_n1.json

@@ -12,7 +12,8 @@ cp $S/kernel_stats.csv $R/profiles/${TAG}_rocprofv3_kernel_stats.csv
 cp $S/pmc_summary.txt $R/profiles/${TAG}_rocprofv3_pmc_summary.txt
 cp $S/hbm_traffic.json $R/profiles/hbm_traffic.json
 for f in bench_n1_separate_launches.json bench_n1_forced_exchange.json fused_phase_times.txt bench_foveal.jsonl bench_forward_topk.jsonl \
-         foveal_kernel_stats.csv forward_topk_kernel_stats.csv kernel_stats_nofuse.csv; do
+         foveal_kernel_stats.csv forward_topk_kernel_stats.csv kernel_stats_nofuse.csv foveal_testing_kernel_stats.csv wavelet_kernel_stats.csv \
+         embedded_pmc_summary.txt; do
   [ -s $S/$f ] && cp $S/$f $R/profiles/${TAG}_$f
 done
 ls -la $R/profiles
