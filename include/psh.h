@@ -91,6 +91,10 @@ extern "C" {
 /* EMBED_TAPS: psh_scan_topk_embedded on a suffix-rows kernel whose supports form ONE interval (Foveal): the running sums
  * by walking the taps, as for kernels with a gap, instead of differences of prefix sums (A/B tests; same results). */
 #define PSH_FLAG_EMBED_TAPS   128
+/* EMBED_PLAN_KEEP: psh_scan_topk_embedded: the caller's word that the previous sampled call on THIS workspace scanned with
+ * the SAME kernel matrix (same contents): what that call found in the matrix (the plan region of the workspace) is used
+ * again instead of being worked out by one more small launch (~25 us).  Wrong results if the matrix differs. */
+#define PSH_FLAG_EMBED_PLAN_KEEP 256
 /* RESERVE_CUS: the scan leaves a few compute units free (grid = CUs - 4): set by callers that run a collective and a
  * merge on a side stream beside the NEXT scan -- the fused launch otherwise owns every CU of the chip, and work on
  * another stream would wait for it (or make its last block wait). */

@@ -17,7 +17,7 @@ PSH_OK = 0
 PSH_STATUS_OK, PSH_STATUS_OVERFLOW, PSH_STATUS_RETRY = 0, 1, 2
 PSH_MAX_W, PSH_MAX_K, PSH_MAX_B_PER_LAUNCH = 256, 16384, 1024
 # psh_profile.flags (include/psh.h)
-FLAG_UNSORTED, FLAG_FILTER_VALU, FLAG_EMBED_DENSE, FLAG_ROWS_GENERIC, FLAG_NO_FUSE, FLAG_RESERVE_CUS, FLAG_EMBED_MX, FLAG_EMBED_TAPS = 1, 2, 4, 8, 16, 32, 64, 128
+FLAG_UNSORTED, FLAG_FILTER_VALU, FLAG_EMBED_DENSE, FLAG_ROWS_GENERIC, FLAG_NO_FUSE, FLAG_RESERVE_CUS, FLAG_EMBED_MX, FLAG_EMBED_TAPS, FLAG_EMBED_PLAN_KEEP = 1, 2, 4, 8, 16, 32, 64, 128, 256
 
 
 class NativeLibraryError(RuntimeError):
@@ -169,10 +169,12 @@ class Workspace:
     def __init__(self, device: torch.device):
         self.device = device
         self.buf = None
+        self.plan_of = None        # (kernel tensor, its version, B): whose plan the last embedded call left in `buf`
 
     def get(self, nbytes: int) -> torch.Tensor:
         if self.buf is None or self.buf.numel() < nbytes:
             self.buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self.plan_of = None
             self.arm()
         return self.buf
 
@@ -312,9 +314,13 @@ def embedding_supported(d: int, K: int) -> bool:
 
 def scan_topk_embedded(dataset: torch.Tensor, kernel: torch.Tensor, hx: torch.Tensor, k: int, h: int = 0,
                        r_offset: int = 0, hxnorm: torch.Tensor | None = None, workspace: Workspace | None = None,
-                       exhaustive: bool = False, profile: bool = False, out: tuple | None = None, flags: int = 0):
+                       exhaustive: bool = False, profile: bool = False, out: tuple | None = None, flags: int = 0,
+                       keep_plan: bool = False):
     """The scan behind a linear embedding: kernel (d, K) float32 device (unpadded), hx (B, d)
-    embedded queries.  Same returns and conventions as scan_topk."""
+    embedded queries.  Same returns and conventions as scan_topk.
+    keep_plan: the caller changes `kernel` only through torch (in-place edits bump its version): when the last sampled call
+    on `workspace` scanned with this very tensor at this version, what the library found in the matrix is used again
+    (PSH_FLAG_EMBED_PLAN_KEEP) instead of being worked out by one more launch."""
     ds = _dev_tensor(dataset, torch.float32, "dataset")
     ker = _dev_tensor(kernel, torch.float32, "kernel")
     q = _dev_tensor(hx, torch.float32, "hx")
@@ -331,10 +337,18 @@ def scan_topk_embedded(dataset: torch.Tensor, kernel: torch.Tensor, hx: torch.Te
     if B > PSH_MAX_B_PER_LAUNCH and not profile:
         parts = [scan_topk_embedded(ds, ker, q[i:i + PSH_MAX_B_PER_LAUNCH].contiguous(), k, h=h, r_offset=r_offset,
                                     hxnorm=None if hxnorm is None else hxnorm[i:i + PSH_MAX_B_PER_LAUNCH].contiguous(),
-                                    workspace=workspace, exhaustive=exhaustive, flags=flags)
+                                    workspace=workspace, exhaustive=exhaustive, flags=flags, keep_plan=keep_plan)
                  for i in range(0, B, PSH_MAX_B_PER_LAUNCH)]
         return tuple(torch.cat([p[j] for p in parts], dim=0) for j in range(3))
-    ws = (workspace or Workspace(dev)).get(workspace_bytes(R, T, B, K, h, k))
+    wsobj = workspace or Workspace(dev)
+    ws = wsobj.get(workspace_bytes(R, T, B, K, h, k))
+    if not exhaustive:
+        po = wsobj.plan_of
+        planned = not (flags & (FLAG_EMBED_DENSE | FLAG_EMBED_TAPS | FLAG_EMBED_MX))     # the library works the plan out at all
+        if keep_plan and planned and po is not None and po[0] is kernel and po[1:] == (kernel._version, B):
+            flags |= FLAG_EMBED_PLAN_KEEP
+        # (a call of the non-exhaustive entry point leaves the plan of ITS kernel in the workspace, unless it kept one)
+        wsobj.plan_of = (kernel, kernel._version, B) if planned else None
     if out is not None:
         out_d = _dev_tensor(out[0], torch.float32, "out[0]")
         out_idx = _dev_tensor(out[1], torch.int32, "out[1]")

@@ -558,6 +558,9 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     const bool want_plan = p.ker && !p.emb_dense && !p.emb_taps && !p.emx && p.Tp > 1 &&
                            embed_px_supported(tile_floats_for(p.W), p.B, p.emb_d, p.W, false) &&
                            embed_px_supported(tile_floats_for(p.W), p.B, p.emb_d, p.W, true);
+    // (in front of the decision between the sampled and the exhaustive path: with PSH_FLAG_EMBED_PLAN_KEEP the next call may
+    //  take the other one)
+    if (want_plan && !(flags_of(profile) & PSH_FLAG_EMBED_PLAN_KEEP)) HIP_TRY(launch_embed_plan(p.ker, p.emb_d, p.W, w.eplan, s));
 
     // small problems (everything fits the candidate buffer), one-window rows (their
     // numerator uses another reduction order, handled by the exhaustive kernel only) or
@@ -592,10 +595,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
         return run_exhaustive(device, s, dataset, queries, qnorm, p, w, out_d, out_idx, out_status, profile);
     const int64_t stride = p.R / n_sample;
     const int64_t row0 = stride / 2;
-    if (want_plan) {
-        HIP_TRY(launch_embed_plan(p.ker, p.emb_d, p.W, w.eplan, s));
-        p.eplan = w.eplan;
-    }
+    if (want_plan) p.eplan = w.eplan;
 
     const bool stages = profile && profile->mode == PSH_PROFILE_STAGES;
     const bool events = profile && profile->mode == PSH_PROFILE_EVENTS && profile->ev_scan_begin && profile->ev_scan_end;

@@ -152,6 +152,53 @@ __global__ __launch_bounds__(PSH_PLAN_THREADS) void embed_plan_kernel(const floa
         atomicAdd(&s_ngroups, 1);
     }
     if (tid < d) plan->prog[tid] = me;
+    // the verification's schedule: rows longest first, each onto the lane slot with the fewest taps so far (wave 0 -- one
+    // DPP minimum per row --, the rest across the threads)
+    __shared__ int s_bin[PSH_EMB_MAX_D], s_t4[PSH_EMB_MAX_D], s_tot, s_long, s_nl, s_lmax;
+    if (tid == 0) { s_tot = 0; s_long = 1; }
+    __syncthreads();
+    int my_t4 = 0;
+    if (tid < d) {                                           // the dense chain's span of a row, in whole groups of 4 taps (an empty row: one)
+        const int n = me.w > 0 ? topU - (me.x & ~3) : 0;
+        my_t4 = n > 0 ? (n + 3) >> 2 : 1;
+        s_t4[tid] = my_t4;
+        atomicAdd(&s_tot, my_t4);
+        atomicMax(&s_long, my_t4);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        int NL = (s_tot + s_long - 1) / s_long;
+        NL = NL < 1 ? 1 : (NL > 64 ? 64 : NL);
+        int load = 0;
+        for (int i = d - 1; i >= 0; --i) {                   // (s_prog: short supports first)
+            int key = tid < NL ? ((load << 6) | tid) : 0x7fffffff;        // the least loaded slot: a minimum over the wave on the DPP path
+            { int k2 = __builtin_amdgcn_update_dpp(key, key, 0x111, 0xf, 0xf, false); key = k2 < key ? k2 : key; }
+            { int k2 = __builtin_amdgcn_update_dpp(key, key, 0x112, 0xf, 0xf, false); key = k2 < key ? k2 : key; }
+            { int k2 = __builtin_amdgcn_update_dpp(key, key, 0x114, 0xf, 0xf, false); key = k2 < key ? k2 : key; }
+            { int k2 = __builtin_amdgcn_update_dpp(key, key, 0x118, 0xf, 0xf, false); key = k2 < key ? k2 : key; }
+            { int k2 = __builtin_amdgcn_update_dpp(key, key, 0x142, 0xa, 0xf, false); key = k2 < key ? k2 : key; }
+            { int k2 = __builtin_amdgcn_update_dpp(key, key, 0x143, 0xc, 0xf, false); key = k2 < key ? k2 : key; }
+            key = __builtin_amdgcn_readlane(key, 63);
+            if ((key & 63) == tid) { load += s_t4[i]; s_bin[i] = tid; }
+        }
+        int lmax = load;
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) { const int v2 = __shfl_xor(lmax, o2, 64); lmax = v2 > lmax ? v2 : lmax; }
+        if (tid == 0) { s_nl = NL; s_lmax = lmax; plan->vnl = NL; plan->vmax = 4 * lmax; }
+    }
+    __syncthreads();
+    if (tid < 66) {                                          // where a slot's rows start: the rows of the slots before it
+        int w = 0;
+        for (int i = 0; i < d; ++i) w += s_bin[i] < tid ? 1 : 0;
+        plan->vstart[tid] = w;
+    }
+    if (tid < d) {                                           // a slot's rows longest first
+        const int b = s_bin[tid];
+        int w = 0;
+        for (int i = 0; i < d; ++i) w += (s_bin[i] < b || (s_bin[i] == b && i > tid)) ? 1 : 0;
+        const int lo = me.w > 0 ? (me.x & ~3) : 0, ath = me.w > 0 ? me.x : 0;
+        plan->vrow[w] = make_int2(lo | (my_t4 << 8) | (ath << 16) | (me.y << 24), me.z);
+    }
     __syncthreads();
     if (tid == 0) {
         float e2p = 0.0f, c2s = 0.0f;
@@ -223,13 +270,15 @@ __device__ __forceinline__ float prefix_store(const Stage& st, float* dst, int n
     return pmax;
 }
 
+#define PSH_PX_DLCAP 320          // row differences per wave: (survivors per verification pass) x d floats
 __host__ __device__ inline size_t px_shmem_bytes(int tile_floats, int B, int d, int threads) {
     const int nw = threads / 64;
     return (size_t)tile_floats * nw * sizeof(float)                                  // wave-private tiles (E)
            + (size_t)(((B + 3) & ~3) + 4) * sizeof(int)                             // per-query append cursors + work cursor
            + (size_t)nw * PSH_PEND * 16                                             // wave-private pending admissions
-           + (size_t)d * 16 + (size_t)(d + 1) * 16 + (size_t)(d + 4) * 16           // rows (verification), merged rows, their {c', c', offset}
-           + (size_t)nw * 192 * 4;                                                  // verification scratch
+           + (((size_t)d * 8 + 15) & ~(size_t)15) + 272                             // verification schedule: rows, slot starts
+           + (size_t)(d + 1) * 16 + (size_t)(d + 4) * 16                            // merged rows, their {c', c', offset}
+           + (size_t)nw * (64 + PSH_PX_DLCAP) * 4;                                  // verification scratch: survivor list, row differences
 }
 
 // THREADS / NBG: 1024 threads (4 waves per SIMD, 128 VGPRs) with 2 queries per pass over the rows, or -- batches of 7 and
@@ -248,11 +297,12 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
     u32x4* pend0 = reinterpret_cast<u32x4*>(lcount + ((a.B + 3) & ~3) + 4);
     u32x4* pend = pend0 + (size_t)wave_in_block * PSH_PEND;
     const int K = a.W, d = a.emb_d;
-    int4* prog = reinterpret_cast<int4*>(pend0 + (size_t)NW * PSH_PEND);     // d x {first tap a_i, row, c bits, n_i}
-    int4* gtab = prog + d;                                                   // ngroups (+1) merged rows
+    int2* vrow = reinterpret_cast<int2*>(pend0 + (size_t)NW * PSH_PEND);     // the verification's rows, slot by slot
+    int* vstart = reinterpret_cast<int*>(reinterpret_cast<char*>(vrow) + (((size_t)d * 8 + 15) & ~(size_t)15));   // 66 slot starts
+    int4* gtab = reinterpret_cast<int4*>(vstart + 68);                       // ngroups (+1) merged rows
     int4* rtab = gtab + d + 1;                                               // ngroups (+3) x {c' bits twice, byte offset of E[a_i], -}
-    int* sl = reinterpret_cast<int*>(rtab + d + 4) + (size_t)wave_in_block * 192;   // wave-private: 64 survivors,
-    float* Dl = reinterpret_cast<float*>(sl + 64);                                   //   128 row differences
+    int* sl = reinterpret_cast<int*>(rtab + d + 4) + (size_t)wave_in_block * (64 + PSH_PX_DLCAP);   // wave-private: 64 survivors,
+    float* Dl = reinterpret_cast<float*>(sl + 64);                                   //   PSH_PX_DLCAP row differences
     int npend = 0;
 
     const int ktop = __builtin_amdgcn_readfirstlane(plan->ktop);
@@ -262,7 +312,10 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
     if (threadIdx.x == 0) *next_unit = 0;
     if (MODE == PSH_MODE_FILTER)
         for (int q = (int)threadIdx.x; q < a.B; q += THREADS) lcount[q] = 0;
-    for (int i = (int)threadIdx.x; i < d; i += THREADS) prog[i] = plan->prog[i];
+    for (int i = (int)threadIdx.x; i < d; i += THREADS) vrow[i] = plan->vrow[i];
+    for (int i = (int)threadIdx.x; i < 66; i += THREADS) vstart[i] = plan->vstart[i];
+    const int vnl = __builtin_amdgcn_readfirstlane(plan->vnl);
+    const int vmax = __builtin_amdgcn_readfirstlane(plan->vmax);
     for (int i = (int)threadIdx.x; i <= ngroups + 2; i += THREADS) {
         const int4 ge = i <= ngroups ? plan->gtab[i] : make_int4(0, 0, 0, 0);
         if (i <= ngroups) gtab[i] = ge;
@@ -332,132 +385,128 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
         // 64 / ceil(d/2) survivors per pass; one lane per survivor then adds the d squares in row order.  A row's taps need
         // no matrix: c_i on [a_i, ktop), zero elsewhere -- the zero taps the dense chain visits inside its span of
         // 4-tap groups are visited too (fma(0, y, .) matters for non-finite y).
-        // `staged` (the call at the end of a unit, when E is no longer needed): the survivors' windows are first copied
-        // into the wave's tile, as many as fit, with all their loads in flight together -- the chains then run at LDS
-        // latency.  Mid-unit (a full list) the chains read global memory, 16 taps' worth of loads at a time.  (A load per
-        // step of the chain made every step a round trip: most of the tutorial's scan, whose 6 x 14 k survivors outnumber
-        // its segments ten to one.)
+        // Exact verification of the listed survivors (window index | query << 12): the dense chains in the oracle's order
+        // (a row's span of whole 4-tap groups from its first tap rounded down; c_i on [a_i, ktop), the zero taps of the span
+        // visited too: fma(0, y, .) matters for non-finite y), then the d squares in row order by one lane per survivor.
+        // The rows of a survivor are spread over `vnl` lanes by the plan -- longest row first onto the least loaded lane, so the
+        // lanes' tap counts are even (Foveal(1.15, 0.9, 126): 865 taps, the longest row 115 -> 8 lanes, 8 survivors a pass
+        // of 116 steps; a row pair per lane -- 17 lanes, 3 survivors, 136 steps -- was 2.7x the work per survivor).  Every lane
+        // walks its list of rows, 4 taps a step, all lanes `vmax` taps.
+        // `staged` (the call at the end of a unit, when E is no longer needed): the survivors' windows are first copied into
+        // the wave's tile, as many as fit, with all their loads in flight together -- the chains then run at LDS latency.
+        // Mid-unit (a full list: rare) a step reads its 4 samples from global memory.
         auto verify_list = [&](bool staged) {
             wave_lds_fence();
-            const int H = (d + 1) >> 1, EPP = 64 / H;
-            const int el = lane / H, l = lane - el * H;
-            const int4 oA = prog[l];
-            const int sB = d - 1 - l;
-            const bool hasB = sB > l;
-            const int4 oB = prog[hasB ? sB : l];
-            // the dense chain's span: from the first tap rounded down to a multiple of 4 to the last non-zero tap
-            const int loA = oA.w > 0 ? (oA.x & ~3) : 0, loB = oB.w > 0 ? (oB.x & ~3) : 0;
-            const int nA = oA.w > 0 ? ktop - loA : 0, nB = oB.w > 0 ? ktop - loB : 0;
-            const float cA = __uint_as_float((unsigned)oA.z), cB = __uint_as_float((unsigned)oB.z);
             const int Kst = (K + 3) & ~3;
-            int nst = (a.tile_floats / Kst) / EPP * EPP;      // windows per staging batch: whole passes
-            if (nst < EPP) staged = false;
+            int spp = 64 / vnl;                              // survivors per pass
+            spp = spp < PSH_PX_DLCAP / d ? spp : PSH_PX_DLCAP / d;
+            int nst = (a.tile_floats / Kst) / spp * spp;      // windows per staging batch: whole passes
+            if (nst < spp) staged = false;
             if (!staged) nst = 64;
             const int nq4 = (Kst + 63) >> 6;
+            const int sv = lane / vnl, ls = lane - sv * vnl;
+            const int r0 = vstart[ls], r1 = vstart[ls + 1];
 #pragma unroll 1
             for (int s0 = 0; s0 < ns; s0 += nst) {
-            const int s1 = (s0 + nst) < ns ? (s0 + nst) : ns;
-            if (staged) {
-                wave_lds_fence();                            // the batch before this one has been read
+                const int s1 = (s0 + nst) < ns ? (s0 + nst) : ns;
+                if (staged) {
+                    wave_lds_fence();                        // the batch before this one has been read
 #pragma unroll 1
-                for (int sb = s0; sb < s1; sb += 4) {
-                    float v[4][4];
+                    for (int sb = s0; sb < s1; sb += 4) {
+                        float v[4][4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int su = (sb + u) < s1 ? (sb + u) : (s1 - 1);
-                        const float* yw = yrow_g + (sl[su] & 4095);
+                        for (int u = 0; u < 4; ++u) {
+                            const int su = (sb + u) < s1 ? (sb + u) : (s1 - 1);
+                            const float* yw = yrow_g + (sl[su] & 4095);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            int j = lane + 64 * q;
-                            j = j < K ? j : K - 1;
-                            if (q < nq4) v[u][q] = yw[j];
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int j = lane + 64 * q;
-                            if (q < nq4 && sb + u < s1 && j < Kst) tile[(sb + u - s0) * Kst + j] = j < K ? v[u][q] : 0.0f;
-                        }
-                }
-                wave_lds_fence();
-            }
-#pragma unroll 1
-            for (int e0 = s0; e0 < s1; e0 += EPP) {
-                const bool lv = el < EPP && e0 + el < s1;
-                const int ent = lv ? sl[e0 + el] : 0;
-                const int pwin = ent & 4095, b = ent >> 12;
-                const int nA4 = lv ? ((nA + 3) & ~3) : 0, nB4 = (lv && hasB) ? ((nB + 3) & ~3) : 0;
-                const float* ys = tile + (lv ? (e0 - s0 + el) * Kst : 0);       // the staged window
-                auto chain = [&](int lo, int n4, int ath, float c) -> float {
-                    int lm = n4;
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) { const int o2 = __shfl_xor(lm, off, 64); lm = o2 > lm ? o2 : lm; }
-                    lm = __builtin_amdgcn_readfirstlane(lm);
-                    float hy = 0.0f;
-                    const float* yw = yrow_g + pwin;
-#pragma unroll 1
-                    for (int it = 0; it < lm; it += 16) {
-                        float yb[16];
-                        if (staged) {
-#pragma unroll
-                            for (int q = 0; q < 16; q += 4) {        // lo + it is a multiple of 4; the batch is padded to Kst
-                                int j = lo + it + q;
-                                j = j < Kst ? j : Kst - 4;
-                                const f32x4 v4 = *reinterpret_cast<const f32x4*>(ys + j);
-                                yb[q] = v4[0]; yb[q + 1] = v4[1]; yb[q + 2] = v4[2]; yb[q + 3] = v4[3];
-                            }
-                        } else {
-#pragma unroll
-                            for (int q = 0; q < 16; ++q) {
-                                int j = lo + it + q;
+                            for (int q = 0; q < 4; ++q) {
+                                int j = lane + 64 * q;
                                 j = j < K ? j : K - 1;
-                                yb[q] = yw[j];
+                                if (q < nq4) v[u][q] = yw[j];
                             }
                         }
 #pragma unroll
-                        for (int q = 0; q < 16; ++q) {           // lo, n4 are multiples of 4: a group of 4 taps is all or nothing
-                            const int j = lo + it + q;
-                            const bool on = (j >= ath) && (j < ktop);
-                            const float y = j < K ? yb[q] : 0.0f;
-                            const float t = __builtin_fmaf(on ? c : 0.0f, y, hy);
-                            hy = (it + q < n4) ? t : hy;
-                        }
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int j = lane + 64 * q;
+                                if (q < nq4 && sb + u < s1 && j < Kst) tile[(sb + u - s0) * Kst + j] = j < K ? v[u][q] : 0.0f;
+                            }
                     }
-                    return hy;
-                };
-                const float hyA = chain(loA, nA4, oA.x, cA);
-                const float hyB = chain(loB, nB4, oB.x, cB);
-                if (lv) {
-                    const float* hxb = a.hx + (int64_t)b * d;
-                    Dl[el * d + oA.y] = __fsub_rn(hxb[oA.y], hyA);
-                    if (hasB) Dl[el * d + oB.y] = __fsub_rn(hxb[oB.y], hyB);
-                }
-                wave_lds_fence();
-                float ea = __uint_as_float(PSH_INF_BITS);
-                bool hit = false;
-                if (lv && l == 0) {
-                    ea = 0.0f;
-                    for (int i = 0; i < d; ++i) { const float D = Dl[el * d + i]; ea = __builtin_fmaf(D, D, ea); }
-                    hit = ea < __uint_as_float(a.qstate[b].tau2_bits);
-                }
-                const unsigned long long mask = __ballot(hit);
-                wave_lds_fence();                            // Dl is rewritten by the next pass
-                if (!mask) continue;
-                const int nh2 = __popcll(mask);
-                if (npend + nh2 > PSH_PEND) {
-                    pend_flush(pend, npend, lcount, a, lane);
-                    npend = 0;
                     wave_lds_fence();
                 }
-                if (hit) {
-                    const int slot = npend + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                 __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                    pend[slot] = u32x4{__float_as_uint(ea), (unsigned)r_global, (unsigned)(seg_start + pwin), (unsigned)b};
+#pragma unroll 1
+                for (int e0 = s0; e0 < s1; e0 += spp) {
+                    const bool lv = sv < spp && e0 + sv < s1;
+                    const int ent = lv ? sl[e0 + sv] : 0;
+                    const int pwin = ent & 4095, b = ent >> 12;
+                    // the query's coordinates into the survivor's row of Dl (one round of loads for the whole pass)
+                    if (lv) {
+                        const float* hxb = a.hx + (int64_t)b * d;
+                        for (int i = ls; i < d; i += vnl) Dl[sv * d + i] = hxb[i];
+                    }
+                    wave_lds_fence();
+                    const float* ys = tile + (lv ? (e0 - s0 + sv) * Kst : 0);      // the staged window
+                    const float* yw = yrow_g + pwin;
+                    int r = r0;
+                    int2 cur = (lv && r < r1) ? vrow[r] : make_int2(0, 0);
+                    int pos = 0;
+                    float hy = 0.0f;
+#pragma unroll 1
+                    for (int step = 0; step < vmax; step += 4) {
+                        const bool act = lv && r < r1;
+                        const int lo = cur.x & 255, n4 = ((cur.x >> 8) & 127) << 2, ath = (cur.x >> 16) & 255;
+                        const float c = __uint_as_float((unsigned)cur.y);
+                        const bool cnz = (cur.y & 0x7fffffff) != 0;
+                        const int j0 = lo + pos;                                    // a multiple of 4, below Kst while act
+                        f32x4 y4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (staged) {
+                            y4 = *reinterpret_cast<const f32x4*>(ys + (act ? j0 : 0));
+                        } else if (act) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) y4[q] = (j0 + q < K) ? yw[j0 + q] : 0.0f;
+                        }
+                        float t = hy;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const bool on = (j0 + q >= ath) && (j0 + q < ktop);
+                            t = cnz ? __builtin_fmaf(on ? c : 0.0f, y4[q], t) : t;   // (an empty row visits no tap)
+                        }
+                        hy = act ? t : hy;
+                        pos += 4;
+                        if (act && pos >= n4) {                                     // the row is done: D_i = hx_i - hy_i, next row
+                            const int row = (cur.x >> 24) & 127;
+                            Dl[sv * d + row] = __fsub_rn(Dl[sv * d + row], hy);
+                            hy = 0.0f;
+                            pos = 0;
+                            ++r;
+                            if (r < r1) cur = vrow[r];
+                        }
+                    }
+                    wave_lds_fence();
+                    float ea = __uint_as_float(PSH_INF_BITS);
+                    bool hit = false;
+                    if (lv && ls == 0) {
+                        ea = 0.0f;
+                        for (int i = 0; i < d; ++i) { const float D = Dl[sv * d + i]; ea = __builtin_fmaf(D, D, ea); }
+                        hit = ea < __uint_as_float(a.qstate[b].tau2_bits);
+                    }
+                    const unsigned long long mask = __ballot(hit);
+                    wave_lds_fence();                        // Dl is rewritten by the next pass
+                    if (!mask) continue;
+                    const int nh2 = __popcll(mask);
+                    if (npend + nh2 > PSH_PEND) {
+                        pend_flush(pend, npend, lcount, a, lane);
+                        npend = 0;
+                        wave_lds_fence();
+                    }
+                    if (hit) {
+                        const int slot = npend + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                        pend[slot] = u32x4{__float_as_uint(ea), (unsigned)r_global, (unsigned)(seg_start + pwin), (unsigned)b};
+                    }
+                    npend += nh2;
                 }
-                npend += nh2;
-            }
             }
             wave_lds_fence();                                // sl is refilled afterwards
         };

@@ -133,6 +133,11 @@ struct EmbedPlan {
     int pad[2];
     int4 prog[PSH_EMB_MAX_D];        // rows, short supports first: {first tap a_i, row, c_i bits, taps n_i}
     int4 gtab[PSH_EMB_MAX_D + 1];    // merged rows: {c' bits, byte offset of E[a_i], member rows (a byte each), members}
+    // the exact verification's schedule: the rows of a survivor spread over `vnl` lanes so that the lanes' tap counts are
+    // even (longest row first onto the least loaded lane); lane slot s runs vrow[vstart[s] .. vstart[s + 1])
+    int vnl, vmax, vpad[2];          // lanes per survivor, taps of the busiest lane (a multiple of 4)
+    int vstart[68];
+    int2 vrow[PSH_EMB_MAX_D];        // {first tap & ~3 | (taps / 4) << 8 | first tap a_i << 16 | row << 24, c_i bits}
 };
 #define PSH_PLAN_BYTES 8192
 static_assert(sizeof(EmbedPlan) <= PSH_PLAN_BYTES, "plan region");

@@ -182,6 +182,42 @@ def test_prefix_sum_scan_equals_oracle_and_tap_walk(hip_device, oracle_mod, R, T
     assert_exact(dd, idx, td, tidx, "prefix sums vs tap walk")
 
 
+def test_kept_plan_and_changed_kernels(hip_device, oracle_mod):
+    """keep_plan: the second call with the same kernel tensor skips the plan launch (PSH_FLAG_EMBED_PLAN_KEEP) -- same
+    results; an in-place edit of the tensor, another tensor or a grown workspace are noticed and planned afresh."""
+    from shadowing_amd import _native
+    rng = np.random.default_rng(5)
+    R, T, K, h, k, B = 2048, 700, 61, 5, 300, 2
+    ds = syn.dataset(R, T, 91)
+    ds_t = torch.as_tensor(np.ascontiguousarray(ds[:, 0, :])).to(hip_device)
+    x = syn.gbm_log_returns((B, K), 92)
+    ws = _native.Workspace(hip_device)
+
+    def run(ker_np, ker_t, kk=k):
+        hx = torch.nn.functional.conv1d(torch.tensor(x)[:, None, :], torch.tensor(ker_np)[:, None, :])[:, :, 0]
+        out = _native.scan_topk_embedded(ds_t, ker_t, hx.contiguous().to(hip_device), kk, h=h, workspace=ws, keep_plan=True)
+        torch.cuda.synchronize()
+        od, oidx = oracle_mod.scan_topk_embedded(ds, ker_np, hx.numpy(), kk, h=h)
+        assert np.all(out[2].cpu().numpy() == 0)
+        assert_exact(out[0].cpu().numpy(), out[1].cpu().numpy(), od, oidx, "kept plan")
+
+    k1 = _interval_kernel(rng, 12, K, K, 3)
+    t1 = torch.tensor(k1).to(hip_device)
+    run(k1, t1)
+    assert ws.plan_of is not None and ws.plan_of[0] is t1
+    run(k1, t1)                                               # kept
+    k2 = k1.copy(); k2[:, 20:27] = 0                           # a gap: another structure, same tensor edited in place
+    t1.copy_(torch.tensor(k2))
+    run(k2, t1)
+    assert not _native.embed_plan(ws)["one_interval"]
+    k3 = _interval_kernel(rng, 9, K, K - 4)
+    t3 = torch.tensor(k3).to(hip_device)
+    run(k3, t3)                                               # another tensor
+    assert _native.embed_plan(ws)["one_interval"] and _native.embed_plan(ws)["d"] == 9
+    run(k3, t3, kk=12000)                                     # a larger k: the workspace grows, the plan with it
+    run(k3, t3, kk=12000)
+
+
 def test_kernels_the_prefix_sum_scan_does_not_take(hip_device, oracle_mod):
     """A gap in the common support (ImputationContext), more than 64 distinct rows, a row that is not one constant: the
     plan says so on the device and the tap walk / the dense chains do the work -- same results."""
