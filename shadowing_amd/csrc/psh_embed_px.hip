@@ -20,8 +20,8 @@
 // and h' (<= 2 u n_i |c_i| ymax, 6 u ||hx||) the cheap embedding lies within
 //     Rad = ymax * u sqrt(sum_i (c_i (n_i + 2)^2)^2) + Pmax * 2 u ||c||_2 + 6 u ||hx||_2          (each with a 5 % margin)
 // of the exact one; a window survives unless  acc^ > (sqrt(tau)(1 + 2^-15) + Rad)^2 (1 + 2^-14);  survivors get the exact
-// dense chain in the oracle's order (oracle/psh_oracle.c: embedded_acc), their samples re-read from global memory (the
-// tile holds E), and only exact values are ever ranked: results are bit-identical to the tap walk's and the dense chains'.
+// dense chain in the oracle's order (oracle/psh_oracle.c: embedded_acc) -- their rows spread evenly over the lanes by the plan,
+// their samples re-read from global memory (the tile holds E) --, and only exact values are ever ranked: results are bit-identical to the tap walk's and the dense chains'.
 // Non-finite data: an infinite Pmax / ymax makes the threshold infinite, a NaN in E fails every '>' -- either way the
 // windows are verified exactly.
 //
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(PSH_PLAN_THREADS) void embed_plan_kernel(const floa
         }
         if (n == 0) oks = true;
         if (!oks) atomicAnd(&s_ok, 0);
-        int rk = 0;                                          // short supports first (the verification pairs row l with row d-1-l)
+        int rk = 0;                                          // short supports first (the schedule below takes them longest first)
         for (int i2 = 0; i2 < d; ++i2) { const int l2 = s_row[i2].x; rk += (l2 > lowest || (l2 == lowest && i2 < tid)) ? 1 : 0; }
         s_prog[rk] = make_int4(lowest, tid, (int)__float_as_uint(c), n);
     }
@@ -151,7 +151,6 @@ __global__ __launch_bounds__(PSH_PLAN_THREADS) void embed_plan_kernel(const floa
         plan->gtab[g] = make_int4((int)__float_as_uint(__fmul_rn(__uint_as_float((unsigned)me.z), rm)), off, members, cnt);
         atomicAdd(&s_ngroups, 1);
     }
-    if (tid < d) plan->prog[tid] = me;
     // the verification's schedule: rows longest first, each onto the lane slot with the fewest taps so far (wave 0 -- one
     // DPP minimum per row --, the rest across the threads)
     __shared__ int s_bin[PSH_EMB_MAX_D], s_t4[PSH_EMB_MAX_D], s_tot, s_long, s_nl, s_lmax;

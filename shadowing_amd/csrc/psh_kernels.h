@@ -131,7 +131,6 @@ struct EmbedPlan {
     int contig, ktop, ngroups, d;
     float cerr_y, cerr_p;
     int pad[2];
-    int4 prog[PSH_EMB_MAX_D];        // rows, short supports first: {first tap a_i, row, c_i bits, taps n_i}
     int4 gtab[PSH_EMB_MAX_D + 1];    // merged rows: {c' bits, byte offset of E[a_i], member rows (a byte each), members}
     // the exact verification's schedule: the rows of a survivor spread over `vnl` lanes so that the lanes' tap counts are
     // even (longest row first onto the least loaded lane); lane slot s runs vrow[vstart[s] .. vstart[s + 1])

@@ -473,16 +473,18 @@ def test_forward_topk_on_the_device_large(hip_device, oracle_mod):
     assert np.array_equal(flat.cpu().numpy(), oi[..., 0])
 
 
-def test_large_k_ordering_with_duplicated_paths(hip_device, oracle_mod):
-    """k = 12000 over an ensemble whose rows repeat 8 times: every distance value occurs 8 times, so the ordering
-    stage (kpad = 16384, merge sort by ranking through global scratch) leans on the (r, t) tie-break everywhere."""
+@pytest.mark.parametrize("k,B", [(12000, 1), (6000, 3), (4096, 2), (3000, 2)])
+def test_large_k_ordering_with_duplicated_paths(hip_device, oracle_mod, k, B):
+    """Large k over an ensemble whose rows repeat 8 times: every distance value occurs 8 times, so the ordering stage
+    (kpad >= 4096: 1024-item chunk sorts and a merge by ranking over kpad / 1024 blocks per query; below: one block's merge
+    sort) leans on the (r, t) tie-break everywhere -- inside a wave's run, across runs, across chunks."""
     base = syn.dataset(256, 1024, 91)
     ds = np.ascontiguousarray(np.tile(base, (8, 1, 1)))
-    q = syn.gbm_log_returns((1, 20), 92)
-    d, idx, status, _ = hip_scan(hip_device, ds, q, 12000, 20)
-    if status[0] != 0:
-        d, idx, _, _ = hip_scan(hip_device, ds, q, 12000, 20, exhaustive=True)
-    od, oidx = oracle_mod.scan_topk(ds, q, 12000, h=20)
+    q = syn.gbm_log_returns((B, 20), 92)
+    d, idx, status, _ = hip_scan(hip_device, ds, q, k, 20)
+    if np.any(status != 0):
+        d, idx, _, _ = hip_scan(hip_device, ds, q, k, 20, exhaustive=True)
+    od, oidx = oracle_mod.scan_topk(ds, q, k, h=20)
     assert_exact(d, idx, od, oidx, "large k, 8-fold ties")
 
 
