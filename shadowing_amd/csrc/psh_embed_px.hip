@@ -399,8 +399,10 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
             const int Kst = (K + 3) & ~3;
             int spp = 64 / vnl;                              // survivors per pass
             spp = spp < PSH_PX_DLCAP / d ? spp : PSH_PX_DLCAP / d;
-            int nst = (a.tile_floats / Kst) / spp * spp;      // windows per staging batch: whole passes
-            if (nst < spp) staged = false;
+            const int fit = a.tile_floats / Kst;              // windows the tile can stage (5 at K = 252)
+            if (staged && fit < spp) spp = fit;               // long windows: fewer survivors a pass rather than global reads
+            if (spp < 1) { spp = 1; staged = false; }
+            int nst = fit / spp * spp;                        // windows per staging batch: whole passes
             if (!staged) nst = 64;
             const int nq4 = (Kst + 63) >> 6;
             const int sv = lane / vnl, ls = lane - sv * vnl;

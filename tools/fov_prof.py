@@ -19,11 +19,11 @@ x = torch.tensor(syn.gbm_log_returns((B, 126), 2))
 hx = emb(x[:, None, :])[:, 0, :].contiguous().to(dev)
 ws = _native.Workspace(dev)
 for _ in range(4):
-    out = _native.scan_topk_embedded(ds, ker, hx, k, h=252, workspace=ws, flags=flags)
+    out = _native.scan_topk_embedded(ds, ker, hx, k, h=252, workspace=ws, flags=flags, keep_plan=True)
 torch.cuda.synchronize()
 import time
 t0 = time.perf_counter()
 for _ in range(10):
-    _native.scan_topk_embedded(ds, ker, hx, k, h=252, workspace=ws, flags=flags)
+    _native.scan_topk_embedded(ds, ker, hx, k, h=252, workspace=ws, flags=flags, keep_plan=True)
 torch.cuda.synchronize()
 print("ms per call", (time.perf_counter() - t0) * 100)
