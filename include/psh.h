@@ -95,6 +95,9 @@ extern "C" {
  * the SAME kernel matrix (same contents): what that call found in the matrix (the plan region of the workspace) is used
  * again instead of being worked out by one more small launch (~25 us).  Wrong results if the matrix differs. */
 #define PSH_FLAG_EMBED_PLAN_KEEP 256
+/* EMBED_MX_SPLIT: with EMBED_MX: the full scan's rejection test with the three split-precision products the bootstrap uses
+ * instead of one f16 product (a ten times smaller radius, three times the matrix-core work; A/B tests -- same results). */
+#define PSH_FLAG_EMBED_MX_SPLIT 512
 /* RESERVE_CUS: the scan leaves a few compute units free (grid = CUs - 4): set by callers that run a collective and a
  * merge on a side stream beside the NEXT scan -- the fused launch otherwise owns every CU of the chip, and work on
  * another stream would wait for it (or make its last block wait). */

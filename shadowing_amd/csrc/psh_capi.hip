@@ -161,6 +161,7 @@ struct Problem {
     bool emb_dense;       // PSH_FLAG_EMBED_DENSE
     bool rows_generic;    // PSH_FLAG_ROWS_GENERIC
     bool emb_taps;        // PSH_FLAG_EMBED_TAPS
+    bool emx_split;       // PSH_FLAG_EMBED_MX_SPLIT
     const EmbedPlan* eplan;   // embedded scan, sampled path: the plan region of the workspace when embed_plan_kernel runs, else nullptr
     bool emx;             // PSH_FLAG_EMBED_MX and the kernel fits: embed_mx_kernel (BOOT / FILTER)
 };
@@ -187,6 +188,7 @@ int check_problem(const float* dataset, int64_t R, int64_t T, int64_t r_offset, 
     p->emb_dense = false;
     p->rows_generic = false;
     p->emb_taps = false;
+    p->emx_split = false;
     p->eplan = nullptr;
     p->emx = false;
     return PSH_OK;
@@ -307,7 +309,7 @@ ScanArgs make_scan_args(const float* dataset, const float* queries, const Proble
     a.emb_d = p.emb_d;
     a.emb_wide = plan.wide;
     a.emb_dense = p.emb_dense ? 1 : 0;                  // PSH_FLAG_EMBED_DENSE: skip the suffix-rows fast path (A/B tests)
-    a.emb_mx = p.emx ? 1 : 0;
+    a.emb_mx = p.emx ? (p.emx_split ? 3 : 1) : 0;
     a.emb_taps = p.emb_taps ? 1 : 0;
     a.plan = p.eplan;
     a.B = p.B;
@@ -544,6 +546,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     p.emb_dense = (flags_of(profile) & PSH_FLAG_EMBED_DENSE) != 0;
     p.rows_generic = (flags_of(profile) & PSH_FLAG_ROWS_GENERIC) != 0;
     p.emb_taps = (flags_of(profile) & PSH_FLAG_EMBED_TAPS) != 0;
+    p.emx_split = (flags_of(profile) & PSH_FLAG_EMBED_MX_SPLIT) != 0;
     p.emx = p.ker && (flags_of(profile) & PSH_FLAG_EMBED_MX) && !p.emb_dense && p.Tp > 1 &&
             embed_mx_supported(p.emb_d, p.W, p.B, tile_floats_for(p.W));
     Workspace w;

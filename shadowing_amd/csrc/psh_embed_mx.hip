@@ -69,7 +69,11 @@ typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
 
 // NG: groups of 4 kernel rows computed (ceil(d / 4)); a compile-time constant so that the product loop has NO branch around
 // its MFMAs -- with one, the accumulators are shuffled between AGPRs and VGPRs at every merge (96 + 96 moves per K step).
-template <bool ALIGNED, int MODE, int NG>
+// NP: products accumulated per tile.  3 = the split above (the bootstrap: its minima feed the admission level).  1 = hi . hi
+// alone (the full scan): eps = 2^-10 + 2^-22 + 2 K' 2^-24 -- ten times the split's radius, a few times more survivors, each one
+// exact dense chain -- for a third of the MFMAs and half the fragment reads; matrix cores and vector ALUs do not overlap on
+// this part (their busy times ADD UP to the kernel's in every counter run), so an MFMA saved is time saved.
+template <bool ALIGNED, int MODE, int NG, int NP>
 __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NW = PSH_EMX_THREADS / 64;
@@ -129,11 +133,12 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)(v - (float)hi);
         bh[e] = hi;
-        bl[e] = lo;
+        if (NP == 3) bl[e] = lo;
     }
     __syncthreads();
     // eps: splits and the dropped lo.lo term (3 * 2^-22) + fp32 accumulation of 3 K' products (3 * 32 KS * 2^-24), doubled
-    const float eps = PSH_EMX_EPS_REL + 2.0f * (float)(3 * 32 * dm.KS) / 16777216.0f;
+    const float eps = NP == 3 ? PSH_EMX_EPS_REL + 2.0f * (float)(3 * 32 * dm.KS) / 16777216.0f
+                              : 1.001f * (1.0f / 1024.0f + 1.0f / 4194304.0f) + 2.0f * (float)(32 * dm.KS) / 16777216.0f;
     const float cerr = eps * __builtin_sqrtf(__uint_as_float((unsigned)ctl[2])) * 1.001f;
 
     const int nfloat = PSH_SEG + K - 1;
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                     const f16x4v hi = __builtin_convertvector(v, f16x4v);
                     const f32x4 res = v - __builtin_convertvector(hi, f32x4);
                     *reinterpret_cast<f16x4v*>(yh + emx_pad(4 * m)) = hi;
-                    *reinterpret_cast<f16x4v*>(yl + emx_pad(4 * m)) = __builtin_convertvector(res, f16x4v);
+                    if (NP == 3) *reinterpret_cast<f16x4v*>(yl + emx_pad(4 * m)) = __builtin_convertvector(res, f16x4v);
                 }
             }
             if (MODE == PSH_MODE_FILTER && npend > 0) {   // stores ahead of the prefetch: vmcnt retires in order
@@ -276,8 +281,10 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                         const _Float16* pl = blc + (size_t)(4 * g + r4) * 4 * dm.CS + 32 * ks;
                         fb[r4][0] = *reinterpret_cast<const f16x4v*>(ph);
                         fb[r4][1] = *reinterpret_cast<const f16x4v*>(ph + 4);
-                        fb[r4][2] = *reinterpret_cast<const f16x4v*>(pl);
-                        fb[r4][3] = *reinterpret_cast<const f16x4v*>(pl + 4);
+                        if (NP == 3) {
+                            fb[r4][2] = *reinterpret_cast<const f16x4v*>(pl);
+                            fb[r4][3] = *reinterpret_cast<const f16x4v*>(pl + 4);
+                        }
                     }
                 };
                 // the 24 MFMAs of a group: the three products of a tile are 8 instructions apart (no back-to-back dependence)
@@ -288,29 +295,32 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                         // (a concatenation of register pairs, not eight element moves: built element by element the fragments cost
                         //  ~5700 VALU instructions per segment, 1.5 ms of a 3.5 ms scan)
                         bhf[r4] = __builtin_shufflevector(fb[r4][0], fb[r4][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                        blf[r4] = __builtin_shufflevector(fb[r4][2], fb[r4][3], 0, 1, 2, 3, 4, 5, 6, 7);
+                        if (NP == 3) blf[r4] = __builtin_shufflevector(fb[r4][2], fb[r4][3], 0, 1, 2, 3, 4, 5, 6, 7);
                     }
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
                         C[0][4 * g + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bhf[r4], C[0][4 * g + r4], 0, 0, 0);
                         C[1][4 * g + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bhf[r4], C[1][4 * g + r4], 0, 0, 0);
                     }
+                    if (NP == 3) {
 #pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        C[0][4 * g + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bhf[r4], C[0][4 * g + r4], 0, 0, 0);
-                        C[1][4 * g + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bhf[r4], C[1][4 * g + r4], 0, 0, 0);
-                    }
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            C[0][4 * g + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bhf[r4], C[0][4 * g + r4], 0, 0, 0);
+                            C[1][4 * g + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bhf[r4], C[1][4 * g + r4], 0, 0, 0);
+                        }
 #pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        C[0][4 * g + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, blf[r4], C[0][4 * g + r4], 0, 0, 0);
-                        C[1][4 * g + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, blf[r4], C[1][4 * g + r4], 0, 0, 0);
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            C[0][4 * g + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, blf[r4], C[0][4 * g + r4], 0, 0, 0);
+                            C[1][4 * g + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, blf[r4], C[1][4 * g + r4], 0, 0, 0);
+                        }
                     }
                 };
 #pragma unroll 1
                 for (int ks = 0; ks < dm.KS; ++ks) {
                     const int p0 = emx_pad(arow + 32 * ks), p1 = emx_pad(arow + 256 + 32 * ks);
                     const f16x8 ah0 = *reinterpret_cast<const f16x8*>(yh + p0), ah1 = *reinterpret_cast<const f16x8*>(yh + p1);
-                    const f16x8 al0 = *reinterpret_cast<const f16x8*>(yl + p0), al1 = *reinterpret_cast<const f16x8*>(yl + p1);
+                    f16x8 al0 = ah0, al1 = ah1;
+                    if (NP == 3) { al0 = *reinterpret_cast<const f16x8*>(yl + p0); al1 = *reinterpret_cast<const f16x8*>(yl + p1); }
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {                                      // (rows >= d of the last group: zero copies)
                         f16x4v fb[4][4];
@@ -417,25 +427,27 @@ bool embed_mx_supported(int d, int K, int B, int tile_floats) {
     return d >= 1 && d <= PSH_EMX_MAX_D && K >= 1 && K <= 256 && emx_shmem_bytes(K, d, B, tile_floats) <= PSH_LDS_BYTES;
 }
 
-template <bool ALIGNED, int MODE, int NG>
+template <bool ALIGNED, int MODE, int NG, int NP>
 static hipError_t launch_emx_ng(const ScanArgs& a, int grid, hipStream_t s) {
     const size_t shmem = emx_shmem_bytes(a.W, a.emb_d, a.B, a.tile_floats);
-    hipError_t e = hipFuncSetAttribute((const void*)embed_mx_kernel<ALIGNED, MODE, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipError_t e = hipFuncSetAttribute((const void*)embed_mx_kernel<ALIGNED, MODE, NG, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((embed_mx_kernel<ALIGNED, MODE, NG>), dim3(grid), dim3(PSH_EMX_THREADS), shmem, s, a);
+    hipLaunchKernelGGL((embed_mx_kernel<ALIGNED, MODE, NG, NP>), dim3(grid), dim3(PSH_EMX_THREADS), shmem, s, a);
     return hipGetLastError();
 }
 
-template <bool ALIGNED, int MODE>
+template <bool ALIGNED, int MODE, int NP>
 static hipError_t launch_emx(const ScanArgs& a, int grid, hipStream_t s) {
     const int ng = (a.emb_d + 3) >> 2;
-    return ng == 1 ? launch_emx_ng<ALIGNED, MODE, 1>(a, grid, s) : ng == 2 ? launch_emx_ng<ALIGNED, MODE, 2>(a, grid, s)
-                                                                          : launch_emx_ng<ALIGNED, MODE, 3>(a, grid, s);
+    return ng == 1 ? launch_emx_ng<ALIGNED, MODE, 1, NP>(a, grid, s) : ng == 2 ? launch_emx_ng<ALIGNED, MODE, 2, NP>(a, grid, s)
+                                                                              : launch_emx_ng<ALIGNED, MODE, 3, NP>(a, grid, s);
 }
 
+// the bootstrap with the split products; the full scan with one product, or -- a.emb_mx == 3: PSH_FLAG_EMBED_MX_SPLIT -- the split too
 hipError_t launch_embed_mx(const ScanArgs& a, int mode, bool aligned, int grid, hipStream_t s) {
-    if (mode == PSH_MODE_BOOT) return aligned ? launch_emx<true, PSH_MODE_BOOT>(a, grid, s) : launch_emx<false, PSH_MODE_BOOT>(a, grid, s);
-    return aligned ? launch_emx<true, PSH_MODE_FILTER>(a, grid, s) : launch_emx<false, PSH_MODE_FILTER>(a, grid, s);
+    if (mode == PSH_MODE_BOOT) return aligned ? launch_emx<true, PSH_MODE_BOOT, 3>(a, grid, s) : launch_emx<false, PSH_MODE_BOOT, 3>(a, grid, s);
+    if (a.emb_mx == 3) return aligned ? launch_emx<true, PSH_MODE_FILTER, 3>(a, grid, s) : launch_emx<false, PSH_MODE_FILTER, 3>(a, grid, s);
+    return aligned ? launch_emx<true, PSH_MODE_FILTER, 1>(a, grid, s) : launch_emx<false, PSH_MODE_FILTER, 1>(a, grid, s);
 }
 
 }  // namespace psh

@@ -377,6 +377,11 @@ def test_dense_kernel_on_the_matrix_cores_equals_oracle(hip_device, oracle_mod, 
         dd[bad], idx[bad] = d2, i2
     od, oidx = oracle_mod.scan_topk_embedded(ds, ker, hx, k, h=h)
     assert_exact(dd, idx, od, oidx, f"embed_mx {(R, T, d, K, h, k, B, kind)}")
+    # the full scan tests with ONE f16 product (a wider ball around the exact embedding, the same survivors' exact chains
+    # decide); PSH_FLAG_EMBED_MX_SPLIT keeps the three split-precision products there too: same results
+    sd, sidx, sstatus, _ = hip_scan_embedded(hip_device, ds, ker, hx, k, h, flags=_native.FLAG_EMBED_MX | _native.FLAG_EMBED_MX_SPLIT)
+    ok = ~(status.astype(bool) | sstatus.astype(bool))
+    assert_exact(dd[ok], idx[ok], sd[ok], sidx[ok], "embed_mx: one product vs the split")
     if prof["path"] == 0 and not status.any():
         assert prof["n_candidates"] >= k              # (its bootstrap samples half segments: another estimate than the plain scan's)
 
