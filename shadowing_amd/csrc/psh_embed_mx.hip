@@ -24,6 +24,8 @@
 // fraction of a percent -- get the exact dense chains in the oracle's order (embedded_acc), and only those values are ranked:
 // results are bit-identical to embed_scan_kernel's.  The bootstrap uses the bound the other way round (upper bounds).
 // 1296 16x16x32 MFMAs per segment (8.6 us per SIMD) against ~15 000 VALU instructions for the dense chains.
+#include <type_traits>
+
 #include "psh_device.h"
 
 namespace psh {
@@ -33,6 +35,8 @@ namespace psh {
 #define PSH_EMX_MAX_D 12
 #define PSH_EMX_PADL 16                      // zero taps in front of a kernel row (shifts reach 15 taps back)
 #define PSH_EMX_QCAP 128                     // survivors (window | query << 12) queued per wave before exact verification
+#define PSH_EMX_QM_MAX_B 256                 // the per-query pass runs on the matrix cores for 3 .. 256 queries (their tables sit in LDS)
+#define PSH_EMX_QM_MIN_B 3
 #define PSH_EMX_EPS_REL (2.0f * (3.0f / 4194304.0f))          // 2 x 3 * 2^-22; the accumulation part is added per K (below)
 
 struct EmxDims {
@@ -59,6 +63,9 @@ __host__ __device__ inline size_t emx_shmem_bytes(int K, int d, int B, int tile_
     n += (size_t)(PSH_EMX_THREADS / 64) * ((size_t)2 * m.nhalf * sizeof(_Float16) + (size_t)(PSH_EMX_TILE ? tile_floats : 0) * sizeof(float)
                                            + (size_t)PSH_PEND * 16 + (size_t)PSH_EMX_QCAP * 4 + 64 * 4);
     n += (size_t)(((B + 3) & ~3) + 8) * sizeof(int) + 64;
+    // the per-query pass on the matrix cores (B <= PSH_EMX_QM_MAX_B): scaled f16 query coordinates, per-query constants,
+    // a wave's transposed window energies
+    if (B <= PSH_EMX_QM_MAX_B) n += (size_t)((B + 3) & ~3) * (32 + 16) + (size_t)(PSH_EMX_THREADS / 64) * 8 * 64 * sizeof(float);
     return n;
 }
 
@@ -73,7 +80,14 @@ typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
 // alone (the full scan): eps = 2^-10 + 2^-22 + 2 K' 2^-24 -- ten times the split's radius, a few times more survivors, each one
 // exact dense chain -- for a third of the MFMAs and half the fragment reads; matrix cores and vector ALUs do not overlap on
 // this part (their busy times ADD UP to the kernel's in every counter run), so an MFMA saved is time saved.
-template <bool ALIGNED, int MODE, int NG, int NP>
+// QM: the per-query pass of the full scan -- acc^ - ||hx||^2 = ||H||^2 - 2 sum_i hx_i H_i for every window and query -- on the
+// matrix cores too (3 .. 256 queries): a lane's accumulator registers ARE an A fragment (row = its column s, K chunk = its
+// row quarter kq: 8 coordinates of ONE of its windows), and a B tile whose column (kq', q) carries query q's coordinates
+// in K chunk kq' only (zeros elsewhere) picks them apart again:  D[s][(kq', q)] = sum_i H_i(window(kq', s)) hx_q[i] -- 2 MFMAs per
+// accumulator slot and 4 queries where the vector ALUs spent 110 packed instructions per query and half segment.  One f16
+// product again: |c^ - c| <= eps2 sqrt(nh nx) <= eps2 (nh + nx) / 2, so the test compares  nh (1 - eps2) - 2 c^  with
+// thr - nx (1 - eps2): nothing per window and query is added.  The window energies reach the D layout through LDS (8 floats a lane).
+template <bool ALIGNED, int MODE, int NG, int NP, bool QM>
 __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NW = PSH_EMX_THREADS / 64;
@@ -97,11 +111,15 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
     unsigned* sq = reinterpret_cast<unsigned*>(pend + PSH_PEND);
     float* Dl = reinterpret_cast<float*>(sq + PSH_EMX_QCAP);                            // 4 survivors x 16 row differences
     int* lcount = reinterpret_cast<int*>(pw + (size_t)NW * per_wave);
-    int* ctl = lcount + ((a.B + 3) & ~3);                                               // [0] work cursor, [1] max|ker| bits, [2..3] cerr^2 (float bits)
+    int* ctl = lcount + ((a.B + 3) & ~3);                                               // [0] work cursor, [1] max|ker| bits, [2] cerr^2, [3] max ||ker_i||_1 (float bits)
+    const int Bp = (a.B + 3) & ~3;
+    _Float16* qh = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(ctl) + 8 * sizeof(int) + 64);   // QM: [Bp][16] scaled query coordinates
+    f32x4* qc = reinterpret_cast<f32x4*>(qh + (size_t)Bp * 16);                          // QM: [Bp] {sqrt(tau)(1+2^-15), nx(1-eps2), -2/s_q, -}
+    float* nhL = reinterpret_cast<float*>(qc + Bp) + (size_t)wave * 8 * 64;             // QM: the wave's window energies, [slot][kq][s]
     int npend = 0, nsq = 0;
 
     // ---- per-block set-up: kernel scale, the shifted hi/lo copies of every row, the radius constant
-    if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; }
+    if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; ctl[3] = 0; }
     if (MODE == PSH_MODE_FILTER)
         for (int q = tid; q < a.B; q += PSH_EMX_THREADS) lcount[q] = 0;
     for (int e = tid; e < d * K; e += PSH_EMX_THREADS) kerF[e] = a.ker[e];
@@ -118,6 +136,7 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
             float l1 = 0.0f;
             for (int j = 0; j < K; ++j) l1 += fabsf(kerF[tid * K + j]);
             atomicAdd(reinterpret_cast<float*>(&ctl[2]), l1 * l1 * 1.0001f);
+            atomicMax(reinterpret_cast<unsigned*>(&ctl[3]), __float_as_uint(l1 * 1.0001f));
         }
     }
     __syncthreads();
@@ -140,6 +159,30 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
     const float eps = NP == 3 ? PSH_EMX_EPS_REL + 2.0f * (float)(3 * 32 * dm.KS) / 16777216.0f
                               : 1.001f * (1.0f / 1024.0f + 1.0f / 4194304.0f) + 2.0f * (float)(32 * dm.KS) / 16777216.0f;
     const float cerr = eps * __builtin_sqrtf(__uint_as_float((unsigned)ctl[2])) * 1.001f;
+    const float kl1max = __uint_as_float((unsigned)ctl[3]);
+    constexpr float eps2 = 1.001f * (1.0f / 1024.0f + 1.0f / 4194304.0f) + 64.0f / 16777216.0f;
+    if (QM) {
+        // per query: its coordinates as f16 at a power-of-two scale of its own (max |hx_i| in [256, 512)), its constants
+        for (int q = tid; q < Bp; q += PSH_EMX_THREADS) {
+            float hq[16], mx = 0.0f, nxq = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                hq[i] = (q < a.B && i < d) ? a.hx[(int64_t)q * d + i] : 0.0f;
+                mx = fmaxf(mx, fabsf(hq[i]));
+                nxq = __builtin_fmaf(hq[i], hq[i], nxq);
+            }
+            const unsigned mb2 = __float_as_uint(mx);
+            int eq = mb2 >= 0x00800000u ? 9 - ((int)((mb2 >> 23) & 255u) - 126) : 0;
+            eq = eq > 100 ? 100 : (eq < -100 ? -100 : eq);
+            const float sq_ = __uint_as_float((unsigned)(127 + eq) << 23);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) qh[q * 16 + i] = (_Float16)(hq[i] * sq_);
+            const float tau = q < a.B ? __uint_as_float(a.qstate[q].tau2_bits) : 0.0f;
+            qc[q] = f32x4{__builtin_sqrtf(tau) * (1.0f + 1.0f / 32768.0f), nxq * (1.0f - eps2) * (1.0f - 1.0f / 1048576.0f),
+                          -2.0f * __uint_as_float((unsigned)(127 - eq) << 23), 0.0f};
+        }
+        __syncthreads();
+    }
 
     const int nfloat = PSH_SEG + K - 1;
     const unsigned n_rs = (unsigned)a.n_rows * (unsigned)a.nseg;
@@ -153,7 +196,8 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
 
     // exact verification of the queued survivors: lane (e, i) runs row i of survivor e (4 per pass), the oracle's order:
     // hy_i = fma chain over all K taps, D_i = hx_i - hy_i, acc = fma chain over i
-    auto verify = [&](int seg_start, int r_global, const float* yrow) {
+    auto verify_impl = [&](int seg_start, int r_global, const float* yrow, auto fast_c) {
+        constexpr bool FAST = decltype(fast_c)::value;
         wave_lds_fence();
         const int el = lane >> 4, il = lane & 15;
 #pragma unroll 1
@@ -162,11 +206,47 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
             const unsigned ent = lv ? sq[e0 + el] : 0u;
             const int pwin = (int)(ent & 4095u), b = (int)(ent >> 12);
             float hy = 0.0f;
-            if (lv && il < d) {
-                const float* kr = kerF + il * K;
-                if (PSH_EMX_TILE) { for (int j = 0; j < K; ++j) hy = __builtin_fmaf(kr[j], tile[lds_pad(pwin + j)], hy); }
-                else { const float* yw = yrow + seg_start + pwin; for (int j = 0; j < K; ++j) hy = __builtin_fmaf(kr[j], yw[j], hy); }
-                Dl[el * 16 + il] = __fsub_rn(a.hx[(int64_t)b * d + il], hy);
+            if constexpr (!FAST) {
+                // (mid-unit, a full queue -- rare: the accumulators are live, so the chain reads memory tap by tap and needs no registers)
+                if (lv && il < d) {
+                    const float* kr = kerF + il * K;
+                    const float* yw = yrow + seg_start + pwin;
+                    for (int j = 0; j < K; ++j) hy = __builtin_fmaf(kr[j], yw[j], hy);
+                    Dl[el * 16 + il] = __fsub_rn(a.hx[(int64_t)b * d + il], hy);
+                }
+            } else {
+                // (unit end: the segment's f16 copies are done with) the 4 survivors' windows are first copied into that LDS,
+                // all loads in flight together, and the chains run at LDS latency: a load per step of the chain was a round
+                // trip to memory per tap (38 us a pass of 4 survivors, a quarter of the 16-query scan)
+                // (survivors 0, 1 at the start of the hi copy, 2, 3 at the start of the lo copy: 2 Kst floats = 4 Kst halves each,
+                //  inside the part every segment rewrites -- the zero tails of the copies must stay zero: 0 * garbage)
+                const int Kst = (K + 3) & ~3;
+                float* ysA = reinterpret_cast<float*>(yh);
+                float* ysB = reinterpret_cast<float*>(yl);
+                {
+                    float v[16];
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) {                              // survivor m >> 2, taps lane + 64 (m & 3)
+                        const int e2 = e0 + (m >> 2);
+                        const int pw2 = (int)((e2 < nsq ? sq[e2] : sq[e0]) & 4095u);
+                        int j = lane + 64 * (m & 3);
+                        j = j < K ? j : K - 1;
+                        v[m] = yrow[seg_start + pw2 + j];
+                    }
+                    wave_lds_fence();                                           // the pass before this one has read ys
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) {
+                        const int j = lane + 64 * (m & 3);
+                        if (j < Kst) (((m >> 2) & 2) ? ysB : ysA)[Kst * ((m >> 2) & 1) + j] = v[m];
+                    }
+                    wave_lds_fence();
+                }
+                const float* kr = kerF + (il < d ? il : 0) * K;
+                const float* yw = ((el & 2) ? ysB : ysA) + Kst * (el & 1);
+                const float hxv = (lv && il < d) ? a.hx[(int64_t)b * d + il] : 0.0f;
+#pragma unroll 4
+                for (int j = 0; j < K; ++j) hy = __builtin_fmaf(kr[j], yw[j], hy);
+                if (lv && il < d) Dl[el * 16 + il] = __fsub_rn(hxv, hy);
             }
             wave_lds_fence();
             float ea = 0.0f;
@@ -193,6 +273,8 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
         nsq = 0;
         wave_lds_fence();
     };
+    auto verify = [&](int seg_start, int r_global, const float* yrow) { verify_impl(seg_start, r_global, yrow, std::false_type{}); };
+    auto verify_end = [&](int seg_start, int r_global, const float* yrow) { verify_impl(seg_start, r_global, yrow, std::true_type{}); };
 
     auto grab = [&]() -> unsigned {
         int v0 = 0;
@@ -338,11 +420,100 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
 #pragma unroll
                 for (int sl = 0; sl < 8; ++sl) { C[sl >> 2][i][sl & 3] *= inv; nh[sl] = __builtin_fmaf(C[sl >> 2][i][sl & 3], C[sl >> 2][i][sl & 3], nh[sl]); }
             }
+            float nh_raw[8];
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) nh_raw[sl] = nh[sl];
 #pragma unroll
             for (int sl = 0; sl < 8; ++sl) {                                            // an inadmissible window never wins, never survives
                 const int p = 16 * (32 * hf + 16 * (sl >> 2) + 4 * kq + (sl & 3)) + scol;
                 nh[sl] = (seg_start + p < a.Tp) ? nh[sl] : __uint_as_float(PSH_INF_BITS);
             }
+            if constexpr (QM) {
+                // ---- the per-query pass on the matrix cores
+                // the scale of the accumulators: |H_i| <= ymax max_i ||ker_i||_1 -> [8192, 16384) (f16 keeps 11 bits down to 6e-5)
+                const unsigned bb = __float_as_uint(ymax * kl1max);
+                int ec = bb >= 0x00800000u ? 14 - ((int)((bb >> 23) & 255u) - 126) : 0;
+                ec = ec > 100 ? 100 : (ec < -100 ? -100 : ec);
+                const float sc = __uint_as_float((unsigned)(127 + ec) << 23), inv_sc = __uint_as_float((unsigned)(127 - ec) << 23);
+                wave_lds_fence();                                                       // the half before this one has read nhL
+                // a non-finite accumulator (non-finite data) spoils the D values of the three other windows of its A row (0 * NaN):
+                // such a half segment takes the careful path for every group (a NaN fails '>' and is kept)
+                bool bad0 = false;
+#pragma unroll
+                for (int sl = 0; sl < 8; ++sl) bad0 = bad0 || !(nh_raw[sl] < __uint_as_float(PSH_INF_BITS));
+                const bool badC = __any(bad0);
+                f16x8 A2[8][(4 * NG > 8) ? 2 : 1];
+#pragma unroll
+                for (int sl = 0; sl < 8; ++sl) {
+                    nhL[sl * 64 + kq * 16 + scol] = nh[sl] * (1.0f - eps2) * (1.0f - 1.0f / 1048576.0f);
+#pragma unroll
+                    for (int h2 = 0; h2 < ((4 * NG > 8) ? 2 : 1); ++h2)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            A2[sl][h2][j] = (8 * h2 + j < 4 * NG) ? (_Float16)(C[sl >> 2][(8 * h2 + j < 4 * NG) ? 8 * h2 + j : 0][sl & 3] * sc) : (_Float16)0.0f;
+                }
+                wave_lds_fence();
+                const int ncol = lane & 15, gq = lane >> 4;                             // D layout: column (kq', q) = ncol, rows 4 gq + rr = s
+                const int kqp = ncol >> 2;
+                // one group of 4 queries: D of a slot, turned into acc^ - nx of the lane's 4 windows of that slot
+                auto eval_slot = [&](int sl, const f16x8 (&B2)[2], float kk) -> f32x4 {
+                    f32x4 D = f32x4{0.f, 0.f, 0.f, 0.f};
+                    D = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[sl][0], B2[0], D, 0, 0, 0);
+                    if (4 * NG > 8) D = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[sl][(4 * NG > 8) ? 1 : 0], B2[1], D, 0, 0, 0);
+                    const f32x4 nt = *reinterpret_cast<const f32x4*>(nhL + sl * 64 + kqp * 16 + 4 * gq);
+                    // (as the register pairs lie: two packed fma, no move -- left to itself the compiler pairs values of
+                    //  DIFFERENT slots and spends 73 moves per group on it)
+                    const f32x2v k2 = f32x2v{kk, kk};
+                    const f32x2v lo2 = __builtin_elementwise_fma(k2, __builtin_shufflevector(D, D, 0, 1), __builtin_shufflevector(nt, nt, 0, 1));
+                    const f32x2v hi2 = __builtin_elementwise_fma(k2, __builtin_shufflevector(D, D, 2, 3), __builtin_shufflevector(nt, nt, 2, 3));
+                    return __builtin_shufflevector(lo2, hi2, 0, 1, 2, 3);
+                };
+#pragma unroll 1
+                for (int Q4 = q_begin & ~3; Q4 < q_end; Q4 += 4) {
+                    const int qn = Q4 + (ncol & 3);
+                    const bool qv = qn >= q_begin && qn < q_end;
+                    f16x8 B2[2];
+                    const f16x8 z8 = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+                    const bool mine2 = qv && gq == kqp;                                 // K chunk gq of column (kq', q): query q's coordinates iff gq == kq'
+                    B2[0] = mine2 ? *reinterpret_cast<const f16x8*>(qh + (size_t)qn * 16) : z8;
+                    B2[1] = mine2 ? *reinterpret_cast<const f16x8*>(qh + (size_t)qn * 16 + 8) : z8;
+                    const f32x4 qcv = qc[qv ? qn : q_begin];
+                    const float st2 = qcv[0] + Rad;
+                    const float thr = qv ? st2 * st2 * (1.0f + 1.0f / 16384.0f) - qcv[1] : -__uint_as_float(PSH_INF_BITS);
+                    const float kk = qcv[2] * inv_sc;
+                    float vm = __uint_as_float(PSH_INF_BITS);
+#pragma unroll
+                    for (int sl = 0; sl < 8; ++sl) {
+                        const f32x4 v = eval_slot(sl, B2, kk);
+                        vm = min3f(vm, min3f(v[0], v[1], v[2]), v[3]);
+                    }
+                    if (!badC && !__any(qv && !(vm > thr))) continue;                   // the common case: nothing of these 4 queries here
+                    unsigned hm = 0u;                                                   // bit 4 sl + rr: the window survives
+#pragma unroll
+                    for (int sl = 0; sl < 8; ++sl) {
+                        const f32x4 v = eval_slot(sl, B2, kk);
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) hm |= !(v[rr] > thr) ? (1u << (4 * sl + rr)) : 0u;
+                    }
+                    if (!qv) hm = 0u;
+                    while (__any(hm != 0u)) {
+                        const bool has0 = hm != 0u;
+                        const int bit = has0 ? (int)__builtin_ctz(hm) : 0;
+                        hm &= hm - 1u;
+                        const int sl = bit >> 2, rr = bit & 3;
+                        const int p = 16 * (32 * hf + 16 * (sl >> 2) + 4 * kqp + (sl & 3)) + 4 * gq + rr;
+                        const bool has = has0 && (seg_start + p < a.Tp);                // (an infinite threshold -- non-finite data -- keeps inadmissible windows too)
+                        const unsigned long long sm = __ballot(has);
+                        if (!sm) continue;
+                        const int ne = __popcll(sm);
+                        if (nsq + ne > PSH_EMX_QCAP) verify(seg_start, r_global, a.dataset + row * a.T);
+                        if (has)
+                            sq[nsq + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u))] =
+                                (unsigned)p | ((unsigned)qn << 12);
+                        nsq += ne;
+                    }
+                }
+            } else {
             // the query's coordinates and level come through the scalar cache, one query AHEAD of their use (one wave per SIMD:
             // nothing else would hide the load)
             float hnx[4 * NG];
@@ -396,23 +567,25 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
 #pragma unroll
                     for (int sl = 0; sl < 8; ++sl) hm |= !(vslot(sl) > thr) ? (1u << sl) : 0u;
                     while (__any(hm != 0u)) {
-                        const bool has = hm != 0u;
-                        const int sl = has ? (int)__builtin_ctz(hm) : 0;
+                        const bool has0 = hm != 0u;
+                        const int sl = has0 ? (int)__builtin_ctz(hm) : 0;
                         hm &= hm - 1u;
+                        const int p = 16 * (32 * hf + 16 * (sl >> 2) + 4 * kq + (sl & 3)) + scol;
+                        const bool has = has0 && (seg_start + p < a.Tp);                // (an infinite threshold -- non-finite data -- keeps inadmissible windows too)
                         const unsigned long long sm = __ballot(has);
+                        if (!sm) continue;
                         const int ne = __popcll(sm);
                         if (nsq + ne > PSH_EMX_QCAP) verify(seg_start, r_global, a.dataset + row * a.T);
-                        if (has) {
-                            const int p = 16 * (32 * hf + 16 * (sl >> 2) + 4 * kq + (sl & 3)) + scol;
+                        if (has)
                             sq[nsq + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u))] =
                                 (unsigned)p | ((unsigned)b << 12);
-                        }
                         nsq += ne;
                     }
                 }
             }
+            }
         }
-        if (MODE == PSH_MODE_FILTER && nsq > 0) verify(seg_start, r_global, a.dataset + row * a.T);   // before the tile is overwritten
+        if (MODE == PSH_MODE_FILTER && nsq > 0) verify_end(seg_start, r_global, a.dataset + row * a.T);   // (the accumulators are dead here: the register-hungry fast chain)
         wave_lds_fence();
         u = un;
     }
@@ -427,27 +600,30 @@ bool embed_mx_supported(int d, int K, int B, int tile_floats) {
     return d >= 1 && d <= PSH_EMX_MAX_D && K >= 1 && K <= 256 && emx_shmem_bytes(K, d, B, tile_floats) <= PSH_LDS_BYTES;
 }
 
-template <bool ALIGNED, int MODE, int NG, int NP>
+template <bool ALIGNED, int MODE, int NG, int NP, bool QM>
 static hipError_t launch_emx_ng(const ScanArgs& a, int grid, hipStream_t s) {
     const size_t shmem = emx_shmem_bytes(a.W, a.emb_d, a.B, a.tile_floats);
-    hipError_t e = hipFuncSetAttribute((const void*)embed_mx_kernel<ALIGNED, MODE, NG, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipError_t e = hipFuncSetAttribute((const void*)embed_mx_kernel<ALIGNED, MODE, NG, NP, QM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((embed_mx_kernel<ALIGNED, MODE, NG, NP>), dim3(grid), dim3(PSH_EMX_THREADS), shmem, s, a);
+    hipLaunchKernelGGL((embed_mx_kernel<ALIGNED, MODE, NG, NP, QM>), dim3(grid), dim3(PSH_EMX_THREADS), shmem, s, a);
     return hipGetLastError();
 }
 
-template <bool ALIGNED, int MODE, int NP>
+template <bool ALIGNED, int MODE, int NP, bool QM>
 static hipError_t launch_emx(const ScanArgs& a, int grid, hipStream_t s) {
     const int ng = (a.emb_d + 3) >> 2;
-    return ng == 1 ? launch_emx_ng<ALIGNED, MODE, 1, NP>(a, grid, s) : ng == 2 ? launch_emx_ng<ALIGNED, MODE, 2, NP>(a, grid, s)
-                                                                              : launch_emx_ng<ALIGNED, MODE, 3, NP>(a, grid, s);
+    return ng == 1 ? launch_emx_ng<ALIGNED, MODE, 1, NP, QM>(a, grid, s) : ng == 2 ? launch_emx_ng<ALIGNED, MODE, 2, NP, QM>(a, grid, s)
+                                                                                  : launch_emx_ng<ALIGNED, MODE, 3, NP, QM>(a, grid, s);
 }
 
-// the bootstrap with the split products; the full scan with one product, or -- a.emb_mx == 3: PSH_FLAG_EMBED_MX_SPLIT -- the split too
+// the bootstrap with the split products; the full scan with one product and -- 3 .. 256 queries -- the per-query pass on the
+// matrix cores too, or (a.emb_mx == 3: PSH_FLAG_EMBED_MX_SPLIT) the split and the vector ALUs as in the bootstrap
 hipError_t launch_embed_mx(const ScanArgs& a, int mode, bool aligned, int grid, hipStream_t s) {
-    if (mode == PSH_MODE_BOOT) return aligned ? launch_emx<true, PSH_MODE_BOOT, 3>(a, grid, s) : launch_emx<false, PSH_MODE_BOOT, 3>(a, grid, s);
-    if (a.emb_mx == 3) return aligned ? launch_emx<true, PSH_MODE_FILTER, 3>(a, grid, s) : launch_emx<false, PSH_MODE_FILTER, 3>(a, grid, s);
-    return aligned ? launch_emx<true, PSH_MODE_FILTER, 1>(a, grid, s) : launch_emx<false, PSH_MODE_FILTER, 1>(a, grid, s);
+    if (mode == PSH_MODE_BOOT) return aligned ? launch_emx<true, PSH_MODE_BOOT, 3, false>(a, grid, s) : launch_emx<false, PSH_MODE_BOOT, 3, false>(a, grid, s);
+    if (a.emb_mx == 3) return aligned ? launch_emx<true, PSH_MODE_FILTER, 3, false>(a, grid, s) : launch_emx<false, PSH_MODE_FILTER, 3, false>(a, grid, s);
+    if (a.B >= PSH_EMX_QM_MIN_B && a.B <= PSH_EMX_QM_MAX_B)
+        return aligned ? launch_emx<true, PSH_MODE_FILTER, 1, true>(a, grid, s) : launch_emx<false, PSH_MODE_FILTER, 1, true>(a, grid, s);
+    return aligned ? launch_emx<true, PSH_MODE_FILTER, 1, false>(a, grid, s) : launch_emx<false, PSH_MODE_FILTER, 1, false>(a, grid, s);
 }
 
 }  // namespace psh
