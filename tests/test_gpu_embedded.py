@@ -357,6 +357,10 @@ def test_kernel_matrix_larger_than_sixteen_tiles_allow(hip_device, oracle_mod):
     (4096, 4096, 11, 252, 20, 1024, 16, "wavelet"),   # configs[4]'s query batch
     (1500, 1200, 9, 256, 0, 64, 2, "dense"),          # PSH_MAX_W taps
     (20000, 300, 4, 16, 5, 400, 1, "dense"),          # short rows: one segment each, mostly inadmissible windows
+    (600, 1100, 7, 40, 3, 150, 9, "dense"),           # the per-query pass on the matrix cores: 9 queries (a ragged group of 4), d <= 8: one K half
+    (300, 2100, 4, 33, 0, 500, 23, "dense"),          #   fewer units than waves: the queries split into groups of their own; one row group
+    (20000, 300, 10, 16, 5, 400, 6, "dense"),         #   short rows: inadmissible windows in every segment, 6 queries
+    (2048, 1500, 11, 200, 9, 2000, 4, "wavelet"),     #   many survivors per unit (k = 2000 of 2.6 M windows): the staged exact chains, 4 at a time
 ])
 def test_dense_kernel_on_the_matrix_cores_equals_oracle(hip_device, oracle_mod, R, T, d, K, h, k, B, kind):
     """PSH_FLAG_EMBED_MX (embed_mx_kernel: hi/lo f16 banded product as the rejection test, exact dense chains for the
