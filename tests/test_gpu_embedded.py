@@ -436,6 +436,34 @@ def test_path_shadowing_with_linear_embedding_runs_native(hip_device, name):
         assert obj2.last_path == "hip" and np.array_equal(bits(d2), bits(d)) and np.array_equal(idx2, idx)
 
 
+def test_path_shadowing_keeps_and_renews_its_scanning_kernel(hip_device, oracle_mod):
+    """shadow(cuda=True) keeps the scanning kernel on the device between calls (and the library's plan of it); an in-place
+    edit of the module's kernel tensor is picked up by the next call."""
+    from shadowing import Foveal, PathShadowing, PredictionContext, RelativeMSE
+    from shadowing_amd import _native
+    ds = syn.dataset(2048, 1024, 61)
+    x = syn.gbm_log_returns((2, 40), 62)
+    fov = Foveal(alpha=1.4, beta=0.9, max_context=40)
+    obj = PathShadowing(fov, RelativeMSE(), ds, PredictionContext(horizon=20))
+
+    def check():
+        d, _, idx = obj.shadow(x, k=300, cuda=True)
+        assert obj.last_path == "hip"
+        ker = fov.kernel[:, 0, :].numpy()
+        hx = fov(torch.tensor(x)[:, None, :])[:, 0, :].numpy()
+        od, oidx = oracle_mod.scan_topk_embedded(ds, ker, hx, 300, h=20)
+        assert_exact(d, idx, od, oidx, "shadow() with a kept kernel")
+
+    check()
+    kept = obj._ker_dev[1]
+    check()
+    assert obj._ker_dev[1] is kept and obj._workspace.plan_of is not None and obj._workspace.plan_of[0] is kept
+    with torch.no_grad():
+        fov.kernel[:, :, :7] = 0.25                            # no longer Foveal's structure: rows are not one constant any more
+    check()
+    assert obj._ker_dev[1] is not kept and not _native.embed_plan(obj._workspace)["one_interval"]
+
+
 def test_overridden_forward_keeps_the_generic_path(hip_device):
     from shadowing import PathEmbedding, PathShadowing, PredictionContext, RelativeMSE
 
