@@ -697,7 +697,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     if (use_mx) {
         const int64_t r2 = (2 * (int64_t)k * n_sample + p.R - 1) / p.R + 8;
         rank2 = (r2 < k && r2 <= bp.entries) ? (int)r2 : 0;
-    } else if (p.ker || rows_path || use_mq) {
+    } else {            // every other scan: the embedded ones, one-window rows, the batched matrix-core scan, the VALU-filter scans
         // The embedded scan (and the scan of one-window rows) ADMITS below an estimate: a candidate costs it an exact
         // d x K chain, and the provable tau of a 1/16 sample lets ~16 k of them through.  The estimate is the r2-th
         // smallest sampled minimum, r2 ~ 1.5 k x the sampled fraction (3 k for the thin 1/64 sample of one-window
@@ -709,7 +709,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
         // LDS-resident path (16384 keys) that 12 k take.
         // (the batched matrix-core scan too, at ~2 k: with the provable tau nearly every second group of 4 queries met a
         //  candidate in a segment and left the fast path of its loop -- the handling of survivors was half its instructions)
-        const int64_t r2 = ((p.ker ? 3 : (use_mq ? 4 : 6)) * (int64_t)k * n_sample + 2 * p.R - 1) / (2 * p.R) + 16;
+        const int64_t r2 = ((p.ker ? 3 : (rows_path ? 6 : 4)) * (int64_t)k * n_sample + 2 * p.R - 1) / (2 * p.R) + 16;
         if (r2 < k && r2 <= bp.entries) k_thr = (int)r2;
     }
     ThresholdArgs ta{w.minbuf, w.min_stride, (int)bp.entries, w.qstate, k_thr, 0,

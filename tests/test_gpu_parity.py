@@ -313,18 +313,18 @@ def test_matrix_core_and_valu_filters_admit_the_same_windows(hip_device):
     d2, i2, s2, p2 = hip_scan(hip_device, ds, q, 1024, 20, profile=True, flags=_native.FLAG_FILTER_VALU)
     assert s1[0] == 0 and s2[0] == 0
     assert_exact(d1, i1, d2, i2, "mx vs valu filter")
-    # same tau; the matrix-core scan files its candidates in two classes and reports the first (below the
-    # ESTIMATE of the k-th smallest, x2): enough for k, far fewer than everything below tau
-    assert 1024 <= p1["n_candidates"] <= p2["n_candidates"]
+    # the matrix-core scan files its candidates in two classes and reports the first (below an ESTIMATE of the k-th
+    # smallest, x2); the VALU-filter scan admits below an estimate of the same kind: enough for k, ~2 k each
+    assert 1024 <= p1["n_candidates"] <= 4 * 1024 and 1024 <= p2["n_candidates"] <= 4 * 1024
 
-    # batched queries: the matrix-core scan admits below an ESTIMATE of the k-th smallest (~2 k windows expected below it;
-    # enough for k or the status says so), the VALU filter below the provable tau of the sample: the result is the same
+    # batched queries: both scans admit below an ESTIMATE of the k-th smallest (~2 k windows expected below it; enough for k or
+    # the status says so) -- the matrix-core bootstrap's minima are upper bounds, the VALU one's exact: the result is the same
     q4 = syn.rolling_queries(6, 20, 79)
     d3, i3, s3, p3 = hip_scan(hip_device, ds, q4, 1024, 20, profile=True)
     d4, i4, s4, p4 = hip_scan(hip_device, ds, q4, 1024, 20, profile=True, flags=_native.FLAG_FILTER_VALU)
     assert not s3.any() and not s4.any()
     assert_exact(d3, i3, d4, i4, "mq vs valu filter")
-    assert 1024 <= p3["n_candidates"] <= p4["n_candidates"]
+    assert 1024 <= p3["n_candidates"] <= 4 * 1024 and 1024 <= p4["n_candidates"] <= 4 * 1024    # both admit ~2 k (estimates of the same level)
 
 
 @pytest.mark.parametrize("kind", ["spikes", "tiny_query", "planted", "one_loud_row", "f16_overflow_inf", "zero_rows"])
