@@ -319,20 +319,19 @@ __device__ inline float acc_single_window(const float* tile, int lane, const_f32
 // NaNs first -- two v_max x, x per tile in the hottest loop of the batched scan; v_min3 returns the non-NaN operands'
 // minimum just the same: a NaN accumulator is ignored, which is what the callers want -- its window can never be admitted.)
 __device__ __forceinline__ float min3f(float a, float b, float c) {
-    float r;
-    // (volatile: the order of the callers' sequences is part of their contract -- an MFMA result must not be read before
-    //  the unit has written it, and the hazard recogniser does not look into inline assembly: tile_min16's callers issue the
-    //  reads of a tile at least two MFMAs' worth of instructions after the MFMA that produced it)
-    asm volatile("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
+    // nested minnum: the compiler forms v_min3_f32 and -- unlike with inline assembly -- knows an MFMA result is being
+    // read: the wait states after the MFMA are its to insert (an asm version of this read accumulators the scheduler had
+    // moved right behind their MFMA)
+    return __builtin_fminf(__builtin_fminf(a, b), c);
 }
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float tile_min16(const f32x16_t& t) {
     // a tree of depth 3 (five independent v_min3 first), not a chain of 8: the chain's latency was the longest stretch of
-    // a query group's epilogue in the batched scan
+    // a query group's epilogue in the batched scan.  Every read of an accumulator register is a compiler-visible
+    // operation: the wait states between an MFMA and the first read of its result are the compiler's to insert.
     const float m0 = min3f(t[0], t[1], t[2]), m1 = min3f(t[3], t[4], t[5]), m2 = min3f(t[6], t[7], t[8]);
     const float m3 = min3f(t[9], t[10], t[11]), m4 = min3f(t[12], t[13], t[14]);
-    return min3f(min3f(m0, m1, m2), m3, min3f(m4, t[15], t[15]));
+    return min3f(min3f(m0, m1, m2), min3f(m3, m4, t[15]), __uint_as_float(PSH_INF_BITS));
 }
 
 __device__ __forceinline__ float min16(const float (&a)[PSH_L]) {
