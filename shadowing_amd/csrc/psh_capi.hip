@@ -75,11 +75,13 @@ struct BootPlan { int64_t rows; int per_wave; int64_t entries; };
 // `estimate`: the scan admits below the sampled ESTIMATE of the k-th distance (embedded scan), so the sample only has
 // to carry that estimate's rank (~2k * sampled fraction) comfortably -- 2k minima instead of the 8k that keep the
 // provable k-th smallest tight.  (Never more entries than the plain plan: the workspace is sized for that one.)
-BootPlan boot_plan(int64_t R, int64_t Tp, int k, bool halves = false, bool estimate = false) {
+// `thin` (with `estimate`): 1/64 of the rows -- the scans whose sample is itself expensive (the batched matrix-core scan's
+// costs 2.2x a scan of the same rows: 0.58 of 4.9 ms at 512 queries with 1/16); the estimate's rank is then ~48.
+BootPlan boot_plan(int64_t R, int64_t Tp, int k, bool halves = false, bool estimate = false, bool thin = false) {
     BootPlan bp{0, 0, 0};
     const int64_t nseg = (Tp + PSH_SEG - 1) / PSH_SEG;
     const int64_t quarter = R / 4;
-    int64_t rows = estimate ? R / 32 : R / 16;
+    int64_t rows = estimate ? (thin ? R / 64 : R / 32) : R / 16;
     const int64_t need_rows = ((estimate ? 2 : 8) * (int64_t)k + nseg - 1) / nseg;      // >= 8k (2k) segment minima
     if (rows < need_rows) rows = need_rows;
     if (rows >= 1 && rows <= quarter) {
@@ -577,7 +579,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     // much and the scan's exact rechecks cost 4.3 us more -- 135.7 vs 134.3 us per step; left off)
     // (the matrix-core embedded scan samples one minimum per HALF segment; a sample too thin for that plan is taken by
     // embed_scan_kernel instead -- the full scan still runs on the matrix cores)
-    BootPlan bp = boot_plan(p.R, p.Tp, k, p.emx, p.ker != nullptr);
+    BootPlan bp = boot_plan(p.R, p.Tp, k, p.emx, p.ker != nullptr || !use_mx, !p.ker && !use_mx);
     const bool boot_emx = p.emx && bp.per_wave == 2;
     if (p.emx && !boot_emx) bp = boot_plan(p.R, p.Tp, k, false, true);
     // one-window rows (T == W + h; PathDistance.forward_topk's N pre-embedded points): rows_kernel, a row per lane.
