@@ -711,7 +711,11 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
         // LDS-resident path (16384 keys) that 12 k take.
         // (the batched matrix-core scan too, at ~2 k: with the provable tau nearly every second group of 4 queries met a
         //  candidate in a segment and left the fast path of its loop -- the handling of survivors was half its instructions)
-        const int64_t r2 = ((p.ker ? 3 : (rows_path ? 6 : 4)) * (int64_t)k * n_sample + 2 * p.R - 1) / (2 * p.R) + 16;
+        // (the thin 1/64 sample of the batched / VALU-filter scans: + 8 on a rank of ~32 -- k windows of the ensemble
+        //  put 16 expected minima of the sample below their level, P(Poisson(16) >= 40) = 3e-7 per query; the minima are
+        //  upper bounds, which only adds to the margin)
+        const bool thin = !p.ker && !rows_path;
+        const int64_t r2 = ((p.ker ? 3 : (rows_path ? 6 : 4)) * (int64_t)k * n_sample + 2 * p.R - 1) / (2 * p.R) + (thin ? 8 : 16);
         if (r2 < k && r2 <= bp.entries) k_thr = (int)r2;
     }
     ThresholdArgs ta{w.minbuf, w.min_stride, (int)bp.entries, w.qstate, k_thr, 0,
