@@ -55,7 +55,8 @@ def main():
             kw = wk.contiguous().to(dev)
             ws = _native.Workspace(dev)
             mxf = _native.FLAG_EMBED_MX            # a dense kernel: rejection test on the matrix cores (what PathShadowing passes)
-            out = _native.scan_topk_embedded(ds[:, 0, :], kw, hxw, c["k"], h=c["h"], workspace=ws, profile=True, flags=mxf)
+            for _ in range(3):                     # the stage times of a WARM call (the first one loads the kernels)
+                out = _native.scan_topk_embedded(ds[:, 0, :], kw, hxw, c["k"], h=c["h"], workspace=ws, profile=True, flags=mxf)
             assert int(out[2].max()) == 0, "overflow"
             nst = max(2, args.steps // 4)
             ms_by = {}
@@ -84,7 +85,8 @@ def main():
         ws = _native.Workspace(dev)
         dsv = ds[:, 0, :]
         # (keep_plan: repeated calls with the same kernel tensor skip the plan launch, as PathShadowing's do)
-        out = _native.scan_topk_embedded(dsv, ker, hx, c["k"], h=c["h"], workspace=ws, profile=True)
+        for _ in range(3):                         # the stage times of a WARM call (the first one loads the kernels)
+            out = _native.scan_topk_embedded(dsv, ker, hx, c["k"], h=c["h"], workspace=ws, profile=True)
         assert int(out[2].max()) == 0, "overflow"
         stages = out[3]
         for _ in range(3):
