@@ -98,6 +98,9 @@ extern "C" {
 /* EMBED_MX_SPLIT: with EMBED_MX: the full scan's rejection test with the three split-precision products the bootstrap uses
  * instead of one f16 product (a ten times smaller radius, three times the matrix-core work; A/B tests -- same results). */
 #define PSH_FLAG_EMBED_MX_SPLIT 512
+/* SELECT_ONE_BLOCK: the selection of a one- or two-query scan by the one-block radix select + sort even where the
+ * ranking on all CUs applies (k <= 4096 and at most 8192 candidates; same results: A/B tests, timing). */
+#define PSH_FLAG_SELECT_ONE_BLOCK 1024
 /* RESERVE_CUS: the scan leaves a few compute units free (grid = CUs - 4): set by callers that run a collective and a
  * merge on a side stream beside the NEXT scan -- the fused launch otherwise owns every CU of the chip, and work on
  * another stream would wait for it (or make its last block wait). */

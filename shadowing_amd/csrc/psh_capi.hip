@@ -585,6 +585,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     // one-window rows (T == W + h; PathDistance.forward_topk's N pre-embedded points): rows_kernel, a row per lane.
     // Its bootstrap takes one exact value per sampled row.
     const bool rows_path = p.Tp == 1 && !p.ker && !p.rows_generic;
+    bool rows_wave_min = false;
     if (rows_path) {
         const int frac = tuning().rows_frac;
         int64_t ns = p.R / frac > 16 * (int64_t)k ? p.R / frac : 16 * (int64_t)k;
@@ -593,6 +594,10 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
         bp.rows = ns >= 2 * (int64_t)k ? ns : 0;
         bp.per_wave = 1;
         bp.entries = bp.rows;
+        // the estimate's rank (below) against the chunks of 64 rows of the sample: sparse enough -> one minimum per chunk
+        const int64_t r2r = (6 * (int64_t)k * bp.rows + 2 * p.R - 1) / (2 * p.R) + 16, chunks = (bp.rows + 63) / 64;
+        rows_wave_min = bp.rows > 0 && r2r < k && 8 * r2r <= chunks;
+        if (rows_wave_min) bp.entries = chunks;
         use_mx = use_mq = false;
     }
     const int64_t n_sample = bp.rows;
@@ -686,6 +691,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
         HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
         int64_t gb = (n_sample + 127) / 128;
         if (gb > 8 * (int64_t)ncu) gb = 8 * (int64_t)ncu;
+        sa.boot_wave_min = rows_wave_min ? 1 : 0;
         HIP_TRY(launch_rows(sa, PSH_MODE_BOOT, (int)(gb < 1 ? 1 : gb), s));
     } else {
         HIP_TRY(launch_scan(sa, PSH_MODE_BOOT, p.aligned, plan_s.grid, s));
@@ -775,6 +781,13 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     se.bcount2 = (use_mx && rank2 > 0) ? w.bcount2 : nullptr;
     if (use_mx && rank2 > 0) { se.dataset = dataset; se.queries = queries; se.T = p.T; se.r_offset = p.r_offset; se.W = p.W; }
     se.dbg_times = tuning().dbg_select;
+    // (the flags sit behind the B <= 2 totals in their 256-byte slot of the workspace)
+    if (B <= 2 && !(flags_of(profile) & PSH_FLAG_SELECT_ONE_BLOCK)) {
+        int tb = 0;
+        while ((1ll << tb) < p.Tp) ++tb;
+        se.rank_tbits = ((p.R + p.r_offset) <= (1ll << (32 - tb))) ? tb : -1;   // rows r_offset .. r_offset + R - 1, t < Tp
+        se.handled = w.total + 32;
+    }
     HIP_TRY(launch_select(se, B, s));
     rc = tm.mark(); if (rc) return rc;                                       // 5
 

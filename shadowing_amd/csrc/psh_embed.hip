@@ -769,7 +769,15 @@ __global__ __launch_bounds__(PSH_ROWS_THREADS) void rows_kernel(ScanArgs a, int 
             if (staged) acc = sumsq8([&](int j) { return __fsub_rn(x[j], tile[lane * ds + j]); }, W);
             else        acc = sumsq8([&](int j) { return __fsub_rn(x[j], yrow[j]); }, W);
             if (MODE == PSH_MODE_BOOT) {
-                if (valid) a.minbuf[(int64_t)b * a.min_stride + i] = acc;
+                if (a.boot_wave_min) {
+                    // an ESTIMATE's rank is a few dozen among thousands of sampled rows: the minimum of a chunk of 64 rows
+                    // says as much as its 64 values (two of the best rows in one chunk: the estimate comes out a shade
+                    // higher), and the threshold kernel selects among 64x fewer entries
+                    float m = (valid && acc == acc) ? acc : __uint_as_float(PSH_INF_BITS);
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+                    if (lane == 0) a.minbuf[(int64_t)b * a.min_stride + c] = m;
+                } else if (valid) a.minbuf[(int64_t)b * a.min_stride + i] = acc;
             } else if (MODE == PSH_MODE_ALL) {               // exhaustive path: one slot per row of the chunk
                 if (valid) {
                     a.cand_d[(int64_t)b * a.cap + i] = dist_from_acc(acc, qstate_k[b].xn);

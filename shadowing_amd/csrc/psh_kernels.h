@@ -112,6 +112,7 @@ struct ScanArgs {
     // embedding  h(y)_i = sum_j ker[i][j] * y[t + j]  against pre-embedded queries hx (B x emb_d)
     float* blockmax;         // BOOT: max |y| each block saw (feeds the f16 scale of the matrix-core filter); nullable
     int use_mx;              // FILTER: cheap test on the matrix cores (scan_mx_kernel) instead of the VALU
+    int boot_wave_min;       // rows_kernel BOOT: one minimum per chunk of 64 sampled rows (minbuf[chunk]) instead of a value per row
     const void* mq_frag;     // batched matrix-core scan: B-fragment table written by the threshold kernel (f16)
     const float* ker;        // emb_d x W row-major
     const float* hx;         // B x emb_d
@@ -192,7 +193,12 @@ struct SelectArgs {
     int* status;             // nullable
     QueryState* qstate;      // nullable
     unsigned long long* dbg_times;   // tuning aid (nullable): phase boundaries of block 0 in wall-clock ticks (100 MHz)
+    int rank_tbits;          // rank_select_kernel: (r, t) of a candidate packs into 32 bits as r << rank_tbits | t (-1: it does not)
+    int* handled;            // nullable: B flags -- rank_select_kernel (one or two queries, up to PSH_RANK_CAP candidates) has written
+                             // the results of query b already: select_kernel returns at once
 };
+#define PSH_RANK_CAP 8192            // candidates rank_select_kernel ranks (8 per thread in registers)
+#define PSH_RANK_GRID 256            // its blocks per query: each ranks its 1/256 of the candidates against all of them
 
 struct MergeSortedArgs {   // k best of G lists, each sorted by (d, r, t), list g holding smaller rows than list g+1
     const float* d;          // list g of query b: d + g * stride_d + b * k_in

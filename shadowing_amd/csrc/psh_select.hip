@@ -364,6 +364,157 @@ __device__ __forceinline__ int finish_rank(const uint64_t* run, int len, int lo,
     return lo;
 }
 
+// ----------------------------------------------------------------------------------
+// The selection of a query or two as a RANKING on all CUs (the fused launch's phase D as a kernel of its own): a scan that
+// admits below an estimate leaves 2-5 k candidates in the blocks' slices, and the one-block radix select + sort above takes
+// 30-45 us over them with 255 CUs idle.  Here PSH_RANK_GRID blocks per query each load ALL candidates (8 per thread, in
+// registers), take 1/PSH_RANK_GRID of them as their own and count, for each of their own, the candidates below it in
+// (d, r, t): rank < k -> out[rank].  No sort, no single block.  Handles: slices (front lists only), no overflow,
+// k <= n <= PSH_RANK_CAP -- anything else leaves handled[b] = 0 and select_kernel, launched behind it, does the work; when
+// handled[b] = 1 that launch returns at once.
+struct RankShared {
+    int offs[PSH_MAX_BLOCKS + 1];
+    uint64_t own_key[PSH_RANK_CAP / PSH_RANK_GRID + 2];
+    int2 own_rt[PSH_RANK_CAP / PSH_RANK_GRID + 2];
+    int rankc[PSH_RANK_CAP / PSH_RANK_GRID + 2];
+    int wtot[PSH_SELECT_THREADS / 64];
+    int overflow;
+};
+__global__ __launch_bounds__(PSH_SELECT_THREADS) void rank_select_kernel(SelectArgs a) {
+    __shared__ RankShared sm;
+    const int b = (int)blockIdx.y, g = (int)blockIdx.x, G = (int)gridDim.x;
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const float* cd = a.cand_d + (int64_t)b * a.cand_stride;
+    const int2* crt = a.cand_rt + (int64_t)b * a.cand_stride;
+    const int* bc = a.bcount + (int64_t)b * PSH_MAX_BLOCKS;
+    const int* bc2 = a.bcount2 ? a.bcount2 + (int64_t)b * PSH_MAX_BLOCKS : nullptr;
+    constexpr int OWN = PSH_RANK_CAP / PSH_RANK_GRID + 2;
+    int dbg_i = 0;
+    auto mark = [&]() { if (a.dbg_times && g == 1 && b == 0 && tid == 0) a.dbg_times[dbg_i] = wall_clock64(); ++dbg_i; };
+    mark();
+    if (tid == 0) { sm.overflow = 0; sm.offs[0] = 0; }
+    if (tid < OWN) sm.rankc[tid] = 0;
+    __syncthreads();
+    // offs[] = exclusive prefix of the slices' sizes: two slices per thread (PSH_MAX_BLOCKS = 2 x 1024), a DPP scan per wave,
+    // the 16 wave totals through LDS
+    {
+        int c2[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = 2 * tid + e;
+            c2[e] = 0;
+            if (i < a.nblk) {
+                const int cf = bc[i], cb = bc2 ? bc2[i] : 0;
+                if (cf + cb > a.slice) sm.overflow = 1;
+                c2[e] = cf < a.slice ? cf : a.slice;
+            }
+        }
+        int v = c2[0] + c2[1];
+        v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);         // inclusive scan over the wave
+        v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);
+        if (lane == 63) sm.wtot[tid >> 6] = v;
+        __syncthreads();
+        int before = 0;
+        for (int w2 = 0; w2 < (tid >> 6); ++w2) before += sm.wtot[w2];
+        const int excl = before + v - (c2[0] + c2[1]);
+        if (2 * tid < a.nblk) sm.offs[2 * tid + 1] = excl + c2[0];
+        if (2 * tid + 1 < a.nblk) sm.offs[2 * tid + 2] = excl + c2[0] + c2[1];
+        __syncthreads();
+    }
+    const int n = sm.offs[a.nblk];
+    mark();
+    const bool ok = !sm.overflow && n >= a.k && n <= PSH_RANK_CAP;           // the same verdict in every block
+    if (g == 0 && tid == 0) a.handled[b] = ok ? 1 : 0;
+    if (!ok) return;
+    if (g == 0 && tid == 0) {
+        if (a.total) a.total[b] = n;
+        if (a.qstate) a.qstate[b].n_valid = a.k;
+    }
+    // all candidates, 8 per thread, as 64-bit keys d << 32 | r << tbits | t (the launcher checked that (r, t) fits 32 bits);
+    // the block's own ones also to LDS
+    constexpr int NE = PSH_RANK_CAP / PSH_SELECT_THREADS;
+    const int e_lo = (int)(((int64_t)n * g) / G), e_hi = (int)(((int64_t)n * (g + 1)) / G);
+    const int nown = e_hi - e_lo;                                             // <= PSH_RANK_CAP / G + 1
+    const int ns = (n + PSH_SELECT_THREADS - 1) / PSH_SELECT_THREADS;
+    // the owning slice of every candidate: the 8 searches of a thread step together (one after the other they were
+    // 64 dependent LDS round trips: 4.5 us); then ALL loads in flight together
+    int lo[NE], ec[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) { const int e = tid + PSH_SELECT_THREADS * i; ec[i] = e < n ? e : n - 1; lo[i] = 0; }
+    int s0 = 1;
+    while (2 * s0 < a.nblk) s0 <<= 1;
+    for (int step = s0; step >= 1; step >>= 1) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int m = lo[i] + step;
+            if (i < ns && m < a.nblk && sm.offs[m] <= ec[i]) lo[i] = m;
+        }
+    }
+    mark();
+    float ld[NE];
+    int2 lrt[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i)
+        if (i < ns) { const int64_t o = (int64_t)lo[i] * a.slice + (ec[i] - sm.offs[lo[i]]); ld[i] = cd[o]; lrt[i] = crt[o]; }
+    uint64_t key[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        key[i] = ~0ull;
+        const int e = tid + PSH_SELECT_THREADS * i;
+        if (i < ns && e < n) {
+            key[i] = ((uint64_t)__float_as_uint(ld[i]) << 32) | (uint64_t)(((unsigned)lrt[i].x << a.rank_tbits) | (unsigned)lrt[i].y);
+            if (e >= e_lo && e < e_hi) { sm.own_key[e - e_lo] = key[i]; sm.own_rt[e - e_lo] = lrt[i]; }
+        }
+    }
+    __syncthreads();
+    mark();
+    // counting on the vector ALUs, 8 own candidates a turn: a 64-bit compare and an add per pair (a ballot + popcount per
+    // pair went through the scalar unit of four waves); two counters share a register for the wave reduction (DPP)
+    for (int j0 = 0; j0 < nown; j0 += 8) {
+        uint64_t ok[8];
+        int c[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) { ok[jj] = (j0 + jj < nown) ? sm.own_key[j0 + jj] : 0ull; c[jj] = 0; }
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            if (i < ns) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) c[jj] += key[i] < ok[jj] ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 8; jj += 2) {
+            int v = c[jj] | (c[jj + 1] << 16);                // <= 8 per lane and counter: 512 per wave
+            v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);     // row_shr 1, 2, 4, 8; row_bcast 15, 31
+            v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+            v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+            v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+            v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);
+            v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);
+            v = __builtin_amdgcn_readlane(v, 63);
+            if (lane == 0) {
+                if (j0 + jj < nown && (v & 0xffff)) atomicAdd(&sm.rankc[j0 + jj], v & 0xffff);
+                if (j0 + jj + 1 < nown && (v >> 16)) atomicAdd(&sm.rankc[j0 + jj + 1], v >> 16);
+            }
+        }
+    }
+    __syncthreads();
+    mark();
+    if (tid < nown) {
+        const int rk = sm.rankc[tid];
+        if (rk < a.k) {
+            const int2 rt = sm.own_rt[tid];
+            a.out_d[(int64_t)b * a.k + rk] = __uint_as_float((unsigned)(sm.own_key[tid] >> 32));
+            a.out_idx[((int64_t)b * a.k + rk) * 2 + 0] = rt.x;
+            a.out_idx[((int64_t)b * a.k + rk) * 2 + 1] = rt.y;
+        }
+    }
+}
+
 __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t items[];   // kpad entries, then key_cap u32 keys
     __shared__ SelectShared sm;
@@ -371,6 +522,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a
 
     const int b = (int)blockIdx.x;
     const int tid = (int)threadIdx.x;
+    if (a.handled && a.handled[b]) return;                // rank_select_kernel has written this query's results
     int dbg_i = 0;
     auto mark = [&]() { if (a.dbg_times && b == 0 && tid == 0) a.dbg_times[dbg_i] = wall_clock64(); ++dbg_i; };
     mark();                                              // 0: start
@@ -1147,6 +1299,13 @@ hipError_t launch_select(const SelectArgs& a0, int B, hipStream_t s) {
     if (shmem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
+    }
+    // one or two queries with few candidates expected: the ranking on all CUs first (rank_select_kernel)
+    if (a.handled) {
+        if (a.bcount && B <= 2 && a.k <= PSH_RANK_CAP / 2 && !a.rank_sort && !a.skip_negative_rows && a.rank_tbits >= 0)
+            hipLaunchKernelGGL(rank_select_kernel, dim3(PSH_RANK_GRID, B), dim3(PSH_SELECT_THREADS), 0, s, a);
+        else
+            a.handled = nullptr;
     }
     hipLaunchKernelGGL(select_kernel, dim3(B), dim3(PSH_SELECT_THREADS), shmem, s, a);
     if (a.rank_sort) {

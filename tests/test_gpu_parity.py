@@ -509,3 +509,53 @@ def test_one_window_rows_equal_oracle(hip_device, oracle_mod, R, W, h, k, B):
     od, oidx = oracle_mod.scan_topk(ds, q, k, h=h)
     assert_exact(d, idx, od, oidx, f"one-window rows R={R} W={W} h={h} k={k} B={B}")
     assert np.all(idx[..., 1] == 0)
+
+
+RANK_CASES = [   # (flags, W, B, k, what)
+    ("FLAG_NO_FUSE", 20, 1, 1024, "two-class slices, front lists"),
+    ("FLAG_FILTER_VALU", 20, 1, 1024, "VALU-filter scan"),
+    ("FLAG_FILTER_VALU", 20, 2, 700, "two queries"),
+    ("FLAG_FILTER_VALU", 40, 1, 2048, "W = 40"),
+]
+
+
+@pytest.mark.parametrize("flag,W,B,k,what", RANK_CASES)
+def test_selection_by_ranking_on_all_cus_equals_the_one_block_selection(hip_device, oracle_mod, flag, W, B, k, what):
+    """One or two queries, k <= 4096, at most 8192 candidates: rank_select_kernel (256 blocks per query, each ranking its
+    share of the candidates against all of them by counting) writes the results and select_kernel returns at once;
+    PSH_FLAG_SELECT_ONE_BLOCK keeps the one-block radix select + sort.  Same bytes, and the oracle's.  The ensemble
+    repeats its rows 4 times: every distance occurs 4 times and (r, t) decides."""
+    from shadowing_amd import _native
+    base = syn.dataset(4096, 2048, 1700)
+    ds = np.ascontiguousarray(np.tile(base, (4, 1, 1)))
+    q = syn.gbm_log_returns((B, W), 1701)
+    fl = getattr(_native, flag)
+    d, idx, status, prof = hip_scan(hip_device, ds, q, k, 20, flags=fl, profile=True)
+    d1, idx1, status1, prof1 = hip_scan(hip_device, ds, q, k, 20, flags=fl | _native.FLAG_SELECT_ONE_BLOCK, profile=True)
+    assert prof["path"] == 0 and not status.any() and not status1.any()
+    assert prof["n_candidates"] == prof1["n_candidates"] <= 8192
+    assert_exact(d, idx, d1, idx1, what + ": ranking vs one block")
+    od, oidx = oracle_mod.scan_topk(ds, q, k, h=20)
+    assert_exact(d, idx, od, oidx, what + ": ranking vs oracle")
+
+
+def test_selection_by_ranking_leaves_what_it_cannot_take(hip_device, oracle_mod):
+    """More than 8192 candidates (an estimate dragged up by rows that repeat 16 times), and row indices that do not pack
+    with t into 32 bits (r_offset near 2^31 / T'): the ranking kernel declines, the one-block selection does the work."""
+    from shadowing_amd import _native
+    base = syn.dataset(1024, 2048, 1710)
+    ds = np.ascontiguousarray(np.tile(base, (16, 1, 1)))
+    q = syn.gbm_log_returns((1, 20), 1711)
+    k = 1024
+    d, idx, status, prof = hip_scan(hip_device, ds, q, k, 20, flags=_native.FLAG_FILTER_VALU, profile=True)
+    if status.any():
+        d, idx, _, _ = hip_scan(hip_device, ds, q, k, 20, exhaustive=True)
+    od, oidx = oracle_mod.scan_topk(ds, q, k, h=20)
+    assert_exact(d, idx, od, oidx, "many candidates")
+    ds2 = syn.dataset(16384, 2048, 1712)
+    off = (1 << 20) + 12345                                 # 2^20 rows x 2^11 windows: one bit too many
+    d2, idx2, st2, _ = hip_scan(hip_device, ds2, q, k, 20, flags=_native.FLAG_FILTER_VALU, r_offset=off)
+    assert not st2.any()
+    od2, oidx2 = oracle_mod.scan_topk(ds2, q, k, h=20)
+    oidx2 = oidx2.copy(); oidx2[..., 0] += off
+    assert_exact(d2, idx2, od2, oidx2, "row offset beyond the packed key")
