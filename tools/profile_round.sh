@@ -32,6 +32,8 @@ timeout 300 python tools/fused_times.py > $OUT/fused_phase_times.txt 2>> $OUT/be
 # the widened rows of the scope table: the reference's Foveal workloads, configs[4] (wavelet), forward_topk
 timeout 600 python tools/bench_foveal.py --steps 20 --generic --which tutorial testing wavelet 2>> $OUT/bench.err | grep "^{" > $OUT/bench_foveal.jsonl
 timeout 300 python tools/bench_forward_topk.py 2>> $OUT/bench.err | grep "^{" > $OUT/bench_forward_topk.jsonl
+timeout 300 python tools/rows_stages.py 2>> $OUT/bench.err | grep "^[0-9]" > $OUT/forward_topk_stages.txt
+timeout 300 python tools/q512_stages.py 2>> $OUT/bench.err | grep "^{" > $OUT/q512_stages.txt
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_foveal -o fov -- python $R/tools/bench_foveal.py --steps 20 --which tutorial testing > $OUT/bench_foveal_prof.log 2>&1
 for f in $(find $OUT/prof_foveal -name "*kernel_stats.csv"); do head -8 $f > $OUT/foveal_kernel_stats.csv; done

@@ -13,7 +13,7 @@ cp $S/pmc_summary.txt $R/profiles/${TAG}_rocprofv3_pmc_summary.txt
 cp $S/hbm_traffic.json $R/profiles/hbm_traffic.json
 for f in bench_n1_separate_launches.json bench_n1_forced_exchange.json fused_phase_times.txt bench_foveal.jsonl bench_forward_topk.jsonl \
          foveal_kernel_stats.csv forward_topk_kernel_stats.csv kernel_stats_nofuse.csv foveal_testing_kernel_stats.csv wavelet_kernel_stats.csv \
-         embedded_pmc_summary.txt; do
+         embedded_pmc_summary.txt forward_topk_stages.txt q512_stages.txt; do
   [ -s $S/$f ] && cp $S/$f $R/profiles/${TAG}_$f
 done
 ls -la $R/profiles
