@@ -651,6 +651,11 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
                 // give-up time of a poll at the 100 MHz wall clock: 2 ms (a block that is not resident); 20 ms when a
                 // collective shares the chip (its workgroups may hold a few CUs until the peers arrive)
                 fu.spin_ticks = (flags_of(profile) & PSH_FLAG_RESERVE_CUS) ? 2000000 : 200000;
+                {
+                    int tb = 0;
+                    while ((1ll << tb) < p.Tp) ++tb;
+                    fu.tbits = ((p.R + p.r_offset) <= (1ll << (32 - tb))) ? tb : -1;   // rows r_offset .. r_offset + R - 1, t < Tp
+                }
                 fa.dbg_times = tuning().dbg_times;
                 if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_begin, s));
                 HIP_TRY(launch_scan_fused(fa, fu, p.aligned, plan_f.grid, s));

@@ -561,6 +561,48 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_fused_kernel(ScanArgs a
             kd[i] = live ? ent[i][0] : 0xffffffffu;
             krt[i] = live ? (((u64)ent[i][1] << 32) | (u64)ent[i][2]) : ~0ull;
         }
+        if (f.tbits >= 0) {
+            // rank of an own candidate = candidates below it in (d, r, t), counted on the vector ALUs 8 own ones a turn
+            // (rank_select_kernel's loop): (r, t) packs into 32 bits (the launcher checked), a 64-bit compare and an add
+            // per pair, two counters to a register through a DPP wave sum.  (A ballot + popcount per pair keeps the scalar
+            // unit of four waves busy: 2.7 of the phase's 5 us.)
+            u64 key[NE];
+#pragma unroll
+            for (int i = 0; i < NE; ++i)
+                key[i] = kd[i] == 0xffffffffu ? ~0ull : (((u64)kd[i] << 32) | (u64)((ent[i][1] << f.tbits) | ent[i][2]));
+            for (int j0 = 0; j0 < mown; j0 += 8) {
+                u64 ok[8];
+                int c[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const u32x4 o = fl[j0 + jj < mown ? j0 + jj : 0];
+                    ok[jj] = j0 + jj < mown ? (((u64)o[0] << 32) | (u64)((o[1] << f.tbits) | o[2])) : 0ull;
+                    c[jj] = 0;
+                }
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    if (i < ns) {
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) c[jj] += key[i] < ok[jj] ? 1 : 0;
+                    }
+                }
+#pragma unroll
+                for (int jj = 0; jj < 8; jj += 2) {
+                    int v = c[jj] | (c[jj + 1] << 16);      // <= 8 per lane and counter
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);
+                    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);
+                    v = __builtin_amdgcn_readlane(v, 63);
+                    if (lane == 0) {
+                        if (j0 + jj < mown && (v & 0xffff)) atomicAdd(&rankc[j0 + jj], v & 0xffff);
+                        if (j0 + jj + 1 < mown && (v >> 16)) atomicAdd(&rankc[j0 + jj + 1], v >> 16);
+                    }
+                }
+            }
+        } else
         for (int i2 = 0; i2 < mown; ++i2) {                 // rank of own candidate i2 = candidates below it in (d, r, t)
             const u32x4 o = fl[i2];
             const unsigned od = o[0];

@@ -71,6 +71,7 @@ struct FusedArgs {
     int* status;
     int* total;
     long long spin_ticks;            // give-up time of a poll in wall-clock ticks (100 MHz)
+    int tbits;                       // ranking: (r, t) packs into 32 bits as r << tbits | t (-1: it does not -- the three-word compare)
 };
 
 struct PrepArgs {

@@ -149,3 +149,18 @@ def test_given_query_norm_is_used(hip_device, oracle_mod):
     assert int(st[0]) == 0
     od, oidx = oracle_mod.scan_topk(ds, q, 100, h=20, qn=qn)
     assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, "qnorm given")
+
+
+def test_fused_ranking_with_duplicated_rows_and_with_row_offsets_beyond_the_packed_key(hip_device, oracle_mod):
+    """Phase D ranks by counting 64-bit keys d << 32 | r << tbits | t when (r, t) packs into 32 bits, and by the
+    three-word compare otherwise (a shard's row offset near 2^32 / 2^tbits).  Rows that repeat 4 times make every
+    distance occur 4 times: (r, t) decides everywhere, in both forms."""
+    base = syn.dataset(2048, 2048, 4300)
+    ds = np.ascontiguousarray(np.tile(base, (4, 1, 1)))
+    q = syn.gbm_log_returns((1, 20), 4301)
+    od, oidx = oracle_mod.scan_topk(ds, q, 512, h=20)
+    for off in (0, 777, (1 << 21) - 8192 + 5, 1 << 22):   # 2^11 windows per row: rows up to 2^21 pack
+        d, idx, status, info = fused_scan(hip_device, ds, q, 512, 20, r_offset=off)
+        assert info["path"] == 2 and status[0] == 0
+        oi = oidx.copy(); oi[..., 0] += off
+        assert_exact(d, idx, od, oi, f"fused ranking, row offset {off}")
