@@ -202,14 +202,15 @@ struct Plan { int grid; int n_qgroups; int q_per_group; int tile_floats; int wid
 // Launch-geometry overrides and device-side time stamps for the scripts under tools/: compiled into the
 // tuning build only (-DPSH_TUNING, `python -m shadowing_amd._build --tuning`).  The product library reads no
 // environment variable and takes no pointer from anywhere but its arguments.
-struct Tuning { int wide_min; bool narrow; int bpc; int rows_frac; unsigned long long* dbg_times; unsigned long long* dbg_select; };
+struct Tuning { int wide_min; bool narrow; int bpc; int rows_frac; unsigned long long* dbg_times; unsigned long long* dbg_select; int xcd_skew; };
 inline Tuning tuning() {
-    Tuning t{PSH_EMB_WIDE_MIN_B, false, 0, 64, nullptr, nullptr};
+    Tuning t{PSH_EMB_WIDE_MIN_B, false, 0, 64, nullptr, nullptr, PSH_FUSED_XCD_SKEW};
 #ifdef PSH_TUNING
     if (const char* e = getenv("PSH_EMBED_WIDE_MIN_B")) { const int v = atoi(e); if (v >= 1) t.wide_min = v; }
     t.narrow = getenv("PSH_EMBED_NARROW") != nullptr;
     if (const char* e = getenv("PSH_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) t.bpc = v; }
     if (const char* e = getenv("PSH_ROWS_FRAC")) { const int v = atoi(e); if (v >= 2) t.rows_frac = v; }
+    if (const char* e = getenv("PSH_XCD_SKEW")) { const int v = atoi(e); if (v >= -64 && v <= 64) t.xcd_skew = v; }
     if (const char* e = getenv("PSH_DBG_TIMES_PTR")) t.dbg_times = (unsigned long long*)strtoull(e, nullptr, 0);
     if (const char* e = getenv("PSH_DBG_SELECT_PTR")) t.dbg_select = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
@@ -656,6 +657,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
                     while ((1ll << tb) < p.Tp) ++tb;
                     fu.tbits = ((p.R + p.r_offset) <= (1ll << (32 - tb))) ? tb : -1;   // rows r_offset .. r_offset + R - 1, t < Tp
                 }
+                fu.xcd_skew = (plan_f.grid % 8 == 0) ? tuning().xcd_skew : 0;      // (a grid that is not whole rounds of the 8 XCDs: no assumption)
                 fa.dbg_times = tuning().dbg_times;
                 if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_begin, s));
                 HIP_TRY(launch_scan_fused(fa, fu, p.aligned, plan_f.grid, s));

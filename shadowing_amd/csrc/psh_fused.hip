@@ -104,8 +104,20 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_fused_kernel(ScanArgs a
     const int nfloat = PSH_SEG + W - 1;
     const const_f32p x = (const_f32p)a.queries;
     const unsigned n_rs = (unsigned)a.n_rows * (unsigned)a.nseg;
-    const unsigned u_lo = (unsigned)(((u64)n_rs * blockIdx.x) / gridDim.x);
-    const unsigned u_hi = (unsigned)(((u64)n_rs * (blockIdx.x + 1)) / gridDim.x);
+    // a block's share of the units.  Blocks are dealt to the XCDs round-robin (MI355X_MICROARCH.md: workgroup dispatch),
+    // and the odd XCDs stream ~4 % slower than the even ones on every box measured (tools/fused_times.py: they end their
+    // equal shares 2.5-4.5 us later, launch after launch): of the units of a pair of blocks (2j, 2j + 1) the even one
+    // takes (256 + skew) / 512.  (Were the dealing different, the shares would merely be 2 % off.)
+    unsigned u_lo, u_hi;
+    {
+        const unsigned pb = blockIdx.x & ~1u;
+        const unsigned p_lo = (unsigned)(((u64)n_rs * pb) / gridDim.x);
+        const unsigned p_hi = (unsigned)(((u64)n_rs * (pb + 2 < gridDim.x ? pb + 2 : gridDim.x)) / gridDim.x);
+        const bool paired = pb + 1 < gridDim.x;
+        const unsigned mid = paired ? p_lo + (unsigned)(((u64)(p_hi - p_lo) * (unsigned)(256 + f.xcd_skew)) >> 9) : p_hi;
+        u_lo = (blockIdx.x & 1u) ? mid : p_lo;
+        u_hi = (blockIdx.x & 1u) ? p_hi : mid;
+    }
 
     // the first sampled segment of every wave is requested before anything else: the header check, the LDS set-up and
     // the block barrier below run under its HBM latency

@@ -47,6 +47,7 @@ struct QueryState {   // one per query, device, 48 bytes
 #define PSH_FUSED_MAGIC 0x5053484655534544ull
 #define PSH_FUSED_MAX_BLOCKS 256     // blocks of the fused launch (one per CU)
 #define PSH_FUSED_MAX_UNITS 4096     // bootstrap minima exchanged (one 16-byte load per thread of a block reads them all)
+#define PSH_FUSED_XCD_SKEW 6          // +-2.3 %: see scan_fused_kernel
 #define PSH_FUSED_FRONT 64           // candidates a block may hand to the distributed selection (~8 expected)
 struct FusedHdr {
     unsigned long long magic;
@@ -71,6 +72,7 @@ struct FusedArgs {
     int* status;
     int* total;
     long long spin_ticks;            // give-up time of a poll in wall-clock ticks (100 MHz)
+    int xcd_skew;                    // of the units of a pair of blocks (2j, 2j + 1) the even one takes (256 + xcd_skew) / 512
     int tbits;                       // ranking: (r, t) packs into 32 bits as r << tbits | t (-1: it does not -- the three-word compare)
 };
 
