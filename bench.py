@@ -36,6 +36,10 @@ REPO = Path(__file__).resolve().parent
 if str(REPO) not in sys.path:
     sys.path.insert(0, str(REPO))
 
+# the host driver of these boxes only supports dmabuf IPC: without this RCCL fails with `hipIpcGetMemHandle: invalid argument`
+# (exported on the GPU boxes already; set here too, before the HIP runtime starts, for whoever launches the ranks)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 
