@@ -82,7 +82,15 @@ BootPlan boot_plan(int64_t R, int64_t Tp, int k, bool halves = false, bool estim
     const int64_t nseg = (Tp + PSH_SEG - 1) / PSH_SEG;
     const int64_t quarter = R / 4;
     int64_t rows = estimate ? (thin ? R / 64 : R / 32) : R / 16;
-    const int64_t need_rows = ((estimate ? 2 : 8) * (int64_t)k + nseg - 1) / nseg;      // >= 8k (2k) segment minima
+    // >= 8k segment minima for the provable bound; an estimate wants its rank (~1.5 k x the sampled fraction + 16) well
+    // inside the sample: >= 1024 minima and >= 8 x the rank
+    int64_t need_rows = (8 * (int64_t)k + nseg - 1) / nseg;
+    if (estimate) {
+        need_rows = (1024 + nseg - 1) / nseg;
+        const double per_row = (double)nseg - 12.0 * (double)k / (double)R;              // entries - 8 x rank, per sampled row
+        if (per_row > 0.25) { const int64_t nr = (int64_t)(128.0 / per_row) + 1; if (nr > need_rows) need_rows = nr; }
+        else need_rows = quarter + 1;                                                    // k too close to the ensemble's size: no sample
+    }
     if (rows < need_rows) rows = need_rows;
     if (rows >= 1 && rows <= quarter) {
         if (halves && rows >= 2) { bp.rows = (rows + 1) / 2; bp.per_wave = 2; bp.entries = bp.rows * nseg * 2; return bp; }
