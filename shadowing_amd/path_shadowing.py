@@ -260,7 +260,10 @@ class PathShadowing:
             self._scan_rows = (key, ds[:, 0, :].contiguous(), weakref.ref(ds))
         return self._scan_rows[1]
 
-    def _native_scan(self, x: torch.Tensor, y: torch.Tensor, k: int):
+    def _native_scan(self, x: torch.Tensor, y: torch.Tensor, k: int, defer_status: bool = False):
+        """(d, idx, resident dataset) on the device.  `defer_status` (Identity scans only): ONE raw call, its status
+        tensor returned as a fourth item instead of being waited for -- the caller reads it together with the results
+        (one synchronisation per call instead of two) and comes back without the flag when it is not zero."""
         dev = self._hip_device()
         _native.load()
         ds = self._resident_dataset(y, dev)
@@ -314,6 +317,9 @@ class PathShadowing:
                                                       exhaustive=exhaustive, flags=fl, keep_plan=True)
         else:
             xq = x[:, 0, :].contiguous().to(dev)
+            if defer_status:
+                d, idx, status = _native.scan_topk(rows, xq, k, h=h, workspace=self._workspace)
+                return d, idx, ds, status
             d, idx = _native.scan_topk_checked(rows, xq, k, h=h, workspace=self._workspace)
             return d, idx, ds
         d, idx, status = scan(None, False)
@@ -394,9 +400,22 @@ class PathShadowing:
         length = x.shape[-1] + self.context.get_out_times()
 
         if cuda and self._native_ok(x, y, k):
-            d, idx, ds = self._native_scan(x, y, k)
-            paths = _native.gather_paths(ds, idx, length)           # (B, k, C, len) on device
+            out = self._native_scan(x, y, k, defer_status=True)
             self.last_path = "hip"
+            if len(out) == 4:
+                # the status travels with the results: gather and copies are enqueued behind the scan unconditionally
+                # (a status other than OK -- the fused launch gave up, candidate slices overflowed -- is rare and then
+                # costs the wasted gather), one synchronisation for everything
+                d, idx, ds, status = out
+                paths = _native.gather_paths(ds, idx, length)
+                hd, hp, hi, hs = self._to_host(d, paths, idx, status)
+                if not hs.any():
+                    return hd, hp, hi
+                if bool((hs == _native.PSH_STATUS_RETRY).any()):
+                    self._workspace.arm()
+                out = self._native_scan(x, y, k)
+            d, idx, ds = out
+            paths = _native.gather_paths(ds, idx, length)           # (B, k, C, len) on device
             return self._to_host(d, paths, idx)
 
         d, idx = self._generic_scan(x, y, k, n_splits, cuda)

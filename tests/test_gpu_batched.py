@@ -164,3 +164,25 @@ def test_resident_copy_follows_edits_of_the_ensemble(hip_device):
     kept.refresh()
     assert kept.shadow(q, k=8, cuda=True)[0][0, 0] == 0
     assert kept._resident is not None and mk(ds.copy())._resident is None
+
+
+def test_shadow_cuda_reads_the_status_with_the_results_and_recovers(hip_device, oracle_mod):
+    """shadow(cuda=True) enqueues the gather and the copies behind the scan and reads the status WITH the results (one
+    synchronisation); a status other than OK -- here: an ensemble of 3000 identical rows, every distance value shared by
+    3000 windows, far more ties than the candidate slices hold -- sends the call through the checked path again."""
+    import shadowing_amd as sa
+    base = syn.dataset(1, 2048, 2100)
+    ds = np.ascontiguousarray(np.tile(base, (3000, 1, 1)))
+    q = syn.single_query(20, 2101)
+    obj = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), ds, sa.PredictionContext(horizon=20))
+    d, paths, idx = obj.shadow(q, k=500, cuda=True)
+    assert obj.last_path == "hip"
+    od, oidx = oracle_mod.scan_topk(rows3(ds), q[None, :], 500, h=20)
+    assert np.array_equal(d.view(np.uint32), od.view(np.uint32)) and np.array_equal(idx, oidx)
+    assert np.array_equal(paths[:, :, 0, :], oracle_mod.gather_paths(rows3(ds), idx, 40))
+    # and an ordinary ensemble right after, on the same object's workspace
+    ds2 = syn.dataset(4096, 2048, 2102)
+    obj2 = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), ds2, sa.PredictionContext(horizon=20))
+    d2, paths2, idx2 = obj2.shadow(q, k=500, cuda=True)
+    od2, oidx2 = oracle_mod.scan_topk(rows3(ds2), q[None, :], 500, h=20)
+    assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32)) and np.array_equal(idx2, oidx2)
