@@ -452,15 +452,37 @@ class PathShadowing:
         The averaging itself is the installed DiscreteProba's own `avg` / `std` on those host arrays (ref :245-252):
         scatspectra's classes when that package is importable, the stand-ins of averaging.py otherwise -- no
         formula of theirs is restated here.  Only called when the caller opted in (see predict())."""
-        d, idx, ds = self._native_scan(x, y, k)
-        paths = _native.gather_paths(ds, idx, x.shape[-1] + self.context.get_out_times())
-        values = to_predict(self.context.select_out_context(paths))
-        if not (isinstance(values, torch.Tensor) and values.dim() >= 2 and tuple(values.shape[:2]) == tuple(d.shape)):
-            raise TypeError("device_predict: to_predict must map the (B, k, C, h) torch tensor of out-context paths to a "
-                            f"torch tensor (B, k, ...); got {type(values).__name__}"
-                            f"{tuple(getattr(values, 'shape', ()))}")
+        length = x.shape[-1] + self.context.get_out_times()
+
+        def evaluate(d, idx, ds):
+            paths = _native.gather_paths(ds, idx, length)
+            values = to_predict(self.context.select_out_context(paths))
+            if not (isinstance(values, torch.Tensor) and values.dim() >= 2 and tuple(values.shape[:2]) == tuple(d.shape)):
+                raise TypeError("device_predict: to_predict must map the (B, k, C, h) torch tensor of out-context paths to a "
+                                f"torch tensor (B, k, ...); got {type(values).__name__}"
+                                f"{tuple(getattr(values, 'shape', ()))}")
+            return values
+
         self.last_path = "hip"
-        d_host, v_host = self._to_host(d, values.contiguous()) if values.is_cuda else (d.cpu().numpy(), values.numpy())
+        out = self._native_scan(x, y, k, defer_status=True)
+        d_host = v_host = None
+        if len(out) == 4:                                   # Identity scan: the status is read with the results (see shadow())
+            d, idx, ds, status = out
+            values = evaluate(d, idx, ds)
+            if values.is_cuda:
+                d_host, v_host, hs = self._to_host(d, values.contiguous(), status)
+                if hs.any():
+                    if bool((hs == _native.PSH_STATUS_RETRY).any()):
+                        self._workspace.arm()
+                    d_host = None
+            else:
+                d_host = None
+            if d_host is None:
+                out = self._native_scan(x, y, k)
+        if d_host is None:
+            d, idx, ds = out
+            values = evaluate(d, idx, ds)
+            d_host, v_host = self._to_host(d, values.contiguous()) if values.is_cuda else (d.cpu().numpy(), values.numpy())
         proba = self.init_averaging_proba(proba_name, d_host[:, :, None], eta)
         return proba.avg(v_host, axis=1), proba.std(v_host, axis=1)
 
