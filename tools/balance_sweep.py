@@ -1,5 +1,6 @@
-"""The fused launch on THIS box: how far apart the XCDs end their shares, and the step time against the stealable tail
-(PSH_TAIL256) and the static even/odd shares (PSH_XCD_SKEW) -- -DPSH_TUNING build."""
+"""The fused launch on THIS box: how far apart the XCDs end their shares, and the step time against the static even/odd
+shares (PSH_XCD_SKEW) -- -DPSH_TUNING build.  (The stealable-tail variant DESIGN.md reports was measured with this script
+and a patched kernel that read PSH_TAIL256; the patch is not in the tree.)"""
 import os, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -14,7 +15,7 @@ buf = torch.zeros(8 * 256, dtype=torch.int64, device=dev)
 os.environ["PSH_DBG_TIMES_PTR"] = str(buf.data_ptr())
 ref = None
 for rnd in range(2):
-    for tl, sk in ((0, 0), (0, 6), (32, 0), (64, 0), (96, 0), (64, 6)):
+    for tl, sk in ((0, 0), (0, 6), (0, 12)):
         os.environ["PSH_TAIL256"] = str(tl); os.environ["PSH_XCD_SKEW"] = str(sk)
         for _ in range(20): out = _native.scan_topk(ds, q, 1024, h=20, workspace=ws)
         torch.cuda.synchronize()
