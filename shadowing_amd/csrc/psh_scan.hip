@@ -707,9 +707,13 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
                 // the survivors of this tile as a per-lane bit mask (pure VALU), then one queue round per
                 // survivor of the busiest lane (usually one): a ballot per accumulator register would put 16
                 // VALU -> SALU round trips on every tile that holds a survivor
+                // (a compare and an add-with-carry per accumulator, hm = 2 hm + [!(acc > thr)], from the last register down:
+                //  the compiler's select + or3 form is 3 instructions per accumulator.  The accumulators were read by
+                //  tile_min16 above and the branch depends on that: no MFMA is in flight on them here.)
                 unsigned hm = 0u;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) hm |= !(acc[g][r] > thr) ? (1u << r) : 0u;
+                for (int r = 15; r >= 0; --r)
+                    asm volatile("v_cmp_ngt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hm) : "v"(acc[g][r]), "v"(thr) : "vcc");
                 if (!lane_ok) hm = 0u;
                 for (;;) {
                     const bool act = hm != 0u;
