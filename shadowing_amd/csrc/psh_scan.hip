@@ -676,12 +676,15 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
             wave_lds_fence();                                              // queue slots are reused
         };
 
+        // (running pointers: the group's two fragments sit 1 KB apart behind one address register, the threshold behind
+        //  another -- six VALU instructions of index arithmetic per group were a seventh of the loop's fast path)
+        const _Float16* fragp = fragL + (size_t)lane * 8;
+        const float* thrp = thrL + qsub;
 #pragma unroll 1
-        for (int G = 0; G < ngroups; ++G) {
-            const f16x8 b0 = *reinterpret_cast<const f16x8*>(fragL + ((size_t)(2 * G + 0) * 64 + lane) * 8);
-            const f16x8 b1 = *reinterpret_cast<const f16x8*>(fragL + ((size_t)(2 * G + 1) * 64 + lane) * 8);
-            const int ql = 4 * G + qsub;                                   // this lane's query within the chunk
-            const float thr = keep_all ? __uint_as_float(PSH_INF_BITS) : thrL[ql];
+        for (int G = 0; G < ngroups; ++G, fragp += 2 * 64 * 8, thrp += 4) {
+            const f16x8 b0 = *reinterpret_cast<const f16x8*>(fragp);
+            const f16x8 b1 = *reinterpret_cast<const f16x8*>(fragp + 64 * 8);
+            const float thr = keep_all ? __uint_as_float(PSH_INF_BITS) : *thrp;
             // all 8 MFMAs of the group first (4 independent accumulator tiles), then the tests:
             // a test-and-branch per tile serialises MFMA latency, min tree and branch 4 times
             f32x16 acc[4];
@@ -698,6 +701,7 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
             if (!__any(!(min3f(min3f(mn[0], mn[1], mn[2]), mn[3], mn[3]) > thr))) continue;
             // survivors are only QUEUED here (window, query): a lane-by-lane exact chain would run ~140
             // instructions for the one or two lanes that hold a survivor; the queue is drained 64 at a time
+            const int ql = 4 * G + qsub;                                   // this lane's query within the chunk
             const bool lane_ok = ql < nq;
             const int nsq0 = nsq;
             bool full = false;                                             // wave-uniform
