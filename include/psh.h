@@ -105,6 +105,14 @@ extern "C" {
  * merge on a side stream beside the NEXT scan -- the fused launch otherwise owns every CU of the chip, and work on
  * another stream would wait for it (or make its last block wait). */
 #define PSH_FLAG_RESERVE_CUS  32
+/* OVERLAP: psh_scan_topk with ONE query (W <= 33): the step as three launches -- sample + admission level, scan, ranking
+ * (psh_stream.hip) -- sized so that the small ones fit on the compute units BESIDE the scan of a call on ANOTHER stream, and
+ * with no barrier inside the scan, so that its blocks take over a compute unit the moment the previous scan's block leaves
+ * it.  For callers with independent queries in flight on two or three streams (a server; a sharded run overlapping its
+ * exchange): per-step time in steady state is the ensemble's streaming time, not the fused launch's ~25 us more.  A
+ * single stream is better served by the fused launch (the default).  Same results, same status protocol
+ * (PSH_STATUS_RETRY -> rerun with PSH_FLAG_NO_FUSE); one workspace per stream, armed by psh_workspace_init. */
+#define PSH_FLAG_OVERLAP      2048
 typedef struct psh_profile {
     int   mode;           /* in */
     int   flags;          /* in: PSH_FLAG_* */
@@ -116,7 +124,8 @@ typedef struct psh_profile {
     float scan_ms;        /* the full sliding-window scan + filter (HBM-bound kernel) */
     float select_ms;      /* radix select + bitonic sort of the survivors   */
     float total_ms;
-    int   path;           /* 0 = sampled threshold path, 1 = exhaustive path, 2 = sampled path as ONE fused launch */
+    int   path;           /* 0 = sampled threshold path, 1 = exhaustive path, 2 = sampled path as ONE fused launch,
+                             3 = the three overlap-friendly launches (PSH_FLAG_OVERLAP) */
     int   n_sample_rows;
     int   grid_blocks;    /* blocks of the scan kernel */
     int   n_candidates;   /* PSH_PROFILE_STAGES: largest per-query candidate count the scan admitted */

@@ -10,11 +10,13 @@ from .path_distance import PathDistance, RelativeMSE
 from .path_embedding import (ArrayType, ContextManagerBase, CrossChannelContext, Foveal, Identity,
                              ImputationContext, PathEmbedding, PredictionContext)
 from .path_shadowing import PathShadowing, select_cartesian_product
+from .plotting import plot_closest, plot_shadow, plot_volatility
 from .statistics import realized_variance
 
 __all__ = [
     "ArrayType", "ContextManagerBase", "PredictionContext", "ImputationContext", "CrossChannelContext",
     "PathEmbedding", "Identity", "Foveal", "PathDistance", "RelativeMSE", "PathShadowing",
     "select_cartesian_product", "DiscreteProba", "Softmax", "Uniform", "realized_variance",
+    "plot_closest", "plot_shadow", "plot_volatility",
 ]
 __version__ = "0.1.0"

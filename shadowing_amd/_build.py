@@ -11,7 +11,7 @@ CSRC = PKG / "csrc"
 LIBDIR = PKG / "lib"
 LIB = LIBDIR / "libpsh_hip.so"
 INCLUDE = PKG.parent / "include"
-SOURCES = [CSRC / "psh_scan.hip", CSRC / "psh_fused.hip", CSRC / "psh_embed.hip", CSRC / "psh_embed_px.hip", CSRC / "psh_embed_mx.hip", CSRC / "psh_select.hip",
+SOURCES = [CSRC / "psh_scan.hip", CSRC / "psh_fused.hip", CSRC / "psh_stream.hip", CSRC / "psh_embed.hip", CSRC / "psh_embed_px.hip", CSRC / "psh_embed_mx.hip", CSRC / "psh_select.hip",
            CSRC / "psh_capi.hip", CSRC / "psh_comm.hip"]
 DEPS = SOURCES + [CSRC / "psh_kernels.h", CSRC / "psh_device.h", INCLUDE / "psh.h"]
 
@@ -53,7 +53,12 @@ def is_stale(lib: Path | None = None) -> bool:
     stamp = _stamp(lib)
     if not lib.exists() or not stamp.exists():
         return True
-    return stamp.read_text().strip() != source_hash()
+    try:
+        return stamp.read_text().strip() != source_hash()
+    except OSError:
+        # a lib-only deployment (no csrc/ or include/ beside the package): nothing to compare with -- the library is
+        # taken as it is
+        return False
 
 
 def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> Path:

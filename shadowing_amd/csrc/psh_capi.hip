@@ -210,15 +210,16 @@ struct Plan { int grid; int n_qgroups; int q_per_group; int tile_floats; int wid
 // Launch-geometry overrides and device-side time stamps for the scripts under tools/: compiled into the
 // tuning build only (-DPSH_TUNING, `python -m shadowing_amd._build --tuning`).  The product library reads no
 // environment variable and takes no pointer from anywhere but its arguments.
-struct Tuning { int wide_min; bool narrow; int bpc; int rows_frac; unsigned long long* dbg_times; unsigned long long* dbg_select; int xcd_skew; };
+struct Tuning { int wide_min; bool narrow; int bpc; int rows_frac; unsigned long long* dbg_times; unsigned long long* dbg_select; int xcd_skew; int stream_threads; };
 inline Tuning tuning() {
-    Tuning t{PSH_EMB_WIDE_MIN_B, false, 0, 64, nullptr, nullptr, PSH_FUSED_XCD_SKEW};
+    Tuning t{PSH_EMB_WIDE_MIN_B, false, 0, 64, nullptr, nullptr, PSH_FUSED_XCD_SKEW, PSH_SCAN_THREADS};
 #ifdef PSH_TUNING
     if (const char* e = getenv("PSH_EMBED_WIDE_MIN_B")) { const int v = atoi(e); if (v >= 1) t.wide_min = v; }
     t.narrow = getenv("PSH_EMBED_NARROW") != nullptr;
     if (const char* e = getenv("PSH_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) t.bpc = v; }
     if (const char* e = getenv("PSH_ROWS_FRAC")) { const int v = atoi(e); if (v >= 2) t.rows_frac = v; }
     if (const char* e = getenv("PSH_XCD_SKEW")) { const int v = atoi(e); if (v >= -64 && v <= 64) t.xcd_skew = v; }
+    if (const char* e = getenv("PSH_STREAM_THREADS")) { const int v = atoi(e); if (v == 512 || v == 1024) t.stream_threads = v; }
     if (const char* e = getenv("PSH_DBG_TIMES_PTR")) t.dbg_times = (unsigned long long*)strtoull(e, nullptr, 0);
     if (const char* e = getenv("PSH_DBG_SELECT_PTR")) t.dbg_select = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
@@ -667,6 +668,28 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
                 }
                 fu.xcd_skew = (plan_f.grid % 8 == 0) ? tuning().xcd_skew : 0;      // (a grid that is not whole rounds of the 8 XCDs: no assumption)
                 fa.dbg_times = tuning().dbg_times;
+                if (flags_of(profile) & PSH_FLAG_OVERLAP) {
+                    // the same step as three launches that can be co-resident with another stream's (psh_stream.hip):
+                    // sample + level (one-wave blocks), the scan (no barrier, no residency requirement), the ranking
+                    int ncu = 0;
+                    HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+                    const Tuning tn = tuning();
+                    int64_t grid_p = 2 * (int64_t)ncu;
+                    if (grid_p > units_f) grid_p = units_f;
+                    const int threads_s = tn.stream_threads == 512 ? 512 : PSH_SCAN_THREADS;
+                    int64_t grid_s = (int64_t)ncu * (PSH_SCAN_THREADS / threads_s);
+                    const int64_t n_rs = p.R * nseg;
+                    if (grid_s * (threads_s / 64) > n_rs) grid_s = (n_rs + (threads_s / 64) - 1) / (threads_s / 64);
+                    if (stream_scan_shmem_bytes(fa.tile_floats, threads_s) * (PSH_SCAN_THREADS / threads_s) <= PSH_LDS_BYTES) {
+                        HIP_TRY(launch_stream_sample(fa, fu, p.aligned, (int)grid_p, tile_floats_for(p.W), s));
+                        if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_begin, s));
+                        HIP_TRY(launch_stream_scan(fa, fu, p.aligned, (int)grid_s, threads_s, s));
+                        if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_end, s));
+                        HIP_TRY(launch_stream_rank(fa, fu, ncu, s));
+                        if (profile) { profile->path = 3; profile->n_sample_rows = (int)rows_f; profile->grid_blocks = (int)grid_s; }
+                        return PSH_OK;
+                    }
+                }
                 if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_begin, s));
                 HIP_TRY(launch_scan_fused(fa, fu, p.aligned, plan_f.grid, s));
                 if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_end, s));

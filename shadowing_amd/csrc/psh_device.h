@@ -155,14 +155,18 @@ __device__ __forceinline__ void step16(float xj, const float (&win)[PSH_L], int 
           acc[8], acc[9], acc[10], acc[11], acc[12], acc[13], acc[14], acc[15]);
 }
 
-template <int WT>
+// PAD = false: the tile is stored unpadded (stage_store<false>) -- every address is the lane's base plus a constant, ONE
+// address register instead of nine (the one-wave sample kernel of psh_stream.hip, which lives in 64 VGPRs; bank
+// conflicts do not matter there)
+template <bool PAD> __device__ __forceinline__ int lds_idx(int p) { return PAD ? lds_pad(p) : p; }
+template <int WT, bool PAD = true>
 __device__ __forceinline__ void accumulate16(const float* tile, int lane, const_f32p x, int W,
                                              float (&acc)[PSH_L]) {
     float win[PSH_L];
     const int base = PSH_L * lane;
 #pragma unroll
     for (int c = 0; c < PSH_L / 4; ++c) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(tile + lds_pad(base + 4 * c));
+        const f32x4 v = *reinterpret_cast<const f32x4*>(tile + lds_idx<PAD>(base + 4 * c));
         win[4 * c + 0] = v[0]; win[4 * c + 1] = v[1]; win[4 * c + 2] = v[2]; win[4 * c + 3] = v[3];
     }
 #pragma unroll
@@ -174,7 +178,7 @@ __device__ __forceinline__ void accumulate16(const float* tile, int lane, const_
     auto block16 = [&](int jb) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 nx = *reinterpret_cast<const f32x4*>(tile + lds_pad(base + jb + PSH_L + 4 * g));
+            const f32x4 nx = *reinterpret_cast<const f32x4*>(tile + lds_idx<PAD>(base + jb + PSH_L + 4 * g));
             const float nv[4] = {nx[0], nx[1], nx[2], nx[3]};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -196,7 +200,7 @@ __device__ __forceinline__ void accumulate16(const float* tile, int lane, const_
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         if (4 * g < rem) {
-            const f32x4 nx = *reinterpret_cast<const f32x4*>(tile + lds_pad(base + j0 + PSH_L + 4 * g));
+            const f32x4 nx = *reinterpret_cast<const f32x4*>(tile + lds_idx<PAD>(base + j0 + PSH_L + 4 * g));
             const float nv[4] = {nx[0], nx[1], nx[2], nx[3]};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -380,12 +384,13 @@ __device__ __forceinline__ void stage_load(Stage& st, const float* __restrict__ 
     for (int q = 0; q < PSH_NSTAGE; ++q) stage_load_one<ALIGNED>(st, q, row, T, seg_start, nfloat, lane);
 }
 
+template <bool PAD = true>
 __device__ __forceinline__ void stage_store(const Stage& st, float* tile, int nfloat, int lane) {
     const int nq = (nfloat + 3) >> 2;
 #pragma unroll
     for (int q = 0; q < PSH_NSTAGE; ++q) {
         const int m = lane + 64 * q;
-        if (q < PSH_NSTAGE - 1 || m < nq) *reinterpret_cast<f32x4*>(tile + lds_pad(4 * m)) = st.v[q];
+        if (q < PSH_NSTAGE - 1 || m < nq) *reinterpret_cast<f32x4*>(tile + lds_idx<PAD>(4 * m)) = st.v[q];
     }
 }
 

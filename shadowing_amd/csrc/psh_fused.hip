@@ -642,7 +642,13 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_fused_kernel(ScanArgs a
     }
     stamp(7);
     if (blockIdx.x == 0 && tid == 0) {
-        f.status[0] = good ? PSH_STATUS_OK_ : PSH_STATUS_RETRY_;
+        // RETRY is sticky: a block that gave up at the second barrier (its deadline passed while THIS block, dispatched
+        // late, had not published yet) wrote RETRY, returned without its out[rank] rows and disarmed the header BEFORE
+        // this point -- its give-up store follows its last failing poll by one round trip, this load follows this block's
+        // publication by the candidate loads and the ranking (several round trips).  OK is only declared over a header
+        // that is still armed.
+        const bool armed = g_load(&hdr->magic) == PSH_FUSED_MAGIC;
+        f.status[0] = (good && armed) ? PSH_STATUS_OK_ : PSH_STATUS_RETRY_;
         if (f.total) f.total[0] = ntotal;
         if (a.qstate) {                                     // diagnostics / the separate launches' state, kept coherent
             QueryState q;

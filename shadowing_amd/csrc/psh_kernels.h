@@ -49,10 +49,22 @@ struct QueryState {   // one per query, device, 48 bytes
 #define PSH_FUSED_MAX_UNITS 4096     // bootstrap minima exchanged (one 16-byte load per thread of a block reads them all)
 #define PSH_FUSED_XCD_SKEW 6          // +-2.3 %: see scan_fused_kernel
 #define PSH_FUSED_FRONT 64           // candidates a block may hand to the distributed selection (~8 expected)
+// the overlap-friendly three-launch step (psh_stream.hip): what its launches hand to each other.  Kernel boundaries on the
+// caller's stream are the synchronisation; the two counters are device-scope atomics.
+struct StreamCtl {
+    unsigned ticket;                 // sample kernel: blocks that have arrived (the last one derives the level); left at 0
+    unsigned ncand;                  // scan kernel: candidates appended to FusedHdr::cand (zeroed by the sample kernel)
+    unsigned ovf;                    // scan kernel: a block met more than PSH_FUSED_FRONT candidates
+    unsigned armed;                  // sample kernel: 1 = the four words below are valid
+    unsigned tau2_bits, thr2_bits, scale_bits, xn_bits;
+    unsigned pad[8];
+};
+#define PSH_STREAM_CAND_CAP (PSH_FUSED_MAX_BLOCKS * PSH_FUSED_FRONT)     // 16-byte entries FusedHdr::cand holds
 struct FusedHdr {
     unsigned long long magic;
     unsigned epoch;
     unsigned pad[13];
+    StreamCtl stream;
     unsigned long long blk[PSH_FUSED_MAX_BLOCKS];            // end-of-scan record of a block: tag << 32 | overflow << 31 | count
     unsigned long long blk2[PSH_FUSED_MAX_BLOCKS];           //   and tag << 32 | the tau2 bits it admitted with (must agree everywhere)
     unsigned long long aflag[PSH_FUSED_MAX_BLOCKS];          // bootstrap: tag << 32 | 1 once the block's minima are written
@@ -263,6 +275,11 @@ bool scan_fused_supported(int W);
 size_t scan_fused_shmem_bytes(int tile_floats);
 hipError_t launch_scan_fused(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, hipStream_t s);
 hipError_t launch_fused_init(FusedHdr* hdr, hipStream_t s);
+// psh_stream.hip: the same step as three launches that can share the chip with another stream's (PSH_FLAG_OVERLAP)
+size_t stream_scan_shmem_bytes(int tile_floats, int threads);
+hipError_t launch_stream_sample(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, int sample_tile_floats, hipStream_t s);
+hipError_t launch_stream_scan(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, int threads, hipStream_t s);
+hipError_t launch_stream_rank(const ScanArgs& a, const FusedArgs& f, int grid, hipStream_t s);
 hipError_t launch_embed_rows(const float* dataset, int64_t R, int64_t T, const float* ker, int d, int K, float* out, hipStream_t s);
 
 }  // namespace psh

@@ -1,0 +1,530 @@
+// psh_stream.hip -- the single-query step as THREE launches sized to share the chip with another stream's step (gfx950).
+// Identity + RelativeMSE (reference path_shadowing.py:149-173, path_distance.py:62-65), the same arithmetic and the same
+// results as scan_fused_kernel / scan_mx_kernel: f16 rejection test on the matrix cores, exact fp32 chain for the
+// survivors, ranking by (d, r, t).  Part of libpsh_hip.so; selected by PSH_FLAG_OVERLAP.
+//
+// Why.  The fused launch (psh_fused.hip) needs every one of its blocks resident, owns every CU for ~100 us, and HBM
+// idles for ~25 us of them (sample, two grid barriers, threshold, ranking, launch ramp).  Those idle stretches cannot be
+// shortened much further inside one launch -- but they need not be idle: a caller that has INDEPENDENT queries (a server,
+// a sharded run that overlaps its exchange) issues them on two or three streams, and then the latency-bound parts of one
+// step can run while another step streams the ensemble.  That only works if the launches can be co-resident:
+//   P  stream_sample_kernel   one-wave blocks, <= 64 VGPRs, one 4.5 KB tile of LDS: the bootstrap sample (one minimum per
+//                             sampled unit) and, in the block that arrives LAST (one device-scope ticket), the admission
+//                             level tau2, the f16 scale and the rejection threshold (scan_fused_kernel's phase B);
+//   S  stream_scan_kernel     16-wave blocks (112 VGPRs, ~146 KB of LDS): scan_fused_kernel's phase C and nothing else -- no
+//                             grid barrier, no polling, no residency requirement.  A block appends its handful of
+//                             candidates to ONE compact list behind one device-scope atomicAdd at its end;
+//   R  stream_rank_kernel     one-wave blocks, <= 64 VGPRs: every block ranks its share of the ~2k candidates against all of
+//                             them by counting (rank_select_kernel's loop) and writes out[rank].
+// Four S waves per SIMD leave 64 VGPRs, a wave slot and 14 KB of LDS per CU: exactly what a P or R wave needs, so P(i+1)
+// and R(i-1) run BESIDE S(i) of another stream, and the blocks of S(i+1) start on a CU the moment S(i)'s block leaves it
+// (no barrier inside S: an XCD that finishes early is refilled early).  Kernel boundaries are the only synchronisation;
+// the status protocol is the fused launch's (anything unusual -> PSH_STATUS_RETRY -> the caller's separate launches).
+#include "psh_device.h"
+
+namespace psh {
+
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) u64 gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+#define PSH_AUX_SC1 16
+
+__device__ __forceinline__ void st_sc1(unsigned* p, unsigned v) {
+    __hip_atomic_store((gu32*)(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t st_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// P: the sample and the admission level
+// ------------------------------------------------------------------------------------------------------------------
+#define PSH_STREAM_HIST 1024
+
+// what the last block derives from the minima: scan_fused_kernel's phase B (same formulas, same roundings towards "keep")
+__device__ inline bool stream_derive(const_f32p xq, int W, float edge_value, const float* qnorm_in, StreamCtl* ctl) {
+    const float tau0 = edge_value * PSH_TAU_MARGIN;
+    const float s = sumsq8([&](int j) { return xq[j]; }, W);
+    const float xn = qnorm_in ? qnorm_in[0] : __builtin_sqrtf(s);
+    unsigned qmaxbits = 0u;
+    for (int j = 0; j < W; ++j) qmaxbits = max(qmaxbits, __float_as_uint(fabsf(xq[j])));
+    if (!(tau0 > 0.0f && tau0 < __uint_as_float(PSH_INF_BITS) && qmaxbits < PSH_INF_BITS)) return false;
+    // scale = 2^sexp: max|x| 2^sexp < 8 and tau0 4^sexp <= 4096 (exponents of the bit patterns: value in [2^(e-1), 2^e))
+    const int et = (int)((__float_as_uint(tau0) >> 23) & 255u) - 126;
+    int sexp = (12 - et) >= 0 ? (12 - et) / 2 : -((et - 12 + 1) / 2);
+    if (qmaxbits >= 0x00800000u) {
+        const int eq = (int)((qmaxbits >> 23) & 255u) - 126;
+        sexp = sexp < 3 - eq ? sexp : 3 - eq;
+    }
+    if (!(sexp <= 60 && sexp >= -60 && __float_as_uint(tau0) >= 0x00800000u)) return false;
+    const float sc = __uint_as_float((unsigned)(127 + sexp) << 23);
+    double nxs = 0.0;
+    for (int j = 0; j < W; ++j) { const double vv = (double)xq[j] * (double)sc; nxs += vv * vv; }
+    const double am = 1.0 / 512.0, bm = 1.0 / 262144.0;
+    const double taus = (double)tau0 * (double)sc * (double)sc;
+    const double T = taus * (1.0 + 1.0 / 131072.0) * (1.0 + 2.0 * am) - nxs * (1.0 - 3.0 * am) * (1.0 - 1e-12) + bm;
+    float Tf = (float)T;
+    if ((double)Tf < T) Tf = __uint_as_float(Tf >= 0.0f ? __float_as_uint(Tf) + 1u : __float_as_uint(Tf) - 1u);
+    if (!(Tf == Tf && fabsf(Tf) < __uint_as_float(PSH_INF_BITS))) return false;
+    ctl->tau2_bits = __float_as_uint(tau0);
+    ctl->thr2_bits = __float_as_uint(Tf);
+    ctl->scale_bits = __float_as_uint(sc);
+    ctl->xn_bits = __float_as_uint(xn);
+    return true;
+}
+
+template <int WT, bool ALIGNED>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void stream_sample_kernel(ScanArgs a, FusedArgs f) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tile = smem;                                      // one wave, one tile; the last block's histogram lives here too
+    const int lane = lane_id();
+    FusedHdr* hdr = f.hdr;
+    StreamCtl* ctl = &hdr->stream;
+    const int W = WT > 0 ? WT : a.W;
+    const int nfloat = PSH_SEG + W - 1;
+    const const_f32p x = (const_f32p)a.queries;
+    const unsigned nbu = (unsigned)f.boot_units;
+
+    auto boot_load = [&](Stage& sx, unsigned uu) {
+        const unsigned ri = fast_div(uu, a.magic_nseg, (unsigned)a.nseg);
+        const unsigned sg = uu - ri * (unsigned)a.nseg;
+        stage_load<ALIGNED>(sx, a.dataset + (f.boot_row0 + (int64_t)ri * f.boot_row_stride) * a.T, a.T, (int)sg * PSH_SEG, nfloat, lane);
+    };
+    unsigned u = blockIdx.x;
+    for (int p = lane; p < a.tile_floats; p += 64) tile[p] = 0.0f;           // no slot is ever read uninitialised
+    // a header psh_workspace_init never saw: no ticket can be trusted -- block 0 says so, the scan and the ranking return
+    const bool armed_hdr = hdr->magic == PSH_FUSED_MAGIC;
+    if (!armed_hdr) {
+        if (blockIdx.x == 0 && lane == 0) { ctl->armed = 0u; ctl->ncand = 0u; ctl->ovf = 0u; }
+        return;
+    }
+    while (u < nbu) {
+        const unsigned ri = fast_div(u, a.magic_nseg, (unsigned)a.nseg);
+        const unsigned sg = u - ri * (unsigned)a.nseg;
+        const int seg_start = (int)sg * PSH_SEG;
+        {   // (no register prefetch of the next unit: 20 VGPRs this wave does not have; the other sample waves of the chip
+            //  cover the latency)
+            Stage st;
+            boot_load(st, u);
+            stage_store<false>(st, tile, nfloat, lane);
+        }
+        wave_lds_fence();
+        const unsigned un = u + gridDim.x;
+        const int t_lane = seg_start + PSH_L * lane;
+        int nvalid = a.Tp - t_lane;
+        nvalid = nvalid < 0 ? 0 : (nvalid > PSH_L ? PSH_L : nvalid);
+        // the exact chains of the lane's 16 windows, taps from the scalar cache (few registers: this wave lives in the 64
+        // VGPRs four scan waves leave on a SIMD; the sample is ~3 % of a scan's arithmetic)
+        float acc[PSH_L];
+        accumulate16<WT, false>(tile, lane, x, W, acc);
+        float m = __uint_as_float(PSH_INF_BITS);
+#pragma unroll
+        for (int i = 0; i < PSH_L; ++i) m = (i < nvalid) ? fminf(m, acc[i]) : m;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+        if (!(m == m)) m = __uint_as_float(PSH_INF_BITS);                  // NaN data: the segment carries no information
+        if (lane == 0) st_sc1(&hdr->minima[u], __float_as_uint(m));        // write-through
+        wave_lds_fence();
+        u = un;
+    }
+    // arrive: the minima have left this CU (drain), then ONE device-scope ticket; the last arriver goes on
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned tk = 0u;
+    if (lane == 0) tk = __hip_atomic_fetch_add((gu32*)&ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tk = (unsigned)__builtin_amdgcn_readfirstlane((int)tk);
+    if (tk != gridDim.x - 1u) return;
+
+    // ---- the last block: rank-th smallest minimum -> tau2 (its bucket's upper edge), scale, threshold
+    unsigned* hist = reinterpret_cast<unsigned*>(smem);
+    for (int i = lane; i < PSH_STREAM_HIST; i += 64) hist[i] = 0u;
+    const __amdgpu_buffer_rsrc_t rmin = st_rsrc(hdr->minima, sizeof(hdr->minima));
+    const int n4 = ((int)nbu + 3) >> 2;                      // 16-byte groups of minima (the array is PSH_FUSED_MAX_UNITS long)
+    unsigned kmin = 0xffffffffu, kmax = 0u;
+    int nfin = 0;
+    for (int g0 = 0; g0 < n4; g0 += 64 * 4) {
+        u32x4v mv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int g = g0 + lane + 64 * q;
+            mv[q] = __builtin_amdgcn_raw_buffer_load_b128(rmin, (g < n4 ? g : 0) * 16, 0, PSH_AUX_SC1);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int g = g0 + lane + 64 * q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (g < n4 && 4 * g + e < (int)nbu && mv[q][e] < PSH_INF_BITS) {
+                    kmin = mv[q][e] < kmin ? mv[q][e] : kmin; kmax = mv[q][e] > kmax ? mv[q][e] : kmax; ++nfin;
+                }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned l2 = __shfl_xor(kmin, off, 64), h2 = __shfl_xor(kmax, off, 64);
+        kmin = l2 < kmin ? l2 : kmin;
+        kmax = h2 > kmax ? h2 : kmax;
+        nfin += __shfl_xor(nfin, off, 64);
+    }
+    bool armed = nfin >= f.rank;
+    unsigned edge = 0u;
+    if (armed) {
+        const unsigned range = kmax - kmin;
+        const int hb = range ? 32 - __builtin_clz(range) : 0;
+        const int shift = hb > 10 ? hb - 10 : 0;                          // (range >> shift) < 1024
+        wave_lds_fence();
+        for (int g0 = 0; g0 < n4; g0 += 64 * 4) {
+            u32x4v mv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int g = g0 + lane + 64 * q;
+                mv[q] = __builtin_amdgcn_raw_buffer_load_b128(rmin, (g < n4 ? g : 0) * 16, 0, PSH_AUX_SC1);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int g = g0 + lane + 64 * q;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (g < n4 && 4 * g + e < (int)nbu && mv[q][e] < PSH_INF_BITS) atomicAdd(&hist[(mv[q][e] - kmin) >> shift], 1u);
+            }
+        }
+        wave_lds_fence();
+        constexpr int PER = PSH_STREAM_HIST / 64;
+        unsigned h[PER];
+        unsigned sl = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) { h[q] = hist[PER * lane + q]; sl += h[q]; }
+        unsigned inc = sl;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned t2 = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += t2;
+        }
+        unsigned cum = inc - sl;
+        const unsigned rk = (unsigned)f.rank;
+        unsigned my_edge = 0u;
+        const bool mine = cum < rk && inc >= rk;                         // exactly one lane
+        if (mine) {
+            int bucket = PER * lane;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                if (cum < rk && cum + h[q] >= rk) bucket = PER * lane + q;
+                cum += h[q];
+            }
+            // every minimum in buckets <= `bucket` is at or below the bucket's upper edge, and there are >= rank of them
+            u64 e2 = (u64)kmin + (((u64)bucket + 1ull) << shift) - 1ull;
+            if (e2 > (u64)kmax) e2 = kmax;
+            my_edge = (unsigned)e2;
+        }
+        const u64 who = __ballot(mine);
+        edge = (unsigned)__builtin_amdgcn_readlane((int)my_edge, who ? (int)__builtin_ctzll(who) : 0);
+    }
+    if (lane == 0) {
+        if (armed) armed = stream_derive(x, W, __uint_as_float(edge), f.qnorm_in, ctl);
+        ctl->armed = armed ? 1u : 0u;
+        ctl->ncand = 0u;
+        ctl->ovf = 0u;
+        ctl->ticket = 0u;                                                 // the next launch on this workspace counts from zero
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// S: the scan
+// ------------------------------------------------------------------------------------------------------------------
+#define PSH_STREAM_FIXED_BYTES 1280   // control words + the block's front list
+enum { S_FRONT = 0, S_NEXT = 1 };
+
+template <int WT, bool ALIGNED, int THREADS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(56))) void stream_scan_kernel(ScanArgs a, FusedArgs f) {
+    static_assert(WT >= 0 && WT <= 33, "the shifted-query band must fit K = 64 (WT = 0: run-time W <= 33)");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NW = THREADS / 64;
+    const int lane = lane_id();
+    const int tid = (int)threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int* ctl = reinterpret_cast<int*>(smem);                                 // 64 control words
+    u32x4* fl = reinterpret_cast<u32x4*>(ctl + 64);                           // PSH_FUSED_FRONT entries {acc bits, r, t, -}
+    float* tiles = smem + PSH_STREAM_FIXED_BYTES / 4;
+    float* tile = tiles + (size_t)wave * a.tile_floats;
+    _Float16* ah0 = reinterpret_cast<_Float16*>(tiles + (size_t)NW * a.tile_floats);
+    _Float16* a1 = ah0 + (size_t)wave * 2 * PSH_MX_NHALF;                     // y^
+    _Float16* a2 = a1 + PSH_MX_NHALF;                                         // (y~^2)^
+    FusedHdr* hdr = f.hdr;
+    const StreamCtl* sc = &hdr->stream;
+    auto stamp = [&](int i) { if (a.dbg_times && tid == 0) a.dbg_times[(size_t)blockIdx.x * 8 + i] = (unsigned long long)wall_clock64(); };
+    stamp(0);
+
+    const int W = WT > 0 ? WT : a.W;
+    const int nfloat = PSH_SEG + W - 1;
+    const const_f32p x = (const_f32p)a.queries;
+    const unsigned n_rs = (unsigned)a.n_rows * (unsigned)a.nseg;
+    const unsigned u_lo = (unsigned)(((u64)n_rs * blockIdx.x) / gridDim.x);
+    const unsigned u_hi = (unsigned)(((u64)n_rs * (blockIdx.x + 1u)) / gridDim.x);
+
+    auto decode = [&](unsigned uu, unsigned& ri, unsigned& sg) {
+        ri = fast_div(uu, a.magic_nseg, (unsigned)a.nseg);
+        sg = uu - ri * (unsigned)a.nseg;
+    };
+    auto load_unit = [&](Stage& sx, unsigned uu) {
+        unsigned ri, sg;
+        decode(uu, ri, sg);
+        stage_load<ALIGNED>(sx, a.dataset + (a.row0 + (int64_t)ri * a.row_stride) * a.T, a.T, (int)sg * PSH_SEG, nfloat, lane);
+    };
+    // the first unit of every wave is requested before anything else (static: unit u_lo + wave; the queue starts behind them)
+    Stage st;
+    unsigned u = u_lo + (unsigned)wave;
+    if (u < u_hi) load_unit(st, u);
+
+    if (tid == 0) { ctl[S_FRONT] = 0; ctl[S_NEXT] = NW; }
+    // what the sample kernel left (an earlier launch on this stream: plain loads)
+    const bool armed = sc->armed != 0u;
+    const float tau2 = __uint_as_float(sc->tau2_bits);
+    const float thr2 = __uint_as_float(sc->thr2_bits);
+    const float scale = __uint_as_float(sc->scale_bits);
+    const float xn = __uint_as_float(sc->xn_bits);
+    if (!armed) return;                                                       // uniform: the ranking reports PSH_STATUS_RETRY
+    {   // every slot of the f16 arrays a segment does not write must be finite (0 * NaN poisons a row)
+        unsigned* z = reinterpret_cast<unsigned*>(a1);
+        for (int i = lane; i < PSH_MX_NHALF; i += 64) z[i] = 0u;              // 2 arrays x NHALF halves = NHALF dwords
+    }
+    f16x8 bx[4], bo[4];
+    {
+        const int n = lane & 31, hk = lane >> 5;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int j = 16 * s + 8 * hk + i - n;
+                const bool in = j >= 0 && j < W;
+                const float xv = x[in ? j : 0];
+                bx[s][i] = (_Float16)(in ? -2.0f * (xv * scale) : 0.0f);
+                bo[s][i] = (_Float16)(in ? 1.0f : 0.0f);
+            }
+    }
+    __syncthreads();
+    stamp(1);
+    auto grab = [&]() -> unsigned {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(&ctl[S_NEXT], 1);
+        return u_lo + (unsigned)__builtin_amdgcn_readfirstlane(v);
+    };
+    while (u < u_hi) {
+        unsigned ri, sg;
+        decode(u, ri, sg);
+        const int64_t row = a.row0 + (int64_t)ri * a.row_stride;
+        const int seg_start = (int)sg * PSH_SEG;
+        const int r_global = (int)(row + a.r_offset);
+
+        stage_store(st, tile, nfloat, lane);
+        {
+            const int nq = (nfloat + 3) >> 2;
+#pragma unroll
+            for (int q = 0; q < PSH_NSTAGE; ++q) {
+                const int m = lane + 64 * q;
+                if (q < PSH_NSTAGE - 1 || m < nq) {
+                    const f32x4 v = st.v[q] * scale;
+                    const f32x4 v2 = v * v;
+                    *reinterpret_cast<f16x4*>(a1 + mx_half(4 * m)) = __builtin_convertvector(v, f16x4);
+                    *reinterpret_cast<f16x4*>(a2 + mx_half(4 * m)) = __builtin_convertvector(v2, f16x4);
+                }
+            }
+        }
+        wave_lds_fence();
+        const unsigned un = grab();
+        if (un < u_hi) load_unit(st, un);
+
+        const int m = lane & 31, hk = lane >> 5;
+        f16x8 fa[4];
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fa[s] = *reinterpret_cast<const f16x8*>(a2 + mx_half(32 * m + 16 * s + 8 * hk));
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s], bo[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fa[s] = *reinterpret_cast<const f16x8*>(a1 + mx_half(32 * m + 16 * s + 8 * hk));
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s], bx[s], acc, 0, 0, 0);
+        bool keep = false;                                 // NaN-safe: !(t^ > thr)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) keep = keep || !(acc[r] > thr2);
+        if (__any(keep)) {
+            unsigned hm = 0u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hm |= !(acc[r] > thr2) ? (1u << r) : 0u;
+#pragma unroll 1
+            for (int r = 0; r < 16; ++r) {
+                const int p = 32 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + m;      // C layout: row -> window
+                bool hit = (((hm >> r) & 1u) != 0u) && (seg_start + p < a.Tp);
+                if (!__ballot(hit)) continue;
+                float v = 0.0f;
+                if (hit) { if constexpr (WT > 0) v = exact_one<(WT > 0 ? WT : 20)>(tile, p, x); else v = exact_one_rt(tile, p, x, W); }
+                hit = hit && (v < tau2);
+                const unsigned long long mask = __ballot(hit);
+                if (!mask) continue;
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&ctl[S_FRONT], __popcll(mask));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (hit) {
+                    const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    if (slot < PSH_FUSED_FRONT) fl[slot] = u32x4{__float_as_uint(v), (unsigned)r_global, (unsigned)(seg_start + p), 0u};
+                }
+            }
+        }
+        wave_lds_fence();  // all lanes done with the tile before it is overwritten
+        u = un;
+    }
+    stamp(2);
+    __syncthreads();
+    // the block's candidates go to ONE compact list: a device-scope atomicAdd per block (not per candidate)
+    if (wave == 0) {
+        const int nfront = ctl[S_FRONT];
+        const int mown = nfront < PSH_FUSED_FRONT ? nfront : PSH_FUSED_FRONT;
+        unsigned base = 0u;
+        if (lane == 0 && mown > 0) base = __hip_atomic_fetch_add((gu32*)&hdr->stream.ncand, (unsigned)mown, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        if (lane < mown && base + (unsigned)lane < PSH_STREAM_CAND_CAP) {
+            u32x4 e = fl[lane];
+            e[0] = __float_as_uint(dist_from_acc(__uint_as_float(e[0]), xn));
+            reinterpret_cast<u32x4*>(hdr->cand)[base + (unsigned)lane] = e;
+        }
+        if (lane == 0 && nfront > PSH_FUSED_FRONT) __hip_atomic_store((gu32*)&hdr->stream.ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    stamp(3);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// R: ranking by counting
+// ------------------------------------------------------------------------------------------------------------------
+template <bool PACKED>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void stream_rank_kernel(ScanArgs a, FusedArgs f) {
+    const int lane = lane_id();
+    FusedHdr* hdr = f.hdr;
+    const StreamCtl* sc = &hdr->stream;
+    const int ncand = (int)sc->ncand;
+    const bool good = sc->armed != 0u && sc->ovf == 0u && ncand >= a.k && ncand <= PSH_STREAM_CAND_CAP;
+    if (blockIdx.x == 0 && lane == 0) {
+        f.status[0] = good ? PSH_STATUS_OK_ : PSH_STATUS_RETRY_;
+        if (f.total) f.total[0] = ncand;
+        if (a.qstate) {                                     // diagnostics / the separate launches' state, kept coherent
+            QueryState q;
+            q.xn = __uint_as_float(sc->xn_bits); q.tau_bits = sc->tau2_bits; q.n_valid = good ? a.k : 0; q.nx = 0.0f;
+            q.thr_base = __uint_as_float(PSH_INF_BITS); q.mx_scale = __uint_as_float(sc->scale_bits);
+            q.mx_thr = __uint_as_float(sc->thr2_bits); q.tau2_bits = sc->tau2_bits; q.mx_thr2 = q.mx_thr;
+            q.pad[0] = q.pad[1] = q.pad[2] = 0;
+            a.qstate[0] = q;
+        }
+    }
+    if (!good) return;
+    const u32x4v* cand = reinterpret_cast<const u32x4v*>(hdr->cand);
+    const int per = (ncand + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int lo = (int)blockIdx.x * per;
+    const int hi = lo + per < ncand ? lo + per : ncand;
+    constexpr int NB = 4;                                    // candidate loads in flight per lane
+    for (int j0 = lo; j0 < hi; j0 += 8) {
+        // the (up to) 8 own candidates of this turn: lane jj holds candidate j0 + jj, its key goes to scalar registers
+        const u32x4v mine = cand[j0 + (lane & 7) < hi ? j0 + (lane & 7) : lo];
+        const u64 mkey = PACKED ? (((u64)mine[0] << 32) | (u64)((mine[1] << f.tbits) | mine[2]))
+                                : (((u64)mine[1] << 32) | (u64)mine[2]);
+        u64 okey[8];
+        unsigned od[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            okey[jj] = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mkey >> 32), jj) << 32)
+                       | (u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)mkey, jj);
+            od[jj] = (unsigned)__builtin_amdgcn_readlane((int)mine[0], jj);
+        }
+        int c[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) c[jj] = 0;
+        for (int i0 = 0; i0 < ncand; i0 += 64 * NB) {
+            u32x4v e[NB];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int ci = i0 + lane + 64 * q;
+                e[q] = cand[ci < ncand ? ci : ncand - 1];
+            }
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const bool live = i0 + lane + 64 * q < ncand;
+                if (PACKED) {
+                    const u64 key = live ? (((u64)e[q][0] << 32) | (u64)((e[q][1] << f.tbits) | e[q][2])) : ~0ull;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) c[jj] += key < okey[jj] ? 1 : 0;
+                } else {
+                    const unsigned kd = live ? e[q][0] : 0xffffffffu;
+                    const u64 krt = live ? (((u64)e[q][1] << 32) | (u64)e[q][2]) : ~0ull;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) c[jj] += (kd < od[jj] || (kd == od[jj] && krt < okey[jj])) ? 1 : 0;
+                }
+            }
+        }
+        int rank = 0;                                        // lane jj keeps the rank of own candidate jj
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            int v = c[jj];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            rank = lane == jj ? v : rank;
+        }
+        if (lane < 8 && j0 + lane < hi && rank < a.k) {
+            f.out_d[rank] = __uint_as_float(mine[0]);
+            f.out_idx[2 * rank + 0] = (int)mine[1];
+            f.out_idx[2 * rank + 1] = (int)mine[2];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+size_t stream_scan_shmem_bytes(int tile_floats, int threads) {
+    return (size_t)PSH_STREAM_FIXED_BYTES + (size_t)tile_floats * (threads / 64) * sizeof(float)
+           + (size_t)(threads / 64) * 2 * PSH_MX_NHALF * sizeof(_Float16);
+}
+size_t stream_sample_shmem_bytes(int tile_floats) {
+    const size_t t = (size_t)tile_floats * sizeof(float), h = (size_t)PSH_STREAM_HIST * sizeof(unsigned);
+    return t > h ? t : h;
+}
+
+template <typename K>
+static hipError_t launch_k(K kernel, int grid, int threads, size_t shmem, hipStream_t s, const ScanArgs& a, const FusedArgs& f) {
+    if (shmem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), shmem, s, a, f);
+    return hipGetLastError();
+}
+
+hipError_t launch_stream_sample(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, int sample_tile_floats, hipStream_t s) {
+    const size_t shmem = stream_sample_shmem_bytes(sample_tile_floats);
+    ScanArgs b = a;
+    b.tile_floats = sample_tile_floats;
+    if (a.W == 20)
+        return aligned ? launch_k(stream_sample_kernel<20, true>, grid, 64, shmem, s, b, f)
+                       : launch_k(stream_sample_kernel<20, false>, grid, 64, shmem, s, b, f);
+    return aligned ? launch_k(stream_sample_kernel<0, true>, grid, 64, shmem, s, b, f)
+                   : launch_k(stream_sample_kernel<0, false>, grid, 64, shmem, s, b, f);
+}
+
+template <int THREADS>
+static hipError_t launch_stream_scan_t(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, hipStream_t s) {
+    const size_t shmem = stream_scan_shmem_bytes(a.tile_floats, THREADS);
+    if (a.W == 20)
+        return aligned ? launch_k(stream_scan_kernel<20, true, THREADS>, grid, THREADS, shmem, s, a, f)
+                       : launch_k(stream_scan_kernel<20, false, THREADS>, grid, THREADS, shmem, s, a, f);
+    return aligned ? launch_k(stream_scan_kernel<0, true, THREADS>, grid, THREADS, shmem, s, a, f)
+                   : launch_k(stream_scan_kernel<0, false, THREADS>, grid, THREADS, shmem, s, a, f);
+}
+hipError_t launch_stream_scan(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, int threads, hipStream_t s) {
+    return threads == 512 ? launch_stream_scan_t<512>(a, f, aligned, grid, s) : launch_stream_scan_t<PSH_SCAN_THREADS>(a, f, aligned, grid, s);
+}
+
+hipError_t launch_stream_rank(const ScanArgs& a, const FusedArgs& f, int grid, hipStream_t s) {
+    return f.tbits >= 0 ? launch_k(stream_rank_kernel<true>, grid, 64, 0, s, a, f)
+                        : launch_k(stream_rank_kernel<false>, grid, 64, 0, s, a, f);
+}
+
+}  // namespace psh

@@ -13,6 +13,7 @@ collective, and there is no collective on the data path itself.
 """
 from __future__ import annotations
 
+import weakref
 from typing import Callable
 
 import numpy as np
@@ -22,6 +23,16 @@ import torch.distributed as dist
 from . import _native
 from .path_distance import RelativeMSE
 from .path_embedding import Identity, PathEmbedding, PredictionContext
+
+
+def _close_comm(comm, device) -> None:
+    """Finalizer of a library-owned communicator (ShardedPathShadowing.close, object collection, interpreter exit)."""
+    try:
+        if torch.cuda.is_available():
+            torch.cuda.synchronize(device)
+        comm.close()
+    except Exception:  # noqa: BLE001  (interpreter shutdown: the runtime may be gone already)
+        pass
 
 
 def shard_rows(R: int, world_size: int, rank: int) -> tuple[int, int]:
@@ -158,6 +169,8 @@ class ShardedPathShadowing:
                 dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
                                            group=self.group)
             self._comm = _native.Comm(self.device, G, rank, box[0])
+            # the communicator belongs to libpsh_hip.so: it goes away with this object (or at interpreter exit)
+            self._comm_finalizer = weakref.finalize(self, _close_comm, self._comm, self.device)
             self._side = torch.cuda.Stream(device=self.device)
             self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(8)]
             for a, b in self._events:              # materialise the hipEvent handles
@@ -165,14 +178,17 @@ class ShardedPathShadowing:
         return self._comm
 
     def _use_library(self, B: int, k: int) -> bool:
-        if self.exchange == "torch" or self._local_topk is not None or self._merge is not None or not self.device.type == "cuda":
-            return False
-        return (B * k) % 2 == 0
+        usable = (self._local_topk is None and self._merge is None and self.device.type == "cuda" and (B * k) % 2 == 0)
+        if self.exchange == "library" and not usable:
+            raise _native.NativeLibraryError(
+                'exchange="library" (psh_exchange_merge) needs a HIP device, the native scan and an even B*k '
+                f'(device {self.device}, B*k = {B * k}); use exchange="auto" or "torch"')
+        return usable and self.exchange != "torch"
 
     def close(self):
         if self._comm is not None:
-            torch.cuda.synchronize(self.device)
-            self._comm.close()
+            self._comm_finalizer.detach()
+            _close_comm(self._comm, self.device)
             self._comm = None
 
     def local_scan(self, q: torch.Tensor, k: int, out=None, check: bool = True, unsorted: bool = False, flags: int = 0):

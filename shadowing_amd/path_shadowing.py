@@ -170,9 +170,21 @@ class PathShadowing:
             return False
         ds = self.dataset
         if isinstance(ds, torch.Tensor):
-            return True                               # keyed on the tensor's version counter
-        arr = np.asarray(ds)
-        return not arr.flags.writeable
+            # keyed on the tensor's version counter, which every in-place TORCH op bumps.  (A CPU tensor made by
+            # torch.from_numpy can still be edited through the numpy array without a bump: callers who do that pass
+            # cache=False or call refresh() -- documented in README.)
+            return True
+        arr = ds if isinstance(ds, np.ndarray) else None
+        if arr is None:
+            return False                              # lists etc.: converted (and re-read) per call
+        # read-only all the way down: a read-only VIEW of a writeable base (arr.view() with writeable=False,
+        # np.broadcast_to) can still change through its base
+        while isinstance(arr, np.ndarray):
+            if arr.flags.writeable:
+                return False
+            arr = arr.base
+        import mmap
+        return arr is None or isinstance(arr, (bytes, mmap.mmap))   # owns its data / immutable bytes / a file mapped read-only
 
     # ------------------------------------------------------------------ native path
     def _native_kind(self, x: torch.Tensor, y: torch.Tensor, k: int) -> str | None:
@@ -288,7 +300,7 @@ class PathShadowing:
                 h = 0
             # the scanning kernel on the device, kept while the module's kernel tensor is the same object at the same
             # version (an in-place edit bumps it): no upload per call, and the library may keep what it found in the matrix
-            kkey = (id(ker), ker._version, kind, str(dev), id(self.context) if kind == "padded" else None)
+            kkey = (id(ker), ker._version, kind, str(dev), tuple(self.context.portion) if kind == "padded" else None)
             if getattr(self, "_ker_dev", None) is None or self._ker_dev[0] != kkey:
                 if kind == "padded":
                     ker2 = self.context.pad_context(ker)[:, 0, :].contiguous().to(dev)

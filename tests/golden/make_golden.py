@@ -51,6 +51,9 @@ def main():
                     help="ONLY the configs[2]-shaped cases with more queries than one query chunk of the batched scan")
     ap.add_argument("--edge", action="store_true",
                     help="ONLY the embedded one-window-per-row cases (T == K + h)")
+    ap.add_argument("--predict", action="store_true",
+                    help="ONLY the predict() cases: the reference's own predict() (PS:256-301) with averaging classes of "
+                         "known arithmetic (tests/_known_proba.py) injected where un-vendored scatspectra's would be")
     ap.add_argument("--cross", action="store_true",
                     help="ONLY the CrossChannelContext cases (multi-channel ensemble, scan on channel 0)")
     args = ap.parse_args()
@@ -121,6 +124,38 @@ def main():
                    meta=json.dumps(dict(reference_seconds=round(dt, 3), numpy=np.__version__, torch=torch.__version__)))
         np.savez_compressed(HERE / f"{name}.npz", **out)
         print(f"{name}: dataset{ds.shape} d{d.shape} idx{idx.shape} paths{paths.shape} ref {dt:.2f}s")
+
+    if args.predict:
+        spec2 = importlib.util.spec_from_file_location("psh_known_proba", REPO / "tests" / "_known_proba.py")
+        kp = importlib.util.module_from_spec(spec2)
+        spec2.loader.exec_module(kp)
+        ps_mod = sys.modules["shadowing.path_shadowing.path_shadowing"]     # PS:9 bound the names at import: rebind them there
+        ps_mod.Softmax, ps_mod.Uniform, ps_mod.DiscreteProba = kp.Softmax, kp.Uniform, kp.DiscreteProba
+        Ts = [5, 10, 20]
+
+        def rv(x):                                          # the tutorial's statistic (statistics.py:5-16), vol=True
+            return ref.realized_variance(x, Ts, vol=True)
+
+        def run_predict(name, emb, ds, q, h, k, eta, proba_name, n_ds, n_ctx):
+            obj = ref.PathShadowing(emb, ref.RelativeMSE(), ds, ref.PredictionContext(horizon=h))
+            mean, std = obj.predict(q, k, rv, eta=eta, proba_name=proba_name, n_dataset_splits=n_ds, n_context_splits=n_ctx)
+            d, paths, idx = obj.shadow(q, k=k, n_splits=n_ds, cuda=False)
+            out = dict(queries=np.asarray(q, dtype=np.float32), dataset=ds, h=h, k=k, eta=-1.0 if eta is None else eta,
+                       proba_name=proba_name, n_dataset_splits=n_ds, n_context_splits=n_ctx, Ts=np.array(Ts), mean=mean, std=std,
+                       d=d, idx=idx, dataset_sha256=syn.sha256(ds),
+                       meta=json.dumps(dict(numpy=np.__version__, torch=torch.__version__, proba="tests/_known_proba.py")))
+            if isinstance(emb, ref.Foveal):
+                out.update(foveal=np.array([1.15, 0.9, emb.kernel.shape[-1]]))
+            np.savez_compressed(HERE / f"{name}.npz", **out)
+            print(f"{name}: mean{mean.shape} std{std.shape} {mean.dtype}")
+
+        run_predict("predict_identity_softmax", ref.Identity(20), syn.dataset(96, 400, 90), syn.gbm_log_returns((6, 20), 91),
+                    20, 48, 0.05, "softmax", 2, 3)
+        run_predict("predict_identity_uniform", ref.Identity(20), syn.dataset(96, 400, 90), syn.gbm_log_returns((4, 1, 20), 92),
+                    20, 32, None, "uniform", 1, 1)
+        run_predict("predict_foveal_softmax", ref.Foveal(1.15, 0.9, 64), syn.dataset(80, 500, 93), syn.gbm_log_returns((4, 64), 94),
+                    20, 40, 0.1, "softmax", 1, 2)
+        return
 
     if args.batched:
         # BASELINE.json configs[2] in small: more rolling query dates than one query chunk (112) of the batched scan

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import CROSS_GOLDENS, EMBEDDED_GOLDENS, IMPUTATION_GOLDENS, assert_exact, assert_matches_reference, bits, load_golden, rows3
+from _util import CROSS_GOLDENS, EMBEDDED_GOLDENS, IMPUTATION_GOLDENS, PREDICT_GOLDENS, predict_case, assert_exact, assert_matches_reference, bits, load_golden, rows3
 from shadowing_amd import synthetic as syn
 
 pytestmark = pytest.mark.gpu
@@ -613,6 +613,28 @@ def test_predict_keeps_the_paths_on_the_device_when_asked_to(hip_device, monkeyp
     # and a callable that does not return a tensor under device_predict is an error, not a silent fallback
     with pytest.raises(TypeError):
         obj.predict(x, k=16, to_predict=lambda p: 1.0, cuda=True, device_predict=True)
+
+
+@pytest.mark.parametrize("name", PREDICT_GOLDENS)
+@pytest.mark.parametrize("device_predict", [False, True])
+def test_predict_cuda_matches_the_reference_predict(hip_device, monkeypatch, name, device_predict):
+    """predict(cuda=True[, device_predict=True]) against the REFERENCE's own predict() (PS:256-301) run with the
+    known-arithmetic averaging classes of tests/_known_proba.py (make_golden.py --predict): Identity (fused / batched
+    scan) and Foveal (prefix-sum scan).  Host statistic: the same float32 paths -> bit-equal; device statistic: a float32
+    mean of squares reduced by torch on the GPU instead of numpy on the host -> 2e-6."""
+    import shadowing_amd as sa
+    obj, g = predict_case(name, sa, monkeypatch)
+    Ts = [int(t) for t in g["Ts"]]
+    m, s = obj.predict(g["queries"], int(g["k"]), lambda f: sa.realized_variance(f, Ts, vol=True), eta=g["eta"],
+                       proba_name=str(g["proba_name"]), n_dataset_splits=int(g["n_dataset_splits"]),
+                       n_context_splits=int(g["n_context_splits"]), cuda=True, device_predict=device_predict)
+    assert obj.last_path == "hip"
+    assert m.shape == g["mean"].shape and s.shape == g["std"].shape
+    if device_predict:
+        np.testing.assert_allclose(m, g["mean"], rtol=2e-6)
+        np.testing.assert_allclose(s, g["std"], rtol=2e-5, atol=1e-12)
+    else:
+        assert np.array_equal(m, g["mean"]) and np.array_equal(s, g["std"])
 
 
 def test_reference_test_cell_1_forward_topk_prefix_consistency_on_the_device(hip_device):

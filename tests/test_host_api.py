@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import shadowing_amd as sa
-from _util import SMALL_GOLDENS, assert_exact, load_golden
+from _util import PREDICT_GOLDENS, SMALL_GOLDENS, assert_exact, load_golden, predict_case
 from shadowing_amd import synthetic as syn
 from shadowing_amd.path_shadowing import _dim_array, _numpy, _torch
 
@@ -19,6 +19,22 @@ def test_drop_in_import_paths():
                            realized_variance, select_cartesian_product)
     from shadowing.path_shadowing import PathDistance, PathEmbedding  # noqa: F401
     assert shadowing.PathShadowing is sa.PathShadowing
+    # tutorial.ipynb:21-24 / testing.ipynb:134-136 import the figure helpers from the same package
+    from shadowing import plot_closest, plot_shadow, plot_volatility  # noqa: F401
+
+
+def test_plot_helpers_draw_without_scatspectra():
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    from shadowing import plot_closest, plot_shadow, plot_volatility
+    rng = np.random.default_rng(0)
+    present, paths, d = rng.standard_normal(20) * 0.01, rng.standard_normal((8, 1, 30)) * 0.01, np.linspace(0.3, 0.6, 8)
+    plot_closest(present, paths, num_trajectories=5)
+    plot_shadow(present, d, paths, eta=0.1)
+    plot_volatility(present, np.full((2, 11), 0.2), [5, 10], distances=d, close_paths=paths, eta=0.1)
+    assert len(plt.get_fignums()) == 3
+    plt.close("all")
 
 
 @pytest.mark.parametrize("name", SMALL_GOLDENS)
@@ -135,6 +151,20 @@ def test_predict_from_paths_with_a_fake_proba(monkeypatch):
     assert np.allclose(m, (paths[..., -3:] ** 2).sum(-1).mean(1)) and m.shape == (5, 1) and s.shape == (5, 1)
 
 
+@pytest.mark.parametrize("name", PREDICT_GOLDENS)
+def test_predict_matches_the_reference_predict(name, monkeypatch):
+    """predict() (shadow -> select_out_context -> proba.avg / std over the k paths, context splits concatenated) against
+    the REFERENCE's own predict() run with the same known-arithmetic averaging classes (PS:245-252, 256-301): pins the
+    slicing and axis conventions around the un-vendored classes against the reference, bit for bit on the host path."""
+    obj, g = predict_case(name, sa, monkeypatch)
+    Ts = [int(t) for t in g["Ts"]]
+    m, s = obj.predict(g["queries"], int(g["k"]), lambda f: sa.realized_variance(f, Ts, vol=True), eta=g["eta"],
+                       proba_name=str(g["proba_name"]), n_dataset_splits=int(g["n_dataset_splits"]),
+                       n_context_splits=int(g["n_context_splits"]), cuda=False)
+    assert m.shape == g["mean"].shape and s.shape == g["std"].shape
+    assert np.array_equal(m, g["mean"]) and np.array_equal(s, g["std"])
+
+
 def test_predict_runs_on_the_host_path():
     ds = syn.dataset(32, 256, 3)
     obj = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), ds, sa.PredictionContext(10))
@@ -224,6 +254,9 @@ def test_resident_copy_policy():
     ro = ds.copy(); ro.flags.writeable = False
     assert mk(ro)._may_keep_resident() and mk(torch.tensor(ds))._may_keep_resident()
     assert mk(ds, cache=True)._may_keep_resident() and not mk(ro, cache=False)._may_keep_resident()
+    # a read-only VIEW of a writeable base can change through the base: never kept
+    view = ds.view(); view.flags.writeable = False
+    assert not mk(view)._may_keep_resident() and not mk(np.broadcast_to(ds[:1], ds.shape))._may_keep_resident()
     with pytest.raises(ValueError):
         mk(ds, cache="yes")
     obj = mk(ro)
