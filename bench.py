@@ -65,6 +65,11 @@ def parse():
     ap.add_argument("--filter", choices=("mx", "valu"), default="mx",
                     help="rejection test of the scan: matrix cores (default) or vector ALUs (PSH_FLAG_FILTER_VALU; comparison runs)")
     ap.add_argument("--no-fuse", action="store_true", help="the separate bootstrap / threshold / scan / select launches")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="single query: consecutive steps (independent queries) are issued round-robin on this many HIP "
+                         "streams as the three overlap-friendly launches of PSH_FLAG_OVERLAP (sample + level, barrier-free "
+                         "scan, ranking), so one step's latency-bound launches run beside another step's scan; 1 = one "
+                         "stream, the fused single launch")
     ap.add_argument("--sweep", type=str, default=None,
                     help="comma-separated GPU counts: run each in turn, print one JSON line per N (stdout) and the "
                          "weak-scaling efficiency against the first (stderr)")
@@ -209,6 +214,11 @@ def main():
     R, T, W, h, k, B = args.rows_per_gpu, args.T, args.W, args.horizon, args.k, args.queries
     Tp = T - W - h + 1
     flags = (_native.FLAG_FILTER_VALU if args.filter == "valu" else 0) | (_native.FLAG_NO_FUSE if args.no_fuse else 0)
+    # independent single queries on several streams: the overlap-friendly launches (the library falls back to the fused /
+    # separate launches by itself where they do not apply)
+    n_streams = args.streams if (B == 1 and not args.no_fuse and args.filter != "valu" and args.streams > 1) else 1
+    if n_streams > 1:
+        flags |= _native.FLAG_OVERLAP
     # per-rank block of the ensemble: block g is dataset(R, T, seed=g); rank 0's block at
     # the default sizes is exactly the dataset of tests/golden/cfg2_R32768.npz
     ds_host = syn.dataset(R, T, seed=rank)
@@ -216,11 +226,14 @@ def main():
     ds = torch.from_numpy(ds_host).to(dev)                    # resident in HBM before any timing
     q = torch.from_numpy(np.ascontiguousarray(q_host)).to(dev)
     ws = _native.Workspace(dev)
+    # one workspace per stream (its header carries per-call state), results of a stream's steps in its own buffers
+    streams = [torch.cuda.Stream(dev) for _ in range(n_streams)] if n_streams > 1 else [None]
+    wss = [ws] + [_native.Workspace(dev) for _ in range(n_streams - 1)]
 
     sharded = None
     if use_pg:
         sharded = ShardedPathShadowing(sa.Identity(W), sa.RelativeMSE(), ds, rank * R, sa.PredictionContext(h), device=dev,
-                                       always_exchange=args.force_sharded)
+                                       always_exchange=args.force_sharded, streams=n_streams)
 
     # HIP events around the dominant kernel on every EV_EVERY-th timed step: an event record is a barrier packet of its own
     # on the stream (~5 us for the pair, measured: 112 vs 101 us per step with a pair on every step), so bracketing every
@@ -232,6 +245,12 @@ def main():
     torch.cuda.synchronize()
 
     statuses = []
+    step_flags = [flags]
+    cfg = {"n_streams": n_streams, "count": 0}
+    outs = [(torch.empty((B, k), dtype=torch.float32, device=dev), torch.empty((B, k, 2), dtype=torch.int32, device=dev))
+            for _ in range(n_streams)]
+    status_ring = list(torch.zeros((args.steps + args.warmup + 8, B), dtype=torch.int32, device=dev).unbind(0))
+    torch.cuda.synchronize()
 
     pending = []       # sharded path: the step whose all-gather is still in flight
 
@@ -246,7 +265,17 @@ def main():
             pending.append(nxt)
             return out
         ev = ev_pairs[i // EV_EVERY] if (i is not None and i % EV_EVERY == 0) else None
-        d, idx, st = _native.scan_topk(ds[:, 0, :], q, k, h=h, workspace=ws, scan_events=ev, flags=flags)
+        c = cfg["count"]
+        cfg["count"] = c + 1
+        si = c % cfg["n_streams"]
+        # results go to this stream's own buffers (a later step on the same stream overwrites them, in stream order); the
+        # status words of ALL steps are kept: every one of them is looked at after the timed region
+        out = (outs[si][0], outs[si][1], status_ring[c % len(status_ring)])
+        if streams[si] is None or cfg["n_streams"] == 1:
+            d, idx, st = _native.scan_topk(ds[:, 0, :], q, k, h=h, workspace=wss[0], scan_events=ev, flags=step_flags[0], out=out)
+        else:
+            with torch.cuda.stream(streams[si]):
+                d, idx, st = _native.scan_topk(ds[:, 0, :], q, k, h=h, workspace=wss[si], scan_events=ev, flags=step_flags[0], out=out)
         statuses.append(st)
         return d, idx
 
@@ -258,6 +287,7 @@ def main():
     first = step()
     d0, i0 = first if sharded is None else drain()
     torch.cuda.synchronize()
+    d0, i0 = d0.clone(), i0.clone()
     if statuses and int(statuses[-1].max().item()) != 0:
         raise SystemExit("candidate buffer overflow on the benchmark workload (unexpected)")
     if (world == 1 and not args.no_parity and (R, T, W, h, k, B) == (32768, 4096, 20, 20, 1024, 1)
@@ -283,6 +313,7 @@ def main():
             raise SystemExit(f"PARITY FAILURE against the oracle on queries {sel}")
 
     def timed_region():
+        cfg["count"] = 0
         for _ in range(args.warmup):
             step()
         drain()
@@ -311,15 +342,29 @@ def main():
     elapsed, host_enqueue, bad = timed_region()
     fused_retry = False
     if bad == 2 and not args.no_fuse:
-        # a fused launch gave up somewhere (PSH_STATUS_RETRY: its results are invalid): the whole timed region is run
-        # again through the separate launches, on every rank, and THAT is what is reported
+        # a fused launch / an overlap step gave up somewhere (PSH_STATUS_RETRY: its results are invalid): the whole timed
+        # region is run again through the separate launches, on every rank, and THAT is what is reported
         fused_retry = True
-        flags |= _native.FLAG_NO_FUSE
+        flags = (flags & ~_native.FLAG_OVERLAP) | _native.FLAG_NO_FUSE
+        step_flags[0] = flags
         if sharded is not None:
             sharded.fuse = False
         elapsed, host_enqueue, bad = timed_region()
     if bad != 0:
         raise SystemExit("candidate buffer overflow during the timed steps (unexpected)")
+    # the bracketed launches of THE timed region (the comparison region below records over the same events)
+    scan_ms = [a.elapsed_time(b) for a, b in ev_pairs] if sharded is None else []
+    end_gaps_ms = [ev_pairs[j][1].elapsed_time(ev_pairs[j + 1][1]) / EV_EVERY for j in range(len(ev_pairs) - 1)] if sharded is None else []
+    overlap_mode = bool(flags & _native.FLAG_OVERLAP)
+    single_stream = None
+    if overlap_mode and sharded is None:
+        # beside the headline: the same K steps on ONE stream as the fused single launch (what an isolated caller gets)
+        keep = (step_flags[0], cfg["n_streams"])
+        step_flags[0], cfg["n_streams"] = flags & ~_native.FLAG_OVERLAP, 1
+        el1, _, bad1 = timed_region()
+        step_flags[0], cfg["n_streams"] = keep
+        single_stream = {"ms_per_step": round(1e3 * el1 / args.steps, 5), "value": round(world * R * Tp * B * args.steps / el1, 1),
+                         "unit": "windows/s", "launches": "psh::scan_fused_kernel, one stream" if bad1 == 0 else "fused launch gave up (status %d)" % bad1}
 
     windows_per_step = world * R * Tp * B
     value = windows_per_step * args.steps / elapsed
@@ -339,7 +384,11 @@ def main():
     torch.cuda.synchronize()
     one_ms = one[0].elapsed_time(one[1])
     fused = info.get("path") == 2
-    kernel_name = ("psh::scan_fused_kernel<%s,true> (the WHOLE step in one launch: bootstrap, threshold, f16 matrix-core "
+    overlap_mode = info.get("path") == 3
+    kernel_name = ("psh::stream_scan_kernel<%s,true> (the scan of the three overlap-friendly launches: f16 matrix-core rejection "
+                   "test + exact fp32 recheck over the whole ensemble, no barrier; psh::stream_sample_kernel before it and "
+                   "psh::stream_rank_kernel behind it run beside the scans of the other streams)" % wt if overlap_mode else
+                   "psh::scan_fused_kernel<%s,true> (the WHOLE step in one launch: bootstrap, threshold, f16 matrix-core "
                    "rejection test + exact fp32 recheck over the ensemble, distributed selection)" % wt if fused else
                    ("psh::scan_mx_kernel<%s,true>" if B == 1 else "psh::scan_mq_kernel<%s,true>") % wt
                    + " (full scan: f16 matrix-core rejection test + exact fp32 recheck)" if mx
@@ -347,9 +396,13 @@ def main():
     alg_bytes = R * T * 4 + B * W * 4 + B * k * 12          # one read of the ensemble + query + result
     roofline = None
     if sharded is None:
-        scan_ms = [a.elapsed_time(b) for a, b in ev_pairs]
         avg_ms = float(np.mean(scan_ms))
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        # Launches of different streams are CO-RESIDENT in overlap mode (the blocks of scan i+1 take over a compute unit
+        # when scan i's block leaves it): a launch's begin-to-end duration then spans two scans sharing the chip, and the
+        # sum of the durations exceeds the wall time.  What a launch costs is the interval between the ENDS of consecutive
+        # scan launches, from the same HIP events; with one stream the two figures coincide up to the launch gap.
+        interval_ms = float(np.mean(end_gaps_ms)) if (overlap_mode and end_gaps_ms) else None
+        achieved = alg_bytes / ((interval_ms if interval_ms else avg_ms) * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, the guide's gfx950 correction): they
         # cannot be collected inside this run (PMC passes are their own rocprofv3 runs, tools/profile_round.sh), so the
         # figure is READ from the committed summary of those passes and labelled as such
@@ -359,7 +412,8 @@ def main():
         if tfile.exists():
             try:
                 tj = json.loads(tfile.read_text())
-                if tj.get("workload") == f"R={R},T={T},W={W},h={h},k={k},B={B}" and ("scan_fused" in tj.get("kernel", "")) == fused:
+                if (tj.get("workload") == f"R={R},T={T},W={W},h={h},k={k},B={B}" and ("scan_fused" in tj.get("kernel", "")) == fused
+                        and ("stream_scan" in tj.get("kernel", "")) == overlap_mode):
                     traffic = tj.get("hbm_bytes_per_launch")
                     traffic_source = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)"
             except Exception:   # noqa: BLE001
@@ -370,6 +424,11 @@ def main():
                     "avg_launch_ms": round(avg_ms, 5), "min_launch_ms": round(float(np.min(scan_ms)), 5),
                     "launches_timed": len(scan_ms), "launches_timed_every": EV_EVERY,
                     "frac_of_measured_copy_rate": round(achieved / HBM_COPY_GBPS, 4)}
+        if interval_ms:
+            roofline["avg_launch_interval_ms"] = round(interval_ms, 5)
+            roofline["note"] = ("overlap mode: `achieved` = algorithmic bytes / avg_launch_interval_ms (end-to-end interval of consecutive "
+                                "scan launches, HIP events on the launches' own streams); avg_launch_ms is a launch's begin-to-end "
+                                "duration WHILE it shares the chip with the neighbouring scan (profiles/: the kernel trace gives both)")
     else:
         achieved = alg_bytes / (one_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
@@ -404,10 +463,14 @@ def main():
                        "sharding": "rows (R) across ranks, local top-k + one all-gather + merge; consecutive steps "
                                    "(independent queries) pipelined: the all-gather of step i overlaps the scan of step i+1"
                                    if use_pg else "none",
-                       "inputs_resident_in_hbm": True},
+                       "inputs_resident_in_hbm": True,
+                       "issue": (f"consecutive steps are independent queries issued round-robin on {n_streams} HIP streams "
+                                 "(PSH_FLAG_OVERLAP: sample + level, barrier-free scan, ranking per step)") if n_streams > 1 else "one stream"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "achieved_hbm_GBps_whole_step": round(world * alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+            "streams": n_streams,
+            "single_stream_fused": single_stream,
             "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 5),
             "stages_ms_separate_launches": stages,
             "parity_vs_reference_golden": parity,

@@ -235,15 +235,21 @@ def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, 
         return tuple(torch.cat([p[j] for p in parts], dim=0) for j in range(3))
     nbytes = int(workspace_bytes(R, T, B, W, h, k) * extra_workspace_factor)
     ws = (workspace or Workspace(dev)).get(nbytes)
+    status = None
     if out is not None:       # caller-provided (B,k) f32 / (B,k,2) i32 contiguous device tensors (e.g. views of a send buffer)
         out_d = _dev_tensor(out[0], torch.float32, "out[0]")
         out_idx = _dev_tensor(out[1], torch.int32, "out[1]")
         if tuple(out_d.shape) != (B, k) or tuple(out_idx.shape) != (B, k, 2):
             raise ValueError("out must be ((B,k) float32, (B,k,2) int32)")
+        if len(out) > 2:      # ... and optionally the (B,) int32 status words (no allocation at all in the call then)
+            status = _dev_tensor(out[2], torch.int32, "out[2]")
+            if tuple(status.shape) != (B,):
+                raise ValueError("out[2] must be (B,) int32")
     else:
         out_d = torch.empty((B, k), dtype=torch.float32, device=dev)
         out_idx = torch.empty((B, k, 2), dtype=torch.int32, device=dev)
-    status = torch.empty((B,), dtype=torch.int32, device=dev)
+    if status is None:
+        status = torch.empty((B,), dtype=torch.int32, device=dev)
     prof = None
     if profile:
         prof = PshProfile()

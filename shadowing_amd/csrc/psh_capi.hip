@@ -210,16 +210,19 @@ struct Plan { int grid; int n_qgroups; int q_per_group; int tile_floats; int wid
 // Launch-geometry overrides and device-side time stamps for the scripts under tools/: compiled into the
 // tuning build only (-DPSH_TUNING, `python -m shadowing_amd._build --tuning`).  The product library reads no
 // environment variable and takes no pointer from anywhere but its arguments.
-struct Tuning { int wide_min; bool narrow; int bpc; int rows_frac; unsigned long long* dbg_times; unsigned long long* dbg_select; int xcd_skew; int stream_threads; };
+struct Tuning { int wide_min; bool narrow; int bpc; int rows_frac; unsigned long long* dbg_times; unsigned long long* dbg_select; int xcd_skew; int stream_pgrid_per_cu; int stream_skip; int stream_units; int stream_rgrid_per_cu; };
 inline Tuning tuning() {
-    Tuning t{PSH_EMB_WIDE_MIN_B, false, 0, 64, nullptr, nullptr, PSH_FUSED_XCD_SKEW, PSH_SCAN_THREADS};
+    Tuning t{PSH_EMB_WIDE_MIN_B, false, 0, 64, nullptr, nullptr, PSH_FUSED_XCD_SKEW, 2, 0, 2048, 2};
 #ifdef PSH_TUNING
     if (const char* e = getenv("PSH_EMBED_WIDE_MIN_B")) { const int v = atoi(e); if (v >= 1) t.wide_min = v; }
     t.narrow = getenv("PSH_EMBED_NARROW") != nullptr;
     if (const char* e = getenv("PSH_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) t.bpc = v; }
     if (const char* e = getenv("PSH_ROWS_FRAC")) { const int v = atoi(e); if (v >= 2) t.rows_frac = v; }
     if (const char* e = getenv("PSH_XCD_SKEW")) { const int v = atoi(e); if (v >= -64 && v <= 64) t.xcd_skew = v; }
-    if (const char* e = getenv("PSH_STREAM_THREADS")) { const int v = atoi(e); if (v == 512 || v == 1024) t.stream_threads = v; }
+    if (const char* e = getenv("PSH_STREAM_PGRID")) { const int v = atoi(e); if (v >= 1 && v <= 16) t.stream_pgrid_per_cu = v; }
+    if (const char* e = getenv("PSH_STREAM_SKIP")) t.stream_skip = atoi(e);      // bit 0: no sample launch, 1: no ranking, 2: no scan (timing ablations: results are stale)
+    if (const char* e = getenv("PSH_STREAM_RGRID")) { const int v = atoi(e); if (v >= 1 && v <= 8) t.stream_rgrid_per_cu = v; }
+    if (const char* e = getenv("PSH_STREAM_UNITS")) { const int v = atoi(e); if (v >= 256 && v <= PSH_FUSED_MAX_UNITS) t.stream_units = v; }
     if (const char* e = getenv("PSH_DBG_TIMES_PTR")) t.dbg_times = (unsigned long long*)strtoull(e, nullptr, 0);
     if (const char* e = getenv("PSH_DBG_SELECT_PTR")) t.dbg_select = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
@@ -674,19 +677,36 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
                     int ncu = 0;
                     HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
                     const Tuning tn = tuning();
-                    int64_t grid_p = 2 * (int64_t)ncu;
-                    if (grid_p > units_f) grid_p = units_f;
-                    const int threads_s = tn.stream_threads == 512 ? 512 : PSH_SCAN_THREADS;
-                    int64_t grid_s = (int64_t)ncu * (PSH_SCAN_THREADS / threads_s);
+                    // a thinner sample than the fused launch's: its 16 MB are HBM traffic beside ANOTHER step's scan here.
+                    // 2048 units; the level is the (2k x sampled fraction + 8)-th smallest minimum: the k best windows of the
+                    // ensemble put 2k/2 x fraction = 16 expected minima below their level, P(Poisson(16) >= 40) = 3e-7 that
+                    // fewer than k windows lie below the estimate (-> PSH_STATUS_RETRY)
+                    int64_t rows_p = tn.stream_units / nseg;
+                    if (rows_p > p.R / 4) rows_p = p.R / 4;
+                    if (rows_p < 1) rows_p = 1;
+                    const int64_t units_p = rows_p * nseg;
+                    int64_t r2p = (2 * (int64_t)k * rows_p + p.R - 1) / p.R + 8;
+                    if (r2p < 24) r2p = 24;
+                    int64_t grid_p = (int64_t)tn.stream_pgrid_per_cu * ncu;
+                    if (grid_p > units_p) grid_p = units_p;
+                    int64_t grid_s = ncu;
                     const int64_t n_rs = p.R * nseg;
-                    if (grid_s * (threads_s / 64) > n_rs) grid_s = (n_rs + (threads_s / 64) - 1) / (threads_s / 64);
-                    if (stream_scan_shmem_bytes(fa.tile_floats, threads_s) * (PSH_SCAN_THREADS / threads_s) <= PSH_LDS_BYTES) {
-                        HIP_TRY(launch_stream_sample(fa, fu, p.aligned, (int)grid_p, tile_floats_for(p.W), s));
+                    if (grid_s * (PSH_SCAN_THREADS / 64) > n_rs) grid_s = (n_rs + (PSH_SCAN_THREADS / 64) - 1) / (PSH_SCAN_THREADS / 64);
+                    int front = (int)(PSH_STREAM_CAND_CAP / grid_s);
+                    if (front > PSH_FUSED_FRONT) front = PSH_FUSED_FRONT;
+                    if (stream_scan_shmem_bytes(fa.tile_floats) <= PSH_LDS_BYTES &&
+                        units_p >= 256 && r2p <= units_p / 2 && 5 * (int64_t)k <= grid_s * front) {
+                        fu.boot_units = (int)units_p;
+                        fu.boot_row_stride = p.R / rows_p;
+                        fu.boot_row0 = fu.boot_row_stride / 2;
+                        fu.rank = (int)r2p;
+                        fu.front = front;
+                        if (!(tn.stream_skip & 1)) HIP_TRY(launch_stream_sample(fa, fu, p.aligned, (int)grid_p, tile_floats_for(p.W), s));
                         if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_begin, s));
-                        HIP_TRY(launch_stream_scan(fa, fu, p.aligned, (int)grid_s, threads_s, s));
+                        if (!(tn.stream_skip & 4)) HIP_TRY(launch_stream_scan(fa, fu, p.aligned, (int)grid_s, s));
                         if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_end, s));
-                        HIP_TRY(launch_stream_rank(fa, fu, ncu, s));
-                        if (profile) { profile->path = 3; profile->n_sample_rows = (int)rows_f; profile->grid_blocks = (int)grid_s; }
+                        if (!(tn.stream_skip & 2)) HIP_TRY(launch_stream_rank(fa, fu, tn.stream_rgrid_per_cu * ncu, s));   // ~2.5k candidates: <= 8 own ones per wave, ONE pass over all of them
+                        if (profile) { profile->path = 3; profile->n_sample_rows = (int)rows_p; profile->grid_blocks = (int)grid_s; }
                         return PSH_OK;
                     }
                 }

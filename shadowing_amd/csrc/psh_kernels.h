@@ -70,6 +70,9 @@ struct FusedHdr {
     unsigned long long aflag[PSH_FUSED_MAX_BLOCKS];          // bootstrap: tag << 32 | 1 once the block's minima are written
     unsigned minima[PSH_FUSED_MAX_UNITS];                    // bootstrap: float bits of a (row, segment) minimum
     unsigned long long cand[PSH_FUSED_MAX_BLOCKS * PSH_FUSED_FRONT * 2];   // {r << 32 | d bits, t}
+    // psh_stream.hip: the B fragments of the shifted query the sample kernel prepares for the scan (whose candidates go to
+    // `cand` as ONE compact list of {d bits, r, t, -} entries, StreamCtl::ncand of them)
+    unsigned short bxtab[4 * 64 * 8];                        // [K-step][lane][8 halves]: -2 x~ shifted by the lane's column
 };
 #define PSH_FUSED_BYTES ((sizeof(psh::FusedHdr) + 255) / 256 * 256)
 
@@ -86,6 +89,7 @@ struct FusedArgs {
     long long spin_ticks;            // give-up time of a poll in wall-clock ticks (100 MHz)
     int xcd_skew;                    // of the units of a pair of blocks (2j, 2j + 1) the even one takes (256 + xcd_skew) / 512
     int tbits;                       // ranking: (r, t) packs into 32 bits as r << tbits | t (-1: it does not -- the three-word compare)
+    int front;                       // stream scan: candidates a block may hold (<= PSH_FUSED_FRONT; PSH_STREAM_CAND_CAP / blocks)
 };
 
 struct PrepArgs {
@@ -276,9 +280,9 @@ size_t scan_fused_shmem_bytes(int tile_floats);
 hipError_t launch_scan_fused(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, hipStream_t s);
 hipError_t launch_fused_init(FusedHdr* hdr, hipStream_t s);
 // psh_stream.hip: the same step as three launches that can share the chip with another stream's (PSH_FLAG_OVERLAP)
-size_t stream_scan_shmem_bytes(int tile_floats, int threads);
+size_t stream_scan_shmem_bytes(int tile_floats);
 hipError_t launch_stream_sample(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, int sample_tile_floats, hipStream_t s);
-hipError_t launch_stream_scan(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, int threads, hipStream_t s);
+hipError_t launch_stream_scan(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, hipStream_t s);
 hipError_t launch_stream_rank(const ScanArgs& a, const FusedArgs& f, int grid, hipStream_t s);
 hipError_t launch_embed_rows(const float* dataset, int64_t R, int64_t T, const float* ker, int d, int K, float* out, hipStream_t s);
 

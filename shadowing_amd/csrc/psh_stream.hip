@@ -78,6 +78,10 @@ template <int WT, bool ALIGNED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void stream_sample_kernel(ScanArgs a, FusedArgs f) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    // This wave shares its SIMD with four scan waves of another step, all OLDER than it: the arbiter serves the oldest
+    // first, and at the default priority a sample / ranking launch took 70 us beside a scan (10-35 us alone) -- long enough
+    // to gate the next scan of its own stream.  Its work is a few per cent of a scan's: it goes first.
+    __builtin_amdgcn_s_setprio(3);
     float* tile = smem;                                      // one wave, one tile; the last block's histogram lives here too
     const int lane = lane_id();
     FusedHdr* hdr = f.hdr;
@@ -220,12 +224,32 @@ void stream_sample_kernel(ScanArgs a, FusedArgs f) {
         const u64 who = __ballot(mine);
         edge = (unsigned)__builtin_amdgcn_readlane((int)my_edge, who ? (int)__builtin_ctzll(who) : 0);
     }
+    unsigned sbits = 0u;
     if (lane == 0) {
         if (armed) armed = stream_derive(x, W, __uint_as_float(edge), f.qnorm_in, ctl);
         ctl->armed = armed ? 1u : 0u;
         ctl->ncand = 0u;
         ctl->ovf = 0u;
         ctl->ticket = 0u;                                                 // the next launch on this workspace counts from zero
+        sbits = armed ? ctl->scale_bits : 0u;
+    }
+    // the scan's B fragments of the shifted query (column n of K-step s holds -2 x~[16 s + 8 hk + i - n]): prepared ONCE
+    // here, a 4 KB table every scan block fetches with four 16-byte loads per lane instead of 32 scattered ones
+    const float scale = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)sbits));
+    {
+        const int n = lane & 31, hk = lane >> 5;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f16x8 b;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int j = 16 * s + 8 * hk + i - n;
+                const bool in = j >= 0 && j < W;
+                const float xv = x[in ? j : 0];
+                b[i] = (_Float16)(in ? -2.0f * (xv * scale) : 0.0f);
+            }
+            *reinterpret_cast<f16x8*>(hdr->bxtab + (size_t)(s * 64 + lane) * 8) = b;
+        }
     }
 }
 
@@ -235,11 +259,12 @@ void stream_sample_kernel(ScanArgs a, FusedArgs f) {
 #define PSH_STREAM_FIXED_BYTES 1280   // control words + the block's front list
 enum { S_FRONT = 0, S_NEXT = 1 };
 
-template <int WT, bool ALIGNED, int THREADS>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(56))) void stream_scan_kernel(ScanArgs a, FusedArgs f) {
+template <int WT, bool ALIGNED>
+__global__ __launch_bounds__(PSH_SCAN_THREADS) __attribute__((amdgpu_num_vgpr(56)))   // (56 arch + 56 acc = 112 of the unified file)
+void stream_scan_kernel(ScanArgs a, FusedArgs f) {
     static_assert(WT >= 0 && WT <= 33, "the shifted-query band must fit K = 64 (WT = 0: run-time W <= 33)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NW = THREADS / 64;
+    constexpr int NW = PSH_SCAN_THREADS / 64;
     const int lane = lane_id();
     const int tid = (int)threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -275,35 +300,34 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(56))) void 
     Stage st;
     unsigned u = u_lo + (unsigned)wave;
     if (u < u_hi) load_unit(st, u);
-
-    if (tid == 0) { ctl[S_FRONT] = 0; ctl[S_NEXT] = NW; }
-    // what the sample kernel left (an earlier launch on this stream: plain loads)
-    const bool armed = sc->armed != 0u;
+    // what the sample kernel left (an earlier launch on this stream: plain loads): the shifted-query fragments ...
+    f16x8 bx[4], bo[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bx[s] = *reinterpret_cast<const f16x8*>(hdr->bxtab + (size_t)(s * 64 + lane) * 8);
+    // ... and the admission level (scalar loads; first needed inside the loop, so the set-up below runs under their latency)
+    const unsigned armed_w = sc->armed;
     const float tau2 = __uint_as_float(sc->tau2_bits);
     const float thr2 = __uint_as_float(sc->thr2_bits);
     const float scale = __uint_as_float(sc->scale_bits);
     const float xn = __uint_as_float(sc->xn_bits);
-    if (!armed) return;                                                       // uniform: the ranking reports PSH_STATUS_RETRY
+    if (tid == 0) { ctl[S_FRONT] = 0; ctl[S_NEXT] = NW; }
     {   // every slot of the f16 arrays a segment does not write must be finite (0 * NaN poisons a row)
         unsigned* z = reinterpret_cast<unsigned*>(a1);
         for (int i = lane; i < PSH_MX_NHALF; i += 64) z[i] = 0u;              // 2 arrays x NHALF halves = NHALF dwords
     }
-    f16x8 bx[4], bo[4];
-    {
+    {   // the band of ones (window energies): arithmetic only
         const int n = lane & 31, hk = lane >> 5;
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int j = 16 * s + 8 * hk + i - n;
-                const bool in = j >= 0 && j < W;
-                const float xv = x[in ? j : 0];
-                bx[s][i] = (_Float16)(in ? -2.0f * (xv * scale) : 0.0f);
-                bo[s][i] = (_Float16)(in ? 1.0f : 0.0f);
+                bo[s][i] = (_Float16)((j >= 0 && j < W) ? 1.0f : 0.0f);
             }
     }
     __syncthreads();
     stamp(1);
+    if (armed_w == 0u) return;                                                // uniform: the ranking reports PSH_STATUS_RETRY
     auto grab = [&]() -> unsigned {
         int v = 0;
         if (lane == 0) v = atomicAdd(&ctl[S_NEXT], 1);
@@ -317,6 +341,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(56))) void 
         const int r_global = (int)(row + a.r_offset);
 
         stage_store(st, tile, nfloat, lane);
+        if (a.dbg_times && tid == 0 && u == u_lo) a.dbg_times[(size_t)blockIdx.x * 8 + 4] = (unsigned long long)wall_clock64();   // first data in the tile
         {
             const int nq = (nfloat + 3) >> 2;
 #pragma unroll
@@ -369,7 +394,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(56))) void 
                 base = __builtin_amdgcn_readfirstlane(base);
                 if (hit) {
                     const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                    if (slot < PSH_FUSED_FRONT) fl[slot] = u32x4{__float_as_uint(v), (unsigned)r_global, (unsigned)(seg_start + p), 0u};
+                    if (slot < f.front) fl[slot] = u32x4{__float_as_uint(v), (unsigned)r_global, (unsigned)(seg_start + p), 0u};
                 }
             }
         }
@@ -378,10 +403,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(56))) void 
     }
     stamp(2);
     __syncthreads();
-    // the block's candidates go to ONE compact list: a device-scope atomicAdd per block (not per candidate)
+    // the block's candidates (distances in place of acc) go to ONE compact list behind ONE device-scope atomicAdd per block
+    // (0.3 us of a block's 75; a list per block made the ranking search for every candidate's slot: 60 us instead of 9)
     if (wave == 0) {
         const int nfront = ctl[S_FRONT];
-        const int mown = nfront < PSH_FUSED_FRONT ? nfront : PSH_FUSED_FRONT;
+        const int mown = nfront < f.front ? nfront : f.front;
         unsigned base = 0u;
         if (lane == 0 && mown > 0) base = __hip_atomic_fetch_add((gu32*)&hdr->stream.ncand, (unsigned)mown, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
@@ -390,7 +416,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(56))) void 
             e[0] = __float_as_uint(dist_from_acc(__uint_as_float(e[0]), xn));
             reinterpret_cast<u32x4*>(hdr->cand)[base + (unsigned)lane] = e;
         }
-        if (lane == 0 && nfront > PSH_FUSED_FRONT) __hip_atomic_store((gu32*)&hdr->stream.ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0 && nfront > f.front) __hip_atomic_store((gu32*)&hdr->stream.ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     stamp(3);
 }
@@ -401,6 +427,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_vgpr(56))) void 
 template <bool PACKED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void stream_rank_kernel(ScanArgs a, FusedArgs f) {
+    __builtin_amdgcn_s_setprio(3);                           // (see stream_sample_kernel)
     const int lane = lane_id();
     FusedHdr* hdr = f.hdr;
     const StreamCtl* sc = &hdr->stream;
@@ -479,9 +506,9 @@ void stream_rank_kernel(ScanArgs a, FusedArgs f) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-size_t stream_scan_shmem_bytes(int tile_floats, int threads) {
-    return (size_t)PSH_STREAM_FIXED_BYTES + (size_t)tile_floats * (threads / 64) * sizeof(float)
-           + (size_t)(threads / 64) * 2 * PSH_MX_NHALF * sizeof(_Float16);
+size_t stream_scan_shmem_bytes(int tile_floats) {
+    return (size_t)PSH_STREAM_FIXED_BYTES + (size_t)tile_floats * (PSH_SCAN_THREADS / 64) * sizeof(float)
+           + (size_t)(PSH_SCAN_THREADS / 64) * 2 * PSH_MX_NHALF * sizeof(_Float16);
 }
 size_t stream_sample_shmem_bytes(int tile_floats) {
     const size_t t = (size_t)tile_floats * sizeof(float), h = (size_t)PSH_STREAM_HIST * sizeof(unsigned);
@@ -509,17 +536,13 @@ hipError_t launch_stream_sample(const ScanArgs& a, const FusedArgs& f, bool alig
                    : launch_k(stream_sample_kernel<0, false>, grid, 64, shmem, s, b, f);
 }
 
-template <int THREADS>
-static hipError_t launch_stream_scan_t(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, hipStream_t s) {
-    const size_t shmem = stream_scan_shmem_bytes(a.tile_floats, THREADS);
+hipError_t launch_stream_scan(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, hipStream_t s) {
+    const size_t shmem = stream_scan_shmem_bytes(a.tile_floats);
     if (a.W == 20)
-        return aligned ? launch_k(stream_scan_kernel<20, true, THREADS>, grid, THREADS, shmem, s, a, f)
-                       : launch_k(stream_scan_kernel<20, false, THREADS>, grid, THREADS, shmem, s, a, f);
-    return aligned ? launch_k(stream_scan_kernel<0, true, THREADS>, grid, THREADS, shmem, s, a, f)
-                   : launch_k(stream_scan_kernel<0, false, THREADS>, grid, THREADS, shmem, s, a, f);
-}
-hipError_t launch_stream_scan(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, int threads, hipStream_t s) {
-    return threads == 512 ? launch_stream_scan_t<512>(a, f, aligned, grid, s) : launch_stream_scan_t<PSH_SCAN_THREADS>(a, f, aligned, grid, s);
+        return aligned ? launch_k(stream_scan_kernel<20, true>, grid, PSH_SCAN_THREADS, shmem, s, a, f)
+                       : launch_k(stream_scan_kernel<20, false>, grid, PSH_SCAN_THREADS, shmem, s, a, f);
+    return aligned ? launch_k(stream_scan_kernel<0, true>, grid, PSH_SCAN_THREADS, shmem, s, a, f)
+                   : launch_k(stream_scan_kernel<0, false>, grid, PSH_SCAN_THREADS, shmem, s, a, f);
 }
 
 hipError_t launch_stream_rank(const ScanArgs& a, const FusedArgs& f, int grid, hipStream_t s) {

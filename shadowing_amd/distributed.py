@@ -82,7 +82,17 @@ class ShardedPathShadowing:
     def __init__(self, embedding: Identity, distance: RelativeMSE, local_dataset, row_offset: int,
                  context: PredictionContext | None = None, group=None, device: torch.device | None = None,
                  local_topk: Callable | None = None, merge: Callable | None = None, always_exchange: bool = False,
-                 exchange: str = "auto"):
+                 exchange: str = "auto", emulate_world: tuple | None = None, streams: int = 1):
+        """`emulate_world = (G, n_windows_global, fill)`: this ONE process stands for rank 0 of a G-rank world whose
+        collective is replaced by `fill(gathered, q, k)` -- it writes the lists of ranks 1..G-1 into rows 1..G-1 of the
+        receive buffer (G, 3*B*k int32: (B,k) distance bits, then (B,k,2) indices), exactly where the all-gather would have
+        left them.  Everything else (local scan into the send buffer, merge of the G lists) is the production code: how a
+        full configs[3] (8 x 32768 rows) is exercised on one GPU.
+
+        `streams` > 1 (HIP device): consecutive scan_begin() calls -- independent query batches -- issue their local scan
+        round-robin on that many private streams, single queries as the overlap-friendly launches (PSH_FLAG_OVERLAP): the
+        sample and the ranking of one step, and the exchange of another, run beside a third step's scan, and nothing in a
+        scan waits for co-residency (no reserved compute units, no polling next to the collective's workgroups)."""
         if type(distance) is not RelativeMSE:
             raise TypeError("the sharded scan implements RelativeMSE only")
         if type(embedding) is Identity:
@@ -108,6 +118,9 @@ class ShardedPathShadowing:
             raise ValueError('exchange must be "auto", "library" or "torch"')
         self.exchange = exchange
         self.fuse = True            # False: the local scan as separate launches (PSH_FLAG_NO_FUSE)
+        self._emulate = emulate_world
+        if emulate_world is not None:
+            self.always_exchange, self.exchange = True, "torch"
         self._comm = None
         self._side = None
         self._events = None
@@ -139,13 +152,22 @@ class ShardedPathShadowing:
             self._workspace = None
         self.dataset = ds.contiguous()
         self.device = self.dataset.device
+        self._scan_streams = None
+        if streams > 1 and local_topk is None and self.device.type == "cuda":
+            self._scan_streams = [torch.cuda.Stream(self.device) for _ in range(int(streams))]
+            self._scan_ws = [_native.Workspace(self.device) for _ in range(int(streams))]
+        self._step = 0
 
     @property
     def world_size(self) -> int:
+        if self._emulate is not None:
+            return int(self._emulate[0])
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
     def n_windows_global(self) -> int:
         """Admissible windows of the whole (sharded) ensemble: one all-reduce, once."""
+        if self._n_global is None and self._emulate is not None:
+            self._n_global = int(self._emulate[1])
         if self._n_global is None:
             h = self.context.get_out_times()
             R_local, _, T = self.dataset.shape
@@ -191,7 +213,8 @@ class ShardedPathShadowing:
             _close_comm(self._comm, self.device)
             self._comm = None
 
-    def local_scan(self, q: torch.Tensor, k: int, out=None, check: bool = True, unsorted: bool = False, flags: int = 0):
+    def local_scan(self, q: torch.Tensor, k: int, out=None, check: bool = True, unsorted: bool = False, flags: int = 0,
+                   workspace=None):
         """This rank's candidates: (d (B,k), idx (B,k,2), status) with global row numbers,
         padded with (+inf, -1) when the shard holds fewer than k windows."""
         h = self.context.get_out_times()
@@ -211,7 +234,7 @@ class ShardedPathShadowing:
             d, idx = self._local_topk(self.dataset[:, 0, :], q, k_local, h, self.row_offset)
             status = None
         else:
-            d, idx, status = _native_local_topk(self.dataset[:, 0, :], q, k_local, h, self.row_offset, self._workspace,
+            d, idx, status = _native_local_topk(self.dataset[:, 0, :], q, k_local, h, self.row_offset, workspace or self._workspace,
                                                 out=out if k_local == k else None, check=check, ker=self._ker,
                                                 unsorted=unsorted, flags=flags)
         if k_local < k:
@@ -232,6 +255,18 @@ class ShardedPathShadowing:
         return self.scan_begin(queries, k, check=check).finish()
 
     def scan_begin(self, queries: torch.Tensor, k: int, check: bool = True) -> "PendingScan":
+        if self._scan_streams is None:
+            return self._scan_begin(queries, k, check, None)
+        # this step's stream: it sees everything the caller's stream has enqueued so far (the queries), and the caller's
+        # stream sees the results through PendingScan.finish()
+        i = self._step % len(self._scan_streams)
+        self._step += 1
+        s = self._scan_streams[i]
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            return self._scan_begin(queries, k, check, self._scan_ws[i])
+
+    def _scan_begin(self, queries: torch.Tensor, k: int, check: bool, ws) -> "PendingScan":
         """First half of scan(): the local scan and the START of the all-gather (async_op).  `finish()` on
         the returned handle makes the compute stream wait for the collective and merges.  A stream of
         independent query batches (rolling query dates) is pipelined by beginning batch i+1 before finishing
@@ -261,9 +296,11 @@ class ShardedPathShadowing:
             sorted_merge = _native.merge_sorted_supported(G, k)
             library = exchange and self._use_library(B, k)
             comm = self._library_exchange() if library else None
+            # private scan streams: nothing in the scan needs co-residency, so no compute unit is reserved for the collective
+            mode = _native.FLAG_OVERLAP if ws is not None else (_native.FLAG_RESERVE_CUS if library else 0)
             d, idx, self.last_status = self.local_scan(q, k, out=out, check=check, unsorted=exchange and not sorted_merge,
-                                                       flags=(_native.FLAG_RESERVE_CUS if library else 0)
-                                                       | (0 if self.fuse else _native.FLAG_NO_FUSE) | getattr(self, "_emb_flags", 0))
+                                                       flags=(mode if self.fuse else _native.FLAG_NO_FUSE) | getattr(self, "_emb_flags", 0),
+                                                       workspace=ws)
             if d.data_ptr() != out[0].data_ptr():     # shard smaller than k: padded copies were made
                 out[0].copy_(d)
                 out[1].copy_(idx)
@@ -285,9 +322,13 @@ class ShardedPathShadowing:
                 comm.exchange_merge(send, gathered, B, k, out_d, out_idx, merge_ws, self._side, ev_a, ev_b)
                 return PendingScan(self, None, (send, gathered, "library", ev_b, merge_ws), (out_d, out_idx), B, k)
             gathered = torch.empty((G, 3 * B * k), dtype=torch.int32, device=self.device)
+            if self._emulate is not None:
+                gathered[0].copy_(send)
+                self._emulate[2](gathered, q, k)
+                return PendingScan(self, _Done(), (send, gathered, "sorted" if sorted_merge else "general"), None, B, k)
             work = dist.all_gather_into_tensor(gathered.view(-1), send, group=self.group, async_op=True)
             return PendingScan(self, work, (send, gathered, "sorted" if sorted_merge else "general"), None, B, k)
-        d, idx, self.last_status = self.local_scan(q, k, check=check, flags=getattr(self, "_emb_flags", 0))
+        d, idx, self.last_status = self.local_scan(q, k, check=check, flags=getattr(self, "_emb_flags", 0), workspace=ws)
         if not exchange:
             return PendingScan(self, None, None, (d, idx), B, k)
         # generic form (CPU tests, odd B*k): pack (d, r, t) as 3 x int32, one all-gather
@@ -316,9 +357,15 @@ class ShardedPathShadowing:
             t = idx[..., 1].long()
             for b, i in zip(*torch.nonzero(mine, as_tuple=True)):
                 paths[b, i, 0] = self.dataset[r[b, i], 0, t[b, i]:t[b, i] + length]
-        if self.world_size > 1:
+        if self.world_size > 1 and self._emulate is None:
             dist.all_reduce(paths, op=dist.ReduceOp.SUM, group=self.group)
         return d.cpu().numpy(), paths.cpu().numpy(), idx.cpu().numpy()
+
+
+class _Done:
+    """The 'collective' of an emulated world: nothing to wait for."""
+    def wait(self):
+        return None
 
 
 class PendingScan:
@@ -326,15 +373,29 @@ class PendingScan:
 
     def __init__(self, owner: ShardedPathShadowing, work, buffers, local, B: int, k: int):
         self._owner, self._work, self._buffers, self._result, self._B, self._k = owner, work, buffers, local, B, k
+        # the private stream this step was begun on, if any (scan_begin runs under `with torch.cuda.stream(s)`)
+        cur = torch.cuda.current_stream(owner.device) if owner.device.type == "cuda" else None
+        self._stream = cur if (owner._scan_streams is not None and cur in owner._scan_streams) else None
 
     def finish(self):
         """(d (B,k), idx (B,k,2)) on the device, identical on all ranks.  Waits for the collective on the
         compute STREAM (no host synchronisation with the RCCL backend) and merges the gathered lists."""
+        cur = torch.cuda.current_stream(self._owner.device) if self._owner.device.type == "cuda" else None
         if self._buffers is not None and self._buffers[2] == "library":
             # the merged lists are written by the side stream: whoever consumes them on this stream waits for the event
-            torch.cuda.current_stream(self._owner.device).wait_event(self._buffers[3])
+            cur.wait_event(self._buffers[3])
             self._buffers = None
+            for t in self._result:
+                t.record_stream(cur)
             return self._result
+        if self._stream is not None:
+            # begun on one of the owner's private streams: what follows here (the wait for the collective, the merge, the
+            # consumer) is on the caller's stream, behind everything that private stream has enqueued for this step
+            cur.wait_stream(self._stream)
+            self._stream = None
+            if self._result is not None:
+                for t in self._result:
+                    t.record_stream(cur)
         if self._result is None:
             o, B, k = self._owner, self._B, self._k
             G = o.world_size

@@ -1,0 +1,197 @@
+"""The single-query step as THREE overlap-friendly launches (psh_stream.hip, PSH_FLAG_OVERLAP: sample + admission level in
+one-wave blocks, the barrier-free scan, the ranking) against the oracle and the reference's goldens -- alone, and the way
+it is meant to be used: independent queries in flight on several streams, every result checked.  Status protocol of
+include/psh.h: PSH_STATUS_RETRY -> the same call with PSH_FLAG_NO_FUSE."""
+import numpy as np
+import pytest
+import torch
+
+from _util import assert_exact, assert_matches_reference, load_golden
+from shadowing_amd import synthetic as syn
+from test_gpu_fused import FUSED_KINDS, _adversarial, checked_scan, fused_scan
+
+pytestmark = pytest.mark.gpu
+OVERLAP = 2048        # PSH_FLAG_OVERLAP
+
+
+@pytest.mark.parametrize("R,T,W,h,k", [
+    (4096, 4096, 20, 20, 1024),
+    (6000, 2048, 20, 11, 700),
+    (2048, 2048, 20, 0, 200),
+    (3000, 2051, 20, 20, 300),      # T % 4 != 0: unaligned rows, ragged last segment
+    (5000, 1100, 8, 7, 200),        # run-time window lengths
+    (5000, 1100, 17, 7, 200),
+    (5000, 1100, 33, 7, 200),
+    (40000, 1024, 20, 20, 3000),
+    (1200, 9000, 20, 20, 64),       # long rows: 9 segments per row
+    (300, 2048, 20, 20, 50),        # fewer units than the scan has waves
+])
+def test_overlap_launches_equal_oracle(hip_device, oracle_mod, R, T, W, h, k):
+    ds = syn.dataset(R, T, 5000 + R)
+    q = syn.gbm_log_returns((1, W), 5100 + W)
+    d, idx, status, info = fused_scan(hip_device, ds, q, k, h, flags=OVERLAP)
+    od, oidx = oracle_mod.scan_topk(ds, q, k, h=h)
+    if info["path"] != 3:                 # too small for the sampled path / the sample: the library's other paths serve it
+        assert status[0] == 0
+    else:
+        assert status[0] == 0, "ordinary data: the three launches serve the call themselves"
+    assert_exact(d, idx, od, oidx, f"overlap R={R} T={T} W={W} h={h} k={k}")
+
+
+def test_overlap_path_is_taken_at_configs1_size_and_matches_the_reference(hip_device):
+    g = load_golden("cfg2_R32768")
+    d, idx, status, info = fused_scan(hip_device, g["dataset"], g["queries"], g["k"], g["h"], flags=OVERLAP)
+    assert info["path"] == 3 and status[0] == 0
+    assert_matches_reference(d, idx, g, None, what="cfg2 overlap launches")
+    d2, idx2, st2, info2 = fused_scan(hip_device, g["dataset"], g["queries"], g["k"], g["h"])
+    assert info2["path"] == 2 and st2[0] == 0
+    assert_exact(d, idx, d2, idx2, "overlap launches vs the fused launch")
+
+
+@pytest.mark.parametrize("n_streams", [2, 3])
+def test_independent_queries_on_several_streams(hip_device, oracle_mod, n_streams):
+    """What the mode is for: 48 calls with five different queries in rotation, issued round-robin on 2 / 3 streams (one
+    workspace per stream, no synchronisation in between): launches of different steps share the chip.  Every result checked."""
+    from shadowing_amd import _native
+    ds = syn.dataset(16384, 2048, 5200)
+    ds_t = torch.as_tensor(ds[:, 0, :].copy()).to(hip_device)
+    qs = [syn.gbm_log_returns((1, 20), 5201 + i) for i in range(5)]
+    q_t = [torch.as_tensor(q).to(hip_device) for q in qs]
+    streams = [torch.cuda.Stream(hip_device) for _ in range(n_streams)]
+    wss = [_native.Workspace(hip_device) for _ in range(n_streams)]
+    torch.cuda.synchronize()
+    outs = []
+    for i in range(48):
+        with torch.cuda.stream(streams[i % n_streams]):
+            outs.append(_native.scan_topk(ds_t, q_t[i % 5], 512, h=20, workspace=wss[i % n_streams], flags=OVERLAP))
+    torch.cuda.synchronize()
+    want = [oracle_mod.scan_topk(ds, q, 512, h=20) for q in qs]
+    for i, (d, idx, st) in enumerate(outs):
+        assert int(st[0]) == 0, i
+        assert_exact(d.cpu().numpy(), idx.cpu().numpy(), *want[i % 5], f"step {i}")
+
+
+def test_overlap_steps_beside_a_fused_launch_and_a_batched_scan(hip_device, oracle_mod):
+    """Nothing in the overlap launches needs the chip to itself: a fused launch (which DOES) and a batched scan run on other
+    streams at the same time; the overlap steps stay exact, the fused launch either serves its call or says RETRY."""
+    from shadowing_amd import _native
+    ds = syn.dataset(16384, 2048, 5300)
+    ds_t = torch.as_tensor(ds[:, 0, :].copy()).to(hip_device)
+    q1 = syn.gbm_log_returns((1, 20), 5301)
+    qb = syn.rolling_queries(24, 20, 5302)
+    s = [torch.cuda.Stream(hip_device) for _ in range(3)]
+    ws = [_native.Workspace(hip_device) for _ in range(3)]
+    torch.cuda.synchronize()
+    got = []
+    for rep in range(6):
+        with torch.cuda.stream(s[0]):
+            got.append(("overlap", _native.scan_topk(ds_t, torch.as_tensor(q1).to(hip_device), 300, h=20, workspace=ws[0], flags=OVERLAP)))
+        with torch.cuda.stream(s[1]):
+            got.append(("fused", _native.scan_topk(ds_t, torch.as_tensor(q1).to(hip_device), 300, h=20, workspace=ws[1])))
+        with torch.cuda.stream(s[2]):
+            got.append(("batch", _native.scan_topk(ds_t, torch.as_tensor(qb).to(hip_device), 300, h=20, workspace=ws[2])))
+    torch.cuda.synchronize()
+    w1 = oracle_mod.scan_topk(ds, q1, 300, h=20)
+    wb = oracle_mod.scan_topk(ds, qb, 300, h=20)
+    for kind, (d, idx, st) in got:
+        st = st.cpu().numpy()
+        if kind == "fused" and st[0] == 2:
+            continue                                    # the fused launch was not co-resident: it says so (status protocol)
+        assert (st == 0).all(), kind
+        assert_exact(d.cpu().numpy(), idx.cpu().numpy(), *(wb if kind == "batch" else w1), kind)
+
+
+def test_unarmed_workspace_is_detected(hip_device, oracle_mod):
+    from shadowing_amd import _native
+    ds = syn.dataset(4096, 2048, 5400)
+    q = syn.gbm_log_returns((1, 20), 5401)
+
+    class Raw(_native.Workspace):
+        def arm(self):
+            self.buf.view(torch.int32).random_(0, 2 ** 31 - 1)          # garbage instead of psh_workspace_init
+
+    ws = Raw(hip_device)
+    d, idx, status, info = fused_scan(hip_device, ds, q, 300, 20, ws=ws, flags=OVERLAP)
+    assert info["path"] == 3 and status[0] == 2
+    _native.Workspace.arm(ws)
+    d, idx, status, info = fused_scan(hip_device, ds, q, 300, 20, ws=ws, flags=OVERLAP)
+    assert info["path"] == 3 and status[0] == 0
+    od, oidx = oracle_mod.scan_topk(ds, q, 300, h=20)
+    assert_exact(d, idx, od, oidx, "after psh_workspace_init")
+
+
+@pytest.mark.parametrize("kind", FUSED_KINDS)
+def test_overlap_launches_with_adversarial_data_through_the_status_protocol(hip_device, oracle_mod, kind):
+    """Whatever the magnitudes: either the three launches return the exact result, or they say PSH_STATUS_RETRY and the
+    separate launches (then, for ties en masse, the exhaustive path) do.  Never a silently wrong row."""
+    from shadowing_amd import _native
+    R, T, h, k = 12000, 2048, 11, 700
+    ds, q = _adversarial(kind, R, T, 4400 + FUSED_KINDS.index(kind))
+    d, idx, status, info = fused_scan(hip_device, ds, q, k, h, flags=OVERLAP)
+    assert info["path"] == 3 and status[0] in (0, 2)
+    od, oidx = oracle_mod.scan_topk(ds, q, k, h=h)
+    if status[0] == 0:
+        assert_exact(d, idx, od, oidx, kind + " (overlap launches)")
+    ds_t = torch.as_tensor(np.ascontiguousarray(ds if ds.ndim == 2 else ds[:, 0, :])).to(hip_device)
+    d2, idx2 = _native.scan_topk_checked(ds_t, torch.as_tensor(np.atleast_2d(q)).to(hip_device), k, h=h, flags=OVERLAP)
+    torch.cuda.synchronize()
+    assert_exact(d2.cpu().numpy(), idx2.cpu().numpy(), od, oidx, kind + " (status protocol)")
+
+
+def test_given_query_norm_and_row_offsets(hip_device, oracle_mod):
+    """qnorm handed in; duplicated rows (every distance 4 times: (r, t) decides) with row offsets on both sides of what
+    packs into the ranking's 64-bit keys."""
+    from shadowing_amd import _native
+    ds = syn.dataset(4096, 2048, 5500)
+    q = syn.gbm_log_returns((1, 20), 5501)
+    qn = np.array([0.123], np.float32)
+    d, idx, st = _native.scan_topk(torch.as_tensor(ds[:, 0, :].copy()).to(hip_device), torch.as_tensor(q).to(hip_device), 100, h=20,
+                                   qnorm=torch.as_tensor(qn).to(hip_device), flags=OVERLAP)
+    torch.cuda.synchronize()
+    assert int(st[0]) == 0
+    od, oidx = oracle_mod.scan_topk(ds, q, 100, h=20, qn=qn)
+    assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, "qnorm given")
+    base = syn.dataset(2048, 2048, 5502)
+    ds4 = np.ascontiguousarray(np.tile(base, (4, 1, 1)))
+    od, oidx = oracle_mod.scan_topk(ds4, q, 512, h=20)
+    for off in (0, 777, (1 << 21) - 8192 + 5, 1 << 22):
+        d, idx, status, info = fused_scan(hip_device, ds4, q, 512, 20, r_offset=off, flags=OVERLAP)
+        assert info["path"] == 3 and status[0] == 0
+        oi = oidx.copy(); oi[..., 0] += off
+        assert_exact(d, idx, od, oi, f"overlap ranking, row offset {off}")
+
+
+def test_sharded_class_on_private_streams(hip_device, oracle_mod, tmp_path):
+    """ShardedPathShadowing(streams=3): consecutive scan_begin() calls on private streams as overlap launches, the exchange
+    (1-rank RCCL: all-gather + merge still run) behind each; pipelined and checked."""
+    import torch.distributed as dist
+    import shadowing_amd as sa
+    from shadowing_amd.distributed import ShardedPathShadowing
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/pg", rank=0, world_size=1, device_id=hip_device)
+    objs = []
+    try:
+        big = syn.dataset(16384, 2048, 5600)
+        for exchange in ("library", "torch"):
+            obj = ShardedPathShadowing(sa.Identity(20), sa.RelativeMSE(), big, 0, sa.PredictionContext(20), device=hip_device,
+                                       always_exchange=True, exchange=exchange, streams=3)
+            objs.append(obj)
+            qs = [torch.tensor(syn.gbm_log_returns((1, 20), 5601 + i)) for i in range(7)]
+            outs, pend = [], None
+            for qi in qs:
+                nxt = obj.scan_begin(qi, 256, check=False)
+                if pend is not None:
+                    outs.append(pend.finish())
+                pend = nxt
+            outs.append(pend.finish())
+            torch.cuda.synchronize()
+            for qi, (dd, ii) in zip(qs, outs):
+                od, oi = oracle_mod.scan_topk(big, qi.numpy(), 256, h=20)
+                assert_exact(dd.cpu().numpy(), ii.cpu().numpy(), od, oi, f"private streams, {exchange} exchange")
+            d, paths, idx = obj.shadow(syn.rolling_queries(3, 20, 5610), 128)     # a batch through the same object
+            od, opaths, oidx = oracle_mod.shadow(big, syn.rolling_queries(3, 20, 5610), 128, 20)
+            assert_exact(d, idx, od, oidx, "batch on private streams")
+            assert np.array_equal(paths, opaths)
+    finally:
+        for o in objs:
+            o.close()
+        dist.destroy_process_group()
