@@ -259,7 +259,7 @@ def main():
             # steps are independent query batches: step i+1 begins (local scan, start of its all-gather) before step i
             # is finished (wait for its all-gather on the compute stream, merge) -- the ~20 us collective latency runs
             # under the next scan.  Every step's merged result is complete when the timed region ends (drain()).
-            nxt = sharded.scan_begin(q, k, check=False)   # no host sync inside the timed loop
+            nxt = sharded.scan_begin(q, k, check=False, queries_ready=True)   # no host sync inside the timed loop; q was uploaded long ago
             statuses.append(sharded.last_status)
             out = pending.pop().finish() if pending else None
             pending.append(nxt)
@@ -322,6 +322,7 @@ def main():
         if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
+        cfg["count"] = 0
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(i)
@@ -339,6 +340,13 @@ def main():
             el, bad = float(t[0].item()), int(t[1].item())
         return el, host, bad
 
+    # The CU-masked scan streams of the sharded run are BLOCKING streams (hipExtStreamCreateWithCUMask takes no flags):
+    # anything enqueued on the legacy default stream would serialise with all of them.  The sharded steps are therefore
+    # issued from a stream of their own.
+    main_stream = torch.cuda.Stream(dev) if (sharded is not None and n_streams > 1) else None
+    if main_stream is not None:
+        main_stream.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(main_stream)
     elapsed, host_enqueue, bad = timed_region()
     fused_retry = False
     if bad == 2 and not args.no_fuse:

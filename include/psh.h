@@ -101,9 +101,11 @@ extern "C" {
 /* SELECT_ONE_BLOCK: the selection of a one- or two-query scan by the one-block radix select + sort even where the
  * ranking on all CUs applies (k <= 4096 and at most 8192 candidates; same results: A/B tests, timing). */
 #define PSH_FLAG_SELECT_ONE_BLOCK 1024
-/* RESERVE_CUS: the scan leaves a few compute units free (grid = CUs - 4): set by callers that run a collective and a
- * merge on a side stream beside the NEXT scan -- the fused launch otherwise owns every CU of the chip, and work on
- * another stream would wait for it (or make its last block wait). */
+/* RESERVE_CUS: the scan leaves a few compute units free: set by callers that run a collective and a merge on a side
+ * stream beside the NEXT scan -- a scan otherwise owns every CU of the chip, and work on another stream would wait for
+ * it (or make its last block wait).  Fused launch: grid = CUs - 4.  With PSH_FLAG_OVERLAP: grid = CUs -
+ * PSH_STREAM_RESERVED_CUS, for streams made by psh_stream_create_reserving (consecutive scans overlap there, so only a
+ * CU mask keeps compute units free). */
 #define PSH_FLAG_RESERVE_CUS  32
 /* OVERLAP: psh_scan_topk with ONE query (W <= 33): the step as three launches -- sample + admission level, scan, ranking
  * (psh_stream.hip) -- sized so that the small ones fit on the compute units BESIDE the scan of a call on ANOTHER stream, and
@@ -313,6 +315,19 @@ int psh_exchange_merge(psh_comm* comm, void* compute_stream, void* side_stream,
                        const int32_t* send, int32_t* gathered, int B, int k,
                        float* out_d, int32_t* out_idx, void* merge_workspace, size_t merge_workspace_bytes,
                        void* ev_scan_done, void* ev_merged);
+
+/*
+ * A HIP stream whose kernels never run on `reserve_cus` of the device's compute units (hipExtStreamCreateWithCUMask): for
+ * callers that keep a collective and a merge in flight on ANOTHER stream beside their scans.  A scan block holds its
+ * compute unit for ~75 us; a foreign workgroup that does not fit into what the scan leaves free (one wave slot, 64 VGPRs
+ * per SIMD, 16 KB of LDS) would otherwise wait for a block to leave -- and delay the next scan's block there by as much.
+ * Scans on such a stream must be issued with PSH_FLAG_RESERVE_CUS (their grid then matches the compute units they can
+ * use).  out_reserved receives the number actually reserved (0 when the device has too few).  The stream belongs to the
+ * caller: psh_stream_destroy (or hipStreamDestroy).  (The reference has no counterpart: its multi-GPU story is absent.)
+ */
+#define PSH_STREAM_RESERVED_CUS 8
+int psh_stream_create_reserving(int device, int reserve_cus, void** out_stream, int* out_reserved);
+int psh_stream_destroy(int device, void* stream);
 
 /*
  * Path gather of shadow() (path_shadowing.py:211-216):

@@ -41,7 +41,7 @@ EXPORTS = ("psh_version", "psh_strerror", "psh_last_hip_error", "psh_workspace_b
            "psh_scan_topk_embedded_exhaustive", "psh_merge_workspace_bytes", "psh_merge_topk",
            "psh_merge_topk_gathered", "psh_merge_sorted_gathered", "psh_gather_paths", "psh_embed_rows",
            "psh_embedded_supported", "psh_embed_plan_offset", "psh_workspace_init", "psh_last_comm_error", "psh_comm_unique_id", "psh_comm_create",
-           "psh_comm_destroy", "psh_comm_world", "psh_exchange_merge")
+           "psh_comm_destroy", "psh_comm_world", "psh_exchange_merge", "psh_stream_create_reserving", "psh_stream_destroy")
 
 _lib = None
 
@@ -90,6 +90,10 @@ def load() -> C.CDLL:
     L.psh_comm_world.argtypes = [vp]
     L.psh_exchange_merge.restype = i32
     L.psh_exchange_merge.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, C.c_size_t, vp, vp]
+    L.psh_stream_create_reserving.restype = i32
+    L.psh_stream_create_reserving.argtypes = [i32, i32, C.POINTER(vp), C.POINTER(i32)]
+    L.psh_stream_destroy.restype = i32
+    L.psh_stream_destroy.argtypes = [i32, vp]
     L.psh_workspace_init.restype = i32
     L.psh_workspace_init.argtypes = [i32, vp, vp, C.c_size_t]
     L.psh_query_norm.restype = i32
@@ -211,8 +215,8 @@ def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, 
     right around the dominant scan kernel, without any synchronisation.
     `unsorted=True`: the k best come back in arbitrary order (PSH_FLAG_UNSORTED; for callers that
     merge afterwards).  `flags`: further PSH_FLAG_* bits (A/B switches of tests and tools).
-    `info`: a dict that receives the launch plan's facts (path: 0 separate launches, 1 exhaustive, 2 fused; ...)
-    without any synchronisation.
+    `info`: a dict that receives the launch plan's facts (path: 0 separate launches, 1 exhaustive, 2 fused, 3 the
+    overlap-friendly launches; ...) without any synchronisation.
     """
     ds = _dev_tensor(dataset, torch.float32, "dataset")
     q = _dev_tensor(queries, torch.float32, "queries")
@@ -440,6 +444,68 @@ class Comm:
                                        None if merge_ws is None else merge_ws.data_ptr(), 0 if merge_ws is None else merge_ws.numel(),
                                        ev_scan_done.cuda_event, ev_merged.cuda_event)
         _check(rc, "psh_exchange_merge")
+
+
+PSH_STREAM_RESERVED_CUS = 8
+
+
+def reserving_stream(device: torch.device, reserve_cus: int = PSH_STREAM_RESERVED_CUS):
+    """(torch stream, CUs reserved): a stream whose kernels leave `reserve_cus` compute units alone
+    (psh_stream_create_reserving), wrapped for torch.  The raw stream lives as long as the process (a handful per object)."""
+    h, got = C.c_void_p(), C.c_int(0)
+    _check(load().psh_stream_create_reserving(device.index, int(reserve_cus), C.byref(h), C.byref(got)), "psh_stream_create_reserving")
+    return torch.cuda.ExternalStream(h.value, device=device), int(got.value)
+
+
+class PreparedStep:
+    """One step of the row-sharded scan with everything but the stream and the query pointer fixed beforehand: the local
+    psh_scan_topk into the send buffer, then psh_exchange_merge (all-gather + merge on the side stream).  The per-step host
+    cost is two ctypes calls over pre-built argument lists -- no tensor is allocated, no Python-side check repeated (a rank
+    that spends 100 us of Python per 85 us step is host-bound).  Buffers are owned here and REUSED by the next launch()."""
+
+    def __init__(self, comm: "Comm", dataset: torch.Tensor, r_offset: int, B: int, W: int, k: int, h: int, workspace: "Workspace",
+                 side: "torch.cuda.Stream", flags: int, sorted_merge: bool):
+        ds = _dev_tensor(dataset, torch.float32, "dataset")
+        dev = ds.device
+        R, T = ds.shape
+        G = comm.world
+        self.B, self.W, self.k = B, W, k
+        self.send = torch.empty(3 * B * k, dtype=torch.int32, device=dev)
+        self.gathered = torch.empty((G, 3 * B * k), dtype=torch.int32, device=dev)
+        self.out_d = torch.empty((B, k), dtype=torch.float32, device=dev)
+        self.out_idx = torch.empty((B, k, 2), dtype=torch.int32, device=dev)
+        self.status = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self.merge_ws = None
+        if not sorted_merge:
+            self.merge_ws = torch.empty(merge_workspace_bytes(B, k), dtype=torch.uint8, device=dev)
+        self.ev_a, self.ev_b = torch.cuda.Event(), torch.cuda.Event()
+        self.ev_a.record(); self.ev_b.record()                  # materialise the hipEvent handles
+        ws = workspace.get(workspace_bytes(R, T, B, W, h, k))
+        self._keep = (ds, ws, side, comm, workspace)
+        self.prof = PshProfile()
+        self.prof.mode = 1
+        self.prof.flags = flags | (0 if sorted_merge else FLAG_UNSORTED)
+        L = load()
+        self._scan_fn, self._exch_fn = L.psh_scan_topk, L.psh_exchange_merge
+        self._scan_args = [dev.index, None, ds.data_ptr(), R, T, r_offset, None, None, B, W, h, k, self.send.data_ptr(),
+                           self.send.data_ptr() + 4 * B * k, self.status.data_ptr(), ws.data_ptr(), ws.numel(), C.byref(self.prof)]
+        self._exch_args = [comm._h, None, side.cuda_stream, self.send.data_ptr(), self.gathered.data_ptr(), B, k,
+                           self.out_d.data_ptr(), self.out_idx.data_ptr(),
+                           None if self.merge_ws is None else self.merge_ws.data_ptr(), 0 if self.merge_ws is None else self.merge_ws.numel(),
+                           self.ev_a.cuda_event, self.ev_b.cuda_event]
+
+    def launch(self, stream_ptr: int, q_ptr: int) -> None:
+        a = self._scan_args
+        a[1] = stream_ptr
+        a[6] = q_ptr
+        rc = self._scan_fn(*a)
+        if rc:
+            _check(rc, "psh_scan_topk")
+        e = self._exch_args
+        e[1] = stream_ptr
+        rc = self._exch_fn(*e)
+        if rc:
+            _check(rc, "psh_exchange_merge")
 
 
 def merge_topk(d_lists: torch.Tensor, idx_lists: torch.Tensor, k: int):

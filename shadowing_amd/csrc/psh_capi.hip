@@ -495,6 +495,41 @@ int psh_workspace_bytes(int64_t R, int64_t T, int B, int W, int h, int k, size_t
     return PSH_OK;
 }
 
+int psh_stream_create_reserving(int device, int reserve_cus, void** out_stream, int* out_reserved) {
+    if (!out_stream || reserve_cus < 0) return PSH_ERR_ARG;
+    DeviceGuard g(device);
+    if (!g.ok) { snprintf(g_hip_err, sizeof(g_hip_err), "hipSetDevice(%d) failed", device); return PSH_ERR_HIP; }
+    int ncu = 0;
+    HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+    if (reserve_cus * 4 > ncu) reserve_cus = 0;             // a small device: nothing is reserved
+    // one bit per compute unit; the FIRST `reserve_cus` bits are cleared (on a multi-XCD part the bits interleave over
+    // the XCDs, so eight of them are one compute unit per XCD; were they not, they would be eight units of one XCD --
+    // either way that many units stay free)
+    uint32_t mask[32];
+    const int words = (ncu + 31) / 32;
+    if (words > 32) return PSH_ERR_UNSUPPORTED;
+    for (int w = 0; w < words; ++w) {
+        uint32_t m = 0xffffffffu;
+        const int rem = ncu - 32 * w;
+        if (rem < 32) m = (rem <= 0) ? 0u : ((1u << rem) - 1u);
+        mask[w] = m;
+    }
+    for (int b = 0; b < reserve_cus; ++b) mask[b / 32] &= ~(1u << (b % 32));
+    hipStream_t s = nullptr;
+    HIP_TRY(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask));
+    *out_stream = (void*)s;
+    if (out_reserved) *out_reserved = reserve_cus;
+    return PSH_OK;
+}
+
+int psh_stream_destroy(int device, void* stream) {
+    if (!stream) return PSH_ERR_ARG;
+    DeviceGuard g(device);
+    if (!g.ok) { snprintf(g_hip_err, sizeof(g_hip_err), "hipSetDevice(%d) failed", device); return PSH_ERR_HIP; }
+    HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return PSH_OK;
+}
+
 int psh_workspace_init(int device, void* stream, void* workspace, size_t workspace_bytes) {
     if (!workspace || ((uintptr_t)workspace & 255u) != 0) return PSH_ERR_ARG;
     if (workspace_bytes < PSH_FUSED_BYTES) return PSH_ERR_WORKSPACE;
@@ -690,6 +725,8 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
                     int64_t grid_p = (int64_t)tn.stream_pgrid_per_cu * ncu;
                     if (grid_p > units_p) grid_p = units_p;
                     int64_t grid_s = ncu;
+                    // a stream made by psh_stream_create_reserving: one block per compute unit the stream may use
+                    if ((flags_of(profile) & PSH_FLAG_RESERVE_CUS) && ncu >= 4 * PSH_STREAM_RESERVED_CUS) grid_s = ncu - PSH_STREAM_RESERVED_CUS;
                     const int64_t n_rs = p.R * nseg;
                     if (grid_s * (PSH_SCAN_THREADS / 64) > n_rs) grid_s = (n_rs + (PSH_SCAN_THREADS / 64) - 1) / (PSH_SCAN_THREADS / 64);
                     int front = (int)(PSH_STREAM_CAND_CAP / grid_s);
@@ -710,11 +747,16 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
                         return PSH_OK;
                     }
                 }
+                // (a caller that asked for the overlap-friendly launches may be on a stream that cannot hold the fused
+                //  launch's blocks all at once -- a CU mask, other scans in flight: where they do not apply, the separate
+                //  launches serve the call, never the fused one)
+                if (!(flags_of(profile) & PSH_FLAG_OVERLAP)) {
                 if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_begin, s));
                 HIP_TRY(launch_scan_fused(fa, fu, p.aligned, plan_f.grid, s));
                 if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_end, s));
                 if (profile) { profile->path = 2; profile->n_sample_rows = (int)rows_f; profile->grid_blocks = plan_f.grid; }
                 return PSH_OK;
+                }
             }
         }
     }
@@ -789,6 +831,9 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
 
     Plan plan_f;
     rc = plan_scan(device, p, p.R, &plan_f); if (rc) return rc;
+    // a CU-masked stream (psh_stream_create_reserving): one resident round of blocks on the compute units it may use
+    if ((flags_of(profile) & PSH_FLAG_RESERVE_CUS) && (flags_of(profile) & PSH_FLAG_OVERLAP) && plan_f.grid > 4 * PSH_STREAM_RESERVED_CUS && !p.ker)
+        plan_f.grid -= PSH_STREAM_RESERVED_CUS;
     ScanArgs fa = make_scan_args(dataset, queries, p, w, plan_f, 0, 1, p.R);
     fa.use_mx = use_mx ? 1 : 0;
     fa.bcount2 = (use_mx && rank2 > 0) ? w.bcount2 : nullptr;

@@ -82,7 +82,7 @@ class ShardedPathShadowing:
     def __init__(self, embedding: Identity, distance: RelativeMSE, local_dataset, row_offset: int,
                  context: PredictionContext | None = None, group=None, device: torch.device | None = None,
                  local_topk: Callable | None = None, merge: Callable | None = None, always_exchange: bool = False,
-                 exchange: str = "auto", emulate_world: tuple | None = None, streams: int = 1):
+                 exchange: str = "auto", emulate_world: tuple | None = None, streams: int = 1, reserve_cus: bool = False):
         """`emulate_world = (G, n_windows_global, fill)`: this ONE process stands for rank 0 of a G-rank world whose
         collective is replaced by `fill(gathered, q, k)` -- it writes the lists of ranks 1..G-1 into rows 1..G-1 of the
         receive buffer (G, 3*B*k int32: (B,k) distance bits, then (B,k,2) indices), exactly where the all-gather would have
@@ -92,7 +92,12 @@ class ShardedPathShadowing:
         `streams` > 1 (HIP device): consecutive scan_begin() calls -- independent query batches -- issue their local scan
         round-robin on that many private streams, single queries as the overlap-friendly launches (PSH_FLAG_OVERLAP): the
         sample and the ranking of one step, and the exchange of another, run beside a third step's scan, and nothing in a
-        scan waits for co-residency (no reserved compute units, no polling next to the collective's workgroups)."""
+        scan waits for co-residency (no polling next to the collective's workgroups).  `reserve_cus=True` makes the private
+        streams CU-masked ones (psh_stream_create_reserving: PSH_STREAM_RESERVED_CUS compute units stay free for the
+        collective and the merge, whose workgroups otherwise wait for a scan block to leave); such streams are BLOCKING HIP
+        streams (the masked-stream API takes no flags): call scan_begin() / finish() from a stream other than the legacy
+        default stream then, or every step serialises with it.  Off by default: with the one-rank exchange that can be
+        measured here it was slower (123 against 111 us per step), and no multi-GPU node was available to tune it on."""
         if type(distance) is not RelativeMSE:
             raise TypeError("the sharded scan implements RelativeMSE only")
         if type(embedding) is Identity:
@@ -153,10 +158,17 @@ class ShardedPathShadowing:
         self.dataset = ds.contiguous()
         self.device = self.dataset.device
         self._scan_streams = None
+        self._reserve = 0
         if streams > 1 and local_topk is None and self.device.type == "cuda":
-            self._scan_streams = [torch.cuda.Stream(self.device) for _ in range(int(streams))]
+            # the scans of consecutive steps overlap on these streams and would take EVERY compute unit between them: the
+            # collective and the merge on the side stream get theirs through a CU mask (psh_stream_create_reserving)
+            made = ([_native.reserving_stream(self.device) for _ in range(int(streams))] if reserve_cus
+                    else [(torch.cuda.Stream(self.device), 0) for _ in range(int(streams))])
+            self._scan_streams = [m[0] for m in made]
+            self._reserve = min(m[1] for m in made)
             self._scan_ws = [_native.Workspace(self.device) for _ in range(int(streams))]
         self._step = 0
+        self._fast = {}             # (B, W, k) -> ring of _native.PreparedStep (private streams, library exchange)
 
     @property
     def world_size(self) -> int:
@@ -254,17 +266,64 @@ class ShardedPathShadowing:
         check `last_status` once at the end)."""
         return self.scan_begin(queries, k, check=check).finish()
 
-    def scan_begin(self, queries: torch.Tensor, k: int, check: bool = True) -> "PendingScan":
+    def scan_begin(self, queries: torch.Tensor, k: int, check: bool = True, queries_ready: bool = False) -> "PendingScan":
+        """`queries_ready` (private streams only): the caller's word that `queries` is already materialised in HBM (nothing
+        still enqueued on the current stream writes it): the step's private stream then does not wait for the current
+        stream -- which, in a pipelined loop, has just been told to wait for the merged result of an EARLIER step, a
+        dependency the queries do not have."""
         if self._scan_streams is None:
             return self._scan_begin(queries, k, check, None)
+        fast = self._fast_step(queries, k, check, queries_ready)
+        if fast is not None:
+            return fast
         # this step's stream: it sees everything the caller's stream has enqueued so far (the queries), and the caller's
         # stream sees the results through PendingScan.finish()
         i = self._step % len(self._scan_streams)
         self._step += 1
         s = self._scan_streams[i]
-        s.wait_stream(torch.cuda.current_stream(self.device))
+        if not queries_ready:
+            s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s):
             return self._scan_begin(queries, k, check, self._scan_ws[i])
+
+    def _fast_step(self, queries, k: int, check: bool, queries_ready: bool = False):
+        """The lean form of a step on the private streams (a host that spends more Python per step than the GPU spends
+        scanning is the bottleneck): Identity scan, library exchange, queries already a float32 (B, W) tensor on the device,
+        no per-call status check.  Prepared argument lists and a ring of buffers per (B, W, k) (_native.PreparedStep); two
+        ctypes calls per step.  Results live in the ring: valid until 2 x streams further scan_begin() calls."""
+        if (check or self._linear or self._local_topk is not None or self._merge is not None or self._emulate is not None
+                or not isinstance(queries, torch.Tensor) or queries.device != self.device or queries.dtype != torch.float32
+                or queries.dim() != 2 or not queries.is_contiguous() or not self.fuse):
+            return None
+        B, W = queries.shape
+        G = self.world_size
+        if not ((G > 1 or self.always_exchange) and self._use_library(B, k)):
+            return None
+        h = self.context.get_out_times()
+        R_local, _, T = self.dataset.shape
+        if W != self.embedding.kernel.shape[-1] or R_local * max(T - W - h + 1, 0) < k or k > self.n_windows_global():
+            return None                                      # (short shards, errors: the general path pads / raises)
+        key = (B, W, k)
+        ring = self._fast.get(key)
+        if ring is None:
+            comm = self._library_exchange()
+            n = len(self._scan_streams)
+            sorted_merge = _native.merge_sorted_supported(G, k)
+            ring = [_native.PreparedStep(comm, self.dataset[:, 0, :], self.row_offset, B, W, k, h, self._scan_ws[j % n], self._side,
+                                         (_native.FLAG_OVERLAP | (_native.FLAG_RESERVE_CUS if self._reserve else 0)) if B == 1 else 0,
+                                         sorted_merge) for j in range(2 * n)]
+            torch.cuda.synchronize(self.device)
+            self._fast[key] = ring
+        j = self._step % len(ring)
+        self._step += 1
+        slot = ring[j]
+        s = self._scan_streams[j % len(self._scan_streams)]
+        if not queries_ready:
+            s.wait_stream(torch.cuda.current_stream(self.device))
+        queries.record_stream(s)
+        slot.launch(s.cuda_stream, queries.data_ptr())
+        self.last_status = slot.status
+        return PendingScan(self, None, (None, None, "library", slot.ev_b, "ring"), (slot.out_d, slot.out_idx), B, k)
 
     def _scan_begin(self, queries: torch.Tensor, k: int, check: bool, ws) -> "PendingScan":
         """First half of scan(): the local scan and the START of the all-gather (async_op).  `finish()` on
@@ -297,7 +356,8 @@ class ShardedPathShadowing:
             library = exchange and self._use_library(B, k)
             comm = self._library_exchange() if library else None
             # private scan streams: nothing in the scan needs co-residency, so no compute unit is reserved for the collective
-            mode = _native.FLAG_OVERLAP if ws is not None else (_native.FLAG_RESERVE_CUS if library else 0)
+            mode = ((_native.FLAG_OVERLAP | (_native.FLAG_RESERVE_CUS if self._reserve else 0)) if ws is not None
+                    else (_native.FLAG_RESERVE_CUS if library else 0))
             d, idx, self.last_status = self.local_scan(q, k, out=out, check=check, unsorted=exchange and not sorted_merge,
                                                        flags=(mode if self.fuse else _native.FLAG_NO_FUSE) | getattr(self, "_emb_flags", 0),
                                                        workspace=ws)
@@ -384,9 +444,11 @@ class PendingScan:
         if self._buffers is not None and self._buffers[2] == "library":
             # the merged lists are written by the side stream: whoever consumes them on this stream waits for the event
             cur.wait_event(self._buffers[3])
+            ring = self._buffers[4] == "ring"                # (the lean path's results live in buffers the owner keeps)
             self._buffers = None
-            for t in self._result:
-                t.record_stream(cur)
+            if not ring:
+                for t in self._result:
+                    t.record_stream(cur)
             return self._result
         if self._stream is not None:
             # begun on one of the owner's private streams: what follows here (the wait for the collective, the merge, the

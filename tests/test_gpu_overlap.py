@@ -195,3 +195,63 @@ def test_sharded_class_on_private_streams(hip_device, oracle_mod, tmp_path):
         for o in objs:
             o.close()
         dist.destroy_process_group()
+
+
+def test_sharded_class_lean_steps(hip_device, oracle_mod, tmp_path):
+    """The lean form of a step (ShardedPathShadowing._fast_step: prepared argument lists, a ring of buffers, two ctypes
+    calls): device queries, check=False, library exchange -- 20 single queries pipelined three deep, then a batch of 4."""
+    import torch.distributed as dist
+    import shadowing_amd as sa
+    from shadowing_amd.distributed import ShardedPathShadowing
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/pg", rank=0, world_size=1, device_id=hip_device)
+    obj = None
+    try:
+        big = syn.dataset(16384, 2048, 5700)
+        obj = ShardedPathShadowing(sa.Identity(20), sa.RelativeMSE(), big, 0, sa.PredictionContext(20), device=hip_device,
+                                   always_exchange=True, exchange="library", streams=3)
+        for B, n in ((1, 20), (4, 5)):
+            qs = [torch.tensor(syn.gbm_log_returns((B, 20), 5701 + 10 * B + i)).to(hip_device) for i in range(n)]
+            outs, pend = [], []
+            for qi in qs:
+                pend.append(obj.scan_begin(qi, 256, check=False))
+                if len(pend) == 3:
+                    dd, ii = pend.pop(0).finish()
+                    outs.append((dd.clone(), ii.clone()))            # ring buffers: copy before they are reused
+            for p_ in pend:
+                dd, ii = p_.finish()
+                outs.append((dd.clone(), ii.clone()))
+            torch.cuda.synchronize()
+            assert (B, 20, 256) in obj._fast, "the lean path must have served these calls"
+            assert int(obj.last_status.max().item()) == 0
+            for qi, (dd, ii) in zip(qs, outs):
+                od, oi = oracle_mod.scan_topk(big, qi.cpu().numpy(), 256, h=20)
+                assert_exact(dd.cpu().numpy(), ii.cpu().numpy(), od, oi, f"lean steps B={B}")
+    finally:
+        if obj is not None:
+            obj.close()
+        dist.destroy_process_group()
+
+
+def test_cu_masked_stream(hip_device, oracle_mod):
+    """psh_stream_create_reserving: a stream that leaves PSH_STREAM_RESERVED_CUS compute units alone; overlap launches issued
+    on it with PSH_FLAG_RESERVE_CUS (grid = the compute units the stream may use) stay exact."""
+    from shadowing_amd import _native
+    s, reserved = _native.reserving_stream(hip_device)
+    assert reserved == _native.PSH_STREAM_RESERVED_CUS
+    ds = syn.dataset(16384, 2048, 5800)
+    q = syn.gbm_log_returns((1, 20), 5801)
+    ws = _native.Workspace(hip_device)
+    main = torch.cuda.Stream(hip_device)                     # (masked streams are blocking streams: stay off the default stream)
+    with torch.cuda.stream(main):
+        ds_t = torch.as_tensor(ds[:, 0, :].copy()).to(hip_device)
+        q_t = torch.as_tensor(q).to(hip_device)
+    main.synchronize()
+    info = {}
+    with torch.cuda.stream(s):
+        d, idx, st = _native.scan_topk(ds_t, q_t, 400, h=20, workspace=ws, flags=OVERLAP | _native.FLAG_RESERVE_CUS, info=info)
+    s.synchronize()
+    assert info["path"] == 3 and int(st[0]) == 0
+    ncu = torch.cuda.get_device_properties(hip_device).multi_processor_count
+    assert info["grid_blocks"] == ncu - reserved
+    od, oidx = oracle_mod.scan_topk(ds, q, 400, h=20)
+    assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, "overlap launches on a CU-masked stream")
