@@ -432,6 +432,41 @@ def main():
                     "avg_launch_ms": round(avg_ms, 5), "min_launch_ms": round(float(np.min(scan_ms)), 5),
                     "launches_timed": len(scan_ms), "launches_timed_every": EV_EVERY,
                     "frac_of_measured_copy_rate": round(achieved / HBM_COPY_GBPS, 4)}
+        if B > 1 and mx:
+            # A batch is NOT bandwidth-bound: every ensemble byte is used by B queries (physical HBM traffic is one read of
+            # the ensemble per launch: 0.5 GB in ~4 ms).  What bounds scan_mq_kernel is the matrix cores plus the vector ALUs
+            # behind them ("report VALU utilisation + effective GB/s"): per 1024-window segment and group of four
+            # queries 8 v_mfma_f32_32x32x16_f16 (4 tiles x K = 32: 20 taps + 7 shifts of the 8-window rows) and a 34-v_min3
+            # epilogue.  `achieved` = ISSUED matrix-core flop/s (2 x 32 x 32 x 16 per MFMA; 62.5 % of the MACs are useful
+            # ones, 20 taps x 1024 (window, query) pairs per tile pair) against the guide's dense f16 peak; busy fractions of
+            # the matrix cores and the vector ALUs come from the committed PMC pass of this command, when there is one.
+            nseg_b = (Tp + 1023) // 1024
+            groups = (B + 3) // 4
+            mfma_per_launch = R * nseg_b * (groups * 8 + 8)                 # + the 8 window-energy MFMAs of a segment
+            flops = mfma_per_launch * 2 * 32 * 32 * 16
+            ach_tf = flops / (avg_ms * 1e-3) / 1e12
+            MFMA_F16_DENSE_TF = 2500.0                                       # MI355X_MICROARCH.md: ~2.5 PF dense bf16 / f16
+            pmc = None
+            pfile = REPO / "profiles" / "q512_pmc.json"
+            if pfile.exists():
+                try:
+                    pj = json.loads(pfile.read_text())
+                    if pj.get("workload") == f"R={R},T={T},W={W},h={h},k={k},B={B}":
+                        pmc = pj
+                except Exception:   # noqa: BLE001
+                    pmc = None
+            roofline = {"bound": "mfma+valu", "kernel": kernel_name, "achieved": round(ach_tf, 1), "peak": MFMA_F16_DENSE_TF,
+                        "unit": "TFLOP/s", "frac": round(ach_tf / MFMA_F16_DENSE_TF, 4),
+                        "mfma_per_launch": mfma_per_launch, "issued_flops_per_launch": flops, "useful_mac_fraction": 0.625,
+                        "matrix_core_busy_frac": pmc.get("matrix_core_busy_frac") if pmc else None,
+                        "valu_busy_frac": pmc.get("valu_busy_frac") if pmc else None,
+                        "pmc_source": "profiles/q512_pmc.json (rocprofv3 --pmc passes of this command: SQ_VALU_MFMA_BUSY_CYCLES, "
+                                      "SQ_ACTIVE_INST_VALU, SQ_BUSY_CYCLES; not measured in this run)" if pmc else None,
+                        "traffic": pmc.get("hbm_bytes_per_launch") if pmc else None,
+                        "effective_GBps_per_query_equivalent": round(B * R * T * 4 / (avg_ms * 1e-3) / 1e9, 1),
+                        "physical_algorithmic_GBps": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 1),
+                        "avg_launch_ms": round(avg_ms, 5), "min_launch_ms": round(float(np.min(scan_ms)), 5),
+                        "launches_timed": len(scan_ms), "launches_timed_every": EV_EVERY}
         if interval_ms:
             roofline["avg_launch_interval_ms"] = round(interval_ms, 5)
             roofline["note"] = ("overlap mode: `achieved` = algorithmic bytes / avg_launch_interval_ms (end-to-end interval of consecutive "

@@ -581,16 +581,17 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
                 };
                 // (fetching a row's E values while the row before it is computed -- two register sets, 768 threads for the
                 //  registers -- measured slower, 1.92 against 1.57 ms: four waves per SIMD hide the LDS latency better)
+                // Two rows a turn, ALWAYS: an odd row count ends on a blank entry (c' = 0, lane `ngroups` holds h' = 0: e = 0,
+                // nothing is added; rtab has ngroups + 3 entries).  A separate copy of the row body for the odd row made the
+                // compiler spill 15 registers around it.
                 int4 oa = rtab[0];
-                int i = 0;
 #pragma unroll 1
-                for (; i + 1 < ngroups; i += 2) {
+                for (int i = 0; i < ngroups; i += 2) {
                     const int4 ob = rtab[i + 1];
                     row_step(oa, i);
-                    oa = rtab[i + 2];                        // (up to entry ngroups + 1: blank)
+                    oa = rtab[i + 2];                        // (up to entry ngroups + 2: blank)
                     row_step(ob, i + 1);
                 }
-                if (i < ngroups) row_step(oa, i);
             };
             if constexpr (NBG == 2) {
                 if (nq == 2) rows(std::integral_constant<int, 2>{}); else rows(std::integral_constant<int, 1>{});

@@ -87,3 +87,15 @@ def test_product_never_imports_the_oracle():
     for p in (REPO / "shadowing_amd").rglob("*"):
         if p.suffix in (".py", ".hip", ".h", ".cpp"):
             assert not re.search(r"^\s*(from|import)\s+oracle\b|libpsh_oracle|#include\s*[<\"][^\n]*oracle|psh_oracle_\w+\s*\(", p.read_text(), flags=re.M), p
+
+
+def test_integration_md_build_line_lists_every_source():
+    """INTEGRATION.md section 1's hipcc command must name exactly the translation units _build.py compiles (a maintainer
+    following it otherwise gets undefined symbols)."""
+    import re
+    from pathlib import Path
+    from shadowing_amd import _build
+    text = (Path(__file__).resolve().parent.parent / "INTEGRATION.md").read_text()
+    block = text[text.index("hipcc --offload-arch=gfx950"):text.index("-o libpsh_hip.so")]
+    listed = set(re.findall(r"shadowing_amd/csrc/(\w+\.hip)", block))
+    assert listed == {p.name for p in _build.SOURCES}

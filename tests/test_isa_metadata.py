@@ -1,0 +1,78 @@
+"""Register / spill metadata of the hot kernels, read from the compiler's own output (hipcc -S for gfx950, no GPU needed):
+the dominant instantiations must not spill, the overlap-friendly launches must fit the registers four scan waves leave on
+a SIMD, and no hot loop of the Foveal prefix-sum scan may touch scratch memory."""
+import re
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import pytest
+
+from shadowing_amd import _build
+
+CSRC = _build.CSRC
+
+
+def _asm(name: str, tmp: Path) -> str:
+    out = tmp / (name + ".s")
+    flags = [f for f in _build.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    res = subprocess.run([_build.hipcc_path(), *flags, f"-I{_build.INCLUDE}", f"-I{CSRC}", "-S", "--cuda-device-only",
+                          str(CSRC / (name + ".hip")), "-o", str(out)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    return out.read_text()
+
+
+def _kernels(txt: str) -> dict:
+    meta = {}
+    for blk in txt.split("  - .agpr_count:")[1:]:
+        g = lambda k: re.search(r"\." + k + r":\s+(\S+)", blk).group(1)   # noqa: E731
+        meta[g("name")] = dict(vgpr=int(g("vgpr_count")), spill=int(g("vgpr_spill_count")), scratch=int(g("private_segment_fixed_size")))
+    return meta
+
+
+@pytest.fixture(scope="module")
+def asm(tmp_path_factory):
+    tmp = tmp_path_factory.mktemp("isa")
+    names = ["psh_stream", "psh_fused", "psh_embed_px"]
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        return dict(zip(names, pool.map(lambda n: _asm(n, tmp), names)))
+
+
+def test_overlap_launches_fit_beside_each_other(asm):
+    """Four scan waves of 112 VGPRs leave 64 of a SIMD's 512: the sample and ranking kernels must need no more, the scan no
+    more than 112, none of the W = 20 instantiations may spill."""
+    k = _kernels(asm["psh_stream"])
+    scan = {n: m for n, m in k.items() if "stream_scan_kernel" in n}
+    small = {n: m for n, m in k.items() if "stream_sample_kernel" in n or "stream_rank_kernel" in n}
+    assert scan and small
+    assert all(m["vgpr"] <= 112 for m in scan.values()), scan
+    assert all(m["vgpr"] <= 64 and m["spill"] == 0 and m["scratch"] == 0 for m in small.values()), small
+    assert all(m["spill"] == 0 for n, m in scan.items() if "ILi20E" in n), scan
+
+
+def test_fused_launch_does_not_spill(asm):
+    k = _kernels(asm["psh_fused"])
+    fused = {n: m for n, m in k.items() if "scan_fused_kernel" in n}
+    assert fused and all(m["spill"] == 0 and m["vgpr"] <= 128 for m in fused.values()), fused
+
+
+def test_foveal_prefix_sum_scan_keeps_scratch_out_of_its_hot_loops(asm):
+    """embed_px_kernel: the sample instantiations do not spill at all; the full-scan ones keep a dozen values (set-up,
+    verification of survivors) in scratch but NOT inside the row loops (every loop with >= 16 packed fma)."""
+    txt = asm["psh_embed_px"]
+    k = _kernels(txt)
+    boot = {n: m for n, m in k.items() if "embed_px_kernelILb" in n and "ELi0ELi1024" in n}
+    assert boot and all(m["spill"] == 0 for m in boot.values()), boot
+    for name in [n for n in k if "embed_px_kernelILb" in n and "ELi1ELi1024" in n]:
+        body = txt[txt.index("\n" + name + ":"):]
+        body = body[:body.index("s_endpgm")].splitlines()
+        labels = {m.group(1): i for i, ln in enumerate(body) for m in [re.match(r"(\.LBB\d+_\d+):", ln)] if m}
+        hot = 0
+        for i, ln in enumerate(body):
+            m = re.match(r"\s+s_cbranch_\w+ (\.LBB\d+_\d+)", ln)
+            if m and labels.get(m.group(1), i + 1) < i:                 # a backward branch: labels[...] .. i is a loop
+                loop = body[labels[m.group(1)]:i]
+                if sum("v_pk_fma_f32" in x for x in loop) >= 16 and not any(re.match(r"\s+s_cbranch", x) for x in loop[:-1]):
+                    hot += 1
+                    assert not any("scratch_" in x for x in loop), f"{name}: scratch access inside a row loop"
+        assert hot >= 1, f"{name}: no row loop found"

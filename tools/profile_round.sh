@@ -16,16 +16,27 @@ done
 python $R/tools/summarize_pmc.py $OUT --traffic $OUT/hbm_traffic.json > $OUT/pmc_summary.txt 2>&1
 cp $OUT/hbm_traffic.json $R/profiles/hbm_traffic.json 2>/dev/null
 cd $R
-# the headline line: configs[1], the whole step as one fused launch (with the CPU baselines)
-timeout 600 python bench.py --steps ${STEPS:-200} --warmup 20 > $OUT/bench_n1.json 2> $OUT/bench.err
+# the headline line: configs[1], independent steps on 3 streams as the overlap-friendly launches (with the CPU baselines)
+timeout 600 python bench.py --steps ${STEPS:-1000} --warmup 20 > $OUT/bench_n1.json 2> $OUT/bench.err
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_n1_20steps.json 2>> $OUT/bench.err
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o scan -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_prof.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o scan -- python $R/bench.py --steps 1000 --warmup 20 --no-cpu-baseline > $OUT/bench_prof.log 2>&1
 for f in $(find $OUT/prof_stats -name "*kernel_stats.csv"); do cp $f $OUT/kernel_stats.csv; done
+python $R/tools/overlap_trace.py $OUT/prof_stats > $OUT/overlap_trace_summary.txt 2>&1
+# the same workload on ONE stream: the fused single launch (what an isolated caller gets; r02's headline)
+cd $R
+timeout 300 python bench.py --steps 1000 --warmup 20 --no-cpu-baseline --streams 1 > $OUT/bench_n1_fused_one_stream.json 2>> $OUT/bench.err
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_fused -o scan -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --streams 1 > $OUT/bench_prof_fused.log 2>&1
+for f in $(find $OUT/prof_stats_fused -name "*kernel_stats.csv"); do cp $f $OUT/kernel_stats_fused_one_stream.csv; done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_nofuse -o scan -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-fuse > $OUT/bench_prof_nofuse.log 2>&1
 for f in $(find $OUT/prof_stats_nofuse -name "*kernel_stats.csv"); do cp $f $OUT/kernel_stats_nofuse.csv; done
 cd $R
 timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-fuse > $OUT/bench_n1_separate_launches.json 2>> $OUT/bench.err
+bash tools/pmc_mq.sh > $OUT/pmc_mq_summary.txt 2>&1          # (writes profiles/q512_pmc.json, which the next line reads)
+cd $R
 timeout 300 python bench.py --steps 20 --warmup 3 --queries 512 --no-cpu-baseline > $OUT/bench_n1_q512.json 2>> $OUT/bench.err
+cp $R/profiles/q512_pmc.json $OUT/q512_pmc.json 2>/dev/null
 timeout 300 python bench.py --filter valu --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_n1_valu_filter.json 2>> $OUT/bench.err
 timeout 300 python bench.py --gpus 1 --force-sharded --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_n1_forced_exchange.json 2>> $OUT/bench.err
 timeout 300 python tools/fused_times.py > $OUT/fused_phase_times.txt 2>> $OUT/bench.err
