@@ -658,6 +658,81 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     const bool stages = profile && profile->mode == PSH_PROFILE_STAGES;
     const bool events = profile && profile->mode == PSH_PROFILE_EVENTS && profile->ev_scan_begin && profile->ev_scan_end;
 
+    // ---- the step as three overlap-friendly launches (psh_stream.hip: sample + levels in one-wave blocks, the barrier-free
+    // scan, the ranking): ONE query when the caller says other steps are in flight on other streams (PSH_FLAG_OVERLAP), and
+    // always for two or three queries -- they ride one pass over the ensemble at about one query's cost, where the batched
+    // scan (sized for hundreds of queries) streams at half rate.
+    {
+        const bool small_batch = !p.ker && !rows_path && B >= 2 && B <= PSH_STREAM_MAX_Q && !(flags_of(profile) & PSH_FLAG_FILTER_VALU);
+        const bool one_overlap = use_mx && B == 1 && (flags_of(profile) & PSH_FLAG_OVERLAP);
+        if ((small_batch || one_overlap) && !rows_path && !stages && !(flags_of(profile) & PSH_FLAG_NO_FUSE) && scan_fused_supported(p.W)) {
+            int ncu = 0;
+            HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+            const Tuning tn = tuning();
+            const int64_t nseg = (p.Tp + PSH_SEG - 1) / PSH_SEG;
+            // a thinner sample than the fused launch's: its megabytes are HBM traffic beside ANOTHER step's scan here.  2048
+            // units (what the exchange area holds, split between the queries); the level is the (2k x sampled fraction + 8)-th
+            // smallest minimum: the k best windows of the ensemble put 2k/2 x fraction = 16 expected minima below their level,
+            // P(Poisson(16) >= 40) = 3e-7 that fewer than k windows lie below the estimate (-> PSH_STATUS_RETRY)
+            int64_t units_cap = tn.stream_units < 2048 ? tn.stream_units : 2048;     // (the sample kernel keeps a query's minima in registers: <= 2048)
+            if (units_cap > PSH_FUSED_MAX_UNITS / B) units_cap = PSH_FUSED_MAX_UNITS / B;
+            int64_t rows_p = units_cap / nseg;
+            if (rows_p > p.R / 4) rows_p = p.R / 4;
+            if (rows_p < 1) rows_p = 1;
+            const int64_t units_p = rows_p * nseg;
+            int64_t r2p = (2 * (int64_t)k * rows_p + p.R - 1) / p.R + 8;
+            if (r2p < 24) r2p = 24;
+            // sample blocks: two per CU when other steps' scans hold the CUs (what fits beside them); a step that runs alone
+            // (two or three queries, no PSH_FLAG_OVERLAP) spreads its units over eight one-wave blocks per CU
+            int64_t grid_p = (int64_t)((flags_of(profile) & PSH_FLAG_OVERLAP) ? tn.stream_pgrid_per_cu : 8) * ncu;
+            if (grid_p > units_p) grid_p = units_p;
+            int64_t grid_s = ncu;
+            // a stream made by psh_stream_create_reserving: one block per compute unit the stream may use
+            if ((flags_of(profile) & PSH_FLAG_RESERVE_CUS) && ncu >= 4 * PSH_STREAM_RESERVED_CUS) grid_s = ncu - PSH_STREAM_RESERVED_CUS;
+            const int64_t n_rs = p.R * nseg;
+            if (grid_s * (PSH_SCAN_THREADS / 64) > n_rs) grid_s = (n_rs + (PSH_SCAN_THREADS / 64) - 1) / (PSH_SCAN_THREADS / 64);
+            const int front = B == 1 ? PSH_FUSED_FRONT : 2 * PSH_FUSED_FRONT;
+            const int cand_cap = PSH_STREAM_CAND_CAP / B;
+            const int logical = PSH_SEG + p.W + 3;
+            const int tile_fl = (logical + ((logical >> 6) << 2) + 4 + 3) & ~3;
+            int tb = 0;
+            while ((1ll << tb) < p.Tp) ++tb;
+            if (stream_scan_shmem_bytes_q(tile_fl, B) <= PSH_LDS_BYTES && units_p >= 256 && r2p <= units_p / 2 &&
+                5 * (int64_t)k <= (int64_t)cand_cap && 5 * (int64_t)k * B <= grid_s * front * 2) {
+                Plan plan_s{(int)grid_s, 1, B, tile_fl, 0};
+                ScanArgs fa = make_scan_args(dataset, queries, p, w, plan_s, 0, 1, p.R);
+                fa.tile_floats = tile_fl;
+                fa.dbg_times = tn.dbg_times;
+                FusedArgs fu;
+                memset(&fu, 0, sizeof(fu));
+                fu.hdr = w.fused;
+                fu.boot_units = (int)units_p;
+                fu.boot_row_stride = p.R / rows_p;
+                fu.boot_row0 = fu.boot_row_stride / 2;
+                fu.rank = (int)r2p;
+                fu.qnorm_in = qnorm;
+                fu.out_d = out_d;
+                fu.out_idx = out_idx;
+                fu.status = out_status;
+                fu.total = w.total;
+                fu.tbits = ((p.R + p.r_offset) <= (1ll << (32 - tb))) ? tb : -1;   // rows r_offset .. r_offset + R - 1, t < Tp
+                fu.front = front;
+                fu.nq = B;
+                fu.units_stride = (int)((PSH_FUSED_MAX_UNITS / B) & ~3);
+                fu.cand_cap = cand_cap;
+                fu.k_out = k;
+                if (!(tn.stream_skip & 1)) HIP_TRY(launch_stream_sample(fa, fu, p.aligned, (int)grid_p, tile_floats_for(p.W), s));
+                if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_begin, s));
+                if (!(tn.stream_skip & 4)) HIP_TRY(launch_stream_scan(fa, fu, p.aligned, (int)grid_s, s));
+                if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_end, s));
+                // (~2.5 k candidates per query: <= 8 own ones per wave, ONE pass over all of them)
+                if (!(tn.stream_skip & 2)) HIP_TRY(launch_stream_rank(fa, fu, tn.stream_rgrid_per_cu * ncu, s));
+                if (profile) { profile->path = 3; profile->n_sample_rows = (int)rows_p; profile->grid_blocks = (int)grid_s; }
+                return PSH_OK;
+            }
+        }
+    }
+
     // ---- the whole step as ONE launch (psh_fused.hip): a single query on the matrix-core scan whose bootstrap sample is
     // one minimum per (row, segment) unit and fits the exchange area.  Anything that goes wrong inside raises
     // PSH_STATUS_RETRY in out_status and the caller reruns with PSH_FLAG_NO_FUSE.
@@ -706,47 +781,6 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
                 }
                 fu.xcd_skew = (plan_f.grid % 8 == 0) ? tuning().xcd_skew : 0;      // (a grid that is not whole rounds of the 8 XCDs: no assumption)
                 fa.dbg_times = tuning().dbg_times;
-                if (flags_of(profile) & PSH_FLAG_OVERLAP) {
-                    // the same step as three launches that can be co-resident with another stream's (psh_stream.hip):
-                    // sample + level (one-wave blocks), the scan (no barrier, no residency requirement), the ranking
-                    int ncu = 0;
-                    HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
-                    const Tuning tn = tuning();
-                    // a thinner sample than the fused launch's: its 16 MB are HBM traffic beside ANOTHER step's scan here.
-                    // 2048 units; the level is the (2k x sampled fraction + 8)-th smallest minimum: the k best windows of the
-                    // ensemble put 2k/2 x fraction = 16 expected minima below their level, P(Poisson(16) >= 40) = 3e-7 that
-                    // fewer than k windows lie below the estimate (-> PSH_STATUS_RETRY)
-                    int64_t rows_p = tn.stream_units / nseg;
-                    if (rows_p > p.R / 4) rows_p = p.R / 4;
-                    if (rows_p < 1) rows_p = 1;
-                    const int64_t units_p = rows_p * nseg;
-                    int64_t r2p = (2 * (int64_t)k * rows_p + p.R - 1) / p.R + 8;
-                    if (r2p < 24) r2p = 24;
-                    int64_t grid_p = (int64_t)tn.stream_pgrid_per_cu * ncu;
-                    if (grid_p > units_p) grid_p = units_p;
-                    int64_t grid_s = ncu;
-                    // a stream made by psh_stream_create_reserving: one block per compute unit the stream may use
-                    if ((flags_of(profile) & PSH_FLAG_RESERVE_CUS) && ncu >= 4 * PSH_STREAM_RESERVED_CUS) grid_s = ncu - PSH_STREAM_RESERVED_CUS;
-                    const int64_t n_rs = p.R * nseg;
-                    if (grid_s * (PSH_SCAN_THREADS / 64) > n_rs) grid_s = (n_rs + (PSH_SCAN_THREADS / 64) - 1) / (PSH_SCAN_THREADS / 64);
-                    int front = (int)(PSH_STREAM_CAND_CAP / grid_s);
-                    if (front > PSH_FUSED_FRONT) front = PSH_FUSED_FRONT;
-                    if (stream_scan_shmem_bytes(fa.tile_floats) <= PSH_LDS_BYTES &&
-                        units_p >= 256 && r2p <= units_p / 2 && 5 * (int64_t)k <= grid_s * front) {
-                        fu.boot_units = (int)units_p;
-                        fu.boot_row_stride = p.R / rows_p;
-                        fu.boot_row0 = fu.boot_row_stride / 2;
-                        fu.rank = (int)r2p;
-                        fu.front = front;
-                        if (!(tn.stream_skip & 1)) HIP_TRY(launch_stream_sample(fa, fu, p.aligned, (int)grid_p, tile_floats_for(p.W), s));
-                        if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_begin, s));
-                        if (!(tn.stream_skip & 4)) HIP_TRY(launch_stream_scan(fa, fu, p.aligned, (int)grid_s, s));
-                        if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_end, s));
-                        if (!(tn.stream_skip & 2)) HIP_TRY(launch_stream_rank(fa, fu, tn.stream_rgrid_per_cu * ncu, s));   // ~2.5k candidates: <= 8 own ones per wave, ONE pass over all of them
-                        if (profile) { profile->path = 3; profile->n_sample_rows = (int)rows_p; profile->grid_blocks = (int)grid_s; }
-                        return PSH_OK;
-                    }
-                }
                 // (a caller that asked for the overlap-friendly launches may be on a stream that cannot hold the fused
                 //  launch's blocks all at once -- a CU mask, other scans in flight: where they do not apply, the separate
                 //  launches serve the call, never the fused one)

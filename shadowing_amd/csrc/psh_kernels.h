@@ -51,13 +51,14 @@ struct QueryState {   // one per query, device, 48 bytes
 #define PSH_FUSED_FRONT 64           // candidates a block may hand to the distributed selection (~8 expected)
 // the overlap-friendly three-launch step (psh_stream.hip): what its launches hand to each other.  Kernel boundaries on the
 // caller's stream are the synchronisation; the two counters are device-scope atomics.
+#define PSH_STREAM_MAX_Q 3           // queries one overlap-friendly step serves (their B fragments sit in LDS beside the scan's tiles)
 struct StreamCtl {
-    unsigned ticket;                 // sample kernel: blocks that have arrived (the last one derives the level); left at 0
-    unsigned ncand;                  // scan kernel: candidates appended to FusedHdr::cand (zeroed by the sample kernel)
-    unsigned ovf;                    // scan kernel: a block met more than PSH_FUSED_FRONT candidates
-    unsigned armed;                  // sample kernel: 1 = the four words below are valid
-    unsigned tau2_bits, thr2_bits, scale_bits, xn_bits;
-    unsigned pad[8];
+    unsigned ticket;                 // sample kernel: blocks that have arrived (the last one derives the levels); left at 0
+    unsigned ovf;                    // scan kernel: a block met more candidates than its list holds
+    unsigned armed;                  // sample kernel: 1 = the words below are valid
+    unsigned scale_bits;             // the f16 scale (ONE for all queries of the step: the largest every query's proof allows)
+    unsigned ncand[4];               // scan kernel: candidates appended to query q's region of FusedHdr::cand (zeroed by the sample kernel)
+    unsigned tau2_bits[4], thr2_bits[4], xn_bits[4];   // per query: admission level, rejection threshold, ||x||
 };
 #define PSH_STREAM_CAND_CAP (PSH_FUSED_MAX_BLOCKS * PSH_FUSED_FRONT)     // 16-byte entries FusedHdr::cand holds
 struct FusedHdr {
@@ -72,7 +73,7 @@ struct FusedHdr {
     unsigned long long cand[PSH_FUSED_MAX_BLOCKS * PSH_FUSED_FRONT * 2];   // {r << 32 | d bits, t}
     // psh_stream.hip: the B fragments of the shifted query the sample kernel prepares for the scan (whose candidates go to
     // `cand` as ONE compact list of {d bits, r, t, -} entries, StreamCtl::ncand of them)
-    unsigned short bxtab[4 * 64 * 8];                        // [K-step][lane][8 halves]: -2 x~ shifted by the lane's column
+    unsigned short bxtab[PSH_STREAM_MAX_Q * 4 * 64 * 8];     // [query][K-step][lane][8 halves]: -2 x~ shifted by the lane's column
 };
 #define PSH_FUSED_BYTES ((sizeof(psh::FusedHdr) + 255) / 256 * 256)
 
@@ -89,7 +90,11 @@ struct FusedArgs {
     long long spin_ticks;            // give-up time of a poll in wall-clock ticks (100 MHz)
     int xcd_skew;                    // of the units of a pair of blocks (2j, 2j + 1) the even one takes (256 + xcd_skew) / 512
     int tbits;                       // ranking: (r, t) packs into 32 bits as r << tbits | t (-1: it does not -- the three-word compare)
-    int front;                       // stream scan: candidates a block may hold (<= PSH_FUSED_FRONT; PSH_STREAM_CAND_CAP / blocks)
+    int front;                       // stream scan: candidates a block may hold (all its queries together)
+    int nq;                          // stream launches: queries of the step (<= PSH_STREAM_MAX_Q)
+    int units_stride;                // stream launches: query q's sampled minima start at minima[q * units_stride]
+    int cand_cap;                    // stream launches: entries of a query's region of `cand` (query q: cand + q * cand_cap entries)
+    int k_out;                       // stream launches: row length of out_d / out_idx (= k)
 };
 
 struct PrepArgs {
@@ -284,6 +289,7 @@ size_t stream_scan_shmem_bytes(int tile_floats);
 hipError_t launch_stream_sample(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, int sample_tile_floats, hipStream_t s);
 hipError_t launch_stream_scan(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, hipStream_t s);
 hipError_t launch_stream_rank(const ScanArgs& a, const FusedArgs& f, int grid, hipStream_t s);
+size_t stream_scan_shmem_bytes_q(int tile_floats, int nq);
 hipError_t launch_embed_rows(const float* dataset, int64_t R, int64_t T, const float* ker, int d, int K, float* out, hipStream_t s);
 
 }  // namespace psh

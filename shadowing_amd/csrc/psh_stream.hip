@@ -20,6 +20,12 @@
 // and R(i-1) run BESIDE S(i) of another stream, and the blocks of S(i+1) start on a CU the moment S(i)'s block leaves it
 // (no barrier inside S: an XCD that finishes early is refilled early).  Kernel boundaries are the only synchronisation;
 // the status protocol is the fused launch's (anything unusual -> PSH_STATUS_RETRY -> the caller's separate launches).
+//
+// Two or three queries (PSH_STREAM_MAX_Q) ride the same three launches: a sampled unit and a scanned unit are loaded and
+// converted ONCE, the window energies are one banded product, and every query adds four MFMAs with its own shifted-query
+// fragments and a threshold test, so a batch of 2 or 3 costs little more than one query, where the batched scan
+// (scan_mq_kernel: 8 waves per CU, sized for hundreds of queries) streams at half rate.  One f16 scale serves all queries of
+// the step: the largest that every query's proof allows (each query bounds it from above by its own max|x| and tau2).
 #include "psh_device.h"
 
 namespace psh {
@@ -38,19 +44,19 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t st_rsrc(const void* base, unsi
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// P: the sample and the admission level
+// P: the sample and the admission levels
 // ------------------------------------------------------------------------------------------------------------------
 #define PSH_STREAM_HIST 1024
 
-// what the last block derives from the minima: scan_fused_kernel's phase B (same formulas, same roundings towards "keep")
-__device__ inline bool stream_derive(const_f32p xq, int W, float edge_value, const float* qnorm_in, StreamCtl* ctl) {
-    const float tau0 = edge_value * PSH_TAU_MARGIN;
-    const float s = sumsq8([&](int j) { return xq[j]; }, W);
-    const float xn = qnorm_in ? qnorm_in[0] : __builtin_sqrtf(s);
+// scan_fused_kernel's phase B in two steps (same formulas, same roundings towards "keep"): the largest scale exponent a
+// query allows -- scale = 2^sexp with max|x| 2^sexp < 8 and tau0 4^sexp <= 4096 -- then, under the step's common scale,
+// the query's rejection threshold.
+__device__ inline bool stream_sexp(const_f32p xq, int W, float tau0, int* sexp_out) {
     unsigned qmaxbits = 0u;
+#pragma unroll 1
     for (int j = 0; j < W; ++j) qmaxbits = max(qmaxbits, __float_as_uint(fabsf(xq[j])));
     if (!(tau0 > 0.0f && tau0 < __uint_as_float(PSH_INF_BITS) && qmaxbits < PSH_INF_BITS)) return false;
-    // scale = 2^sexp: max|x| 2^sexp < 8 and tau0 4^sexp <= 4096 (exponents of the bit patterns: value in [2^(e-1), 2^e))
+    // (exponents of the bit patterns: value in [2^(e-1), 2^e))
     const int et = (int)((__float_as_uint(tau0) >> 23) & 255u) - 126;
     int sexp = (12 - et) >= 0 ? (12 - et) / 2 : -((et - 12 + 1) / 2);
     if (qmaxbits >= 0x00800000u) {
@@ -58,8 +64,12 @@ __device__ inline bool stream_derive(const_f32p xq, int W, float edge_value, con
         sexp = sexp < 3 - eq ? sexp : 3 - eq;
     }
     if (!(sexp <= 60 && sexp >= -60 && __float_as_uint(tau0) >= 0x00800000u)) return false;
-    const float sc = __uint_as_float((unsigned)(127 + sexp) << 23);
+    *sexp_out = sexp;
+    return true;
+}
+__device__ inline bool stream_threshold(const_f32p xq, int W, float tau0, float sc, float* thr_out) {
     double nxs = 0.0;
+#pragma unroll 1
     for (int j = 0; j < W; ++j) { const double vv = (double)xq[j] * (double)sc; nxs += vv * vv; }
     const double am = 1.0 / 512.0, bm = 1.0 / 262144.0;
     const double taus = (double)tau0 * (double)sc * (double)sc;
@@ -67,10 +77,7 @@ __device__ inline bool stream_derive(const_f32p xq, int W, float edge_value, con
     float Tf = (float)T;
     if ((double)Tf < T) Tf = __uint_as_float(Tf >= 0.0f ? __float_as_uint(Tf) + 1u : __float_as_uint(Tf) - 1u);
     if (!(Tf == Tf && fabsf(Tf) < __uint_as_float(PSH_INF_BITS))) return false;
-    ctl->tau2_bits = __float_as_uint(tau0);
-    ctl->thr2_bits = __float_as_uint(Tf);
-    ctl->scale_bits = __float_as_uint(sc);
-    ctl->xn_bits = __float_as_uint(xn);
+    *thr_out = Tf;
     return true;
 }
 
@@ -88,7 +95,7 @@ void stream_sample_kernel(ScanArgs a, FusedArgs f) {
     StreamCtl* ctl = &hdr->stream;
     const int W = WT > 0 ? WT : a.W;
     const int nfloat = PSH_SEG + W - 1;
-    const const_f32p x = (const_f32p)a.queries;
+    const int nq = f.nq;
     const unsigned nbu = (unsigned)f.boot_units;
 
     auto boot_load = [&](Stage& sx, unsigned uu) {
@@ -101,7 +108,7 @@ void stream_sample_kernel(ScanArgs a, FusedArgs f) {
     // a header psh_workspace_init never saw: no ticket can be trusted -- block 0 says so, the scan and the ranking return
     const bool armed_hdr = hdr->magic == PSH_FUSED_MAGIC;
     if (!armed_hdr) {
-        if (blockIdx.x == 0 && lane == 0) { ctl->armed = 0u; ctl->ncand = 0u; ctl->ovf = 0u; }
+        if (blockIdx.x == 0 && lane == 0) { ctl->armed = 0u; ctl->ovf = 0u; for (int q = 0; q < 4; ++q) ctl->ncand[q] = 0u; }
         return;
     }
     while (u < nbu) {
@@ -120,16 +127,19 @@ void stream_sample_kernel(ScanArgs a, FusedArgs f) {
         int nvalid = a.Tp - t_lane;
         nvalid = nvalid < 0 ? 0 : (nvalid > PSH_L ? PSH_L : nvalid);
         // the exact chains of the lane's 16 windows, taps from the scalar cache (few registers: this wave lives in the 64
-        // VGPRs four scan waves leave on a SIMD; the sample is ~3 % of a scan's arithmetic)
-        float acc[PSH_L];
-        accumulate16<WT, false>(tile, lane, x, W, acc);
-        float m = __uint_as_float(PSH_INF_BITS);
+        // VGPRs four scan waves leave on a SIMD; the sample is ~3 % of a scan's arithmetic); the unit serves every query
+#pragma unroll 1
+        for (int q = 0; q < nq; ++q) {
+            float acc[PSH_L];
+            accumulate16<WT, false>(tile, lane, (const_f32p)a.queries + (size_t)q * W, W, acc);
+            float m = __uint_as_float(PSH_INF_BITS);
 #pragma unroll
-        for (int i = 0; i < PSH_L; ++i) m = (i < nvalid) ? fminf(m, acc[i]) : m;
+            for (int i = 0; i < PSH_L; ++i) m = (i < nvalid) ? fminf(m, acc[i]) : m;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
-        if (!(m == m)) m = __uint_as_float(PSH_INF_BITS);                  // NaN data: the segment carries no information
-        if (lane == 0) st_sc1(&hdr->minima[u], __float_as_uint(m));        // write-through
+            for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+            if (!(m == m)) m = __uint_as_float(PSH_INF_BITS);              // NaN data: the segment carries no information
+            if (lane == 0) st_sc1(&hdr->minima[(size_t)q * f.units_stride + u], __float_as_uint(m));   // write-through
+        }
         wave_lds_fence();
         u = un;
     }
@@ -140,141 +150,164 @@ void stream_sample_kernel(ScanArgs a, FusedArgs f) {
     tk = (unsigned)__builtin_amdgcn_readfirstlane((int)tk);
     if (tk != gridDim.x - 1u) return;
 
-    // ---- the last block: rank-th smallest minimum -> tau2 (its bucket's upper edge), scale, threshold
+    // ---- the last block, per query: rank-th smallest minimum -> tau0 (its bucket's upper edge) and the scale it allows
     unsigned* hist = reinterpret_cast<unsigned*>(smem);
-    for (int i = lane; i < PSH_STREAM_HIST; i += 64) hist[i] = 0u;
-    const __amdgpu_buffer_rsrc_t rmin = st_rsrc(hdr->minima, sizeof(hdr->minima));
-    const int n4 = ((int)nbu + 3) >> 2;                      // 16-byte groups of minima (the array is PSH_FUSED_MAX_UNITS long)
-    unsigned kmin = 0xffffffffu, kmax = 0u;
-    int nfin = 0;
-    for (int g0 = 0; g0 < n4; g0 += 64 * 4) {
-        u32x4v mv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int g = g0 + lane + 64 * q;
-            mv[q] = __builtin_amdgcn_raw_buffer_load_b128(rmin, (g < n4 ? g : 0) * 16, 0, PSH_AUX_SC1);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int g = g0 + lane + 64 * q;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (g < n4 && 4 * g + e < (int)nbu && mv[q][e] < PSH_INF_BITS) {
-                    kmin = mv[q][e] < kmin ? mv[q][e] : kmin; kmax = mv[q][e] > kmax ? mv[q][e] : kmax; ++nfin;
-                }
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned l2 = __shfl_xor(kmin, off, 64), h2 = __shfl_xor(kmax, off, 64);
-        kmin = l2 < kmin ? l2 : kmin;
-        kmax = h2 > kmax ? h2 : kmax;
-        nfin += __shfl_xor(nfin, off, 64);
-    }
-    bool armed = nfin >= f.rank;
-    unsigned edge = 0u;
-    if (armed) {
-        const unsigned range = kmax - kmin;
-        const int hb = range ? 32 - __builtin_clz(range) : 0;
-        const int shift = hb > 10 ? hb - 10 : 0;                          // (range >> shift) < 1024
+    const int n4 = ((int)nbu + 3) >> 2;                      // 16-byte groups of a query's minima
+    bool armed = true;
+    int sexp_common = 1000;
+    float tau0q[PSH_STREAM_MAX_Q];
+#pragma unroll 1
+    for (int q = 0; q < nq; ++q) {
+        const __amdgpu_buffer_rsrc_t rmin = st_rsrc(hdr->minima + (size_t)q * f.units_stride, (unsigned)(4 * n4) * 4u);
         wave_lds_fence();
+        for (int i = lane; i < PSH_STREAM_HIST; i += 64) hist[i] = 0u;
+        unsigned kmin = 0xffffffffu, kmax = 0u;
+        int nfin = 0;
         for (int g0 = 0; g0 < n4; g0 += 64 * 4) {
             u32x4v mv[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int g = g0 + lane + 64 * q;
-                mv[q] = __builtin_amdgcn_raw_buffer_load_b128(rmin, (g < n4 ? g : 0) * 16, 0, PSH_AUX_SC1);
+            for (int c = 0; c < 4; ++c) {
+                const int g = g0 + lane + 64 * c;
+                mv[c] = __builtin_amdgcn_raw_buffer_load_b128(rmin, (g < n4 ? g : 0) * 16, 0, PSH_AUX_SC1);
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int g = g0 + lane + 64 * q;
+            for (int c = 0; c < 4; ++c) {
+                const int g = g0 + lane + 64 * c;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (g < n4 && 4 * g + e < (int)nbu && mv[q][e] < PSH_INF_BITS) atomicAdd(&hist[(mv[q][e] - kmin) >> shift], 1u);
+                    if (g < n4 && 4 * g + e < (int)nbu && mv[c][e] < PSH_INF_BITS) {
+                        kmin = mv[c][e] < kmin ? mv[c][e] : kmin; kmax = mv[c][e] > kmax ? mv[c][e] : kmax; ++nfin;
+                    }
             }
         }
-        wave_lds_fence();
-        constexpr int PER = PSH_STREAM_HIST / 64;
-        unsigned h[PER];
-        unsigned sl = 0;
 #pragma unroll
-        for (int q = 0; q < PER; ++q) { h[q] = hist[PER * lane + q]; sl += h[q]; }
-        unsigned inc = sl;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned t2 = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += t2;
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned l2 = __shfl_xor(kmin, off, 64), h2 = __shfl_xor(kmax, off, 64);
+            kmin = l2 < kmin ? l2 : kmin;
+            kmax = h2 > kmax ? h2 : kmax;
+            nfin += __shfl_xor(nfin, off, 64);
         }
-        unsigned cum = inc - sl;
-        const unsigned rk = (unsigned)f.rank;
-        unsigned my_edge = 0u;
-        const bool mine = cum < rk && inc >= rk;                         // exactly one lane
-        if (mine) {
-            int bucket = PER * lane;
+        unsigned edge = 0u;
+        if (nfin >= f.rank) {
+            const unsigned range = kmax - kmin;
+            const int hb = range ? 32 - __builtin_clz(range) : 0;
+            const int shift = hb > 10 ? hb - 10 : 0;                      // (range >> shift) < 1024
+            wave_lds_fence();
+            for (int g0 = 0; g0 < n4; g0 += 64 * 4) {
+                u32x4v mv[4];
 #pragma unroll
-            for (int q = 0; q < PER; ++q) {
-                if (cum < rk && cum + h[q] >= rk) bucket = PER * lane + q;
-                cum += h[q];
+                for (int c = 0; c < 4; ++c) {
+                    const int g = g0 + lane + 64 * c;
+                    mv[c] = __builtin_amdgcn_raw_buffer_load_b128(rmin, (g < n4 ? g : 0) * 16, 0, PSH_AUX_SC1);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int g = g0 + lane + 64 * c;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (g < n4 && 4 * g + e < (int)nbu && mv[c][e] < PSH_INF_BITS) atomicAdd(&hist[(mv[c][e] - kmin) >> shift], 1u);
+                }
             }
-            // every minimum in buckets <= `bucket` is at or below the bucket's upper edge, and there are >= rank of them
-            u64 e2 = (u64)kmin + (((u64)bucket + 1ull) << shift) - 1ull;
-            if (e2 > (u64)kmax) e2 = kmax;
-            my_edge = (unsigned)e2;
+            wave_lds_fence();
+            constexpr int PER = PSH_STREAM_HIST / 64;
+            unsigned h[PER];
+            unsigned sl = 0;
+#pragma unroll
+            for (int c = 0; c < PER; ++c) { h[c] = hist[PER * lane + c]; sl += h[c]; }
+            unsigned inc = sl;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned t2 = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += t2;
+            }
+            unsigned cum = inc - sl;
+            const unsigned rk = (unsigned)f.rank;
+            unsigned my_edge = 0u;
+            const bool mine = cum < rk && inc >= rk;                     // exactly one lane
+            if (mine) {
+                int bucket = PER * lane;
+#pragma unroll
+                for (int c = 0; c < PER; ++c) {
+                    if (cum < rk && cum + h[c] >= rk) bucket = PER * lane + c;
+                    cum += h[c];
+                }
+                // every minimum in buckets <= `bucket` is at or below the bucket's upper edge, and there are >= rank of them
+                u64 e2 = (u64)kmin + (((u64)bucket + 1ull) << shift) - 1ull;
+                if (e2 > (u64)kmax) e2 = kmax;
+                my_edge = (unsigned)e2;
+            }
+            const u64 who = __ballot(mine);
+            edge = (unsigned)__builtin_amdgcn_readlane((int)my_edge, who ? (int)__builtin_ctzll(who) : 0);
+        } else {
+            armed = false;
         }
-        const u64 who = __ballot(mine);
-        edge = (unsigned)__builtin_amdgcn_readlane((int)my_edge, who ? (int)__builtin_ctzll(who) : 0);
+        tau0q[q] = __uint_as_float(edge) * PSH_TAU_MARGIN;
+        int sx = 0;
+        if (armed && !stream_sexp((const_f32p)a.queries + (size_t)q * W, W, tau0q[q], &sx)) armed = false;   // (uniform: scalar inputs)
+        sexp_common = sx < sexp_common ? sx : sexp_common;
     }
-    unsigned sbits = 0u;
-    if (lane == 0) {
-        if (armed) armed = stream_derive(x, W, __uint_as_float(edge), f.qnorm_in, ctl);
-        ctl->armed = armed ? 1u : 0u;
-        ctl->ncand = 0u;
-        ctl->ovf = 0u;
-        ctl->ticket = 0u;                                                 // the next launch on this workspace counts from zero
-        sbits = armed ? ctl->scale_bits : 0u;
-    }
-    // the scan's B fragments of the shifted query (column n of K-step s holds -2 x~[16 s + 8 hk + i - n]): prepared ONCE
-    // here, a 4 KB table every scan block fetches with four 16-byte loads per lane instead of 32 scattered ones
-    const float scale = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)sbits));
-    {
+    // ---- ONE scale for the step (every query's conditions bound it from above), then every query's threshold and fragments
+    const float scale = armed ? __uint_as_float((unsigned)(127 + sexp_common) << 23) : 0.0f;
+#pragma unroll 1
+    for (int q = 0; q < nq; ++q) {
+        const const_f32p xq = (const_f32p)a.queries + (size_t)q * W;
+        float thr = 0.0f;
+        if (armed && !stream_threshold(xq, W, tau0q[q], scale, &thr)) armed = false;
+        if (lane == 0) {
+            const float s2 = sumsq8([&](int j) { return xq[j]; }, W);
+            ctl->tau2_bits[q] = __float_as_uint(tau0q[q]);
+            ctl->thr2_bits[q] = __float_as_uint(thr);
+            ctl->xn_bits[q] = __float_as_uint(f.qnorm_in ? f.qnorm_in[q] : __builtin_sqrtf(s2));
+            ctl->ncand[q] = 0u;
+        }
+        // the scan's B fragments of the shifted query (column n of K-step s holds -2 x~[16 s + 8 hk + i - n]): prepared ONCE
+        // here, a 4 KB table every scan block fetches with four 16-byte loads per lane instead of 32 scattered ones
         const int n = lane & 31, hk = lane >> 5;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
+#pragma unroll 1
+        for (int s = 0; s < 4; ++s) {                        // (once per launch: compact code, not speed)
             f16x8 b;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int j = 16 * s + 8 * hk + i - n;
                 const bool in = j >= 0 && j < W;
-                const float xv = x[in ? j : 0];
+                const float xv = a.queries[(size_t)q * W + (in ? j : 0)];
                 b[i] = (_Float16)(in ? -2.0f * (xv * scale) : 0.0f);
             }
-            *reinterpret_cast<f16x8*>(hdr->bxtab + (size_t)(s * 64 + lane) * 8) = b;
+            *reinterpret_cast<f16x8*>(hdr->bxtab + ((size_t)q * 4 * 64 + (size_t)(s * 64 + lane)) * 8) = b;
         }
+    }
+    if (lane == 0) {
+        ctl->scale_bits = __float_as_uint(scale);
+        ctl->armed = armed ? 1u : 0u;
+        ctl->ovf = 0u;
+        ctl->ticket = 0u;                                                 // the next launch on this workspace counts from zero
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // S: the scan
 // ------------------------------------------------------------------------------------------------------------------
-#define PSH_STREAM_FIXED_BYTES 1280   // control words + the block's front list
+#define PSH_STREAM_FIXED_BYTES 256    // control words; the block's candidate list follows
+#define PSH_STREAM_FL(NQ) ((NQ) == 1 ? PSH_FUSED_FRONT : 2 * PSH_FUSED_FRONT)
 enum { S_FRONT = 0, S_NEXT = 1 };
 
-template <int WT, bool ALIGNED>
-__global__ __launch_bounds__(PSH_SCAN_THREADS) __attribute__((amdgpu_num_vgpr(56)))   // (56 arch + 56 acc = 112 of the unified file)
-void stream_scan_kernel(ScanArgs a, FusedArgs f) {
+template <int WT, bool ALIGNED, int NQ>
+__device__ __forceinline__ void stream_scan_body(const ScanArgs& a, const FusedArgs& f) {
     static_assert(WT >= 0 && WT <= 33, "the shifted-query band must fit K = 64 (WT = 0: run-time W <= 33)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NW = PSH_SCAN_THREADS / 64;
+    constexpr int NFL = PSH_STREAM_FL(NQ);
     const int lane = lane_id();
     const int tid = (int)threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int* ctl = reinterpret_cast<int*>(smem);                                 // 64 control words
-    u32x4* fl = reinterpret_cast<u32x4*>(ctl + 64);                           // PSH_FUSED_FRONT entries {acc bits, r, t, -}
-    float* tiles = smem + PSH_STREAM_FIXED_BYTES / 4;
+    u32x4* fl = reinterpret_cast<u32x4*>(ctl + 64);                           // NFL entries {acc bits, r, t, query}
+    float* tiles = reinterpret_cast<float*>(fl + NFL);
     float* tile = tiles + (size_t)wave * a.tile_floats;
     _Float16* ah0 = reinterpret_cast<_Float16*>(tiles + (size_t)NW * a.tile_floats);
     _Float16* a1 = ah0 + (size_t)wave * 2 * PSH_MX_NHALF;                     // y^
     _Float16* a2 = a1 + PSH_MX_NHALF;                                         // (y~^2)^
+    _Float16* bxl = ah0 + (size_t)NW * 2 * PSH_MX_NHALF;                      // NQ > 1: the other queries' fragment tables, 4 KB each
     FusedHdr* hdr = f.hdr;
     const StreamCtl* sc = &hdr->stream;
     auto stamp = [&](int i) { if (a.dbg_times && tid == 0) a.dbg_times[(size_t)blockIdx.x * 8 + i] = (unsigned long long)wall_clock64(); };
@@ -282,7 +315,6 @@ void stream_scan_kernel(ScanArgs a, FusedArgs f) {
 
     const int W = WT > 0 ? WT : a.W;
     const int nfloat = PSH_SEG + W - 1;
-    const const_f32p x = (const_f32p)a.queries;
     const unsigned n_rs = (unsigned)a.n_rows * (unsigned)a.nseg;
     const unsigned u_lo = (unsigned)(((u64)n_rs * blockIdx.x) / gridDim.x);
     const unsigned u_hi = (unsigned)(((u64)n_rs * (blockIdx.x + 1u)) / gridDim.x);
@@ -300,16 +332,27 @@ void stream_scan_kernel(ScanArgs a, FusedArgs f) {
     Stage st;
     unsigned u = u_lo + (unsigned)wave;
     if (u < u_hi) load_unit(st, u);
-    // what the sample kernel left (an earlier launch on this stream: plain loads): the shifted-query fragments ...
+    // what the sample kernel left (an earlier launch on this stream: plain loads): the shifted-query fragments -- the first
+    // query's in registers, a second and third query's block-shared in LDS, read per use (registers: acc + a query's own
+    // accumulators + one set of fragments is what fits 128; the LDS pipe is this kernel's co-limit, 27 KB of traffic per unit and
+    // wave being 80 % of what it delivers in a unit's time, so every query read from LDS costs ~12 %) ...
     f16x8 bx[4], bo[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) bx[s] = *reinterpret_cast<const f16x8*>(hdr->bxtab + (size_t)(s * 64 + lane) * 8);
-    // ... and the admission level (scalar loads; first needed inside the loop, so the set-up below runs under their latency)
+    if constexpr (NQ > 1) {
+        for (int i = tid; i < (NQ - 1) * 4 * 64; i += PSH_SCAN_THREADS)
+            *reinterpret_cast<f16x8*>(bxl + (size_t)i * 8) = *reinterpret_cast<const f16x8*>(hdr->bxtab + ((size_t)4 * 64 + (size_t)i) * 8);
+    }
+    // ... and the admission levels (scalar loads; first needed inside the loop, so the set-up below runs under their latency)
     const unsigned armed_w = sc->armed;
-    const float tau2 = __uint_as_float(sc->tau2_bits);
-    const float thr2 = __uint_as_float(sc->thr2_bits);
     const float scale = __uint_as_float(sc->scale_bits);
-    const float xn = __uint_as_float(sc->xn_bits);
+    float tau2[NQ], thr2[NQ], xn[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        tau2[q] = __uint_as_float(sc->tau2_bits[q]);
+        thr2[q] = __uint_as_float(sc->thr2_bits[q]);
+        xn[q] = __uint_as_float(sc->xn_bits[q]);
+    }
     if (tid == 0) { ctl[S_FRONT] = 0; ctl[S_NEXT] = NW; }
     {   // every slot of the f16 arrays a segment does not write must be finite (0 * NaN poisons a row)
         unsigned* z = reinterpret_cast<unsigned*>(a1);
@@ -333,6 +376,32 @@ void stream_scan_kernel(ScanArgs a, FusedArgs f) {
         if (lane == 0) v = atomicAdd(&ctl[S_NEXT], 1);
         return u_lo + (unsigned)__builtin_amdgcn_readfirstlane(v);
     };
+    // the survivors of one query's accumulator tile: exact chain from the fp32 tile, admitted below the query's level
+    auto admit = [&](const f32x16& acc, int q, float thr, float tau, int seg_start, int r_global) {
+        const int m = lane & 31, hk = lane >> 5;
+        const const_f32p x = (const_f32p)a.queries + (size_t)q * W;
+        unsigned hm = 0u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hm |= !(acc[r] > thr) ? (1u << r) : 0u;
+#pragma unroll 1
+        for (int r = 0; r < 16; ++r) {
+            const int p = 32 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + m;         // C layout: row -> window
+            bool hit = (((hm >> r) & 1u) != 0u) && (seg_start + p < a.Tp);
+            if (!__ballot(hit)) continue;
+            float v = 0.0f;
+            if (hit) { if constexpr (WT > 0) v = exact_one<(WT > 0 ? WT : 20)>(tile, p, x); else v = exact_one_rt(tile, p, x, W); }
+            hit = hit && (v < tau);
+            const unsigned long long mask = __ballot(hit);
+            if (!mask) continue;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&ctl[S_FRONT], __popcll(mask));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (hit) {
+                const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                if (slot < NFL) fl[slot] = u32x4{__float_as_uint(v), (unsigned)r_global, (unsigned)(seg_start + p), (unsigned)q};
+            }
+        }
+    };
     while (u < u_hi) {
         unsigned ri, sg;
         decode(u, ri, sg);
@@ -343,11 +412,11 @@ void stream_scan_kernel(ScanArgs a, FusedArgs f) {
         stage_store(st, tile, nfloat, lane);
         if (a.dbg_times && tid == 0 && u == u_lo) a.dbg_times[(size_t)blockIdx.x * 8 + 4] = (unsigned long long)wall_clock64();   // first data in the tile
         {
-            const int nq = (nfloat + 3) >> 2;
+            const int nq4 = (nfloat + 3) >> 2;
 #pragma unroll
             for (int q = 0; q < PSH_NSTAGE; ++q) {
                 const int m = lane + 64 * q;
-                if (q < PSH_NSTAGE - 1 || m < nq) {
+                if (q < PSH_NSTAGE - 1 || m < nq4) {
                     const f32x4 v = st.v[q] * scale;
                     const f32x4 v2 = v * v;
                     *reinterpret_cast<f16x4*>(a1 + mx_half(4 * m)) = __builtin_convertvector(v, f16x4);
@@ -370,83 +439,113 @@ void stream_scan_kernel(ScanArgs a, FusedArgs f) {
         for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s], bo[s], acc, 0, 0, 0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) fa[s] = *reinterpret_cast<const f16x8*>(a1 + mx_half(32 * m + 16 * s + 8 * hk));
+        if constexpr (NQ == 1) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s], bx[s], acc, 0, 0, 0);
-        bool keep = false;                                 // NaN-safe: !(t^ > thr)
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s], bx[s], acc, 0, 0, 0);
+            bool keep = false;                             // NaN-safe: !(t^ > thr)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) keep = keep || !(acc[r] > thr2);
-        if (__any(keep)) {
-            unsigned hm = 0u;
+            for (int r = 0; r < 16; ++r) keep = keep || !(acc[r] > thr2[0]);
+            if (__any(keep)) admit(acc, 0, thr2[0], tau2[0], seg_start, r_global);
+        } else {
+            // the window energies are in `acc`; every query adds its own banded product on top of them (the energies are the
+            // C operand of its first MFMA: no copy); the last query works in place
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hm |= !(acc[r] > thr2) ? (1u << r) : 0u;
-#pragma unroll 1
-            for (int r = 0; r < 16; ++r) {
-                const int p = 32 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + m;      // C layout: row -> window
-                bool hit = (((hm >> r) & 1u) != 0u) && (seg_start + p < a.Tp);
-                if (!__ballot(hit)) continue;
-                float v = 0.0f;
-                if (hit) { if constexpr (WT > 0) v = exact_one<(WT > 0 ? WT : 20)>(tile, p, x); else v = exact_one_rt(tile, p, x, W); }
-                hit = hit && (v < tau2);
-                const unsigned long long mask = __ballot(hit);
-                if (!mask) continue;
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&ctl[S_FRONT], __popcll(mask));
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (hit) {
-                    const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                    if (slot < f.front) fl[slot] = u32x4{__float_as_uint(v), (unsigned)r_global, (unsigned)(seg_start + p), 0u};
-                }
+            for (int q = 1; q < NQ; ++q) {
+                const _Float16* bp = bxl + ((size_t)(q - 1) * 4 * 64 + (size_t)lane) * 8;
+                f32x16 aq = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0], *reinterpret_cast<const f16x8*>(bp), acc, 0, 0, 0);
+#pragma unroll
+                for (int s = 1; s < 4; ++s) aq = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s], *reinterpret_cast<const f16x8*>(bp + (size_t)s * 64 * 8), aq, 0, 0, 0);
+                bool keep = false;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) keep = keep || !(aq[r] > thr2[q]);
+                if (__any(keep)) admit(aq, q, thr2[q], tau2[q], seg_start, r_global);
             }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s], bx[s], acc, 0, 0, 0);
+            bool keep = false;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) keep = keep || !(acc[r] > thr2[0]);
+            if (__any(keep)) admit(acc, 0, thr2[0], tau2[0], seg_start, r_global);
         }
         wave_lds_fence();  // all lanes done with the tile before it is overwritten
         u = un;
     }
     stamp(2);
     __syncthreads();
-    // the block's candidates (distances in place of acc) go to ONE compact list behind ONE device-scope atomicAdd per block
-    // (0.3 us of a block's 75; a list per block made the ranking search for every candidate's slot: 60 us instead of 9)
+    // the block's candidates (distances in place of acc) go to ONE compact list per query behind ONE device-scope atomicAdd per
+    // block and query (0.3 us of a block's 75; a list per block made the ranking search for every candidate's slot: 60 us
+    // instead of 9)
     if (wave == 0) {
         const int nfront = ctl[S_FRONT];
-        const int mown = nfront < f.front ? nfront : f.front;
-        unsigned base = 0u;
-        if (lane == 0 && mown > 0) base = __hip_atomic_fetch_add((gu32*)&hdr->stream.ncand, (unsigned)mown, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-        if (lane < mown && base + (unsigned)lane < PSH_STREAM_CAND_CAP) {
-            u32x4 e = fl[lane];
-            e[0] = __float_as_uint(dist_from_acc(__uint_as_float(e[0]), xn));
-            reinterpret_cast<u32x4*>(hdr->cand)[base + (unsigned)lane] = e;
+        const int mown = nfront < NFL ? nfront : NFL;
+#pragma unroll
+        for (int c0 = 0; c0 < NFL; c0 += 64) {
+            if (c0 >= mown) break;
+            const bool have = c0 + lane < mown;
+            u32x4 e = have ? fl[c0 + lane] : u32x4{0u, 0u, 0u, 0xffffffffu};
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const bool mine = have && (int)e[3] == q;
+                const unsigned long long mask = __ballot(mine);
+                if (!mask) continue;
+                unsigned base = 0u;
+                if (lane == 0) base = __hip_atomic_fetch_add((gu32*)&hdr->stream.ncand[q], (unsigned)__popcll(mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                if (mine) {
+                    const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    if (slot < (unsigned)f.cand_cap) {
+                        u32x4 o = e;
+                        o[0] = __float_as_uint(dist_from_acc(__uint_as_float(e[0]), xn[q]));
+                        reinterpret_cast<u32x4*>(hdr->cand)[(size_t)q * f.cand_cap + slot] = o;
+                    }
+                }
+            }
         }
-        if (lane == 0 && nfront > f.front) __hip_atomic_store((gu32*)&hdr->stream.ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0 && nfront > NFL) __hip_atomic_store((gu32*)&hdr->stream.ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     stamp(3);
 }
 
+// one query: 112 registers (56 arch + 56 acc of the unified file), so that a sample or ranking wave of another stream's step fits
+// beside four of these on a SIMD; two or three queries: the whole file (their steps are rarely run beside others)
+template <int WT, bool ALIGNED>
+__global__ __launch_bounds__(PSH_SCAN_THREADS) __attribute__((amdgpu_num_vgpr(56))) void stream_scan_kernel(ScanArgs a, FusedArgs f) {
+    stream_scan_body<WT, ALIGNED, 1>(a, f);
+}
+template <int WT, bool ALIGNED, int NQ>
+__global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_q_kernel(ScanArgs a, FusedArgs f) {
+    stream_scan_body<WT, ALIGNED, NQ>(a, f);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
-// R: ranking by counting
+// R: ranking by counting (grid.y = query)
 // ------------------------------------------------------------------------------------------------------------------
 template <bool PACKED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void stream_rank_kernel(ScanArgs a, FusedArgs f) {
     __builtin_amdgcn_s_setprio(3);                           // (see stream_sample_kernel)
     const int lane = lane_id();
+    const int q = (int)blockIdx.y;
     FusedHdr* hdr = f.hdr;
     const StreamCtl* sc = &hdr->stream;
-    const int ncand = (int)sc->ncand;
-    const bool good = sc->armed != 0u && sc->ovf == 0u && ncand >= a.k && ncand <= PSH_STREAM_CAND_CAP;
+    const int ncand = (int)sc->ncand[q];
+    const bool good = sc->armed != 0u && sc->ovf == 0u && ncand >= a.k && ncand <= f.cand_cap;
     if (blockIdx.x == 0 && lane == 0) {
-        f.status[0] = good ? PSH_STATUS_OK_ : PSH_STATUS_RETRY_;
-        if (f.total) f.total[0] = ncand;
+        f.status[q] = good ? PSH_STATUS_OK_ : PSH_STATUS_RETRY_;
+        if (f.total) f.total[q] = ncand;
         if (a.qstate) {                                     // diagnostics / the separate launches' state, kept coherent
-            QueryState q;
-            q.xn = __uint_as_float(sc->xn_bits); q.tau_bits = sc->tau2_bits; q.n_valid = good ? a.k : 0; q.nx = 0.0f;
-            q.thr_base = __uint_as_float(PSH_INF_BITS); q.mx_scale = __uint_as_float(sc->scale_bits);
-            q.mx_thr = __uint_as_float(sc->thr2_bits); q.tau2_bits = sc->tau2_bits; q.mx_thr2 = q.mx_thr;
-            q.pad[0] = q.pad[1] = q.pad[2] = 0;
-            a.qstate[0] = q;
+            QueryState qs;
+            qs.xn = __uint_as_float(sc->xn_bits[q]); qs.tau_bits = sc->tau2_bits[q]; qs.n_valid = good ? a.k : 0; qs.nx = 0.0f;
+            qs.thr_base = __uint_as_float(PSH_INF_BITS); qs.mx_scale = __uint_as_float(sc->scale_bits);
+            qs.mx_thr = __uint_as_float(sc->thr2_bits[q]); qs.tau2_bits = sc->tau2_bits[q]; qs.mx_thr2 = qs.mx_thr;
+            qs.pad[0] = qs.pad[1] = qs.pad[2] = 0;
+            a.qstate[q] = qs;
         }
     }
     if (!good) return;
-    const u32x4v* cand = reinterpret_cast<const u32x4v*>(hdr->cand);
+    const u32x4v* cand = reinterpret_cast<const u32x4v*>(hdr->cand) + (size_t)q * f.cand_cap;
+    float* out_d = f.out_d + (size_t)q * f.k_out;
+    int32_t* out_idx = f.out_idx + (size_t)q * f.k_out * 2;
     const int per = (ncand + (int)gridDim.x - 1) / (int)gridDim.x;
     const int lo = (int)blockIdx.x * per;
     const int hi = lo + per < ncand ? lo + per : ncand;
@@ -498,30 +597,33 @@ void stream_rank_kernel(ScanArgs a, FusedArgs f) {
             rank = lane == jj ? v : rank;
         }
         if (lane < 8 && j0 + lane < hi && rank < a.k) {
-            f.out_d[rank] = __uint_as_float(mine[0]);
-            f.out_idx[2 * rank + 0] = (int)mine[1];
-            f.out_idx[2 * rank + 1] = (int)mine[2];
+            out_d[rank] = __uint_as_float(mine[0]);
+            out_idx[2 * rank + 0] = (int)mine[1];
+            out_idx[2 * rank + 1] = (int)mine[2];
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-size_t stream_scan_shmem_bytes(int tile_floats) {
-    return (size_t)PSH_STREAM_FIXED_BYTES + (size_t)tile_floats * (PSH_SCAN_THREADS / 64) * sizeof(float)
-           + (size_t)(PSH_SCAN_THREADS / 64) * 2 * PSH_MX_NHALF * sizeof(_Float16);
+size_t stream_scan_shmem_bytes_q(int tile_floats, int nq) {
+    return (size_t)PSH_STREAM_FIXED_BYTES + (size_t)(nq == 1 ? PSH_FUSED_FRONT : 2 * PSH_FUSED_FRONT) * 16
+           + (size_t)tile_floats * (PSH_SCAN_THREADS / 64) * sizeof(float)
+           + (size_t)(PSH_SCAN_THREADS / 64) * 2 * PSH_MX_NHALF * sizeof(_Float16)
+           + (nq > 1 ? (size_t)(nq - 1) * 4 * 64 * 8 * sizeof(_Float16) : 0);
 }
+size_t stream_scan_shmem_bytes(int tile_floats) { return stream_scan_shmem_bytes_q(tile_floats, 1); }
 size_t stream_sample_shmem_bytes(int tile_floats) {
     const size_t t = (size_t)tile_floats * sizeof(float), h = (size_t)PSH_STREAM_HIST * sizeof(unsigned);
     return t > h ? t : h;
 }
 
 template <typename K>
-static hipError_t launch_k(K kernel, int grid, int threads, size_t shmem, hipStream_t s, const ScanArgs& a, const FusedArgs& f) {
+static hipError_t launch_k(K kernel, dim3 grid, int threads, size_t shmem, hipStream_t s, const ScanArgs& a, const FusedArgs& f) {
     if (shmem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), shmem, s, a, f);
+    hipLaunchKernelGGL(kernel, grid, dim3(threads), shmem, s, a, f);
     return hipGetLastError();
 }
 
@@ -530,24 +632,35 @@ hipError_t launch_stream_sample(const ScanArgs& a, const FusedArgs& f, bool alig
     ScanArgs b = a;
     b.tile_floats = sample_tile_floats;
     if (a.W == 20)
-        return aligned ? launch_k(stream_sample_kernel<20, true>, grid, 64, shmem, s, b, f)
-                       : launch_k(stream_sample_kernel<20, false>, grid, 64, shmem, s, b, f);
-    return aligned ? launch_k(stream_sample_kernel<0, true>, grid, 64, shmem, s, b, f)
-                   : launch_k(stream_sample_kernel<0, false>, grid, 64, shmem, s, b, f);
+        return aligned ? launch_k(stream_sample_kernel<20, true>, dim3(grid), 64, shmem, s, b, f)
+                       : launch_k(stream_sample_kernel<20, false>, dim3(grid), 64, shmem, s, b, f);
+    return aligned ? launch_k(stream_sample_kernel<0, true>, dim3(grid), 64, shmem, s, b, f)
+                   : launch_k(stream_sample_kernel<0, false>, dim3(grid), 64, shmem, s, b, f);
 }
 
-hipError_t launch_stream_scan(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, hipStream_t s) {
-    const size_t shmem = stream_scan_shmem_bytes(a.tile_floats);
+template <int NQ>
+static hipError_t launch_stream_scan_q(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, hipStream_t s) {
+    const size_t shmem = stream_scan_shmem_bytes_q(a.tile_floats, NQ);
     if (a.W == 20)
-        return aligned ? launch_k(stream_scan_kernel<20, true>, grid, PSH_SCAN_THREADS, shmem, s, a, f)
-                       : launch_k(stream_scan_kernel<20, false>, grid, PSH_SCAN_THREADS, shmem, s, a, f);
-    return aligned ? launch_k(stream_scan_kernel<0, true>, grid, PSH_SCAN_THREADS, shmem, s, a, f)
-                   : launch_k(stream_scan_kernel<0, false>, grid, PSH_SCAN_THREADS, shmem, s, a, f);
+        return aligned ? launch_k(stream_scan_q_kernel<20, true, NQ>, dim3(grid), PSH_SCAN_THREADS, shmem, s, a, f)
+                       : launch_k(stream_scan_q_kernel<20, false, NQ>, dim3(grid), PSH_SCAN_THREADS, shmem, s, a, f);
+    return aligned ? launch_k(stream_scan_q_kernel<0, true, NQ>, dim3(grid), PSH_SCAN_THREADS, shmem, s, a, f)
+                   : launch_k(stream_scan_q_kernel<0, false, NQ>, dim3(grid), PSH_SCAN_THREADS, shmem, s, a, f);
+}
+hipError_t launch_stream_scan(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, hipStream_t s) {
+    if (f.nq == 2) return launch_stream_scan_q<2>(a, f, aligned, grid, s);
+    if (f.nq == 3) return launch_stream_scan_q<3>(a, f, aligned, grid, s);
+    const size_t shmem = stream_scan_shmem_bytes_q(a.tile_floats, 1);
+    if (a.W == 20)
+        return aligned ? launch_k(stream_scan_kernel<20, true>, dim3(grid), PSH_SCAN_THREADS, shmem, s, a, f)
+                       : launch_k(stream_scan_kernel<20, false>, dim3(grid), PSH_SCAN_THREADS, shmem, s, a, f);
+    return aligned ? launch_k(stream_scan_kernel<0, true>, dim3(grid), PSH_SCAN_THREADS, shmem, s, a, f)
+                   : launch_k(stream_scan_kernel<0, false>, dim3(grid), PSH_SCAN_THREADS, shmem, s, a, f);
 }
 
 hipError_t launch_stream_rank(const ScanArgs& a, const FusedArgs& f, int grid, hipStream_t s) {
-    return f.tbits >= 0 ? launch_k(stream_rank_kernel<true>, grid, 64, 0, s, a, f)
-                        : launch_k(stream_rank_kernel<false>, grid, 64, 0, s, a, f);
+    return f.tbits >= 0 ? launch_k(stream_rank_kernel<true>, dim3(grid, f.nq), 64, 0, s, a, f)
+                        : launch_k(stream_rank_kernel<false>, dim3(grid, f.nq), 64, 0, s, a, f);
 }
 
 }  // namespace psh

@@ -255,3 +255,53 @@ def test_cu_masked_stream(hip_device, oracle_mod):
     assert info["grid_blocks"] == ncu - reserved
     od, oidx = oracle_mod.scan_topk(ds, q, 400, h=20)
     assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, "overlap launches on a CU-masked stream")
+
+
+@pytest.mark.parametrize("B", [2, 3])
+@pytest.mark.parametrize("R,T,W,h,k", [
+    (8192, 4096, 20, 20, 1024),
+    (6000, 2048, 20, 11, 700),
+    (3000, 2051, 20, 20, 300),      # unaligned rows
+    (5000, 1100, 8, 7, 200),        # run-time window lengths
+    (5000, 1100, 33, 7, 200),
+    (1200, 9000, 20, 20, 64),
+])
+def test_two_and_three_queries_ride_the_overlap_launches(hip_device, oracle_mod, B, R, T, W, h, k):
+    """Two or three queries: ONE sample launch (a sampled unit serves every query), ONE scan (the unit converted once, the
+    window energies one product, four MFMAs and a threshold test per query under ONE common f16 scale), a ranking launch
+    with a row of blocks per query -- the default for such batches, no flag needed.  Queries of very different magnitudes
+    share the scale of the most demanding one."""
+    ds = syn.dataset(R, T, 6000 + R)
+    q = syn.gbm_log_returns((B, W), 6100 + W + B)
+    q[B - 1] *= np.float32(7.5)                           # a louder query: it dictates the common scale
+    d, idx, status, info = fused_scan(hip_device, ds, q, k, h)
+    assert info["path"] == 3 and (status == 0).all()
+    od, oidx = oracle_mod.scan_topk(ds, q, k, h=h)
+    assert_exact(d, idx, od, oidx, f"{B} queries on the overlap launches")
+    # the batched scan (what larger batches take; its own status protocol may send a query to the exhaustive path) agrees
+    from shadowing_amd import _native
+    ds_t = torch.as_tensor(np.ascontiguousarray(ds[:, 0, :])).to(hip_device)
+    d2, idx2 = _native.scan_topk_checked(ds_t, torch.as_tensor(q).to(hip_device), k, h=h, flags=16)      # PSH_FLAG_NO_FUSE
+    torch.cuda.synchronize()
+    assert_exact(d, idx, d2.cpu().numpy(), idx2.cpu().numpy(), "overlap launches vs the batched scan")
+
+
+def test_small_batch_status_protocol_and_reference_golden(hip_device, oracle_mod):
+    """A batch of 3 where one query is all zeros (every distance +inf: its sample carries no level -> RETRY for the step) goes
+    through scan_topk_checked; and the reference's own multi-query golden through the seam."""
+    from shadowing_amd import _native
+    import shadowing_amd as sa
+    ds = syn.dataset(8192, 2048, 6200)
+    q = syn.gbm_log_returns((3, 20), 6201)
+    q[1] = 0.0
+    ds_t = torch.as_tensor(ds[:, 0, :].copy()).to(hip_device)
+    d, idx = _native.scan_topk_checked(ds_t, torch.as_tensor(q).to(hip_device), 100, h=20)
+    torch.cuda.synchronize()
+    od, oidx = oracle_mod.scan_topk(ds, q, 100, h=20)
+    got_d, got_i = d.cpu().numpy(), idx.cpu().numpy()
+    assert np.array_equal(got_d[[0, 2]].view(np.uint32), od[[0, 2]].view(np.uint32)) and np.array_equal(got_i[[0, 2]], oidx[[0, 2]])
+    assert np.isinf(got_d[1]).all()
+    g = load_golden("cfg3_rolling_R2048")
+    obj = sa.PathShadowing(sa.Identity(g["W"]), sa.RelativeMSE(), g["dataset"], sa.PredictionContext(g["h"]))
+    dd, paths, ii = obj.shadow(g["queries"][:3], k=g["k"], cuda=True)
+    assert_matches_reference(dd, ii, {**g, "d": g["d"][:3], "idx": g["idx"][:3]}, None, what="3 queries of cfg3_rolling_R2048")
