@@ -682,9 +682,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
             const int64_t units_p = rows_p * nseg;
             int64_t r2p = (2 * (int64_t)k * rows_p + p.R - 1) / p.R + 8;
             if (r2p < 24) r2p = 24;
-            // sample blocks: two per CU when other steps' scans hold the CUs (what fits beside them); a step that runs alone
-            // (two or three queries, no PSH_FLAG_OVERLAP) spreads its units over eight one-wave blocks per CU
-            int64_t grid_p = (int64_t)((flags_of(profile) & PSH_FLAG_OVERLAP) ? tn.stream_pgrid_per_cu : 8) * ncu;
+            int64_t grid_p = (int64_t)tn.stream_pgrid_per_cu * ncu;
             if (grid_p > units_p) grid_p = units_p;
             int64_t grid_s = ncu;
             // a stream made by psh_stream_create_reserving: one block per compute unit the stream may use

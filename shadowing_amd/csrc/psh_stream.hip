@@ -307,7 +307,7 @@ __device__ __forceinline__ void stream_scan_body(const ScanArgs& a, const FusedA
     _Float16* ah0 = reinterpret_cast<_Float16*>(tiles + (size_t)NW * a.tile_floats);
     _Float16* a1 = ah0 + (size_t)wave * 2 * PSH_MX_NHALF;                     // y^
     _Float16* a2 = a1 + PSH_MX_NHALF;                                         // (y~^2)^
-    _Float16* bxl = ah0 + (size_t)NW * 2 * PSH_MX_NHALF;                      // NQ > 1: the other queries' fragment tables, 4 KB each
+    _Float16* bxl = ah0 + (size_t)NW * 2 * PSH_MX_NHALF;                      // NQ > 1: the queries' fragment tables, 4 KB each
     FusedHdr* hdr = f.hdr;
     const StreamCtl* sc = &hdr->stream;
     auto stamp = [&](int i) { if (a.dbg_times && tid == 0) a.dbg_times[(size_t)blockIdx.x * 8 + i] = (unsigned long long)wall_clock64(); };
@@ -332,16 +332,18 @@ __device__ __forceinline__ void stream_scan_body(const ScanArgs& a, const FusedA
     Stage st;
     unsigned u = u_lo + (unsigned)wave;
     if (u < u_hi) load_unit(st, u);
-    // what the sample kernel left (an earlier launch on this stream: plain loads): the shifted-query fragments -- the first
-    // query's in registers, a second and third query's block-shared in LDS, read per use (registers: acc + a query's own
-    // accumulators + one set of fragments is what fits 128; the LDS pipe is this kernel's co-limit, 27 KB of traffic per unit and
-    // wave being 80 % of what it delivers in a unit's time, so every query read from LDS costs ~12 %) ...
+    // what the sample kernel left (an earlier launch on this stream: plain loads): the shifted-query fragments -- one query's in
+    // registers; two or three queries' block-shared in LDS, read per use (a second set in registers spills 15 of them inside
+    // the loop at the 128-register cap of four waves per SIMD: 142 us for two queries against 107 from LDS; the LDS pipe is
+    // this kernel's co-limit -- 27 KB of traffic per unit and wave are 80 % of what it delivers in a unit's time -- so every
+    // query read from LDS costs ~12 %) ...
     f16x8 bx[4], bo[4];
+    if constexpr (NQ == 1) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) bx[s] = *reinterpret_cast<const f16x8*>(hdr->bxtab + (size_t)(s * 64 + lane) * 8);
-    if constexpr (NQ > 1) {
-        for (int i = tid; i < (NQ - 1) * 4 * 64; i += PSH_SCAN_THREADS)
-            *reinterpret_cast<f16x8*>(bxl + (size_t)i * 8) = *reinterpret_cast<const f16x8*>(hdr->bxtab + ((size_t)4 * 64 + (size_t)i) * 8);
+        for (int s = 0; s < 4; ++s) bx[s] = *reinterpret_cast<const f16x8*>(hdr->bxtab + (size_t)(s * 64 + lane) * 8);
+    } else {
+        for (int i = tid; i < NQ * 4 * 64; i += PSH_SCAN_THREADS)
+            *reinterpret_cast<f16x8*>(bxl + (size_t)i * 8) = *reinterpret_cast<const f16x8*>(hdr->bxtab + (size_t)i * 8);
     }
     // ... and the admission levels (scalar loads; first needed inside the loop, so the set-up below runs under their latency)
     const unsigned armed_w = sc->armed;
@@ -448,10 +450,10 @@ __device__ __forceinline__ void stream_scan_body(const ScanArgs& a, const FusedA
             if (__any(keep)) admit(acc, 0, thr2[0], tau2[0], seg_start, r_global);
         } else {
             // the window energies are in `acc`; every query adds its own banded product on top of them (the energies are the
-            // C operand of its first MFMA: no copy); the last query works in place
+            // C operand of its first MFMA: no copy)
 #pragma unroll
-            for (int q = 1; q < NQ; ++q) {
-                const _Float16* bp = bxl + ((size_t)(q - 1) * 4 * 64 + (size_t)lane) * 8;
+            for (int q = 0; q < NQ; ++q) {
+                const _Float16* bp = bxl + ((size_t)q * 4 * 64 + (size_t)lane) * 8;
                 f32x16 aq = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0], *reinterpret_cast<const f16x8*>(bp), acc, 0, 0, 0);
 #pragma unroll
                 for (int s = 1; s < 4; ++s) aq = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s], *reinterpret_cast<const f16x8*>(bp + (size_t)s * 64 * 8), aq, 0, 0, 0);
@@ -460,12 +462,6 @@ __device__ __forceinline__ void stream_scan_body(const ScanArgs& a, const FusedA
                 for (int r = 0; r < 16; ++r) keep = keep || !(aq[r] > thr2[q]);
                 if (__any(keep)) admit(aq, q, thr2[q], tau2[q], seg_start, r_global);
             }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s], bx[s], acc, 0, 0, 0);
-            bool keep = false;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) keep = keep || !(acc[r] > thr2[0]);
-            if (__any(keep)) admit(acc, 0, thr2[0], tau2[0], seg_start, r_global);
         }
         wave_lds_fence();  // all lanes done with the tile before it is overwritten
         u = un;
@@ -609,7 +605,7 @@ size_t stream_scan_shmem_bytes_q(int tile_floats, int nq) {
     return (size_t)PSH_STREAM_FIXED_BYTES + (size_t)(nq == 1 ? PSH_FUSED_FRONT : 2 * PSH_FUSED_FRONT) * 16
            + (size_t)tile_floats * (PSH_SCAN_THREADS / 64) * sizeof(float)
            + (size_t)(PSH_SCAN_THREADS / 64) * 2 * PSH_MX_NHALF * sizeof(_Float16)
-           + (nq > 1 ? (size_t)(nq - 1) * 4 * 64 * 8 * sizeof(_Float16) : 0);
+           + (nq > 1 ? (size_t)nq * 4 * 64 * 8 * sizeof(_Float16) : 0);
 }
 size_t stream_scan_shmem_bytes(int tile_floats) { return stream_scan_shmem_bytes_q(tile_floats, 1); }
 size_t stream_sample_shmem_bytes(int tile_floats) {
