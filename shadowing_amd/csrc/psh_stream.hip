@@ -81,16 +81,22 @@ __device__ inline bool stream_threshold(const_f32p xq, int W, float tau0, float 
     return true;
 }
 
-template <int WT, bool ALIGNED>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
+// NWP waves per block: 1 when the launch has to fit beside another step's scan blocks (one query, PSH_FLAG_OVERLAP); 4 for the
+// two- and three-query step, whose last block then works on its queries side by side (a wave per query: the tail of the
+// launch -- selection, threshold, fragment table -- is 12 us per query when one wave does them in turn)
+template <int WT, bool ALIGNED, int NWP>
+__global__ __launch_bounds__(64 * NWP) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void stream_sample_kernel(ScanArgs a, FusedArgs f) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // This wave shares its SIMD with four scan waves of another step, all OLDER than it: the arbiter serves the oldest
     // first, and at the default priority a sample / ranking launch took 70 us beside a scan (10-35 us alone) -- long enough
     // to gate the next scan of its own stream.  Its work is a few per cent of a scan's: it goes first.
     __builtin_amdgcn_s_setprio(3);
-    float* tile = smem;                                      // one wave, one tile; the last block's histogram lives here too
     const int lane = lane_id();
+    const int wave = NWP == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float* tile = smem + (size_t)wave * a.tile_floats;       // a tile per wave; the last block's histograms live there too
+    __shared__ int sh_last, sh_sexp[4], sh_armed[4];
+    __shared__ float sh_tau0[4];
     FusedHdr* hdr = f.hdr;
     StreamCtl* ctl = &hdr->stream;
     const int W = WT > 0 ? WT : a.W;
@@ -103,12 +109,12 @@ void stream_sample_kernel(ScanArgs a, FusedArgs f) {
         const unsigned sg = uu - ri * (unsigned)a.nseg;
         stage_load<ALIGNED>(sx, a.dataset + (f.boot_row0 + (int64_t)ri * f.boot_row_stride) * a.T, a.T, (int)sg * PSH_SEG, nfloat, lane);
     };
-    unsigned u = blockIdx.x;
+    unsigned u = blockIdx.x * NWP + (unsigned)wave;
     for (int p = lane; p < a.tile_floats; p += 64) tile[p] = 0.0f;           // no slot is ever read uninitialised
     // a header psh_workspace_init never saw: no ticket can be trusted -- block 0 says so, the scan and the ranking return
     const bool armed_hdr = hdr->magic == PSH_FUSED_MAGIC;
     if (!armed_hdr) {
-        if (blockIdx.x == 0 && lane == 0) { ctl->armed = 0u; ctl->ovf = 0u; for (int q = 0; q < 4; ++q) ctl->ncand[q] = 0u; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->armed = 0u; ctl->ovf = 0u; for (int q = 0; q < 4; ++q) ctl->ncand[q] = 0u; }
         return;
     }
     while (u < nbu) {
@@ -122,7 +128,7 @@ void stream_sample_kernel(ScanArgs a, FusedArgs f) {
             stage_store<false>(st, tile, nfloat, lane);
         }
         wave_lds_fence();
-        const unsigned un = u + gridDim.x;
+        const unsigned un = u + gridDim.x * NWP;
         const int t_lane = seg_start + PSH_L * lane;
         int nvalid = a.Tp - t_lane;
         nvalid = nvalid < 0 ? 0 : (nvalid > PSH_L ? PSH_L : nvalid);
@@ -143,21 +149,22 @@ void stream_sample_kernel(ScanArgs a, FusedArgs f) {
         wave_lds_fence();
         u = un;
     }
-    // arrive: the minima have left this CU (drain), then ONE device-scope ticket; the last arriver goes on
+    // arrive: the minima have left this CU (drain), then ONE device-scope ticket per block; the last arriver goes on
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned tk = 0u;
-    if (lane == 0) tk = __hip_atomic_fetch_add((gu32*)&ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    tk = (unsigned)__builtin_amdgcn_readfirstlane((int)tk);
-    if (tk != gridDim.x - 1u) return;
+    if (NWP > 1) __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned tk = __hip_atomic_fetch_add((gu32*)&ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh_last = tk == gridDim.x - 1u ? 1 : 0;
+    }
+    if (NWP > 1) __syncthreads(); else wave_lds_fence();
+    if (!sh_last) return;
 
     // ---- the last block, per query: rank-th smallest minimum -> tau0 (its bucket's upper edge) and the scale it allows
-    unsigned* hist = reinterpret_cast<unsigned*>(smem);
+    unsigned* hist = reinterpret_cast<unsigned*>(tile);
     const int n4 = ((int)nbu + 3) >> 2;                      // 16-byte groups of a query's minima
-    bool armed = true;
-    int sexp_common = 1000;
-    float tau0q[PSH_STREAM_MAX_Q];
 #pragma unroll 1
-    for (int q = 0; q < nq; ++q) {
+    for (int q = (NWP == 1 ? 0 : wave); q < nq; q += NWP) {
+        bool armed = true;
         const __amdgpu_buffer_rsrc_t rmin = st_rsrc(hdr->minima + (size_t)q * f.units_stride, (unsigned)(4 * n4) * 4u);
         wave_lds_fence();
         for (int i = lane; i < PSH_STREAM_HIST; i += 64) hist[i] = 0u;
@@ -241,21 +248,26 @@ void stream_sample_kernel(ScanArgs a, FusedArgs f) {
         } else {
             armed = false;
         }
-        tau0q[q] = __uint_as_float(edge) * PSH_TAU_MARGIN;
+        const float tau0 = __uint_as_float(edge) * PSH_TAU_MARGIN;
         int sx = 0;
-        if (armed && !stream_sexp((const_f32p)a.queries + (size_t)q * W, W, tau0q[q], &sx)) armed = false;   // (uniform: scalar inputs)
-        sexp_common = sx < sexp_common ? sx : sexp_common;
+        if (armed && !stream_sexp((const_f32p)a.queries + (size_t)q * W, W, tau0, &sx)) armed = false;   // (uniform: scalar inputs)
+        if (lane == 0) { sh_tau0[q] = tau0; sh_sexp[q] = sx; sh_armed[q] = armed ? 1 : 0; }
     }
+    if (NWP > 1) __syncthreads(); else wave_lds_fence();
     // ---- ONE scale for the step (every query's conditions bound it from above), then every query's threshold and fragments
+    bool armed = true;
+    int sexp_common = 1000;
+    for (int q = 0; q < nq; ++q) { armed = armed && sh_armed[q] != 0; sexp_common = sh_sexp[q] < sexp_common ? sh_sexp[q] : sexp_common; }
     const float scale = armed ? __uint_as_float((unsigned)(127 + sexp_common) << 23) : 0.0f;
 #pragma unroll 1
-    for (int q = 0; q < nq; ++q) {
+    for (int q = (NWP == 1 ? 0 : wave); q < nq; q += NWP) {
         const const_f32p xq = (const_f32p)a.queries + (size_t)q * W;
+        const float tau0q_ = sh_tau0[q];
         float thr = 0.0f;
-        if (armed && !stream_threshold(xq, W, tau0q[q], scale, &thr)) armed = false;
+        if (armed && !stream_threshold(xq, W, tau0q_, scale, &thr)) sh_armed[q] = 0;
         if (lane == 0) {
             const float s2 = sumsq8([&](int j) { return xq[j]; }, W);
-            ctl->tau2_bits[q] = __float_as_uint(tau0q[q]);
+            ctl->tau2_bits[q] = __float_as_uint(tau0q_);
             ctl->thr2_bits[q] = __float_as_uint(thr);
             ctl->xn_bits[q] = __float_as_uint(f.qnorm_in ? f.qnorm_in[q] : __builtin_sqrtf(s2));
             ctl->ncand[q] = 0u;
@@ -276,7 +288,9 @@ void stream_sample_kernel(ScanArgs a, FusedArgs f) {
             *reinterpret_cast<f16x8*>(hdr->bxtab + ((size_t)q * 4 * 64 + (size_t)(s * 64 + lane)) * 8) = b;
         }
     }
-    if (lane == 0) {
+    if (NWP > 1) __syncthreads(); else wave_lds_fence();
+    if (threadIdx.x == 0) {
+        for (int q = 0; q < nq; ++q) armed = armed && sh_armed[q] != 0;   // (a threshold that came out non-finite)
         ctl->scale_bits = __float_as_uint(scale);
         ctl->armed = armed ? 1u : 0u;
         ctl->ovf = 0u;
@@ -623,15 +637,21 @@ static hipError_t launch_k(K kernel, dim3 grid, int threads, size_t shmem, hipSt
     return hipGetLastError();
 }
 
+template <int NWP>
+static hipError_t launch_stream_sample_w(const ScanArgs& b, const FusedArgs& f, bool aligned, int grid, size_t shmem, hipStream_t s) {
+    if (b.W == 20)
+        return aligned ? launch_k(stream_sample_kernel<20, true, NWP>, dim3(grid), 64 * NWP, shmem, s, b, f)
+                       : launch_k(stream_sample_kernel<20, false, NWP>, dim3(grid), 64 * NWP, shmem, s, b, f);
+    return aligned ? launch_k(stream_sample_kernel<0, true, NWP>, dim3(grid), 64 * NWP, shmem, s, b, f)
+                   : launch_k(stream_sample_kernel<0, false, NWP>, dim3(grid), 64 * NWP, shmem, s, b, f);
+}
+// grid: one-wave blocks for one query (they have to fit beside another step's scan), a quarter as many four-wave blocks for two
+// or three
 hipError_t launch_stream_sample(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, int sample_tile_floats, hipStream_t s) {
-    const size_t shmem = stream_sample_shmem_bytes(sample_tile_floats);
     ScanArgs b = a;
     b.tile_floats = sample_tile_floats;
-    if (a.W == 20)
-        return aligned ? launch_k(stream_sample_kernel<20, true>, dim3(grid), 64, shmem, s, b, f)
-                       : launch_k(stream_sample_kernel<20, false>, dim3(grid), 64, shmem, s, b, f);
-    return aligned ? launch_k(stream_sample_kernel<0, true>, dim3(grid), 64, shmem, s, b, f)
-                   : launch_k(stream_sample_kernel<0, false>, dim3(grid), 64, shmem, s, b, f);
+    if (f.nq == 1) return launch_stream_sample_w<1>(b, f, aligned, grid, stream_sample_shmem_bytes(sample_tile_floats), s);
+    return launch_stream_sample_w<4>(b, f, aligned, (grid + 3) / 4, 4 * stream_sample_shmem_bytes(sample_tile_floats), s);
 }
 
 template <int NQ>
