@@ -135,12 +135,19 @@ int psh_exchange_merge(psh_comm* c, void* compute_stream, void* side_stream,
             rc = PSH_ERR_HIP;
             break;
         }
-        const ncclResult_t r = c->api.AllGather(send, gathered, n, kNcclInt32, c->comm, ss);
-        if (r != 0) { rc = nccl_fail(c->api, "ncclAllGather", r); break; }
+        int dbg_skip = 0;
+#ifdef PSH_TUNING
+        if (const char* e = getenv("PSH_DBG_EXCHANGE_SKIP")) dbg_skip = atoi(e);      // timing ablations (tools/): 1 no collective, 2 no merge
+#endif
+        if (!(dbg_skip & 1)) {
+            const ncclResult_t r = c->api.AllGather(send, gathered, n, kNcclInt32, c->comm, ss);
+            if (r != 0) { rc = nccl_fail(c->api, "ncclAllGather", r); break; }
+        }
         // list g of query b: distances at gathered + g*n + b*k (floats), pairs at gathered + g*n + B*k + 2*b*k
         const float* dg = reinterpret_cast<const float*>(gathered);
         const int32_t* ig = gathered + (size_t)B * k;
-        if (G <= 64 && (int64_t)G * k * 4 <= 128 * 1024)
+        if (dbg_skip & 2) {
+        } else if (G <= 64 && (int64_t)G * k * 4 <= 128 * 1024)
             rc = psh_merge_sorted_gathered(c->device, ss, dg, ig, G, (int64_t)n, (int64_t)n / 2, B, k, k, out_d, out_idx);
         else
             rc = psh_merge_topk_gathered(c->device, ss, dg, ig, G, (int64_t)n, (int64_t)n / 2, B, k, k, out_d, out_idx,
