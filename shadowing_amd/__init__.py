@@ -9,7 +9,7 @@ from .averaging import DiscreteProba, Softmax, Uniform
 from .path_distance import PathDistance, RelativeMSE
 from .path_embedding import (ArrayType, ContextManagerBase, CrossChannelContext, Foveal, Identity,
                              ImputationContext, PathEmbedding, PredictionContext)
-from .path_shadowing import PathShadowing, select_cartesian_product
+from .path_shadowing import PathShadowing, PendingShadow, select_cartesian_product
 from .plotting import plot_closest, plot_shadow, plot_volatility
 from .statistics import realized_variance
 

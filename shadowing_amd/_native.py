@@ -457,6 +457,59 @@ def reserving_stream(device: torch.device, reserve_cus: int = PSH_STREAM_RESERVE
     return torch.cuda.ExternalStream(h.value, device=device), int(got.value)
 
 
+class PreparedShadow:
+    """One single-query shadow() on the device -- psh_scan_topk as the overlap-friendly launches, then psh_gather_paths -- with
+    everything but the stream fixed beforehand: argument lists built once, the query staged through a pinned buffer of its own,
+    results in buffers the slot owns.  The per-call host cost is one small copy and two ctypes calls (the general path spends
+    ~250 us of Python per call, three times what the device needs).  One slot serves one call at a time: the caller hands it
+    out again only after the previous call's results have been taken."""
+
+    def __init__(self, rows: torch.Tensor, ds3: torch.Tensor, W: int, k: int, h: int, workspace: "Workspace", flags: int):
+        rows = _dev_tensor(rows, torch.float32, "rows")
+        dev = rows.device
+        R, T = rows.shape
+        C_ = ds3.shape[1]
+        self.q_pin = torch.empty((1, W), dtype=torch.float32, pin_memory=True)
+        self.q_dev = torch.empty((1, W), dtype=torch.float32, device=dev)
+        self.d = torch.empty((1, k), dtype=torch.float32, device=dev)
+        self.idx = torch.empty((1, k, 2), dtype=torch.int32, device=dev)
+        self.status = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.paths = torch.zeros((1, k, C_, W + h), dtype=torch.float32, device=dev)
+        self.host = tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (self.d, self.paths, self.idx, self.status))
+        self.event = torch.cuda.Event()
+        ws = workspace.get(workspace_bytes(R, T, 1, W, h, k))
+        self._keep = (rows, ds3, ws, workspace)
+        self.prof = PshProfile()
+        self.prof.mode = 1
+        self.prof.flags = flags
+        L = load()
+        self._scan_fn, self._gather_fn = L.psh_scan_topk, L.psh_gather_paths
+        self._scan_args = [dev.index, None, rows.data_ptr(), R, T, 0, self.q_dev.data_ptr(), None, 1, W, h, k, self.d.data_ptr(),
+                           self.idx.data_ptr(), self.status.data_ptr(), ws.data_ptr(), ws.numel(), C.byref(self.prof)]
+        self._gather_args = [dev.index, None, ds3.data_ptr(), ds3.shape[0], C_, ds3.shape[2], 0, self.idx.data_ptr(), k, W + h,
+                             self.paths.data_ptr()]
+
+    def launch(self, stream: "torch.cuda.Stream", x_row: torch.Tensor) -> None:
+        """x_row: (1, W) float32 CPU tensor.  Everything is enqueued on `stream`, the D2H copies of the results included."""
+        self.q_pin.copy_(x_row)
+        sp = stream.cuda_stream
+        with torch.cuda.stream(stream):
+            self.q_dev.copy_(self.q_pin, non_blocking=True)
+            a = self._scan_args
+            a[1] = sp
+            rc = self._scan_fn(*a)
+            if rc:
+                _check(rc, "psh_scan_topk")
+            g = self._gather_args
+            g[1] = sp
+            rc = self._gather_fn(*g)
+            if rc:
+                _check(rc, "psh_gather_paths")
+            for h_, t in zip(self.host, (self.d, self.paths, self.idx, self.status)):
+                h_.copy_(t, non_blocking=True)
+            self.event.record()
+
+
 class PreparedStep:
     """One step of the row-sharded scan with everything but the stream and the query pointer fixed beforehand: the local
     psh_scan_topk into the send buffer, then psh_exchange_merge (all-gather + merge on the side stream).  The per-step host

@@ -439,6 +439,56 @@ class PathShadowing:
         paths = y[r[..., None], :, t]                                # (B, k, len, C)
         return _numpy(d), _numpy(paths.permute(0, 1, 3, 2).contiguous()), _numpy(idx)
 
+    def shadow_async(self, x_context: ArrayType, k: int = 1, streams: int = 3) -> "PendingShadow":
+        """shadow(cuda=True) without waiting for the result: the call only ENQUEUES the scan and the path gather and returns a
+        handle whose `.result()` gives shadow()'s triple.  For callers with independent queries in flight (a server; a loop
+        over query dates whose results are consumed later): consecutive calls rotate over `streams` private HIP streams, and
+        a single query (Identity + RelativeMSE + PredictionContext) runs there as the overlap-friendly launches
+        (PSH_FLAG_OVERLAP, psh_stream.hip) -- the sample and ranking launches of one call run beside the scan of another, so
+        a stream of calls costs ~85 us each at the benchmark size where blocking calls cost ~230 (scan + copies).  The
+        reference has no counterpart (its shadow() is blocking, ref :181-218); any configuration this path does not cover is
+        served by shadow() itself at call time and handed back through the same handle."""
+        ksize = self.embedding.kernel.shape[-1]
+        if ksize != 0 and ksize != x_context.shape[-1]:
+            raise Exception("The embedding kernel should be of the same size as the context.")
+        x = _torch(_dim_array(x_context))
+        y = self._dataset_tensor()
+        if not (self._native_kind(x, y, k) == "identity" and x.shape[0] == 1):
+            return PendingShadow(self, None, self.shadow(x_context, k, cuda=True), None)
+        dev = self._hip_device()
+        _native.load()
+        ds = self._resident_dataset(y, dev)
+        rows = self._scan_rows_of(ds)
+        h = self.context.get_out_times()
+        W = x.shape[-1]
+        if k > ds.shape[0] * (ds.shape[-1] - W - h + 1):
+            raise RuntimeError("selected index k out of range")       # (the reference fails inside torch.topk, ref :165)
+        # prepared slots (argument lists, pinned staging, result buffers): rebuilt when anything they were built for changes
+        key = (ds.data_ptr(), tuple(ds.shape), ds._version, W, k, h, int(streams), str(dev))
+        st = getattr(self, "_async", None)
+        if st is None or st["key"] != key:
+            n = int(streams)
+            cur = torch.cuda.current_stream(dev)
+            st = self._async = {"key": key, "i": 0, "streams": [torch.cuda.Stream(dev) for _ in range(n)],
+                                "ws": [_native.Workspace(dev) for _ in range(n)], "free": [], "n": n}
+            for s_ in st["streams"]:
+                s_.wait_stream(cur)                                   # (the resident ensemble may just have been uploaded there)
+            st["slots"] = [[] for _ in range(n)]
+        i = st["i"] % st["n"]
+        st["i"] += 1
+        # a free slot of this stream, or a new one (a slot is busy until its handle's result() has been taken)
+        pool = st["slots"][i]
+        slot = next((sl for sl in pool if not sl.busy), None)
+        if slot is None:
+            with torch.cuda.stream(st["streams"][i]):
+                slot = _native.PreparedShadow(rows, ds, W, k, h, st["ws"][i], _native.FLAG_OVERLAP)
+            slot.busy = False
+            pool.append(slot)
+        slot.busy = True
+        slot.launch(st["streams"][i], x[:, 0, :])
+        self.last_path = "hip"
+        return PendingShadow(self, slot.event, slot, (x_context, k))
+
     @staticmethod
     def init_averaging_proba(proba_name: str, distances: np.ndarray, eta: float | None) -> DiscreteProba:
         """"uniform" or "softmax" averaging over the shadowing paths (ref :220-232)."""
@@ -527,3 +577,28 @@ class PathShadowing:
             means.append(m)
             stds.append(s)
         return np.concatenate(means), np.concatenate(stds)
+
+
+class PendingShadow:
+    """Handle of PathShadowing.shadow_async(): `.result()` -> (distances (B,k), paths (B,k,C,W+h), indices (B,k,2)) as numpy
+    arrays, exactly what shadow() returns; `.done()` -> whether the device has finished (no waiting)."""
+
+    def __init__(self, owner: PathShadowing, event, payload, call):
+        self._owner, self._event, self._payload, self._call = owner, event, payload, call
+
+    def done(self) -> bool:
+        return self._event is None or self._event.query()
+
+    def result(self):
+        if self._event is None:
+            return self._payload                                      # served by shadow() at call time
+        if self._call is not None:
+            self._event.synchronize()
+            slot = self._payload
+            hd, hp, hi, hs = (t.numpy().copy() for t in slot.host)    # (the pinned buffers go back to the slot)
+            slot.busy = False
+            if hs.any():                                              # the status protocol: rare; the blocking path copes
+                x_context, k = self._call
+                hd, hp, hi = self._owner.shadow(x_context, k, cuda=True)
+            self._payload, self._call = (hd, hp, hi), None
+        return self._payload

@@ -34,6 +34,14 @@ def test_hip_embedded_matches_reference_goldens(hip_device, oracle_mod, name):
     assert_matches_reference(d, idx, g, all_dist, what=name)                     # what actually holds: bit equality
     od, oidx = oracle_mod.scan_topk_embedded(ds, g["kernel"], g["hx"], g["k"], h=h)
     assert_exact(d, idx, od, oidx, name + " vs oracle")
+    # dense kernels small enough for it: the same through the matrix-core rejection test (PSH_FLAG_EMBED_MX -- what
+    # PathShadowing passes for every stock non-Foveal embedding: the wavelet bank of configs[4], the user kernel)
+    from shadowing_amd import _native
+    if g["kernel"].shape[0] <= 12 and not name.startswith("foveal"):
+        d2, idx2, st2, _ = hip_scan_embedded(hip_device, ds, g["kernel"], g["hx"], g["k"], h, flags=_native.FLAG_EMBED_MX)
+        assert np.all(st2 == 0)
+        assert_matches_reference(d2, idx2, g, all_dist, what=name + " (matrix cores)")
+        assert_exact(d2, idx2, od, oidx, name + " (matrix cores) vs oracle")
 
 
 def _foveal_kernel(alpha, beta, K):

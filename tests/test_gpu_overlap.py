@@ -305,3 +305,35 @@ def test_small_batch_status_protocol_and_reference_golden(hip_device, oracle_mod
     obj = sa.PathShadowing(sa.Identity(g["W"]), sa.RelativeMSE(), g["dataset"], sa.PredictionContext(g["h"]))
     dd, paths, ii = obj.shadow(g["queries"][:3], k=g["k"], cuda=True)
     assert_matches_reference(dd, ii, {**g, "d": g["d"][:3], "idx": g["idx"][:3]}, None, what="3 queries of cfg3_rolling_R2048")
+
+
+def test_shadow_async_equals_shadow(hip_device, oracle_mod):
+    """PathShadowing.shadow_async(): a dozen independent queries enqueued back to back (three private streams, overlap
+    launches), collected afterwards: each triple equals the blocking shadow(cuda=True)'s -- distances, gathered paths,
+    indices -- and the oracle's; configurations the asynchronous path does not cover come back through the same handle."""
+    import shadowing_amd as sa
+    ds = syn.dataset(16384, 2048, 5900)
+    obj = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), torch.as_tensor(ds), sa.PredictionContext(horizon=20))
+    qs = [syn.gbm_log_returns((20,), 5901 + i) for i in range(12)]
+    handles = [obj.shadow_async(q, k=300) for q in qs]
+    assert obj.last_path == "hip" and len({id(h) for h in handles}) == 12
+    for q, hnd in zip(qs, handles):
+        d, paths, idx = hnd.result()
+        assert hnd.done() and hnd.result()[0] is d
+        d0, p0, i0 = obj.shadow(q, k=300, cuda=True)
+        assert np.array_equal(d.view(np.uint32), d0.view(np.uint32)) and np.array_equal(idx, i0) and np.array_equal(paths, p0)
+        od, opaths, oidx = oracle_mod.shadow(ds, q[None, :], 300, 20)
+        assert_exact(d, idx, od, oidx, "shadow_async")
+        assert np.array_equal(paths, opaths)
+    # a batch, and a Foveal embedding: served by shadow() at call time, same handle type
+    qb = syn.rolling_queries(5, 20, 5950)
+    d, paths, idx = obj.shadow_async(qb, k=64).result()
+    d0, p0, i0 = obj.shadow(qb, k=64, cuda=True)
+    assert np.array_equal(d, d0) and np.array_equal(idx, i0) and np.array_equal(paths, p0)
+    fov = sa.PathShadowing(sa.Foveal(1.4, 0.9, 40), sa.RelativeMSE(), torch.as_tensor(ds), sa.PredictionContext(horizon=20))
+    x = syn.gbm_log_returns((40,), 5960)
+    d, paths, idx = fov.shadow_async(x, k=50).result()
+    d0, p0, i0 = fov.shadow(x, k=50, cuda=True)
+    assert np.array_equal(d, d0) and np.array_equal(idx, i0)
+    with pytest.raises(Exception):
+        obj.shadow_async(np.zeros(7, np.float32), k=5)
