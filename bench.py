@@ -50,7 +50,9 @@ HBM_COPY_GBPS = 6290.0   # same guide: what a float4 copy kernel measures on thi
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=1000,
+                    help="timed steps (default 1000 = ~0.1 s of device time: the first ~3 ms of load after an idle period are "
+                         "slower on these boxes for every kernel -- tools/cold_probe.py -- and a long run averages that out)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows-per-gpu", type=int, default=32768)
     ap.add_argument("--T", type=int, default=4096)
