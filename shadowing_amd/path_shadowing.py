@@ -589,6 +589,15 @@ class PendingShadow:
     def done(self) -> bool:
         return self._event is None or self._event.query()
 
+    def __del__(self):
+        # a handle dropped without result(): its slot goes back to the pool once the device is done with it
+        try:
+            if self._call is not None and self._event is not None:
+                self._event.synchronize()
+                self._payload.busy = False
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
     def result(self):
         if self._event is None:
             return self._payload                                      # served by shadow() at call time
