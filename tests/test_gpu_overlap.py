@@ -337,3 +337,47 @@ def test_shadow_async_equals_shadow(hip_device, oracle_mod):
     assert np.array_equal(d, d0) and np.array_equal(idx, i0)
     with pytest.raises(Exception):
         obj.shadow_async(np.zeros(7, np.float32), k=5)
+
+
+def test_blocking_shadow_prepared_slot(hip_device, oracle_mod):
+    """shadow(cuda=True) for ONE Identity query runs through a prepared slot (fused launch on the caller's stream, results
+    into buffers the object keeps): the returned arrays are the caller's own (a later call does not change them), the slot
+    follows k / the ensemble / the workspace buffer when they change, a multi-channel ensemble gathers every channel, and
+    data the single launch gives up on (constant rows: every window ties) comes back exact through the general path."""
+    import shadowing_amd as sa
+    ds = syn.dataset(8192, 2048, 6100)
+    obj = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), torch.as_tensor(ds), sa.PredictionContext(horizon=20))
+    kept = []
+    for i, k in enumerate((200, 200, 64, 200)):
+        q = syn.gbm_log_returns((20,), 6101 + i)
+        d, paths, idx = obj.shadow(q, k=k, cuda=True)
+        assert obj.last_path == "hip" and getattr(obj, "_sync_slot", None) is not None
+        od, opaths, oidx = oracle_mod.shadow(ds, q[None, :], k, 20)
+        assert_exact(d, idx, od, oidx, f"prepared shadow call {i}")
+        assert np.array_equal(paths, opaths)
+        kept.append((d, paths, idx, od, opaths, oidx))
+        if i == 1:
+            # a batch through the same object grows its workspace: the slot is rebuilt against the new buffer
+            qb = syn.rolling_queries(16, 20, 6150)
+            db, _, ib = obj.shadow(qb, k=200, cuda=True)
+            odb, oib = oracle_mod.scan_topk(ds, qb, 200, h=20)
+            assert_exact(db, ib, odb, oib, "batch between prepared calls")
+    for d, paths, idx, od, opaths, oidx in kept:                      # earlier results are untouched by later calls
+        assert np.array_equal(d.view(np.uint32), od.view(np.uint32)) and np.array_equal(idx, oidx) and np.array_equal(paths, opaths)
+    # another ensemble behind the same object
+    ds2 = syn.dataset(4096, 1024, 6200)
+    obj.dataset = torch.as_tensor(ds2)
+    q = syn.gbm_log_returns((20,), 6201)
+    d, paths, idx = obj.shadow(q, k=100, cuda=True)
+    od, opaths, oidx = oracle_mod.shadow(ds2, q[None, :], 100, 20)
+    assert_exact(d, idx, od, oidx, "prepared shadow, new ensemble")
+    assert np.array_equal(paths, opaths)
+    # every window ties: RETRY inside the launch -> general path, still exact
+    flat = np.full((2048, 1, 512), 0.01, np.float32)
+    objf = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), torch.as_tensor(flat), sa.PredictionContext(horizon=20))
+    q = syn.gbm_log_returns((20,), 6300)
+    for _ in range(2):
+        d, paths, idx = objf.shadow(q, k=300, cuda=True)
+        od, opaths, oidx = oracle_mod.shadow(flat, q[None, :], 300, 20)
+        assert_exact(d, idx, od, oidx, "prepared shadow, ties")
+        assert np.array_equal(paths, opaths)
