@@ -41,23 +41,39 @@ namespace psh {
 
 struct EmxDims {
     int KS;        // 32-tap steps: ceil((K + 15) / 32)
-    int CS;        // halves per shifted copy of a kernel row (zero padded on both sides), copies on different banks
+    int CS;        // split products (NP = 3): halves per shifted copy of a kernel row (zero padded on both sides), 4 copies, hi and lo
+    int CS8;       // one product (NP = 1): halves per copy, 8 copies (every fragment one aligned 16-byte read), hi only
+    unsigned pos8; // nibble c: where copy c of a row sits among the row's 8 (see below)
     int nhalf;     // halves of a segment's f16 copy: 1024 + 32 KS
 };
+// The 8-copy layout and the LDS banks.  A ds_read_b128 is served in four groups of 16 lanes ({0-3, 12-15, 20-27}, {4-11, 16-19,
+// 28-31} and the same + 32), one cycle per group when its 16 lanes touch 16 different 16-byte slots of the 256-byte bank row.
+// Lane (s = lane & 15, kq = lane >> 4) reads copy c = -s & 7 at slot  base_c + 2 - (s + c) / 8 + kq: a group touches 12 different
+// addresses in 8 copies, and they fall on 12 different slots iff the copies' bases do (mod 16) what an exhaustive search allows --
+// with one stride S between neighbouring copies: S = 3, 7, 9 or 13 (mod 16) slots and the copies in the orders below.  A copy is
+// 4 KS + 2 slots long, so S = that + 1, + 3 or + 5 (39 slots = 312 halves for K = 252: the size the 4 + 4 split copies have).
+// (r02: 4 copies read with ds_read2_b64 -- half the bytes per LDS cycle of a b128, and 5 two-way conflicts in every 16 lanes:
+//  SQ_LDS_BANK_CONFLICT 3.7 cycles per LDS instruction cycle, the LDS the product loop's bound at 2.2x its MFMA time.)
 __host__ __device__ inline EmxDims emx_dims(int K) {
     EmxDims d;
     d.KS = (K + 15 + 31) / 32;
     int cs = 32 * d.KS + PSH_EMX_PADL + 8;   // the last fragment ends at 32 (KS - 1) + 24 + PADL + 7
-    if ((cs & 31) == 0) cs += 8;             // (measured: a bank-aligned stride, 32 mod 128 halves, and padded A rows change nothing)
+    if ((cs & 31) == 0) cs += 8;
     d.CS = cs;
+    int S = 4 * d.KS + 3;                    // slots of 8 halves; 4 KS + 2 are read
+    while ((S & 15) != 3 && (S & 15) != 7 && (S & 15) != 9 && (S & 15) != 13) S += 2;
+    d.CS8 = 8 * S;
+    // position of copy c, c = 0 .. 7 (lowest nibble first)
+    d.pos8 = (S & 15) == 3 ? 0x64175302u : (S & 15) == 7 ? 0x52176304u : (S & 15) == 9 ? 0x54176302u : 0x74265310u;
     d.nhalf = 1024 + 32 * d.KS;
-
     return d;
 }
 
 __host__ __device__ inline size_t emx_shmem_bytes(int K, int d, int B, int tile_floats) {
     const EmxDims m = emx_dims(K);
     size_t n = (size_t)PSH_EMX_MAX_D * 4 * m.CS * sizeof(_Float16) * 2;              // B operand: 12 rows x 4 shifted copies, hi and lo
+    const size_t n8 = (size_t)PSH_EMX_MAX_D * 8 * m.CS8 * sizeof(_Float16);           // ... or 12 rows x 8 copies, hi
+    n = n > n8 ? n : n8;
     n += (size_t)d * K * sizeof(float);                                               // the fp32 kernel (exact verification)
     n = (n + 15) & ~(size_t)15;
     n += (size_t)(PSH_EMX_THREADS / 64) * ((size_t)2 * m.nhalf * sizeof(_Float16) + (size_t)(PSH_EMX_TILE ? tile_floats : 0) * sizeof(float)
@@ -97,9 +113,10 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
     const int K = a.W, d = a.emb_d;
     const EmxDims dm = emx_dims(K);
     // ---- LDS carve
-    _Float16* bh = reinterpret_cast<_Float16*>(smem);                                  // [12][4][CS] hi
+    _Float16* bh = reinterpret_cast<_Float16*>(smem);                                  // [12][4][CS] hi  (NP = 1: [12][8][CS8])
     _Float16* bl = bh + (size_t)PSH_EMX_MAX_D * 4 * dm.CS;                              // [12][4][CS] lo
-    float* kerF = reinterpret_cast<float*>(bl + (size_t)PSH_EMX_MAX_D * 4 * dm.CS);     // d x K fp32
+    const size_t bop_halves = (size_t)PSH_EMX_MAX_D * (8 * dm.CS > 8 * dm.CS8 ? 8 * dm.CS : 8 * dm.CS8);
+    float* kerF = reinterpret_cast<float*>(bh + bop_halves);                            // d x K fp32
     char* pw = reinterpret_cast<char*>(kerF) + (((size_t)d * K * 4 + 15) & ~(size_t)15);
     const int tile_fl = PSH_EMX_TILE ? a.tile_floats : 0;
     const size_t per_wave = (size_t)2 * dm.nhalf * 2 + (size_t)tile_fl * 4 + (size_t)PSH_PEND * 16 + (size_t)PSH_EMX_QCAP * 4 + 64 * 4;
@@ -144,15 +161,28 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
     const int ek = kmb >= 0x00800000u ? 9 - ((int)((kmb >> 23) & 255u) - 126) : 0;      // max|ker| 2^ek in [256, 512)
     const int ekc = ek > 100 ? 100 : (ek < -100 ? -100 : ek);
     const float sk = __uint_as_float((unsigned)(127 + ekc) << 23);
-    for (int e = tid; e < PSH_EMX_MAX_D * 4 * dm.CS; e += PSH_EMX_THREADS) {
-        // copy c of row i:  copy[x] = L_i[x + c],  L_i[x] = ker_i[x - PADL] (zero outside [0, K))
-        const int i = e / (4 * dm.CS), rem = e - i * 4 * dm.CS, c = rem / dm.CS, x2 = rem - c * dm.CS;
-        const int j = x2 + c - PSH_EMX_PADL;
-        float v = (i < d && j >= 0 && j < K) ? kerF[i * K + j] * sk : 0.0f;
-        const _Float16 hi = (_Float16)v;
-        const _Float16 lo = (_Float16)(v - (float)hi);
-        bh[e] = hi;
-        if (NP == 3) bl[e] = lo;
+    if (NP == 3) {
+        for (int e = tid; e < PSH_EMX_MAX_D * 4 * dm.CS; e += PSH_EMX_THREADS) {
+            // copy c of row i:  copy[x] = L_i[x + c],  L_i[x] = ker_i[x - PADL] (zero outside [0, K))
+            const int i = e / (4 * dm.CS), rem = e - i * 4 * dm.CS, c = rem / dm.CS, x2 = rem - c * dm.CS;
+            const int j = x2 + c - PSH_EMX_PADL;
+            float v = (i < d && j >= 0 && j < K) ? kerF[i * K + j] * sk : 0.0f;
+            const _Float16 hi = (_Float16)v;
+            const _Float16 lo = (_Float16)(v - (float)hi);
+            bh[e] = hi;
+            bl[e] = lo;
+        }
+    } else {
+        for (int e = tid; e < PSH_EMX_MAX_D * 8 * dm.CS8; e += PSH_EMX_THREADS) {
+            // the copy at position ps of row i is copy c with pos8[c] == ps
+            const int i = e / (8 * dm.CS8), rem = e - i * 8 * dm.CS8, ps = rem / dm.CS8, x2 = rem - ps * dm.CS8;
+            int c = 0;
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) c = ((dm.pos8 >> (4 * cc)) & 15u) == (unsigned)ps ? cc : c;
+            const int j = x2 + c - PSH_EMX_PADL;
+            const float v = (i < d && j >= 0 && j < K) ? kerF[i * K + j] * sk : 0.0f;
+            bh[e] = (_Float16)v;
+        }
     }
     __syncthreads();
     // eps: splits and the dropped lo.lo term (3 * 2^-22) + fp32 accumulation of 3 K' products (3 * 32 KS * 2^-24), doubled
@@ -350,7 +380,66 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int i = 0; i < 4 * NG; ++i) C[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            {
+            if constexpr (NP == 1) {
+                // ---- one product, 8 copies: every fragment ONE aligned 16-byte read, software-pipelined by hand (left to itself
+                // the compiler reads one fragment into ONE register quad, waits, issues its two MFMAs, reads the next: the LDS
+                // latency of every fragment in the open, r02).  NG == 3: a ring of three 4-row groups, a group's reads issued two
+                // groups (16 MFMAs = 256 cycles) before its MFMAs; NG < 3: all of a step's reads, then its MFMAs.
+                const int cpy = (-scol) & 7;
+                const int ps = (int)((dm.pos8 >> (4 * cpy)) & 15u);
+                const _Float16* bp = bh + (size_t)ps * dm.CS8 + (PSH_EMX_PADL - scol - cpy) + 8 * kq;
+                const int rstride = 8 * dm.CS8;
+                const _Float16* ap = yh + 16 * (32 * hf + scol) + 8 * kq;               // A row of M tile 0: m = 32 hf + (lane & 15); M tile 1: + 256
+                auto ldB = [&](f16x8 (&f)[4], int g, int ks) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) f[r4] = *reinterpret_cast<const f16x8*>(bp + (size_t)(4 * g + r4) * rstride + 32 * ks);
+                };
+                auto mm = [&](const f16x8 (&f)[4], int g, const f16x8& a0, const f16x8& a1) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        C[0][4 * g + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, f[r4], C[0][4 * g + r4], 0, 0, 0);
+                        C[1][4 * g + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, f[r4], C[1][4 * g + r4], 0, 0, 0);
+                    }
+                };
+                if constexpr (NG == 3) {
+                    f16x8 F0[4], F1[4], F2[4];
+                    f16x8 a0 = *reinterpret_cast<const f16x8*>(ap), a1 = *reinterpret_cast<const f16x8*>(ap + 256);
+                    ldB(F0, 0, 0);
+                    ldB(F1, 1, 0);
+#pragma unroll 1
+                    for (int ks = 0; ks < dm.KS; ++ks) {
+                        // (the reads of step KS -- past the copies and the segment's tail, inside the block's LDS -- feed nothing)
+                        ldB(F2, 2, ks);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mm(F0, 0, a0, a1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const f16x8 n0 = *reinterpret_cast<const f16x8*>(ap + 32 * (ks + 1));
+                        const f16x8 n1 = *reinterpret_cast<const f16x8*>(ap + 256 + 32 * (ks + 1));
+                        ldB(F0, 0, ks + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mm(F1, 1, a0, a1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        ldB(F1, 1, ks + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mm(F2, 2, a0, a1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        a0 = n0;
+                        a1 = n1;
+                    }
+                } else {
+#pragma unroll 1
+                    for (int ks = 0; ks < dm.KS; ++ks) {
+                        f16x8 F[NG][4];
+                        const f16x8 a0 = *reinterpret_cast<const f16x8*>(ap + 32 * ks), a1 = *reinterpret_cast<const f16x8*>(ap + 256 + 32 * ks);
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) ldB(F[g], g, ks);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) mm(F[g], g, a0, a1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else {
                 const int cpy = (-scol) & 3;                                            // the copy whose fragment is 8-byte aligned for this shift
                 const _Float16* bhc = bh + (size_t)cpy * dm.CS + (PSH_EMX_PADL - scol - cpy) + 8 * kq;
                 const _Float16* blc = bl + (size_t)cpy * dm.CS + (PSH_EMX_PADL - scol - cpy) + 8 * kq;
