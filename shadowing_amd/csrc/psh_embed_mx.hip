@@ -24,12 +24,19 @@
 // fraction of a percent -- get the exact dense chains in the oracle's order (embedded_acc), and only those values are ranked:
 // results are bit-identical to embed_scan_kernel's.  The bootstrap uses the bound the other way round (upper bounds).
 // 1296 16x16x32 MFMAs per segment (8.6 us per SIMD) against ~15 000 VALU instructions for the dense chains.
+#include <cstdlib>
 #include <type_traits>
 
 #include "psh_device.h"
 
 namespace psh {
 
+#ifndef PSH_EMX_LOCK
+#define PSH_EMX_LOCK 0
+#endif
+#ifndef PSH_EMX_PRIO
+#define PSH_EMX_PRIO 0
+#endif
 #define PSH_EMX_THREADS 512                  // 8 waves, two per SIMD: one wave's epilogue / conversion runs beside the other's MFMAs
 #define PSH_EMX_TILE 0                       // fp32 copy of the segment in LDS for the exact verification (0: the survivors' windows are re-read from global memory)
 #define PSH_EMX_MAX_D 12
@@ -74,8 +81,7 @@ __host__ __device__ inline size_t emx_shmem_bytes(int K, int d, int B, int tile_
     size_t n = (size_t)PSH_EMX_MAX_D * 4 * m.CS * sizeof(_Float16) * 2;              // B operand: 12 rows x 4 shifted copies, hi and lo
     const size_t n8 = (size_t)PSH_EMX_MAX_D * 8 * m.CS8 * sizeof(_Float16);           // ... or 12 rows x 8 copies, hi
     n = n > n8 ? n : n8;
-    n += (size_t)d * K * sizeof(float);                                               // the fp32 kernel (exact verification)
-    n = (n + 15) & ~(size_t)15;
+    n += (size_t)d * ((K + 3) & ~3) * sizeof(float);                                  // the fp32 kernel (exact verification), rows padded to 16 bytes
     n += (size_t)(PSH_EMX_THREADS / 64) * ((size_t)2 * m.nhalf * sizeof(_Float16) + (size_t)(PSH_EMX_TILE ? tile_floats : 0) * sizeof(float)
                                            + (size_t)PSH_PEND * 16 + (size_t)PSH_EMX_QCAP * 4 + 64 * 4);
     n += (size_t)(((B + 3) & ~3) + 8) * sizeof(int) + 64;
@@ -116,8 +122,9 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
     _Float16* bh = reinterpret_cast<_Float16*>(smem);                                  // [12][4][CS] hi  (NP = 1: [12][8][CS8])
     _Float16* bl = bh + (size_t)PSH_EMX_MAX_D * 4 * dm.CS;                              // [12][4][CS] lo
     const size_t bop_halves = (size_t)PSH_EMX_MAX_D * (8 * dm.CS > 8 * dm.CS8 ? 8 * dm.CS : 8 * dm.CS8);
-    float* kerF = reinterpret_cast<float*>(bh + bop_halves);                            // d x K fp32
-    char* pw = reinterpret_cast<char*>(kerF) + (((size_t)d * K * 4 + 15) & ~(size_t)15);
+    const int Kst = (K + 3) & ~3;                                                       // row stride of the fp32 kernel: rows 16-byte aligned, zero tail
+    float* kerF = reinterpret_cast<float*>(bh + bop_halves);                            // d x Kst fp32
+    char* pw = reinterpret_cast<char*>(kerF) + (size_t)d * Kst * 4;
     const int tile_fl = PSH_EMX_TILE ? a.tile_floats : 0;
     const size_t per_wave = (size_t)2 * dm.nhalf * 2 + (size_t)tile_fl * 4 + (size_t)PSH_PEND * 16 + (size_t)PSH_EMX_QCAP * 4 + 64 * 4;
     char* mine = pw + (size_t)wave * per_wave;
@@ -134,12 +141,19 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
     f32x4* qc = reinterpret_cast<f32x4*>(qh + (size_t)Bp * 16);                          // QM: [Bp] {sqrt(tau)(1+2^-15), nx(1-eps2), -2/s_q, -}
     float* nhL = reinterpret_cast<float*>(qc + Bp) + (size_t)wave * 8 * 64;             // QM: the wave's window energies, [slot][kq][s]
     int npend = 0, nsq = 0;
+#ifdef PSH_TUNING
+    unsigned long long tacc[4] = {0ull, 0ull, 0ull, 0ull}, tlast = __builtin_amdgcn_s_memtime();     // set-up+convert / product / energies + per-query pass / verification at the unit's end
+    unsigned tcount[2] = {0u, 0u};                                                                   // survivors verified at unit ends, passes of 4
+    auto tstamp = [&](int i) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tacc[i] += t - tlast; tlast = t; };
+#else
+    auto tstamp = [&](int) {};
+#endif
 
     // ---- per-block set-up: kernel scale, the shifted hi/lo copies of every row, the radius constant
-    if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; ctl[3] = 0; }
+    if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; ctl[3] = 0; ctl[4] = 0; ctl[5] = 0; ctl[6] = 0; ctl[7] = 0; }
     if (MODE == PSH_MODE_FILTER)
         for (int q = tid; q < a.B; q += PSH_EMX_THREADS) lcount[q] = 0;
-    for (int e = tid; e < d * K; e += PSH_EMX_THREADS) kerF[e] = a.ker[e];
+    for (int e = tid; e < d * Kst; e += PSH_EMX_THREADS) { const int i = e / Kst, j = e - i * Kst; kerF[e] = j < K ? a.ker[i * K + j] : 0.0f; }
     {
         unsigned* z = reinterpret_cast<unsigned*>(yh);
         for (int i = lane; i < dm.nhalf; i += 64) z[i] = 0u;                            // 2 arrays x nhalf halves = nhalf dwords
@@ -147,11 +161,11 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
     __syncthreads();
     {
         unsigned mb = 0u;
-        for (int e = tid; e < d * K; e += PSH_EMX_THREADS) mb = max(mb, __float_as_uint(fabsf(kerF[e])));
+        for (int e = tid; e < d * Kst; e += PSH_EMX_THREADS) mb = max(mb, __float_as_uint(fabsf(kerF[e])));
         if (mb) atomicMax(reinterpret_cast<unsigned*>(&ctl[1]), mb);
         if (tid < d) {                                                                  // ||ker_i||_1^2 summed over the rows
             float l1 = 0.0f;
-            for (int j = 0; j < K; ++j) l1 += fabsf(kerF[tid * K + j]);
+            for (int j = 0; j < K; ++j) l1 += fabsf(kerF[tid * Kst + j]);
             atomicAdd(reinterpret_cast<float*>(&ctl[2]), l1 * l1 * 1.0001f);
             atomicMax(reinterpret_cast<unsigned*>(&ctl[3]), __float_as_uint(l1 * 1.0001f));
         }
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
             // copy c of row i:  copy[x] = L_i[x + c],  L_i[x] = ker_i[x - PADL] (zero outside [0, K))
             const int i = e / (4 * dm.CS), rem = e - i * 4 * dm.CS, c = rem / dm.CS, x2 = rem - c * dm.CS;
             const int j = x2 + c - PSH_EMX_PADL;
-            float v = (i < d && j >= 0 && j < K) ? kerF[i * K + j] * sk : 0.0f;
+            float v = (i < d && j >= 0 && j < K) ? kerF[i * Kst + j] * sk : 0.0f;
             const _Float16 hi = (_Float16)v;
             const _Float16 lo = (_Float16)(v - (float)hi);
             bh[e] = hi;
@@ -180,7 +194,7 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
 #pragma unroll
             for (int cc = 0; cc < 8; ++cc) c = ((dm.pos8 >> (4 * cc)) & 15u) == (unsigned)ps ? cc : c;
             const int j = x2 + c - PSH_EMX_PADL;
-            const float v = (i < d && j >= 0 && j < K) ? kerF[i * K + j] * sk : 0.0f;
+            const float v = (i < d && j >= 0 && j < K) ? kerF[i * Kst + j] * sk : 0.0f;
             bh[e] = (_Float16)v;
         }
     }
@@ -239,7 +253,7 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
             if constexpr (!FAST) {
                 // (mid-unit, a full queue -- rare: the accumulators are live, so the chain reads memory tap by tap and needs no registers)
                 if (lv && il < d) {
-                    const float* kr = kerF + il * K;
+                    const float* kr = kerF + il * Kst;
                     const float* yw = yrow + seg_start + pwin;
                     for (int j = 0; j < K; ++j) hy = __builtin_fmaf(kr[j], yw[j], hy);
                     Dl[el * 16 + il] = __fsub_rn(a.hx[(int64_t)b * d + il], hy);
@@ -250,7 +264,6 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                 // trip to memory per tap (38 us a pass of 4 survivors, a quarter of the 16-query scan)
                 // (survivors 0, 1 at the start of the hi copy, 2, 3 at the start of the lo copy: 2 Kst floats = 4 Kst halves each,
                 //  inside the part every segment rewrites -- the zero tails of the copies must stay zero: 0 * garbage)
-                const int Kst = (K + 3) & ~3;
                 float* ysA = reinterpret_cast<float*>(yh);
                 float* ysB = reinterpret_cast<float*>(yl);
                 {
@@ -271,11 +284,34 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                     }
                     wave_lds_fence();
                 }
-                const float* kr = kerF + (il < d ? il : 0) * K;
+                const float* kr = kerF + (il < d ? il : 0) * Kst;
                 const float* yw = ((el & 2) ? ysB : ysA) + Kst * (el & 1);
                 const float hxv = (lv && il < d) ? a.hx[(int64_t)b * d + il] : 0.0f;
-#pragma unroll 4
-                for (int j = 0; j < K; ++j) hy = __builtin_fmaf(kr[j], yw[j], hy);
+                {
+                    // the chain in the oracle's order, its operands 16 taps at a time as 16-byte LDS reads, the next 16 in flight
+                    // (a read per operand and tap, four taps at a time, sat at LDS latency every four fma: 16 k cycles a pass)
+                    const f32x4* kr4 = reinterpret_cast<const f32x4*>(kr);
+                    const f32x4* yw4 = reinterpret_cast<const f32x4*>(yw);
+                    const int nv = K >> 2, gmax = (Kst >> 2) - 1;
+                    f32x4 kb[4], yb[4];
+#pragma unroll
+                    for (int u2 = 0; u2 < 4; ++u2) { const int g4 = u2 < gmax ? u2 : gmax; kb[u2] = kr4[g4]; yb[u2] = yw4[g4]; }
+#pragma unroll 1
+                    for (int g0 = 0; g0 < nv; g0 += 4) {
+                        f32x4 kn[4], yn[4];
+#pragma unroll
+                        for (int u2 = 0; u2 < 4; ++u2) { const int g4 = g0 + 4 + u2 < gmax ? g0 + 4 + u2 : gmax; kn[u2] = kr4[g4]; yn[u2] = yw4[g4]; }
+#pragma unroll
+                        for (int u2 = 0; u2 < 4; ++u2)
+                            if (g0 + u2 < nv) {
+#pragma unroll
+                                for (int e4 = 0; e4 < 4; ++e4) hy = __builtin_fmaf(kb[u2][e4], yb[u2][e4], hy);
+                            }
+#pragma unroll
+                        for (int u2 = 0; u2 < 4; ++u2) { kb[u2] = kn[u2]; yb[u2] = yn[u2]; }
+                    }
+                    for (int j = 4 * nv; j < K; ++j) hy = __builtin_fmaf(kr[j], yw[j], hy);
+                }
                 if (lv && il < d) Dl[el * 16 + il] = __fsub_rn(hxv, hy);
             }
             wave_lds_fence();
@@ -380,6 +416,19 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int i = 0; i < 4 * NG; ++i) C[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // The two waves of a SIMD (w and w + 4) take turns on the matrix cores: one product loop at a time per SIMD, the other
+            // wave in its epilogue on the vector ALUs meanwhile.  Left alone the pair drifts into the same phase, where each
+            // gets half a pipe and the other pipe idles (r02 / r03 counters: MFMA-busy + VALU-busy = 87 % of the kernel's time).
+            if constexpr (NP == 1 && MODE == PSH_MODE_FILTER && PSH_EMX_LOCK) {
+                int got = 1;
+                do {
+                    if (lane == 0) got = atomicCAS(&ctl[4 + (wave & 3)], 0, 1);
+                    got = __builtin_amdgcn_readfirstlane(got);
+                    if (got) __builtin_amdgcn_s_sleep(4);
+                } while (got);
+            }
+            tstamp(0);
+            if constexpr (NP == 1 && MODE == PSH_MODE_FILTER && PSH_EMX_PRIO != 0) __builtin_amdgcn_s_setprio(PSH_EMX_PRIO);
             if constexpr (NP == 1) {
                 // ---- one product, 8 copies: every fragment ONE aligned 16-byte read, software-pipelined by hand (left to itself
                 // the compiler reads one fragment into ONE register quad, waits, issues its two MFMAs, reads the next: the LDS
@@ -406,26 +455,33 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                     f16x8 a0 = *reinterpret_cast<const f16x8*>(ap), a1 = *reinterpret_cast<const f16x8*>(ap + 256);
                     ldB(F0, 0, 0);
                     ldB(F1, 1, 0);
+                    // One read BETWEEN two MFMAs, into the buffer whose MFMAs were issued a group earlier: a block of 4 - 6 reads
+                    // behind 8 MFMAs holds the wave's next MFMA back by ~50 cycles per read (tools/ubench_emx_loop.hip: 1141 cycles
+                    // per step for one wave in the loop -- and the partner wave is in its epilogue more often than not -- against
+                    // 545 interleaved; the MFMAs alone: 405).
+#define PSH_EMX_STEP(FM, gm, FL, gl, ksl, EXTRA0, EXTRA1)                                                                              \
+                    _Pragma("unroll") for (int r4 = 0; r4 < 4; ++r4) {                                                                 \
+                        C[0][4 * (gm) + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, FM[r4], C[0][4 * (gm) + r4], 0, 0, 0);       \
+                        __builtin_amdgcn_sched_barrier(0);                                                                             \
+                        FL[r4] = *reinterpret_cast<const f16x8*>(bp + (size_t)(4 * (gl) + r4) * rstride + 32 * (ksl));                 \
+                        if (r4 == 0) { EXTRA0; }                                                                                       \
+                        if (r4 == 2) { EXTRA1; }                                                                                       \
+                        __builtin_amdgcn_sched_barrier(0);                                                                             \
+                        C[1][4 * (gm) + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, FM[r4], C[1][4 * (gm) + r4], 0, 0, 0);       \
+                        __builtin_amdgcn_sched_barrier(0);                                                                             \
+                    }
 #pragma unroll 1
                     for (int ks = 0; ks < dm.KS; ++ks) {
                         // (the reads of step KS -- past the copies and the segment's tail, inside the block's LDS -- feed nothing)
-                        ldB(F2, 2, ks);
-                        __builtin_amdgcn_sched_barrier(0);
-                        mm(F0, 0, a0, a1);
-                        __builtin_amdgcn_sched_barrier(0);
-                        const f16x8 n0 = *reinterpret_cast<const f16x8*>(ap + 32 * (ks + 1));
-                        const f16x8 n1 = *reinterpret_cast<const f16x8*>(ap + 256 + 32 * (ks + 1));
-                        ldB(F0, 0, ks + 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                        mm(F1, 1, a0, a1);
-                        __builtin_amdgcn_sched_barrier(0);
-                        ldB(F1, 1, ks + 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                        mm(F2, 2, a0, a1);
-                        __builtin_amdgcn_sched_barrier(0);
+                        f16x8 n0, n1;
+                        PSH_EMX_STEP(F0, 0, F2, 2, ks, (void)0, (void)0)
+                        PSH_EMX_STEP(F1, 1, F0, 0, ks + 1, n0 = *reinterpret_cast<const f16x8*>(ap + 32 * (ks + 1)),
+                                     n1 = *reinterpret_cast<const f16x8*>(ap + 256 + 32 * (ks + 1)))
+                        PSH_EMX_STEP(F2, 2, F1, 1, ks + 1, (void)0, (void)0)
                         a0 = n0;
                         a1 = n1;
                     }
+#undef PSH_EMX_STEP
                 } else {
 #pragma unroll 1
                     for (int ks = 0; ks < dm.KS; ++ks) {
@@ -500,14 +556,39 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                     }
                 }
             }
+            if constexpr (NP == 1 && MODE == PSH_MODE_FILTER && PSH_EMX_PRIO != 0) __builtin_amdgcn_s_setprio(0);
+            if constexpr (NP == 1 && MODE == PSH_MODE_FILTER && PSH_EMX_LOCK) {
+                if (lane == 0) __hip_atomic_store(&ctl[4 + (wave & 3)], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            tstamp(1);
             // ---- back to the data's units; ||H||^2 per window.  Slot (mt, r) of the lane: window 16 (32 hf + 16 mt + 4 kq + r) + scol
             float nh[8];
 #pragma unroll
             for (int sl = 0; sl < 8; ++sl) nh[sl] = 0.0f;
+            if constexpr (QM) {
+                // the accumulators stay in the product's units (inv is a power of two: the energies are scaled instead, exactly) and
+                // are squared as the register pairs lie -- (r0, r1), (r2, r3) of a tile -- with packed fma: 48 instructions where
+                // scaling + squaring element by element cost 96 v_pk_mul + 48 v_pk_fma + 184 moves that gathered the pairs
+                f32x2v np[2][2];
 #pragma unroll
-            for (int i = 0; i < 4 * NG; ++i) {                                         // (rows >= d: zero copies of the kernel -> exact zeros)
+                for (int mt = 0; mt < 2; ++mt) { np[mt][0] = f32x2v{0.f, 0.f}; np[mt][1] = f32x2v{0.f, 0.f}; }
 #pragma unroll
-                for (int sl = 0; sl < 8; ++sl) { C[sl >> 2][i][sl & 3] *= inv; nh[sl] = __builtin_fmaf(C[sl >> 2][i][sl & 3], C[sl >> 2][i][sl & 3], nh[sl]); }
+                for (int i = 0; i < 4 * NG; ++i) {                                     // (rows >= d: zero copies of the kernel -> exact zeros)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const f32x2v lo2 = __builtin_shufflevector(C[mt][i], C[mt][i], 0, 1), hi2 = __builtin_shufflevector(C[mt][i], C[mt][i], 2, 3);
+                        np[mt][0] = __builtin_elementwise_fma(lo2, lo2, np[mt][0]);
+                        np[mt][1] = __builtin_elementwise_fma(hi2, hi2, np[mt][1]);
+                    }
+                }
+#pragma unroll
+                for (int sl = 0; sl < 8; ++sl) nh[sl] = (np[sl >> 2][(sl & 3) >> 1][sl & 1] * inv) * inv;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4 * NG; ++i) {                                     // (rows >= d: zero copies of the kernel -> exact zeros)
+#pragma unroll
+                    for (int sl = 0; sl < 8; ++sl) { C[sl >> 2][i][sl & 3] *= inv; nh[sl] = __builtin_fmaf(C[sl >> 2][i][sl & 3], C[sl >> 2][i][sl & 3], nh[sl]); }
+                }
             }
             float nh_raw[8];
 #pragma unroll
@@ -532,6 +613,18 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                 for (int sl = 0; sl < 8; ++sl) bad0 = bad0 || !(nh_raw[sl] < __uint_as_float(PSH_INF_BITS));
                 const bool badC = __any(bad0);
                 f16x8 A2[8][(4 * NG > 8) ? 2 : 1];
+                {
+                    // product units -> the A fragments' scale in one (power-of-two) factor, again pair-wise in place
+                    const float k2 = inv * sc;
+                    const f32x2v k22 = f32x2v{k2, k2};
+#pragma unroll
+                    for (int i = 0; i < 4 * NG; ++i)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            const f32x2v lo2 = __builtin_shufflevector(C[mt][i], C[mt][i], 0, 1) * k22, hi2 = __builtin_shufflevector(C[mt][i], C[mt][i], 2, 3) * k22;
+                            C[mt][i] = __builtin_shufflevector(lo2, hi2, 0, 1, 2, 3);
+                        }
+                }
 #pragma unroll
                 for (int sl = 0; sl < 8; ++sl) {
                     nhL[sl * 64 + kq * 16 + scol] = nh[sl] * (1.0f - eps2) * (1.0f - 1.0f / 1048576.0f);
@@ -539,7 +632,7 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                     for (int h2 = 0; h2 < ((4 * NG > 8) ? 2 : 1); ++h2)
 #pragma unroll
                         for (int j = 0; j < 8; ++j)
-                            A2[sl][h2][j] = (8 * h2 + j < 4 * NG) ? (_Float16)(C[sl >> 2][(8 * h2 + j < 4 * NG) ? 8 * h2 + j : 0][sl & 3] * sc) : (_Float16)0.0f;
+                            A2[sl][h2][j] = (8 * h2 + j < 4 * NG) ? (_Float16)C[sl >> 2][(8 * h2 + j < 4 * NG) ? 8 * h2 + j : 0][sl & 3] : (_Float16)0.0f;
                 }
                 wave_lds_fence();
                 const int ncol = lane & 15, gq = lane >> 4;                             // D layout: column (kq', q) = ncol, rows 4 gq + rr = s
@@ -673,11 +766,23 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                 }
             }
             }
+            tstamp(2);
         }
+#ifdef PSH_TUNING
+        tcount[0] += (unsigned)nsq; tcount[1] += (unsigned)((nsq + 3) >> 2);
+#endif
         if (MODE == PSH_MODE_FILTER && nsq > 0) verify_end(seg_start, r_global, a.dataset + row * a.T);   // (the accumulators are dead here: the register-hungry fast chain)
+        tstamp(3);
         wave_lds_fence();
         u = un;
     }
+#ifdef PSH_TUNING
+    if (MODE == PSH_MODE_FILTER && a.dbg_times && lane == 0)
+    {
+        for (int i = 0; i < 4; ++i) a.dbg_times[((size_t)blockIdx.x * NW + wave) * 6 + i] = tacc[i];
+        for (int i = 0; i < 2; ++i) a.dbg_times[((size_t)blockIdx.x * NW + wave) * 6 + 4 + i] = tcount[i];
+    }
+#endif
     if (MODE == PSH_MODE_FILTER) {
         if (npend > 0) pend_flush(pend, npend, lcount, a, lane);
         __syncthreads();
@@ -707,7 +812,11 @@ static hipError_t launch_emx(const ScanArgs& a, int grid, hipStream_t s) {
 
 // the bootstrap with the split products; the full scan with one product and -- 3 .. 256 queries -- the per-query pass on the
 // matrix cores too, or (a.emb_mx == 3: PSH_FLAG_EMBED_MX_SPLIT) the split and the vector ALUs as in the bootstrap
-hipError_t launch_embed_mx(const ScanArgs& a, int mode, bool aligned, int grid, hipStream_t s) {
+hipError_t launch_embed_mx(const ScanArgs& a0, int mode, bool aligned, int grid, hipStream_t s) {
+    ScanArgs a = a0;
+#ifdef PSH_TUNING
+    if (const char* e = getenv("PSH_DBG_TIMES_PTR")) a.dbg_times = (unsigned long long*)strtoull(e, nullptr, 0);   // tools/emx_phases.py
+#endif
     if (mode == PSH_MODE_BOOT) return aligned ? launch_emx<true, PSH_MODE_BOOT, 3, false>(a, grid, s) : launch_emx<false, PSH_MODE_BOOT, 3, false>(a, grid, s);
     if (a.emb_mx == 3) return aligned ? launch_emx<true, PSH_MODE_FILTER, 3, false>(a, grid, s) : launch_emx<false, PSH_MODE_FILTER, 3, false>(a, grid, s);
     if (a.B >= PSH_EMX_QM_MIN_B && a.B <= PSH_EMX_QM_MAX_B)
