@@ -41,6 +41,7 @@ namespace psh {
 #define PSH_EMX_TILE 0                       // fp32 copy of the segment in LDS for the exact verification (0: the survivors' windows are re-read from global memory)
 #define PSH_EMX_MAX_D 12
 #define PSH_EMX_PADL 16                      // zero taps in front of a kernel row (shifts reach 15 taps back)
+#define PSH_EMX_CS8 312                     // halves per copy of the 8-copy layout: 39 slots of 16 bytes, 7 (mod 16)
 #define PSH_EMX_QCAP 128                     // survivors (window | query << 12) queued per wave before exact verification
 #define PSH_EMX_QM_MAX_B 256                 // the per-query pass runs on the matrix cores for 3 .. 256 queries (their tables sit in LDS)
 #define PSH_EMX_QM_MIN_B 3
@@ -67,11 +68,11 @@ __host__ __device__ inline EmxDims emx_dims(int K) {
     int cs = 32 * d.KS + PSH_EMX_PADL + 8;   // the last fragment ends at 32 (KS - 1) + 24 + PADL + 7
     if ((cs & 31) == 0) cs += 8;
     d.CS = cs;
-    int S = 4 * d.KS + 3;                    // slots of 8 halves; 4 KS + 2 are read
-    while ((S & 15) != 3 && (S & 15) != 7 && (S & 15) != 9 && (S & 15) != 13) S += 2;
-    d.CS8 = 8 * S;
-    // position of copy c, c = 0 .. 7 (lowest nibble first)
-    d.pos8 = (S & 15) == 3 ? 0x64175302u : (S & 15) == 7 ? 0x52176304u : (S & 15) == 9 ? 0x54176302u : 0x74265310u;
+    // (orders for the four strides, position of copy c = 0 .. 7 lowest nibble first: 3: 0x64175302, 7: 0x52176304, 9: 0x54176302,
+    //  13: 0x74265310.)  ONE stride serves every K <= 256: 39 slots (KS <= 9: 4 KS + 2 <= 38), so that the 12 rows' and 8 copies'
+    //  offsets are instruction immediates in the product loop instead of an address add per read.
+    d.CS8 = PSH_EMX_CS8;
+    d.pos8 = 0x52176304u;
     d.nhalf = 1024 + 32 * d.KS;
     return d;
 }
@@ -436,8 +437,8 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                 // groups (16 MFMAs = 256 cycles) before its MFMAs; NG < 3: all of a step's reads, then its MFMAs.
                 const int cpy = (-scol) & 7;
                 const int ps = (int)((dm.pos8 >> (4 * cpy)) & 15u);
-                const _Float16* bp = bh + (size_t)ps * dm.CS8 + (PSH_EMX_PADL - scol - cpy) + 8 * kq;
-                const int rstride = 8 * dm.CS8;
+                const _Float16* bp = bh + (size_t)ps * PSH_EMX_CS8 + (PSH_EMX_PADL - scol - cpy) + 8 * kq;
+                constexpr int rstride = 8 * PSH_EMX_CS8;
                 const _Float16* ap = yh + 16 * (32 * hf + scol) + 8 * kq;               // A row of M tile 0: m = 32 hf + (lane & 15); M tile 1: + 256
                 auto ldB = [&](f16x8 (&f)[4], int g, int ks) {
 #pragma unroll
@@ -452,34 +453,42 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                 };
                 if constexpr (NG == 3) {
                     f16x8 F0[4], F1[4], F2[4];
-                    f16x8 a0 = *reinterpret_cast<const f16x8*>(ap), a1 = *reinterpret_cast<const f16x8*>(ap + 256);
+                    f16x8 a0 = *reinterpret_cast<const f16x8*>(ap), a1 = *reinterpret_cast<const f16x8*>(ap + 256), b0, b1;
                     ldB(F0, 0, 0);
                     ldB(F1, 1, 0);
                     // One read BETWEEN two MFMAs, into the buffer whose MFMAs were issued a group earlier: a block of 4 - 6 reads
                     // behind 8 MFMAs holds the wave's next MFMA back by ~50 cycles per read (tools/ubench_emx_loop.hip: 1141 cycles
                     // per step for one wave in the loop -- and the partner wave is in its epilogue more often than not -- against
-                    // 545 interleaved; the MFMAs alone: 405).
-#define PSH_EMX_STEP(FM, gm, FL, gl, ksl, EXTRA0, EXTRA1)                                                                              \
+                    // 545 interleaved; the MFMAs alone: 405).  Two steps per turn (the A fragments alternate between two register
+                    // sets, no moves), every offset an immediate: 2 vector-ALU instructions per 48 MFMAs besides them.
+#define PSH_EMX_STEP(A0, A1, FM, gm, FL, gl, OFS, EXTRA0, EXTRA1)                                                                      \
                     _Pragma("unroll") for (int r4 = 0; r4 < 4; ++r4) {                                                                 \
-                        C[0][4 * (gm) + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, FM[r4], C[0][4 * (gm) + r4], 0, 0, 0);       \
+                        C[0][4 * (gm) + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0, FM[r4], C[0][4 * (gm) + r4], 0, 0, 0);       \
                         __builtin_amdgcn_sched_barrier(0);                                                                             \
-                        FL[r4] = *reinterpret_cast<const f16x8*>(bp + (size_t)(4 * (gl) + r4) * rstride + 32 * (ksl));                 \
+                        FL[r4] = *reinterpret_cast<const f16x8*>(bpk + (size_t)(4 * (gl) + r4) * rstride + (OFS));                     \
                         if (r4 == 0) { EXTRA0; }                                                                                       \
                         if (r4 == 2) { EXTRA1; }                                                                                       \
                         __builtin_amdgcn_sched_barrier(0);                                                                             \
-                        C[1][4 * (gm) + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, FM[r4], C[1][4 * (gm) + r4], 0, 0, 0);       \
+                        C[1][4 * (gm) + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1, FM[r4], C[1][4 * (gm) + r4], 0, 0, 0);       \
                         __builtin_amdgcn_sched_barrier(0);                                                                             \
                     }
+                    const _Float16* bpk = bp;
+                    const _Float16* apk = ap;
 #pragma unroll 1
-                    for (int ks = 0; ks < dm.KS; ++ks) {
+                    for (int ks = 0; ks < dm.KS; ks += 2) {
                         // (the reads of step KS -- past the copies and the segment's tail, inside the block's LDS -- feed nothing)
-                        f16x8 n0, n1;
-                        PSH_EMX_STEP(F0, 0, F2, 2, ks, (void)0, (void)0)
-                        PSH_EMX_STEP(F1, 1, F0, 0, ks + 1, n0 = *reinterpret_cast<const f16x8*>(ap + 32 * (ks + 1)),
-                                     n1 = *reinterpret_cast<const f16x8*>(ap + 256 + 32 * (ks + 1)))
-                        PSH_EMX_STEP(F2, 2, F1, 1, ks + 1, (void)0, (void)0)
-                        a0 = n0;
-                        a1 = n1;
+                        PSH_EMX_STEP(a0, a1, F0, 0, F2, 2, 0, (void)0, (void)0)
+                        PSH_EMX_STEP(a0, a1, F1, 1, F0, 0, 32, b0 = *reinterpret_cast<const f16x8*>(apk + 32),
+                                     b1 = *reinterpret_cast<const f16x8*>(apk + 256 + 32))
+                        PSH_EMX_STEP(a0, a1, F2, 2, F1, 1, 32, (void)0, (void)0)
+                        if (ks + 1 < dm.KS) {
+                            PSH_EMX_STEP(b0, b1, F0, 0, F2, 2, 32, (void)0, (void)0)
+                            PSH_EMX_STEP(b0, b1, F1, 1, F0, 0, 64, a0 = *reinterpret_cast<const f16x8*>(apk + 64),
+                                         a1 = *reinterpret_cast<const f16x8*>(apk + 256 + 64))
+                            PSH_EMX_STEP(b0, b1, F2, 2, F1, 1, 64, (void)0, (void)0)
+                        }
+                        bpk += 64;
+                        apk += 64;
                     }
 #undef PSH_EMX_STEP
                 } else {
