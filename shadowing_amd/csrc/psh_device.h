@@ -328,6 +328,7 @@ __device__ __forceinline__ float min3f(float a, float b, float c) {
     // moved right behind their MFMA)
     return __builtin_fminf(__builtin_fminf(a, b), c);
 }
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }   // v_max3_f32, as above
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float tile_min16(const f32x16_t& t) {
     // a tree of depth 3 (five independent v_min3 first), not a chain of 8: the chain's latency was the longest stretch of

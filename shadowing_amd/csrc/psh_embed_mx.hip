@@ -31,12 +31,6 @@
 
 namespace psh {
 
-#ifndef PSH_EMX_LOCK
-#define PSH_EMX_LOCK 0
-#endif
-#ifndef PSH_EMX_PRIO
-#define PSH_EMX_PRIO 0
-#endif
 #define PSH_EMX_THREADS 512                  // 8 waves, two per SIMD: one wave's epilogue / conversion runs beside the other's MFMAs
 #define PSH_EMX_TILE 0                       // fp32 copy of the segment in LDS for the exact verification (0: the survivors' windows are re-read from global memory)
 #define PSH_EMX_MAX_D 12
@@ -206,25 +200,37 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
     const float cerr = eps * __builtin_sqrtf(__uint_as_float((unsigned)ctl[2])) * 1.001f;
     const float kl1max = __uint_as_float((unsigned)ctl[3]);
     constexpr float eps2 = 1.001f * (1.0f / 1024.0f + 1.0f / 4194304.0f) + 64.0f / 16777216.0f;
+    float sqc = 1.0f, thrG = 0.0f;
+    int eqc = 0;
     if (QM) {
-        // per query: its coordinates as f16 at a power-of-two scale of its own (max |hx_i| in [256, 512)), its constants
+        // the queries' coordinates as f16 at ONE power-of-two scale (the largest |hx_i| of the batch in [256, 512)): with one scale
+        // the window energies can enter the per-query MFMAs as their C operand (below).  A coordinate more than 2^-22 below the
+        // batch's largest is a subnormal f16 -- absolute error 2^-25 / s instead of 2^-11 relative:  2 sum_i |H_i| 2^-25 / s <=
+        // 2^-24 sqrt(12 nh) / s <= 2^-12 nh + 12 * 2^-38 / s^2  -- a 2^-12 on the energies' factor and thrG on the thresholds.
+        unsigned mq = 0u;
+        for (int e = tid; e < a.B * d; e += PSH_EMX_THREADS) mq = max(mq, __float_as_uint(fabsf(a.hx[e])));
+        if (mq) atomicMax(reinterpret_cast<unsigned*>(&ctl[4]), mq);
+        __syncthreads();
+        const unsigned mb2 = (unsigned)ctl[4];
+        int eq = mb2 >= 0x00800000u ? 9 - ((int)((mb2 >> 23) & 255u) - 126) : 0;
+        eq = eq > 100 ? 100 : (eq < -100 ? -100 : eq);
+        eqc = eq;
+        sqc = __uint_as_float((unsigned)(127 + eq) << 23);
+        {
+            const float mxf = __uint_as_float(mb2);
+            thrG = (mxf * (1.0f / 33554432.0f)) * (mxf * (1.0f / 33554432.0f));        // 2^-50 max|hx|^2 >= 12 * 2^-38 / s^2  (1 / s <= max|hx| / 256)
+        }
         for (int q = tid; q < Bp; q += PSH_EMX_THREADS) {
-            float hq[16], mx = 0.0f, nxq = 0.0f;
+            float hq[16], nxq = 0.0f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 hq[i] = (q < a.B && i < d) ? a.hx[(int64_t)q * d + i] : 0.0f;
-                mx = fmaxf(mx, fabsf(hq[i]));
                 nxq = __builtin_fmaf(hq[i], hq[i], nxq);
             }
-            const unsigned mb2 = __float_as_uint(mx);
-            int eq = mb2 >= 0x00800000u ? 9 - ((int)((mb2 >> 23) & 255u) - 126) : 0;
-            eq = eq > 100 ? 100 : (eq < -100 ? -100 : eq);
-            const float sq_ = __uint_as_float((unsigned)(127 + eq) << 23);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) qh[q * 16 + i] = (_Float16)(hq[i] * sq_);
+            for (int i = 0; i < 16; ++i) qh[q * 16 + i] = (_Float16)(hq[i] * sqc);
             const float tau = q < a.B ? __uint_as_float(a.qstate[q].tau2_bits) : 0.0f;
-            qc[q] = f32x4{__builtin_sqrtf(tau) * (1.0f + 1.0f / 32768.0f), nxq * (1.0f - eps2) * (1.0f - 1.0f / 1048576.0f),
-                          -2.0f * __uint_as_float((unsigned)(127 - eq) << 23), 0.0f};
+            qc[q] = f32x4{__builtin_sqrtf(tau) * (1.0f + 1.0f / 32768.0f), nxq * (1.0f - eps2) * (1.0f - 1.0f / 1048576.0f), 0.0f, 0.0f};
         }
         __syncthreads();
     }
@@ -417,19 +423,7 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int i = 0; i < 4 * NG; ++i) C[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // The two waves of a SIMD (w and w + 4) take turns on the matrix cores: one product loop at a time per SIMD, the other
-            // wave in its epilogue on the vector ALUs meanwhile.  Left alone the pair drifts into the same phase, where each
-            // gets half a pipe and the other pipe idles (r02 / r03 counters: MFMA-busy + VALU-busy = 87 % of the kernel's time).
-            if constexpr (NP == 1 && MODE == PSH_MODE_FILTER && PSH_EMX_LOCK) {
-                int got = 1;
-                do {
-                    if (lane == 0) got = atomicCAS(&ctl[4 + (wave & 3)], 0, 1);
-                    got = __builtin_amdgcn_readfirstlane(got);
-                    if (got) __builtin_amdgcn_s_sleep(4);
-                } while (got);
-            }
             tstamp(0);
-            if constexpr (NP == 1 && MODE == PSH_MODE_FILTER && PSH_EMX_PRIO != 0) __builtin_amdgcn_s_setprio(PSH_EMX_PRIO);
             if constexpr (NP == 1) {
                 // ---- one product, 8 copies: every fragment ONE aligned 16-byte read, software-pipelined by hand (left to itself
                 // the compiler reads one fragment into ONE register quad, waits, issues its two MFMAs, reads the next: the LDS
@@ -565,10 +559,6 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                     }
                 }
             }
-            if constexpr (NP == 1 && MODE == PSH_MODE_FILTER && PSH_EMX_PRIO != 0) __builtin_amdgcn_s_setprio(0);
-            if constexpr (NP == 1 && MODE == PSH_MODE_FILTER && PSH_EMX_LOCK) {
-                if (lane == 0) __hip_atomic_store(&ctl[4 + (wave & 3)], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
             tstamp(1);
             // ---- back to the data's units; ||H||^2 per window.  Slot (mt, r) of the lane: window 16 (32 hf + 16 mt + 4 kq + r) + scol
             float nh[8];
@@ -613,14 +603,18 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                 const unsigned bb = __float_as_uint(ymax * kl1max);
                 int ec = bb >= 0x00800000u ? 14 - ((int)((bb >> 23) & 255u) - 126) : 0;
                 ec = ec > 100 ? 100 : (ec < -100 ? -100 : ec);
-                const float sc = __uint_as_float((unsigned)(127 + ec) << 23), inv_sc = __uint_as_float((unsigned)(127 - ec) << 23);
+                const float sc = __uint_as_float((unsigned)(127 + ec) << 23);
                 wave_lds_fence();                                                       // the half before this one has read nhL
                 // a non-finite accumulator (non-finite data) spoils the D values of the three other windows of its A row (0 * NaN):
                 // such a half segment takes the careful path for every group (a NaN fails '>' and is kept)
                 bool bad0 = false;
 #pragma unroll
                 for (int sl = 0; sl < 8; ++sl) bad0 = bad0 || !(nh_raw[sl] < __uint_as_float(PSH_INF_BITS));
-                const bool badC = __any(bad0);
+                // one scale for the 4 x 4 queries of every group:  v = nt + kk D,  kk = -2 / (s sc) < 0  ->  D' = nt / kk + D  with nt / kk
+                // the C operand of the slot's first MFMA;  v > thr  <=>  D' < thr / kk, the smallest v the largest D'.  (The MFMA adds
+                // nt / kk in fp32 like any partial sum: the (1 - 2^-20) on the energies covers 16 such roundings.)
+                const float inv_kk = (-0.5f * sqc) * sc;
+                const bool badC = __any(bad0) || eqc + ec > 120 || eqc + ec < -120;
                 f16x8 A2[8][(4 * NG > 8) ? 2 : 1];
                 {
                     // product units -> the A fragments' scale in one (power-of-two) factor, again pair-wise in place
@@ -634,31 +628,21 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                             C[mt][i] = __builtin_shufflevector(lo2, hi2, 0, 1, 2, 3);
                         }
                 }
+                {
+                    const float nf = ((1.0f - eps2 - 1.0f / 4096.0f) * (1.0f - 1.0f / 1048576.0f)) * inv_kk;
 #pragma unroll
-                for (int sl = 0; sl < 8; ++sl) {
-                    nhL[sl * 64 + kq * 16 + scol] = nh[sl] * (1.0f - eps2) * (1.0f - 1.0f / 1048576.0f);
+                    for (int sl = 0; sl < 8; ++sl) {
+                        nhL[sl * 64 + kq * 16 + scol] = nh[sl] * nf;
 #pragma unroll
-                    for (int h2 = 0; h2 < ((4 * NG > 8) ? 2 : 1); ++h2)
+                        for (int h2 = 0; h2 < ((4 * NG > 8) ? 2 : 1); ++h2)
 #pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            A2[sl][h2][j] = (8 * h2 + j < 4 * NG) ? (_Float16)C[sl >> 2][(8 * h2 + j < 4 * NG) ? 8 * h2 + j : 0][sl & 3] : (_Float16)0.0f;
+                            for (int j = 0; j < 8; ++j)
+                                A2[sl][h2][j] = (8 * h2 + j < 4 * NG) ? (_Float16)C[sl >> 2][(8 * h2 + j < 4 * NG) ? 8 * h2 + j : 0][sl & 3] : (_Float16)0.0f;
+                    }
                 }
                 wave_lds_fence();
                 const int ncol = lane & 15, gq = lane >> 4;                             // D layout: column (kq', q) = ncol, rows 4 gq + rr = s
                 const int kqp = ncol >> 2;
-                // one group of 4 queries: D of a slot, turned into acc^ - nx of the lane's 4 windows of that slot
-                auto eval_slot = [&](int sl, const f16x8 (&B2)[2], float kk) -> f32x4 {
-                    f32x4 D = f32x4{0.f, 0.f, 0.f, 0.f};
-                    D = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[sl][0], B2[0], D, 0, 0, 0);
-                    if (4 * NG > 8) D = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[sl][(4 * NG > 8) ? 1 : 0], B2[1], D, 0, 0, 0);
-                    const f32x4 nt = *reinterpret_cast<const f32x4*>(nhL + sl * 64 + kqp * 16 + 4 * gq);
-                    // (as the register pairs lie: two packed fma, no move -- left to itself the compiler pairs values of
-                    //  DIFFERENT slots and spends 73 moves per group on it)
-                    const f32x2v k2 = f32x2v{kk, kk};
-                    const f32x2v lo2 = __builtin_elementwise_fma(k2, __builtin_shufflevector(D, D, 0, 1), __builtin_shufflevector(nt, nt, 0, 1));
-                    const f32x2v hi2 = __builtin_elementwise_fma(k2, __builtin_shufflevector(D, D, 2, 3), __builtin_shufflevector(nt, nt, 2, 3));
-                    return __builtin_shufflevector(lo2, hi2, 0, 1, 2, 3);
-                };
 #pragma unroll 1
                 for (int Q4 = q_begin & ~3; Q4 < q_end; Q4 += 4) {
                     const int qn = Q4 + (ncol & 3);
@@ -669,23 +653,31 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                     B2[0] = mine2 ? *reinterpret_cast<const f16x8*>(qh + (size_t)qn * 16) : z8;
                     B2[1] = mine2 ? *reinterpret_cast<const f16x8*>(qh + (size_t)qn * 16 + 8) : z8;
                     const f32x4 qcv = qc[qv ? qn : q_begin];
+                    // D' of the 8 slots: energies in, the slots' first MFMAs, then their second ones (independent accumulators back to back)
+                    f32x4 D[8];
+#pragma unroll
+                    for (int sl = 0; sl < 8; ++sl) D[sl] = *reinterpret_cast<const f32x4*>(nhL + sl * 64 + kqp * 16 + 4 * gq);
                     const float st2 = qcv[0] + Rad;
-                    const float thr = qv ? st2 * st2 * (1.0f + 1.0f / 16384.0f) - qcv[1] : -__uint_as_float(PSH_INF_BITS);
-                    const float kk = qcv[2] * inv_sc;
-                    float vm = __uint_as_float(PSH_INF_BITS);
+                    const float thr = qv ? (st2 * st2 * (1.0f + 1.0f / 16384.0f) - qcv[1]) + thrG : -__uint_as_float(PSH_INF_BITS);
+                    const float thrp = thr * inv_kk;                                    // (a query that is not there: +inf -- nothing is above it)
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int sl = 0; sl < 8; ++sl) {
-                        const f32x4 v = eval_slot(sl, B2, kk);
-                        vm = min3f(vm, min3f(v[0], v[1], v[2]), v[3]);
+                    for (int sl = 0; sl < 8; ++sl) D[sl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[sl][0], B2[0], D[sl], 0, 0, 0);
+                    if (4 * NG > 8) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int sl = 0; sl < 8; ++sl) D[sl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[sl][(4 * NG > 8) ? 1 : 0], B2[1], D[sl], 0, 0, 0);
                     }
-                    if (!badC && !__any(qv && !(vm > thr))) continue;                   // the common case: nothing of these 4 queries here
-                    unsigned hm = 0u;                                                   // bit 4 sl + rr: the window survives
+                    __builtin_amdgcn_sched_barrier(0);
+                    float vm = -__uint_as_float(PSH_INF_BITS);
 #pragma unroll
-                    for (int sl = 0; sl < 8; ++sl) {
-                        const f32x4 v = eval_slot(sl, B2, kk);
+                    for (int sl = 0; sl < 8; ++sl) vm = max3f(vm, max3f(D[sl][0], D[sl][1], D[sl][2]), D[sl][3]);
+                    if (!badC && !__any(qv && !(vm < thrp))) continue;                  // the common case: nothing of these 4 queries here
+                    unsigned hm = 0u;                                                   // bit 4 sl + rr: the window survives (a NaN fails '<' and is kept)
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) hm |= !(v[rr] > thr) ? (1u << (4 * sl + rr)) : 0u;
-                    }
+                    for (int sl = 0; sl < 8; ++sl)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) hm |= !(D[sl][rr] < thrp) ? (1u << (4 * sl + rr)) : 0u;
                     if (!qv) hm = 0u;
                     while (__any(hm != 0u)) {
                         const bool has0 = hm != 0u;
