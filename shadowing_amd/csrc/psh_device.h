@@ -328,6 +328,19 @@ __device__ __forceinline__ float min3f(float a, float b, float c) {
     // moved right behind their MFMA)
     return __builtin_fminf(__builtin_fminf(a, b), c);
 }
+// The maximum of a non-negative value over the wave, in every lane (uniform): four DPP steps inside the rows of 16 lanes, then the
+// four rows through SGPRs -- no trip through the LDS crossbar (six dependent ds_bpermute are ~100+ cycles each beside a busy LDS).
+__device__ __forceinline__ float wave_max_nonneg(float x) {
+    int v = __float_as_int(x);
+    auto step = [&](int moved) { v = __float_as_int(fmaxf(__int_as_float(v), __int_as_float(moved))); };
+    step(__builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));    // quad_perm [1, 0, 3, 2]
+    step(__builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));    // quad_perm [2, 3, 0, 1]
+    step(__builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));   // row_half_mirror
+    step(__builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));   // row_mirror
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(v, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(v, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(v, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(v, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
 __device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }   // v_max3_f32, as above
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float tile_min16(const f32x16_t& t) {

@@ -359,9 +359,26 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
         const unsigned rs2 = uu - qg2 * n_rs;
         const unsigned ri2 = fast_div(rs2, a.magic_nseg, (unsigned)a.nseg);
         const unsigned sg2 = rs2 - ri2 * (unsigned)a.nseg;
+        sx.v[PSH_NSTAGE - 1] = f32x4{0.f, 0.f, 0.f, 0.f};  // (the last, partial stage: lanes past the segment would otherwise KEEP the old one -- live across the unit)
         stage_load<ALIGNED>(sx, a.dataset + (a.row0 + (int64_t)ri2 * a.row_stride) * a.T, a.T, (int)sg2 * PSH_SEG, nfloat, lane);
     };
-    // one segment in flight from HBM besides the one being worked on (one wave per SIMD: nothing else hides the latency)
+    // One segment in flight from HBM besides the one being worked on.  The full scan (LATE) has no 20 registers to keep it in
+    // across a unit -- the compiler spilled part of it right behind the loads, i.e. WAITED for HBM twice per unit (r03: 7.6 k of a
+    // unit's 35 k cycles) -- so there the next unit is only TOUCHED at the top of this one (one dword per 128-byte line: the
+    // segment comes to the L2) and read into registers at its end, when the accumulators are dead.
+    constexpr bool LATE = (MODE == PSH_MODE_FILTER && NP == 1);
+    auto touch_unit = [&](unsigned uu) -> float {
+        const unsigned qg2 = fast_div(uu, a.magic_nrs, n_rs);
+        const unsigned rs2 = uu - qg2 * n_rs;
+        const unsigned ri2 = fast_div(rs2, a.magic_nseg, (unsigned)a.nseg);
+        const unsigned sg2 = rs2 - ri2 * (unsigned)a.nseg;
+        const float* rowp = a.dataset + (a.row0 + (int64_t)ri2 * a.row_stride) * a.T;
+        int p = (int)sg2 * PSH_SEG + 32 * lane;
+        const int pl = (int)sg2 * PSH_SEG + nfloat - 1;
+        p = p < pl ? p : pl;
+        p = p < (int)a.T - 1 ? p : (int)a.T - 1;
+        return rowp[p];
+    };
     Stage st;
     unsigned u = grab();
     if (u < u_hi) load_unit(st, u);
@@ -384,8 +401,7 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
             for (int q = 0; q < PSH_NSTAGE; ++q)
                 if (q < PSH_NSTAGE - 1 || lane + 64 * q < nq)
                     ymax = fmaxf(ymax, fmaxf(fmaxf(fabsf(st.v[q][0]), fabsf(st.v[q][1])), fmaxf(fabsf(st.v[q][2]), fabsf(st.v[q][3]))));
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, off, 64));
+            ymax = wave_max_nonneg(ymax);
             const unsigned yb = __float_as_uint(ymax);
             ey = yb >= 0x00800000u ? 9 - ((int)((yb >> 23) & 255u) - 126) : 0;          // ymax 2^ey in [256, 512)
             ey = ey > 100 ? 100 : (ey < -100 ? -100 : ey);
@@ -407,8 +423,10 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                 npend = 0;
             }
             un = grab();
-            if (un < u_hi) load_unit(st, un);
+            if (!LATE && un < u_hi) load_unit(st, un);
         }
+        float touched = 0.0f;
+        if (LATE && un < u_hi) touched = touch_unit(un);
         wave_lds_fence();
 
         const float inv = __uint_as_float((unsigned)(127 - ey - ekc) << 23);
@@ -773,6 +791,10 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
         tcount[0] += (unsigned)nsq; tcount[1] += (unsigned)((nsq + 3) >> 2);
 #endif
         if (MODE == PSH_MODE_FILTER && nsq > 0) verify_end(seg_start, r_global, a.dataset + row * a.T);   // (the accumulators are dead here: the register-hungry fast chain)
+        if (LATE) {
+            asm volatile("" ::"v"(touched));                                                               // (the touch has landed: one register across the unit)
+            load_unit(st, un < u_hi ? un : u);             // (unconditionally: a segment kept "as it was" would be live across the whole unit)
+        }
         tstamp(3);
         wave_lds_fence();
         u = un;

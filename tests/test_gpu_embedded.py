@@ -418,6 +418,29 @@ def test_dense_kernel_on_the_matrix_cores_with_awkward_magnitudes(hip_device, or
     assert_exact(dd, idx, od, oidx, "embed_mx, awkward magnitudes")
 
 
+def test_dense_kernel_on_the_matrix_cores_one_scale_for_a_batch_over_many_decades(hip_device, oracle_mod):
+    """The per-query pass puts the whole batch's coordinates into f16 at ONE power-of-two scale (the window energies enter the
+    MFMAs as their C operand): 16 queries whose magnitudes span 11 decades, coordinates that are f16-subnormal at that scale
+    -- the slack on energies and thresholds keeps the test a rejection test; results are the oracle's."""
+    from shadowing_amd import _native
+    R, T, d, K, h, k, B = 2048, 1400, 11, 100, 6, 200, 16
+    ds = syn.dataset(R, T, 811)
+    ker = syn.wavelet_bank((d - 1) // 2, K)
+    x = syn.gbm_log_returns((B, K), 812)
+    x *= (10.0 ** np.random.default_rng(813).integers(-7, 5, size=B)).astype(np.float32)[:, None]
+    for b in (0, 7):                                            # planted near-matches of a quiet and of a loud query
+        ds[100 + b, 0, 50:50 + K] = x[b] * np.float32(1.001)
+    hx = torch.nn.functional.conv1d(torch.tensor(x)[:, None, :], torch.tensor(ker)[:, None, :])[:, :, 0].numpy()
+    hx[3, 2::3] *= np.float32(1e-9)                             # coordinates far below their query's largest
+    dd, idx, status, _ = hip_scan_embedded(hip_device, ds, ker, hx, k, h, flags=_native.FLAG_EMBED_MX)
+    if status.any():
+        bad = np.nonzero(status)[0]
+        d2, i2, _, _ = hip_scan_embedded(hip_device, ds, ker, hx[bad], k, h, exhaustive=True)
+        dd[bad], idx[bad] = d2, i2
+    od, oidx = oracle_mod.scan_topk_embedded(ds, ker, hx, k, h=h)
+    assert_exact(dd, idx, od, oidx, "embed_mx, one scale for queries over 11 decades")
+
+
 # ---- through the reference's own API -----------------------------------------------------------------
 @pytest.mark.parametrize("name", ["foveal_tutorial_small", "user_kernel_d5_K23", "foveal_ragged_B7"])
 def test_path_shadowing_with_linear_embedding_runs_native(hip_device, name):
