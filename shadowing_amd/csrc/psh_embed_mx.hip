@@ -9,7 +9,9 @@
 //   A  row m = the samples from window 16 m on (64 rows per segment, taken 32 at a time: two M tiles per half segment):
 //      fragment = 8 consecutive halves at 16 m + 32 ks + 8 kq -- an aligned 16-byte LDS read of the segment's f16 copy;
 //   B  one N tile PER KERNEL ROW i, its 16 columns the 16 shifts s:  B[k][s] = ker_i[k - s]  -> fragment = 8 consecutive
-//      taps at 32 ks + 8 kq - s: two aligned 8-byte reads of the copy of the row shifted by (-s) mod 4 (4 copies, hi and lo);
+//      taps at 32 ks + 8 kq - s: the full scan (one product) reads it as ONE aligned 16 bytes from the copy of the row shifted by
+//      (-s) mod 8 (8 copies, placed on the LDS banks so that a read's four lane groups are conflict-free: emx_dims); the
+//      bootstrap (split products) as two aligned 8-byte reads of the copy shifted by (-s) mod 4 (4 copies, hi and lo);
 //   C  tile (M tile, i), column s (the lane), row (the register): H_i of window 16 m + s.  K' = K + 15 taps in 32-tap steps.
 // A half segment (512 windows) keeps 2 x 12 tiles x 4 = 96 accumulator registers per lane -- all of them VGPRs the epilogue
 // can read (a whole segment's 192 spill: the vector ALUs cannot take AGPR operands).
@@ -24,6 +26,20 @@
 // fraction of a percent -- get the exact dense chains in the oracle's order (embedded_acc), and only those values are ranked:
 // results are bit-identical to embed_scan_kernel's.  The bootstrap uses the bound the other way round (upper bounds).
 // 1296 16x16x32 MFMAs per segment (8.6 us per SIMD) against ~15 000 VALU instructions for the dense chains.
+//
+// r03, the full scan (FILTER, one product: 432 MFMAs a segment + 128 of the per-query pass).  Measured per half segment and wave
+// with tools/emx_phases.py: the matrix cores and the vector ALUs of a SIMD do NOT overlap between its two waves here (a raised
+// priority or a lock that keeps the two out of the product loop together only moves time from one phase to the other), so the
+// kernel's time is the SUM of its MFMA cycles, its vector-ALU issue cycles and its stalls -- and each was cut:
+//   * product loop: fragments software-pipelined by hand, ONE 16-byte read between two MFMAs (a block of reads behind 8 MFMAs
+//     costs ~50 cycles per read: tools/ubench_emx_loop.hip), every offset an immediate, two steps per turn: no vector-ALU
+//     instruction in the loop, bank conflicts 3.7 -> 0.3 cycles per LDS cycle;
+//   * energies and the A fragments of the per-query pass from the UNSCALED accumulators with packed operations on the register
+//     pairs as they lie (450 -> 234 instructions), one f16 scale for the batch's queries so that the energies enter the per-query
+//     MFMAs as their C operand (59 -> 44 per four queries);
+//   * the next unit is touched into the L2 at a unit's top and read at its end (kept in registers across a unit it was spilled
+//     right behind its loads: a wait for HBM per unit); survivors' exact chains read 16 taps per LDS round trip.
+// configs[4]'s shard (R = 32768, 16 queries): 1.61 -> 1.15 ms.
 #include <cstdlib>
 #include <type_traits>
 

@@ -33,8 +33,8 @@ def _kernels(txt: str) -> dict:
 @pytest.fixture(scope="module")
 def asm(tmp_path_factory):
     tmp = tmp_path_factory.mktemp("isa")
-    names = ["psh_stream", "psh_fused", "psh_embed_px"]
-    with ThreadPoolExecutor(max_workers=3) as pool:
+    names = ["psh_stream", "psh_fused", "psh_embed_px", "psh_embed_mx"]
+    with ThreadPoolExecutor(max_workers=4) as pool:
         return dict(zip(names, pool.map(lambda n: _asm(n, tmp), names)))
 
 
@@ -77,3 +77,30 @@ def test_foveal_prefix_sum_scan_keeps_scratch_out_of_its_hot_loops(asm):
                     hot += 1
                     assert not any("scratch_" in x for x in loop), f"{name}: scratch access inside a row loop"
         assert hot >= 1, f"{name}: no row loop found"
+
+
+def test_wavelet_scan_on_the_matrix_cores_does_not_spill_and_keeps_its_product_loop_clean(asm):
+    """embed_mx_kernel: the bootstrap and the full scan (one product; per-query pass on the matrix cores or not) do not spill
+    for 1, 2 or 3 row groups (the split-product full scan, an A/B flag, may); the production product loop (three row groups)
+    is MFMAs and 16-byte LDS reads only -- 48 + 28 per turn, no vector-ALU instruction between them."""
+    txt = asm["psh_embed_mx"]
+    k = {n: m for n, m in _kernels(txt).items() if "embed_mx_kernel" in n}
+    assert len(k) == 24
+    prod = {n: m for n, m in k.items() if not re.search(r"ELi1ELi[123]ELi3ELb0E", n)}     # (FILTER, NP = 3: PSH_FLAG_EMBED_MX_SPLIT)
+    assert len(prod) == 18 and all(m["spill"] == 0 and m["scratch"] == 0 for m in prod.values()), prod
+    for name in [n for n in k if re.search(r"ILb[01]ELi1ELi3ELi1ELb1E", n)]:
+        body = txt[txt.index("\n" + name + ":"):]
+        body = body[:body.index("s_endpgm")].splitlines()
+        loops = []
+        labels = {m.group(1): i for i, ln in enumerate(body) for m in [re.match(r"(\.LBB\d+_\d+):", ln)] if m}
+        for i, ln in enumerate(body):
+            m = re.match(r"\s+s_c?branch\w* (\.LBB\d+_\d+)", ln)
+            if m and labels.get(m.group(1), i + 1) < i:
+                ops = [x.split()[0] for x in body[labels[m.group(1)]:i] if re.match(r"\s+[a-z]", x)]
+                if sum(o.startswith("v_mfma") for o in ops) >= 48:
+                    loops.append(ops)
+        assert loops, name
+        ops = min(loops, key=len)                                         # the innermost loop holding the 48 MFMAs
+        assert sum(o.startswith("v_mfma") for o in ops) == 48 and sum(o == "ds_read_b128" for o in ops) == 28, ops
+        assert not [o for o in ops if o.startswith("v_") and not o.startswith("v_mfma") and o not in ("v_add_u32_e32",)], ops
+        assert sum(o == "v_add_u32_e32" for o in ops) <= 2, ops

@@ -12,3 +12,7 @@ for CTRS in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_
 done
 python $R/tools/summarize_pmc.py $OUT | grep -E "^==|embed_mx_kernel<true, 1" > $OUT/pmc_summary.txt 2>&1
 cat $OUT/emx_prof.log; cut -c1-150 $OUT/pmc_summary.txt
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_emx -o f -- python $R/tools/emx_prof.py 16 > $OUT/emx_prof_trace.log 2>&1
+for f in $(find $OUT/prof_emx -name "*kernel_stats.csv"); do grep "Name\|psh::" $f > $OUT/wavelet_kernel_stats.csv; done
+cat $OUT/wavelet_kernel_stats.csv | cut -c1-160
+python $R/tools/emx_phases.py 2>&1 | tail -4 > $OUT/emx_phases.txt; cat $OUT/emx_phases.txt
