@@ -172,6 +172,10 @@ int psh_query_norm(int device, void* stream, const float* queries, int B, int W,
  *   out_idx   device, B x k x 2 int32 = [r_offset + r, t]
  *   out_status device, B int32 (PSH_STATUS_*)
  *
+ * "device" for the small arguments (queries, out_d, out_idx, out_status; paths of psh_gather_paths) means device-ADDRESSABLE:
+ * pinned host memory mapped into the device's address space (hipHostMalloc) is fine -- a blocking caller can have the kernels
+ * read its query from and write its results into host memory and spare two copies (what shadowing_amd's shadow() does for one
+ * query: 80 bytes in, B*k*12 bytes + the gathered paths out).  The ensemble and the workspace belong in HBM.
  * Requires R*(T-W-h+1) >= k (the reference raises for k larger than a split,
  * path_shadowing.py:165) and r_offset + R, T < 2^31.
  * One-window rows (T == W + h, e.g. N pre-embedded points of PathDistance.forward_topk with
