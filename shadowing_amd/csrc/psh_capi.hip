@@ -916,8 +916,8 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     se.bcount2 = (use_mx && rank2 > 0) ? w.bcount2 : nullptr;
     if (use_mx && rank2 > 0) { se.dataset = dataset; se.queries = queries; se.T = p.T; se.r_offset = p.r_offset; se.W = p.W; }
     se.dbg_times = tuning().dbg_select;
-    // (the flags sit behind the B <= 2 totals in their 256-byte slot of the workspace)
-    if (B <= 2 && !(flags_of(profile) & PSH_FLAG_SELECT_ONE_BLOCK)) {
+    // (the flags sit behind the B <= 8 totals in their 256-byte slot of the workspace: ints 32 .. 39)
+    if (B <= PSH_RANK_MAX_B && !(flags_of(profile) & PSH_FLAG_SELECT_ONE_BLOCK)) {
         int tb = 0;
         while ((1ll << tb) < p.Tp) ++tb;
         se.rank_tbits = ((p.R + p.r_offset) <= (1ll << (32 - tb))) ? tb : -1;   // rows r_offset .. r_offset + R - 1, t < Tp

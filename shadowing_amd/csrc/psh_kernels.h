@@ -222,7 +222,9 @@ struct SelectArgs {
                              // the results of query b already: select_kernel returns at once
 };
 #define PSH_RANK_CAP 8192            // candidates rank_select_kernel ranks (8 per thread in registers)
-#define PSH_RANK_GRID 256            // its blocks per query: each ranks its 1/256 of the candidates against all of them
+#define PSH_RANK_GRID 256            // its blocks per query (one or two queries; 3 .. 8 queries: 256 / B -- measured: 4 queries 176 -> 155 us per call, 8: 199 -> 189, 16: no gain): each ranks its share of the candidates against all of them
+#define PSH_RANK_MAX_B 8
+#define PSH_RANK_OWN (PSH_RANK_CAP / 16 + 2)   // a block's own candidates at most
 
 struct MergeSortedArgs {   // k best of G lists, each sorted by (d, r, t), list g holding smaller rows than list g+1
     const float* d;          // list g of query b: d + g * stride_d + b * k_in

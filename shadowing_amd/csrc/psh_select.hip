@@ -374,9 +374,9 @@ __device__ __forceinline__ int finish_rank(const uint64_t* run, int len, int lo,
 // handled[b] = 1 that launch returns at once.
 struct RankShared {
     int offs[PSH_MAX_BLOCKS + 1];
-    uint64_t own_key[PSH_RANK_CAP / PSH_RANK_GRID + 2];
-    int2 own_rt[PSH_RANK_CAP / PSH_RANK_GRID + 2];
-    int rankc[PSH_RANK_CAP / PSH_RANK_GRID + 2];
+    uint64_t own_key[PSH_RANK_OWN];
+    int2 own_rt[PSH_RANK_OWN];
+    int rankc[PSH_RANK_OWN];
     int wtot[PSH_SELECT_THREADS / 64];
     int overflow;
 };
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void rank_select_kernel(SelectA
     const int2* crt = a.cand_rt + (int64_t)b * a.cand_stride;
     const int* bc = a.bcount + (int64_t)b * PSH_MAX_BLOCKS;
     const int* bc2 = a.bcount2 ? a.bcount2 + (int64_t)b * PSH_MAX_BLOCKS : nullptr;
-    constexpr int OWN = PSH_RANK_CAP / PSH_RANK_GRID + 2;
+    constexpr int OWN = PSH_RANK_OWN;
     int dbg_i = 0;
     auto mark = [&]() { if (a.dbg_times && g == 1 && b == 0 && tid == 0) a.dbg_times[dbg_i] = wall_clock64(); ++dbg_i; };
     mark();
@@ -1300,11 +1300,14 @@ hipError_t launch_select(const SelectArgs& a0, int B, hipStream_t s) {
         hipError_t e = hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
     }
-    // one or two queries with few candidates expected: the ranking on all CUs first (rank_select_kernel)
+    // up to 8 queries with few candidates expected: the ranking on all CUs first (rank_select_kernel), 256 blocks for one or two
+    // queries, 256 / B for more (a block's own share stays within PSH_RANK_OWN down to 16 blocks)
     if (a.handled) {
-        if (a.bcount && B <= 2 && a.k <= PSH_RANK_CAP / 2 && !a.rank_sort && !a.skip_negative_rows && a.rank_tbits >= 0)
-            hipLaunchKernelGGL(rank_select_kernel, dim3(PSH_RANK_GRID, B), dim3(PSH_SELECT_THREADS), 0, s, a);
-        else
+        if (a.bcount && B <= PSH_RANK_MAX_B && a.k <= PSH_RANK_CAP / 2 && !a.rank_sort && !a.skip_negative_rows && a.rank_tbits >= 0) {
+            int G = PSH_RANK_GRID;
+            if (B > 2) { G = PSH_RANK_GRID / B; if (G < 16) G = 16; }
+            hipLaunchKernelGGL(rank_select_kernel, dim3(G, B), dim3(PSH_SELECT_THREADS), 0, s, a);
+        } else
             a.handled = nullptr;
     }
     hipLaunchKernelGGL(select_kernel, dim3(B), dim3(PSH_SELECT_THREADS), shmem, s, a);
