@@ -77,7 +77,7 @@ struct BootPlan { int64_t rows; int per_wave; int64_t entries; };
 // provable k-th smallest tight.  (Never more entries than the plain plan: the workspace is sized for that one.)
 // `thin` (with `estimate`): 1/64 of the rows -- the scans whose sample is itself expensive (the batched matrix-core scan's
 // costs 2.2x a scan of the same rows: 0.58 of 4.9 ms at 512 queries with 1/16); the estimate's rank is then ~48.
-BootPlan boot_plan(int64_t R, int64_t Tp, int k, bool halves = false, bool estimate = false, bool thin = false) {
+BootPlan boot_plan(int64_t R, int64_t Tp, int k, bool halves = false, bool estimate = false, bool thin = false, double margin = 12.0) {
     BootPlan bp{0, 0, 0};
     const int64_t nseg = (Tp + PSH_SEG - 1) / PSH_SEG;
     const int64_t quarter = R / 4;
@@ -87,7 +87,7 @@ BootPlan boot_plan(int64_t R, int64_t Tp, int k, bool halves = false, bool estim
     int64_t need_rows = (8 * (int64_t)k + nseg - 1) / nseg;
     if (estimate) {
         need_rows = (1024 + nseg - 1) / nseg;
-        const double per_row = (double)nseg - 12.0 * (double)k / (double)R;              // entries - 8 x rank, per sampled row
+        const double per_row = (double)nseg - margin * (double)k / (double)R;            // entries - 8 x rank (margin 12; 4.5: 3 x rank), per sampled row
         if (per_row > 0.25) { const int64_t nr = (int64_t)(128.0 / per_row) + 1; if (nr > need_rows) need_rows = nr; }
         else need_rows = quarter + 1;                                                    // k too close to the ensemble's size: no sample
     }
@@ -628,6 +628,17 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     // (the matrix-core embedded scan samples one minimum per HALF segment; a sample too thin for that plan is taken by
     // embed_scan_kernel instead -- the full scan still runs on the matrix cores)
     BootPlan bp = boot_plan(p.R, p.Tp, k, p.emx, p.ker != nullptr || !use_mx, !p.ker && !use_mx);
+    // A single query with a LARGE k (the reference's own example call: Identity(20), R = 32768, k = 8192 -- testing.ipynb): the
+    // provable bound wants 8 k segment minima, more than a quarter of the rows have; the plan then fell to one minimum per LANE
+    // (264 k minima, 0.19 ms to find the k-th among them, a bound that admitted 4.6 k candidates per k).  Such a call admits below
+    // an ESTIMATE instead, like the embedded scans do: 1/32 of the rows, the r2-th smallest of their segment minima with ~1.5 k
+    // windows of the ensemble expected below it; fewer than k found -> status -> the caller's exhaustive pass.
+    bool mx_estimate = false;
+    // (a sample of moderate size keeps its provable bound: per lane up to 100 k minima, per segment up to an eighth of the rows)
+    if (use_mx && ((bp.per_wave == 0 && bp.entries > 100000) || (bp.per_wave == 1 && bp.rows * 8 > p.R))) {
+        const BootPlan be = boot_plan(p.R, p.Tp, k, false, true, false, 4.5);
+        if (be.per_wave == 1 && be.entries <= w.min_stride) { bp = be; mx_estimate = true; }
+    }
     const bool boot_emx = p.emx && bp.per_wave == 2;
     if (p.emx && !boot_emx) bp = boot_plan(p.R, p.Tp, k, false, true);
     // one-window rows (T == W + h; PathDistance.forward_topk's N pre-embedded points): rows_kernel, a row per lane.
@@ -834,7 +845,10 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     // smallest acc (the rank2-th smallest sampled minimum ~ 2k windows of the whole ensemble below it)
     int rank2 = 0;
     int k_thr = k;             // the rank the threshold kernel selects exactly
-    if (use_mx) {
+    if (use_mx && mx_estimate) {
+        const int64_t r2 = (3 * (int64_t)k * n_sample + 2 * p.R - 1) / (2 * p.R) + 16;
+        if (r2 < k && r2 <= bp.entries) k_thr = (int)r2;
+    } else if (use_mx) {
         const int64_t r2 = (2 * (int64_t)k * n_sample + p.R - 1) / p.R + 8;
         rank2 = (r2 < k && r2 <= bp.entries) ? (int)r2 : 0;
     } else {            // every other scan: the embedded ones, one-window rows, the batched matrix-core scan, the VALU-filter scans

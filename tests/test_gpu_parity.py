@@ -411,6 +411,37 @@ def test_two_class_slices_fall_back_when_the_estimate_is_too_low(hip_device, ora
     assert_exact(d2, idx2, od2, oidx2, "two-class normal")
 
 
+@pytest.mark.parametrize("k", [4096, 8192, 16384])
+def test_single_query_with_a_large_k_admits_below_an_estimate(hip_device, oracle_mod, k):
+    """The reference's own example call (testing.ipynb: Identity(20), R = 32768, k = 8192): the provable bound would want 8 k
+    segment minima -- more than the rows have to give -- so the scan admits below an ESTIMATE from a 1/32 sample (~1.5 k windows
+    expected below it) and the selection checks that k were found.  Exact against the oracle; the candidates stay a small
+    multiple of k.  Near-copies of the query planted in sampled rows only drag the estimate down: fewer than k found -> status
+    -> the exhaustive pass, still exact."""
+    from shadowing_amd import _native
+    R, T, h = 32768, 4096, 20
+    ds = syn.dataset(R, T, 0)[:, 0, :]
+    q = syn.single_query(20, 1801)[None, :]
+    d, idx, status, prof = hip_scan(hip_device, ds, q, k, h, profile=True)
+    assert status[0] == 0 and prof["path"] == 0 and prof["n_sample_rows"] == 1024
+    assert k <= prof["n_candidates"] < 3 * k
+    od, oidx = oracle_mod.scan_topk(ds, q, k, h=h)
+    assert_exact(d, idx, od, oidx, f"large k = {k}")
+    if k == 8192:
+        ds2 = ds.copy()
+        rng = np.random.default_rng(1802)
+        for r in range(16, R, 32):                             # the sampled rows (stride 32, first row 16): a near-copy in each
+            t = int(rng.integers(0, T - 60))
+            ds2[r, t:t + 20] = q[0] * (1 + 0.01 * rng.standard_normal(20).astype(np.float32))
+        dev = torch.device("cuda", 0)
+        dsd, qd = torch.as_tensor(ds2).to(dev), torch.as_tensor(q).to(dev)
+        _, _, st = _native.scan_topk(dsd, qd, k, h=h)
+        assert int(st[0]) != 0                                 # the estimate sits among the planted copies: short of k
+        d2, i2 = _native.scan_topk_checked(dsd, qd, k, h=h)
+        od2, oidx2 = oracle_mod.scan_topk(ds2, q, k, h=h)
+        assert_exact(d2.cpu().numpy(), i2.cpu().numpy(), od2, oidx2, "large k, estimate fooled")
+
+
 @pytest.mark.parametrize("G,k_in,k,B", [(8, 1024, 1024, 1), (3, 500, 700, 2), (2, 64, 200, 4), (1, 128, 128, 2), (5, 100, 37, 2)])
 def test_merge_of_sorted_gathered_lists(hip_device, oracle_mod, G, k_in, k, B):
     """psh_merge_sorted_gathered: G sorted per-shard lists (ascending row blocks) -> global k best, positions

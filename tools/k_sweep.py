@@ -1,0 +1,24 @@
+import sys, time
+sys.path.insert(0, "/root/repo")
+import numpy as np, torch
+import shadowing_amd as sa
+from shadowing_amd import _native, synthetic as syn
+dev = torch.device("cuda", 0)
+ds = torch.as_tensor(syn.dataset(32768, 4096, 0)).cuda()
+q = torch.as_tensor(syn.single_query(20, 1)[None]).cuda()
+ws = _native.Workspace(dev)
+for k in (1024, 4096, 8192, 16384):
+    for _ in range(3): out = _native.scan_topk(ds[:, 0, :], q, k, h=20, workspace=ws)
+    torch.cuda.synchronize()
+    *_, prof = _native.scan_topk(ds[:, 0, :], q, k, h=20, workspace=ws, profile=True)
+    t0 = time.perf_counter()
+    for _ in range(50): _native.scan_topk(ds[:, 0, :], q, k, h=20, workspace=ws)
+    torch.cuda.synchronize()
+    print(k, "us per call", round((time.perf_counter() - t0) / 50 * 1e6, 1), {a: round(b, 4) if isinstance(b, float) else b for a, b in prof.items()})
+obj = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), ds, sa.PredictionContext(horizon=20))
+x = syn.single_query(20, 1)
+for k in (1024, 8192):
+    for _ in range(3): obj.shadow(x, k=k, cuda=True)
+    t0 = time.perf_counter()
+    for _ in range(30): obj.shadow(x, k=k, cuda=True)
+    print("shadow() k", k, "us per call", round((time.perf_counter() - t0) / 30 * 1e6, 1))
