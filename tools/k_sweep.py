@@ -1,5 +1,8 @@
+"""Probe: one Identity(20) query at configs[1]'s ensemble for k = 1024 ... 16384 (testing.ipynb's own example call asks for k = 8192):
+scan time per call with the stage times of one profiled call, and PathShadowing.shadow() with its gathered paths."""
 import sys, time
-sys.path.insert(0, "/root/repo")
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np, torch
 import shadowing_amd as sa
 from shadowing_amd import _native, synthetic as syn
@@ -18,7 +21,7 @@ for k in (1024, 4096, 8192, 16384):
 obj = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), ds, sa.PredictionContext(horizon=20))
 x = syn.single_query(20, 1)
 for k in (1024, 8192):
-    for _ in range(3): obj.shadow(x, k=k, cuda=True)
+    for _ in range(5): obj.shadow(x, k=k, cuda=True)
     t0 = time.perf_counter()
     for _ in range(30): obj.shadow(x, k=k, cuda=True)
     print("shadow() k", k, "us per call", round((time.perf_counter() - t0) / 30 * 1e6, 1))

@@ -43,6 +43,7 @@ timeout 300 python tools/fused_times.py > $OUT/fused_phase_times.txt 2>> $OUT/be
 # the widened rows of the scope table: the reference's Foveal workloads, configs[4] (wavelet), forward_topk
 timeout 600 python tools/bench_foveal.py --steps 20 --generic --which tutorial testing wavelet 2>> $OUT/bench.err | grep "^{" > $OUT/bench_foveal.jsonl
 timeout 300 python tools/bench_forward_topk.py 2>> $OUT/bench.err | grep "^{" > $OUT/bench_forward_topk.jsonl
+timeout 300 python tools/k_sweep.py 2>> $OUT/bench.err | grep "us per call" > $OUT/k_sweep.txt
 timeout 300 python tools/rows_stages.py 2>> $OUT/bench.err | grep "^[0-9]" > $OUT/forward_topk_stages.txt
 timeout 300 python tools/q512_stages.py 2>> $OUT/bench.err | grep "^{" > $OUT/q512_stages.txt
 cd /tmp
