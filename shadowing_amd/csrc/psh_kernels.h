@@ -224,6 +224,7 @@ struct SelectArgs {
 #define PSH_RANK_CAP 8192            // candidates rank_select_kernel ranks (8 per thread in registers)
 #define PSH_RANK_GRID 256            // its blocks per query (one or two queries; 3 .. 8 queries: 256 / B -- measured: 4 queries 176 -> 155 us per call, 8: 199 -> 189, 16: no gain): each ranks its share of the candidates against all of them
 #define PSH_RANK_MAX_B 8
+#define PSH_RANK_NMAX PSH_RANK_CAP    // candidates it takes in all (passes of PSH_RANK_CAP: one); a block's own share must fit PSH_RANK_OWN
 #define PSH_RANK_OWN (PSH_RANK_CAP / 16 + 2)   // a block's own candidates at most
 
 struct MergeSortedArgs {   // k best of G lists, each sorted by (d, r, t), list g holding smaller rows than list g+1

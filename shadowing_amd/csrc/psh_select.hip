@@ -427,78 +427,89 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void rank_select_kernel(SelectA
     }
     const int n = sm.offs[a.nblk];
     mark();
-    const bool ok = !sm.overflow && n >= a.k && n <= PSH_RANK_CAP;           // the same verdict in every block
+    const bool ok = !sm.overflow && n >= a.k && n <= PSH_RANK_NMAX && n / G + 1 <= OWN - 1;    // the same verdict in every block
     if (g == 0 && tid == 0) a.handled[b] = ok ? 1 : 0;
     if (!ok) return;
     if (g == 0 && tid == 0) {
         if (a.total) a.total[b] = n;
         if (a.qstate) a.qstate[b].n_valid = a.k;
     }
-    // all candidates, 8 per thread, as 64-bit keys d << 32 | r << tbits | t (the launcher checked that (r, t) fits 32 bits);
-    // the block's own ones also to LDS
+    // candidates as 64-bit keys d << 32 | r << tbits | t (the launcher checked that (r, t) fits 32 bits).  The block's own share
+    // goes to LDS first; then ALL candidates pass through the registers PSH_RANK_CAP at a time (8 per thread) and are counted
+    // against the own ones (one pass: PSH_RANK_NMAX == PSH_RANK_CAP; more passes were measured and lose to the radix select beyond that).
     constexpr int NE = PSH_RANK_CAP / PSH_SELECT_THREADS;
     const int e_lo = (int)(((int64_t)n * g) / G), e_hi = (int)(((int64_t)n * (g + 1)) / G);
-    const int nown = e_hi - e_lo;                                             // <= PSH_RANK_CAP / G + 1
-    const int ns = (n + PSH_SELECT_THREADS - 1) / PSH_SELECT_THREADS;
-    // the owning slice of every candidate: the 8 searches of a thread step together (one after the other they were
-    // 64 dependent LDS round trips: 4.5 us); then ALL loads in flight together
-    int lo[NE], ec[NE];
-#pragma unroll
-    for (int i = 0; i < NE; ++i) { const int e = tid + PSH_SELECT_THREADS * i; ec[i] = e < n ? e : n - 1; lo[i] = 0; }
+    const int nown = e_hi - e_lo;                                             // <= n / G + 1
     int s0 = 1;
     while (2 * s0 < a.nblk) s0 <<= 1;
-    for (int step = s0; step >= 1; step >>= 1) {
-#pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const int m = lo[i] + step;
-            if (i < ns && m < a.nblk && sm.offs[m] <= ec[i]) lo[i] = m;
-        }
-    }
-    mark();
-    float ld[NE];
-    int2 lrt[NE];
-#pragma unroll
-    for (int i = 0; i < NE; ++i)
-        if (i < ns) { const int64_t o = (int64_t)lo[i] * a.slice + (ec[i] - sm.offs[lo[i]]); ld[i] = cd[o]; lrt[i] = crt[o]; }
-    uint64_t key[NE];
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        key[i] = ~0ull;
-        const int e = tid + PSH_SELECT_THREADS * i;
-        if (i < ns && e < n) {
-            key[i] = ((uint64_t)__float_as_uint(ld[i]) << 32) | (uint64_t)(((unsigned)lrt[i].x << a.rank_tbits) | (unsigned)lrt[i].y);
-            if (e >= e_lo && e < e_hi) { sm.own_key[e - e_lo] = key[i]; sm.own_rt[e - e_lo] = lrt[i]; }
-        }
+    if (tid < nown) {
+        const int e = e_lo + tid;
+        int l0 = 0;
+        for (int step = s0; step >= 1; step >>= 1) { const int m = l0 + step; if (m < a.nblk && sm.offs[m] <= e) l0 = m; }
+        const int64_t o = (int64_t)l0 * a.slice + (e - sm.offs[l0]);
+        const int2 rt = crt[o];
+        sm.own_key[tid] = ((uint64_t)__float_as_uint(cd[o]) << 32) | (uint64_t)(((unsigned)rt.x << a.rank_tbits) | (unsigned)rt.y);
+        sm.own_rt[tid] = rt;
     }
     __syncthreads();
     mark();
-    // counting on the vector ALUs, 8 own candidates a turn: a 64-bit compare and an add per pair (a ballot + popcount per
-    // pair went through the scalar unit of four waves); two counters share a register for the wave reduction (DPP)
-    for (int j0 = 0; j0 < nown; j0 += 8) {
-        uint64_t ok[8];
-        int c[8];
+#pragma unroll 1
+    for (int p0 = 0; p0 < n; p0 += PSH_RANK_CAP) {
+        const int np = (n - p0) < PSH_RANK_CAP ? (n - p0) : PSH_RANK_CAP;
+        const int ns = (np + PSH_SELECT_THREADS - 1) / PSH_SELECT_THREADS;
+        // the owning slice of every candidate: the 8 searches of a thread step together (one after the other they were
+        // 64 dependent LDS round trips: 4.5 us); then ALL loads in flight together
+        int lo[NE], ec[NE];
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) { ok[jj] = (j0 + jj < nown) ? sm.own_key[j0 + jj] : 0ull; c[jj] = 0; }
+        for (int i = 0; i < NE; ++i) { const int e = p0 + tid + PSH_SELECT_THREADS * i; ec[i] = e < n ? e : n - 1; lo[i] = 0; }
+        for (int step = s0; step >= 1; step >>= 1) {
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            if (i < ns) {
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) c[jj] += key[i] < ok[jj] ? 1 : 0;
+            for (int i = 0; i < NE; ++i) {
+                const int m = lo[i] + step;
+                if (i < ns && m < a.nblk && sm.offs[m] <= ec[i]) lo[i] = m;
             }
         }
+        float ld[NE];
+        int2 lrt[NE];
 #pragma unroll
-        for (int jj = 0; jj < 8; jj += 2) {
-            int v = c[jj] | (c[jj + 1] << 16);                // <= 8 per lane and counter: 512 per wave
-            v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);     // row_shr 1, 2, 4, 8; row_bcast 15, 31
-            v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
-            v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
-            v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
-            v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);
-            v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);
-            v = __builtin_amdgcn_readlane(v, 63);
-            if (lane == 0) {
-                if (j0 + jj < nown && (v & 0xffff)) atomicAdd(&sm.rankc[j0 + jj], v & 0xffff);
-                if (j0 + jj + 1 < nown && (v >> 16)) atomicAdd(&sm.rankc[j0 + jj + 1], v >> 16);
+        for (int i = 0; i < NE; ++i)
+            if (i < ns) { const int64_t o = (int64_t)lo[i] * a.slice + (ec[i] - sm.offs[lo[i]]); ld[i] = cd[o]; lrt[i] = crt[o]; }
+        uint64_t key[NE];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            key[i] = ~0ull;
+            const int e = p0 + tid + PSH_SELECT_THREADS * i;
+            if (i < ns && e < n)
+                key[i] = ((uint64_t)__float_as_uint(ld[i]) << 32) | (uint64_t)(((unsigned)lrt[i].x << a.rank_tbits) | (unsigned)lrt[i].y);
+        }
+        // counting on the vector ALUs, 8 own candidates a turn: a 64-bit compare and an add per pair (a ballot + popcount per
+        // pair went through the scalar unit of four waves); two counters share a register for the wave reduction (DPP)
+        for (int j0 = 0; j0 < nown; j0 += 8) {
+            uint64_t ok8[8];
+            int c[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) { ok8[jj] = (j0 + jj < nown) ? sm.own_key[j0 + jj] : 0ull; c[jj] = 0; }
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                if (i < ns) {
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) c[jj] += key[i] < ok8[jj] ? 1 : 0;
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 8; jj += 2) {
+                int v = c[jj] | (c[jj + 1] << 16);                // <= 8 per lane and counter: 512 per wave
+                v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);     // row_shr 1, 2, 4, 8; row_bcast 15, 31
+                v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);
+                v = __builtin_amdgcn_readlane(v, 63);
+                if (lane == 0) {
+                    if (j0 + jj < nown && (v & 0xffff)) atomicAdd(&sm.rankc[j0 + jj], v & 0xffff);
+                    if (j0 + jj + 1 < nown && (v >> 16)) atomicAdd(&sm.rankc[j0 + jj + 1], v >> 16);
+                }
             }
         }
     }
@@ -1082,6 +1093,7 @@ __device__ __forceinline__ int lower_bound_dw(const unsigned* run, int len, unsi
 __global__ __launch_bounds__(PSH_CHUNK) void chunk_sort_kernel(SelectArgs a) {
     __shared__ uint64_t runs[PSH_CHUNK];
     const int b = (int)blockIdx.y, tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (a.handled && a.handled[b]) return;                // rank_select_kernel has written this query's results, in order
     uint64_t* G = a.sort_scratch + (int64_t)b * a.cand_stride + (size_t)blockIdx.x * PSH_CHUNK;
     const int2* sel_rt = a.sel_rt + (int64_t)b * a.kpad;
     const uint64_t mine = G[tid];
@@ -1117,6 +1129,7 @@ __global__ __launch_bounds__(PSH_CHUNK) void chunk_sort_kernel(SelectArgs a) {
 __global__ __launch_bounds__(PSH_CHUNK) void chunk_merge_kernel(SelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned dw[];      // the distance words of the query's kpad items, chunk by chunk
     const int b = (int)blockIdx.y, tid = (int)threadIdx.x, me = (int)blockIdx.x;
+    if (a.handled && a.handled[b]) return;
     const uint64_t* G = a.sort_scratch + (int64_t)b * a.cand_stride;
     const int2* sel_rt = a.sel_rt + (int64_t)b * a.kpad;
     {
@@ -1303,7 +1316,9 @@ hipError_t launch_select(const SelectArgs& a0, int B, hipStream_t s) {
     // up to 8 queries with few candidates expected: the ranking on all CUs first (rank_select_kernel), 256 blocks for one or two
     // queries, 256 / B for more (a block's own share stays within PSH_RANK_OWN down to 16 blocks)
     if (a.handled) {
-        if (a.bcount && B <= PSH_RANK_MAX_B && a.k <= PSH_RANK_CAP / 2 && !a.rank_sort && !a.skip_negative_rows && a.rank_tbits >= 0) {
+        // (k <= PSH_RANK_CAP / 2: beyond that the candidates outnumber one pass -- measured with up to five passes: k = 8192 146 us
+        //  per call against 153, k = 16384 235 against 186, six queries with k = 8192 0.42 ms against 0.30: the counting is O(n^2 / blocks))
+        if (a.bcount && B <= PSH_RANK_MAX_B && a.k <= PSH_RANK_CAP / 2 && !a.skip_negative_rows && a.rank_tbits >= 0) {
             int G = PSH_RANK_GRID;
             if (B > 2) { G = PSH_RANK_GRID / B; if (G < 16) G = 16; }
             hipLaunchKernelGGL(rank_select_kernel, dim3(G, B), dim3(PSH_SELECT_THREADS), 0, s, a);
