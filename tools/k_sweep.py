@@ -21,7 +21,8 @@ for k in (1024, 4096, 8192, 16384):
 obj = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), ds, sa.PredictionContext(horizon=20))
 x = syn.single_query(20, 1)
 for k in (1024, 8192):
-    for _ in range(5): obj.shadow(x, k=k, cuda=True)
-    t0 = time.perf_counter()
-    for _ in range(30): obj.shadow(x, k=k, cuda=True)
-    print("shadow() k", k, "us per call", round((time.perf_counter() - t0) / 30 * 1e6, 1))
+    for _ in range(10): obj.shadow(x, k=k, cuda=True)
+    ts = []
+    for _ in range(50):
+        t0 = time.perf_counter(); obj.shadow(x, k=k, cuda=True); ts.append(time.perf_counter() - t0)
+    print("shadow() k", k, "us per call", round(float(np.median(ts)) * 1e6, 1), "(median of 50)")
