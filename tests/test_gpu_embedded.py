@@ -588,6 +588,13 @@ def test_path_shadowing_with_a_cross_channel_context_runs_native(hip_device, nam
     assert obj.context.select_out_context(paths).shape[-2] == oc
     d2, _, idx2 = obj.shadow(g["queries"], k=g["k"], cuda=True)          # second call: resident ensemble + channel-0 copy reused
     assert np.array_equal(bits(d), bits(d2)) and np.array_equal(idx, idx2)
+    # ONE query at a time (Identity: the blocking call's prepared slot -- kernels writing the pinned result buffer): the rows
+    # of the batch's result, every channel gathered
+    # (Foveal: the module's own conv1d embeds one query in another summation order than a batch -- ulps; not compared)
+    for b in range(d.shape[0] if name.startswith("crosschannel_identity") else 0):
+        d1, p1, i1 = obj.shadow(g["queries"][b], k=g["k"], cuda=True)
+        assert obj.last_path == "hip"
+        assert np.array_equal(bits(d1[0]), bits(d[b])) and np.array_equal(i1[0], idx[b]) and np.array_equal(p1[0], paths[b])
 
 
 class _KnownProba:
