@@ -67,11 +67,13 @@ def parse():
     ap.add_argument("--filter", choices=("mx", "valu"), default="mx",
                     help="rejection test of the scan: matrix cores (default) or vector ALUs (PSH_FLAG_FILTER_VALU; comparison runs)")
     ap.add_argument("--no-fuse", action="store_true", help="the separate bootstrap / threshold / scan / select launches")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=0,
                     help="single query: consecutive steps (independent queries) are issued round-robin on this many HIP "
                          "streams as the three overlap-friendly launches of PSH_FLAG_OVERLAP (sample + level, barrier-free "
                          "scan, ranking), so one step's latency-bound launches run beside another step's scan; 1 = one "
-                         "stream, the fused single launch")
+                         "stream, the fused single launch; 0 (default) = 3, or 2 for the row-sharded step, whose exchange "
+                         "and merge run on a stream of their own (measured on one rank with the exchange forced: 88.7 us "
+                         "per step on 2 scan streams, 105.5 on 3, 114.5 on 1)")
     ap.add_argument("--sweep", type=str, default=None,
                     help="comma-separated GPU counts: run each in turn, print one JSON line per N (stdout) and the "
                          "weak-scaling efficiency against the first (stderr)")
@@ -218,7 +220,8 @@ def main():
     flags = (_native.FLAG_FILTER_VALU if args.filter == "valu" else 0) | (_native.FLAG_NO_FUSE if args.no_fuse else 0)
     # independent single queries on several streams: the overlap-friendly launches (the library falls back to the fused /
     # separate launches by itself where they do not apply)
-    n_streams = args.streams if (B == 1 and not args.no_fuse and args.filter != "valu" and args.streams > 1) else 1
+    want_streams = args.streams if args.streams > 0 else (2 if use_pg else 3)
+    n_streams = want_streams if (B == 1 and not args.no_fuse and args.filter != "valu" and want_streams > 1) else 1
     if n_streams > 1:
         flags |= _native.FLAG_OVERLAP
     # per-rank block of the ensemble: block g is dataset(R, T, seed=g); rank 0's block at

@@ -89,8 +89,9 @@ class ShardedPathShadowing:
         left them.  Everything else (local scan into the send buffer, merge of the G lists) is the production code: how a
         full configs[3] (8 x 32768 rows) is exercised on one GPU.
 
-        `streams` > 1 (HIP device): consecutive scan_begin() calls -- independent query batches -- issue their local scan
-        round-robin on that many private streams, single queries as the overlap-friendly launches (PSH_FLAG_OVERLAP): the
+        `streams` > 1 (HIP device; 2 is the measured optimum -- the exchange and the merge run on a stream of their own beside
+        them: 88.7 us per step on one rank with the exchange forced, 105.5 with 3, 114.5 with 1): consecutive scan_begin() calls
+        -- independent query batches -- issue their local scan round-robin on that many private streams, single queries as the overlap-friendly launches (PSH_FLAG_OVERLAP): the
         sample and the ranking of one step, and the exchange of another, run beside a third step's scan, and nothing in a
         scan waits for co-residency (no polling next to the collective's workgroups).  `reserve_cus=True` makes the private
         streams CU-masked ones (psh_stream_create_reserving: PSH_STREAM_RESERVED_CUS compute units stay free for the
