@@ -74,6 +74,11 @@ def parse():
                          "stream, the fused single launch; 0 (default) = 3, or 2 for the row-sharded step, whose exchange "
                          "and merge run on a stream of their own (measured on one rank with the exchange forced: 88.7 us "
                          "per step on 2 scan streams, 105.5 on 3, 114.5 on 1)")
+    ap.add_argument("--cpu-oracle", action="store_true",
+                    help="TEST HOOK, measures nothing: the row-sharded control flow of this file (process group, step / drain / "
+                         "timed_region, the parity checks, the JSON line) on CPU tensors over gloo, with the CPU oracle standing in "
+                         "for the HIP scan -- tests/test_bench_flow_cpu.py runs it with two ranks so that a Python-level bug "
+                         "cannot burn a multi-GPU lease")
     ap.add_argument("--sweep", type=str, default=None,
                     help="comma-separated GPU counts: run each in turn, print one JSON line per N (stdout) and the "
                          "weak-scaling efficiency against the first (stderr)")
@@ -120,12 +125,53 @@ def sweep(counts: list[int], argv: list[str]) -> int:
             return 1
         print(line, flush=True)
         lines.append(json.loads(line))
+    for row in sweep_report(lines):
+        sys.stderr.write(row + "\n")
+    return 0
+
+
+def sweep_report(lines: list[dict]) -> list[str]:
+    """One text row per JSON line of a sweep: weak-scaling efficiency = value_N / (N / N0 * value_N0) against the FIRST
+    line.  A line whose run did not verify itself (parity false, or a multi-rank line whose RCCL world is not its
+    n_gpus) is marked: its number is not evidence."""
     base = lines[0]
+    rows = []
     for j in lines:
         eff = j["value"] / (base["value"] * j["n_gpus"] / base["n_gpus"])
-        sys.stderr.write(f"[sweep] n_gpus={j['n_gpus']} rccl_world_size={j.get('rccl_world_size')} ms_per_step={j['ms_per_step']:.4f} "
-                         f"value={j['value']:.4g} {j['unit']} weak_scaling_efficiency={eff:.3f}\n")
-    return 0
+        marks = []
+        if j["n_gpus"] > 1 and j.get("rccl_world_size") != j["n_gpus"]:
+            marks.append("RCCL-WORLD-MISMATCH")
+        if j.get("parity_vs_golden") is False or (j.get("parity_rotating_queries") or {}).get("ok") is False:
+            marks.append("PARITY-FAILED")
+        if j.get("parity_vs_golden") is None:
+            marks.append("parity-unchecked")
+        rows.append(f"[sweep] n_gpus={j['n_gpus']} rccl_world_size={j.get('rccl_world_size')} ms_per_step={j['ms_per_step']:.4f} "
+                    f"value={j['value']:.4g} {j['unit']} weak_scaling_efficiency={eff:.3f}" + ("".join(" " + m for m in marks)))
+    return rows
+
+
+def host_merge(d_all: np.ndarray, i_all: np.ndarray, k: int):
+    """k best by (d, r, t) out of (B, n) candidates on the host (numpy lexsort); entries with r < 0 are padding.  The
+    checker's merge: the distributed oracle of the parity checks and the --cpu-oracle hook use it, never a timed step."""
+    B = d_all.shape[0]
+    out_d = np.empty((B, k), np.float32)
+    out_i = np.empty((B, k, 2), np.int32)
+    for b in range(B):
+        real = i_all[b, :, 0] >= 0
+        dd, ii = d_all[b][real], i_all[b][real]
+        o = np.lexsort((ii[:, 1], ii[:, 0], dd))[:k]
+        out_d[b], out_i[b] = dd[o], ii[o]
+    return out_d, out_i
+
+
+def same_result(d: np.ndarray, idx: np.ndarray, ed: np.ndarray, eidx: np.ndarray, tie_free_order: bool) -> bool:
+    """Bit-equal distances and identical (r, t).  `tie_free_order` False: the expected rows come from the reference, whose
+    order among exactly tied distances is arbitrary (unstable partial sort): sorted distances and the SET of pairs."""
+    if tie_free_order:
+        return bool(np.array_equal(d.view(np.uint32), ed.view(np.uint32)) and np.array_equal(idx, eidx))
+    if not np.array_equal(d.view(np.uint32), np.sort(ed, axis=1).view(np.uint32)):
+        return False
+    return all({tuple(v) for v in idx[b]} == {tuple(v) for v in eidx[b]} for b in range(idx.shape[0]))
 
 
 def cpu_baseline(ds: np.ndarray, q: np.ndarray, k: int, h: int) -> dict:
@@ -197,23 +243,35 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    if torch.cuda.device_count() <= local_rank:
-        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    on_gpu = not args.cpu_oracle
+    if on_gpu:
+        assert torch.cuda.is_available(), "bench.py needs a HIP device"
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device("cpu")
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
 
     import torch.distributed as dist
-    use_pg = world > 1 or args.force_sharded
+    use_pg = world > 1 or args.force_sharded or not on_gpu
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        if on_gpu:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import shadowing_amd as sa
     from shadowing_amd import _native, synthetic as syn
     from shadowing_amd.distributed import ShardedPathShadowing
-    _native.load()   # fail loudly if the HIP extension is missing
+    if on_gpu:
+        _native.load()   # fail loudly if the HIP extension is missing
 
     R, T, W, h, k, B = args.rows_per_gpu, args.T, args.W, args.horizon, args.k, args.queries
     Tp = T - W - h + 1
@@ -227,52 +285,86 @@ def main():
     # per-rank block of the ensemble: block g is dataset(R, T, seed=g); rank 0's block at
     # the default sizes is exactly the dataset of tests/golden/cfg2_R32768.npz
     ds_host = syn.dataset(R, T, seed=rank)
-    q_host = syn.single_query(W, syn.QUERY_SEED)[None, :] if B == 1 else syn.rolling_queries(B, W, syn.QUERY_SEED)
+    # NQ DISTINCT query batches take turns through the steps (step c: batch c % NQ on stream c % n_streams): a result left
+    # in a stream's buffers at the end of the timed region is checked against what ITS query must give, so workspace or
+    # buffer aliasing between co-resident steps cannot go unnoticed at speed.  Batch 0 is the golden fixtures' query.
+    NQ = 4
+    q_seeds = [syn.QUERY_SEED] + [1000 + j for j in range(1, NQ)]
+    q_hosts = [np.ascontiguousarray(syn.single_query(W, sd)[None, :] if B == 1 else syn.rolling_queries(B, W, sd)) for sd in q_seeds]
+    q_host = q_hosts[0]
+    if not on_gpu:
+        n_streams = 1
     ds = torch.from_numpy(ds_host).to(dev)                    # resident in HBM before any timing
-    q = torch.from_numpy(np.ascontiguousarray(q_host)).to(dev)
-    ws = _native.Workspace(dev)
+    qs = [torch.from_numpy(qh).to(dev) for qh in q_hosts]
+    q = qs[0]
+    ws = _native.Workspace(dev) if on_gpu else None
     # one workspace per stream (its header carries per-call state), results of a stream's steps in its own buffers
     streams = [torch.cuda.Stream(dev) for _ in range(n_streams)] if n_streams > 1 else [None]
     wss = [ws] + [_native.Workspace(dev) for _ in range(n_streams - 1)]
 
+    def oracle_local(ds2d, qq, kk, hh, r_offset):
+        # (--cpu-oracle only) the checker stands in for the HIP scan so that the control flow runs without a GPU
+        import oracle
+        d_, i_ = oracle.scan_topk(ds2d.numpy(), qq.numpy(), kk, h=hh, r_offset=r_offset, nthreads=2)
+        return torch.from_numpy(d_), torch.from_numpy(i_)
+
+    def torch_host_merge(d_all, i_all, kk):
+        d_, i_ = host_merge(d_all.numpy(), i_all.numpy(), kk)
+        return torch.from_numpy(d_), torch.from_numpy(i_)
+
     sharded = None
-    if use_pg:
+    if use_pg and on_gpu:
         sharded = ShardedPathShadowing(sa.Identity(W), sa.RelativeMSE(), ds, rank * R, sa.PredictionContext(h), device=dev,
                                        always_exchange=args.force_sharded, streams=n_streams)
+    elif use_pg:
+        sharded = ShardedPathShadowing(sa.Identity(W), sa.RelativeMSE(), ds, rank * R, sa.PredictionContext(h),
+                                       local_topk=oracle_local, merge=torch_host_merge, always_exchange=True)
 
     # HIP events around the dominant kernel on every EV_EVERY-th timed step: an event record is a barrier packet of its own
     # on the stream (~5 us for the pair, measured: 112 vs 101 us per step with a pair on every step), so bracketing every
     # launch would tax the very step time the metric is
     EV_EVERY = 4
-    ev_pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range((args.steps + EV_EVERY - 1) // EV_EVERY)]
+    ev_pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                for _ in range((args.steps + EV_EVERY - 1) // EV_EVERY)] if on_gpu else []
     for a, b in ev_pairs:   # materialise the hipEvent handles
         a.record(); b.record()
-    torch.cuda.synchronize()
+    sync()
 
     statuses = []
+    last_query = {}    # stream -> the query batch of the last step issued on it
     step_flags = [flags]
     cfg = {"n_streams": n_streams, "count": 0}
     outs = [(torch.empty((B, k), dtype=torch.float32, device=dev), torch.empty((B, k, 2), dtype=torch.int32, device=dev))
             for _ in range(n_streams)]
     status_ring = list(torch.zeros((args.steps + args.warmup + 8, B), dtype=torch.int32, device=dev).unbind(0))
-    torch.cuda.synchronize()
+    sync()
 
-    pending = []       # sharded path: the step whose all-gather is still in flight
+    pending = []       # sharded path: (the step whose all-gather is still in flight, its query batch)
+    from collections import deque
+    finished = deque(maxlen=2)     # sharded path: the last merged results (they live in the ring: valid until 2 x streams further steps)
 
     def step(i=None):
+        c = cfg["count"]
+        cfg["count"] = c + 1
+        qi = c % NQ
+        q = qs[qi]
         if sharded is not None:
             # steps are independent query batches: step i+1 begins (local scan, start of its all-gather) before step i
             # is finished (wait for its all-gather on the compute stream, merge) -- the ~20 us collective latency runs
             # under the next scan.  Every step's merged result is complete when the timed region ends (drain()).
-            nxt = sharded.scan_begin(q, k, check=False, queries_ready=True)   # no host sync inside the timed loop; q was uploaded long ago
-            statuses.append(sharded.last_status)
-            out = pending.pop().finish() if pending else None
-            pending.append(nxt)
+            nxt = sharded.scan_begin(q, k, check=False, queries_ready=True)   # no host sync inside the timed loop; the queries were uploaded long ago
+            if sharded.last_status is not None and not sharded._fast:
+                statuses.append(sharded.last_status)       # (the prepared ring keeps every step's status word itself: status_max())
+            out = None
+            if pending:
+                pend, pq = pending.pop()
+                out = pend.finish()
+                finished.append((pq, out))
+            pending.append((nxt, qi))
             return out
         ev = ev_pairs[i // EV_EVERY] if (i is not None and i % EV_EVERY == 0) else None
-        c = cfg["count"]
-        cfg["count"] = c + 1
         si = c % cfg["n_streams"]
+        last_query[si] = qi
         # results go to this stream's own buffers (a later step on the same stream overwrites them, in stream order); the
         # status words of ALL steps are kept: every one of them is looked at after the timed region
         out = (outs[si][0], outs[si][1], status_ring[c % len(status_ring)])
@@ -286,26 +378,75 @@ def main():
 
     # ---- first result: parity against the reference's golden vector (N = 1, default sizes)
     def drain():
-        return pending.pop().finish() if pending else None
+        if not pending:
+            return None
+        pend, pq = pending.pop()
+        out = pend.finish()
+        finished.append((pq, out))
+        return out
+
+    # ---- the checker's answer for a query batch over the WHOLE (sharded) ensemble: every rank runs the CPU oracle on its
+    #      own block (its share of the host cores), the lists travel through the process group, rank 0 merges on the host
+    expected_cache = {}
+
+    def expected_by_oracle(qi: int, sel=None):
+        key = (qi, None if sel is None else tuple(sel))
+        if key in expected_cache:
+            return expected_cache[key]
+        import oracle
+        oracle.build()
+        qq = q_hosts[qi] if sel is None else q_hosts[qi][list(sel)]
+        threads = max(1, (os.cpu_count() or 1) // world)
+        od, oi = oracle.scan_topk(ds_host, qq, min(k, R * Tp), h=h, r_offset=rank * R, nthreads=threads)
+        if world > 1:
+            box = [None] * world
+            dist.all_gather_object(box, (od, oi))
+            od, oi = host_merge(np.concatenate([b[0] for b in box], axis=1), np.concatenate([b[1] for b in box], axis=1), k)
+        expected_cache[key] = (od, oi)
+        return od, oi
 
     parity = None
     first = step()
     d0, i0 = first if sharded is None else drain()
-    torch.cuda.synchronize()
+    sync()
     d0, i0 = d0.clone(), i0.clone()
     if statuses and int(statuses[-1].max().item()) != 0:
         raise SystemExit("candidate buffer overflow on the benchmark workload (unexpected)")
-    if (world == 1 and not args.no_parity and (R, T, W, h, k, B) == (32768, 4096, 20, 20, 1024, 1)
-            and (REPO / "tests/golden/cfg2_R32768.npz").exists()):
+    if sharded is not None and sharded._fast and sharded.status_max() != 0:
+        raise SystemExit("the first sharded step gave up (status %d; unexpected)" % sharded.status_max())
+    default_sizes = (R, T, W, h, k, B) == (32768, 4096, 20, 20, 1024, 1)
+    golden_name = None
+    if not args.no_parity and default_sizes and world == 1 and (REPO / "tests/golden/cfg2_R32768.npz").exists():
         g = np.load(REPO / "tests/golden/cfg2_R32768.npz")
         if syn.sha256(ds_host) == str(g["dataset_sha256"]):
-            od = np.sort(g["d"], axis=1)
-            parity = bool(np.array_equal(d0.cpu().numpy().view(np.uint32), od.view(np.uint32))
-                          and {tuple(v) for v in i0.cpu().numpy()[0]} == {tuple(v) for v in g["idx"][0]})
+            golden_name = "tests/golden/cfg2_R32768.npz"
+            parity = same_result(d0.cpu().numpy(), i0.cpu().numpy(), g["d"], g["idx"], tie_free_order=False)
             if not parity:
                 raise SystemExit("PARITY FAILURE against tests/golden/cfg2_R32768.npz")
+    if not args.no_parity and default_sizes and world in (2, 4, 8) and (REPO / "tests/golden/cfg4_R262144.npz").exists():
+        # N > 1: the reference's own output on the concatenated rank blocks (tests/golden/make_golden.py --sharded);
+        # every rank vouches for its block's bytes, rank 0 compares the first merged result
+        g = np.load(REPO / "tests/golden/cfg4_R262144.npz")
+        mine = torch.tensor([1.0 if syn.sha256(ds_host) == str(g["block_sha256"][rank]) else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(mine, op=dist.ReduceOp.MIN)
+        if float(mine.item()) == 1.0:
+            golden_name = f"tests/golden/cfg4_R262144.npz (d_N{world}, idx_N{world})"
+            parity = same_result(d0.cpu().numpy(), i0.cpu().numpy(), g[f"d_N{world}"], g[f"idx_N{world}"], tie_free_order=False)
+            flag = torch.tensor([1.0 if parity else 0.0], dtype=torch.float64, device=dev)
+            dist.broadcast(flag, src=0)
+            if float(flag.item()) != 1.0:
+                raise SystemExit(f"PARITY FAILURE against {golden_name}")
+    parity_first_oracle = None
+    if not args.no_parity and parity is None and B == 1 and (world > 1 or not on_gpu):
+        # other sizes / rank counts: the first merged result against the distributed oracle
+        od, oi = expected_by_oracle(0)
+        parity_first_oracle = same_result(d0.cpu().numpy(), i0.cpu().numpy(), od, oi, tie_free_order=True)
+        flag = torch.tensor([1.0 if parity_first_oracle else 0.0], dtype=torch.float64, device=dev)
+        dist.broadcast(flag, src=0)
+        if float(flag.item()) != 1.0:
+            raise SystemExit("PARITY FAILURE of the first merged result against the distributed oracle")
     parity_oracle = None
-    if world == 1 and not args.no_parity and B > 1:
+    if world == 1 and on_gpu and not args.no_parity and B > 1:
         # a batch: the first result of the run against the CPU oracle on a subset of the queries spread over the
         # query chunks of the batched scan (first, around the chunk boundary, last)
         import oracle
@@ -323,22 +464,27 @@ def main():
             step()
         drain()
         statuses.clear()
-        torch.cuda.synchronize()
+        sync()
+        if sharded is not None:
+            sharded.reset_status()
         if use_pg:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         cfg["count"] = 0
+        finished.clear()
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(i)
         drain()                                            # the last step's exchange and merge belong to the timed region
         host = time.perf_counter() - t0                    # host time to enqueue all steps (<< elapsed unless host-bound)
-        torch.cuda.synchronize()
+        sync()
         if use_pg:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         el = time.perf_counter() - t0
         bad = int(torch.stack(statuses).max().item()) if statuses else 0
+        if sharded is not None:
+            bad = max(bad, sharded.status_max())           # EVERY step of the prepared ring, not the slots' last launches
         if use_pg:
             t = torch.tensor([el, float(bad)], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -348,7 +494,7 @@ def main():
     # The CU-masked scan streams of the sharded run are BLOCKING streams (hipExtStreamCreateWithCUMask takes no flags):
     # anything enqueued on the legacy default stream would serialise with all of them.  The sharded steps are therefore
     # issued from a stream of their own.
-    main_stream = torch.cuda.Stream(dev) if (sharded is not None and n_streams > 1) else None
+    main_stream = torch.cuda.Stream(dev) if (sharded is not None and n_streams > 1 and on_gpu) else None
     if main_stream is not None:
         main_stream.wait_stream(torch.cuda.current_stream(dev))
         torch.cuda.set_stream(main_stream)
@@ -365,8 +511,34 @@ def main():
         elapsed, host_enqueue, bad = timed_region()
     if bad != 0:
         raise SystemExit("candidate buffer overflow during the timed steps (unexpected)")
+
+    # ---- what the timed steps LEFT BEHIND, against the checker: the last result of every stream (unsharded) / the last two
+    #      merged results (sharded) must be what their own query batch gives
+    rotating = None
+    if not args.no_parity:
+        sync()
+        left = ([(last_query[si], outs[si]) for si in sorted(last_query)] if sharded is None else list(finished))
+        sel = None if B == 1 else sorted({0, min(111, B - 1), min(112, B - 1), B // 2, B - 1})
+        ok, checked = True, []
+        for qi, (dd, ii) in left:
+            od, oi = expected_by_oracle(qi, sel)
+            got_d, got_i = dd.cpu().numpy(), ii.cpu().numpy()
+            if sel is not None:
+                got_d, got_i = got_d[sel], got_i[sel]
+            ok = ok and same_result(got_d, got_i, od, oi, tie_free_order=True)
+            checked.append(qi)
+        if use_pg:
+            flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = float(flag.item()) == 1.0
+        rotating = {"ok": bool(ok), "query_batches_checked": checked, "distinct_query_batches": NQ,
+                    "against": "oracle/psh_oracle.c over the whole ensemble" + (" (every rank its block, host merge)" if world > 1 else ""),
+                    "what": "the result each stream's LAST timed step left in its buffers" if sharded is None
+                            else "the last two merged results of the timed region"}
+        if not ok:
+            raise SystemExit(f"PARITY FAILURE after the timed region: results of query batches {checked} differ from the oracle")
     # the bracketed launches of THE timed region (the comparison region below records over the same events)
-    scan_ms = [a.elapsed_time(b) for a, b in ev_pairs] if sharded is None else []
+    scan_ms = [a.elapsed_time(b) for a, b in ev_pairs] if (sharded is None and on_gpu) else []
     end_gaps_ms = [ev_pairs[j][1].elapsed_time(ev_pairs[j + 1][1]) / EV_EVERY for j in range(len(ev_pairs) - 1)] if sharded is None else []
     overlap_mode = bool(flags & _native.FLAG_OVERLAP)
     single_stream = None
@@ -389,13 +561,15 @@ def main():
     # which path serves the call (the launch plan's answer) -- and, for the sharded run, ONE bracketed launch of the
     # local scan outside the timed loop (per-GPU kernel time; the timed loop itself carries no events there)
     info = {}
-    one = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-    for e in one:
-        e.record()
-    torch.cuda.synchronize()
-    _native.scan_topk(ds[:, 0, :], q, k, h=h, workspace=ws, flags=flags, info=info, scan_events=one)
-    torch.cuda.synchronize()
-    one_ms = one[0].elapsed_time(one[1])
+    one_ms = float("nan")
+    if on_gpu:
+        one = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        for e in one:
+            e.record()
+        torch.cuda.synchronize()
+        _native.scan_topk(ds[:, 0, :], q, k, h=h, workspace=ws, flags=flags, info=info, scan_events=one)
+        torch.cuda.synchronize()
+        one_ms = one[0].elapsed_time(one[1])
     fused = info.get("path") == 2
     overlap_mode = info.get("path") == 3
     kernel_name = ("psh::stream_scan_kernel<%s,true> (the scan of the three overlap-friendly launches: f16 matrix-core rejection "
@@ -477,7 +651,7 @@ def main():
             roofline["note"] = ("overlap mode: `achieved` = algorithmic bytes / avg_launch_interval_ms (end-to-end interval of consecutive "
                                 "scan launches, HIP events on the launches' own streams); avg_launch_ms is a launch's begin-to-end "
                                 "duration WHILE it shares the chip with the neighbouring scan (profiles/: the kernel trace gives both)")
-    else:
+    elif on_gpu:
         achieved = alg_bytes / (one_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
@@ -486,7 +660,7 @@ def main():
 
     stages = None
     cpu = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and on_gpu:
         # per-stage HIP-event timings of the SEPARATE launches (the fused launch has no stages to bracket); one untimed call
         # first: kernels the timed steps never ran are loaded on their first launch
         _native.scan_topk(ds[:, 0, :], q, k, h=h, workspace=ws, flags=flags | _native.FLAG_NO_FUSE)
@@ -501,7 +675,7 @@ def main():
         out = {
             "metric": "windows scanned/sec (k-nearest-path scan, Identity + RelativeMSE, W=20, k=1024)",
             "value": round(value, 1), "unit": "windows/s", "n_gpus": world,
-            "rccl_world_size": dist.get_world_size() if use_pg else None, "steps": args.steps, "warmup": args.warmup,
+            "rccl_world_size": dist.get_world_size() if (use_pg and on_gpu) else None, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: single query, R=32768 paths/GPU x T=4096, W=20, horizon=20, k=1024"
@@ -522,7 +696,12 @@ def main():
             "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 5),
             "stages_ms_separate_launches": stages,
             "parity_vs_reference_golden": parity,
+            "parity_vs_golden": parity if parity is not None else parity_first_oracle,
+            "parity_golden": golden_name if parity is not None else ("distributed oracle (no committed fixture for these sizes)"
+                                                                    if parity_first_oracle is not None else None),
             "parity_vs_oracle_query_subset": parity_oracle,
+            "parity_rotating_queries": rotating,
+            "cpu_oracle_test_hook": (not on_gpu) or None,
             "fused_launch_gave_up_rerun_as_separate_launches": fused_retry,
         }
         os.write(json_fd, (json.dumps(out) + "\n").encode())

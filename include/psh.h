@@ -181,6 +181,18 @@ int psh_query_norm(int device, void* stream, const float* queries, int B, int W,
  * One-window rows (T == W + h, e.g. N pre-embedded points of PathDistance.forward_topk with
  * W = T = d): the reference's numerator is then the contiguous 8-lane reduce, and the scan
  * runs a row per lane (rows_kernel) instead of a segment per wave.
+ *
+ * STATUS PROTOCOL -- every caller looks at out_status before it uses the results (PSH_FLAG_NO_FUSE or not, whatever B):
+ *   PSH_STATUS_OK        out_d / out_idx of that query are the exact answer.
+ *   PSH_STATUS_OVERFLOW  that query's candidate slices overflowed (massive exact ties) or fewer than k windows lay below the
+ *                        sampled estimate: its results are INVALID -> psh_scan_topk_exhaustive for that query.
+ *   PSH_STATUS_RETRY     the launches that serve 1, 2 or 3 queries (W <= 33) -- the fused single launch for one query,
+ *                        the three overlap-friendly launches for one query under PSH_FLAG_OVERLAP and for EVERY call with
+ *                        B = 2 or 3, flag or no flag -- admit below a statistical estimate and give up when it falls short
+ *                        of k, when a block's candidate list overflows, or on a workspace psh_workspace_init never armed:
+ *                        results of EVERY query of the call are INVALID (stale) -> the same call with PSH_FLAG_NO_FUSE
+ *                        (the separate launches: a provable bound, per-query OVERFLOW as above).
+ * shadowing_amd/_native.py: scan_topk_checked is this protocol in 20 lines.
  */
 int psh_scan_topk(int device, void* stream,
                   const float* dataset, int64_t R, int64_t T, int64_t r_offset,
@@ -343,6 +355,44 @@ int psh_stream_destroy(int device, void* stream);
 int psh_gather_paths(int device, void* stream,
                      const float* dataset, int64_t R, int64_t C, int64_t T, int64_t r_offset,
                      const int32_t* idx, int64_t n, int len, float* out);
+
+/*
+ * NON-FINITE SAMPLES.  The scans above judge a window by its own K samples (a NaN inside it: distance NaN, never
+ * returned while k clean windows exist).  The reference's embedding is a conv1d whose kernel is ZERO-PADDED by the
+ * horizon (path_embedding.py:48-51), and 0 * NaN = 0 * inf = NaN: there a window is NaN as soon as one sample of
+ * y[r, :, t : t+K+h] -- the window, its h future samples, any channel -- is NaN or +-inf.  A caller that wants exactly that
+ * for an ensemble holding such samples scans rows in which every non-finite sample has been written back over the h
+ * samples before it:
+ *   psh_count_nonfinite  *out_count (device, 8 bytes) = number of NaN / +-inf among n floats: 0 (almost always) -> scan
+ *                        the ensemble as it is;
+ *   psh_smear_nonfinite  out[r, q] (device R x T) = NaN if any channel of dataset (device R x C x T) holds a non-finite sample in
+ *                        [q, q + back], else dataset[r, 0, q]; pass `out` as the scan's dataset with back = h, gather
+ *                        paths from the original.  shadowing_amd.PathShadowing does this once per resident ensemble.
+ */
+int psh_count_nonfinite(int device, void* stream, const float* x, int64_t n, unsigned long long* out_count);
+int psh_smear_nonfinite(int device, void* stream, const float* dataset, int64_t R, int64_t C, int64_t T, int back, float* out);
+
+/*
+ * The reductions of predict_from_paths() (path_shadowing.py:245-252: `proba.avg(values, axis=1)`,
+ * `proba.std(values, axis=1)` over the k shadowing paths):
+ *   out_mean[b, i] = sum_j w[b, j] * values[b, j, i]
+ *   out_std [b, i] = sqrt(sum_j w[b, j] * (values[b, j, i] - out_mean[b, i])^2)
+ * values: device B x k x m float32 (the statistic `to_predict` evaluated on the out-context of the k paths);
+ * weights: device B x k float64 AS GIVEN (the averaging class's, normalised or not -- nothing is renormalised), or NULL:
+ * uniform 1/k;  out_mean, out_std: device B x m float64.  Sums in double, fixed order.
+ */
+int psh_weighted_moments(int device, void* stream, const float* values, const double* weights, int B, int k, int m,
+                         double* out_mean, double* out_std);
+
+/*
+ * realized_variance (shadowing/statistics.py:5-16) of n_rows rows of log-returns:
+ *   out[r, i] = mean(x[r, :Ts[i]]^2) * 252        (its square root if vol != 0)
+ * x: device, row r starts at x + r * row_stride and holds `len` samples (a view into gathered paths: row_stride = W + h,
+ * x = paths + W, len = h);  Ts: HOST array of nT <= 64 maturities in samples (clipped to len, as numpy's slice is);
+ * out: device n_rows x nT float32.  Squares in fp32, sums in double.
+ */
+int psh_realized_variance(int device, void* stream, const float* x, int64_t n_rows, int64_t row_stride, int len,
+                          const int* Ts, int nT, int vol, float* out);
 
 #ifdef __cplusplus
 }

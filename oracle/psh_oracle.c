@@ -28,6 +28,12 @@
  *       torch.topk(largest=False) twice + cat.  The reference's order among
  *       exactly equal distances is arbitrary (unstable partial sort); the
  *       oracle defines the canonical order (d asc, r asc, t asc).
+ *   NON-FINITE SAMPLES (probed on the reference, tests/golden/nan_in_ensemble_*.npz): the embedding is a conv1d whose
+ *       kernel -- one-hot rows for Identity, any (d,1,K) kernel otherwise -- is zero-padded by the horizon
+ *       (path_embedding.py:48-51), and 0 * NaN = 0 * inf = NaN: EVERY embedded coordinate of window t is NaN as soon as ONE
+ *       sample of y[t : t+K+h] -- the window or its h future samples -- is NaN or +-inf.  Such a window's distance is NaN
+ *       and torch.topk(largest=False) ranks it last (path_shadowing.py:165): it never enters the top-k while k clean
+ *       windows exist.  Restated below as nonfinite_prefix() / the `nf` tests.
  *   path_shadowing.py:43-58             flat index -> (r_global, t) int32.
  *   path_shadowing.py:211-216           path gather: dataset[r, t : t+W+h].
  */
@@ -105,6 +111,15 @@ float psh_oracle_sumsq8(const float* x, int W) {
 }
 float psh_oracle_qnorm(const float* x, int W) { return sqrtf(psh_oracle_sumsq8(x, W)); }
 
+/* nf[p] = number of non-finite samples among y[0 .. p-1] (p = 0..T); returns nf[T].  Window t of a scan with field F = K + h
+ * is contaminated (distance NaN) iff nf[t + F] != nf[t]. */
+static int64_t nonfinite_prefix(const float* y, int64_t T, int32_t* nf) {
+    int32_t c = 0;
+    nf[0] = 0;
+    for (int64_t p = 0; p < T; ++p) { c += !isfinite(y[p]); nf[p + 1] = c; }
+    return c;
+}
+
 /* numerator accumulators for NV consecutive windows of one row (vectorisable
  * across windows; the chain over j stays sequential, as in the reference) */
 #define NV 16
@@ -167,9 +182,11 @@ int psh_oracle_scan_topk(const float* dataset, int64_t R, int64_t T, int64_t r_o
             heap_t hp; hp.v = all + (size_t)tid * k; hp.n = 0; hp.k = k;
             float acc[NV];
             float tail[2 * NV + 4096];
+            int32_t* nf = (int32_t*)malloc(sizeof(int32_t) * (size_t)(T + 1));
 #pragma omp for schedule(dynamic, 8)
             for (int64_t r = 0; r < R; ++r) {
                 const float* y = dataset + r * T;
+                const int dirty = nf && nonfinite_prefix(y, T, nf) != 0;     /* rare: the row holds NaN / inf */
                 for (int64_t t0 = 0; t0 < Tp; t0 += NV) {
                     int nv = (int)((Tp - t0) < NV ? (Tp - t0) : NV);
                     if (Tp == 1) {
@@ -188,6 +205,9 @@ int psh_oracle_scan_topk(const float* dataset, int64_t R, int64_t T, int64_t r_o
                             acc[v] = a;
                         }
                     }
+                    if (dirty)      /* a non-finite sample anywhere in y[t : t+W+h] makes the embedded window NaN */
+                        for (int v = 0; v < nv; ++v)
+                            if (nf[t0 + v + W + h] != nf[t0 + v]) acc[v] = NAN;
                     for (int v = 0; v < nv; ++v) {
                         cand_t c;
                         c.d = sqrtf(acc[v]) / xn;
@@ -201,6 +221,7 @@ int psh_oracle_scan_topk(const float* dataset, int64_t R, int64_t T, int64_t r_o
                 }
             }
             counts[tid] = hp.n;
+            free(nf);
         }
         /* merge the per-thread lists */
         int n = 0;
@@ -296,12 +317,15 @@ int psh_oracle_scan_topk_embedded(const float* dataset, int64_t R, int64_t T, in
             const int tid = 0;
 #endif
             heap_t hp; hp.v = all + (size_t)tid * k; hp.n = 0; hp.k = k;
+            int32_t* nf = (int32_t*)malloc(sizeof(int32_t) * (size_t)(T + 1));
 #pragma omp for schedule(dynamic, 4)
             for (int64_t r = 0; r < R; ++r) {
                 const float* y = dataset + r * T;
+                const int dirty = nf && nonfinite_prefix(y, T, nf) != 0;
                 for (int64_t t = 0; t < Tp; ++t) {
                     cand_t c;
                     c.d = sqrtf(Tp == 1 ? embedded_acc_one_window(y, ker, d, K, x) : embedded_acc(y + t, ker, d, K, x)) / xn;
+                    if (dirty && nf[t + K + h] != nf[t]) c.d = NAN;    /* the zero taps of the padded kernel see it too */
                     c.r = (int32_t)(r_offset + r);
                     c.t = (int32_t)t;
                     if (hp.n < k) { if (c.d == c.d) heap_offer(&hp, c); }
@@ -309,6 +333,7 @@ int psh_oracle_scan_topk_embedded(const float* dataset, int64_t R, int64_t T, in
                 }
             }
             counts[tid] = hp.n;
+            free(nf);
         }
         int n = 0;
         for (int t = 0; t < nthreads; ++t) {
@@ -339,10 +364,16 @@ int psh_oracle_all_distances_embedded(const float* dataset, int64_t R, int64_t T
     const int64_t Tp = T - K - h + 1;
     if (Tp <= 0) return -1;
 #pragma omp parallel for schedule(static)
-    for (int64_t r = 0; r < R; ++r)
-        for (int64_t t = 0; t < Tp; ++t)
+    for (int64_t r = 0; r < R; ++r) {
+        int32_t* nf = (int32_t*)malloc(sizeof(int32_t) * (size_t)(T + 1));
+        const int dirty = nf && nonfinite_prefix(dataset + r * T, T, nf) != 0;
+        for (int64_t t = 0; t < Tp; ++t) {
             out[r * Tp + t] = sqrtf(Tp == 1 ? embedded_acc_one_window(dataset + r * T, ker, d, K, hx)
                                             : embedded_acc(dataset + r * T + t, ker, d, K, hx)) / xn;
+            if (dirty && nf[t + K + h] != nf[t]) out[r * Tp + t] = NAN;
+        }
+        free(nf);
+    }
     return 0;
 }
 
@@ -351,13 +382,17 @@ int psh_oracle_all_distances(const float* dataset, int64_t R, int64_t T,
                              const float* x, float xn, int W, int h, float* out /* R x Tp */) {
     const int64_t Tp = T - W - h + 1;
     if (Tp <= 0) return -1;
-    for (int64_t r = 0; r < R; ++r)
+    int32_t* nf = (int32_t*)malloc(sizeof(int32_t) * (size_t)(T + 1));
+    for (int64_t r = 0; r < R; ++r) {
+        const int dirty = nf && nonfinite_prefix(dataset + r * T, T, nf) != 0;
         for (int64_t t = 0; t < Tp; ++t) {
             float a = 0.0f;
             if (Tp == 1) a = acc_single_window_row(dataset + r * T, x, W);
             else for (int j = 0; j < W; ++j) { float D = x[j] - dataset[r * T + t + j]; a = fmaf(D, D, a); }
-            out[r * Tp + t] = sqrtf(a) / xn;
+            out[r * Tp + t] = (dirty && nf[t + W + h] != nf[t]) ? NAN : sqrtf(a) / xn;
         }
+    }
+    free(nf);
     return 0;
 }
 

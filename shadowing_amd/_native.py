@@ -41,7 +41,8 @@ EXPORTS = ("psh_version", "psh_strerror", "psh_last_hip_error", "psh_workspace_b
            "psh_scan_topk_embedded_exhaustive", "psh_merge_workspace_bytes", "psh_merge_topk",
            "psh_merge_topk_gathered", "psh_merge_sorted_gathered", "psh_gather_paths", "psh_embed_rows",
            "psh_embedded_supported", "psh_embed_plan_offset", "psh_workspace_init", "psh_last_comm_error", "psh_comm_unique_id", "psh_comm_create",
-           "psh_comm_destroy", "psh_comm_world", "psh_exchange_merge", "psh_stream_create_reserving", "psh_stream_destroy")
+           "psh_comm_destroy", "psh_comm_world", "psh_exchange_merge", "psh_stream_create_reserving", "psh_stream_destroy",
+           "psh_weighted_moments", "psh_realized_variance", "psh_count_nonfinite", "psh_smear_nonfinite")
 
 _lib = None
 
@@ -124,6 +125,14 @@ def load() -> C.CDLL:
     L.psh_embedded_supported.argtypes = [i32, i32]
     L.psh_embed_rows.restype = i32
     L.psh_embed_rows.argtypes = [i32, vp, vp, i64, i64, vp, i32, i32, vp]
+    L.psh_count_nonfinite.restype = i32
+    L.psh_count_nonfinite.argtypes = [i32, vp, vp, i64, vp]
+    L.psh_smear_nonfinite.restype = i32
+    L.psh_smear_nonfinite.argtypes = [i32, vp, vp, i64, i64, i64, i32, vp]
+    L.psh_weighted_moments.restype = i32
+    L.psh_weighted_moments.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp, vp]
+    L.psh_realized_variance.restype = i32
+    L.psh_realized_variance.argtypes = [i32, vp, vp, i64, i64, i32, C.POINTER(C.c_int), i32, i32, vp]
     L.psh_gather_paths.restype = i32
     L.psh_gather_paths.argtypes = [i32, vp, vp, i64, i64, i64, i64, vp, i64, i32, vp]
     _lib = L
@@ -545,7 +554,11 @@ class PreparedStep:
         self.gathered = torch.empty((G, 3 * B * k), dtype=torch.int32, device=dev)
         self.out_d = torch.empty((B, k), dtype=torch.float32, device=dev)
         self.out_idx = torch.empty((B, k, 2), dtype=torch.int32, device=dev)
-        self.status = torch.zeros((B,), dtype=torch.int32, device=dev)
+        # a status row PER LAUNCH (round-robin over STATUS_ROWS): a PSH_STATUS_RETRY of any step stays visible after later
+        # launches of this slot have reused every other buffer (`status` is the row of the latest launch)
+        self.status_all = torch.zeros((self.STATUS_ROWS, B), dtype=torch.int32, device=dev)
+        self.status = self.status_all[0]
+        self._launches = 0
         self.merge_ws = None
         if not sorted_merge:
             self.merge_ws = torch.empty(merge_workspace_bytes(B, k), dtype=torch.uint8, device=dev)
@@ -559,16 +572,23 @@ class PreparedStep:
         L = load()
         self._scan_fn, self._exch_fn = L.psh_scan_topk, L.psh_exchange_merge
         self._scan_args = [dev.index, None, ds.data_ptr(), R, T, r_offset, None, None, B, W, h, k, self.send.data_ptr(),
-                           self.send.data_ptr() + 4 * B * k, self.status.data_ptr(), ws.data_ptr(), ws.numel(), C.byref(self.prof)]
+                           self.send.data_ptr() + 4 * B * k, self.status_all.data_ptr(), ws.data_ptr(), ws.numel(), C.byref(self.prof)]
+        self._status_base = self.status_all.data_ptr()
         self._exch_args = [comm._h, None, side.cuda_stream, self.send.data_ptr(), self.gathered.data_ptr(), B, k,
                            self.out_d.data_ptr(), self.out_idx.data_ptr(),
                            None if self.merge_ws is None else self.merge_ws.data_ptr(), 0 if self.merge_ws is None else self.merge_ws.numel(),
                            self.ev_a.cuda_event, self.ev_b.cuda_event]
 
+    STATUS_ROWS = 1024
+
     def launch(self, stream_ptr: int, q_ptr: int) -> None:
         a = self._scan_args
         a[1] = stream_ptr
         a[6] = q_ptr
+        row = self._launches % self.STATUS_ROWS
+        self._launches += 1
+        a[14] = self._status_base + 4 * self.B * row
+        self.status = self.status_all[row]
         rc = self._scan_fn(*a)
         if rc:
             _check(rc, "psh_scan_topk")
@@ -660,4 +680,88 @@ def gather_paths(dataset: torch.Tensor, idx: torch.Tensor, length: int, r_offset
         out = torch.zeros(tuple(ix.shape[:-1]) + (Cc, length), dtype=torch.float32, device=ds.device)
     _check(load().psh_gather_paths(ds.device.index, _stream_ptr(ds.device), ds.data_ptr(), R, Cc, T, r_offset,
                                    ix.data_ptr(), n, length, out.data_ptr()), "psh_gather_paths")
+    return out
+
+
+def weighted_moments(values: torch.Tensor, weights: torch.Tensor | None):
+    """(mean, std) over axis 1 of a (B, k, ...) float32 statistic with (B, k) float64 weights (None: uniform) --
+    predict_from_paths()'s `proba.avg(values, axis=1)`, `proba.std(values, axis=1)` on the device; float64 (B, ...)."""
+    v = _dev_tensor(values, torch.float32, "values")
+    if v.dim() < 2:
+        raise ValueError("values must be (B, k, ...)")
+    B, k = v.shape[:2]
+    m = v.numel() // (B * k) if B * k else 0
+    if m == 0:
+        raise ValueError("values is empty")
+    w_ptr = None
+    if weights is not None:
+        w = _dev_tensor(weights, torch.float64, "weights")
+        if tuple(w.shape) != (B, k):
+            raise ValueError(f"weights must be (B, k) = ({B}, {k}), got {tuple(w.shape)}")
+        w_ptr = w.data_ptr()
+    mean = torch.empty((B,) + tuple(v.shape[2:]), dtype=torch.float64, device=v.device)
+    std = torch.empty_like(mean)
+    _check(load().psh_weighted_moments(v.device.index, _stream_ptr(v.device), v.data_ptr(), w_ptr, B, k, m,
+                                       mean.data_ptr(), std.data_ptr()), "psh_weighted_moments")
+    return mean, std
+
+
+def _uniform_rows(x: torch.Tensor):
+    """(n_rows, row_stride) when x (..., L) -- last dim contiguous -- is n_rows rows a constant stride apart (a contiguous
+    tensor, or a slice of the last dimension of one: the out-context view of gathered paths), else None."""
+    if x.dim() == 0 or x.stride(-1) != 1:
+        return None
+    if x.dim() == 1:
+        return 1, x.shape[0]
+    rs = x.stride(-2) if x.shape[-2] > 1 else None
+    n = 1
+    for dim in range(x.dim() - 2, -1, -1):
+        if x.shape[dim] > 1:
+            if rs is None:
+                rs = x.stride(dim) // n if n else x.stride(dim)
+            if x.stride(dim) != rs * n:
+                return None
+        n *= x.shape[dim]
+    return n, (rs if rs is not None else x.shape[-1])
+
+
+def realized_variance(x: torch.Tensor, Ts, vol: bool = False) -> torch.Tensor | None:
+    """statistics.realized_variance on a float32 HIP tensor (..., L): (..., len(Ts)) float32, or None when this tensor's
+    layout is not rows a constant stride apart (the caller then uses torch ops)."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.numel() > 0):
+        return None
+    Ts = [int(T) for T in Ts]
+    rows = _uniform_rows(x)
+    if rows is None or not Ts or len(Ts) > 64 or min(Ts) <= 0:
+        return None
+    n_rows, row_stride = rows
+    L = x.shape[-1]
+    if row_stride < L:
+        return None
+    out = torch.empty(tuple(x.shape[:-1]) + (len(Ts),), dtype=torch.float32, device=x.device)
+    arr = (C.c_int * len(Ts))(*Ts)
+    _check(load().psh_realized_variance(x.device.index, _stream_ptr(x.device), x.data_ptr(), n_rows, row_stride, L, arr, len(Ts),
+                                        1 if vol else 0, out.data_ptr()), "psh_realized_variance")
+    return out
+
+
+def count_nonfinite(x: torch.Tensor) -> int:
+    """Number of NaN / +-inf samples of a float32 HIP tensor (one pass, one host synchronisation)."""
+    t = _dev_tensor(x, torch.float32, "x")
+    out = torch.empty((1,), dtype=torch.int64, device=t.device)
+    _check(load().psh_count_nonfinite(t.device.index, _stream_ptr(t.device), t.data_ptr(), t.numel(), out.data_ptr()),
+           "psh_count_nonfinite")
+    return int(out.item())
+
+
+def smear_nonfinite(dataset: torch.Tensor, back: int) -> torch.Tensor:
+    """(R, T) rows for the scan of an (R, C, T) ensemble that holds non-finite samples: NaN wherever any channel has one
+    within the next `back` samples (the reference's zero-padded conv, see include/psh.h), channel 0 elsewhere."""
+    ds = _dev_tensor(dataset, torch.float32, "dataset")
+    if ds.dim() != 3:
+        raise ValueError("dataset must be (R, C, T)")
+    R, Cc, T = ds.shape
+    out = torch.empty((R, T), dtype=torch.float32, device=ds.device)
+    _check(load().psh_smear_nonfinite(ds.device.index, _stream_ptr(ds.device), ds.data_ptr(), R, Cc, T, int(back), out.data_ptr()),
+           "psh_smear_nonfinite")
     return out

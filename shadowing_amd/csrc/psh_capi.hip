@@ -1090,4 +1090,48 @@ int psh_gather_paths(int device, void* stream, const float* dataset, int64_t R, 
     return PSH_OK;
 }
 
+int psh_count_nonfinite(int device, void* stream, const float* x, int64_t n, unsigned long long* out_count) {
+    if (!x || !out_count || n < 0) return PSH_ERR_ARG;
+    DeviceGuard g(device);
+    if (!g.ok) { snprintf(g_hip_err, sizeof(g_hip_err), "hipSetDevice(%d) failed", device); return PSH_ERR_HIP; }
+    HIP_TRY(launch_count_nonfinite(x, n, out_count, (hipStream_t)stream));
+    return PSH_OK;
+}
+
+int psh_smear_nonfinite(int device, void* stream, const float* dataset, int64_t R, int64_t C, int64_t T, int back, float* out) {
+    if (!dataset || !out || R < 0 || C <= 0 || T <= 0 || back < 0) return PSH_ERR_ARG;
+    if (R * T >= ((int64_t)1 << 31) * 256) return PSH_ERR_UNSUPPORTED;
+    DeviceGuard g(device);
+    if (!g.ok) { snprintf(g_hip_err, sizeof(g_hip_err), "hipSetDevice(%d) failed", device); return PSH_ERR_HIP; }
+    HIP_TRY(launch_smear_nonfinite(dataset, R, C, T, back, out, (hipStream_t)stream));
+    return PSH_OK;
+}
+
+int psh_weighted_moments(int device, void* stream, const float* values, const double* weights, int B, int k, int m,
+                         double* out_mean, double* out_std) {
+    if (!values || !out_mean || !out_std || B <= 0 || k <= 0 || m <= 0) return PSH_ERR_ARG;
+    DeviceGuard g(device);
+    if (!g.ok) { snprintf(g_hip_err, sizeof(g_hip_err), "hipSetDevice(%d) failed", device); return PSH_ERR_HIP; }
+    MomentsArgs a{values, weights, B, k, m, out_mean, out_std};
+    HIP_TRY(launch_moments(a, (hipStream_t)stream));
+    return PSH_OK;
+}
+
+int psh_realized_variance(int device, void* stream, const float* x, int64_t n_rows, int64_t row_stride, int len,
+                          const int* Ts, int nT, int vol, float* out) {
+    if (!x || !Ts || !out || n_rows < 0 || len <= 0 || row_stride < len || nT <= 0) return PSH_ERR_ARG;
+    if (nT > PSH_RV_MAX_T) return PSH_ERR_UNSUPPORTED;
+    if (n_rows == 0) return PSH_OK;
+    DeviceGuard g(device);
+    if (!g.ok) { snprintf(g_hip_err, sizeof(g_hip_err), "hipSetDevice(%d) failed", device); return PSH_ERR_HIP; }
+    RvArgs a{};
+    a.x = x; a.n_rows = n_rows; a.row_stride = row_stride; a.nT = nT; a.vol = vol ? 1 : 0; a.out = out;
+    for (int i = 0; i < nT; ++i) {
+        if (Ts[i] <= 0) return PSH_ERR_ARG;
+        a.Ts[i] = Ts[i] < len ? Ts[i] : len;                 // numpy: x[..., :T] clips to the row
+    }
+    HIP_TRY(launch_realized_variance(a, (hipStream_t)stream));
+    return PSH_OK;
+}
+
 }  // extern "C"

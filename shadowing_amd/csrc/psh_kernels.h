@@ -294,5 +294,26 @@ hipError_t launch_stream_scan(const ScanArgs& a, const FusedArgs& f, bool aligne
 hipError_t launch_stream_rank(const ScanArgs& a, const FusedArgs& f, int grid, hipStream_t s);
 size_t stream_scan_shmem_bytes_q(int tile_floats, int nq);
 hipError_t launch_embed_rows(const float* dataset, int64_t R, int64_t T, const float* ker, int d, int K, float* out, hipStream_t s);
+// psh_predict.hip: the reductions of predict_from_paths() on the device
+struct MomentsArgs {
+    const float* values;      // (B, k, m)
+    const double* weights;    // (B, k), or nullptr: uniform 1/k
+    int B, k, m;
+    double* out_mean;         // (B, m)
+    double* out_std;          // (B, m)
+};
+#define PSH_RV_MAX_T 64
+struct RvArgs {
+    const float* x;           // n_rows rows, row_stride floats apart
+    int64_t n_rows, row_stride;
+    int Ts[PSH_RV_MAX_T];     // maturities (already clipped to the row length)
+    int nT, vol;
+    float* out;               // (n_rows, nT)
+};
+// psh_prep.hip: non-finite samples the way the reference's zero-padded conv treats them
+hipError_t launch_count_nonfinite(const float* x, int64_t n, unsigned long long* out, hipStream_t s);
+hipError_t launch_smear_nonfinite(const float* ds, int64_t R, int64_t C, int64_t T, int back, float* out, hipStream_t s);
+hipError_t launch_moments(const MomentsArgs& a, hipStream_t s);
+hipError_t launch_realized_variance(const RvArgs& a, hipStream_t s);
 
 }  // namespace psh

@@ -158,6 +158,12 @@ class ShardedPathShadowing:
             self._workspace = None
         self.dataset = ds.contiguous()
         self.device = self.dataset.device
+        # the rows the native scan reads: the shard itself, or -- it holds NaN / +-inf samples -- a copy with them written back
+        # over the horizon, so that windows are NaN exactly where the reference's zero-padded conv makes them NaN
+        # (PathShadowing._scan_rows_of, psh_prep.hip); paths are gathered from `dataset`
+        self._rows = self.dataset[:, 0, :]
+        if local_topk is None and self.dataset.numel() and _native.count_nonfinite(self.dataset):
+            self._rows = _native.smear_nonfinite(self.dataset, int(self.context.get_out_times()))
         self._scan_streams = None
         self._reserve = 0
         if streams > 1 and local_topk is None and self.device.type == "cuda":
@@ -206,6 +212,9 @@ class ShardedPathShadowing:
             self._comm = _native.Comm(self.device, G, rank, box[0])
             # the communicator belongs to libpsh_hip.so: it goes away with this object (or at interpreter exit)
             self._comm_finalizer = weakref.finalize(self, _close_comm, self._comm, self.device)
+            # not at interpreter exit: a synchronize / ncclCommDestroy there hangs when a peer rank is already gone with a
+            # collective pending; close() is the orderly path (the OS reclaims the rest)
+            self._comm_finalizer.atexit = False
             self._side = torch.cuda.Stream(device=self.device)
             self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(8)]
             for a, b in self._events:              # materialise the hipEvent handles
@@ -219,6 +228,22 @@ class ShardedPathShadowing:
                 'exchange="library" (psh_exchange_merge) needs a HIP device, the native scan and an even B*k '
                 f'(device {self.device}, B*k = {B * k}); use exchange="auto" or "torch"')
         return usable and self.exchange != "torch"
+
+    def status_max(self) -> int:
+        """Largest status word of ANY step issued through the prepared ring since reset_status() (one host
+        synchronisation): 0 = every step's results were valid; PSH_STATUS_RETRY = some step gave up.  `last_status` only
+        shows the latest launch of one slot."""
+        worst = 0
+        for ring in self._fast.values():
+            for slot in ring:
+                worst = max(worst, int(slot.status_all.max().item()))
+        return worst
+
+    def reset_status(self) -> None:
+        """Forget the status history (call with the device idle, e.g. after a synchronize)."""
+        for ring in self._fast.values():
+            for slot in ring:
+                slot.status_all.zero_()
 
     def close(self):
         if self._comm is not None:
@@ -247,7 +272,7 @@ class ShardedPathShadowing:
             d, idx = self._local_topk(self.dataset[:, 0, :], q, k_local, h, self.row_offset)
             status = None
         else:
-            d, idx, status = _native_local_topk(self.dataset[:, 0, :], q, k_local, h, self.row_offset, workspace or self._workspace,
+            d, idx, status = _native_local_topk(self._rows, q, k_local, h, self.row_offset, workspace or self._workspace,
                                                 out=out if k_local == k else None, check=check, ker=self._ker,
                                                 unsorted=unsorted, flags=flags)
         if k_local < k:
@@ -291,7 +316,10 @@ class ShardedPathShadowing:
         """The lean form of a step on the private streams (a host that spends more Python per step than the GPU spends
         scanning is the bottleneck): Identity scan, library exchange, queries already a float32 (B, W) tensor on the device,
         no per-call status check.  Prepared argument lists and a ring of buffers per (B, W, k) (_native.PreparedStep); two
-        ctypes calls per step.  Results live in the ring: valid until 2 x streams further scan_begin() calls."""
+        ctypes calls per step.  Results live in the ring: valid until 2 x streams further scan_begin() calls -- the GPU
+        orders a slot's next scan and exchange behind its previous exchange, NOT behind whoever reads the merged result:
+        a consumer enqueues its reads of (d, idx) before it begins the 2 x streams-th step after this one (a pipelined
+        loop that finishes step i right after beginning step i + 1 does)."""
         if (check or self._linear or self._local_topk is not None or self._merge is not None or self._emulate is not None
                 or not isinstance(queries, torch.Tensor) or queries.device != self.device or queries.dtype != torch.float32
                 or queries.dim() != 2 or not queries.is_contiguous() or not self.fuse):
@@ -310,7 +338,7 @@ class ShardedPathShadowing:
             comm = self._library_exchange()
             n = len(self._scan_streams)
             sorted_merge = _native.merge_sorted_supported(G, k)
-            ring = [_native.PreparedStep(comm, self.dataset[:, 0, :], self.row_offset, B, W, k, h, self._scan_ws[j % n], self._side,
+            ring = [_native.PreparedStep(comm, self._rows, self.row_offset, B, W, k, h, self._scan_ws[j % n], self._side,
                                          (_native.FLAG_OVERLAP | (_native.FLAG_RESERVE_CUS if self._reserve else 0)) if B == 1 else 0,
                                          sorted_merge) for j in range(2 * n)]
             torch.cuda.synchronize(self.device)
@@ -321,6 +349,11 @@ class ShardedPathShadowing:
         s = self._scan_streams[j % len(self._scan_streams)]
         if not queries_ready:
             s.wait_stream(torch.cuda.current_stream(self.device))
+        # the slot's buffers are reused: this scan writes `send`, which the all-gather of the slot's PREVIOUS step reads on
+        # the side stream, and this step's merge overwrites `gathered` / `out_*` behind it -- so the scan waits for that
+        # exchange's end (ev_b still carries its record; 2 x streams steps ago, long complete unless a rank lags in the
+        # collective -- exactly when the order matters)
+        s.wait_event(slot.ev_b)
         queries.record_stream(s)
         slot.launch(s.cuda_stream, queries.data_ptr())
         self.last_status = slot.status
@@ -340,6 +373,8 @@ class ShardedPathShadowing:
             with single_thread():
                 queries = self.embedding(queries.to(kdev, dtype=torch.float32)[:, None, :])[:, 0, :]
         q = queries.to(self.device, dtype=torch.float32).contiguous()
+        if ws is not None and q.device.type == "cuda":
+            q.record_stream(torch.cuda.current_stream(self.device))   # read on this private stream, maybe allocated on the caller's
         B = q.shape[0]
         G = self.world_size
         if k > self.n_windows_global():
@@ -459,6 +494,10 @@ class PendingScan:
             if self._result is not None:
                 for t in self._result:
                     t.record_stream(cur)
+            if self._buffers is not None:
+                for t in self._buffers[:2]:                  # send / gathered: allocated on the private stream, merged on this one
+                    if isinstance(t, torch.Tensor):
+                        t.record_stream(cur)
         if self._result is None:
             o, B, k = self._owner, self._B, self._k
             G = o.world_size

@@ -122,6 +122,7 @@ class PathShadowing:
         self._workspace = None
         self.last_profile = None
         self.last_path = None       # "hip" / "torch": which implementation served the last shadow() / predict()
+        self.last_predict_reduction = None   # device_predict: "device" (psh_weighted_moments) / "host" (the class's own avg / std)
 
     @staticmethod
     def _load_with_scatspectra(dataset):
@@ -264,12 +265,19 @@ class PathShadowing:
 
     def _scan_rows_of(self, ds: torch.Tensor) -> torch.Tensor:
         """(R, T) rows the scan reads: the ensemble itself, or -- several channels, CrossChannelContext -- a
-        contiguous copy of channel 0 kept beside it."""
-        if ds.shape[1] == 1:
-            return ds[:, 0, :]
-        key = (ds.data_ptr(), tuple(ds.shape), ds._version)
+        contiguous copy of channel 0 kept beside it.  An ensemble that holds NaN / +-inf samples (looked for ONCE per
+        resident copy: psh_count_nonfinite) is scanned through rows in which those samples are written back over the
+        horizon before them, so that a window is NaN exactly where the reference's zero-padded conv makes it NaN -- a
+        non-finite sample anywhere in y[r, :, t : t+K+h] (ref path_embedding.py:48-51, :129-132; psh_prep.hip); paths are
+        still gathered from the ensemble itself."""
+        back = 0 if type(self.context) is ImputationContext else int(self.context.get_out_times())
+        key = (ds.data_ptr(), tuple(ds.shape), ds._version, back)
         if self._scan_rows is None or self._scan_rows[0] != key or self._scan_rows[2]() is not ds:
-            self._scan_rows = (key, ds[:, 0, :].contiguous(), weakref.ref(ds))
+            if _native.count_nonfinite(ds):
+                rows = _native.smear_nonfinite(ds, back)
+            else:
+                rows = ds[:, 0, :] if ds.shape[1] == 1 else ds[:, 0, :].contiguous()
+            self._scan_rows = (key, rows, weakref.ref(ds))
         return self._scan_rows[1]
 
     def _native_scan(self, x: torch.Tensor, y: torch.Tensor, k: int, defer_status: bool = False):
@@ -548,10 +556,13 @@ class PathShadowing:
                            proba_name: str, eta: float | None):
         """shadow() + predict_from_paths() with the PATHS kept on the GPU: the k paths of every query (74 MB for
         the tutorial's call) stay in HBM and `to_predict` is evaluated there on the device tensor of their
-        out-context; what crosses PCIe are the (B, k) distances and the (B, k, ...) statistic -- a few hundred KB.
-        The averaging itself is the installed DiscreteProba's own `avg` / `std` on those host arrays (ref :245-252):
-        scatspectra's classes when that package is importable, the stand-ins of averaging.py otherwise -- no
-        formula of theirs is restated here.  Only called when the caller opted in (see predict())."""
+        out-context; what crosses PCIe are the (B, k) distances -- the installed DiscreteProba turns them into its weights
+        on the host (ref :245-250: scatspectra's classes when that package is importable, the stand-ins of averaging.py
+        otherwise; no formula of theirs is restated) -- and the (B, ...) moments: `avg` / `std` over the k paths
+        (ref :251-252) are reduced on the device by psh_weighted_moments when the class's own avg / std are the weighted
+        moments of weights it exposes (moment_weights checks that on a probe; `last_predict_reduction` says which way a
+        call went); any other class receives the (B, k, ...) statistic on the host and reduces it itself.  Only called
+        when the caller opted in (see predict())."""
         length = x.shape[-1] + self.context.get_out_times()
 
         def evaluate(d, idx, ds):
@@ -565,25 +576,34 @@ class PathShadowing:
 
         self.last_path = "hip"
         out = self._native_scan(x, y, k, defer_status=True)
-        d_host = v_host = None
+        d_host = values = None
         if len(out) == 4:                                   # Identity scan: the status is read with the results (see shadow())
             d, idx, ds, status = out
             values = evaluate(d, idx, ds)
-            if values.is_cuda:
-                d_host, v_host, hs = self._to_host(d, values.contiguous(), status)
-                if hs.any():
-                    if bool((hs == _native.PSH_STATUS_RETRY).any()):
-                        self._workspace.arm()
-                    d_host = None
-            else:
+            d_host, hs = self._to_host(d, status)
+            if hs.any():
+                if bool((hs == _native.PSH_STATUS_RETRY).any()):
+                    self._workspace.arm()
                 d_host = None
-            if d_host is None:
                 out = self._native_scan(x, y, k)
         if d_host is None:
             d, idx, ds = out
             values = evaluate(d, idx, ds)
-            d_host, v_host = self._to_host(d, values.contiguous()) if values.is_cuda else (d.cpu().numpy(), values.numpy())
+            (d_host,) = self._to_host(d)
+        # what has crossed PCIe so far: the (B, k) distances.  The installed class turns them into weights on the host (its
+        # formula is its own); if its avg / std ARE the weighted moments of those weights -- checked on a probe, the class
+        # stays authoritative -- the (B, k, ...) statistic is reduced where it is (psh_weighted_moments) and only the
+        # (B, ...) moments come back.  Any other class gets the statistic on the host, as before.
         proba = self.init_averaging_proba(proba_name, d_host[:, :, None], eta)
+        self.last_predict_reduction = "host"
+        if values.is_cuda and values.dtype == torch.float32:
+            w = moment_weights(proba, values.shape[0], values.shape[1])
+            if w is not None:
+                wt = None if w is True else torch.from_numpy(w).to(values.device)
+                mean, std = _native.weighted_moments(values.contiguous(), wt)
+                self.last_predict_reduction = "device"
+                return self._to_host(mean, std)
+        v_host = self._to_host(values.contiguous())[0] if values.is_cuda else values.numpy()
         return proba.avg(v_host, axis=1), proba.std(v_host, axis=1)
 
     def predict(self, x_context: ArrayType, k: int, to_predict: Callable, eta: float | None = None,
@@ -615,6 +635,40 @@ class PathShadowing:
             means.append(m)
             stds.append(s)
         return np.concatenate(means), np.concatenate(stds)
+
+
+def moment_weights(proba, B: int, k: int):
+    """The (B, k) float64 weights of an averaging object IF its `avg` / `std` over axis 1 are the weighted moments
+    sum_j w_j x_j and sqrt(sum_j w_j (x_j - mean)^2) of those weights: True for uniform weights 1/k, an array otherwise,
+    None when the object does not expose weights or when ITS OWN avg / std disagree with the moments on a probe (then the
+    caller lets the object reduce on the host: the class is the authority, nothing of it is restated)."""
+    if not hasattr(proba, "weights"):
+        return None
+    w = proba.weights
+    if w is not None:
+        try:
+            w = np.asarray(w, dtype=np.float64)
+        except Exception:  # noqa: BLE001
+            return None
+        while w.ndim > 2 and w.shape[-1] == 1:
+            w = w[..., 0]
+        if w.shape != (B, k):
+            return None
+        w = np.ascontiguousarray(w)
+    wf = np.full((B, k), 1.0 / k) if w is None else w
+    j = np.arange(B * k * 2, dtype=np.float64).reshape(B, k, 2)
+    probe = np.cos(0.37 * j) + 0.01 * j / (B * k)
+    try:
+        a, sd = np.asarray(proba.avg(probe, axis=1)), np.asarray(proba.std(probe, axis=1))
+    except Exception:  # noqa: BLE001
+        return None
+    m = (wf[:, :, None] * probe).sum(axis=1)
+    v = np.sqrt((wf[:, :, None] * (probe - m[:, None, :]) ** 2).sum(axis=1))
+    if a.shape != m.shape or sd.shape != v.shape:
+        return None
+    if not (np.allclose(a, m, rtol=1e-10, atol=1e-13) and np.allclose(sd, v, rtol=1e-10, atol=1e-13)):
+        return None
+    return True if w is None else w
 
 
 class PendingShadow:

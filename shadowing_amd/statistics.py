@@ -12,6 +12,13 @@ def realized_variance(x, Ts, vol: bool = False):
     """x: (..., T) log-returns; Ts: iterable of maturities (in samples).
     Returns (..., len(Ts)): mean(x^2[..., :T]) * 252 (its square root if vol)."""
     if isinstance(x, torch.Tensor):
+        if x.is_cuda and x.dtype == torch.float32:
+            # on the HIP device: one launch of the library's reduction (psh_realized_variance) over the rows where they lie
+            # -- the out-context VIEW of the gathered paths included, no copy
+            from . import _native
+            out = _native.realized_variance(x, Ts, vol)
+            if out is not None:
+                return out
         x2 = x ** 2
         out = torch.stack([x2[..., :int(T)].mean(-1) for T in Ts], dim=-1) * 252
         return out ** 0.5 if vol else out

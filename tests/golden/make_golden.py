@@ -56,6 +56,10 @@ def main():
                          "known arithmetic (tests/_known_proba.py) injected where un-vendored scatspectra's would be")
     ap.add_argument("--cross", action="store_true",
                     help="ONLY the CrossChannelContext cases (multi-channel ensemble, scan on channel 0)")
+    ap.add_argument("--nan", action="store_true", help="ONLY the NaN / inf-in-the-ensemble cases of the Identity scan")
+    ap.add_argument("--sharded", action="store_true",
+                    help="ONLY BASELINE configs[3]: the ensembles bench.py --gpus N scans (rank blocks dataset(32768,4096,seed=g), "
+                         "g < N) for N = 2, 4, 8, the reference run on each WHOLE ensemble (~10 min, ~10 GB)")
     args = ap.parse_args()
 
     ref = load_reference()
@@ -124,6 +128,43 @@ def main():
                    meta=json.dumps(dict(reference_seconds=round(dt, 3), numpy=np.__version__, torch=torch.__version__)))
         np.savez_compressed(HERE / f"{name}.npz", **out)
         print(f"{name}: dataset{ds.shape} d{d.shape} idx{idx.shape} paths{paths.shape} ref {dt:.2f}s")
+
+    if args.nan:
+        # NaN / +-inf planted in the ENSEMBLE: torch.topk(largest=False) ranks NaN distances last (PS:165), so windows that
+        # touch a NaN never enter the top-k while k finite ones exist; an infinite sample makes its windows' distances +inf
+        ds = syn.dataset(96, 700, 50)
+        g = np.random.default_rng(51)
+        for r, t in zip(g.integers(0, 96, 40), g.integers(0, 700, 40)):
+            ds[r, 0, t] = np.nan
+        for r, t in zip(g.integers(0, 96, 6), g.integers(0, 700, 6)):
+            ds[r, 0, t] = np.inf if (r + t) % 2 else -np.inf
+        ds[7, 0, :] = np.nan                                   # a whole row
+        run("nan_in_ensemble_B1", ds, syn.single_query(20, 52), 20, 20, 64, 3, True)
+        run("nan_in_ensemble_B3", ds, syn.rolling_queries(3, 20, 53), 20, 20, 64, 2, True)
+        run("nan_in_ensemble_B9", ds, syn.rolling_queries(9, 20, 54), 20, 20, 48, 1, True)
+        return
+
+    if args.sharded:
+        # what `bench.py --gpus N` scans: rank g holds dataset(32768, 4096, seed=g) as rows [g*32768, (g+1)*32768); the
+        # reference sees the N blocks as ONE ensemble (it has no multi-GPU path: PS:170-173 is the merge being restated)
+        blocks = [syn.dataset(32768, 4096, g) for g in range(8)]
+        q = syn.single_query(20, 1)
+        out = dict(queries=np.atleast_2d(q).astype(np.float32), W=20, h=20, k=1024, rows_per_rank=32768, T=4096,
+                   block_sha256=np.array([syn.sha256(b) for b in blocks]))
+        secs = {}
+        for N in (2, 4, 8):
+            ds = np.concatenate(blocks[:N], axis=0)
+            obj = ref.PathShadowing(ref.Identity(20), ref.RelativeMSE(), ds, ref.PredictionContext(horizon=20))
+            t0 = time.time()
+            d, paths, idx = obj.shadow(q, k=1024, n_splits=64 * N, cuda=False)
+            secs[N] = round(time.time() - t0, 1)
+            out[f"d_N{N}"], out[f"idx_N{N}"] = d, idx
+            print(f"cfg4 N={N}: R={ds.shape[0]} d{d.shape} idx{idx.shape} ref {secs[N]}s", flush=True)
+            del obj, ds
+        out["meta"] = json.dumps(dict(gen="concatenate([dataset(32768,4096,g) for g in range(N)])", qgen="single_query(20,1)",
+                                      reference_seconds=secs, numpy=np.__version__, torch=torch.__version__))
+        np.savez_compressed(HERE / "cfg4_R262144.npz", **out)
+        return
 
     if args.predict:
         spec2 = importlib.util.spec_from_file_location("psh_known_proba", REPO / "tests" / "_known_proba.py")

@@ -26,9 +26,12 @@ G, RS, T, W, H, K = 8, 32768, 4096, 20, 20, 1024
 @pytest.fixture(scope="module")
 def ensemble(hip_device):
     """(host (G*RS, 1, T) array, list of G device shards (RS, T))."""
-    free, _ = torch.cuda.mem_get_info(hip_device)
+    free, total = torch.cuda.mem_get_info(hip_device)
     if free < 12 * 2 ** 30:
-        pytest.skip("needs 12 GiB of free HBM")
+        # an MI355X has 288 GB: too little free HBM there is a fault to look at, not a reason to drop all configs[3] evidence
+        if total >= 200 * 2 ** 30:
+            pytest.fail(f"only {free / 2 ** 30:.1f} GiB of {total / 2 ** 30:.0f} GiB HBM free: the configs[3] tests need 12 GiB")
+        pytest.skip("needs 12 GiB of free HBM (a smaller part than the MI355X this suite is for)")
     host = np.empty((G * RS, 1, T), np.float32)
     shards = []
     for g in range(G):
@@ -71,6 +74,30 @@ def test_configs3_full_size_eight_logical_shards(hip_device, oracle_mod, ensembl
     # the general (unsorted) merge agrees
     gd, gi = _native.merge_topk_gathered(gathered, G, B, K, K)
     assert torch.equal(gd, md) and torch.equal(gi, mi)
+
+
+@pytest.mark.parametrize("N", [2, 4, 8])
+def test_configs3_equals_the_reference_run_on_the_whole_ensemble(hip_device, ensemble, N):
+    """tests/golden/cfg4_R262144.npz: the REFERENCE's own shadow(cuda=False) on the concatenated rank blocks of
+    `bench.py --gpus N` (make_golden.py --sharded; N = 2, 4, 8 -- 1.06e9 windows at N = 8).  The first N shards scanned on
+    the device + the sorted merge return the reference's distances bit for bit and its (row, t) pairs -- the fixture
+    bench.py checks its first merged result against on a real N-GPU run."""
+    from shadowing_amd import _native
+    from _util import GOLDEN
+    import bench
+    g = np.load(GOLDEN / "cfg4_R262144.npz")
+    host, shards = ensemble
+    for r in range(N):
+        assert syn.sha256(host[r * RS:(r + 1) * RS]) == str(g["block_sha256"][r])
+    q = np.ascontiguousarray(g["queries"])
+    assert np.array_equal(q, syn.single_query(W, syn.QUERY_SEED)[None, :])
+    gathered = _scan_shards(hip_device, shards, q)[:N].contiguous()
+    md, mi = _native.merge_sorted_gathered(gathered, N, 1, K, K)
+    torch.cuda.synchronize()
+    assert bench.same_result(md.cpu().numpy(), mi.cpu().numpy(), g[f"d_N{N}"], g[f"idx_N{N}"], tie_free_order=False)
+    # (no exact ties inside this top-k: the reference's order is then the canonical one, element for element)
+    if len(np.unique(g[f"d_N{N}"])) == K:
+        assert_exact(md.cpu().numpy(), mi.cpu().numpy(), g[f"d_N{N}"], g[f"idx_N{N}"], f"configs[3] N={N} vs the reference")
 
 
 def test_configs3_overlap_launches_per_shard(hip_device, oracle_mod, ensemble):

@@ -1,0 +1,124 @@
+"""NaN / +-inf samples in the ENSEMBLE, the reference's way: its embedding is a conv1d whose kernel is zero-padded by the
+horizon (path_embedding.py:48-51), and 0 * NaN = 0 * inf = NaN -- a window is NaN as soon as one sample of
+y[r, :, t : t+K+h] is non-finite, and torch.topk(largest=False) ranks it last (path_shadowing.py:165).  Reference goldens
+(tests/golden/nan_in_ensemble_*.npz, make_golden.py --nan) through every Identity path -- fused launch, overlap launches,
+the 2-3 query launches, the batched scan, the separate launches -- plus the embedded scans, the sharded class and the
+C ABI's two preparation entry points against numpy."""
+import numpy as np
+import pytest
+import torch
+
+from _util import NAN_GOLDENS, assert_exact, assert_matches_reference, load_golden, rows3, syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _dirty(R, T, seed, n_nan=60, n_inf=10, C=1):
+    ds = syn.gbm_log_returns((R, C, T), seed)
+    g = np.random.default_rng(seed + 1)
+    for r, c, t in zip(g.integers(0, R, n_nan), g.integers(0, C, n_nan), g.integers(0, T, n_nan)):
+        ds[r, c, t] = np.nan
+    for r, c, t in zip(g.integers(0, R, n_inf), g.integers(0, C, n_inf), g.integers(0, T, n_inf)):
+        ds[r, c, t] = np.inf if (r + t) % 2 else -np.inf
+    return ds
+
+
+@pytest.mark.parametrize("C,back", [(1, 0), (1, 20), (3, 7), (2, 300)])
+def test_count_and_smear_equal_numpy(hip_device, C, back):
+    from shadowing_amd import _native
+    ds = _dirty(130, 257, 900 + C + back, C=C)
+    dt = torch.as_tensor(ds).to(hip_device)
+    assert _native.count_nonfinite(dt) == int((~np.isfinite(ds)).sum())
+    assert _native.count_nonfinite(torch.as_tensor(syn.dataset(33, 1001, 3)).to(hip_device)) == 0
+    bad = (~np.isfinite(ds)).any(axis=1)                                   # (R, T): any channel
+    want = ds[:, 0, :].copy()
+    for r, p in zip(*np.nonzero(bad)):
+        want[r, max(0, p - back):p + 1] = np.nan
+    got = _native.smear_nonfinite(dt, back).cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
+
+
+@pytest.mark.parametrize("name", NAN_GOLDENS)
+def test_shadow_matches_the_reference_with_nonfinite_samples(hip_device, oracle_mod, name):
+    """shadow(cuda=True) == the reference's own output (1 query: the fused launch; 3: the overlap launches; 9: the batched
+    scan), paths included (gathered from the ensemble itself, NaNs and all)."""
+    import shadowing_amd as sa
+    g = load_golden(name)
+    ds = rows3(g["dataset"])
+    obj = sa.PathShadowing(sa.Identity(g["W"]), sa.RelativeMSE(), torch.as_tensor(ds), sa.PredictionContext(g["h"]))
+    d, paths, idx = obj.shadow(g["queries"], k=g["k"], cuda=True)
+    assert obj.last_path == "hip"
+    all_dist = [oracle_mod.all_distances(ds, q, g["h"]) for q in g["queries"]]
+    assert_matches_reference(d, idx, g, all_dist, what=name)
+    od, opaths, oidx = oracle_mod.shadow(ds, g["queries"], g["k"], g["h"])
+    assert_exact(d, idx, od, oidx, name + " vs oracle")
+    assert np.array_equal(paths, opaths, equal_nan=True)
+    assert np.isfinite(d).all()                                            # k clean windows exist: no NaN is returned
+
+
+def test_every_identity_path_with_nonfinite_samples(hip_device, oracle_mod):
+    """A larger dirty ensemble (sampled threshold paths, not the tiny-ensemble ones): fused launch, shadow_async (overlap
+    launches), 2 and 3 queries, a batch, and the separate launches through the C ABI on the smeared rows -- all equal
+    the oracle, whose rule is pinned on the reference's goldens."""
+    import shadowing_amd as sa
+    from shadowing_amd import _native
+    R, T, W, h, k = 4096, 2048, 20, 20, 300
+    ds = _dirty(R, T, 7100, n_nan=4000, n_inf=500)
+    ds[11, 0, :] = np.nan
+    obj = sa.PathShadowing(sa.Identity(W), sa.RelativeMSE(), torch.as_tensor(ds), sa.PredictionContext(h))
+    for B in (1, 2, 3, 9):
+        q = syn.rolling_queries(B, W, 7200 + B)
+        d, paths, idx = obj.shadow(q, k=k, cuda=True)
+        od, opaths, oidx = oracle_mod.shadow(ds, q, k, h)
+        assert_exact(d, idx, od, oidx, f"dirty ensemble, {B} queries")
+        assert np.array_equal(paths, opaths, equal_nan=True)
+    q = syn.single_query(W, 7300)
+    d, paths, idx = obj.shadow_async(q, k=k).result()
+    od, opaths, oidx = oracle_mod.shadow(ds, q[None, :], k, h)
+    assert_exact(d, idx, od, oidx, "dirty ensemble, shadow_async")
+    # the C ABI on the prepared rows, separate launches and exhaustive path
+    dt = torch.as_tensor(ds).to(hip_device)
+    rows = _native.smear_nonfinite(dt, h)
+    qd = torch.as_tensor(q[None, :]).to(hip_device)
+    for kw in (dict(flags=_native.FLAG_NO_FUSE), dict(exhaustive=True)):
+        dd, ii, st = _native.scan_topk(rows, qd, k, h=h, **kw)[:3]
+        torch.cuda.synchronize()
+        assert int(st.max().item()) == 0
+        assert_exact(dd.cpu().numpy(), ii.cpu().numpy(), od, oidx, f"dirty ensemble, C ABI {kw}")
+    # windows whose FUTURE holds the non-finite sample are exactly what the smear adds: without it the result differs
+    dd, ii, _ = _native.scan_topk(dt[:, 0, :].contiguous(), qd, k, h=h, flags=_native.FLAG_NO_FUSE)[:3]
+    torch.cuda.synchronize()
+    assert not np.array_equal(ii.cpu().numpy(), oidx)
+
+
+@pytest.mark.parametrize("kind", ["foveal", "wavelet"])
+def test_embedded_scans_with_nonfinite_samples(hip_device, oracle_mod, kind):
+    import shadowing_amd as sa
+    R, T, h, k = 1024, 1500, 30, 200
+    ds = _dirty(R, T, 7400, n_nan=300, n_inf=60)
+    if kind == "foveal":
+        emb = sa.Foveal(alpha=1.3, beta=0.9, max_context=60)
+    else:
+        emb = sa.PathEmbedding(torch.tensor(syn.wavelet_bank(3, 64))[:, None, :])
+    K = emb.kernel.shape[-1]
+    x = syn.gbm_log_returns((3, K), 7401)
+    obj = sa.PathShadowing(emb, sa.RelativeMSE(), torch.as_tensor(ds), sa.PredictionContext(h))
+    d, paths, idx = obj.shadow(x, k=k, cuda=True)
+    assert obj.last_path == "hip"
+    hx = emb(torch.tensor(x)[:, None, :])[:, 0, :].numpy()
+    od, oidx = oracle_mod.scan_topk_embedded(ds, emb.kernel[:, 0, :].numpy(), hx, k, h=h)
+    assert_exact(d, idx, od, oidx, f"dirty ensemble, {kind}")
+
+
+def test_sharded_class_with_nonfinite_samples(hip_device, oracle_mod):
+    import shadowing_amd as sa
+    from shadowing_amd.distributed import ShardedPathShadowing
+    R, T, W, h, k = 2048, 1024, 20, 20, 128
+    ds = _dirty(R, T, 7500, n_nan=900, n_inf=100)
+    obj = ShardedPathShadowing(sa.Identity(W), sa.RelativeMSE(), torch.as_tensor(ds), 5000, sa.PredictionContext(h),
+                               device=hip_device, always_exchange=True)
+    q = syn.rolling_queries(2, W, 7501)
+    d, idx = obj.scan(torch.as_tensor(q), k)
+    torch.cuda.synchronize()
+    od, oidx = oracle_mod.scan_topk(ds, q, k, h=h, r_offset=5000)
+    assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, "dirty shard")

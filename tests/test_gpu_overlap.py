@@ -307,6 +307,37 @@ def test_small_batch_status_protocol_and_reference_golden(hip_device, oracle_mod
     assert_matches_reference(dd, ii, {**g, "d": g["d"][:3], "idx": g["idx"][:3]}, None, what="3 queries of cfg3_rolling_R2048")
 
 
+@pytest.mark.parametrize("B", [2, 3])
+def test_plain_small_batch_call_reports_retry_and_the_protocol_recovers(hip_device, oracle_mod, B):
+    """include/psh.h, psh_scan_topk's status protocol: a PLAIN call (no flag) with 2 or 3 queries rides the overlap
+    launches and may say PSH_STATUS_RETRY for the whole call.  Forced here two ways -- an all-zero query (its sample carries
+    no level) and an ensemble of constant rows (every window ties: a block's list overflows) -- the raw call must SAY so
+    in every query's status word, and the same call with PSH_FLAG_NO_FUSE (+ the exhaustive path where that says OVERFLOW)
+    must return the oracle's answer."""
+    from shadowing_amd import _native
+    k, h = 100, 20
+    cases = []
+    ds = syn.dataset(8192, 2048, 6400 + B)
+    q = syn.gbm_log_returns((B, 20), 6410 + B)
+    q[B - 1] = 0.0
+    cases.append(("zero query", ds, q))
+    flat = np.full((2048, 1, 512), 0.01, np.float32)
+    cases.append(("constant rows", flat, syn.gbm_log_returns((B, 20), 6420 + B)))
+    for name, dsx, qx in cases:
+        ds_t = torch.as_tensor(np.ascontiguousarray(dsx[:, 0, :])).to(hip_device)
+        q_t = torch.as_tensor(qx).to(hip_device)
+        ws = _native.Workspace(hip_device)
+        info = {}
+        _, _, st = _native.scan_topk(ds_t, q_t, k, h=h, workspace=ws, info=info)
+        torch.cuda.synchronize()
+        assert info.get("path") == 3, f"{name}: a plain {B}-query call takes the overlap launches (path {info.get('path')})"
+        assert (st.cpu().numpy() == _native.PSH_STATUS_RETRY).all(), f"{name}: status {st.cpu().numpy()}"
+        d, idx = _native.scan_topk_checked(ds_t, q_t, k, h=h, workspace=ws)
+        torch.cuda.synchronize()
+        od, oidx = oracle_mod.scan_topk(dsx, qx, k, h=h)
+        assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, f"{B} queries, {name}, through the status protocol")
+
+
 def test_shadow_async_equals_shadow(hip_device, oracle_mod):
     """PathShadowing.shadow_async(): a dozen independent queries enqueued back to back (three private streams, overlap
     launches), collected afterwards: each triple equals the blocking shadow(cuda=True)'s -- distances, gathered paths,

@@ -290,3 +290,38 @@ def test_forward_topk_matches_reference_golden(name, oracle_mod):
     T2 = y.shape[1]
     for b in range(x.shape[0]):
         assert {(int(f) // T2, int(f) % T2) for f in oi[b, :, 0]} == {tuple(v) for v in z["idx"][b]}
+
+
+def test_moment_weights_keeps_the_averaging_class_authoritative():
+    """path_shadowing.moment_weights: weights are taken for the device reduction only when the class's OWN avg / std are
+    the weighted moments of the weights it exposes (checked on a probe); anything else reduces on the host itself."""
+    from shadowing_amd.path_shadowing import moment_weights
+    from shadowing_amd.averaging import Softmax, Uniform
+    d = np.random.default_rng(0).random((3, 50, 1)) + 0.3
+    w = moment_weights(Softmax(d, 0.2), 3, 50)
+    assert isinstance(w, np.ndarray) and w.shape == (3, 50) and w.dtype == np.float64 and np.allclose(w.sum(axis=1), 1.0)
+    assert moment_weights(Uniform(), 3, 50) is True
+    assert moment_weights(Softmax(d, 0.2), 3, 49) is None          # shape mismatch
+
+    class NoWeights:
+        def avg(self, x, axis=1):
+            return x.mean(axis=1)
+
+        def std(self, x, axis=1):
+            return x.std(axis=1)
+
+    assert moment_weights(NoWeights(), 3, 50) is None
+
+    class OtherStd(Softmax):                                     # exposes weights, reduces differently
+        def std(self, x, axis=0):
+            return np.abs(x).max(axis=axis)
+
+    assert moment_weights(OtherStd(d, 0.2), 3, 50) is None
+
+    class Unnormalised(Softmax):                                 # weights as given: nothing is renormalised
+        def __init__(self, dd):
+            super().__init__(dd, 0.2)
+            self.weights = self.weights * 3.0
+
+    w3 = moment_weights(Unnormalised(d), 3, 50)
+    assert isinstance(w3, np.ndarray) and np.allclose(w3.sum(axis=1), 3.0)

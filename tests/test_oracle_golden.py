@@ -6,11 +6,11 @@ order among exact ties, gathered paths identical."""
 import numpy as np
 import pytest
 
-from _util import (BATCHED_GOLDENS, BIG_GOLDENS, CROSS_GOLDENS, ONE_WINDOW_EMBEDDED_GOLDENS, EMBEDDED_GOLDENS, IMPUTATION_GOLDENS, SMALL_GOLDENS, assert_matches_reference, bits, canonical,
+from _util import (NAN_GOLDENS, BATCHED_GOLDENS, BIG_GOLDENS, CROSS_GOLDENS, ONE_WINDOW_EMBEDDED_GOLDENS, EMBEDDED_GOLDENS, IMPUTATION_GOLDENS, SMALL_GOLDENS, assert_matches_reference, bits, canonical,
                    load_golden, rows3)
 
 
-@pytest.mark.parametrize("name", SMALL_GOLDENS + BIG_GOLDENS + BATCHED_GOLDENS)
+@pytest.mark.parametrize("name", SMALL_GOLDENS + BIG_GOLDENS + BATCHED_GOLDENS + NAN_GOLDENS)
 def test_oracle_reproduces_reference(oracle_mod, name):
     g = load_golden(name)
     ds = rows3(g["dataset"])
@@ -203,3 +203,24 @@ def test_host_path_with_a_cross_channel_context_matches_reference(name):
     assert np.array_equal(bits(np.sort(d, 1)), bits(np.sort(g["d"], 1)))
     assert paths.shape == g["paths"].shape
     assert obj.context.select_out_context(paths).shape[-2] == int(g["out_context_channels"])
+
+
+def test_oracle_per_block_and_host_merge_reproduce_the_sharded_reference_golden(oracle_mod):
+    """tests/golden/cfg4_R262144.npz, N = 2 (the reference on 2 x 32768 rows = 2.7e8 windows): the oracle on each rank block
+    with its global row offset + bench.py's host merge -- exactly the distributed checker bench.py uses for N > 1 -- give
+    the reference's output.  (N = 4 and N = 8 are checked against the HIP path on the GPU box: tests/test_gpu_configs3.py.)"""
+    import bench
+    from _util import GOLDEN
+    from shadowing_amd import synthetic as syn
+    g = np.load(GOLDEN / "cfg4_R262144.npz")
+    RS, T, k, h = int(g["rows_per_rank"]), int(g["T"]), int(g["k"]), int(g["h"])
+    ds, ix = [], []
+    for r in range(2):
+        block = syn.dataset(RS, T, seed=r)
+        assert syn.sha256(block) == str(g["block_sha256"][r])
+        d, idx = oracle_mod.scan_topk(block, g["queries"], k, h=h, r_offset=r * RS)
+        ds.append(d)
+        ix.append(idx)
+    md, mi = bench.host_merge(np.concatenate(ds, axis=1), np.concatenate(ix, axis=1), k)
+    assert bench.same_result(md, mi, g["d_N2"], g["idx_N2"], tie_free_order=False)
+    assert mi[..., 0].max() >= RS                            # both blocks contribute
