@@ -357,20 +357,22 @@ int psh_gather_paths(int device, void* stream,
                      const int32_t* idx, int64_t n, int len, float* out);
 
 /*
- * NON-FINITE SAMPLES.  The scans above judge a window by its own K samples (a NaN inside it: distance NaN, never
- * returned while k clean windows exist).  The reference's embedding is a conv1d whose kernel is ZERO-PADDED by the
- * horizon (path_embedding.py:48-51), and 0 * NaN = 0 * inf = NaN: there a window is NaN as soon as one sample of
- * y[r, :, t : t+K+h] -- the window, its h future samples, any channel -- is NaN or +-inf.  A caller that wants exactly that
- * for an ensemble holding such samples scans rows in which every non-finite sample has been written back over the h
- * samples before it:
+ * NON-FINITE SAMPLES.  The scans above judge a window by its own samples -- psh_scan_topk by all W of them,
+ * psh_scan_topk_embedded by the taps [lo, hi) that the span of some kernel row covers (first to last tap with a non-zero
+ * entry in any row) -- a NaN among those: distance NaN, never returned while k clean windows exist.  The reference's
+ * embedding is a conv1d whose kernel is ZERO-PADDED by the horizon (path_embedding.py:48-51), and 0 * NaN = 0 * inf =
+ * NaN: there a window is NaN as soon as one sample of y[r, :, t : t+K+h] -- the window, its h future samples, any channel
+ * -- is NaN or +-inf.  A caller that wants exactly that for an ensemble holding such samples scans rows in which every
+ * non-finite sample has been written over the h + (K - hi) samples before it and the lo samples after it:
  *   psh_count_nonfinite  *out_count (device, 8 bytes) = number of NaN / +-inf among n floats: 0 (almost always) -> scan
  *                        the ensemble as it is;
  *   psh_smear_nonfinite  out[r, q] (device R x T) = NaN if any channel of dataset (device R x C x T) holds a non-finite sample in
- *                        [q, q + back], else dataset[r, 0, q]; pass `out` as the scan's dataset with back = h, gather
- *                        paths from the original.  shadowing_amd.PathShadowing does this once per resident ensemble.
+ *                        [q - fwd, q + back], else dataset[r, 0, q]; pass `out` as the scan's dataset with back = h + K - hi,
+ *                        fwd = lo, gather paths from the original.  shadowing_amd.PathShadowing does this once per
+ *                        resident ensemble.
  */
 int psh_count_nonfinite(int device, void* stream, const float* x, int64_t n, unsigned long long* out_count);
-int psh_smear_nonfinite(int device, void* stream, const float* dataset, int64_t R, int64_t C, int64_t T, int back, float* out);
+int psh_smear_nonfinite(int device, void* stream, const float* dataset, int64_t R, int64_t C, int64_t T, int back, int fwd, float* out);
 
 /*
  * The reductions of predict_from_paths() (path_shadowing.py:245-252: `proba.avg(values, axis=1)`,

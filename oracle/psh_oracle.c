@@ -296,64 +296,96 @@ int psh_oracle_scan_topk_embedded(const float* dataset, int64_t R, int64_t T, in
     if (R < 0 || T <= 0 || B < 0 || K <= 0 || d <= 0 || h < 0 || k <= 0) return -1;
     const int64_t Tp = T - K - h + 1;
     if (Tp <= 0) return -1;
+    if (B == 0) return 0;
 #ifdef _OPENMP
     if (nthreads <= 0) nthreads = omp_get_max_threads();
 #else
     nthreads = 1;
 #endif
-    /* the embedding of a window does not depend on the query: embed once per window,
-     * then one pass per query over the d coordinates */
-    for (int b = 0; b < B; ++b) {
-        const float* x = hx + (int64_t)b * d;
-        const float xn = hxnorm ? hxnorm[b] : psh_oracle_qnorm(x, d);
-        cand_t* all = (cand_t*)malloc(sizeof(cand_t) * (size_t)k * (size_t)nthreads);
-        int* counts = (int*)calloc((size_t)nthreads, sizeof(int));
-        if (!all || !counts) { free(all); free(counts); return -2; }
+    /* the embedding of a window does not depend on the query: ONE pass over the ensemble, every window embedded once
+     * (d fma chains over the K taps), then one chain over the d coordinates per query; a bounded heap per (thread, query) */
+    cand_t* all = (cand_t*)malloc(sizeof(cand_t) * (size_t)k * (size_t)nthreads * (size_t)B);
+    int* counts = (int*)calloc((size_t)nthreads * (size_t)B, sizeof(int));
+    float* xn = (float*)malloc(sizeof(float) * (size_t)B);
+    if (!all || !counts || !xn) { free(all); free(counts); free(xn); return -2; }
+    for (int b = 0; b < B; ++b) xn[b] = hxnorm ? hxnorm[b] : psh_oracle_qnorm(hx + (int64_t)b * d, d);
+    int oom = 0;
 #pragma omp parallel num_threads(nthreads)
-        {
+    {
 #ifdef _OPENMP
-            const int tid = omp_get_thread_num();
+        const int tid = omp_get_thread_num();
 #else
-            const int tid = 0;
+        const int tid = 0;
 #endif
-            heap_t hp; hp.v = all + (size_t)tid * k; hp.n = 0; hp.k = k;
-            int32_t* nf = (int32_t*)malloc(sizeof(int32_t) * (size_t)(T + 1));
+        heap_t* hp = (heap_t*)malloc(sizeof(heap_t) * (size_t)B);
+        float* e = (float*)malloc(sizeof(float) * (size_t)d);
+        int32_t* nf = (int32_t*)malloc(sizeof(int32_t) * (size_t)(T + 1));
+        if (!hp || !e || !nf) {
+#pragma omp atomic write
+            oom = 1;
+        }
+        if (hp) for (int b = 0; b < B; ++b) { hp[b].v = all + ((size_t)tid * B + b) * k; hp[b].n = 0; hp[b].k = k; }
 #pragma omp for schedule(dynamic, 4)
-            for (int64_t r = 0; r < R; ++r) {
-                const float* y = dataset + r * T;
-                const int dirty = nf && nonfinite_prefix(y, T, nf) != 0;
-                for (int64_t t = 0; t < Tp; ++t) {
+        for (int64_t r = 0; r < R; ++r) {
+            if (!hp || !e || !nf) continue;
+            const float* y = dataset + r * T;
+            const int dirty = nonfinite_prefix(y, T, nf) != 0;
+            for (int64_t t = 0; t < Tp; ++t) {
+                const float* yw = y + t;
+                for (int i = 0; i < d; ++i) {                 /* hy_i: fma chain over increasing j */
+                    const float* kr = ker + (int64_t)i * K;
+                    float ev = 0.0f;
+                    for (int j = 0; j < K; ++j) ev = fmaf(kr[j], yw[j], ev);
+                    e[i] = ev;
+                }
+                const int bad = dirty && nf[t + K + h] != nf[t];     /* the zero taps of the padded kernel see it too */
+                for (int b = 0; b < B; ++b) {
+                    const float* x = hx + (int64_t)b * d;
+                    float acc;
+                    if (Tp == 1) {                             /* one window per row: the 8-lane order over d */
+                        float D[4096];
+                        if (d > 4096) { acc = NAN; }
+                        else { for (int i = 0; i < d; ++i) D[i] = x[i] - e[i]; acc = psh_oracle_sumsq8(D, d); }
+                    } else {
+                        acc = 0.0f;
+                        for (int i = 0; i < d; ++i) { const float D = x[i] - e[i]; acc = fmaf(D, D, acc); }
+                    }
                     cand_t c;
-                    c.d = sqrtf(Tp == 1 ? embedded_acc_one_window(y, ker, d, K, x) : embedded_acc(y + t, ker, d, K, x)) / xn;
-                    if (dirty && nf[t + K + h] != nf[t]) c.d = NAN;    /* the zero taps of the padded kernel see it too */
+                    c.d = bad ? NAN : sqrtf(acc) / xn[b];
                     c.r = (int32_t)(r_offset + r);
                     c.t = (int32_t)t;
-                    if (hp.n < k) { if (c.d == c.d) heap_offer(&hp, c); }
-                    else if (cand_less(&c, &hp.v[0])) heap_offer(&hp, c);
+                    if (hp[b].n < k) { if (c.d == c.d) heap_offer(&hp[b], c); }
+                    else if (cand_less(&c, &hp[b].v[0])) heap_offer(&hp[b], c);
                 }
             }
-            counts[tid] = hp.n;
-            free(nf);
         }
+        if (hp) for (int b = 0; b < B; ++b) counts[(size_t)tid * B + b] = hp[b].n;
+        free(hp); free(e); free(nf);
+    }
+    if (oom) { free(all); free(counts); free(xn); return -2; }
+    cand_t* merged = (cand_t*)malloc(sizeof(cand_t) * (size_t)k * (size_t)nthreads);
+    if (!merged) { free(all); free(counts); free(xn); return -2; }
+    for (int b = 0; b < B; ++b) {
         int n = 0;
         for (int t = 0; t < nthreads; ++t) {
-            if (t * k != n) memmove(all + n, all + (size_t)t * k, sizeof(cand_t) * (size_t)counts[t]);
-            n += counts[t];
+            const int c = counts[(size_t)t * B + b];
+            memcpy(merged + n, all + ((size_t)t * B + b) * k, sizeof(cand_t) * (size_t)c);
+            n += c;
         }
-        qsort(all, (size_t)n, sizeof(cand_t), cand_cmp_qsort);
+        qsort(merged, (size_t)n, sizeof(cand_t), cand_cmp_qsort);
         for (int i = 0; i < k; ++i) {
             if (i < n) {
-                out_d[(int64_t)b * k + i] = all[i].d;
-                out_idx[((int64_t)b * k + i) * 2 + 0] = all[i].r;
-                out_idx[((int64_t)b * k + i) * 2 + 1] = all[i].t;
+                out_d[(int64_t)b * k + i] = merged[i].d;
+                out_idx[((int64_t)b * k + i) * 2 + 0] = merged[i].r;
+                out_idx[((int64_t)b * k + i) * 2 + 1] = merged[i].t;
             } else {
                 out_d[(int64_t)b * k + i] = INFINITY;
                 out_idx[((int64_t)b * k + i) * 2 + 0] = -1;
                 out_idx[((int64_t)b * k + i) * 2 + 1] = -1;
             }
         }
-        free(all); free(counts);
     }
+    free(merged); free(all); free(counts); free(xn);
     return 0;
 }
 

@@ -128,7 +128,7 @@ def load() -> C.CDLL:
     L.psh_count_nonfinite.restype = i32
     L.psh_count_nonfinite.argtypes = [i32, vp, vp, i64, vp]
     L.psh_smear_nonfinite.restype = i32
-    L.psh_smear_nonfinite.argtypes = [i32, vp, vp, i64, i64, i64, i32, vp]
+    L.psh_smear_nonfinite.argtypes = [i32, vp, vp, i64, i64, i64, i32, i32, vp]
     L.psh_weighted_moments.restype = i32
     L.psh_weighted_moments.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp, vp]
     L.psh_realized_variance.restype = i32
@@ -754,14 +754,15 @@ def count_nonfinite(x: torch.Tensor) -> int:
     return int(out.item())
 
 
-def smear_nonfinite(dataset: torch.Tensor, back: int) -> torch.Tensor:
+def smear_nonfinite(dataset: torch.Tensor, back: int, fwd: int = 0) -> torch.Tensor:
     """(R, T) rows for the scan of an (R, C, T) ensemble that holds non-finite samples: NaN wherever any channel has one
-    within the next `back` samples (the reference's zero-padded conv, see include/psh.h), channel 0 elsewhere."""
+    among the `fwd` samples before and the `back` samples after (the reference's zero-padded conv, see include/psh.h),
+    channel 0 elsewhere."""
     ds = _dev_tensor(dataset, torch.float32, "dataset")
     if ds.dim() != 3:
         raise ValueError("dataset must be (R, C, T)")
     R, Cc, T = ds.shape
     out = torch.empty((R, T), dtype=torch.float32, device=ds.device)
-    _check(load().psh_smear_nonfinite(ds.device.index, _stream_ptr(ds.device), ds.data_ptr(), R, Cc, T, int(back), out.data_ptr()),
+    _check(load().psh_smear_nonfinite(ds.device.index, _stream_ptr(ds.device), ds.data_ptr(), R, Cc, T, int(back), int(fwd), out.data_ptr()),
            "psh_smear_nonfinite")
     return out

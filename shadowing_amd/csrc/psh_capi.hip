@@ -211,10 +211,12 @@ struct Plan { int grid; int n_qgroups; int q_per_group; int tile_floats; int wid
 // Launch-geometry overrides and device-side time stamps for the scripts under tools/: compiled into the
 // tuning build only (-DPSH_TUNING, `python -m shadowing_amd._build --tuning`).  The product library reads no
 // environment variable and takes no pointer from anywhere but its arguments.
-struct Tuning { int wide_min; bool narrow; int bpc; int rows_frac; unsigned long long* dbg_times; unsigned long long* dbg_select; int xcd_skew; int stream_pgrid_per_cu; int stream_skip; int stream_units; int stream_rgrid_per_cu; };
+struct Tuning { int dbg; int px_r1; int wide_min; bool narrow; int bpc; int rows_frac; unsigned long long* dbg_times; unsigned long long* dbg_select; int xcd_skew; int stream_pgrid_per_cu; int stream_skip; int stream_units; int stream_rgrid_per_cu; };
 inline Tuning tuning() {
-    Tuning t{PSH_EMB_WIDE_MIN_B, false, 0, 64, nullptr, nullptr, PSH_FUSED_XCD_SKEW, 2, 0, 2048, 2};
+    Tuning t{0, 0, PSH_EMB_WIDE_MIN_B, false, 0, 64, nullptr, nullptr, PSH_FUSED_XCD_SKEW, 2, 0, 2048, 2};
 #ifdef PSH_TUNING
+    if (const char* e = getenv("PSH_DBG")) t.dbg = atoi(e);
+    if (const char* e = getenv("PSH_PX_R1")) { const int v = atoi(e); if (v >= 2) t.px_r1 = v; }   // prefix-sum scan: rows of the first phase (a large value: one phase)
     if (const char* e = getenv("PSH_EMBED_WIDE_MIN_B")) { const int v = atoi(e); if (v >= 1) t.wide_min = v; }
     t.narrow = getenv("PSH_EMBED_NARROW") != nullptr;
     if (const char* e = getenv("PSH_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) t.bpc = v; }
@@ -327,6 +329,8 @@ ScanArgs make_scan_args(const float* dataset, const float* queries, const Proble
     a.emb_dense = p.emb_dense ? 1 : 0;                  // PSH_FLAG_EMBED_DENSE: skip the suffix-rows fast path (A/B tests)
     a.emb_mx = p.emx ? (p.emx_split ? 3 : 1) : 0;
     a.emb_taps = p.emb_taps ? 1 : 0;
+    a.emb_r1 = tuning().px_r1;
+    a.dbg = tuning().dbg;
     a.plan = p.eplan;
     a.B = p.B;
     a.n_qgroups = plan.n_qgroups;
@@ -1098,12 +1102,12 @@ int psh_count_nonfinite(int device, void* stream, const float* x, int64_t n, uns
     return PSH_OK;
 }
 
-int psh_smear_nonfinite(int device, void* stream, const float* dataset, int64_t R, int64_t C, int64_t T, int back, float* out) {
-    if (!dataset || !out || R < 0 || C <= 0 || T <= 0 || back < 0) return PSH_ERR_ARG;
+int psh_smear_nonfinite(int device, void* stream, const float* dataset, int64_t R, int64_t C, int64_t T, int back, int fwd, float* out) {
+    if (!dataset || !out || R < 0 || C <= 0 || T <= 0 || back < 0 || fwd < 0) return PSH_ERR_ARG;
     if (R * T >= ((int64_t)1 << 31) * 256) return PSH_ERR_UNSUPPORTED;
     DeviceGuard g(device);
     if (!g.ok) { snprintf(g_hip_err, sizeof(g_hip_err), "hipSetDevice(%d) failed", device); return PSH_ERR_HIP; }
-    HIP_TRY(launch_smear_nonfinite(dataset, R, C, T, back, out, (hipStream_t)stream));
+    HIP_TRY(launch_smear_nonfinite(dataset, R, C, T, back, fwd, out, (hipStream_t)stream));
     return PSH_OK;
 }
 

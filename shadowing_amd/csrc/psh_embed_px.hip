@@ -8,9 +8,10 @@
 // and the cheap embedding costs ONE LDS read and three packed-able operations per row, window and query
 //     S = Pk - E[t + a_i];  e = hx_i - c_i S;  acc^ += e^2
 // instead of one packed add per TAP and window (115 taps against 34 rows -- 27 distinct -- for Foveal(1.15, 0.9, 126)).
-//   * E is summed in DOUBLE by a scan over the staged registers (4 samples per lane serially, the lane totals through six
-//     DPP steps, the five 256-sample blocks chained through a scalar) -- exact to ~2^-42 ymax -- and rounded ONCE to fp32:
-//     an entry is off by at most u |E|, so  |S^_i - S_i| <= 2 u Pmax + u n_i ymax (+ 2^-31 ymax),  Pmax = max |E|.
+//   * E is a scan over the staged registers in fp32 (4 samples per lane serially, the lane totals through six DPP steps, the
+//     five 256-sample blocks chained through a scalar double): an entry is off by at most 16 u A, A = the segment's sum
+//     of |y| (prefix_store), so  |S^_i - S_i| <= 32 u A.  (Round 2 summed in double and rounded once -- 2 u max|E| --
+//     for 260 of the kernel's 1220 vector instructions per segment; the radius below is 0.5 % of sqrt(tau) either way.)
 //   * IDENTICAL rows (same a_i, same c_i: Foveal's short scales repeat) are merged, up to 4 to a group:
 //     sum_j (hx_j - c S)^2 = m (mean hx - c S)^2 + V  -- one row with c' = sqrt(m) c and h' = sqrt(m) mean hx; V >= 0 is
 //     dropped by the rejection test (conservative) and added back by the bootstrap's upper bounds.
@@ -18,11 +19,11 @@
 //     holds two windows 64 apart (ds_read2st64_b32), ready for v_pk_add_f32 / v_pk_fma_f32.
 // Bound-then-verify like the tap walk (psh_embed.hip): with the exact chain's own n_i^2 u |c_i| ymax, the rounding of c'
 // and h' (<= 2 u n_i |c_i| ymax, 6 u ||hx||) the cheap embedding lies within
-//     Rad = ymax * u sqrt(sum_i (c_i (n_i + 2)^2)^2) + Pmax * 2 u ||c||_2 + 6 u ||hx||_2          (each with a 5 % margin)
+//     Rad = ymax * u sqrt(sum_i (c_i (n_i + 2)^2)^2) + A * 32 u ||c||_2 + 6 u ||hx||_2            (each with a 5 % margin)
 // of the exact one; a window survives unless  acc^ > (sqrt(tau)(1 + 2^-15) + Rad)^2 (1 + 2^-14);  survivors get the exact
 // dense chain in the oracle's order (oracle/psh_oracle.c: embedded_acc) -- their rows spread evenly over the lanes by the plan,
 // their samples re-read from global memory (the tile holds E) --, and only exact values are ever ranked: results are bit-identical to the tap walk's and the dense chains'.
-// Non-finite data: an infinite Pmax / ymax makes the threshold infinite, a NaN in E fails every '>' -- either way the
+// Non-finite data: an infinite A / ymax makes the threshold infinite, a NaN in E fails every '>' -- either way the
 // windows are verified exactly.
 //
 // The structure is recognised ON THE DEVICE (embed_plan_kernel, one small launch per call: the library cannot look at the
@@ -46,6 +47,8 @@ __global__ __launch_bounds__(PSH_PLAN_THREADS) void embed_plan_kernel(const floa
     __shared__ int4 s_row[PSH_EMB_MAX_D];                    // {first tap, row, c bits, taps}
     __shared__ int4 s_prog[PSH_EMB_MAX_D];                   // the same, longest support last
     __shared__ int s_rep[PSH_EMB_MAX_D];                     // rank among the identical rows before it
+    __shared__ int4 s_grp[PSH_EMB_MAX_D];                    // merged rows in the order they were found
+    __shared__ float s_gw[PSH_EMB_MAX_D], s_gws[PSH_EMB_MAX_D];   // their weights; the weights in ranked order
     __shared__ float s_e2[PSH_EMB_MAX_D], s_c2[PSH_EMB_MAX_D];
     const int tid = (int)threadIdx.x;
     if (d > PSH_EMB_MAX_D || K > 256) { if (tid == 0) { plan->contig = 0; plan->ngroups = 0; } return; }
@@ -148,8 +151,38 @@ __global__ __launch_bounds__(PSH_PLAN_THREADS) void embed_plan_kernel(const floa
             if (o.z == me.z && 4 * (o.w > 0 ? o.x : topU) == off && s_rep[j] > rep && s_rep[j] < rep + 4) { members |= o.y << (8 * (s_rep[j] - rep)); ++cnt; }
         }
         const float rm = cnt == 1 ? 1.0f : (cnt == 2 ? 1.41421356f : (cnt == 3 ? 1.7320508f : 2.0f));
-        plan->gtab[g] = make_int4((int)__float_as_uint(__fmul_rn(__uint_as_float((unsigned)me.z), rm)), off, members, cnt);
+        const float cm = __fmul_rn(__uint_as_float((unsigned)me.z), rm);
+        s_grp[g] = make_int4((int)__float_as_uint(cm), off, members, cnt);
+        // what the group adds to the squared distance of an unrelated window, up to the data's variance: c'^2 x taps
+        s_gw[g] = (me.w > 0 && fabsf(cm) < 1.0e18f) ? cm * cm * (float)me.w : 0.0f;
         atomicAdd(&s_ngroups, 1);
+    }
+    __syncthreads();
+    // The scan walks the merged rows HEAVIEST FIRST and stops early for windows whose partial sum of squares is already
+    // above the threshold (embed_px_kernel): rank by weight, ties by position; r1 = the rows of the first phase -- the
+    // smallest even count that carries 85 % of the total weight (kernels with fewer than 8 merged rows: no early exit).
+    if (tid < s_ngroups) {
+        const float w = s_gw[tid];
+        int rk = 0;
+        for (int j = 0; j < s_ngroups; ++j) { const float wj = s_gw[j]; rk += (wj > w || (wj == w && j < tid)) ? 1 : 0; }
+        plan->gtab[rk] = s_grp[tid];
+        s_gws[rk] = w;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int G = s_ngroups;
+        float tot = 0.0f;
+        for (int j = 0; j < G; ++j) tot += s_gws[j];
+        int r1 = G;
+        if (G >= 8 && tot > 0.0f) {
+            float cum = 0.0f;
+            for (int j = 0; j < G; ++j) {
+                cum += s_gws[j];
+                if (cum >= 0.85f * tot && ((j + 1) & 1) == 0) { r1 = j + 1; break; }
+            }
+            if (r1 > G - 4) r1 = G;                          // nothing worth a second phase
+        }
+        plan->r1 = r1;
     }
     // the verification's schedule: rows longest first, each onto the lane slot with the fewest taps so far (wave 0 -- one
     // DPP minimum per row --, the rest across the threads)
@@ -226,58 +259,64 @@ hipError_t launch_embed_plan(const float* ker, int d, int K, EmbedPlan* plan, hi
     return hipGetLastError();
 }
 
-// inc += (inc of the lane CTRL names, 0.0 where there is none): one step of the wave scan, on the DPP path of the VALU
+// inc += (inc of the lane CTRL names, 0 where there is none): one step of the wave scan, a v_add_f32 with a DPP operand
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_add(double inc) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(inc), CTRL, ROW_MASK, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(inc), CTRL, ROW_MASK, 0xf, true);
-    return inc + __hiloint2double(hi, lo);
+__device__ __forceinline__ float dpp_add(float inc) {
+    return inc + __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(inc), CTRL, ROW_MASK, 0xf, true));
 }
 
-// Exclusive prefix sums of the staged segment (element 4 (lane + 64 q) + r of Stage) -> dst[0 .. 4 nq]; returns max |E|.
+// Exclusive prefix sums of the staged segment (element 4 (lane + 64 q) + r of Stage) -> dst[0 .. 4 nq]; returns the sum of
+// |y| over the staged samples (what bounds the rounding of the sums, below).
+// fp32 all the way, except the carry from one 256-sample block to the next (a double: two scalar-rate instructions a block):
+// 3 adds inside a lane, six DPP adds across the wave, one subtraction and two adds to place an entry -- every E^[m] is a
+// sum of the y_j, j < m, in SOME order with at most PSH_PX_SCAN_OPS roundings on a term's way, so
+//     |E^[m] - E[m]| <= PSH_PX_SCAN_OPS u sum_j |y_j|        (u = 2^-24; Higham's bound for any summation order)
+// -- 400x the error of sums taken in double and rounded once, and still ~0.5 % of the radius sqrt(tau) the rejection
+// test works with at the benchmark sizes; the double-precision scan it replaces was 260 of the kernel's 1220 vector
+// instructions per segment, this one is 70.
+#define PSH_PX_SCAN_OPS 16
 __device__ __forceinline__ float prefix_store(const Stage& st, float* dst, int nfloat, int lane) {
     const int nq = (nfloat + 3) >> 2;
     double carry = 0.0;
-    float pmax = 0.0f;
+    float ab = 0.0f;
 #pragma unroll
     for (int q = 0; q < PSH_NSTAGE; ++q) {
         const int m = lane + 64 * q;
         const bool on = q < PSH_NSTAGE - 1 || m < nq;      // (group nq, all zeros, carries E[nfloat] when nfloat % 4 == 0)
-        const double d0 = on ? (double)st.v[q][0] : 0.0;
-        const double d1 = d0 + (on ? (double)st.v[q][1] : 0.0);
-        const double d2 = d1 + (on ? (double)st.v[q][2] : 0.0);
-        const double d3 = d2 + (on ? (double)st.v[q][3] : 0.0);
+        const float v0 = on ? st.v[q][0] : 0.0f, v1 = on ? st.v[q][1] : 0.0f, v2 = on ? st.v[q][2] : 0.0f, v3 = on ? st.v[q][3] : 0.0f;
+        ab += (fabsf(v0) + fabsf(v1)) + (fabsf(v2) + fabsf(v3));
+        const float d0 = v0, d1 = d0 + v1, d2 = d1 + v2, d3 = d2 + v3;
         // inclusive scan of the lane totals: within the rows of 16 lanes (row_shr 1, 2, 4, 8), then across them
         // (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3)
-        double inc = d3;
+        float inc = d3;
         inc = dpp_add<0x111, 0xf>(inc);
         inc = dpp_add<0x112, 0xf>(inc);
         inc = dpp_add<0x114, 0xf>(inc);
         inc = dpp_add<0x118, 0xf>(inc);
         inc = dpp_add<0x142, 0xa>(inc);
         inc = dpp_add<0x143, 0xc>(inc);
-        const double x = carry + (inc - d3);                 // (the lane's own total taken off again: ~2^-53 of |inc|)
-        const f32x4 E = f32x4{(float)x, (float)(x + d0), (float)(x + d1), (float)(x + d2)};
-        carry += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(inc), 63), __builtin_amdgcn_readlane(__double2loint(inc), 63));
-        if (on || m == nq) {
-            *reinterpret_cast<f32x4*>(dst + 4 * m) = E;
-            pmax = fmaxf(pmax, fmaxf(fmaxf(fabsf(E[0]), fabsf(E[1])), fmaxf(fabsf(E[2]), fabsf(E[3]))));
-        }
+        const float x = (float)carry + (inc - d3);          // exclusive: the lane's own total taken off again
+        const f32x4 E = f32x4{x, x + d0, x + d1, x + d2};
+        carry += (double)__uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(inc), 63));
+        if (on || m == nq) *reinterpret_cast<f32x4*>(dst + 4 * m) = E;
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, off, 64));
-    return pmax;
+    for (int off = 32; off > 0; off >>= 1) ab += __shfl_xor(ab, off, 64);
+    return ab * 1.0001f;                                     // (its own fp32 rounding: ~30 u)
 }
 
 #define PSH_PX_DLCAP 320          // row differences per wave: (survivors per verification pass) x d floats
+#define PSH_PX_ALIVE 64           // live windows per wave, segment and query that the sparse second phase of the row loop takes
 __host__ __device__ inline size_t px_shmem_bytes(int tile_floats, int B, int d, int threads) {
     const int nw = threads / 64;
+    const int nbg = threads == 512 ? 6 : 2;                                         // (PSH_PX_WIDE_NBG / PSH_PX_NBG)
     return (size_t)tile_floats * nw * sizeof(float)                                  // wave-private tiles (E)
            + (size_t)(((B + 3) & ~3) + 4) * sizeof(int)                             // per-query append cursors + work cursor
            + (size_t)nw * PSH_PEND * 16                                             // wave-private pending admissions
            + (((size_t)d * 8 + 15) & ~(size_t)15) + 272                             // verification schedule: rows, slot starts
            + (size_t)(d + 1) * 16 + (size_t)(d + 4) * 16                            // merged rows, their {c', c', offset}
-           + (size_t)nw * (64 + PSH_PX_DLCAP) * 4;                                  // verification scratch: survivor list, row differences
+           + (size_t)nw * (64 + PSH_PX_DLCAP) * 4                                   // verification scratch: survivor list, row differences
+           + (size_t)nw * (2 * PSH_PX_ALIVE + nbg * 64) * 4;                        // second phase: live windows, coordinates by row
 }
 
 // THREADS / NBG: 1024 threads (4 waves per SIMD, 128 VGPRs) with 2 queries per pass over the rows, or -- batches of 7 and
@@ -302,10 +341,16 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
     int4* rtab = gtab + d + 1;                                               // ngroups (+3) x {c' bits twice, byte offset of E[a_i], -}
     int* sl = reinterpret_cast<int*>(rtab + d + 4) + (size_t)wave_in_block * (64 + PSH_PX_DLCAP);   // wave-private: 64 survivors,
     float* Dl = reinterpret_cast<float*>(sl + 64);                                   //   PSH_PX_DLCAP row differences
+    // wave-private, second phase of the row loop: live windows (index, partial sum), the query group's coordinates by merged row
+    int* alp = reinterpret_cast<int*>(rtab + d + 4) + (size_t)NW * (64 + PSH_PX_DLCAP) + (size_t)wave_in_block * (2 * PSH_PX_ALIVE + NBG * 64);
+    float* ala = reinterpret_cast<float*>(alp + PSH_PX_ALIVE);
+    float* hq = ala + PSH_PX_ALIVE;
     int npend = 0;
 
     const int ktop = __builtin_amdgcn_readfirstlane(plan->ktop);
     const int ngroups = __builtin_amdgcn_readfirstlane(plan->ngroups);
+    int r1_plan = __builtin_amdgcn_readfirstlane(a.emb_r1 > 0 ? a.emb_r1 : plan->r1);
+    if (r1_plan < 2 || (r1_plan & 1) || r1_plan > ngroups) r1_plan = ngroups;          // (phases are whole pairs of rows)
     const float cerr_y = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(plan->cerr_y)));
     const float cerr_p = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(plan->cerr_p)));
     if (threadIdx.x == 0) *next_unit = 0;
@@ -355,7 +400,7 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
             pend_flush(pend, npend, lcount, a, lane);
             npend = 0;
         }
-        float ymax = 0.0f, pmax;
+        float ymax = 0.0f, asum;
         {
             Stage st;
             stage_load<ALIGNED>(st, a.dataset + row * a.T, a.T, seg_start, nfloat, lane);
@@ -366,12 +411,14 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
                                              fmaxf(fabsf(st.v[q][2]), fabsf(st.v[q][3]))));
                 }
             }
-            pmax = prefix_store(st, tile, nfloat, lane);     // the tile holds E, not y
+            asum = prefix_store(st, tile, nfloat, lane);     // the tile holds E, not y
         }
         wave_lds_fence();
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, off, 64));
-        const float err = __builtin_fmaf(ymax, cerr_y, pmax * cerr_p);
+        // radius of the cheap embedding around the exact one: the exact chain's own rounding (ymax), the prefix sums'
+        // (two entries per running sum, each within PSH_PX_SCAN_OPS u asum; cerr_p = 2 u ||c||_2 with its margin)
+        const float err = __builtin_fmaf(ymax, cerr_y, asum * ((float)PSH_PX_SCAN_OPS * cerr_p));
 
         const int r_global = (int)(row + a.r_offset);
         const int q_begin = (int)qgi * a.q_per_group;
@@ -544,11 +591,13 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
                         const float rsm = ge.w == 1 ? 1.0f : (ge.w == 2 ? 0.70710678f : (ge.w == 3 ? 0.57735027f : 0.5f));
                         hgt[g] = (int)__float_as_uint(sum * rsm);
                     }
+                    hq[g * 64 + lane] = __uint_as_float((unsigned)hgt[g]);   // the same coordinates by row, for the sparse second phase
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) { vs += __shfl_xor(vs, off, 64); sq += __shfl_xor(sq, off, 64); }
                     Vq[g] = vs * (1.0f + 1.0f / 256.0f);
                     hnq[g] = 6.0f * 5.9604645e-8f * 1.001f * __builtin_sqrtf(sq);
                 }
+                wave_lds_fence();
             }
             f32x2 acc[NBG][8];
 #pragma unroll
@@ -560,7 +609,7 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
             // coordinate out of the lane that holds it
             const char* tile_b = reinterpret_cast<const char*>(tile + lane);
             // (NQ, the queries of this pass, is a compile-time constant of the loop: no branch inside a row)
-            auto rows = [&](auto nq_c) {
+            auto rows = [&](auto nq_c, int r_from, int r_to) {
                 constexpr int NQ = decltype(nq_c)::value;
                 auto row_step = [&](const int4& o, int i) {
                     const f32x2 c2 = f32x2{__uint_as_float((unsigned)o.x), __uint_as_float((unsigned)o.y)};
@@ -584,31 +633,132 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
                 // Two rows a turn, ALWAYS: an odd row count ends on a blank entry (c' = 0, lane `ngroups` holds h' = 0: e = 0,
                 // nothing is added; rtab has ngroups + 3 entries).  A separate copy of the row body for the odd row made the
                 // compiler spill 15 registers around it.
-                int4 oa = rtab[0];
+                int4 oa = rtab[r_from];                       // (r_from is even: the rows of a phase come in pairs)
 #pragma unroll 1
-                for (int i = 0; i < ngroups; i += 2) {
+                for (int i = r_from; i < r_to; i += 2) {
                     const int4 ob = rtab[i + 1];
                     row_step(oa, i);
                     oa = rtab[i + 2];                        // (up to entry ngroups + 2: blank)
                     row_step(ob, i + 1);
                 }
             };
-            if constexpr (NBG == 2) {
-                if (nq == 2) rows(std::integral_constant<int, 2>{}); else rows(std::integral_constant<int, 1>{});
-            } else {
-                switch (nq) {
-                    case 1: rows(std::integral_constant<int, 1>{}); break;
-                    case 2: rows(std::integral_constant<int, 2>{}); break;
-                    case 3: rows(std::integral_constant<int, 3>{}); break;
-                    case 4: rows(std::integral_constant<int, 4>{}); break;
-                    case 5: rows(std::integral_constant<int, 5>{}); break;
-                    default: rows(std::integral_constant<int, NBG>{}); break;
+            auto run_rows = [&](int r_from, int r_to) {
+                if constexpr (NBG == 2) {
+                    if (nq == 2) rows(std::integral_constant<int, 2>{}, r_from, r_to); else rows(std::integral_constant<int, 1>{}, r_from, r_to);
+                } else {
+                    switch (nq) {
+                        case 1: rows(std::integral_constant<int, 1>{}, r_from, r_to); break;
+                        case 2: rows(std::integral_constant<int, 2>{}, r_from, r_to); break;
+                        case 3: rows(std::integral_constant<int, 3>{}, r_from, r_to); break;
+                        case 4: rows(std::integral_constant<int, 4>{}, r_from, r_to); break;
+                        case 5: rows(std::integral_constant<int, 5>{}, r_from, r_to); break;
+                        default: rows(std::integral_constant<int, NBG>{}, r_from, r_to); break;
+                    }
                 }
+            };
+            // FILTER: the merged rows come heaviest first (the plan), and a partial sum of squares only grows -- after the
+            // first r1 rows most windows are above the threshold already and need none of the others.  The few that are
+            // not (a handful per segment) finish their rows as (window, row) pairs across the lanes; a segment with more of
+            // them than the list holds (nothing may be rejected: non-finite data; or a threshold that rejects little)
+            // runs the remaining rows for everybody, as before.
+            const int r1 = MODE == PSH_MODE_FILTER ? r1_plan : ngroups;
+            run_rows(0, r1);
+            // windows of the lane at or below `thr` (or NaN) as a bit mask.  The common case -- none of the 16 -- costs a
+            // minimum and two comparisons, not 16 (fminf drops a NaN; the sum of the non-negative values keeps it).
+            auto below = [&](int g, float thr) -> unsigned {
+                float mn = acc[g][0][0];
+                f32x2 sm2 = acc[g][0];
+#pragma unroll
+                for (int w = 1; w < PSH_L; ++w) mn = fminf(mn, acc[g][w >> 1][w & 1]);
+#pragma unroll
+                for (int w = 1; w < 8; ++w) sm2 += acc[g][w];
+                const float sm1 = sm2[0] + sm2[1];
+                unsigned hm = 0u;
+                if (__any(!(mn > thr) || !(sm1 == sm1))) {
+#pragma unroll
+                    for (int w = 0; w < PSH_L; ++w) hm |= !(acc[g][w >> 1][w & 1] > thr) ? (1u << w) : 0u;
+                    hm &= vmask;
+                }
+                return hm;
+            };
+            // survivors go to the wave's list; the whole wave verifies them together (verify_list)
+            auto list_survivor = [&](bool has, int pwin, int b) {
+                const unsigned long long sm = __ballot(has);
+                if (!sm) return;
+                const int ne = __popcll(sm);
+                if (ns + ne > 64) { verify_list(false); ns = 0; }
+                if (has) sl[ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u))] = pwin | (b << 12);
+                ns += ne;
+            };
+            unsigned done = 0u;                              // queries of the pass finished by the sparse second phase
+            bool dense = false;
+            if (MODE == PSH_MODE_FILTER && r1 < ngroups) {
+#pragma unroll
+                for (int g = 0; g < NBG; ++g) {
+                    if (g >= nq || dense) continue;
+                    const int b = b0 + g;
+                    const float tau = __uint_as_float(qstate_k[b].tau2_bits);
+                    const float st = __builtin_sqrtf(tau) * (1.0f + 1.0f / 32768.0f) + (err + hnq[g]);
+                    const float thr = st * st * (1.0f + 1.0f / 16384.0f);
+                    unsigned hm = below(g, thr);
+                    // the lane's live windows (index, partial sum) into the wave's list
+                    int nal = 0;
+                    while (__any(hm != 0u)) {
+                        const bool has = hm != 0u;
+                        const int w = has ? (int)__builtin_ctz(hm) : 0;
+                        hm &= hm - 1u;
+                        const unsigned long long sm = __ballot(has);
+                        const int ne = __popcll(sm);
+                        if (nal + ne > PSH_PX_ALIVE) { dense = true; break; }
+                        if (has) {
+                            const int slot = nal + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u));
+                            float pv = 0.0f;
+#pragma unroll
+                            for (int w2 = 0; w2 < PSH_L; ++w2) pv = (w2 == w) ? acc[g][w2 >> 1][w2 & 1] : pv;
+                            alp[slot] = lane + 64 * w;
+                            ala[slot] = pv;
+                        }
+                        nal += ne;
+                    }
+                    if (dense) continue;
+                    done |= 1u << g;
+                    if (nal == 0) continue;
+                    wave_lds_fence();
+                    // second phase: four live windows a turn, 16 lanes each; lane `sub` of a window takes the merged rows
+                    // r1 + sub, r1 + sub + 16, ..; the 16 partial sums meet through four DPP rotations of the row
+                    const int sub = lane & 15, grp = lane >> 4;
+                    const float* hqg = hq + g * 64;
+#pragma unroll 1
+                    for (int e0 = 0; e0 < nal; e0 += 4) {
+                        const bool lv = e0 + grp < nal;
+                        const int pw = lv ? alp[e0 + grp] : 0;
+                        const float Ek = tile[pw + ktop];
+                        const char* tp = reinterpret_cast<const char*>(tile + pw);
+                        float s2 = 0.0f;
+#pragma unroll 1
+                        for (int r = r1; r < ngroups; r += 16) {
+                            const int rr = (r + sub) < ngroups ? (r + sub) : ngroups;   // (entry ngroups: blank, c' = 0, offset 0)
+                            const int4 o = rtab[rr];
+                            const float hv = (r + sub) < ngroups ? hqg[rr] : 0.0f;
+                            const float S = *reinterpret_cast<const float*>(tp + o.z) - Ek;
+                            const float e = __builtin_fmaf(__uint_as_float((unsigned)o.x), S, hv);
+                            s2 = __builtin_fmaf(e, e, s2);
+                        }
+                        s2 += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(s2), 0x128, 0xf, 0xf, false));   // row_ror:8
+                        s2 += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(s2), 0x124, 0xf, 0xf, false));   // row_ror:4
+                        s2 += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(s2), 0x122, 0xf, 0xf, false));   // row_ror:2
+                        s2 += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(s2), 0x121, 0xf, 0xf, false));   // row_ror:1
+                        const float tot = (lv ? ala[e0 + grp] : 0.0f) + s2;
+                        list_survivor(lv && sub == 0 && !(tot > thr), pw, b);
+                    }
+                    wave_lds_fence();                        // the list is refilled for the next query
+                }
+                if (dense) run_rows(r1, ngroups);
             }
 #pragma unroll
             for (int g = 0; g < NBG; ++g) {
                 const int b = b0 + g;
-                if (g >= nq) continue;
+                if (g >= nq || ((done >> g) & 1u)) continue;
                 const float errq = err + hnq[g];
                 if (MODE == PSH_MODE_BOOT) {
                     // upper bound of the exact acc of the lane's (wave's) best window
@@ -630,33 +780,12 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
                     const float tau = __uint_as_float(qstate_k[b].tau2_bits);
                     const float st = __builtin_sqrtf(tau) * (1.0f + 1.0f / 32768.0f) + errq;
                     const float thr = st * st * (1.0f + 1.0f / 16384.0f);
-                    // the common case -- nothing of the lane's 16 windows at or below the threshold (or NaN) -- costs a
-                    // minimum and two comparisons, not 16
-                    // (fminf drops a NaN; the sum of the non-negative values keeps it)
-                    float mn = acc[g][0][0];
-                    f32x2 sm2 = acc[g][0];
-#pragma unroll
-                    for (int w = 1; w < PSH_L; ++w) mn = fminf(mn, acc[g][w >> 1][w & 1]);
-#pragma unroll
-                    for (int w = 1; w < 8; ++w) sm2 += acc[g][w];
-                    const float sm1 = sm2[0] + sm2[1];
-                    unsigned hm = 0u;
-                    if (__any(!(mn > thr) || !(sm1 == sm1))) {
-#pragma unroll
-                        for (int w = 0; w < PSH_L; ++w) hm |= !(acc[g][w >> 1][w & 1] > thr) ? (1u << w) : 0u;
-                        hm &= vmask;
-                    }
-                    // survivors go to the wave's list; the whole wave verifies them together (verify_list)
+                    unsigned hm = below(g, thr);
                     while (__any(hm != 0u)) {
                         const bool has = hm != 0u;
                         const int w = has ? (int)__builtin_ctz(hm) : 0;
                         hm &= hm - 1u;
-                        const unsigned long long sm = __ballot(has);
-                        const int ne = __popcll(sm);
-                        if (ns + ne > 64) { verify_list(false); ns = 0; }
-                        if (has) sl[ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u))] =
-                            (lane + 64 * w) | (b << 12);
-                        ns += ne;
+                        list_survivor(has, lane + 64 * w, b);
                     }
                 }
             }

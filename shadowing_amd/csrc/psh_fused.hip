@@ -408,7 +408,14 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_fused_kernel(ScanArgs a
             }
         }
         wave_lds_fence();
+#ifdef PSH_TUNING
+        // PSH_DBG bit 4: the launch's SKELETON -- sample, both barriers, level, ranking, and ONE unit per wave (the one
+        // requested before the level is known) instead of the block's share of the ensemble (tools/fused_skeleton.py;
+        // results are invalid: the ranking sees too few candidates and says RETRY)
+        const unsigned un = (a.dbg & 16) ? u_hi : grab();
+#else
         const unsigned un = grab();
+#endif
         if (un < u_hi) load_unit(st, un);
 
         const int m = lane & 31, hk = lane >> 5;

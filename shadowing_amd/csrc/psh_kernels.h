@@ -145,6 +145,8 @@ struct ScanArgs {
     int emb_dense;           // embedded scan: always the dense chains, even when the kernel has suffix rows (tests, PSH_EMBED=dense)
     int emb_taps;            // embedded scan, suffix rows: walk the taps even when the support is one interval (PSH_FLAG_EMBED_TAPS)
     int emb_mx;              // embedded scan: the dense kernel's rejection test on the matrix cores (embed_mx_kernel: BOOT / FILTER)
+    int dbg;                 // tuning build only (PSH_DBG): timing ablations / scheduling experiments of the kernel at hand
+    int emb_r1;              // prefix-sum scan: merged rows of the first phase, 0 = the plan's (tuning build: PSH_PX_R1)
     const struct EmbedPlan* plan;   // embedded scan, BOOT / FILTER: what embed_plan_kernel found in the matrix (nullable: dense chains / tap walk decided in the kernel)
 };
 
@@ -155,7 +157,8 @@ struct ScanArgs {
 struct EmbedPlan {
     int contig, ktop, ngroups, d;
     float cerr_y, cerr_p;
-    int pad[2];
+    int r1;                          // merged rows of the scan's first phase (gtab is ordered heaviest first); == ngroups: one phase
+    int pad[1];
     int4 gtab[PSH_EMB_MAX_D + 1];    // merged rows: {c' bits, byte offset of E[a_i], member rows (a byte each), members}
     // the exact verification's schedule: the rows of a survivor spread over `vnl` lanes so that the lanes' tap counts are
     // even (longest row first onto the least loaded lane); lane slot s runs vrow[vstart[s] .. vstart[s + 1])
@@ -312,7 +315,7 @@ struct RvArgs {
 };
 // psh_prep.hip: non-finite samples the way the reference's zero-padded conv treats them
 hipError_t launch_count_nonfinite(const float* x, int64_t n, unsigned long long* out, hipStream_t s);
-hipError_t launch_smear_nonfinite(const float* ds, int64_t R, int64_t C, int64_t T, int back, float* out, hipStream_t s);
+hipError_t launch_smear_nonfinite(const float* ds, int64_t R, int64_t C, int64_t T, int back, int fwd, float* out, hipStream_t s);
 hipError_t launch_moments(const MomentsArgs& a, hipStream_t s);
 hipError_t launch_realized_variance(const RvArgs& a, hipStream_t s);
 

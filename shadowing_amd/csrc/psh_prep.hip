@@ -4,9 +4,10 @@
 // 0 * NaN = 0 * inf = NaN: every embedded coordinate of window t is NaN as soon as ONE sample of the conv's field
 // y[r, :, t : t+K+h] -- the window, its h future samples, any channel -- is NaN or +-inf (probed on the reference:
 // tests/golden/nan_in_ensemble_*.npz); torch.topk(largest=False) then ranks the window last (path_shadowing.py:165).
-// The scans of this library judge a window by its own K samples.  Both agree on an ensemble in which a non-finite
-// sample at p has been written back over [p-h, p] as NaN: window [t, t+K) then holds a NaN iff the field [t, t+K+h)
-// held a non-finite sample.  psh_count_nonfinite says whether an ensemble needs that (almost none does: one pass, once
+// The scans of this library judge a window by the taps [lo, hi) of its K samples that some kernel row's span covers
+// (Identity: all of them; Foveal(.., 126) with its longest row of 115 samples: the last 115).  Both agree on an ensemble in
+// which a non-finite sample at p has been written over [p - h - (K - hi), p + lo] as NaN: the covered taps of window t
+// then hold a NaN iff the field [t, t+K+h) held a non-finite sample.  psh_count_nonfinite says whether an ensemble needs that (almost none does: one pass, once
 // per resident ensemble), psh_smear_nonfinite builds the (R, T) rows the scan reads; paths are gathered from the
 // original.
 #include <hip/hip_runtime.h>
@@ -48,28 +49,29 @@ hipError_t launch_count_nonfinite(const float* x, int64_t n, unsigned long long*
     return hipGetLastError();
 }
 
-// out[r, q] = NaN if any channel holds a non-finite sample in [q, q + back] (clipped to the row), else dataset[r, 0, q].
-// A thread per output sample; the look-ahead stops at the first hit.  Only run for an ensemble that holds non-finite
+// out[r, q] = NaN if any channel holds a non-finite sample in [q - fwd, q + back] (clipped to the row), else dataset[r, 0, q].
+// A thread per output sample; the look-around stops at the first hit.  Only run for an ensemble that holds non-finite
 // samples at all (psh_count_nonfinite), once per resident copy.
 __global__ __launch_bounds__(256) void smear_nonfinite_kernel(const float* __restrict__ ds, int64_t R, int64_t C, int64_t T,
-                                                              int back, float* __restrict__ out) {
+                                                              int back, int fwd, float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R * T) return;
     const int64_t r = i / T, q = i - r * T;
+    const int64_t lo = (q - fwd > 0) ? q - fwd : 0;
     const int64_t hi = (q + back < T - 1) ? q + back : T - 1;
     bool bad = false;
     for (int64_t c = 0; c < C && !bad; ++c) {
         const float* row = ds + (r * C + c) * T;
-        for (int64_t p = q; p <= hi; ++p)
+        for (int64_t p = lo; p <= hi; ++p)
             if (nonfinite(row[p])) { bad = true; break; }
     }
     out[i] = bad ? __uint_as_float(0x7fc00000u) : ds[r * C * T + q];
 }
 
-hipError_t launch_smear_nonfinite(const float* ds, int64_t R, int64_t C, int64_t T, int back, float* out, hipStream_t s) {
+hipError_t launch_smear_nonfinite(const float* ds, int64_t R, int64_t C, int64_t T, int back, int fwd, float* out, hipStream_t s) {
     const int64_t n = R * T;
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(smear_nonfinite_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ds, R, C, T, back, out);
+    hipLaunchKernelGGL(smear_nonfinite_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ds, R, C, T, back, fwd, out);
     return hipGetLastError();
 }
 

@@ -590,6 +590,10 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
         stage_load<ALIGNED>(sx, a.dataset + (a.row0 + (int64_t)ri * a.row_stride) * a.T, a.T, (int)sg * PSH_SEG, nfloat, lane);
     };
 
+#ifdef PSH_TUNING
+    const int dbg = __builtin_amdgcn_readfirstlane(a.dbg);
+    if ((dbg & 1) && wave_in_block >= 4) __builtin_amdgcn_s_setprio(1);       // the second wave of every SIMD ahead of the first
+#endif
     Stage st;
     unsigned u = grab();
     if (u < u_hi) load_unit(st, u);
@@ -601,7 +605,7 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
         const int r_global = (int)(row + a.r_offset);
 
         stage_store(st, tile, nfloat, lane);
-        float lmax = 0.0f;
+        float lmax = 0.0f, nanq = 0.0f;
         {
             const int nqd = (nfloat + 3) >> 2;
 #pragma unroll
@@ -611,6 +615,7 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
                     const f32x4 v = st.v[q] * scale;
                     const f32x4 v2 = v * v;
                     lmax = fmaxf(fmaxf(lmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                    nanq += (v2[0] + v2[1]) + (v2[2] + v2[3]);             // (v_max drops a NaN; a sum of squares keeps it)
                     *reinterpret_cast<f16x4*>(a1 + mx_half(4 * m)) = __builtin_convertvector(v, f16x4);
                     *reinterpret_cast<f16x4*>(a2 + mx_half(4 * m)) = __builtin_convertvector(v2, f16x4);
                 }
@@ -620,8 +625,10 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
         if (npend > 0) { pend_flush(pend, npend, lcount, a, lane); npend = 0; }
         const unsigned un = grab();
         if (un < u_hi) load_unit(st, un);
-        // a value beyond f16 range (or no armed filter): nothing may be rejected in this segment
-        const bool keep_all = __any(!(lmax <= 128.0f)) || !(scale > 0.0f);
+        // a value beyond f16 range, a NaN (the banded product spreads it over the 32 outputs of its A row -- 0 x NaN -- and the
+        // minimum over a tile drops NaNs: clean windows beside it would be rejected unseen), or no armed filter: nothing may
+        // be rejected in this segment
+        const bool keep_all = __any(!(lmax <= 128.0f) || !(nanq == nanq)) || !(scale > 0.0f);
 
         // window energies of the 4 row groups, and the y^ fragments, once per segment
         f32x16 ny[4];
@@ -688,10 +695,20 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
             // all 8 MFMAs of the group first (4 independent accumulator tiles), then the tests:
             // a test-and-branch per tile serialises MFMA latency, min tree and branch 4 times
             f32x16 acc[4];
+#ifdef PSH_TUNING
+            if (dbg & 2) __builtin_amdgcn_s_setprio(2);
+#endif
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fy[g][0], b0, ny[g], 0, 0, 0);
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fy[g][1], b1, acc[g], 0, 0, 0);
+#ifdef PSH_TUNING
+            if (dbg & 2) __builtin_amdgcn_s_setprio(0);
+            if (dbg & 8) {                                                 // ablation: no epilogue (results invalid)
+                asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]));
+                continue;
+            }
+#endif
             float mn[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -699,6 +716,9 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
             }
             // values are finite here unless keep_all (then thr = +inf keeps NaN too)
             if (!__any(!(min3f(min3f(mn[0], mn[1], mn[2]), mn[3], mn[3]) > thr))) continue;
+#ifdef PSH_TUNING
+            if (dbg & 4) continue;                                         // ablation: no survivor handling (results invalid)
+#endif
             // survivors are only QUEUED here (window, query): a lane-by-lane exact chain would run ~140
             // instructions for the one or two lanes that hold a survivor; the queue is drained 64 at a time
             const int ql = 4 * G + qsub;                                   // this lane's query within the chunk

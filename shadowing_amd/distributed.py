@@ -163,7 +163,10 @@ class ShardedPathShadowing:
         # (PathShadowing._scan_rows_of, psh_prep.hip); paths are gathered from `dataset`
         self._rows = self.dataset[:, 0, :]
         if local_topk is None and self.dataset.numel() and _native.count_nonfinite(self.dataset):
-            self._rows = _native.smear_nonfinite(self.dataset, int(self.context.get_out_times()))
+            if self._linear:
+                raise ValueError("the sharded scan behind a linear embedding needs a finite ensemble (NaN / +-inf samples: "
+                                 "the reference's zero-padded conv spreads them over taps the native scan does not visit)")
+            self._rows = _native.smear_nonfinite(self.dataset, int(self.context.get_out_times()), 0)
         self._scan_streams = None
         self._reserve = 0
         if streams > 1 and local_topk is None and self.device.type == "cuda":

@@ -118,6 +118,8 @@ class PathShadowing:
         self.cache = cache
         self._resident = None       # (key, device tensor (R, C, T), weakref to the host tensor) -- the ensemble in HBM
         self._scan_rows = None      # (key, device tensor (R, T)): channel 0 of a multi-channel ensemble
+        self._dirty = False         # the resident ensemble holds NaN / +-inf samples (set by _scan_rows_of)
+        self._served_by = "hip"     # what the last _native_scan ran: "hip", or "torch" (a dirty ensemble behind a linear embedding)
         self._gen = 0               # bumped by refresh()
         self._workspace = None
         self.last_profile = None
@@ -266,15 +268,18 @@ class PathShadowing:
     def _scan_rows_of(self, ds: torch.Tensor) -> torch.Tensor:
         """(R, T) rows the scan reads: the ensemble itself, or -- several channels, CrossChannelContext -- a
         contiguous copy of channel 0 kept beside it.  An ensemble that holds NaN / +-inf samples (looked for ONCE per
-        resident copy: psh_count_nonfinite) is scanned through rows in which those samples are written back over the
-        horizon before them, so that a window is NaN exactly where the reference's zero-padded conv makes it NaN -- a
-        non-finite sample anywhere in y[r, :, t : t+K+h] (ref path_embedding.py:48-51, :129-132; psh_prep.hip); paths are
-        still gathered from the ensemble itself."""
-        back = 0 if type(self.context) is ImputationContext else int(self.context.get_out_times())
+        resident copy: psh_count_nonfinite; `self._dirty` afterwards) is scanned by the Identity scan through rows in which
+        those samples are written back over the horizon before them, so that a window is NaN exactly where the reference's
+        zero-padded conv makes it NaN -- a non-finite sample anywhere in y[r, :, t : t+W+h] (ref path_embedding.py:48-51,
+        :129-132; psh_prep.hip); paths are still gathered from the ensemble itself.  (The embedded scans look at the taps
+        their kernel rows span, which no rewriting of the data turns into the conv's rule for every kernel: a dirty ensemble
+        behind a linear embedding takes the generic torch formulation, _native_scan.)"""
+        back = int(self.context.get_out_times())
         key = (ds.data_ptr(), tuple(ds.shape), ds._version, back)
         if self._scan_rows is None or self._scan_rows[0] != key or self._scan_rows[2]() is not ds:
-            if _native.count_nonfinite(ds):
-                rows = _native.smear_nonfinite(ds, back)
+            self._dirty = bool(_native.count_nonfinite(ds))
+            if self._dirty:
+                rows = _native.smear_nonfinite(ds, back, 0)
             else:
                 rows = ds[:, 0, :] if ds.shape[1] == 1 else ds[:, 0, :].contiguous()
             self._scan_rows = (key, rows, weakref.ref(ds))
@@ -286,6 +291,7 @@ class PathShadowing:
         (one synchronisation per call instead of two) and comes back without the flag when it is not zero."""
         dev = self._hip_device()
         _native.load()
+        self._served_by = "hip"
         ds = self._resident_dataset(y, dev)
         rows = self._scan_rows_of(ds)
         h = self.context.get_out_times()
@@ -296,6 +302,18 @@ class PathShadowing:
             # the reference fails inside torch.topk (ref :165) with the same exception type
             raise RuntimeError("selected index k out of range")
         kind = self._native_kind(x, y, k)
+        if kind in ("linear", "padded") and self._dirty:
+            # NaN / +-inf in the ensemble behind a linear embedding: the reference's conv1d makes a window NaN when ANY tap of
+            # its zero-padded kernel meets one (0 * NaN); the native scans only visit the taps their rows span.  Rare enough
+            # to be served by the reference's own formulation in torch ops on this device (memory-bounded splits).
+            R_, T_ = ds.shape[0], ds.shape[-1]
+            per_row = max(T_ - x.shape[-1] + 1, 1) * max(int(self.embedding.kernel.shape[0]), 1) * 4 * 3
+            n_splits = max(1, min(R_, -(-R_ * per_row // (1 << 30))))
+            while R_ // n_splits == 0:
+                n_splits -= 1
+            d, idx = self._generic_scan(x, ds, k, n_splits, True)
+            self._served_by = "torch"
+            return d.to(dev), idx.to(dev), ds
         if kind in ("linear", "padded"):
             # the (tiny) query embedding stays the module's own conv1d (ref :140); the scan
             # over the ensemble takes the unpadded kernel and the horizon as an integer --
@@ -371,6 +389,11 @@ class PathShadowing:
         embedding, distance = self.embedding, self.distance
         dev = self._hip_device() if cuda else torch.device("cpu")
         x = x.to(dev)
+        if cuda:
+            # COPIES on the device: nn.Module.to() moves a module in place, and the caller's embedding must stay where it is
+            # (its kernel's device decides where later calls embed their queries -- another device, another rounding)
+            import copy
+            embedding, distance = copy.deepcopy(embedding), copy.deepcopy(distance)
         embedding = embedding.to(dev)
         distance = distance.to(dev)
         n_query, n_paths = x.shape[0], y.shape[0]
@@ -427,7 +450,7 @@ class PathShadowing:
                 return got
         if cuda and self._native_ok(x, y, k):
             out = self._native_scan(x, y, k, defer_status=True)
-            self.last_path = "hip"
+            self.last_path = self._served_by
             if len(out) == 4:
                 # the status travels with the results: gather and copies are enqueued behind the scan unconditionally
                 # (a status other than OK -- the fused launch gave up, candidate slices overflowed -- is rare and then
@@ -574,8 +597,8 @@ class PathShadowing:
                                 f"{tuple(getattr(values, 'shape', ()))}")
             return values
 
-        self.last_path = "hip"
         out = self._native_scan(x, y, k, defer_status=True)
+        self.last_path = self._served_by
         d_host = values = None
         if len(out) == 4:                                   # Identity scan: the status is read with the results (see shadow())
             d, idx, ds, status = out

@@ -23,8 +23,8 @@ def _dirty(R, T, seed, n_nan=60, n_inf=10, C=1):
     return ds
 
 
-@pytest.mark.parametrize("C,back", [(1, 0), (1, 20), (3, 7), (2, 300)])
-def test_count_and_smear_equal_numpy(hip_device, C, back):
+@pytest.mark.parametrize("C,back,fwd", [(1, 0, 0), (1, 20, 0), (3, 7, 5), (2, 300, 11), (1, 0, 9)])
+def test_count_and_smear_equal_numpy(hip_device, C, back, fwd):
     from shadowing_amd import _native
     ds = _dirty(130, 257, 900 + C + back, C=C)
     dt = torch.as_tensor(ds).to(hip_device)
@@ -33,8 +33,8 @@ def test_count_and_smear_equal_numpy(hip_device, C, back):
     bad = (~np.isfinite(ds)).any(axis=1)                                   # (R, T): any channel
     want = ds[:, 0, :].copy()
     for r, p in zip(*np.nonzero(bad)):
-        want[r, max(0, p - back):p + 1] = np.nan
-    got = _native.smear_nonfinite(dt, back).cpu().numpy()
+        want[r, max(0, p - back):p + fwd + 1] = np.nan
+    got = _native.smear_nonfinite(dt, back, fwd).cpu().numpy()
     assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
 
 
@@ -93,6 +93,11 @@ def test_every_identity_path_with_nonfinite_samples(hip_device, oracle_mod):
 
 @pytest.mark.parametrize("kind", ["foveal", "wavelet"])
 def test_embedded_scans_with_nonfinite_samples(hip_device, oracle_mod, kind):
+    """A dirty ensemble behind a linear embedding: the reference's conv1d makes a window NaN when ANY tap of its zero-padded
+    kernel meets a non-finite sample (also taps no row of the kernel spans: Foveal's head), which the native embedded scans
+    cannot see -- shadow(cuda=True) serves such a call by the reference's formulation in torch ops on the device
+    (last_path "torch"): distances as the oracle's to the embedded path's 1e-5, no window whose field holds a non-finite
+    sample; the same object on a clean ensemble is back on the native scan."""
     import shadowing_amd as sa
     R, T, h, k = 1024, 1500, 30, 200
     ds = _dirty(R, T, 7400, n_nan=300, n_inf=60)
@@ -101,13 +106,25 @@ def test_embedded_scans_with_nonfinite_samples(hip_device, oracle_mod, kind):
     else:
         emb = sa.PathEmbedding(torch.tensor(syn.wavelet_bank(3, 64))[:, None, :])
     K = emb.kernel.shape[-1]
+    ker = emb.kernel[:, 0, :].numpy().copy()
     x = syn.gbm_log_returns((3, K), 7401)
+    hx = emb(torch.tensor(x)[:, None, :])[:, 0, :].numpy()
     obj = sa.PathShadowing(emb, sa.RelativeMSE(), torch.as_tensor(ds), sa.PredictionContext(h))
     d, paths, idx = obj.shadow(x, k=k, cuda=True)
+    assert obj.last_path == "torch"
+    od, oidx = oracle_mod.scan_topk_embedded(ds, ker, hx, k, h=h)
+    np.testing.assert_allclose(d, od, rtol=1e-5)
+    assert np.isfinite(d).all()
+    for b in range(3):
+        for r, t in idx[b]:
+            assert np.isfinite(ds[r, 0, t:t + K + h]).all()
+        assert len({tuple(v) for v in idx[b]} & {tuple(v) for v in oidx[b]}) >= k - 2      # (near-ties at library-chosen orders)
+    clean = syn.dataset(R, T, 7402)
+    obj.dataset = torch.as_tensor(clean)
+    d, paths, idx = obj.shadow(x, k=k, cuda=True)
     assert obj.last_path == "hip"
-    hx = emb(torch.tensor(x)[:, None, :])[:, 0, :].numpy()
-    od, oidx = oracle_mod.scan_topk_embedded(ds, emb.kernel[:, 0, :].numpy(), hx, k, h=h)
-    assert_exact(d, idx, od, oidx, f"dirty ensemble, {kind}")
+    od, oidx = oracle_mod.scan_topk_embedded(clean, ker, hx, k, h=h)
+    assert_exact(d, idx, od, oidx, f"clean ensemble again, {kind}")
 
 
 def test_sharded_class_with_nonfinite_samples(hip_device, oracle_mod):

@@ -32,7 +32,8 @@ def test_realized_variance_kernel_equals_numpy(hip_device, shape, offset, Ts, vo
     want = _ref_rv(paths[..., offset:], Ts, vol)
     pt = torch.as_tensor(paths).to(hip_device)
     view = pt[..., offset:]
-    assert _native._uniform_rows(view) == (int(np.prod(shape[:-1])), shape[-1])
+    n_rows, stride = _native._uniform_rows(view)
+    assert n_rows == int(np.prod(shape[:-1])) and (n_rows == 1 or stride == shape[-1])
     got = realized_variance(view, Ts, vol)
     assert got.is_cuda and got.dtype == torch.float32 and tuple(got.shape) == want.shape
     np.testing.assert_allclose(got.cpu().numpy(), want, rtol=3e-7)
