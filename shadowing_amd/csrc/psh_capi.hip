@@ -827,7 +827,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
         // segment minima as matrix-core upper bounds (boot_mq_kernel) instead of exact chains
         int ncu = 0;
         HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
-        const int chunks = scan_mq_chunks(B);
+        const int chunks = boot_mq_chunks(B);
         int64_t gx = (n_sample * sa.nseg + 7) / 8;
         if (gx > ncu) gx = ncu;
         while (gx * chunks > PSH_MAX_BLOCKS) gx /= 2;

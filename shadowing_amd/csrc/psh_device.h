@@ -433,6 +433,7 @@ __device__ __forceinline__ int mx_half(int idx) {
 // written out at the top of the next iteration, BEFORE the next prefetch is issued.
 #define PSH_PEND 64                       // entries per wave: one flush lane each
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void pend_flush(const u32x4* pend, int npend, int* lcount, const ScanArgs& a, int lane) {
     wave_lds_fence();                                  // other lanes' entries

@@ -275,6 +275,7 @@ bool scan_mx_supported(int W, int B);
 bool scan_mq_supported(int W, int B);          // batched queries on the matrix cores
 size_t scan_mq_shmem_bytes(int tile_floats, int B);
 int scan_mq_chunks(int B);                      // grid.y: chunks of queries whose fragments fit LDS
+int boot_mq_chunks(int B);                      // the same for the bootstrap's fragment layout
 hipError_t launch_scan_mq(const ScanArgs& a, bool aligned, int grid_x, hipStream_t s);
 bool boot_mq_supported(int W);                  // bootstrap minima as matrix-core upper bounds
 hipError_t launch_boot_mq(const ScanArgs& a, bool aligned, int grid_x, hipStream_t s);

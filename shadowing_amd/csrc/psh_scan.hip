@@ -512,8 +512,19 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
 // fragments (built by the threshold kernel, one common power-of-two scale) and thresholds
 // sit in LDS.  A segment holding a value beyond f16 range keeps everything (exact path).
 #define PSH_MQ_THREADS 512
-#define PSH_MQ_CHUNK 112          // queries per block pass (their fragments, thresholds and values sit in LDS)
+#define PSH_MQ_CHUNK 112          // boot_mq_kernel: queries per block pass (their fragments, in the [group][K-step][lane] layout, sit in LDS)
 #define PSH_MQ_QCAP 192           // survivors of the cheap test queued per wave before a dense exact pass
+// scan_mq_kernel keeps TWO zero-padded f16 copies of a query -- xpad = 7 zeros, the W <= 25 scaled taps times -2, zeros; copy 0
+// from half 0, copy 1 from half 1, 20 dwords each -- instead of the 8 shifted copies a [group][K-step][lane] fragment table
+// holds: the fragment of lane (query, shift, hk), K-step s is the 8 halves xpad[o + 16 s ..], o = 7 - shift + 8 hk, i.e. dwords
+// o / 2 + 8 s .. + 3 of copy (o & 1): two dword-aligned ds_read2_b32.  (One copy and a 2-byte-aligned ds_read_b128 is what
+// the compiler would emit and gfx950 serves -- at an eighth of the aligned rate: tools/ubench_lds_unaligned.hip.)  The
+// copies of one query sit PSH_MQ_QDW dwords apart, a query's two copies 24: the 64 lanes of a read meet 64 different banks.
+// 192 bytes per query instead of 512 put PSH_MQS_CHUNK queries beside the waves' tiles: the ensemble is staged, converted
+// and its window energies taken once per segment and 256 queries, not once per 112 (that per-segment work was a quarter of
+// the kernel: profiles/r04_mq_ablations.txt).
+#define PSH_MQ_QDW 48
+#define PSH_MQS_CHUNK 256
 
 template <int WT, bool ALIGNED>
 __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
@@ -530,35 +541,32 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
     _Float16* hbase = reinterpret_cast<_Float16*>(pend0 + (size_t)NW * PSH_PEND);
     _Float16* a1 = hbase + (size_t)wave_in_block * 2 * PSH_MX_NHALF;      // y^
     _Float16* a2 = a1 + PSH_MX_NHALF;                                      // (y~^2)^
-    _Float16* fragL = hbase + (size_t)NW * 2 * PSH_MX_NHALF;               // [group][K-step][lane] x 8 halves
-    float* thrL = reinterpret_cast<float*>(fragL + (size_t)(PSH_MQ_CHUNK / 4) * 2 * 64 * 8);
-    float* tauL = thrL + PSH_MQ_CHUNK;
-    float* xL = tauL + PSH_MQ_CHUNK;                                       // the chunk's queries: the exact recheck reads them
-    unsigned* sq = reinterpret_cast<unsigned*>(xL + PSH_MQ_CHUNK * 25) + (size_t)wave_in_block * PSH_MQ_QCAP;   // survivor queue
+    unsigned* fragL = reinterpret_cast<unsigned*>(hbase + (size_t)NW * 2 * PSH_MX_NHALF);   // [query of the chunk] x PSH_MQ_QDW dwords
+    float* thrL = reinterpret_cast<float*>(fragL + (size_t)PSH_MQS_CHUNK * PSH_MQ_QDW);
+    float* tauL = thrL + PSH_MQS_CHUNK;
+    unsigned* sq = reinterpret_cast<unsigned*>(tauL + PSH_MQS_CHUNK) + (size_t)wave_in_block * PSH_MQ_QCAP;   // survivor queue
     const int W = WT > 0 ? WT : a.W;
     int npend = 0;
     int nsq = 0;
 
-    const int q0 = (int)blockIdx.y * PSH_MQ_CHUNK;                         // this block's queries: [q0, q0 + nq)
-    const int nq = (a.B - q0) < PSH_MQ_CHUNK ? (a.B - q0) : PSH_MQ_CHUNK;
+    const int q0 = (int)blockIdx.y * PSH_MQS_CHUNK;                        // this block's queries: [q0, q0 + nq)
+    const int nq = (a.B - q0) < PSH_MQS_CHUNK ? (a.B - q0) : PSH_MQS_CHUNK;
     const int ngroups = (nq + 3) >> 2;
     if (threadIdx.x == 0) *next_unit = 0;
     for (int q = (int)threadIdx.x; q < a.B; q += PSH_MQ_THREADS) lcount[q] = 0;
     {
         unsigned* z = reinterpret_cast<unsigned*>(a1);
         for (int i = lane; i < PSH_MX_NHALF; i += 64) z[i] = 0u;
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.mq_frag) + (size_t)(q0 >> 2) * 2 * 64;   // 16 bytes = 8 halves
+        // the padded copies of the chunk's queries (PSH_MQ_QDW dwords = twelve 16-byte pieces each); queries past the end of
+        // the batch in the last group: zeros
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.mq_frag) + (size_t)q0 * (PSH_MQ_QDW / 4);
         f32x4* dst = reinterpret_cast<f32x4*>(fragL);
-        for (int i = (int)threadIdx.x; i < ngroups * 2 * 64; i += PSH_MQ_THREADS) {
-            // lanes of queries past the end of the batch: zero fragments
-            const int ln = i & 63, qq = 4 * (i >> 7) + ((ln & 31) >> 3);
-            dst[i] = qq < nq ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        for (int i = (int)threadIdx.x; i < PSH_MQ_CHUNK; i += PSH_MQ_THREADS) {
+        for (int i = (int)threadIdx.x; i < 4 * ngroups * (PSH_MQ_QDW / 4); i += PSH_MQ_THREADS)
+            dst[i] = i < nq * (PSH_MQ_QDW / 4) ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = (int)threadIdx.x; i < 4 * ngroups; i += PSH_MQ_THREADS) {
             thrL[i] = i < nq ? a.qstate[q0 + i].mx_thr : -__uint_as_float(PSH_INF_BITS);   // -inf: reject everything
             tauL[i] = i < nq ? __uint_as_float(a.qstate[q0 + i].tau_bits) : 0.0f;
         }
-        for (int i = (int)threadIdx.x; i < nq * W; i += PSH_MQ_THREADS) xL[i] = a.queries[(int64_t)q0 * W + i];
     }
     __syncthreads();
 
@@ -657,7 +665,7 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
                 hit = hit && (seg_start + p < a.Tp);
                 float v = 0.0f;
                 if (hit) {
-                    const float* xq = xL + ql2 * W;
+                    const float* xq = a.queries + (int64_t)(q0 + ql2) * W;       // (rare path: the exact query comes from memory)
 #pragma unroll
                     for (int j2 = 0; j2 < W; ++j2) {
                         const float D = __fsub_rn(xq[j2], tile[lds_pad(p + j2)]);
@@ -685,12 +693,25 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
 
         // (running pointers: the group's two fragments sit 1 KB apart behind one address register, the threshold behind
         //  another -- six VALU instructions of index arithmetic per group were a seventh of the loop's fast path)
-        const _Float16* fragp = fragL + (size_t)lane * 8;
+        // (the LDS byte address of the lane's first fragment dword: the low half of the flat address of a __shared__ object)
+        unsigned frag_addr = (unsigned)(size_t)(fragL + qsub * PSH_MQ_QDW + ((7 - shift) & 1) * 24 + ((7 - shift + 8 * hk) >> 1));
         const float* thrp = thrL + qsub;
 #pragma unroll 1
-        for (int G = 0; G < ngroups; ++G, fragp += 2 * 64 * 8, thrp += 4) {
-            const f16x8 b0 = *reinterpret_cast<const f16x8*>(fragp);
-            const f16x8 b1 = *reinterpret_cast<const f16x8*>(fragp + 64 * 8);
+        for (int G = 0; G < ngroups; ++G, frag_addr += 4 * PSH_MQ_QDW * 4, thrp += 4) {
+            // four ds_read2_b32 off one address register.  By hand: left to itself the compiler folds the adjacent dword-aligned
+            // pieces into ONE 4-byte-aligned ds_read_b128, which gfx950 serves at an eighth of the aligned rate
+            // (tools/ubench_lds_unaligned.hip); the wait is part of the statement -- the compiler does not count these reads
+            u32x2 f00, f01, f10, f11;
+            asm volatile("ds_read2_b32 %0, %4 offset1:1\n\t"
+                         "ds_read2_b32 %1, %4 offset0:2 offset1:3\n\t"
+                         "ds_read2_b32 %2, %4 offset0:8 offset1:9\n\t"
+                         "ds_read2_b32 %3, %4 offset0:10 offset1:11\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(f00), "=&v"(f01), "=&v"(f10), "=&v"(f11) : "v"(frag_addr) : "memory");
+            const u32x4 w0 = u32x4{f00[0], f00[1], f01[0], f01[1]}, w1 = u32x4{f10[0], f10[1], f11[0], f11[1]};
+            f16x8 b0, b1;
+            __builtin_memcpy(&b0, &w0, 16);
+            __builtin_memcpy(&b1, &w1, 16);
             const float thr = keep_all ? __uint_as_float(PSH_INF_BITS) : *thrp;
             // all 8 MFMAs of the group first (4 independent accumulator tiles), then the tests:
             // a test-and-branch per tile serialises MFMA latency, min tree and branch 4 times
@@ -1047,11 +1068,12 @@ size_t scan_mq_shmem_bytes(int tile_floats, int B) {
     constexpr int NW = PSH_MQ_THREADS / 64;
     return (size_t)tile_floats * NW * sizeof(float) + (size_t)(((B + 3) & ~3) + 4) * sizeof(int)
            + (size_t)NW * PSH_PEND * 16 + (size_t)NW * 2 * PSH_MX_NHALF * sizeof(_Float16)
-           + (size_t)(PSH_MQ_CHUNK / 4) * 2 * 64 * 8 * sizeof(_Float16) + (size_t)2 * PSH_MQ_CHUNK * sizeof(float)
-           + (size_t)PSH_MQ_CHUNK * 25 * sizeof(float) + (size_t)NW * PSH_MQ_QCAP * sizeof(unsigned);
+           + (size_t)PSH_MQS_CHUNK * PSH_MQ_QDW * sizeof(unsigned) + (size_t)2 * PSH_MQS_CHUNK * sizeof(float)
+           + (size_t)NW * PSH_MQ_QCAP * sizeof(unsigned);
 }
 
-int scan_mq_chunks(int B) { return (B + PSH_MQ_CHUNK - 1) / PSH_MQ_CHUNK; }
+int scan_mq_chunks(int B) { return (B + PSH_MQS_CHUNK - 1) / PSH_MQS_CHUNK; }
+int boot_mq_chunks(int B) { return (B + PSH_MQ_CHUNK - 1) / PSH_MQ_CHUNK; }
 
 bool boot_mq_supported(int W) { return W >= 1 && W <= 25; }
 
@@ -1063,7 +1085,7 @@ size_t boot_mq_shmem_bytes(int tile_floats) {
 
 hipError_t launch_boot_mq(const ScanArgs& a, bool aligned, int grid_x, hipStream_t s) {
     const size_t shmem = boot_mq_shmem_bytes(a.tile_floats);
-    const dim3 grid(grid_x, scan_mq_chunks(a.B));
+    const dim3 grid(grid_x, boot_mq_chunks(a.B));
     if (a.W == 20)
         return aligned ? launch_big_lds(boot_mq_kernel<20, true>, grid, PSH_MQ_THREADS, shmem, s, a)
                        : launch_big_lds(boot_mq_kernel<20, false>, grid, PSH_MQ_THREADS, shmem, s, a);

@@ -305,18 +305,16 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
         }
     }
     if (a.mq_frag) {
-        // this query's share of scan_mq_kernel's B-fragment table: group b / 4, K-step s, lane
-        // 32 hk + 8 (b & 3) + shift, element i holds -2 x~[k - shift] for k = 16 s + 8 hk + i in the band
+        // this query's two zero-padded f16 copies for scan_mq_kernel (PSH_MQ_QDW = 48 dwords: copy c at dword 24 c, 20 dwords
+        // used): xpad[i] = -2 x~[i - 7] inside the query, 0 outside; dword d of copy c = (xpad[2 d + c], xpad[2 d + c + 1])
         __syncthreads();
         const float sc = a.qstate[b].mx_scale;             // thread 0 above; 0 = filter not armed
-        if (tid < 256) {
-            const int i = tid & 7, shift = (tid >> 3) & 7, hk = (tid >> 6) & 1, s2 = tid >> 7;
-            const int j = 16 * s2 + 8 * hk + i - shift;
-            const bool in = j >= 0 && j < a.prep.W;
+        if (tid < 96) {
+            const int half = tid & 1, dw = tid >> 1, c = dw >= 24 ? 1 : 0, d = dw - 24 * c;
+            const int j = 2 * d + c + half - 7;
+            const bool in = d < 20 && j >= 0 && j < a.prep.W;
             const float xv = in ? a.prep.queries[(int64_t)b * a.prep.W + j] : 0.0f;
-            const int ln = 32 * hk + 8 * (b & 3) + shift;
-            reinterpret_cast<_Float16*>(a.mq_frag)[(((int64_t)(b >> 2) * 2 + s2) * 64 + ln) * 8 + i] =
-                (_Float16)(in ? -2.0f * (xv * sc) : 0.0f);
+            reinterpret_cast<_Float16*>(a.mq_frag)[(int64_t)b * 96 + tid] = (_Float16)(in ? -2.0f * (xv * sc) : 0.0f);
         }
     }
 }

@@ -543,6 +543,32 @@ def test_sharded_class_with_linear_embedding_over_rccl(hip_device, oracle_mod, t
     assert_exact(md.cpu().numpy(), mi.cpu().numpy(), od, oidx, "4 logical shards")
 
 
+def test_configs4_wavelet_scan_at_its_per_gpu_size_equals_the_oracle(hip_device, oracle_mod):
+    """BASELINE.json configs[4] at ONE GPU's share, exactly what tools/bench_foveal.py --which wavelet times: R = 32768 paths
+    x T = 4096, the W = 252 wavelet bank (11 rows), 16 rolling query dates, k = 1024, horizon 20 -- 1.25e8 windows x 16
+    queries on the matrix cores (embed_mx_kernel) against the oracle's scan of every window (a few seconds on the box's host
+    cores: each window is embedded once for the whole batch), bit for bit."""
+    from shadowing_amd import _native
+    R, T, K, h, k, B = 32768, 4096, 252, 20, 1024, 16
+    ker = syn.wavelet_bank(5, K)
+    ds = syn.dataset(R, T, 71)
+    x = syn.rolling_queries(B, K, 72)
+    hx = torch.nn.functional.conv1d(torch.tensor(x)[:, None, :], torch.tensor(ker)[:, None, :])[:, :, 0].contiguous()
+    dt = torch.as_tensor(ds[:, 0, :].copy()).to(hip_device)
+    kd, hd = torch.tensor(ker).to(hip_device), hx.to(hip_device)
+    ws = _native.Workspace(hip_device)
+    d, idx, st = _native.scan_topk_embedded(dt, kd, hd, k, h=h, workspace=ws, flags=_native.FLAG_EMBED_MX)[:3]
+    torch.cuda.synchronize()
+    bad = torch.nonzero(st != 0).flatten()
+    if bad.numel():                                          # the estimate fell short for a query: the exact pass, as the host class does
+        d2, i2, _ = _native.scan_topk_embedded(dt, kd, hd[bad].contiguous(), k, h=h, workspace=ws, exhaustive=True,
+                                               flags=_native.FLAG_EMBED_MX)[:3]
+        d[bad], idx[bad] = d2, i2
+        torch.cuda.synchronize()
+    od, oidx = oracle_mod.scan_topk_embedded(ds, ker, hx.numpy(), k, h=h)
+    assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, "configs[4] per-GPU size")
+
+
 @pytest.mark.parametrize("name", IMPUTATION_GOLDENS)
 def test_path_shadowing_with_an_imputation_context_runs_native(hip_device, name):
     """PathShadowing(embedding, RelativeMSE, ds, ImputationContext((l, c, r))).shadow(cuda=True) through the
