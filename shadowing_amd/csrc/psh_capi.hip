@@ -833,6 +833,8 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
         while (gx * chunks > PSH_MAX_BLOCKS) gx /= 2;
         if (gx < 1) gx = 1;
         n_blockmax = (int)gx * chunks;
+        sa.mq_frag = w.mq_frag;
+        HIP_TRY(launch_mq_prep(queries, B, p.W, w.mq_frag, s));
         HIP_TRY(launch_boot_mq(sa, p.aligned, (int)gx, s));
     } else if (rows_path) {
         int ncu = 0;

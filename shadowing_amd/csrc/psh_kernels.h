@@ -279,6 +279,7 @@ int boot_mq_chunks(int B);                      // the same for the bootstrap's 
 hipError_t launch_scan_mq(const ScanArgs& a, bool aligned, int grid_x, hipStream_t s);
 bool boot_mq_supported(int W);                  // bootstrap minima as matrix-core upper bounds
 hipError_t launch_boot_mq(const ScanArgs& a, bool aligned, int grid_x, hipStream_t s);
+hipError_t launch_mq_prep(const float* queries, int B, int W, void* mq, hipStream_t s);   // in front of launch_boot_mq: scale, padded query copies, nx~
 hipError_t scan_blocks_per_cu(int W, bool aligned, bool embedded, size_t shmem, int* out);
 hipError_t launch_threshold(const ThresholdArgs& a, int B, hipStream_t s);
 hipError_t launch_select(const SelectArgs& a, int B, hipStream_t s);

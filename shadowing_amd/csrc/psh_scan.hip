@@ -512,18 +512,20 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
 // fragments (built by the threshold kernel, one common power-of-two scale) and thresholds
 // sit in LDS.  A segment holding a value beyond f16 range keeps everything (exact path).
 #define PSH_MQ_THREADS 512
-#define PSH_MQ_CHUNK 112          // boot_mq_kernel: queries per block pass (their fragments, in the [group][K-step][lane] layout, sit in LDS)
 #define PSH_MQ_QCAP 192           // survivors of the cheap test queued per wave before a dense exact pass
 // scan_mq_kernel keeps TWO zero-padded f16 copies of a query -- xpad = 7 zeros, the W <= 25 scaled taps times -2, zeros; copy 0
 // from half 0, copy 1 from half 1, 20 dwords each -- instead of the 8 shifted copies a [group][K-step][lane] fragment table
 // holds: the fragment of lane (query, shift, hk), K-step s is the 8 halves xpad[o + 16 s ..], o = 7 - shift + 8 hk, i.e. dwords
 // o / 2 + 8 s .. + 3 of copy (o & 1): two dword-aligned ds_read2_b32.  (One copy and a 2-byte-aligned ds_read_b128 is what
-// the compiler would emit and gfx950 serves -- at an eighth of the aligned rate: tools/ubench_lds_unaligned.hip.)  The
-// copies of one query sit PSH_MQ_QDW dwords apart, a query's two copies 24: the 64 lanes of a read meet 64 different banks.
-// 192 bytes per query instead of 512 put PSH_MQS_CHUNK queries beside the waves' tiles: the ensemble is staged, converted
+// the compiler would emit and gfx950 serves -- at an eighth of the aligned rate: tools/ubench_lds_unaligned.hip.)  A
+// ds_read2_b32 is two dword reads of 32 lanes each on 32 banks: the queries of a group sit PSH_MQ_QDW = 40 dwords apart, a
+// query's two copies 20, so that the 4 x 8 lanes of a read -- 4 consecutive dwords of either copy of 4 queries -- fall on 32
+// different banks ({0..3, 20..23} + 8 q mod 32).
+// 160 bytes per query instead of 512 put PSH_MQS_CHUNK queries beside the waves' tiles: the ensemble is staged, converted
 // and its window energies taken once per segment and 256 queries, not once per 112 (that per-segment work was a quarter of
 // the kernel: profiles/r04_mq_ablations.txt).
-#define PSH_MQ_QDW 48
+#define PSH_MQ_QDW 40
+#define PSH_MQ_CDW 20
 #define PSH_MQS_CHUNK 256
 
 template <int WT, bool ALIGNED>
@@ -557,7 +559,7 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
     {
         unsigned* z = reinterpret_cast<unsigned*>(a1);
         for (int i = lane; i < PSH_MX_NHALF; i += 64) z[i] = 0u;
-        // the padded copies of the chunk's queries (PSH_MQ_QDW dwords = twelve 16-byte pieces each); queries past the end of
+        // the padded copies of the chunk's queries (PSH_MQ_QDW dwords = ten 16-byte pieces each); queries past the end of
         // the batch in the last group: zeros
         const f32x4* src = reinterpret_cast<const f32x4*>(a.mq_frag) + (size_t)q0 * (PSH_MQ_QDW / 4);
         f32x4* dst = reinterpret_cast<f32x4*>(fragL);
@@ -694,7 +696,7 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
         // (running pointers: the group's two fragments sit 1 KB apart behind one address register, the threshold behind
         //  another -- six VALU instructions of index arithmetic per group were a seventh of the loop's fast path)
         // (the LDS byte address of the lane's first fragment dword: the low half of the flat address of a __shared__ object)
-        unsigned frag_addr = (unsigned)(size_t)(fragL + qsub * PSH_MQ_QDW + ((7 - shift) & 1) * 24 + ((7 - shift + 8 * hk) >> 1));
+        unsigned frag_addr = (unsigned)(size_t)(fragL + qsub * PSH_MQ_QDW + ((7 - shift) & 1) * PSH_MQ_CDW + ((7 - shift + 8 * hk) >> 1));
         const float* thrp = thrL + qsub;
 #pragma unroll 1
         for (int G = 0; G < ngroups; ++G, frag_addr += 4 * PSH_MQ_QDW * 4, thrp += 4) {
@@ -817,6 +819,58 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
 // its own), the scale comes from the queries alone (the bootstrap runs before anything is
 // known about the data): a segment holding |y~| > 128 falls back to the exact chain.
 // Also records the largest |y| per block for the scale of the full scan.
+// What every block of the bootstrap needs of the batch -- the scale, every query's two padded f16 copies (the scan's layout,
+// PSH_MQ_QDW dwords a query) and nx~ -- written ONCE by one block (round 3: every block of every query chunk rebuilt its
+// chunk's 57 KB fragment table from the queries: most of the bootstrap's 0.25 ms at 512 queries).  Layout behind `mq`
+// (the workspace's 512 x B4 bytes, B4 = B rounded up to 4; the threshold kernel later writes the SCAN's copies, at its own
+// scale, at offset 0): boot copies at 192 B4 bytes, nx~ at 384 B4, {scale, 1 / scale^2} at 392 B4.
+#define PSH_MQ_BOOT_OFF(B4) ((size_t)192 * (size_t)(B4))
+#define PSH_MQ_NX_OFF(B4) ((size_t)384 * (size_t)(B4))
+#define PSH_MQ_META_OFF(B4) ((size_t)392 * (size_t)(B4))
+__global__ __launch_bounds__(1024) void mq_prep_kernel(const float* __restrict__ queries, int B, int W, void* mq) {
+    __shared__ unsigned s_max;
+    const int tid = (int)threadIdx.x;
+    if (tid == 0) s_max = 0u;
+    __syncthreads();
+    unsigned mb = 0u;                                       // the largest |x| of the whole batch into [4, 8)
+    for (int64_t j = tid; j < (int64_t)B * W; j += 1024) mb = max(mb, __float_as_uint(fabsf(queries[j])));
+    if (mb) atomicMax(&s_max, mb);
+    __syncthreads();
+    const unsigned qmaxbits = s_max;
+    const int sexp = 3 - ((int)((qmaxbits >> 23) & 255u) - 126);
+    const bool sane = sexp <= 60 && sexp >= -60 && qmaxbits >= 0x00800000u && qmaxbits < PSH_INF_BITS;
+    const float scale = sane ? __uint_as_float((unsigned)(127 + sexp) << 23) : 0.0f;     // 0: exact chain everywhere
+    const float unscale2 = sane ? __uint_as_float((unsigned)(127 - 2 * sexp) << 23) : 0.0f;
+    const int B4 = (B + 3) & ~3;
+    char* base = reinterpret_cast<char*>(mq);
+    _Float16* tab = reinterpret_cast<_Float16*>(base + PSH_MQ_BOOT_OFF(B4));
+    float* nx = reinterpret_cast<float*>(base + PSH_MQ_NX_OFF(B4));
+    for (int64_t i = tid; i < (int64_t)B4 * 2 * PSH_MQ_QDW; i += 1024) {
+        const int b = (int)(i / (2 * PSH_MQ_QDW)), e = (int)(i - (int64_t)b * 2 * PSH_MQ_QDW);
+        const int half = e & 1, dw = e >> 1, c = dw >= PSH_MQ_CDW ? 1 : 0, d = dw - PSH_MQ_CDW * c;
+        const int j = 2 * d + c + half - 7;
+        const bool in = b < B && j >= 0 && j < W;
+        const float xv = in ? queries[(int64_t)b * W + j] : 0.0f;
+        tab[i] = (_Float16)(in ? -2.0f * (xv * scale) : 0.0f);
+    }
+    for (int b = tid; b < B4; b += 1024) {
+        float sq = 0.0f;
+        if (b < B)
+            for (int j = 0; j < W; ++j) { const float v = queries[(int64_t)b * W + j] * scale; sq = __builtin_fmaf(v, v, sq); }
+        nx[b] = sq;
+    }
+    if (tid == 0) {
+        float* meta = reinterpret_cast<float*>(base + PSH_MQ_META_OFF(B4));
+        meta[0] = scale;
+        meta[1] = unscale2;
+    }
+}
+
+hipError_t launch_mq_prep(const float* queries, int B, int W, void* mq, hipStream_t s) {
+    hipLaunchKernelGGL(mq_prep_kernel, dim3(1), dim3(1024), 0, s, queries, B, W, mq);
+    return hipGetLastError();
+}
+
 template <int WT, bool ALIGNED>
 __global__ __launch_bounds__(PSH_MQ_THREADS) void boot_mq_kernel(ScanArgs a) {
     static_assert(WT >= 0 && WT <= 25, "query + 7 shifts must fit K = 32 (WT = 0: run-time W <= 25)");
@@ -829,44 +883,30 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void boot_mq_kernel(ScanArgs a) {
     _Float16* hbase = reinterpret_cast<_Float16*>(next_unit + 4);
     _Float16* a1 = hbase + (size_t)wave_in_block * 2 * PSH_MX_NHALF;
     _Float16* a2 = a1 + PSH_MX_NHALF;
-    _Float16* fragL = hbase + (size_t)NW * 2 * PSH_MX_NHALF;
-    float* nxL = reinterpret_cast<float*>(fragL + (size_t)(PSH_MQ_CHUNK / 4) * 2 * 64 * 8);   // nx~ per query of the chunk
+    unsigned* fragL = reinterpret_cast<unsigned*>(hbase + (size_t)NW * 2 * PSH_MX_NHALF);   // [query of the chunk] x PSH_MQ_QDW dwords
+    float* nxL = reinterpret_cast<float*>(fragL + (size_t)PSH_MQS_CHUNK * PSH_MQ_QDW);       // nx~ per query of the chunk
 
     const int W = WT > 0 ? WT : a.W;
-    const int q0 = (int)blockIdx.y * PSH_MQ_CHUNK;
-    const int nq = (a.B - q0) < PSH_MQ_CHUNK ? (a.B - q0) : PSH_MQ_CHUNK;
+    const int q0 = (int)blockIdx.y * PSH_MQS_CHUNK;
+    const int nq = (a.B - q0) < PSH_MQS_CHUNK ? (a.B - q0) : PSH_MQS_CHUNK;
     const int ngroups = (nq + 3) >> 2;
     if (threadIdx.x == 0) { next_unit[0] = 0; next_unit[1] = 0; next_unit[2] = 0; }
     {
         unsigned* z = reinterpret_cast<unsigned*>(a1);
         for (int i = lane; i < PSH_MX_NHALF; i += 64) z[i] = 0u;
     }
-    __syncthreads();
-    {   // scale: the largest |x| of the whole batch into [4, 8)
-        unsigned mb = 0u;
-        for (int64_t j = threadIdx.x; j < (int64_t)a.B * W; j += PSH_MQ_THREADS) mb = max(mb, __float_as_uint(fabsf(a.queries[j])));
-        if (mb) atomicMax(reinterpret_cast<unsigned*>(next_unit + 2), mb);
-    }
-    __syncthreads();
-    const unsigned qmaxbits = (unsigned)next_unit[2];
-    const int sexp = 3 - ((int)((qmaxbits >> 23) & 255u) - 126);
-    const bool sane = sexp <= 60 && sexp >= -60 && qmaxbits >= 0x00800000u && qmaxbits < PSH_INF_BITS;
-    const float scale = sane ? __uint_as_float((unsigned)(127 + sexp) << 23) : 0.0f;     // 0: exact chain everywhere
-    const float unscale2 = sane ? __uint_as_float((unsigned)(127 - 2 * sexp) << 23) : 0.0f;
-    for (int i = (int)threadIdx.x; i < ngroups * 2 * 64 * 8; i += PSH_MQ_THREADS) {
-        // fragment table entry i = ((2 G + s) * 64 + lane) * 8 + e
-        const int e = i & 7, ln = (i >> 3) & 63, s2 = (i >> 9) & 1, G = i >> 10;
-        const int hk = ln >> 5, qsub = (ln & 31) >> 3, shift = ln & 7;
-        const int j = 16 * s2 + 8 * hk + e - shift, ql = 4 * G + qsub;
-        const bool in = j >= 0 && j < W && ql < nq;
-        const float xv = in ? a.queries[(int64_t)(q0 + ql) * W + j] : 0.0f;
-        fragL[i] = (_Float16)(in ? -2.0f * (xv * scale) : 0.0f);
-    }
-    for (int i = (int)threadIdx.x; i < PSH_MQ_CHUNK; i += PSH_MQ_THREADS) {
-        float s = 0.0f;
-        if (i < nq)
-            for (int j = 0; j < W; ++j) { const float v = a.queries[(int64_t)(q0 + i) * W + j] * scale; s = __builtin_fmaf(v, v, s); }
-        nxL[i] = s;
+    // the batch's scale, this chunk's padded query copies and nx~: written once by mq_prep_kernel (B4 is a multiple of 4:
+    // the last group's queries past the end of the batch are zeros there)
+    const int B4 = (a.B + 3) & ~3;
+    const char* mqb = reinterpret_cast<const char*>(a.mq_frag);
+    const float scale = reinterpret_cast<const float*>(mqb + PSH_MQ_META_OFF(B4))[0];
+    const float unscale2 = reinterpret_cast<const float*>(mqb + PSH_MQ_META_OFF(B4))[1];
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(mqb + PSH_MQ_BOOT_OFF(B4)) + (size_t)q0 * (PSH_MQ_QDW / 4);
+        f32x4* dst = reinterpret_cast<f32x4*>(fragL);
+        for (int i = (int)threadIdx.x; i < 4 * ngroups * (PSH_MQ_QDW / 4); i += PSH_MQ_THREADS) dst[i] = src[i];
+        const float* nxs = reinterpret_cast<const float*>(mqb + PSH_MQ_NX_OFF(B4)) + q0;
+        for (int i = (int)threadIdx.x; i < 4 * ngroups; i += PSH_MQ_THREADS) nxL[i] = nxs[i];
     }
     __syncthreads();
 
@@ -945,10 +985,21 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void boot_mq_kernel(ScanArgs a) {
                 ny[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, bo[0], ny[g], 0, 0, 0);
                 ny[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, bo[1], ny[g], 0, 0, 0);
             }
+            unsigned frag_addr = (unsigned)(size_t)(fragL + qsub * PSH_MQ_QDW + ((7 - shift) & 1) * PSH_MQ_CDW + ((7 - shift + 8 * hk) >> 1));
 #pragma unroll 1
-            for (int G = 0; G < ngroups; ++G) {
-                const f16x8 b0 = *reinterpret_cast<const f16x8*>(fragL + ((size_t)(2 * G + 0) * 64 + lane) * 8);
-                const f16x8 b1 = *reinterpret_cast<const f16x8*>(fragL + ((size_t)(2 * G + 1) * 64 + lane) * 8);
+            for (int G = 0; G < ngroups; ++G, frag_addr += 4 * PSH_MQ_QDW * 4) {
+                // (the scan's fragment reads: four ds_read2_b32 off one address register, see scan_mq_kernel)
+                u32x2 f00, f01, f10, f11;
+                asm volatile("ds_read2_b32 %0, %4 offset1:1\n\t"
+                             "ds_read2_b32 %1, %4 offset0:2 offset1:3\n\t"
+                             "ds_read2_b32 %2, %4 offset0:8 offset1:9\n\t"
+                             "ds_read2_b32 %3, %4 offset0:10 offset1:11\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(f00), "=&v"(f01), "=&v"(f10), "=&v"(f11) : "v"(frag_addr) : "memory");
+                const u32x4 w0 = u32x4{f00[0], f00[1], f01[0], f01[1]}, w1 = u32x4{f10[0], f10[1], f11[0], f11[1]};
+                f16x8 b0, b1;
+                __builtin_memcpy(&b0, &w0, 16);
+                __builtin_memcpy(&b1, &w1, 16);
                 const int ql = 4 * G + qsub;
                 float mn = __uint_as_float(PSH_INF_BITS);
                 f32x16 acc[4];
@@ -1073,14 +1124,14 @@ size_t scan_mq_shmem_bytes(int tile_floats, int B) {
 }
 
 int scan_mq_chunks(int B) { return (B + PSH_MQS_CHUNK - 1) / PSH_MQS_CHUNK; }
-int boot_mq_chunks(int B) { return (B + PSH_MQ_CHUNK - 1) / PSH_MQ_CHUNK; }
+int boot_mq_chunks(int B) { return (B + PSH_MQS_CHUNK - 1) / PSH_MQS_CHUNK; }
 
 bool boot_mq_supported(int W) { return W >= 1 && W <= 25; }
 
 size_t boot_mq_shmem_bytes(int tile_floats) {
     constexpr int NW = PSH_MQ_THREADS / 64;
     return (size_t)tile_floats * NW * sizeof(float) + 16 + (size_t)NW * 2 * PSH_MX_NHALF * sizeof(_Float16)
-           + (size_t)(PSH_MQ_CHUNK / 4) * 2 * 64 * 8 * sizeof(_Float16) + (size_t)PSH_MQ_CHUNK * sizeof(float);
+           + (size_t)PSH_MQS_CHUNK * PSH_MQ_QDW * sizeof(unsigned) + (size_t)PSH_MQS_CHUNK * sizeof(float);
 }
 
 hipError_t launch_boot_mq(const ScanArgs& a, bool aligned, int grid_x, hipStream_t s) {

@@ -305,16 +305,16 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
         }
     }
     if (a.mq_frag) {
-        // this query's two zero-padded f16 copies for scan_mq_kernel (PSH_MQ_QDW = 48 dwords: copy c at dword 24 c, 20 dwords
-        // used): xpad[i] = -2 x~[i - 7] inside the query, 0 outside; dword d of copy c = (xpad[2 d + c], xpad[2 d + c + 1])
+        // this query's two zero-padded f16 copies for scan_mq_kernel (PSH_MQ_QDW = 40 dwords: copy c at dword 20 c):
+        // xpad[i] = -2 x~[i - 7] inside the query, 0 outside; dword d of copy c = (xpad[2 d + c], xpad[2 d + c + 1])
         __syncthreads();
         const float sc = a.qstate[b].mx_scale;             // thread 0 above; 0 = filter not armed
-        if (tid < 96) {
-            const int half = tid & 1, dw = tid >> 1, c = dw >= 24 ? 1 : 0, d = dw - 24 * c;
+        if (tid < 80) {
+            const int half = tid & 1, dw = tid >> 1, c = dw >= 20 ? 1 : 0, d = dw - 20 * c;
             const int j = 2 * d + c + half - 7;
-            const bool in = d < 20 && j >= 0 && j < a.prep.W;
+            const bool in = j >= 0 && j < a.prep.W;
             const float xv = in ? a.prep.queries[(int64_t)b * a.prep.W + j] : 0.0f;
-            reinterpret_cast<_Float16*>(a.mq_frag)[(int64_t)b * 96 + tid] = (_Float16)(in ? -2.0f * (xv * sc) : 0.0f);
+            reinterpret_cast<_Float16*>(a.mq_frag)[(int64_t)b * 80 + tid] = (_Float16)(in ? -2.0f * (xv * sc) : 0.0f);
         }
     }
 }
