@@ -526,7 +526,13 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
 // the kernel: profiles/r04_mq_ablations.txt).
 #define PSH_MQ_QDW 40
 #define PSH_MQ_CDW 20
-#define PSH_MQS_CHUNK 256
+#define PSH_MQS_CHUNK 512         // scan_mq_kernel: queries per pass over the ensemble
+#define PSH_MQB_CHUNK 256         // boot_mq_kernel (it keeps an fp32 tile of its own for segments beyond f16 range)
+// halves of LDS per wave of scan_mq_kernel: the two f16 arrays, or the fp32 tile that takes their place (whichever is larger)
+__host__ __device__ inline int mq_wave_halves(int tile_floats) {
+    const int t = 2 * tile_floats, h = 2 * PSH_MX_NHALF;
+    return ((t > h ? t : h) + 7) & ~7;
+}
 
 template <int WT, bool ALIGNED>
 __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
@@ -535,15 +541,20 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
     constexpr int NW = PSH_MQ_THREADS / 64;
     const int lane = lane_id();
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    float* tile = smem + (size_t)wave_in_block * a.tile_floats;
-    int* lcount = reinterpret_cast<int*>(smem + (size_t)NW * a.tile_floats);
+    int* lcount = reinterpret_cast<int*>(smem);
     int* next_unit = lcount + ((a.B + 3) & ~3);
     u32x4* pend0 = reinterpret_cast<u32x4*>(next_unit + 4);
     u32x4* pend = pend0 + (size_t)wave_in_block * PSH_PEND;
+    // A wave's f16 copies of its segment (y^, (y~^2)^) only feed the A fragments and the window energies, which stay in
+    // registers for the whole query loop: once those are read, the SAME LDS holds the segment's fp32 values for the exact
+    // rechecks (the tile is stored after the fragment reads, not before).  What the tile used to take -- 37 KB of the CU's
+    // 160 -- now holds the padded copies of a whole batch of 512 queries.
+    const int wave_halves = mq_wave_halves(a.tile_floats);
     _Float16* hbase = reinterpret_cast<_Float16*>(pend0 + (size_t)NW * PSH_PEND);
-    _Float16* a1 = hbase + (size_t)wave_in_block * 2 * PSH_MX_NHALF;      // y^
+    _Float16* a1 = hbase + (size_t)wave_in_block * wave_halves;          // y^
     _Float16* a2 = a1 + PSH_MX_NHALF;                                      // (y~^2)^
-    unsigned* fragL = reinterpret_cast<unsigned*>(hbase + (size_t)NW * 2 * PSH_MX_NHALF);   // [query of the chunk] x PSH_MQ_QDW dwords
+    float* tile = reinterpret_cast<float*>(a1);                            // (after the segment's fragments are in registers)
+    unsigned* fragL = reinterpret_cast<unsigned*>(hbase + (size_t)NW * wave_halves);   // [query of the chunk] x PSH_MQ_QDW dwords
     float* thrL = reinterpret_cast<float*>(fragL + (size_t)PSH_MQS_CHUNK * PSH_MQ_QDW);
     float* tauL = thrL + PSH_MQS_CHUNK;
     unsigned* sq = reinterpret_cast<unsigned*>(tauL + PSH_MQS_CHUNK) + (size_t)wave_in_block * PSH_MQ_QCAP;   // survivor queue
@@ -614,7 +625,6 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
         const int seg_start = (int)sg * PSH_SEG;
         const int r_global = (int)(row + a.r_offset);
 
-        stage_store(st, tile, nfloat, lane);
         float lmax = 0.0f, nanq = 0.0f;
         {
             const int nqd = (nfloat + 3) >> 2;
@@ -628,13 +638,16 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
                     nanq += (v2[0] + v2[1]) + (v2[2] + v2[3]);             // (v_max drops a NaN; a sum of squares keeps it)
                     *reinterpret_cast<f16x4*>(a1 + mx_half(4 * m)) = __builtin_convertvector(v, f16x4);
                     *reinterpret_cast<f16x4*>(a2 + mx_half(4 * m)) = __builtin_convertvector(v2, f16x4);
+                } else if (4 * m < PSH_MX_NHALF) {
+                    // the arrays' tail past the segment: zeros again (the previous segment's fp32 tile lay here, and the
+                    // banded product multiplies these slots by its zero taps: 0 x NaN would poison a row)
+                    *reinterpret_cast<f16x4*>(a1 + mx_half(4 * m)) = f16x4{0, 0, 0, 0};
+                    *reinterpret_cast<f16x4*>(a2 + mx_half(4 * m)) = f16x4{0, 0, 0, 0};
                 }
             }
         }
         wave_lds_fence();
         if (npend > 0) { pend_flush(pend, npend, lcount, a, lane); npend = 0; }
-        const unsigned un = grab();
-        if (un < u_hi) load_unit(st, un);
         // a value beyond f16 range, a NaN (the banded product spreads it over the 32 outputs of its A row -- 0 x NaN -- and the
         // minimum over a tile drops NaNs: clean windows beside it would be rejected unseen), or no armed filter: nothing may
         // be rejected in this segment
@@ -654,6 +667,12 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
             ny[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, bo[0], ny[g], 0, 0, 0);
             ny[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, bo[1], ny[g], 0, 0, 0);
         }
+        // the fragments are in registers: the segment's fp32 values take the arrays' place (for the exact rechecks), and only
+        // then is the next unit requested into the staging registers
+        wave_lds_fence();
+        stage_store(st, tile, nfloat, lane);
+        const unsigned un = grab();
+        if (un < u_hi) load_unit(st, un);
 
         // the exact chain for the queued survivors, one per lane
         auto drain = [&]() {
@@ -884,11 +903,11 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void boot_mq_kernel(ScanArgs a) {
     _Float16* a1 = hbase + (size_t)wave_in_block * 2 * PSH_MX_NHALF;
     _Float16* a2 = a1 + PSH_MX_NHALF;
     unsigned* fragL = reinterpret_cast<unsigned*>(hbase + (size_t)NW * 2 * PSH_MX_NHALF);   // [query of the chunk] x PSH_MQ_QDW dwords
-    float* nxL = reinterpret_cast<float*>(fragL + (size_t)PSH_MQS_CHUNK * PSH_MQ_QDW);       // nx~ per query of the chunk
+    float* nxL = reinterpret_cast<float*>(fragL + (size_t)PSH_MQB_CHUNK * PSH_MQ_QDW);       // nx~ per query of the chunk
 
     const int W = WT > 0 ? WT : a.W;
-    const int q0 = (int)blockIdx.y * PSH_MQS_CHUNK;
-    const int nq = (a.B - q0) < PSH_MQS_CHUNK ? (a.B - q0) : PSH_MQS_CHUNK;
+    const int q0 = (int)blockIdx.y * PSH_MQB_CHUNK;
+    const int nq = (a.B - q0) < PSH_MQB_CHUNK ? (a.B - q0) : PSH_MQB_CHUNK;
     const int ngroups = (nq + 3) >> 2;
     if (threadIdx.x == 0) { next_unit[0] = 0; next_unit[1] = 0; next_unit[2] = 0; }
     {
@@ -1117,21 +1136,21 @@ bool scan_mq_supported(int W, int B) { return W >= 1 && W <= 25 && B >= 2; }
 
 size_t scan_mq_shmem_bytes(int tile_floats, int B) {
     constexpr int NW = PSH_MQ_THREADS / 64;
-    return (size_t)tile_floats * NW * sizeof(float) + (size_t)(((B + 3) & ~3) + 4) * sizeof(int)
-           + (size_t)NW * PSH_PEND * 16 + (size_t)NW * 2 * PSH_MX_NHALF * sizeof(_Float16)
+    return (size_t)(((B + 3) & ~3) + 4) * sizeof(int)
+           + (size_t)NW * PSH_PEND * 16 + (size_t)NW * mq_wave_halves(tile_floats) * sizeof(_Float16)
            + (size_t)PSH_MQS_CHUNK * PSH_MQ_QDW * sizeof(unsigned) + (size_t)2 * PSH_MQS_CHUNK * sizeof(float)
            + (size_t)NW * PSH_MQ_QCAP * sizeof(unsigned);
 }
 
 int scan_mq_chunks(int B) { return (B + PSH_MQS_CHUNK - 1) / PSH_MQS_CHUNK; }
-int boot_mq_chunks(int B) { return (B + PSH_MQS_CHUNK - 1) / PSH_MQS_CHUNK; }
+int boot_mq_chunks(int B) { return (B + PSH_MQB_CHUNK - 1) / PSH_MQB_CHUNK; }
 
 bool boot_mq_supported(int W) { return W >= 1 && W <= 25; }
 
 size_t boot_mq_shmem_bytes(int tile_floats) {
     constexpr int NW = PSH_MQ_THREADS / 64;
     return (size_t)tile_floats * NW * sizeof(float) + 16 + (size_t)NW * 2 * PSH_MX_NHALF * sizeof(_Float16)
-           + (size_t)PSH_MQS_CHUNK * PSH_MQ_QDW * sizeof(unsigned) + (size_t)PSH_MQS_CHUNK * sizeof(float);
+           + (size_t)PSH_MQB_CHUNK * PSH_MQ_QDW * sizeof(unsigned) + (size_t)PSH_MQB_CHUNK * sizeof(float);
 }
 
 hipError_t launch_boot_mq(const ScanArgs& a, bool aligned, int grid_x, hipStream_t s) {

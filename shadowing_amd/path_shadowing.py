@@ -660,6 +660,9 @@ class PathShadowing:
         return np.concatenate(means), np.concatenate(stds)
 
 
+_MOMENT_CLASSES: dict = {}      # averaging class -> its avg / std ARE the weighted moments of its `weights` (probed once)
+
+
 def moment_weights(proba, B: int, k: int):
     """The (B, k) float64 weights of an averaging object IF its `avg` / `std` over axis 1 are the weighted moments
     sum_j w_j x_j and sqrt(sum_j w_j (x_j - mean)^2) of those weights: True for uniform weights 1/k, an array otherwise,
@@ -678,6 +681,9 @@ def moment_weights(proba, B: int, k: int):
         if w.shape != (B, k):
             return None
         w = np.ascontiguousarray(w)
+    verdict = _MOMENT_CLASSES.get(type(proba))               # the probe below runs once per averaging CLASS
+    if verdict is not None:
+        return (True if w is None else w) if verdict else None
     wf = np.full((B, k), 1.0 / k) if w is None else w
     j = np.arange(B * k * 2, dtype=np.float64).reshape(B, k, 2)
     probe = np.cos(0.37 * j) + 0.01 * j / (B * k)
@@ -687,11 +693,10 @@ def moment_weights(proba, B: int, k: int):
         return None
     m = (wf[:, :, None] * probe).sum(axis=1)
     v = np.sqrt((wf[:, :, None] * (probe - m[:, None, :]) ** 2).sum(axis=1))
-    if a.shape != m.shape or sd.shape != v.shape:
-        return None
-    if not (np.allclose(a, m, rtol=1e-10, atol=1e-13) and np.allclose(sd, v, rtol=1e-10, atol=1e-13)):
-        return None
-    return True if w is None else w
+    ok = (a.shape == m.shape and sd.shape == v.shape
+          and bool(np.allclose(a, m, rtol=1e-10, atol=1e-13) and np.allclose(sd, v, rtol=1e-10, atol=1e-13)))
+    _MOMENT_CLASSES[type(proba)] = ok
+    return (True if w is None else w) if ok else None
 
 
 class PendingShadow:
