@@ -498,6 +498,7 @@ class PreparedShadow:
                     buf[o_p:o_p + n_p].view(torch.float32).view(1, k, C_, W + h),
                     buf[o_i:o_i + n_i].view(torch.int32).view(1, k, 2),
                     buf[0:4].view(torch.int32))
+        self._carve = carve
         self.host = carve(self._res_host)
         self.d, self.paths, self.idx, self.status = self.host if host_direct else carve(self._res)
         if host_direct:
@@ -514,6 +515,27 @@ class PreparedShadow:
                            self.idx.data_ptr(), self.status.data_ptr(), ws.data_ptr(), ws.numel(), C.byref(self.prof)]
         self._gather_args = [dev.index, None, ds3.data_ptr(), ds3.shape[0], C_, ds3.shape[2], 0, self.idx.data_ptr(), k, W + h,
                              self.paths.data_ptr()]
+
+    # results of this size and more are HANDED to the caller instead of copied out of the slot's pinned buffer (host_direct
+    # slots): at k = 8192 the four numpy copies were 100 us of a 340 us shadow() call
+    HANDOVER_BYTES = 256 * 1024
+
+    def take(self):
+        """(d, paths, idx, status) of the finished call as numpy arrays the caller owns.  Small results are copied out of the
+        pinned buffer (12 us at k = 1024); large ones keep the buffer -- the arrays view it, it lives as long as they do -- and
+        the slot gets a fresh pinned buffer for its next call (torch's pinned-memory cache hands back the block a dropped
+        result returned: no allocation in a steady loop)."""
+        if self._res_host.numel() < self.HANDOVER_BYTES:
+            return tuple(t.numpy().copy() for t in self.host)
+        out = tuple(t.numpy() for t in self.host)
+        self._res_host = torch.empty(self._res_host.numel(), dtype=torch.uint8, pin_memory=True)
+        self.host = self._carve(self._res_host)
+        if self.host_direct:                                 # the kernels write the pinned buffer themselves: new addresses
+            self.host[3].zero_()
+            self.d, self.paths, self.idx, self.status = self.host
+            self._scan_args[12], self._scan_args[13], self._scan_args[14] = self.d.data_ptr(), self.idx.data_ptr(), self.status.data_ptr()
+            self._gather_args[7], self._gather_args[10] = self.idx.data_ptr(), self.paths.data_ptr()
+        return out
 
     def launch(self, stream: "torch.cuda.Stream", x_row: torch.Tensor) -> None:
         """x_row: (1, W) float32 CPU tensor.  Everything is enqueued on `stream`, the D2H copies of the results included."""

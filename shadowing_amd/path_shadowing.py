@@ -501,7 +501,7 @@ class PathShadowing:
         slot.launch(torch.cuda.current_stream(dev), x[:, 0, :])
         slot.event.synchronize()
         self.last_path = "hip"
-        hd, hp, hi, hs = (t.numpy().copy() for t in slot.host)
+        hd, hp, hi, hs = slot.take()
         if hs.any():
             if int(hs[0]) == _native.PSH_STATUS_RETRY:
                 self._workspace.arm()
@@ -724,7 +724,7 @@ class PendingShadow:
         if self._call is not None:
             self._event.synchronize()
             slot = self._payload
-            hd, hp, hi, hs = (t.numpy().copy() for t in slot.host)    # (the pinned buffers go back to the slot)
+            hd, hp, hi, hs = slot.take()                              # (small results: copies; large ones: the pinned buffer itself)
             slot.busy = False
             if hs.any():                                              # the status protocol: rare; the blocking path copes
                 x_context, k = self._call

@@ -1,7 +1,7 @@
 set -x
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r4j; mkdir -p $O
+O=$R/gpurun_out/r4l; mkdir -p $O
 timeout 1200 python -m pytest tests/test_gpu_batched.py tests/test_gpu_nonfinite.py tests/test_gpu_configs3.py tests/test_gpu_parity.py -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" | tail -8 > $O/tests.txt
 for i in 1 2; do timeout 120 python tools/q512_stages.py 2>/dev/null | grep "^{" >> $O/q512_stages.txt; done
 timeout 300 python bench.py --steps 20 --warmup 3 --queries 512 --no-cpu-baseline > $O/bench_q512.json 2> $O/bench_q512.err

@@ -64,4 +64,11 @@ for CTRS in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_
 done
 python $R/tools/summarize_pmc.py $OUT/emb | grep -E "^==|embed_px_kernel<true, 1|embed_mx_kernel<true, 1" > $OUT/embedded_pmc_summary.txt 2>&1
 cd $R
+# round 4: the headline on an ensemble EIGHT times the memory-side cache (2 GiB: the GB/s do not come from the 256 MB MALL),
+# the fused launch's skeleton (what one stream's step cannot go below), the batched scan's ablations, unaligned LDS reads
+timeout 600 python bench.py --steps 500 --warmup 20 --rows-per-gpu 131072 --no-cpu-baseline > $OUT/bench_n1_R131072.json 2>> $OUT/bench.err
+timeout 300 python tools/fused_skeleton.py > $OUT/fused_skeleton.json 2>> $OUT/bench.err
+python -m shadowing_amd._build --tuning > /dev/null 2>&1
+for d in 0 4 8; do echo "PSH_DBG=$d (0 the kernel; 4 no survivor handling; 8 MFMAs only: no epilogue)" >> $OUT/mq_ablations.txt; PSH_LIB=$R/shadowing_amd/lib/libpsh_hip_tuning.so PSH_DBG=$d timeout 120 python tools/q512_stages.py 2>/dev/null | grep "^{" >> $OUT/mq_ablations.txt; done
+hipcc --offload-arch=gfx950 -O3 -o /tmp/ubl tools/ubench_lds_unaligned.hip 2>/dev/null && /tmp/ubl > $OUT/ubench_lds_unaligned.txt 2>&1
 tail -c 600 $OUT/pmc_summary.txt; head -8 $OUT/kernel_stats.csv; cat $OUT/bench_n1.json
