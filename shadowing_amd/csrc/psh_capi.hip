@@ -834,6 +834,10 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
         if (gx < 1) gx = 1;
         n_blockmax = (int)gx * chunks;
         sa.mq_frag = w.mq_frag;
+        {   // (the rank the threshold kernel will select, below: an estimate's rank -> the minima may be estimates too)
+            const int64_t r2e = (4 * (int64_t)k * n_sample + 2 * p.R - 1) / (2 * p.R) + 8;
+            sa.boot_estimate = (r2e < k && r2e <= bp.entries) ? 1 : 0;
+        }
         HIP_TRY(launch_mq_prep(queries, B, p.W, w.mq_frag, s));
         HIP_TRY(launch_boot_mq(sa, p.aligned, (int)gx, s));
     } else if (rows_path) {

@@ -145,6 +145,7 @@ struct ScanArgs {
     int emb_dense;           // embedded scan: always the dense chains, even when the kernel has suffix rows (tests, PSH_EMBED=dense)
     int emb_taps;            // embedded scan, suffix rows: walk the taps even when the support is one interval (PSH_FLAG_EMBED_TAPS)
     int emb_mx;              // embedded scan: the dense kernel's rejection test on the matrix cores (embed_mx_kernel: BOOT / FILTER)
+    int boot_estimate;       // boot_mq_kernel: the minima feed an ESTIMATE of the level (values instead of upper bounds)
     int dbg;                 // tuning build only (PSH_DBG): timing ablations / scheduling experiments of the kernel at hand
     int emb_r1;              // prefix-sum scan: merged rows of the first phase, 0 = the plan's (tuning build: PSH_PX_R1)
     const struct EmbedPlan* plan;   // embedded scan, BOOT / FILTER: what embed_plan_kernel found in the matrix (nullable: dense chains / tap walk decided in the kernel)

@@ -527,7 +527,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_mx_kernel(ScanArgs a) {
 #define PSH_MQ_QDW 40
 #define PSH_MQ_CDW 20
 #define PSH_MQS_CHUNK 512         // scan_mq_kernel: queries per pass over the ensemble
-#define PSH_MQB_CHUNK 256         // boot_mq_kernel (it keeps an fp32 tile of its own for segments beyond f16 range)
+#define PSH_MQB_CHUNK 512         // boot_mq_kernel (it keeps an fp32 tile of its own for segments beyond f16 range: 156 KB of LDS in all)
 // halves of LDS per wave of scan_mq_kernel: the two f16 arrays, or the fp32 tile that takes their place (whichever is larger)
 __host__ __device__ inline int mq_wave_halves(int tile_floats) {
     const int t = 2 * tile_floats, h = 2 * PSH_MX_NHALF;
@@ -846,6 +846,7 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
 #define PSH_MQ_BOOT_OFF(B4) ((size_t)192 * (size_t)(B4))
 #define PSH_MQ_NX_OFF(B4) ((size_t)384 * (size_t)(B4))
 #define PSH_MQ_META_OFF(B4) ((size_t)392 * (size_t)(B4))
+#define PSH_MQ_PREP_Q 16          // queries per block of mq_prep_kernel (every block finds the batch's scale for itself)
 __global__ __launch_bounds__(1024) void mq_prep_kernel(const float* __restrict__ queries, int B, int W, void* mq) {
     __shared__ unsigned s_max;
     const int tid = (int)threadIdx.x;
@@ -853,7 +854,9 @@ __global__ __launch_bounds__(1024) void mq_prep_kernel(const float* __restrict__
     __syncthreads();
     unsigned mb = 0u;                                       // the largest |x| of the whole batch into [4, 8)
     for (int64_t j = tid; j < (int64_t)B * W; j += 1024) mb = max(mb, __float_as_uint(fabsf(queries[j])));
-    if (mb) atomicMax(&s_max, mb);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, off, 64));
+    if ((tid & 63) == 0 && mb) atomicMax(&s_max, mb);
     __syncthreads();
     const unsigned qmaxbits = s_max;
     const int sexp = 3 - ((int)((qmaxbits >> 23) & 255u) - 126);
@@ -864,7 +867,8 @@ __global__ __launch_bounds__(1024) void mq_prep_kernel(const float* __restrict__
     char* base = reinterpret_cast<char*>(mq);
     _Float16* tab = reinterpret_cast<_Float16*>(base + PSH_MQ_BOOT_OFF(B4));
     float* nx = reinterpret_cast<float*>(base + PSH_MQ_NX_OFF(B4));
-    for (int64_t i = tid; i < (int64_t)B4 * 2 * PSH_MQ_QDW; i += 1024) {
+    const int b_lo = (int)blockIdx.x * PSH_MQ_PREP_Q, b_hi = (b_lo + PSH_MQ_PREP_Q) < B4 ? (b_lo + PSH_MQ_PREP_Q) : B4;
+    for (int64_t i = (int64_t)b_lo * 2 * PSH_MQ_QDW + tid; i < (int64_t)b_hi * 2 * PSH_MQ_QDW; i += 1024) {
         const int b = (int)(i / (2 * PSH_MQ_QDW)), e = (int)(i - (int64_t)b * 2 * PSH_MQ_QDW);
         const int half = e & 1, dw = e >> 1, c = dw >= PSH_MQ_CDW ? 1 : 0, d = dw - PSH_MQ_CDW * c;
         const int j = 2 * d + c + half - 7;
@@ -872,13 +876,13 @@ __global__ __launch_bounds__(1024) void mq_prep_kernel(const float* __restrict__
         const float xv = in ? queries[(int64_t)b * W + j] : 0.0f;
         tab[i] = (_Float16)(in ? -2.0f * (xv * scale) : 0.0f);
     }
-    for (int b = tid; b < B4; b += 1024) {
+    for (int b = b_lo + tid; b < b_hi; b += 1024) {
         float sq = 0.0f;
         if (b < B)
             for (int j = 0; j < W; ++j) { const float v = queries[(int64_t)b * W + j] * scale; sq = __builtin_fmaf(v, v, sq); }
         nx[b] = sq;
     }
-    if (tid == 0) {
+    if (tid == 0 && blockIdx.x == 0) {
         float* meta = reinterpret_cast<float*>(base + PSH_MQ_META_OFF(B4));
         meta[0] = scale;
         meta[1] = unscale2;
@@ -886,7 +890,8 @@ __global__ __launch_bounds__(1024) void mq_prep_kernel(const float* __restrict__
 }
 
 hipError_t launch_mq_prep(const float* queries, int B, int W, void* mq, hipStream_t s) {
-    hipLaunchKernelGGL(mq_prep_kernel, dim3(1), dim3(1024), 0, s, queries, B, W, mq);
+    const int B4 = (B + 3) & ~3;
+    hipLaunchKernelGGL(mq_prep_kernel, dim3((unsigned)((B4 + PSH_MQ_PREP_Q - 1) / PSH_MQ_PREP_Q)), dim3(1024), 0, s, queries, B, W, mq);
     return hipGetLastError();
 }
 
@@ -936,8 +941,14 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void boot_mq_kernel(ScanArgs a) {
     const int n = lane & 31, hk = lane >> 5, qsub = n >> 3, shift = n & 7;
     const const_f32p xk = (const_f32p)a.queries;
     // acc~ <= (nx~ (1 + 3a) + t^ + b) / (1 - 2a), a = 2^-9, b = 2^-18; constants rounded up, fp32 slack included
-    const float C1 = 1.0f + 3.0f / 512.0f + 1.0f / 65536.0f, C2 = (1.0f / (1.0f - 2.0f / 512.0f)) * (1.0f + 1.0f / 32768.0f);
-    const float BB = 1.0f / 262144.0f;
+    // When the caller admits below an ESTIMATE anyway (a.boot_estimate: the r-th smallest minimum of a thin sample, a shortfall
+    // reported by the selection -- every large batch does), a minimum need not be an upper bound either: the value itself,
+    // nx~ + t^, is the better estimate of the segment's smallest acc -- the bound's 5a nx~ are ~5 % of an acc near the level,
+    // and the level's 10th power counts the candidates (4.4 k per query with bounds, 2.7 k with values, for k = 1024).
+    const bool est = a.boot_estimate != 0;
+    const float C1 = est ? 1.0f : 1.0f + 3.0f / 512.0f + 1.0f / 65536.0f;
+    const float C2 = est ? 1.0f : (1.0f / (1.0f - 2.0f / 512.0f)) * (1.0f + 1.0f / 32768.0f);
+    const float BB = est ? 0.0f : 1.0f / 262144.0f;
 
     f16x8 bo[2];
 #pragma unroll
@@ -1004,6 +1015,19 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void boot_mq_kernel(ScanArgs a) {
                 ny[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, bo[0], ny[g], 0, 0, 0);
                 ny[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, bo[1], ny[g], 0, 0, 0);
             }
+            if (ragged) {
+                // windows past the row's last admissible one: their ENERGY becomes +inf, once per unit -- it is the C operand of
+                // every group's MFMAs, so their accumulators are +inf in every group and no minimum sees them (masking the 64
+                // accumulators group after group made the last segment of every row four times as long as the others: the
+                // bootstrap's 179 us per launch at 512 queries were its ragged units)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int p = 256 * g + 8 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + shift;
+                        ny[g][r] = (seg_start + p < a.Tp) ? ny[g][r] : __uint_as_float(PSH_INF_BITS);
+                    }
+            }
             unsigned frag_addr = (unsigned)(size_t)(fragL + qsub * PSH_MQ_QDW + ((7 - shift) & 1) * PSH_MQ_CDW + ((7 - shift + 8 * hk) >> 1));
 #pragma unroll 1
             for (int G = 0; G < ngroups; ++G, frag_addr += 4 * PSH_MQ_QDW * 4) {
@@ -1028,23 +1052,21 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void boot_mq_kernel(ScanArgs a) {
                 for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fy[g][1], b1, acc[g], 0, 0, 0);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    if (ragged) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int p = 256 * g + 8 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + shift;
-                            acc[g][r] = (seg_start + p < a.Tp) ? acc[g][r] : __uint_as_float(PSH_INF_BITS);
-                        }
-                    }
                     float m2 = fminf(fminf(acc[g][0], acc[g][1]), acc[g][2]);
 #pragma unroll
                     for (int i = 3; i + 1 < 16; i += 2) m2 = fminf(fminf(m2, acc[g][i]), acc[g][i + 1]);
                     mn = fminf(mn, fminf(m2, acc[g][15]));
                 }
-                // lanes of one query: 8 shifts x 2 halves
-                mn = fminf(mn, __shfl_xor(mn, 1, 64));
-                mn = fminf(mn, __shfl_xor(mn, 2, 64));
-                mn = fminf(mn, __shfl_xor(mn, 4, 64));
-                mn = fminf(mn, __shfl_xor(mn, 32, 64));
+                // lanes of one query: 8 shifts x 2 halves.  On the DPP path of the vector ALUs (quad_perm [1,0,3,2], [2,3,0,1],
+                // row_half_mirror: lane i <-> 7 - i of its 8) and one v_permlane32_swap for the halves: four dependent
+                // ds_bpermute round trips per group were most of this kernel's time (179 us per launch at 512 queries)
+                mn = fminf(mn, __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(mn), 0xB1, 0xf, 0xf, false)));
+                mn = fminf(mn, __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(mn), 0x4E, 0xf, 0xf, false)));
+                mn = fminf(mn, __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(mn), 0x141, 0xf, 0xf, false)));
+                {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mn), __float_as_uint(mn), false, false);
+                    mn = fminf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));      // lane l: min of lanes l % 32 and l % 32 + 32
+                }
                 if (shift == 0 && hk == 0 && ql < nq) {
                     const float ub = (__builtin_fmaf(nxL[ql], C1, mn) + BB) * C2;      // scaled units, >= acc~
                     a.minbuf[(int64_t)(q0 + ql) * a.min_stride + (int64_t)u] = ub * unscale2;
