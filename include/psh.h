@@ -115,6 +115,12 @@ extern "C" {
  * single stream is better served by the fused launch (the default).  Same results, same status protocol
  * (PSH_STATUS_RETRY -> rerun with PSH_FLAG_NO_FUSE); one workspace per stream, armed by psh_workspace_init. */
 #define PSH_FLAG_OVERLAP      2048
+/* MQ_F16: psh_scan_topk with a batch of queries (W <= 25): the rejection test of the batched scan as the f16 banded product
+ * of rounds 2-4 (two K = 16 steps per tile) instead of the 8-bit product (one K = 32 step; the default since round 4).  The
+ * 8-bit test puts every query of the batch on ONE quantisation step: a batch whose queries differ in amplitude by more than
+ * ~4x is better served by f16 (a much smaller query keeps too many windows for its exact recheck -- slower, never wrong).
+ * Same results either way (A/B tests; callers that know their batch). */
+#define PSH_FLAG_MQ_F16       4096
 typedef struct psh_profile {
     int   mode;           /* in */
     int   flags;          /* in: PSH_FLAG_* */

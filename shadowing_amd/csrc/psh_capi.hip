@@ -211,11 +211,12 @@ struct Plan { int grid; int n_qgroups; int q_per_group; int tile_floats; int wid
 // Launch-geometry overrides and device-side time stamps for the scripts under tools/: compiled into the
 // tuning build only (-DPSH_TUNING, `python -m shadowing_amd._build --tuning`).  The product library reads no
 // environment variable and takes no pointer from anywhere but its arguments.
-struct Tuning { int dbg; int px_r1; int wide_min; bool narrow; int bpc; int rows_frac; unsigned long long* dbg_times; unsigned long long* dbg_select; int xcd_skew; int stream_pgrid_per_cu; int stream_skip; int stream_units; int stream_rgrid_per_cu; };
+struct Tuning { int mq_i8; int dbg; int px_r1; int wide_min; bool narrow; int bpc; int rows_frac; unsigned long long* dbg_times; unsigned long long* dbg_select; int xcd_skew; int stream_pgrid_per_cu; int stream_skip; int stream_units; int stream_rgrid_per_cu; };
 inline Tuning tuning() {
-    Tuning t{0, 0, PSH_EMB_WIDE_MIN_B, false, 0, 64, nullptr, nullptr, PSH_FUSED_XCD_SKEW, 2, 0, 2048, 2};
+    Tuning t{1, 0, 0, PSH_EMB_WIDE_MIN_B, false, 0, 64, nullptr, nullptr, PSH_FUSED_XCD_SKEW, 2, 0, 2048, 2};
 #ifdef PSH_TUNING
     if (const char* e = getenv("PSH_DBG")) t.dbg = atoi(e);
+    if (const char* e = getenv("PSH_MQ_I8")) t.mq_i8 = atoi(e) != 0;                  // batched scan: 0 = the f16 rejection test (A/B)
     if (const char* e = getenv("PSH_PX_R1")) { const int v = atoi(e); if (v >= 2) t.px_r1 = v; }   // prefix-sum scan: rows of the first phase (a large value: one phase)
     if (const char* e = getenv("PSH_EMBED_WIDE_MIN_B")) { const int v = atoi(e); if (v >= 1) t.wide_min = v; }
     t.narrow = getenv("PSH_EMBED_NARROW") != nullptr;
@@ -628,6 +629,8 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     bool use_mx = !p.ker && scan_mx_supported(p.W, p.B);
     bool use_mq = !p.ker && scan_mq_supported(p.W, p.B);      // batched queries: 4 queries x 8 shifts per MFMA
     if (flags_of(profile) & PSH_FLAG_FILTER_VALU) use_mx = use_mq = false;
+    // the batched scan's rejection test: the 8-bit product (scan_mq8_kernel) unless the caller asks for f16
+    const bool mq_i8 = tuning().mq_i8 != 0 && !(flags_of(profile) & PSH_FLAG_MQ_F16);
     // (half-segment mode measured for the single-query scan: bootstrap 17.4 -> 12.3 us, but tau admits twice as
     // much and the scan's exact rechecks cost 4.3 us more -- 135.7 vs 134.3 us per step; left off)
     // (the matrix-core embedded scan samples one minimum per HALF segment; a sample too thin for that plan is taken by
@@ -886,7 +889,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
         if (r2 < k && r2 <= bp.entries) k_thr = (int)r2;
     }
     ThresholdArgs ta{w.minbuf, w.min_stride, (int)bp.entries, w.qstate, k_thr, 0,
-                     (use_mx || use_mq) ? w.blockmax : nullptr, n_blockmax, use_mq ? w.mq_frag : nullptr, rank2, pa};
+                     (use_mx || use_mq) ? w.blockmax : nullptr, n_blockmax, use_mq ? w.mq_frag : nullptr, mq_i8 ? 1 : 0, rank2, pa};
     HIP_TRY(launch_threshold(ta, B, s));
     rc = tm.mark(); if (rc) return rc;                                       // 3
 
@@ -923,6 +926,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
         (void)chunks;
         nblk = (int)gx;
         fa.mq_frag = w.mq_frag;
+        fa.mq_i8 = mq_i8 ? 1 : 0;
         fa.slice = w.cap / nblk;
         HIP_TRY(launch_scan_mq(fa, p.aligned, (int)gx, s));
     } else if (rows_path) {

@@ -98,7 +98,7 @@ __device__ __forceinline__ void prep_query(const PrepArgs& a, int b) {
         q.mx_thr = __uint_as_float(PSH_INF_BITS);
         q.tau2_bits = PSH_INF_BITS;                   // = tau until the threshold kernel estimates it
         q.mx_thr2 = __uint_as_float(PSH_INF_BITS);
-        q.pad[0] = q.pad[1] = q.pad[2] = 0;
+        q.mx8_P = q.mx8_L = q.mx8_k1 = 0.0f;         // (the 8-bit test likewise)
         a.qstate[b] = q;
         a.total[b] = 0;
         if (a.status) a.status[b] = PSH_STATUS_OK_;
@@ -331,15 +331,32 @@ __device__ __forceinline__ float min3f(float a, float b, float c) {
 // The maximum of a non-negative value over the wave, in every lane (uniform): four DPP steps inside the rows of 16 lanes, then the
 // four rows through SGPRs -- no trip through the LDS crossbar (six dependent ds_bpermute are ~100+ cycles each beside a busy LDS).
 __device__ __forceinline__ float wave_max_nonneg(float x) {
+    // (as integers: non-negative floats order like their bit patterns, and an integer maximum needs no quieting of its operands
+    //  -- fmaxf() cost a v_max x, x per operand and kept the DPP move a separate instruction; old = 0 with bound_ctrl lets the
+    //  compiler fold the move into the v_max_i32 itself)
     int v = __float_as_int(x);
-    auto step = [&](int moved) { v = __float_as_int(fmaxf(__int_as_float(v), __int_as_float(moved))); };
-    step(__builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));    // quad_perm [1, 0, 3, 2]
-    step(__builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));    // quad_perm [2, 3, 0, 1]
-    step(__builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));   // row_half_mirror
-    step(__builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));   // row_mirror
+    auto step = [&](int moved) { v = v > moved ? v : moved; };
+    step(__builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));     // quad_perm [1, 0, 3, 2]
+    step(__builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));     // quad_perm [2, 3, 0, 1]
+    step(__builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));    // row_half_mirror
+    step(__builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));    // row_mirror
+    const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    const int m01 = r0 > r1 ? r0 : r1, m23 = r2 > r3 ? r2 : r3;
+    return __int_as_float(m01 > m23 ? m01 : m23);
+}
+// The sum of a value over the wave, in every lane (uniform), the same way: pairs, quads, half rows, rows by DPP, the four rows
+// through SGPRs.  (The order of the additions is not the lane order: callers that bound a rounding error allow for any order.)
+__device__ __forceinline__ float wave_sum_dpp(float x) {
+    int v = __float_as_int(x);
+    auto step = [&](int moved) { v = __float_as_int(__int_as_float(v) + __int_as_float(moved)); };
+    step(__builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));     // quad_perm [1, 0, 3, 2]
+    step(__builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));     // quad_perm [2, 3, 0, 1]
+    step(__builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));    // row_half_mirror
+    step(__builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));    // row_mirror
     const float r0 = __int_as_float(__builtin_amdgcn_readlane(v, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(v, 16));
     const float r2 = __int_as_float(__builtin_amdgcn_readlane(v, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(v, 48));
-    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+    return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }   // v_max3_f32, as above
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
@@ -433,6 +450,7 @@ __device__ __forceinline__ int mx_half(int idx) {
 // written out at the top of the next iteration, BEFORE the next prefetch is issued.
 #define PSH_PEND 64                       // entries per wave: one flush lane each
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void pend_flush(const u32x4* pend, int npend, int* lcount, const ScanArgs& a, int lane) {

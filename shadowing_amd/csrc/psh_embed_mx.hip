@@ -94,7 +94,7 @@ __host__ __device__ inline size_t emx_shmem_bytes(int K, int d, int B, int tile_
     n = n > n8 ? n : n8;
     n += (size_t)d * ((K + 3) & ~3) * sizeof(float);                                  // the fp32 kernel (exact verification), rows padded to 16 bytes
     n += (size_t)(PSH_EMX_THREADS / 64) * ((size_t)2 * m.nhalf * sizeof(_Float16) + (size_t)(PSH_EMX_TILE ? tile_floats : 0) * sizeof(float)
-                                           + (size_t)PSH_PEND * 16 + (size_t)PSH_EMX_QCAP * 4 + 64 * 4);
+                                           + (size_t)PSH_PEND * 16 + (size_t)PSH_EMX_QCAP * 8 + 64 * 4);
     n += (size_t)(((B + 3) & ~3) + 8) * sizeof(int) + 64;
     // the per-query pass on the matrix cores (B <= PSH_EMX_QM_MAX_B): scaled f16 query coordinates, per-query constants,
     // a wave's transposed window energies
@@ -137,14 +137,15 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
     float* kerF = reinterpret_cast<float*>(bh + bop_halves);                            // d x Kst fp32
     char* pw = reinterpret_cast<char*>(kerF) + (size_t)d * Kst * 4;
     const int tile_fl = PSH_EMX_TILE ? a.tile_floats : 0;
-    const size_t per_wave = (size_t)2 * dm.nhalf * 2 + (size_t)tile_fl * 4 + (size_t)PSH_PEND * 16 + (size_t)PSH_EMX_QCAP * 4 + 64 * 4;
+    const size_t per_wave = (size_t)2 * dm.nhalf * 2 + (size_t)tile_fl * 4 + (size_t)PSH_PEND * 16 + (size_t)PSH_EMX_QCAP * 8 + 64 * 4;
     char* mine = pw + (size_t)wave * per_wave;
     _Float16* yh = reinterpret_cast<_Float16*>(mine);
     _Float16* yl = yh + dm.nhalf;
     float* tile = reinterpret_cast<float*>(yl + dm.nhalf);
     u32x4* pend = reinterpret_cast<u32x4*>(tile + tile_fl);
     unsigned* sq = reinterpret_cast<unsigned*>(pend + PSH_PEND);
-    float* Dl = reinterpret_cast<float*>(sq + PSH_EMX_QCAP);                            // 4 survivors x 16 row differences
+    unsigned* squ = sq + PSH_EMX_QCAP;                                                  // ... and the (row, segment) index of the unit that queued it
+    float* Dl = reinterpret_cast<float*>(squ + PSH_EMX_QCAP);                           // 4 survivors x 16 row differences
     int* lcount = reinterpret_cast<int*>(pw + (size_t)NW * per_wave);
     int* ctl = lcount + ((a.B + 3) & ~3);                                               // [0] work cursor, [1] max|ker| bits, [2] cerr^2, [3] max ||ker_i||_1 (float bits)
     const int Bp = (a.B + 3) & ~3;
@@ -262,22 +263,34 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
     const int scol = lane & 15, kq = lane >> 4;                                         // column = shift s (and A row), K quarter
 
     // exact verification of the queued survivors: lane (e, i) runs row i of survivor e (4 per pass), the oracle's order:
-    // hy_i = fma chain over all K taps, D_i = hx_i - hy_i, acc = fma chain over i
-    auto verify_impl = [&](int seg_start, int r_global, const float* yrow, auto fast_c) {
+    // hy_i = fma chain over all K taps, D_i = hx_i - hy_i, acc = fma chain over i.
+    // A queue entry carries the (row, segment) index of the unit that found it: at a unit's end only WHOLE passes of four run,
+    // the last one to three survivors wait for the next units' (a pass costs the same 6 - 8 k cycles for one survivor as for
+    // four, and a unit finds 0.5 on average -- 0.41 passes per unit became 0.13); the last unit of the wave flushes.
+    auto coords = [&](unsigned rsu, int& seg_start_e, int64_t& row_e) {
+        const unsigned ri2 = fast_div(rsu, a.magic_nseg, (unsigned)a.nseg);
+        seg_start_e = (int)(rsu - ri2 * (unsigned)a.nseg) * PSH_SEG;
+        row_e = a.row0 + (int64_t)ri2 * a.row_stride;
+    };
+    auto verify_impl = [&](bool whole_passes_only, auto fast_c) {
         constexpr bool FAST = decltype(fast_c)::value;
         wave_lds_fence();
         const int el = lane >> 4, il = lane & 15;
+        const int n_run = whole_passes_only ? (nsq & ~3) : nsq;
 #pragma unroll 1
-        for (int e0 = 0; e0 < nsq; e0 += 4) {
-            const bool lv = e0 + el < nsq;
+        for (int e0 = 0; e0 < n_run; e0 += 4) {
+            const bool lv = e0 + el < n_run;
             const unsigned ent = lv ? sq[e0 + el] : 0u;
             const int pwin = (int)(ent & 4095u), b = (int)(ent >> 12);
+            int seg_start_e;
+            int64_t row_e;
+            coords(lv ? squ[e0 + el] : 0u, seg_start_e, row_e);
             float hy = 0.0f;
             if constexpr (!FAST) {
                 // (mid-unit, a full queue -- rare: the accumulators are live, so the chain reads memory tap by tap and needs no registers)
                 if (lv && il < d) {
                     const float* kr = kerF + il * Kst;
-                    const float* yw = yrow + seg_start + pwin;
+                    const float* yw = a.dataset + row_e * a.T + seg_start_e + pwin;
                     for (int j = 0; j < K; ++j) hy = __builtin_fmaf(kr[j], yw[j], hy);
                     Dl[el * 16 + il] = __fsub_rn(a.hx[(int64_t)b * d + il], hy);
                 }
@@ -292,12 +305,18 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                 {
                     float v[16];
 #pragma unroll
-                    for (int m = 0; m < 16; ++m) {                              // survivor m >> 2, taps lane + 64 (m & 3)
-                        const int e2 = e0 + (m >> 2);
-                        const int pw2 = (int)((e2 < nsq ? sq[e2] : sq[e0]) & 4095u);
-                        int j = lane + 64 * (m & 3);
-                        j = j < K ? j : K - 1;
-                        v[m] = yrow[seg_start + pw2 + j];
+                    for (int m4 = 0; m4 < 4; ++m4) {                            // survivor m4, taps lane + 64 (0 .. 3)
+                        const int e2 = e0 + m4 < n_run ? e0 + m4 : e0;
+                        int ss2;
+                        int64_t row2;
+                        coords(squ[e2], ss2, row2);
+                        const float* yw2 = a.dataset + row2 * a.T + ss2 + (int)(sq[e2] & 4095u);
+#pragma unroll
+                        for (int m1 = 0; m1 < 4; ++m1) {
+                            int j = lane + 64 * m1;
+                            j = j < K ? j : K - 1;
+                            v[4 * m4 + m1] = yw2[j];
+                        }
                     }
                     wave_lds_fence();                                           // the pass before this one has read ys
 #pragma unroll
@@ -355,15 +374,23 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
             }
             if (hit) {
                 const int slot = npend + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                pend[slot] = u32x4{__float_as_uint(ea), (unsigned)r_global, (unsigned)(seg_start + pwin), (unsigned)b};
+                pend[slot] = u32x4{__float_as_uint(ea), (unsigned)(int)(row_e + a.r_offset), (unsigned)(seg_start_e + pwin), (unsigned)b};
             }
             npend += nh;
         }
-        nsq = 0;
+        // the survivors that wait: to the front of the queue
+        const int left = nsq - n_run;
+        unsigned keep0 = 0u, keep1 = 0u;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                        // (an address taken here, not one kept in a register across the unit)
+        if (ln < left) { keep0 = sq[n_run + ln]; keep1 = squ[n_run + ln]; }
+        wave_lds_fence();
+        if (ln < left) { sq[ln] = keep0; squ[ln] = keep1; }
+        nsq = left;
         wave_lds_fence();
     };
-    auto verify = [&](int seg_start, int r_global, const float* yrow) { verify_impl(seg_start, r_global, yrow, std::false_type{}); };
-    auto verify_end = [&](int seg_start, int r_global, const float* yrow) { verify_impl(seg_start, r_global, yrow, std::true_type{}); };
+    auto verify = [&]() { verify_impl(false, std::false_type{}); };
+    auto verify_end = [&](bool whole_passes_only) { verify_impl(whole_passes_only, std::true_type{}); };
 
     auto grab = [&]() -> unsigned {
         int v0 = 0;
@@ -425,7 +452,8 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
             if (MODE == PSH_MODE_FILTER && PSH_EMX_TILE) stage_store(st, tile, nfloat, lane);
 #pragma unroll
             for (int q = 0; q < PSH_NSTAGE; ++q) {
-                const int m = lane + 64 * q;
+                int m = lane + 64 * q;
+                if (q == PSH_NSTAGE - 1) asm volatile("" : "+v"(m));   // (the partial stage's address: computed here, not kept -- spilled -- across the unit)
                 if (q < PSH_NSTAGE - 1 || m < nq) {
                     const f32x4 v = st.v[q] * sy;
                     const f16x4v hi = __builtin_convertvector(v, f16x4v);
@@ -723,10 +751,12 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                         const unsigned long long sm = __ballot(has);
                         if (!sm) continue;
                         const int ne = __popcll(sm);
-                        if (nsq + ne > PSH_EMX_QCAP) verify(seg_start, r_global, a.dataset + row * a.T);
-                        if (has)
-                            sq[nsq + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u))] =
-                                (unsigned)p | ((unsigned)qn << 12);
+                        if (nsq + ne > PSH_EMX_QCAP) verify();
+                        if (has) {
+                            const int slot = nsq + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u));
+                            sq[slot] = (unsigned)p | ((unsigned)qn << 12);
+                            squ[slot] = (unsigned)__builtin_amdgcn_readfirstlane((int)rs);
+                        }
                         nsq += ne;
                     }
                 }
@@ -792,10 +822,12 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                         const unsigned long long sm = __ballot(has);
                         if (!sm) continue;
                         const int ne = __popcll(sm);
-                        if (nsq + ne > PSH_EMX_QCAP) verify(seg_start, r_global, a.dataset + row * a.T);
-                        if (has)
-                            sq[nsq + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u))] =
-                                (unsigned)p | ((unsigned)b << 12);
+                        if (nsq + ne > PSH_EMX_QCAP) verify();
+                        if (has) {
+                            const int slot = nsq + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u));
+                            sq[slot] = (unsigned)p | ((unsigned)b << 12);
+                            squ[slot] = (unsigned)__builtin_amdgcn_readfirstlane((int)rs);
+                        }
                         nsq += ne;
                     }
                 }
@@ -804,9 +836,10 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
             tstamp(2);
         }
 #ifdef PSH_TUNING
-        tcount[0] += (unsigned)nsq; tcount[1] += (unsigned)((nsq + 3) >> 2);
+        tcount[0] += (unsigned)(un < u_hi ? (nsq & ~3) : nsq); tcount[1] += (unsigned)(un < u_hi ? (nsq >> 2) : ((nsq + 3) >> 2));
 #endif
-        if (MODE == PSH_MODE_FILTER && nsq > 0) verify_end(seg_start, r_global, a.dataset + row * a.T);   // (the accumulators are dead here: the register-hungry fast chain)
+        // (the accumulators are dead here: the register-hungry fast chain; whole passes of four while more units follow)
+        if (MODE == PSH_MODE_FILTER && (un < u_hi ? nsq >= 4 : nsq > 0)) verify_end(un < u_hi);
         if (LATE) {
             asm volatile("" ::"v"(touched));                                                               // (the touch has landed: one register across the unit)
             load_unit(st, un < u_hi ? un : u);             // (unconditionally: a segment kept "as it was" would be live across the whole unit)

@@ -300,8 +300,7 @@ __device__ __forceinline__ float prefix_store(const Stage& st, float* dst, int n
         carry += (double)__uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(inc), 63));
         if (on || m == nq) *reinterpret_cast<f32x4*>(dst + 4 * m) = E;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ab += __shfl_xor(ab, off, 64);
+    ab = wave_sum_dpp(ab);                                   // (DPP + SGPRs: six dependent ds_bpermute were ~100 cycles each)
     return ab * 1.0001f;                                     // (its own fp32 rounding: ~30 u)
 }
 
@@ -414,8 +413,7 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
             asum = prefix_store(st, tile, nfloat, lane);     // the tile holds E, not y
         }
         wave_lds_fence();
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, off, 64));
+        ymax = wave_max_nonneg(ymax);
         // radius of the cheap embedding around the exact one: the exact chain's own rounding (ymax), the prefix sums'
         // (two entries per running sum, each within PSH_PX_SCAN_OPS u asum; cerr_p = 2 u ||c||_2 with its margin)
         const float err = __builtin_fmaf(ymax, cerr_y, asum * ((float)PSH_PX_SCAN_OPS * cerr_p));
@@ -666,17 +664,22 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
             // windows of the lane at or below `thr` (or NaN) as a bit mask.  The common case -- none of the 16 -- costs a
             // minimum and two comparisons, not 16 (fminf drops a NaN; the sum of the non-negative values keeps it).
             auto below = [&](int g, float thr) -> unsigned {
-                float mn = acc[g][0][0];
+                // (v_min3 on the values as they are: fminf() quiets every operand first, 16 more instructions per query and unit)
+                const float m0 = min3f(acc[g][0][0], acc[g][0][1], acc[g][1][0]), m1 = min3f(acc[g][1][1], acc[g][2][0], acc[g][2][1]);
+                const float m2 = min3f(acc[g][3][0], acc[g][3][1], acc[g][4][0]), m3 = min3f(acc[g][4][1], acc[g][5][0], acc[g][5][1]);
+                const float m4 = min3f(acc[g][6][0], acc[g][6][1], acc[g][7][0]);
+                const float mn = min3f(min3f(m0, m1, m2), min3f(m3, m4, acc[g][7][1]), __uint_as_float(PSH_INF_BITS));
                 f32x2 sm2 = acc[g][0];
-#pragma unroll
-                for (int w = 1; w < PSH_L; ++w) mn = fminf(mn, acc[g][w >> 1][w & 1]);
 #pragma unroll
                 for (int w = 1; w < 8; ++w) sm2 += acc[g][w];
                 const float sm1 = sm2[0] + sm2[1];
                 unsigned hm = 0u;
                 if (__any(!(mn > thr) || !(sm1 == sm1))) {
+                    // (a compare and an add-with-carry per window, hm = 2 hm + [!(acc > thr)], from the last window down: the
+                    //  compiler's select + or3 form is 3.5 instructions per window)
 #pragma unroll
-                    for (int w = 0; w < PSH_L; ++w) hm |= !(acc[g][w >> 1][w & 1] > thr) ? (1u << w) : 0u;
+                    for (int w = PSH_L - 1; w >= 0; --w)
+                        asm volatile("v_cmp_ngt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hm) : "v"(acc[g][w >> 1][w & 1]), "v"(thr) : "vcc");
                     hm &= vmask;
                 }
                 return hm;

@@ -661,7 +661,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_fused_kernel(ScanArgs a
             QueryState q;
             q.xn = xn; q.tau_bits = __float_as_uint(tau2); q.n_valid = good ? a.k : 0; q.nx = 0.0f;
             q.thr_base = __uint_as_float(PSH_INF_BITS); q.mx_scale = scale; q.mx_thr = thr2;
-            q.tau2_bits = __float_as_uint(tau2); q.mx_thr2 = thr2; q.pad[0] = q.pad[1] = q.pad[2] = 0;
+            q.tau2_bits = __float_as_uint(tau2); q.mx_thr2 = thr2; q.mx8_P = q.mx8_L = q.mx8_k1 = 0.0f;
             a.qstate[0] = q;
         }
         // every block has read the epoch long ago (they all passed the first barrier): the next launch's tags

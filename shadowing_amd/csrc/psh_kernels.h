@@ -32,8 +32,12 @@ struct QueryState {   // one per query, device, 48 bytes
     unsigned tau2_bits;   // ESTIMATE of the k-th smallest acc with a 2x margin (<= tau): candidates below it go to the
                           //   front of a block's slice, the rest of the admitted ones to its back (see select_kernel)
     float mx_thr2;        // the matrix-core rejection threshold that goes with tau2 (<= mx_thr)
-    int pad[3];
+    // the 8-bit rejection test of the batched scan (scan_mq8_kernel; zero = not armed): a segment quantised with step
+    // s_y rejects a window iff  C_w - sum x^ y^  >  mx8_P / s_y + mx8_L   (integers; C_w = floor(mx8_k1 ny / s_y))
+    float mx8_P, mx8_L;
+    float mx8_k1;         // the same for every query of the batch (the kernel reads query 0's)
 };
+static_assert(sizeof(QueryState) == 48, "QueryState is 48 bytes (the host side mirrors it)");
 #define PSH_UNVERIFIED_BITS 0xffffffffu   // cand_d of a back-list entry whose exact distance was not computed by the scan
 
 #define PSH_MAX_BLOCKS 2048          // upper bound of the scan grid
@@ -146,6 +150,7 @@ struct ScanArgs {
     int emb_taps;            // embedded scan, suffix rows: walk the taps even when the support is one interval (PSH_FLAG_EMBED_TAPS)
     int emb_mx;              // embedded scan: the dense kernel's rejection test on the matrix cores (embed_mx_kernel: BOOT / FILTER)
     int boot_estimate;       // boot_mq_kernel: the minima feed an ESTIMATE of the level (values instead of upper bounds)
+    int mq_i8;               // batched scan: the rejection test as an 8-bit product (scan_mq8_kernel; mq_frag holds its int8 table)
     int dbg;                 // tuning build only (PSH_DBG): timing ablations / scheduling experiments of the kernel at hand
     int emb_r1;              // prefix-sum scan: merged rows of the first phase, 0 = the plan's (tuning build: PSH_PX_R1)
     const struct EmbedPlan* plan;   // embedded scan, BOOT / FILTER: what embed_plan_kernel found in the matrix (nullable: dense chains / tap walk decided in the kernel)
@@ -184,6 +189,7 @@ struct ThresholdArgs {
     const float* blockmax;   // nullable: per-block max |y| of the bootstrap scan
     int n_blockmax;
     void* mq_frag;           // nullable: B-fragment table of scan_mq_kernel, (B rounded up to 4) x 256 f16
+    int mq_i8;               // ... as the int8 table and per-query constants of scan_mq8_kernel instead
     int rank2;               // > 0: also estimate tau2 = the rank2-th smallest minimum (two-class candidate slices)
     PrepArgs prep;           // the per-query preparation runs here too (one launch less on the sampled path)
 };

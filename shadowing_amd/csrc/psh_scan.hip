@@ -742,6 +742,9 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
 #endif
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fy[g][0], b0, ny[g], 0, 0, 0);
+#ifdef PSH_TUNING
+            if (!(dbg & 32))                                               // ablation: ONE K-step (what an 8-bit product would issue; results invalid)
+#endif
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fy[g][1], b1, acc[g], 0, 0, 0);
 #ifdef PSH_TUNING
@@ -815,6 +818,320 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq_kernel(ScanArgs a) {
                 }
             }
             if (nsq >= 64) drain();                                        // the ONE in-loop call site (the body is ~200 instructions)
+        }
+        if (nsq > 0) drain();
+        wave_lds_fence();  // all lanes done with the tile before it is overwritten
+        u = un;
+    }
+    if (npend > 0) pend_flush(pend, npend, lcount, a, lane);
+    __syncthreads();
+    for (int q = q0 + (int)threadIdx.x; q < q0 + nq; q += PSH_MQ_THREADS)          // this block's queries only
+        a.bcount[(int64_t)q * PSH_MAX_BLOCKS + blockIdx.x] = lcount[q];
+}
+
+// ----------------------------------------------------------------------------------
+// the same scan with the rejection test as an 8-BIT product (round 4)
+// ----------------------------------------------------------------------------------
+// scan_mq_kernel issues two K = 16 steps of f16 per tile for 20 useful taps of 32, and the matrix cores are what bounds it
+// (75 % busy at the clock the part sustains under that load).  v_mfma_i32_32x32x32_i8 takes the whole band, K = 32, in ONE
+// instruction at the same issue rate: half the MFMAs, half the fragment bytes (4 operand registers per tile and per query
+// group instead of 8), and an integer accumulator whose only error is the quantisation itself -- which is bounded
+// rigorously (threshold_kernel, "scan_mq8_kernel"): the data of a segment on its own step s_y = max|y~| / 127, the queries
+// on one step for the batch, the window energies (f16 squares, as before) turned into the MFMA's integer C operand, and a
+// window is rejected iff  C_w - sum x^ y^  >  P_q / s_y + L_q.  The margin that buys -- ~9 % of the level at the benchmark's
+// sizes, 2.2x the survivors of the f16 test -- costs less than the MFMAs it saves.
+// The queries' copies: 4 per query, shifted by 0..3 BYTES, 10 dwords each (PSH_MQ8_CDW), queries PSH_MQ8_QDW = 40 dwords
+// apart: lane (query, shift, hk) reads dwords (o >> 2) + 4 hk .. + 3 of copy o & 3, o = 7 - shift, as two ds_read2_b32; the
+// 32 lanes of a pass fall on banks {0, 1, 10, 11, 20, 21, 30, 31} + 8 q mod 32 -- all different.
+#define PSH_MQ8_QDW 40
+#define PSH_MQ8_CDW 10
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+typedef int i32x16v __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ int imin3(int a, int b, int c) { const int m = a < b ? a : b; return m < c ? m : c; }   // v_min3_i32
+__device__ __forceinline__ int tile_min16_i(const i32x16v& t) {
+    const int m0 = imin3(t[0], t[1], t[2]), m1 = imin3(t[3], t[4], t[5]), m2 = imin3(t[6], t[7], t[8]);
+    const int m3 = imin3(t[9], t[10], t[11]), m4 = imin3(t[12], t[13], t[14]);
+    return imin3(imin3(m0, m1, m2), imin3(m3, m4, t[15]), 0x7fffffff);
+}
+
+template <int WT, bool ALIGNED>
+__global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq8_kernel(ScanArgs a) {
+    static_assert(WT >= 0 && WT <= 25, "query + 7 shifts must fit K = 32 (WT = 0: run-time W <= 25)");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NW = PSH_MQ_THREADS / 64;
+    const int lane = lane_id();
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int* lcount = reinterpret_cast<int*>(smem);
+    int* next_unit = lcount + ((a.B + 3) & ~3);                           // [0] the work cursor, [1] the batch's k1 (float bits)
+    u32x4* pend0 = reinterpret_cast<u32x4*>(next_unit + 4);
+    u32x4* pend = pend0 + (size_t)wave_in_block * PSH_PEND;
+    // a wave's LDS: the segment's signed bytes y^ (PSH_MX_NHALF of them) and the f16 squares behind them, for as long as the
+    // A fragments and the energies are being read; the segment's fp32 values for the exact rechecks afterwards (as in
+    // scan_mq_kernel: the tile is stored after the fragment reads)
+    const int wave_halves = mq_wave_halves(a.tile_floats);
+    _Float16* hbase = reinterpret_cast<_Float16*>(pend0 + (size_t)NW * PSH_PEND);
+    _Float16* a1 = hbase + (size_t)wave_in_block * wave_halves;
+    signed char* a8 = reinterpret_cast<signed char*>(a1);                  // y^
+    _Float16* a2 = a1 + PSH_MX_NHALF;                                      // (y~^2)^
+    float* tile = reinterpret_cast<float*>(a1);
+    unsigned* fragL = reinterpret_cast<unsigned*>(hbase + (size_t)NW * wave_halves);   // [query of the chunk] x PSH_MQ8_QDW dwords
+    f32x2* plL = reinterpret_cast<f32x2*>(fragL + (size_t)PSH_MQS_CHUNK * PSH_MQ8_QDW);     // {P, L} per query
+    float* tauL = reinterpret_cast<float*>(plL + PSH_MQS_CHUNK);
+    unsigned* sq = reinterpret_cast<unsigned*>(tauL + PSH_MQS_CHUNK) + (size_t)wave_in_block * PSH_MQ_QCAP;   // survivor queue
+    const int W = WT > 0 ? WT : a.W;
+    int npend = 0;
+    int nsq = 0;
+
+    const int q0 = (int)blockIdx.y * PSH_MQS_CHUNK;                        // this block's queries: [q0, q0 + nq)
+    const int nq = (a.B - q0) < PSH_MQS_CHUNK ? (a.B - q0) : PSH_MQS_CHUNK;
+    const int ngroups = (nq + 3) >> 2;
+    if (threadIdx.x == 0) { next_unit[0] = 0; next_unit[1] = 0; }
+    for (int q = (int)threadIdx.x; q < a.B; q += PSH_MQ_THREADS) lcount[q] = 0;
+    __syncthreads();
+    {
+        unsigned* z = reinterpret_cast<unsigned*>(a1);
+        for (int i = lane; i < PSH_MX_NHALF; i += 64) z[i] = 0u;
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.mq_frag) + (size_t)q0 * (PSH_MQ8_QDW / 4);
+        f32x4* dst = reinterpret_cast<f32x4*>(fragL);
+        for (int i = (int)threadIdx.x; i < 4 * ngroups * (PSH_MQ8_QDW / 4); i += PSH_MQ_THREADS)
+            dst[i] = i < nq * (PSH_MQ8_QDW / 4) ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = (int)threadIdx.x; i < 4 * ngroups; i += PSH_MQ_THREADS) {
+            // a query whose test is not armed (no level yet, a non-finite sample): P = +inf keeps everything; so do the
+            // places past the end of the batch in the last group -- their lanes never queue anything (lane_ok)
+            const float k1q = i < nq ? a.qstate[q0 + i].mx8_k1 : 0.0f;
+            f32x2 plq = f32x2{__uint_as_float(PSH_INF_BITS), 0.0f};
+            if (k1q > 0.0f) plq = f32x2{a.qstate[q0 + i].mx8_P, a.qstate[q0 + i].mx8_L};
+            plL[i] = plq;
+            tauL[i] = i < nq ? __uint_as_float(a.qstate[q0 + i].tau_bits) : 0.0f;
+            if (k1q > 0.0f) atomicMax(reinterpret_cast<unsigned*>(next_unit + 1), __float_as_uint(k1q));   // (the armed queries all hold the same value)
+        }
+    }
+    __syncthreads();
+
+    const int nfloat = PSH_SEG + W - 1;
+    const unsigned n_rs = (unsigned)a.n_rows * (unsigned)a.nseg;
+    const unsigned u_lo = (unsigned)(((unsigned long long)n_rs * blockIdx.x) / gridDim.x);
+    const unsigned u_hi = (unsigned)(((unsigned long long)n_rs * (blockIdx.x + 1)) / gridDim.x);
+    typedef const __attribute__((address_space(4))) QueryState* const_qsp;
+    const float scale = ((const_qsp)a.qstate)[0].mx_scale;                // one f16 / 8-bit scale domain for the whole batch
+    const float k1 = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(next_unit[1]));
+    const int n = lane & 31, hk = lane >> 5, qsub = n >> 3, shift = n & 7;
+
+    f16x8 bo[2];                                                           // the band of ones (window energies)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = 16 * s + 8 * hk + i - shift;
+            bo[s][i] = (_Float16)((j >= 0 && j < W) ? 1.0f : 0.0f);
+        }
+
+    auto grab = [&]() -> unsigned {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(next_unit, 1);
+        return u_lo + (unsigned)__builtin_amdgcn_readfirstlane(v);
+    };
+    auto load_unit = [&](Stage& sx, unsigned uu) {
+        const unsigned ri = fast_div(uu, a.magic_nseg, (unsigned)a.nseg);
+        const unsigned sg = uu - ri * (unsigned)a.nseg;
+        stage_load<ALIGNED>(sx, a.dataset + (a.row0 + (int64_t)ri * a.row_stride) * a.T, a.T, (int)sg * PSH_SEG, nfloat, lane);
+    };
+
+#ifdef PSH_TUNING
+    const int dbg = __builtin_amdgcn_readfirstlane(a.dbg);
+#endif
+    Stage st;
+    unsigned u = grab();
+    if (u < u_hi) load_unit(st, u);
+    while (u < u_hi) {
+        const unsigned ri = fast_div(u, a.magic_nseg, (unsigned)a.nseg);
+        const unsigned sg = u - ri * (unsigned)a.nseg;
+        const int64_t row = a.row0 + (int64_t)ri * a.row_stride;
+        const int seg_start = (int)sg * PSH_SEG;
+        const int r_global = (int)(row + a.r_offset);
+
+        // pass 1 over the staged segment: the f16 squares, the largest |y~|, a sum that keeps a NaN
+        float lmax = 0.0f, nanq = 0.0f;
+        const int nqd = (nfloat + 3) >> 2;
+#pragma unroll
+        for (int q = 0; q < PSH_NSTAGE; ++q) {
+            const int m = lane + 64 * q;
+            if (q < PSH_NSTAGE - 1 || m < nqd) {
+                const f32x4 v = st.v[q] * scale;
+                const f32x4 v2 = v * v;
+                lmax = fmaxf(fmaxf(lmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                nanq += (v2[0] + v2[1]) + (v2[2] + v2[3]);
+                *reinterpret_cast<f16x4*>(a2 + mx_half(4 * m)) = __builtin_convertvector(v2, f16x4);
+            } else if (4 * m < PSH_MX_NHALF) {
+                *reinterpret_cast<f16x4*>(a2 + mx_half(4 * m)) = f16x4{0, 0, 0, 0};   // (the previous segment's fp32 tile lay here: 0 x NaN)
+            }
+        }
+        const float lm = wave_max_nonneg(lmax);                            // (per-lane maxima are never NaN: fmaxf drops it)
+        // nothing may be rejected in this segment: a value beyond the f16 range of the squares, a NaN, no armed filter
+        const bool keep_all = !(lm <= 128.0f) || __any(!(nanq == nanq)) || !(scale > 0.0f) || !(k1 > 0.0f);
+        // the segment's step: s_y = max(|y~|, 2^-6) / 127 (a floor keeps the f16 squares' subnormal tail below one unit)
+        const float inv_sy = 127.0f / fmaxf(lm, 0.015625f);
+        // pass 2: y^ = round-to-nearest-even of y~ / s_y through the 1.5 * 2^23 trick (the fma rounds the EXACT product to an
+        // integer: |y^ - y~ / s_y| <= 1/2, what the bound assumes), four to a dword
+#pragma unroll
+        for (int q = 0; q < PSH_NSTAGE; ++q) {
+            const int m = lane + 64 * q;
+            if (q < PSH_NSTAGE - 1 || m < nqd) {
+                const f32x4 v = st.v[q] * scale;
+                const unsigned r0 = __float_as_uint(__builtin_fmaf(v[0], inv_sy, 12582912.0f)), r1 = __float_as_uint(__builtin_fmaf(v[1], inv_sy, 12582912.0f));
+                const unsigned r2 = __float_as_uint(__builtin_fmaf(v[2], inv_sy, 12582912.0f)), r3 = __float_as_uint(__builtin_fmaf(v[3], inv_sy, 12582912.0f));
+                const unsigned w01 = __builtin_amdgcn_perm(r1, r0, 0x0c0c0400u), w23 = __builtin_amdgcn_perm(r3, r2, 0x04000c0cu);
+                *reinterpret_cast<unsigned*>(a8 + 4 * m) = w01 | w23;
+            } else if (4 * m < PSH_MX_NHALF) {
+                *reinterpret_cast<unsigned*>(a8 + 4 * m) = 0u;
+            }
+        }
+        wave_lds_fence();
+        if (npend > 0) { pend_flush(pend, npend, lcount, a, lane); npend = 0; }
+
+        // window energies of the 4 row groups -> the integer C operand, and the y^ fragments, once per segment
+        i32x16v cw[4];
+        i32x4v fy[4];
+        {
+            const float kC = inv_sy * k1;                                  // C_w = floor(ny kC), clamped: the product stays in 32 bits
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f16x8 e0 = *reinterpret_cast<const f16x8*>(a2 + mx_half(256 * g + 8 * n + 8 * hk));
+                const f16x8 e1 = *reinterpret_cast<const f16x8*>(a2 + mx_half(256 * g + 8 * n + 16 + 8 * hk));
+                const u32x2 y0 = *reinterpret_cast<const u32x2*>(a8 + 256 * g + 8 * n + 16 * hk);
+                const u32x2 y1 = *reinterpret_cast<const u32x2*>(a8 + 256 * g + 8 * n + 16 * hk + 8);
+                fy[g] = i32x4v{(int)y0[0], (int)y0[1], (int)y1[0], (int)y1[1]};
+                f32x16 ny;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) ny[i] = 0.0f;
+                ny = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, bo[0], ny, 0, 0, 0);
+                ny = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, bo[1], ny, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) cw[g][i] = (int)fminf(ny[i] * kC, 1073741824.0f);   // (ny >= 0; a NaN -- keep_all -- becomes 0)
+            }
+        }
+        wave_lds_fence();
+        stage_store(st, tile, nfloat, lane);
+        const unsigned un = grab();
+        if (un < u_hi) load_unit(st, un);
+
+        // the exact chain for the queued survivors, one per lane
+        auto drain = [&]() {
+            wave_lds_fence();                                              // other lanes' queue entries
+            while (nsq > 0) {
+                const int m = nsq < 64 ? nsq : 64;
+                nsq -= m;
+                bool hit = lane < m;
+                const unsigned e = hit ? sq[nsq + lane] : 0u;
+                const int p = (int)(e & 0xffffu), ql2 = (int)(e >> 16);
+                hit = hit && (seg_start + p < a.Tp);
+                float v = 0.0f;
+                if (hit) {
+                    const float* xq = a.queries + (int64_t)(q0 + ql2) * W;       // (rare path: the exact query comes from memory)
+#pragma unroll
+                    for (int j2 = 0; j2 < W; ++j2) {
+                        const float D = __fsub_rn(xq[j2], tile[lds_pad(p + j2)]);
+                        v = __builtin_fmaf(D, D, v);
+                    }
+                    hit = v < tauL[ql2];
+                }
+                const unsigned long long mask = __ballot(hit);
+                if (!mask) continue;
+                const int nh = __popcll(mask);
+                if (npend + nh > PSH_PEND) {
+                    pend_flush(pend, npend, lcount, a, lane);
+                    npend = 0;
+                    wave_lds_fence();
+                }
+                if (hit) {
+                    const int slot = npend + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                 __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    pend[slot] = u32x4{__float_as_uint(v), (unsigned)r_global, (unsigned)(seg_start + p), (unsigned)(q0 + ql2)};
+                }
+                npend += nh;
+            }
+            wave_lds_fence();                                              // queue slots are reused
+        };
+
+        const int o = 7 - shift;
+        unsigned frag_addr = (unsigned)(size_t)(fragL + qsub * PSH_MQ8_QDW + (o & 3) * PSH_MQ8_CDW + (o >> 2) + 4 * hk);
+        const f32x2* plp = plL + qsub;
+#pragma unroll 1
+        for (int G = 0; G < ngroups; ++G, frag_addr += 4 * PSH_MQ8_QDW * 4, plp += 4) {
+            // (by hand, as in scan_mq_kernel: the compiler would fold the adjacent dwords into one 4-byte-aligned ds_read_b128)
+            u32x2 f0, f1;
+            asm volatile("ds_read2_b32 %0, %2 offset1:1\n\t"
+                         "ds_read2_b32 %1, %2 offset0:2 offset1:3\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(f0), "=&v"(f1) : "v"(frag_addr) : "memory");
+            const i32x4v bq = i32x4v{(int)f0[0], (int)f0[1], (int)f1[0], (int)f1[1]};
+            // the level in the product's units for THIS segment's step, rounded towards "keep" by the constants' margins;
+            // the clamp keeps the conversion inside 32 bits (beyond it: reject nothing / reject everything, as it should)
+            const f32x2 pl = *plp;
+            const int thr = keep_all ? 0x7fffffff
+                                     : (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(pl[0], inv_sy, pl[1]), -2147483520.0f, 2147483520.0f);
+            i32x16v acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fy[g], bq, cw[g], 0, 0, 0);
+#ifdef PSH_TUNING
+            if (dbg & 8) {                                                 // ablation: no epilogue (results invalid)
+                asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]));
+                continue;
+            }
+#endif
+            int mn[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mn[g] = tile_min16_i(acc[g]);
+            if (!__any(!(imin3(imin3(mn[0], mn[1], mn[2]), mn[3], mn[3]) > thr))) continue;
+#ifdef PSH_TUNING
+            if (dbg & 4) continue;                                         // ablation: no survivor handling (results invalid)
+#endif
+            // survivors are only QUEUED here (window, query); the queue is drained 64 at a time (scan_mq_kernel)
+            const int ql = 4 * G + qsub;                                   // this lane's query within the chunk
+            const bool lane_ok = ql < nq;
+            const int nsq0 = nsq;
+            bool full = false;                                             // wave-uniform
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (!__any(!(mn[g] > thr))) continue;
+                unsigned hm = 0u;                                          // hm = 2 hm + [acc <= thr], from the last register down
+#pragma unroll
+                for (int r = 15; r >= 0; --r)
+                    asm volatile("v_cmp_le_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hm) : "v"(acc[g][r]), "v"(thr) : "vcc");
+                if (!lane_ok) hm = 0u;
+                for (;;) {
+                    const bool act = hm != 0u;
+                    const unsigned long long M = __ballot(act);
+                    if (!M) break;
+                    const int nh = __popcll(M);
+                    if (nsq + nh > PSH_MQ_QCAP) { full = true; break; }
+                    if (act) {
+                        const int r = (int)__builtin_ctz(hm);
+                        hm &= hm - 1u;
+                        const int p = 256 * g + 8 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + shift;
+                        const int slot = nsq + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(M >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo((unsigned)M, 0u));
+                        sq[slot] = ((unsigned)ql << 16) | (unsigned)p;
+                    }
+                    nsq += nh;
+                }
+            }
+            if (full) {
+                // more survivors in one group than the queue holds: forget the group's entries and run its queries exactly
+                nsq = nsq0;
+                const int t_lane = seg_start + PSH_L * lane;
+                int nvalid = a.Tp - t_lane;
+                nvalid = nvalid < 0 ? 0 : (nvalid > PSH_L ? PSH_L : nvalid);
+#pragma unroll 1
+                for (int c = 0; c < 4; ++c) {
+                    const int ql2 = 4 * G + c;
+                    if (ql2 >= nq) break;
+                    float accv[PSH_L];
+                    accumulate16<WT>(tile, lane, (const_f32p)a.queries + (int64_t)(q0 + ql2) * W, W, accv);
+                    emit16<PSH_MODE_FILTER>(a, q0 + ql2, accv, nvalid, lane, u, r_global, t_lane, tauL[ql2], 0.0f, pend, npend, lcount);
+                }
+            }
+            if (nsq >= 64) drain();
         }
         if (nsq > 0) drain();
         wave_lds_fence();  // all lanes done with the tile before it is overwritten
@@ -1160,7 +1477,7 @@ size_t scan_mq_shmem_bytes(int tile_floats, int B) {
     constexpr int NW = PSH_MQ_THREADS / 64;
     return (size_t)(((B + 3) & ~3) + 4) * sizeof(int)
            + (size_t)NW * PSH_PEND * 16 + (size_t)NW * mq_wave_halves(tile_floats) * sizeof(_Float16)
-           + (size_t)PSH_MQS_CHUNK * PSH_MQ_QDW * sizeof(unsigned) + (size_t)2 * PSH_MQS_CHUNK * sizeof(float)
+           + (size_t)PSH_MQS_CHUNK * PSH_MQ_QDW * sizeof(unsigned) + (size_t)3 * PSH_MQS_CHUNK * sizeof(float)   // (8-bit test: {P, L} per query)
            + (size_t)NW * PSH_MQ_QCAP * sizeof(unsigned);
 }
 
@@ -1188,6 +1505,13 @@ hipError_t launch_boot_mq(const ScanArgs& a, bool aligned, int grid_x, hipStream
 hipError_t launch_scan_mq(const ScanArgs& a, bool aligned, int grid_x, hipStream_t s) {
     const size_t shmem = scan_mq_shmem_bytes(a.tile_floats, a.B);
     const dim3 grid(grid_x, scan_mq_chunks(a.B));
+    if (a.mq_i8) {
+        if (a.W == 20)
+            return aligned ? launch_big_lds(scan_mq8_kernel<20, true>, grid, PSH_MQ_THREADS, shmem, s, a)
+                           : launch_big_lds(scan_mq8_kernel<20, false>, grid, PSH_MQ_THREADS, shmem, s, a);
+        return aligned ? launch_big_lds(scan_mq8_kernel<0, true>, grid, PSH_MQ_THREADS, shmem, s, a)
+                       : launch_big_lds(scan_mq8_kernel<0, false>, grid, PSH_MQ_THREADS, shmem, s, a);
+    }
     if (a.W == 20)
         return aligned ? launch_big_lds(scan_mq_kernel<20, true>, grid, PSH_MQ_THREADS, shmem, s, a)
                        : launch_big_lds(scan_mq_kernel<20, false>, grid, PSH_MQ_THREADS, shmem, s, a);

@@ -187,7 +187,8 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
     const float* v = a.minbuf + (int64_t)b * a.min_stride;
     const int n = a.n_entries;
     __shared__ unsigned s_maxbits;                         // largest |value| among the sampled data and this query
-    if (tid == 0) { prep_query(a.prep, b); s_maxbits = 0u; sm.prefix_b = ~0ull; }   // ||x||, sum of squares, state reset
+    __shared__ unsigned s_xmaxbits, s_e2bits, s_nxbits;    // 8-bit test: largest |x| of the batch, largest quantisation residue, largest ||x||^2
+    if (tid == 0) { prep_query(a.prep, b); s_maxbits = 0u; s_xmaxbits = 0u; s_e2bits = 0u; s_nxbits = 0u; sm.prefix_b = ~0ull; }   // ||x||, sum of squares, state reset
     __syncthreads();                                       // (block-scope visibility of qstate[b] for thread 0 below)
     if (a.blockmax) {
         unsigned mb = 0u;                                  // non-negative floats order as their bit patterns
@@ -195,9 +196,12 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
         // batched matrix-core scan: ONE scale for all queries (they share the f16 copy of the data)
         const int64_t xlo = a.mq_frag ? 0 : (int64_t)b * a.prep.W;
         const int64_t xhi = a.mq_frag ? (int64_t)a.prep.B * a.prep.W : xlo + a.prep.W;
+        unsigned xb = 0u;
         for (int64_t j = xlo + tid; j < xhi; j += PSH_SELECT_THREADS)
-            mb = max(mb, __float_as_uint(fabsf(a.prep.queries[j])));
+            xb = max(xb, __float_as_uint(fabsf(a.prep.queries[j])));
+        mb = max(mb, xb);
         if (mb) atomicMax(&s_maxbits, mb);
+        if (xb) atomicMax(&s_xmaxbits, xb);
         __syncthreads();
     }
     if (n < a.k) return;                                   // tau stays +inf (host avoids this)
@@ -304,7 +308,81 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
             if (Tf == Tf && Tf < qs->mx_thr) qs->mx_thr2 = Tf;
         }
     }
-    if (a.mq_frag) {
+    if (a.mq_frag && a.mq_i8) {
+        // scan_mq8_kernel: the queries as signed bytes on ONE step s_x for the batch (they share the data's 8-bit copy), the
+        // rejection level of this query in the product's integer units, and this query's four byte-shifted copies.
+        // With x~ = s_x x^ + ex, y~ = s_y y^ + ey (|ey| <= s_y / 2: y^ = round-to-nearest of y~ / s_y, exactly), c = sum x~ y~:
+        //     c <= s_x s_y sum x^ y^ + (s_x s_y / 2) ||x^||_1 + ||ex||_2 sqrt(ny),     2 E sqrt(ny) <= beta ny + E^2 / beta,
+        // so a window the exact chain admits -- ny - 2 c < Theta := tau (1 + 2^-16) - nx -- satisfies, in units of 2 s_x s_y,
+        //     (1 - beta) ny / (2 s_x s_y) - sum x^ y^  <  (Theta + E^2 / beta) / (2 s_x s_y) + ||x^||_1 / 2.
+        // E = the largest ||ex||_2 of the batch and beta = E / the largest ||x~||_2 (clamped) are the same in every block (maxima
+        // taken through integer atomics: no summation order), so the window side -- C_w, the MFMA's C operand -- is one
+        // for all queries.  Everything is evaluated in double and rounded towards "keep".
+        __syncthreads();
+        const float sc = a.qstate[b].mx_scale;             // thread 0 above; 0 = filter not armed
+        const float xm = __uint_as_float(s_xmaxbits) * sc;
+        const bool armed = sc > 0.0f && xm > 0.0f && xm < __uint_as_float(PSH_INF_BITS);
+        const float inv_sx = armed ? 127.0f / xm : 0.0f;
+        const double s_x = armed ? 1.0 / (double)inv_sx : 0.0;
+        const int W = a.prep.W;
+        auto quant = [&](float xv) -> int {                // x^ of a scaled sample (the same expression wherever it is needed)
+            int q = (int)rintf((xv * sc) * inv_sx);
+            return q > 127 ? 127 : (q < -127 ? -127 : q);
+        };
+        if (armed) {
+            for (int q = tid; q < a.prep.B; q += PSH_SELECT_THREADS) {
+                const float* xq = a.prep.queries + (int64_t)q * W;
+                double e2 = 0.0, nxq = 0.0;
+                for (int j = 0; j < W; ++j) {
+                    const double xs = (double)(xq[j] * sc);
+                    const double r = xs - s_x * (double)quant(xq[j]);
+                    e2 += r * r;
+                    nxq += xs * xs;
+                }
+                float e2f = (float)e2, nxf = (float)nxq;
+                if ((double)e2f < e2) e2f = __uint_as_float(__float_as_uint(e2f) + 1u);      // rounded up (non-negative)
+                if ((double)nxf < nxq) nxf = __uint_as_float(__float_as_uint(nxf) + 1u);
+                atomicMax(&s_e2bits, __float_as_uint(e2f));
+                atomicMax(&s_nxbits, __float_as_uint(nxf));
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            QueryState* qs = a.qstate + b;
+            const unsigned tb = qs->tau_bits;
+            const double E2 = (double)__uint_as_float(s_e2bits), NX = (double)__uint_as_float(s_nxbits);
+            if (armed && tb < PSH_INF_BITS && NX > 0.0 && E2 < (double)__uint_as_float(PSH_INF_BITS)) {
+                double beta = sqrt(E2 / NX);
+                beta = beta < 1.0 / 4096.0 ? 1.0 / 4096.0 : (beta > 0.25 ? 0.25 : beta);
+                const float* xq = a.prep.queries + (int64_t)b * W;
+                double nxs = 0.0, l1 = 0.0;
+                for (int j = 0; j < W; ++j) { const double xs = (double)(xq[j] * sc); nxs += xs * xs; l1 += fabs((double)quant(xq[j])); }
+                const double taus = (double)__uint_as_float(tb) * (double)sc * (double)sc;
+                const double Theta = taus * (1.0 + 1.0 / 65536.0) - nxs * (1.0 - 1e-12);
+                double P = (Theta + E2 * (1.0 + 1e-6) / beta) / (2.0 * s_x);
+                P = P > 0.0 ? P * (1.0 + 1.0 / 1048576.0) : P * (1.0 - 1.0 / 1048576.0);    // (the kernel's fma rounds: 2^-24 of the result)
+                float Pf = (float)P;
+                if ((double)Pf < P) Pf = __uint_as_float(Pf >= 0.0f ? __float_as_uint(Pf) + 1u : __float_as_uint(Pf) - 1u);
+                // + 3: the truncating conversion to an integer, the strict comparison, the f16 squares' subnormal tail
+                const float Lf = (float)(0.5 * l1 + 3.5) * (1.0f + 1.0f / 65536.0f);
+                // the window side from below: the energies come from f16 squares (2^-11 each: 2^-8 covers them with room)
+                float k1 = (float)((1.0 - beta) * (1.0 - 1.0 / 256.0) / (2.0 * s_x) * (1.0 - 1.0 / 1048576.0));
+                if (Pf == Pf && fabsf(Pf) < __uint_as_float(PSH_INF_BITS) && k1 > 0.0f && k1 < __uint_as_float(PSH_INF_BITS)) {
+                    qs->mx8_P = Pf;
+                    qs->mx8_L = Lf;
+                    qs->mx8_k1 = k1;
+                }
+            }
+        }
+        // four byte-shifted copies of xpad = 7 zeros, -x^ (W <= 25 samples), zeros: copy c at dword PSH_MQ8_CDW c holds
+        // xpad[i + c] in byte i (PSH_MQ8_QDW = 40 dwords per query, as the f16 table)
+        if (tid < 160) {
+            const int c = tid / 40, i = tid - 40 * c;
+            const int j = i + c - 7;
+            const bool in = armed && j >= 0 && j < W;
+            reinterpret_cast<signed char*>(a.mq_frag)[(int64_t)b * 160 + tid] = (signed char)(in ? -quant(a.prep.queries[(int64_t)b * W + j]) : 0);
+        }
+    } else if (a.mq_frag) {
         // this query's two zero-padded f16 copies for scan_mq_kernel (PSH_MQ_QDW = 40 dwords: copy c at dword 20 c):
         // xpad[i] = -2 x~[i - 7] inside the query, 0 outside; dword d of copy c = (xpad[2 d + c], xpad[2 d + c + 1])
         __syncthreads();

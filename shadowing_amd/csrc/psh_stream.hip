@@ -548,7 +548,7 @@ void stream_rank_kernel(ScanArgs a, FusedArgs f) {
             qs.xn = __uint_as_float(sc->xn_bits[q]); qs.tau_bits = sc->tau2_bits[q]; qs.n_valid = good ? a.k : 0; qs.nx = 0.0f;
             qs.thr_base = __uint_as_float(PSH_INF_BITS); qs.mx_scale = __uint_as_float(sc->scale_bits);
             qs.mx_thr = __uint_as_float(sc->thr2_bits[q]); qs.tau2_bits = sc->tau2_bits[q]; qs.mx_thr2 = qs.mx_thr;
-            qs.pad[0] = qs.pad[1] = qs.pad[2] = 0;
+            qs.mx8_P = qs.mx8_L = qs.mx8_k1 = 0.0f;
             a.qstate[q] = qs;
         }
     }
