@@ -878,6 +878,8 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq8_kernel(ScanArgs a) {
     f32x2* plL = reinterpret_cast<f32x2*>(fragL + (size_t)PSH_MQS_CHUNK * PSH_MQ8_QDW);     // {P, L} per query
     float* tauL = reinterpret_cast<float*>(plL + PSH_MQS_CHUNK);
     unsigned* sq = reinterpret_cast<unsigned*>(tauL + PSH_MQS_CHUNK) + (size_t)wave_in_block * PSH_MQ_QCAP;   // survivor queue
+    int* thrI = reinterpret_cast<int*>(reinterpret_cast<unsigned*>(tauL + PSH_MQS_CHUNK) + (size_t)NW * PSH_MQ_QCAP)
+                + (size_t)wave_in_block * PSH_MQS_CHUNK;                  // the wave's segment: every query's level in the product's units
     const int W = WT > 0 ? WT : a.W;
     int npend = 0;
     int nsq = 0;
@@ -986,6 +988,14 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq8_kernel(ScanArgs a) {
                 *reinterpret_cast<unsigned*>(a8 + 4 * m) = 0u;
             }
         }
+        // every query's level for THIS segment's step, in the product's units, rounded towards "keep" by the constants'
+        // margins; the clamp keeps the conversion inside 32 bits (beyond it: reject nothing / everything, as it should).
+        // Once per segment and query here instead of once per group and lane in the loop.
+        for (int i = lane; i < 4 * ngroups; i += 64) {
+            const f32x2 pl = plL[i];
+            thrI[i] = keep_all ? 0x7fffffff
+                               : (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(pl[0], inv_sy, pl[1]), -2147483520.0f, 2147483520.0f);
+        }
         wave_lds_fence();
         if (npend > 0) { pend_flush(pend, npend, lcount, a, lane); npend = 0; }
 
@@ -993,7 +1003,8 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq8_kernel(ScanArgs a) {
         i32x16v cw[4];
         i32x4v fy[4];
         {
-            const float kC = inv_sy * k1;                                  // C_w = floor(ny kC), clamped: the product stays in 32 bits
+            // C_w = floor(ny kC) <= 2^30 (ny <= 32 * 128^2 where anything may be rejected: the product stays in 32 bits)
+            const float kC = fminf(inv_sy * k1, 2048.0f);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f16x8 e0 = *reinterpret_cast<const f16x8*>(a2 + mx_half(256 * g + 8 * n + 8 * hk));
@@ -1007,7 +1018,7 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq8_kernel(ScanArgs a) {
                 ny = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, bo[0], ny, 0, 0, 0);
                 ny = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, bo[1], ny, 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) cw[g][i] = (int)fminf(ny[i] * kC, 1073741824.0f);   // (ny >= 0; a NaN -- keep_all -- becomes 0)
+                for (int i = 0; i < 16; ++i) cw[g][i] = (int)fminf(ny[i] * kC, 1073741824.0f);   // (ny >= 0; the clamp only matters under keep_all: inf, NaN)
             }
         }
         wave_lds_fence();
@@ -1053,26 +1064,34 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq8_kernel(ScanArgs a) {
             wave_lds_fence();                                              // queue slots are reused
         };
 
+        // The group loop.  The next group's fragment and level are requested right behind this group's MFMAs and waited for
+        // at the top of the next turn: an LDS round trip per group would otherwise sit between a wave's tests and its next
+        // MFMAs.  (The loop software-pipelined in halves of a group -- the MFMAs of tiles 2, 3 issued before the tests of
+        // tiles 0, 1 and so on, same 64 accumulators -- was built and measured: 3.0 ms per step against 2.85.)
         const int o = 7 - shift;
         unsigned frag_addr = (unsigned)(size_t)(fragL + qsub * PSH_MQ8_QDW + (o & 3) * PSH_MQ8_CDW + (o >> 2) + 4 * hk);
-        const f32x2* plp = plL + qsub;
+        const int* thrp = thrI + qsub;
+        // (fragment reads by hand, as in scan_mq_kernel: the compiler would fold the adjacent dwords into one 4-byte-aligned
+        //  ds_read_b128; the wait is a statement of its own -- tied to the registers, so that nothing reads them before it)
+        u32x2 f0, f1;
+        asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read2_b32 %1, %2 offset0:2 offset1:3"
+                     : "=&v"(f0), "=&v"(f1) : "v"(frag_addr) : "memory");
+        int thr_next = *thrp;
 #pragma unroll 1
-        for (int G = 0; G < ngroups; ++G, frag_addr += 4 * PSH_MQ8_QDW * 4, plp += 4) {
-            // (by hand, as in scan_mq_kernel: the compiler would fold the adjacent dwords into one 4-byte-aligned ds_read_b128)
-            u32x2 f0, f1;
-            asm volatile("ds_read2_b32 %0, %2 offset1:1\n\t"
-                         "ds_read2_b32 %1, %2 offset0:2 offset1:3\n\t"
-                         "s_waitcnt lgkmcnt(0)"
-                         : "=&v"(f0), "=&v"(f1) : "v"(frag_addr) : "memory");
+        for (int G = 0; G < ngroups; ++G) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f0), "+v"(f1) :: "memory");
             const i32x4v bq = i32x4v{(int)f0[0], (int)f0[1], (int)f1[0], (int)f1[1]};
-            // the level in the product's units for THIS segment's step, rounded towards "keep" by the constants' margins;
-            // the clamp keeps the conversion inside 32 bits (beyond it: reject nothing / reject everything, as it should)
-            const f32x2 pl = *plp;
-            const int thr = keep_all ? 0x7fffffff
-                                     : (int)__builtin_amdgcn_fmed3f(__builtin_fmaf(pl[0], inv_sy, pl[1]), -2147483520.0f, 2147483520.0f);
+            const int thr = thr_next;
             i32x16v acc[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fy[g], bq, cw[g], 0, 0, 0);
+            frag_addr += 4 * PSH_MQ8_QDW * 4;
+            thrp += 4;
+            if (G + 1 < ngroups) {
+                asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read2_b32 %1, %2 offset0:2 offset1:3"
+                             : "=&v"(f0), "=&v"(f1) : "v"(frag_addr) : "memory");
+                thr_next = *thrp;
+            }
 #ifdef PSH_TUNING
             if (dbg & 8) {                                                 // ablation: no epilogue (results invalid)
                 asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]));
@@ -1478,7 +1497,7 @@ size_t scan_mq_shmem_bytes(int tile_floats, int B) {
     return (size_t)(((B + 3) & ~3) + 4) * sizeof(int)
            + (size_t)NW * PSH_PEND * 16 + (size_t)NW * mq_wave_halves(tile_floats) * sizeof(_Float16)
            + (size_t)PSH_MQS_CHUNK * PSH_MQ_QDW * sizeof(unsigned) + (size_t)3 * PSH_MQS_CHUNK * sizeof(float)   // (8-bit test: {P, L} per query)
-           + (size_t)NW * PSH_MQ_QCAP * sizeof(unsigned);
+           + (size_t)NW * PSH_MQ_QCAP * sizeof(unsigned) + (size_t)NW * PSH_MQS_CHUNK * sizeof(int);   // (... and a wave's levels for its segment)
 }
 
 int scan_mq_chunks(int B) { return (B + PSH_MQS_CHUNK - 1) / PSH_MQS_CHUNK; }
