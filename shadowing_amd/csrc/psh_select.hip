@@ -189,6 +189,19 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
     __shared__ unsigned s_maxbits;                         // largest |value| among the sampled data and this query
     __shared__ unsigned s_xmaxbits, s_e2bits, s_nxbits;    // 8-bit test: largest |x| of the batch, largest quantisation residue, largest ||x||^2
     if (tid == 0) { prep_query(a.prep, b); s_maxbits = 0u; s_xmaxbits = 0u; s_e2bits = 0u; s_nxbits = 0u; sm.prefix_b = ~0ull; }   // ||x||, sum of squares, state reset
+    // 8-bit test (end of this kernel): what it reads from memory is requested HERE -- thread q keeps query q's samples, the
+    // block's own query goes to LDS --, so that the loads' round trips pass behind the selection instead of after it
+    static_assert(PSH_MAX_B_PER_LAUNCH <= PSH_SELECT_THREADS, "thread q prepares query q");
+    __shared__ float s_xb[25];
+    __shared__ float s_sc;
+    float xv8[25];
+    const bool i8prep = a.mq_frag && a.mq_i8;
+    if (i8prep) {
+#pragma unroll
+        for (int j = 0; j < 25; ++j) xv8[j] = (tid < a.prep.B && j < a.prep.W) ? a.prep.queries[(int64_t)tid * a.prep.W + j] : 0.0f;
+        if (tid < 25) s_xb[tid] = tid < a.prep.W ? a.prep.queries[(int64_t)b * a.prep.W + tid] : 0.0f;
+        if (tid == 0) s_sc = 0.0f;
+    }
     __syncthreads();                                       // (block-scope visibility of qstate[b] for thread 0 below)
     if (a.blockmax) {
         unsigned mb = 0u;                                  // non-negative floats order as their bit patterns
@@ -280,6 +293,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
                         qs->mx_thr = Tf;
                         qs->mx_thr2 = Tf;
                         qs->mx_scale = sc;
+                        if (i8prep) s_sc = sc;
                     }
                 }
             }
@@ -319,7 +333,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
         // taken through integer atomics: no summation order), so the window side -- C_w, the MFMA's C operand -- is one
         // for all queries.  Everything is evaluated in double and rounded towards "keep".
         __syncthreads();
-        const float sc = a.qstate[b].mx_scale;             // thread 0 above; 0 = filter not armed
+        const float sc = s_sc;                             // thread 0 above; 0 = filter not armed
         const float xm = __uint_as_float(s_xmaxbits) * sc;
         const bool armed = sc > 0.0f && xm > 0.0f && xm < __uint_as_float(PSH_INF_BITS);
         const float inv_sx = armed ? 127.0f / xm : 0.0f;
@@ -330,12 +344,12 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
             return q > 127 ? 127 : (q < -127 ? -127 : q);
         };
         if (armed) {
-            for (int q = tid; q < a.prep.B; q += PSH_SELECT_THREADS) {
-                const float* xq = a.prep.queries + (int64_t)q * W;
+            if (tid < a.prep.B) {                          // (B <= PSH_MAX_B_PER_LAUNCH = the block's threads: query tid)
                 double e2 = 0.0, nxq = 0.0;
-                for (int j = 0; j < W; ++j) {
-                    const double xs = (double)(xq[j] * sc);
-                    const double r = xs - s_x * (double)quant(xq[j]);
+#pragma unroll
+                for (int j = 0; j < 25; ++j) {
+                    const double xs = (double)(xv8[j] * sc);
+                    const double r = xs - s_x * (double)quant(xv8[j]);
                     e2 += r * r;
                     nxq += xs * xs;
                 }
@@ -354,9 +368,9 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
             if (armed && tb < PSH_INF_BITS && NX > 0.0 && E2 < (double)__uint_as_float(PSH_INF_BITS)) {
                 double beta = sqrt(E2 / NX);
                 beta = beta < 1.0 / 4096.0 ? 1.0 / 4096.0 : (beta > 0.25 ? 0.25 : beta);
-                const float* xq = a.prep.queries + (int64_t)b * W;
                 double nxs = 0.0, l1 = 0.0;
-                for (int j = 0; j < W; ++j) { const double xs = (double)(xq[j] * sc); nxs += xs * xs; l1 += fabs((double)quant(xq[j])); }
+#pragma unroll
+                for (int j = 0; j < 25; ++j) { const double xs = (double)(s_xb[j] * sc); nxs += xs * xs; l1 += fabs((double)quant(s_xb[j])); }
                 const double taus = (double)__uint_as_float(tb) * (double)sc * (double)sc;
                 const double Theta = taus * (1.0 + 1.0 / 65536.0) - nxs * (1.0 - 1e-12);
                 double P = (Theta + E2 * (1.0 + 1e-6) / beta) / (2.0 * s_x);
@@ -380,7 +394,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
             const int c = tid / 40, i = tid - 40 * c;
             const int j = i + c - 7;
             const bool in = armed && j >= 0 && j < W;
-            reinterpret_cast<signed char*>(a.mq_frag)[(int64_t)b * 160 + tid] = (signed char)(in ? -quant(a.prep.queries[(int64_t)b * W + j]) : 0);
+            reinterpret_cast<signed char*>(a.mq_frag)[(int64_t)b * 160 + tid] = (signed char)(in ? -quant(s_xb[j]) : 0);
         }
     } else if (a.mq_frag) {
         // this query's two zero-padded f16 copies for scan_mq_kernel (PSH_MQ_QDW = 40 dwords: copy c at dword 20 c):

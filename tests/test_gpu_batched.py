@@ -72,6 +72,71 @@ def test_query_chunks_with_independent_queries_and_runtime_window_length(hip_dev
     assert_exact(d, idx, od, oidx, "independent queries")
 
 
+def test_8bit_and_f16_rejection_tests_give_the_same_results(hip_device, oracle_mod):
+    """The batched scan's rejection test as the 8-bit product (the default) and as the f16 product (PSH_FLAG_MQ_F16): the
+    same candidates' exact distances either way, both equal to the oracle."""
+    from shadowing_amd import _native
+    ds = syn.dataset(2048, 2048, 2600)
+    q = syn.rolling_queries(96, 20, 2601)
+    d8, i8, s8, p8 = hip_scan(hip_device, ds, q, 200, 20, profile=True)
+    d16, i16, s16, p16 = hip_scan(hip_device, ds, q, 200, 20, profile=True, flags=_native.FLAG_MQ_F16)
+    assert p8["path"] == 0 and p16["path"] == 0
+    d8, i8 = resolve(hip_device, ds, q, 200, 20, d8, i8, s8)
+    d16, i16 = resolve(hip_device, ds, q, 200, 20, d16, i16, s16)
+    od, oidx = oracle_mod.scan_topk(ds, q, 200, h=20)
+    assert_exact(d8, i8, od, oidx, "8-bit test")
+    assert_exact(d16, i16, od, oidx, "f16 test")
+
+
+@pytest.mark.parametrize("case", ["amplitudes", "outliers", "quiet_segments", "nonfinite", "zero_query", "wide_window"])
+def test_8bit_rejection_test_on_adversarial_batches(hip_device, oracle_mod, case):
+    """What the quantisation bound has to survive: queries whose amplitudes differ by orders of magnitude on ONE step (a quiet
+    query keeps more windows for its exact recheck -- slower, never wrong), segments dominated by an outlier (a coarse
+    step for everything else in them), segments far below the batch's scale (the step's floor), all-zero rows, NaN / inf in
+    the data and in a query, an all-zero query, a 25-sample window (the last length the K = 32 band takes)."""
+    W, h, k = 20, 20, 150
+    ds = syn.dataset(1536, 1400, 2700)
+    q = syn.rolling_queries(40, 20, 2701)
+    g = np.random.default_rng(2702)
+    if case == "amplitudes":
+        q = q * (10.0 ** g.uniform(-3, 3, size=(40, 1))).astype(np.float32)
+    elif case == "outliers":
+        rows = g.integers(0, 1536, 300)
+        ds[rows, 0, g.integers(0, 1400, 300)] *= g.choice([40.0, -300.0, 5000.0], 300).astype(np.float32)
+    elif case == "quiet_segments":
+        ds[:200] *= 1e-4
+        ds[200:230] = 0.0
+        ds[230:260, 0, :700] *= 1e-7
+        ds[260:270, 0, :] = ds[260:270, 0, :1] + 0.0           # constant rows
+    elif case == "nonfinite":
+        ds[g.integers(0, 1536, 40), 0, g.integers(0, 1400, 40)] = np.nan
+        ds[g.integers(0, 1536, 40), 0, g.integers(0, 1400, 40)] = np.inf
+        ds[g.integers(0, 1536, 10), 0, g.integers(0, 1400, 10)] = -np.inf
+        q[3, 5] = np.nan
+        q[9, 0] = np.inf
+    elif case == "zero_query":
+        q[11] = 0.0
+        q[12] = 1e-30
+    elif case == "wide_window":
+        W, h = 25, 3
+        q = syn.gbm_log_returns((40, 25), 2703)
+    ds_scan = ds
+    if case == "nonfinite":
+        # (the reference's rule for non-finite samples -- its zero-padded conv makes a window NaN when its horizon holds one
+        #  too -- is applied to the rows by the library's own kernel, as PathShadowing does before it scans)
+        from shadowing_amd import _native
+        ds_scan = _native.smear_nonfinite(torch.as_tensor(ds).to(hip_device), back=h).cpu().numpy()[:, None, :]
+    d, idx, status, prof = hip_scan(hip_device, ds_scan, q, k, h, profile=True)
+    assert prof["path"] == 0
+    d, idx = resolve(hip_device, ds_scan, q, k, h, d, idx, status)
+    od, oidx = oracle_mod.scan_topk(ds, q, k, h=h)
+    fin = np.isfinite(od).all(axis=1) & np.isfinite(q).all(axis=1)
+    assert fin.sum() >= 35
+    assert_exact(d[fin], idx[fin], od[fin], oidx[fin], case)
+    for b in np.nonzero(~fin)[0]:                                  # a non-finite or all-zero query: nothing finite may come back
+        assert not np.isfinite(d[b]).any() and not np.isfinite(od[b]).any()
+
+
 def test_configs2_full_size_properties(hip_device, oracle_mod):
     """BASELINE configs[2] at its size: 512 rolling query dates x R = 32768 x T = 4096, k = 1024.  Size-independent
     properties for every query (rows sorted, indices admissible and distinct, each returned distance re-derived
