@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--filter", choices=("mx", "valu"), default="mx",
                     help="rejection test of the scan: matrix cores (default) or vector ALUs (PSH_FLAG_FILTER_VALU; comparison runs)")
     ap.add_argument("--no-fuse", action="store_true", help="the separate bootstrap / threshold / scan / select launches")
+    ap.add_argument("--mq-f16", action="store_true",
+                    help="--queries > 1: the batched scan's rejection test as the f16 product (PSH_FLAG_MQ_F16) instead of the 8-bit one (A/B)")
     ap.add_argument("--streams", type=int, default=0,
                     help="single query: consecutive steps (independent queries) are issued round-robin on this many HIP "
                          "streams as the three overlap-friendly launches of PSH_FLAG_OVERLAP (sample + level, barrier-free "
@@ -276,6 +278,8 @@ def main():
     R, T, W, h, k, B = args.rows_per_gpu, args.T, args.W, args.horizon, args.k, args.queries
     Tp = T - W - h + 1
     flags = (_native.FLAG_FILTER_VALU if args.filter == "valu" else 0) | (_native.FLAG_NO_FUSE if args.no_fuse else 0)
+    if args.mq_f16:
+        flags |= _native.FLAG_MQ_F16
     # independent single queries on several streams: the overlap-friendly launches (the library falls back to the fused /
     # separate launches by itself where they do not apply)
     want_streams = args.streams if args.streams > 0 else (2 if use_pg else 3)
@@ -577,8 +581,9 @@ def main():
                    "psh::stream_rank_kernel behind it run beside the scans of the other streams)" % wt if overlap_mode else
                    "psh::scan_fused_kernel<%s,true> (the WHOLE step in one launch: bootstrap, threshold, f16 matrix-core "
                    "rejection test + exact fp32 recheck over the ensemble, distributed selection)" % wt if fused else
-                   ("psh::scan_mx_kernel<%s,true>" if B == 1 else "psh::scan_mq_kernel<%s,true>") % wt
-                   + " (full scan: f16 matrix-core rejection test + exact fp32 recheck)" if mx
+                   ("psh::scan_mx_kernel<%s,true>" if B == 1 else "psh::scan_mq_kernel<%s,true>" if args.mq_f16 else "psh::scan_mq8_kernel<%s,true>") % wt
+                   + (" (full scan: f16 matrix-core rejection test + exact fp32 recheck)" if (B == 1 or args.mq_f16) else
+                      " (full scan: 8-bit matrix-core rejection test, one v_mfma_i32_32x32x32_i8 per tile, + exact fp32 recheck)") if mx
                    else "psh::scan_kernel<%s,true,1> (full scan, VALU rejection test)" % wt)
     alg_bytes = R * T * 4 + B * W * 4 + B * k * 12          # one read of the ensemble + query + result
     roofline = None
@@ -619,12 +624,16 @@ def main():
             # epilogue.  `achieved` = ISSUED matrix-core flop/s (2 x 32 x 32 x 16 per MFMA; 62.5 % of the MACs are useful
             # ones, 20 taps x 1024 (window, query) pairs per tile pair) against the guide's dense f16 peak; busy fractions of
             # the matrix cores and the vector ALUs come from the committed PMC pass of this command, when there is one.
+            # Round 4: the test is an 8-BIT product by default (scan_mq8_kernel): ONE v_mfma_i32_32x32x32_i8 per tile (K = 32
+            # takes the whole band), 4 per segment and group, priced against the guide's dense 8-bit rate (2x the f16 one);
+            # --mq-f16 runs and prices the f16 kernel as before.
             nseg_b = (Tp + 1023) // 1024
             groups = (B + 3) // 4
-            mfma_per_launch = R * nseg_b * (groups * 8 + 8)                 # + the 8 window-energy MFMAs of a segment
-            flops = mfma_per_launch * 2 * 32 * 32 * 16
+            per_group = 8 if args.mq_f16 else 4
+            mfma_per_launch = R * nseg_b * (groups * per_group + 8)         # + the 8 (f16) window-energy MFMAs of a segment
+            flops = R * nseg_b * (groups * per_group * 2 * 32 * 32 * (16 if args.mq_f16 else 32) + 8 * 2 * 32 * 32 * 16)
             ach_tf = flops / (avg_ms * 1e-3) / 1e12
-            MFMA_F16_DENSE_TF = 2500.0                                       # MI355X_MICROARCH.md: ~2.5 PF dense bf16 / f16
+            MFMA_F16_DENSE_TF = 2500.0 if args.mq_f16 else 5000.0            # MI355X_MICROARCH.md: ~2.5 PF dense bf16 / f16, 8-bit at twice that
             pmc = None
             pfile = REPO / "profiles" / "q512_pmc.json"
             if pfile.exists():
@@ -635,7 +644,7 @@ def main():
                 except Exception:   # noqa: BLE001
                     pmc = None
             roofline = {"bound": "mfma+valu", "kernel": kernel_name, "achieved": round(ach_tf, 1), "peak": MFMA_F16_DENSE_TF,
-                        "unit": "TFLOP/s", "frac": round(ach_tf / MFMA_F16_DENSE_TF, 4),
+                        "unit": "TFLOP/s" if args.mq_f16 else "TOP/s (8-bit)", "frac": round(ach_tf / MFMA_F16_DENSE_TF, 4),
                         "mfma_per_launch": mfma_per_launch, "issued_flops_per_launch": flops, "useful_mac_fraction": 0.625,
                         "matrix_core_busy_frac": pmc.get("matrix_core_busy_frac") if pmc else None,
                         "valu_busy_frac": pmc.get("valu_busy_frac") if pmc else None,

@@ -314,7 +314,7 @@ __host__ __device__ inline size_t px_shmem_bytes(int tile_floats, int B, int d, 
            + (size_t)nw * PSH_PEND * 16                                             // wave-private pending admissions
            + (((size_t)d * 8 + 15) & ~(size_t)15) + 272                             // verification schedule: rows, slot starts
            + (size_t)(d + 1) * 16 + (size_t)(d + 4) * 16                            // merged rows, their {c', c', offset}
-           + (size_t)nw * (64 + PSH_PX_DLCAP) * 4                                   // verification scratch: survivor list, row differences
+           + (size_t)nw * (128 + PSH_PX_DLCAP) * 4                                  // verification scratch: survivor list (+ units), row differences
            + (size_t)nw * (2 * PSH_PX_ALIVE + nbg * 64) * 4;                        // second phase: live windows, coordinates by row
 }
 
@@ -338,10 +338,11 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
     int* vstart = reinterpret_cast<int*>(reinterpret_cast<char*>(vrow) + (((size_t)d * 8 + 15) & ~(size_t)15));   // 66 slot starts
     int4* gtab = reinterpret_cast<int4*>(vstart + 68);                       // ngroups (+1) merged rows
     int4* rtab = gtab + d + 1;                                               // ngroups (+3) x {c' bits twice, byte offset of E[a_i], -}
-    int* sl = reinterpret_cast<int*>(rtab + d + 4) + (size_t)wave_in_block * (64 + PSH_PX_DLCAP);   // wave-private: 64 survivors,
-    float* Dl = reinterpret_cast<float*>(sl + 64);                                   //   PSH_PX_DLCAP row differences
+    int* sl = reinterpret_cast<int*>(rtab + d + 4) + (size_t)wave_in_block * (128 + PSH_PX_DLCAP);  // wave-private: 64 survivors,
+    int* slu = sl + 64;                                                              //   the (row, segment) index of each,
+    float* Dl = reinterpret_cast<float*>(slu + 64);                                  //   PSH_PX_DLCAP row differences
     // wave-private, second phase of the row loop: live windows (index, partial sum), the query group's coordinates by merged row
-    int* alp = reinterpret_cast<int*>(rtab + d + 4) + (size_t)NW * (64 + PSH_PX_DLCAP) + (size_t)wave_in_block * (2 * PSH_PX_ALIVE + NBG * 64);
+    int* alp = reinterpret_cast<int*>(rtab + d + 4) + (size_t)NW * (128 + PSH_PX_DLCAP) + (size_t)wave_in_block * (2 * PSH_PX_ALIVE + NBG * 64);
     float* ala = reinterpret_cast<float*>(alp + PSH_PX_ALIVE);
     float* hq = ala + PSH_PX_ALIVE;
     int npend = 0;
@@ -383,6 +384,163 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
 #pragma unroll
     for (int g = 0; g < NBG; ++g) { hgt[g] = 0; Vq[g] = hnq[g] = 0.0f; }
 
+    // A survivor of the cheap test carries the (row, segment) index of the unit that listed it: at a unit's end only WHOLE
+    // passes of the exact verification run (a pass costs the same for one survivor as for its `spp` -- eight at Foveal's
+    // d = 34 -- and a unit lists one now and then), the rest waits for the next units'; the wave's last unit flushes.
+    int ns = 0;                                              // survivors waiting in sl (wave-uniform)
+    auto coords = [&](unsigned rsu, int& seg_start_e, int64_t& row_e) {
+        const unsigned ri2 = fast_div(rsu, a.magic_nseg, (unsigned)a.nseg);
+        seg_start_e = (int)(rsu - ri2 * (unsigned)a.nseg) * PSH_SEG;
+        row_e = a.row0 + (int64_t)ri2 * a.row_stride;
+    };
+    // Exact verification of the listed survivors (window index | query << 12), rows across the lanes: lane (el, l)
+    // runs the chains of row l and then of row d-1-l of survivor el (short and long support: equal work per lane),
+    // 64 / ceil(d/2) survivors per pass; one lane per survivor then adds the d squares in row order.  A row's taps need
+    // no matrix: c_i on [a_i, ktop), zero elsewhere -- the zero taps the dense chain visits inside its span of
+    // 4-tap groups are visited too (fma(0, y, .) matters for non-finite y).
+    // Exact verification of the listed survivors (window index | query << 12): the dense chains in the oracle's order
+    // (a row's span of whole 4-tap groups from its first tap rounded down; c_i on [a_i, ktop), the zero taps of the span
+    // visited too: fma(0, y, .) matters for non-finite y), then the d squares in row order by one lane per survivor.
+    // The rows of a survivor are spread over `vnl` lanes by the plan -- longest row first onto the least loaded lane, so the
+    // lanes' tap counts are even (Foveal(1.15, 0.9, 126): 865 taps, the longest row 115 -> 8 lanes, 8 survivors a pass
+    // of 116 steps; a row pair per lane -- 17 lanes, 3 survivors, 136 steps -- was 2.7x the work per survivor).  Every lane
+    // walks its list of rows, 4 taps a step, all lanes `vmax` taps.
+    // `staged` (the call at the end of a unit, when E is no longer needed): the survivors' windows are first copied into
+    // the wave's tile, as many as fit, with all their loads in flight together -- the chains then run at LDS latency.
+    // Mid-unit (a full list: rare) a step reads its 4 samples from global memory.
+    auto verify_list = [&](bool staged, bool whole_passes_only) {
+        wave_lds_fence();
+        const int Kst = (K + 3) & ~3;
+        int spp = 64 / vnl;                              // survivors per pass
+        spp = spp < PSH_PX_DLCAP / d ? spp : PSH_PX_DLCAP / d;
+        const int fit = a.tile_floats / Kst;              // windows the tile can stage (5 at K = 252)
+        if (staged && fit < spp) spp = fit;               // long windows: fewer survivors a pass rather than global reads
+        if (spp < 1) { spp = 1; staged = false; }
+        int nst = fit / spp * spp;                        // windows per staging batch: whole passes
+        if (!staged) nst = 64;
+        const int ns_all = ns;
+        if (whole_passes_only) ns = ns / spp * spp;      // (the rest waits for the next units' survivors)
+        const int nq4 = (Kst + 63) >> 6;
+        const int sv = lane / vnl, ls = lane - sv * vnl;
+        const int r0 = vstart[ls], r1 = vstart[ls + 1];
+#pragma unroll 1
+        for (int s0 = 0; s0 < ns; s0 += nst) {
+            const int s1 = (s0 + nst) < ns ? (s0 + nst) : ns;
+            if (staged) {
+                wave_lds_fence();                        // the batch before this one has been read
+#pragma unroll 1
+                for (int sb = s0; sb < s1; sb += 4) {
+                    float v[4][4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int su = (sb + u) < s1 ? (sb + u) : (s1 - 1);
+                        int ss_u;
+                        int64_t row_u;
+                        coords((unsigned)slu[su], ss_u, row_u);
+                        const float* yw = a.dataset + row_u * a.T + ss_u + (sl[su] & 4095);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            int j = lane + 64 * q;
+                            j = j < K ? j : K - 1;
+                            if (q < nq4) v[u][q] = yw[j];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int j = lane + 64 * q;
+                            if (q < nq4 && sb + u < s1 && j < Kst) tile[(sb + u - s0) * Kst + j] = j < K ? v[u][q] : 0.0f;
+                        }
+                }
+                wave_lds_fence();
+            }
+#pragma unroll 1
+            for (int e0 = s0; e0 < s1; e0 += spp) {
+                const bool lv = sv < spp && e0 + sv < s1;
+                const int ent = lv ? sl[e0 + sv] : 0;
+                const int pwin = ent & 4095, b = ent >> 12;
+                int seg_start_e;
+                int64_t row_e;
+                coords(lv ? (unsigned)slu[e0 + sv] : 0u, seg_start_e, row_e);
+                // the query's coordinates into the survivor's row of Dl (one round of loads for the whole pass)
+                if (lv) {
+                    const float* hxb = a.hx + (int64_t)b * d;
+                    for (int i = ls; i < d; i += vnl) Dl[sv * d + i] = hxb[i];
+                }
+                wave_lds_fence();
+                const float* ys = tile + (lv ? (e0 - s0 + sv) * Kst : 0);      // the staged window
+                const float* yw = a.dataset + row_e * a.T + seg_start_e + pwin;
+                int r = r0;
+                int2 cur = (lv && r < r1) ? vrow[r] : make_int2(0, 0);
+                int pos = 0;
+                float hy = 0.0f;
+#pragma unroll 1
+                for (int step = 0; step < vmax; step += 4) {
+                    const bool act = lv && r < r1;
+                    const int lo = cur.x & 255, n4 = ((cur.x >> 8) & 127) << 2, ath = (cur.x >> 16) & 255;
+                    const float c = __uint_as_float((unsigned)cur.y);
+                    const bool cnz = (cur.y & 0x7fffffff) != 0;
+                    const int j0 = lo + pos;                                    // a multiple of 4, below Kst while act
+                    f32x4 y4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (staged) {
+                        y4 = *reinterpret_cast<const f32x4*>(ys + (act ? j0 : 0));
+                    } else if (act) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) y4[q] = (j0 + q < K) ? yw[j0 + q] : 0.0f;
+                    }
+                    float t = hy;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool on = (j0 + q >= ath) && (j0 + q < ktop);
+                        t = cnz ? __builtin_fmaf(on ? c : 0.0f, y4[q], t) : t;   // (an empty row visits no tap)
+                    }
+                    hy = act ? t : hy;
+                    pos += 4;
+                    if (act && pos >= n4) {                                     // the row is done: D_i = hx_i - hy_i, next row
+                        const int row = (cur.x >> 24) & 127;
+                        Dl[sv * d + row] = __fsub_rn(Dl[sv * d + row], hy);
+                        hy = 0.0f;
+                        pos = 0;
+                        ++r;
+                        if (r < r1) cur = vrow[r];
+                    }
+                }
+                wave_lds_fence();
+                float ea = __uint_as_float(PSH_INF_BITS);
+                bool hit = false;
+                if (lv && ls == 0) {
+                    ea = 0.0f;
+                    for (int i = 0; i < d; ++i) { const float D = Dl[sv * d + i]; ea = __builtin_fmaf(D, D, ea); }
+                    hit = ea < __uint_as_float(a.qstate[b].tau2_bits);
+                }
+                const unsigned long long mask = __ballot(hit);
+                wave_lds_fence();                        // Dl is rewritten by the next pass
+                if (!mask) continue;
+                const int nh2 = __popcll(mask);
+                if (npend + nh2 > PSH_PEND) {
+                    pend_flush(pend, npend, lcount, a, lane);
+                    npend = 0;
+                    wave_lds_fence();
+                }
+                if (hit) {
+                    const int slot = npend + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                 __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    pend[slot] = u32x4{__float_as_uint(ea), (unsigned)(int)(row_e + a.r_offset), (unsigned)(seg_start_e + pwin), (unsigned)b};
+                }
+                npend += nh2;
+            }
+        }
+        // the survivors that wait: to the front of the list
+        const int left = ns_all - ns;
+        int k0 = 0, k1 = 0;
+        if (lane < left) { k0 = sl[ns + lane]; k1 = slu[ns + lane]; }
+        wave_lds_fence();
+        if (lane < left) { sl[lane] = k0; slu[lane] = k1; }
+        ns = left;
+        wave_lds_fence();                                // sl is refilled afterwards
+    };
+
     for (;;) {
         int v = 0;
         if (lane == 0) v = atomicAdd(next_unit, 1);
@@ -421,141 +579,7 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
         const int r_global = (int)(row + a.r_offset);
         const int q_begin = (int)qgi * a.q_per_group;
         const int q_end = (q_begin + a.q_per_group) < a.B ? (q_begin + a.q_per_group) : a.B;
-        const float* yrow_g = a.dataset + row * a.T + seg_start;   // the segment in global memory
-        int ns = 0;                                          // survivors waiting in sl (wave-uniform)
 
-        // Exact verification of the listed survivors (window index | query << 12), rows across the lanes: lane (el, l)
-        // runs the chains of row l and then of row d-1-l of survivor el (short and long support: equal work per lane),
-        // 64 / ceil(d/2) survivors per pass; one lane per survivor then adds the d squares in row order.  A row's taps need
-        // no matrix: c_i on [a_i, ktop), zero elsewhere -- the zero taps the dense chain visits inside its span of
-        // 4-tap groups are visited too (fma(0, y, .) matters for non-finite y).
-        // Exact verification of the listed survivors (window index | query << 12): the dense chains in the oracle's order
-        // (a row's span of whole 4-tap groups from its first tap rounded down; c_i on [a_i, ktop), the zero taps of the span
-        // visited too: fma(0, y, .) matters for non-finite y), then the d squares in row order by one lane per survivor.
-        // The rows of a survivor are spread over `vnl` lanes by the plan -- longest row first onto the least loaded lane, so the
-        // lanes' tap counts are even (Foveal(1.15, 0.9, 126): 865 taps, the longest row 115 -> 8 lanes, 8 survivors a pass
-        // of 116 steps; a row pair per lane -- 17 lanes, 3 survivors, 136 steps -- was 2.7x the work per survivor).  Every lane
-        // walks its list of rows, 4 taps a step, all lanes `vmax` taps.
-        // `staged` (the call at the end of a unit, when E is no longer needed): the survivors' windows are first copied into
-        // the wave's tile, as many as fit, with all their loads in flight together -- the chains then run at LDS latency.
-        // Mid-unit (a full list: rare) a step reads its 4 samples from global memory.
-        auto verify_list = [&](bool staged) {
-            wave_lds_fence();
-            const int Kst = (K + 3) & ~3;
-            int spp = 64 / vnl;                              // survivors per pass
-            spp = spp < PSH_PX_DLCAP / d ? spp : PSH_PX_DLCAP / d;
-            const int fit = a.tile_floats / Kst;              // windows the tile can stage (5 at K = 252)
-            if (staged && fit < spp) spp = fit;               // long windows: fewer survivors a pass rather than global reads
-            if (spp < 1) { spp = 1; staged = false; }
-            int nst = fit / spp * spp;                        // windows per staging batch: whole passes
-            if (!staged) nst = 64;
-            const int nq4 = (Kst + 63) >> 6;
-            const int sv = lane / vnl, ls = lane - sv * vnl;
-            const int r0 = vstart[ls], r1 = vstart[ls + 1];
-#pragma unroll 1
-            for (int s0 = 0; s0 < ns; s0 += nst) {
-                const int s1 = (s0 + nst) < ns ? (s0 + nst) : ns;
-                if (staged) {
-                    wave_lds_fence();                        // the batch before this one has been read
-#pragma unroll 1
-                    for (int sb = s0; sb < s1; sb += 4) {
-                        float v[4][4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int su = (sb + u) < s1 ? (sb + u) : (s1 - 1);
-                            const float* yw = yrow_g + (sl[su] & 4095);
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                int j = lane + 64 * q;
-                                j = j < K ? j : K - 1;
-                                if (q < nq4) v[u][q] = yw[j];
-                            }
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const int j = lane + 64 * q;
-                                if (q < nq4 && sb + u < s1 && j < Kst) tile[(sb + u - s0) * Kst + j] = j < K ? v[u][q] : 0.0f;
-                            }
-                    }
-                    wave_lds_fence();
-                }
-#pragma unroll 1
-                for (int e0 = s0; e0 < s1; e0 += spp) {
-                    const bool lv = sv < spp && e0 + sv < s1;
-                    const int ent = lv ? sl[e0 + sv] : 0;
-                    const int pwin = ent & 4095, b = ent >> 12;
-                    // the query's coordinates into the survivor's row of Dl (one round of loads for the whole pass)
-                    if (lv) {
-                        const float* hxb = a.hx + (int64_t)b * d;
-                        for (int i = ls; i < d; i += vnl) Dl[sv * d + i] = hxb[i];
-                    }
-                    wave_lds_fence();
-                    const float* ys = tile + (lv ? (e0 - s0 + sv) * Kst : 0);      // the staged window
-                    const float* yw = yrow_g + pwin;
-                    int r = r0;
-                    int2 cur = (lv && r < r1) ? vrow[r] : make_int2(0, 0);
-                    int pos = 0;
-                    float hy = 0.0f;
-#pragma unroll 1
-                    for (int step = 0; step < vmax; step += 4) {
-                        const bool act = lv && r < r1;
-                        const int lo = cur.x & 255, n4 = ((cur.x >> 8) & 127) << 2, ath = (cur.x >> 16) & 255;
-                        const float c = __uint_as_float((unsigned)cur.y);
-                        const bool cnz = (cur.y & 0x7fffffff) != 0;
-                        const int j0 = lo + pos;                                    // a multiple of 4, below Kst while act
-                        f32x4 y4 = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (staged) {
-                            y4 = *reinterpret_cast<const f32x4*>(ys + (act ? j0 : 0));
-                        } else if (act) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) y4[q] = (j0 + q < K) ? yw[j0 + q] : 0.0f;
-                        }
-                        float t = hy;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const bool on = (j0 + q >= ath) && (j0 + q < ktop);
-                            t = cnz ? __builtin_fmaf(on ? c : 0.0f, y4[q], t) : t;   // (an empty row visits no tap)
-                        }
-                        hy = act ? t : hy;
-                        pos += 4;
-                        if (act && pos >= n4) {                                     // the row is done: D_i = hx_i - hy_i, next row
-                            const int row = (cur.x >> 24) & 127;
-                            Dl[sv * d + row] = __fsub_rn(Dl[sv * d + row], hy);
-                            hy = 0.0f;
-                            pos = 0;
-                            ++r;
-                            if (r < r1) cur = vrow[r];
-                        }
-                    }
-                    wave_lds_fence();
-                    float ea = __uint_as_float(PSH_INF_BITS);
-                    bool hit = false;
-                    if (lv && ls == 0) {
-                        ea = 0.0f;
-                        for (int i = 0; i < d; ++i) { const float D = Dl[sv * d + i]; ea = __builtin_fmaf(D, D, ea); }
-                        hit = ea < __uint_as_float(a.qstate[b].tau2_bits);
-                    }
-                    const unsigned long long mask = __ballot(hit);
-                    wave_lds_fence();                        // Dl is rewritten by the next pass
-                    if (!mask) continue;
-                    const int nh2 = __popcll(mask);
-                    if (npend + nh2 > PSH_PEND) {
-                        pend_flush(pend, npend, lcount, a, lane);
-                        npend = 0;
-                        wave_lds_fence();
-                    }
-                    if (hit) {
-                        const int slot = npend + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                        pend[slot] = u32x4{__float_as_uint(ea), (unsigned)r_global, (unsigned)(seg_start + pwin), (unsigned)b};
-                    }
-                    npend += nh2;
-                }
-            }
-            wave_lds_fence();                                // sl is refilled afterwards
-        };
 
         float Pk[PSH_L];                                     // E[t + ktop] of the lane's windows t = lane + 64 w
 #pragma unroll
@@ -689,8 +713,12 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
                 const unsigned long long sm = __ballot(has);
                 if (!sm) return;
                 const int ne = __popcll(sm);
-                if (ns + ne > 64) { verify_list(false); ns = 0; }
-                if (has) sl[ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u))] = pwin | (b << 12);
+                if (ns + ne > 64) verify_list(false, false);
+                if (has) {
+                    const int slot = ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u));
+                    sl[slot] = pwin | (b << 12);
+                    slu[slot] = (int)__builtin_amdgcn_readfirstlane((int)rs);
+                }
                 ns += ne;
             };
             unsigned done = 0u;                              // queries of the pass finished by the sparse second phase
@@ -793,10 +821,11 @@ __global__ __launch_bounds__(THREADS) void embed_px_kernel(ScanArgs a) {
                 }
             }
         }
-        if (MODE == PSH_MODE_FILTER && ns > 0) { verify_list(true); ns = 0; }   // (E is done with: the tile stages the windows)
+        if (MODE == PSH_MODE_FILTER && ns >= 8) verify_list(true, true);     // (E is done with: the tile stages the windows; whole passes)
         wave_lds_fence();  // all lanes done with the tile before it is overwritten
     }
     if (MODE == PSH_MODE_FILTER) {
+        if (ns > 0) verify_list(true, false);                // the survivors still waiting
         if (npend > 0) pend_flush(pend, npend, lcount, a, lane);
         __syncthreads();
         for (int q = (int)threadIdx.x; q < a.B; q += THREADS)

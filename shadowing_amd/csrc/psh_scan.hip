@@ -941,6 +941,10 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq8_kernel(ScanArgs a) {
 
 #ifdef PSH_TUNING
     const int dbg = __builtin_amdgcn_readfirstlane(a.dbg);
+    unsigned long long tacc[3] = {0ull, 0ull, 0ull}, tlast = __builtin_amdgcn_s_memtime();   // per segment: set-up / group loop / drain + hand-over
+    auto tstamp = [&](int i) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tacc[i] += t - tlast; tlast = t; };
+#else
+    auto tstamp = [&](int) {};
 #endif
     Stage st;
     unsigned u = grab();
@@ -1068,6 +1072,7 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq8_kernel(ScanArgs a) {
         // at the top of the next turn: an LDS round trip per group would otherwise sit between a wave's tests and its next
         // MFMAs.  (The loop software-pipelined in halves of a group -- the MFMAs of tiles 2, 3 issued before the tests of
         // tiles 0, 1 and so on, same 64 accumulators -- was built and measured: 3.0 ms per step against 2.85.)
+        tstamp(0);
         const int o = 7 - shift;
         unsigned frag_addr = (unsigned)(size_t)(fragL + qsub * PSH_MQ8_QDW + (o & 3) * PSH_MQ8_CDW + (o >> 2) + 4 * hk);
         const int* thrp = thrI + qsub;
@@ -1152,10 +1157,16 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq8_kernel(ScanArgs a) {
             }
             if (nsq >= 64) drain();
         }
+        tstamp(1);
         if (nsq > 0) drain();
         wave_lds_fence();  // all lanes done with the tile before it is overwritten
         u = un;
+        tstamp(2);
     }
+#ifdef PSH_TUNING
+    if (a.dbg_times && lane == 0)
+        for (int i = 0; i < 3; ++i) a.dbg_times[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave_in_block) * 3 + i] = tacc[i];
+#endif
     if (npend > 0) pend_flush(pend, npend, lcount, a, lane);
     __syncthreads();
     for (int q = q0 + (int)threadIdx.x; q < q0 + nq; q += PSH_MQ_THREADS)          // this block's queries only

@@ -354,11 +354,20 @@ class PathShadowing:
                     return _native.scan_topk_embedded(rows, ker2, q, k, h=h, workspace=self._workspace,
                                                       exhaustive=exhaustive, flags=fl, keep_plan=True)
         else:
+            # a batch's rejection test puts every query on ONE 8-bit step (PSH_FLAG_MQ_F16, include/psh.h): queries that differ
+            # in amplitude by more than ~3x are better served by the f16 test (same results; decided here, where the
+            # queries are still host memory -- a few microseconds of numpy)
+            fl = 0
+            if x.shape[0] > 1 and x.device.type == "cpu":
+                amp = x[:, 0, :].abs().amax(dim=1)
+                lo = amp[amp > 0]
+                if lo.numel() and not (float(amp.max()) <= 3.0 * float(lo.min())):
+                    fl = _native.FLAG_MQ_F16
             xq = x[:, 0, :].contiguous().to(dev)
             if defer_status:
-                d, idx, status = _native.scan_topk(rows, xq, k, h=h, workspace=self._workspace)
+                d, idx, status = _native.scan_topk(rows, xq, k, h=h, workspace=self._workspace, flags=fl)
                 return d, idx, ds, status
-            d, idx = _native.scan_topk_checked(rows, xq, k, h=h, workspace=self._workspace)
+            d, idx = _native.scan_topk_checked(rows, xq, k, h=h, workspace=self._workspace, flags=fl)
             return d, idx, ds
         d, idx, status = scan(None, False)
         bad = torch.nonzero(status != _native.PSH_STATUS_OK).flatten()

@@ -1,7 +1,16 @@
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r4af; mkdir -p $O
-timeout 1500 python -m pytest tests/test_gpu_batched.py -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" | tail -40 > $O/tests.txt
-timeout 120 python tools/q512_stages.py 2>/dev/null | grep "^{" | cut -c1-330 >> $O/abl.txt
-timeout 300 python bench.py --steps 20 --warmup 3 --queries 512 --no-cpu-baseline > $O/bench_q512.json 2> $O/bench_q512.err
-tail -n 40 $O/tests.txt; cat $O/abl.txt; cut -c1-300 $O/bench_q512.json
+O=$R/gpurun_out/r4ag; mkdir -p $O
+L=$R/shadowing_amd/lib
+timeout 1500 python -m pytest tests/test_gpu_embedded.py tests/test_gpu_nonfinite.py tests/test_gpu_predict.py -q -m gpu -x 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" | tail -8 > $O/tests.txt
+for i in 1 2 3; do
+for v in prev new; do
+  if [ $v = prev ]; then export PSH_LIB=$L/libpsh_hip_prev.so; else unset PSH_LIB; fi
+  timeout 300 python tools/bench_foveal.py --which tutorial testing --steps 30 2>/dev/null | python -c "
+import sys, json
+for ln in sys.stdin:
+    if ln.startswith('{'):
+        j = json.loads(ln); print('$v', j['workload'][:8], j['ms_per_call'], j['stages_ms']['scan_ms'])
+" >> $O/ab.txt
+done; done
+tail -n 4 $O/tests.txt; cat $O/ab.txt

@@ -69,6 +69,15 @@ cd $R
 timeout 600 python bench.py --steps 500 --warmup 20 --rows-per-gpu 131072 --no-cpu-baseline > $OUT/bench_n1_R131072.json 2>> $OUT/bench.err
 timeout 300 python tools/fused_skeleton.py > $OUT/fused_skeleton.json 2>> $OUT/bench.err
 python -m shadowing_amd._build --tuning > /dev/null 2>&1
-for d in 0 4 8; do echo "PSH_DBG=$d (0 the kernel; 4 no survivor handling; 8 MFMAs only: no epilogue)" >> $OUT/mq_ablations.txt; PSH_LIB=$R/shadowing_amd/lib/libpsh_hip_tuning.so PSH_DBG=$d timeout 120 python tools/q512_stages.py 2>/dev/null | grep "^{" >> $OUT/mq_ablations.txt; done
+# (the 8-bit rejection test -- scan_mq8_kernel, the default -- and the f16 one it replaced, side by side on this box)
+for i8 in 1 0; do for d in 0 4 8; do echo "PSH_MQ_I8=$i8 (1 scan_mq8_kernel, 0 scan_mq_kernel) PSH_DBG=$d (0 the kernel; 4 no survivor handling; 8 MFMAs only: no epilogue)" >> $OUT/mq_ablations.txt; PSH_LIB=$R/shadowing_amd/lib/libpsh_hip_tuning.so PSH_MQ_I8=$i8 PSH_DBG=$d timeout 120 python tools/q512_stages.py 2>/dev/null | grep "^{" >> $OUT/mq_ablations.txt; done; done
+timeout 300 python bench.py --steps 20 --warmup 3 --queries 512 --mq-f16 --no-cpu-baseline > $OUT/bench_n1_q512_f16_test.json 2>> $OUT/bench.err
+hipcc --offload-arch=gfx950 -O2 -o /tmp/u8 tools/ubench_mfma_i8.hip 2>/dev/null && /tmp/u8 > $OUT/ubench_mfma_i8.txt 2>&1
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_q512 -o q -- python $R/bench.py --steps 10 --warmup 3 --queries 512 --no-cpu-baseline --no-parity > $OUT/bench_prof_q512.log 2>&1
+for f in $(find $OUT/prof_q512 -name "*kernel_stats.csv"); do grep "Name\|psh::" $f > $OUT/q512_kernel_stats.csv; done
+cd $R
+bash tools/mq_clock.sh > $OUT/mq_clock.txt 2>&1
+PSH_MQ_I8=0 bash tools/mq_clock.sh >> $OUT/mq_clock.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 -o /tmp/ubl tools/ubench_lds_unaligned.hip 2>/dev/null && /tmp/ubl > $OUT/ubench_lds_unaligned.txt 2>&1
 tail -c 600 $OUT/pmc_summary.txt; head -8 $OUT/kernel_stats.csv; cat $OUT/bench_n1.json

@@ -9,7 +9,7 @@ import os
 import sys
 
 out = sys.argv[1]
-KEEP = ("stream_scan_kernel", "stream_sample_kernel", "stream_rank_kernel", "scan_fused_kernel", "scan_kernel", "scan_mx_kernel", "scan_mq_kernel", "boot_mq_kernel", "embed_scan_kernel", "embed_px_kernel", "embed_mx_kernel", "rank_sort", "select", "threshold")
+KEEP = ("stream_scan_kernel", "stream_sample_kernel", "stream_rank_kernel", "scan_fused_kernel", "scan_kernel", "scan_mx_kernel", "scan_mq_kernel", "scan_mq8_kernel", "boot_mq_kernel", "embed_scan_kernel", "embed_px_kernel", "embed_mx_kernel", "rank_sort", "select", "threshold")
 means = {}
 for path in sorted(glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
     acc = collections.defaultdict(list)
@@ -57,7 +57,7 @@ if "--mq" in sys.argv:
     # the batched scan (bench.py --queries 512): busy fractions of the matrix cores and the vector ALUs of scan_mq_kernel, and
     # its HBM traffic, for bench.py's "mfma+valu" roofline object
     dst = sys.argv[sys.argv.index("--mq") + 1]
-    kn = next((k for (k, c) in means if "scan_mq_kernel" in k and c == "GRBM_GUI_ACTIVE"), None)
+    kn = next((k for (k, c) in means if ("scan_mq8_kernel" in k or "scan_mq_kernel" in k) and c == "GRBM_GUI_ACTIVE"), None)
     if kn:
         cyc = means[(kn, "GRBM_GUI_ACTIVE")] / 8.0                 # summed over the 8 XCDs -> shader cycles of the launch
         nsimd = 1024.0
