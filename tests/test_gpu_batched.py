@@ -208,6 +208,26 @@ def test_shadow_cuda_identity_matches_the_reference_with_paths(hip_device, oracl
         assert same.mean() > 0.99
 
 
+def test_shadow_cuda_picks_the_f16_test_for_a_batch_of_mixed_amplitudes(hip_device, oracle_mod, monkeypatch):
+    """PathShadowing looks at the host copy of a batch: queries more than ~3x apart in amplitude go to the f16 rejection test
+    (PSH_FLAG_MQ_F16), the others to the 8-bit one -- and either way the call returns the oracle's result."""
+    import shadowing_amd as sa
+    from shadowing_amd import _native
+    ds = syn.dataset(2048, 1500, 2800)
+    obj = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), ds, sa.PredictionContext(horizon=20))
+    seen = []
+    real = _native.scan_topk                                      # (shadow() issues ONE raw call and reads its status with the results)
+    monkeypatch.setattr(_native, "scan_topk", lambda *a, **kw: (seen.append(kw.get("flags", 0)), real(*a, **kw))[1])
+    q = syn.rolling_queries(24, 20, 2801)
+    for scale, want in ((np.ones((24, 1), np.float32), 0), (np.linspace(1.0, 40.0, 24, dtype=np.float32)[:, None], _native.FLAG_MQ_F16)):
+        x = (q * scale).astype(np.float32)
+        n0 = len(seen)
+        d, _, idx = obj.shadow(x, k=100, cuda=True)
+        assert seen[n0] & _native.FLAG_MQ_F16 == want             # (the call's first launch; a query that overflows is rerun exhaustively)
+        od, oidx = oracle_mod.scan_topk(ds, x, 100, h=20)
+        assert_exact(d, idx, od, oidx, f"flags {want}")
+
+
 def test_resident_copy_follows_edits_of_the_ensemble(hip_device):
     """cuda=True: a writeable numpy ensemble is re-read on every call (an in-place edit of one row is seen, as in the
     reference); a torch ensemble stays resident and is re-uploaded when its version counter moves; cache=True keeps
