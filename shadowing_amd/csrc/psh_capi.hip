@@ -824,6 +824,9 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     sa.emb_mx = boot_emx ? 1 : 0;
     sa.blockmax = (use_mx || use_mq) ? w.blockmax : nullptr;
     int n_blockmax = plan_s.grid;
+    // the batch's tables and constants (the bootstrap's f16 copies, nx~, the f16 scale; the 8-bit test's step and residue
+    // norms): whichever bootstrap follows, the threshold kernel reads the meta words
+    if (use_mq) HIP_TRY(launch_mq_prep(queries, B, p.W, w.mq_frag, s));
     // (a single query is better served by the exact bootstrap: 8192 segments are a latency-bound launch either
     // way -- 20.8 vs 18.7 us measured -- and the exact minima admit 9 % fewer candidates)
     if (use_mq && bp.per_wave == 1 && boot_mq_supported(p.W)) {
@@ -841,7 +844,6 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
             const int64_t r2e = (4 * (int64_t)k * n_sample + 2 * p.R - 1) / (2 * p.R) + 8;
             sa.boot_estimate = (r2e < k && r2e <= bp.entries) ? 1 : 0;
         }
-        HIP_TRY(launch_mq_prep(queries, B, p.W, w.mq_frag, s));
         HIP_TRY(launch_boot_mq(sa, p.aligned, (int)gx, s));
     } else if (rows_path) {
         int ncu = 0;

@@ -328,6 +328,12 @@ __device__ __forceinline__ float min3f(float a, float b, float c) {
     // moved right behind their MFMA)
     return __builtin_fminf(__builtin_fminf(a, b), c);
 }
+// x^ of the 8-bit batched scan: a query sample on the batch's step (inv_s0 = 127 / max|x| of the batch) -- ONE expression for
+// mq_prep_kernel (the residues' norms) and threshold_kernel (the table, ||x^||_1): the bound needs them to agree bit for bit
+__device__ __forceinline__ int mq8_quant(float xv, float inv_s0) {
+    const int q = (int)rintf(xv * inv_s0);
+    return q > 127 ? 127 : (q < -127 ? -127 : q);
+}
 // The maximum of a non-negative value over the wave, in every lane (uniform): four DPP steps inside the rows of 16 lanes, then the
 // four rows through SGPRs -- no trip through the LDS crossbar (six dependent ds_bpermute are ~100+ cycles each beside a busy LDS).
 __device__ __forceinline__ float wave_max_nonneg(float x) {

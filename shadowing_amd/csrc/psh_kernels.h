@@ -179,6 +179,13 @@ static_assert(sizeof(EmbedPlan) <= PSH_PLAN_BYTES, "plan region");
                                      // the launch plan: psh_embedded_supported)
 #define PSH_LDS_BYTES (160 * 1024)   // LDS per CU (gfx950)
 
+// the batched scans' per-batch tables in the workspace (mq_frag: 512 x B4 bytes, B4 = B rounded up to 4): the SCAN's query
+// table at offset 0 (written by the threshold kernel), the bootstrap's f16 copies, nx~, and the meta words
+// {f16 scale, 1 / scale^2, largest ||x - s0 x^||^2 bits, largest ||x||^2 bits, largest |x| bits} (mq_prep_kernel)
+#define PSH_MQ_BOOT_OFF(B4) ((size_t)192 * (size_t)(B4))
+#define PSH_MQ_NX_OFF(B4) ((size_t)384 * (size_t)(B4))
+#define PSH_MQ_META_OFF(B4) ((size_t)392 * (size_t)(B4))
+
 struct ThresholdArgs {
     const float* minbuf;
     int64_t min_stride;

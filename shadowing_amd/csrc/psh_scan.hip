@@ -1190,9 +1190,7 @@ __global__ __launch_bounds__(PSH_MQ_THREADS) void scan_mq8_kernel(ScanArgs a) {
 // chunk's 57 KB fragment table from the queries: most of the bootstrap's 0.25 ms at 512 queries).  Layout behind `mq`
 // (the workspace's 512 x B4 bytes, B4 = B rounded up to 4; the threshold kernel later writes the SCAN's copies, at its own
 // scale, at offset 0): boot copies at 192 B4 bytes, nx~ at 384 B4, {scale, 1 / scale^2} at 392 B4.
-#define PSH_MQ_BOOT_OFF(B4) ((size_t)192 * (size_t)(B4))
-#define PSH_MQ_NX_OFF(B4) ((size_t)384 * (size_t)(B4))
-#define PSH_MQ_META_OFF(B4) ((size_t)392 * (size_t)(B4))
+// (PSH_MQ_BOOT_OFF / PSH_MQ_NX_OFF / PSH_MQ_META_OFF: psh_kernels.h -- the threshold kernel reads the meta words too)
 #define PSH_MQ_PREP_Q 16          // queries per block of mq_prep_kernel (every block finds the batch's scale for itself)
 __global__ __launch_bounds__(1024) void mq_prep_kernel(const float* __restrict__ queries, int B, int W, void* mq) {
     __shared__ unsigned s_max;
@@ -1233,6 +1231,42 @@ __global__ __launch_bounds__(1024) void mq_prep_kernel(const float* __restrict__
         float* meta = reinterpret_cast<float*>(base + PSH_MQ_META_OFF(B4));
         meta[0] = scale;
         meta[1] = unscale2;
+    }
+    if (blockIdx.x == gridDim.x - 1) {
+        // the 8-bit test's batch constants (threshold_kernel, "scan_mq8_kernel"), once per batch instead of once per query's
+        // block: with the step s0 = max|x| / 127 and x^ = round(x / s0), the largest ||x - s0 x^||^2 and the largest ||x||^2 of
+        // the batch (UNSCALED: the power-of-two scale the threshold kernel settles on later multiplies both exactly)
+        __shared__ unsigned s_e2, s_nx;
+        if (tid == 0) { s_e2 = 0u; s_nx = 0u; }
+        __syncthreads();
+        const float xmax = __uint_as_float(qmaxbits);
+        const bool ok = qmaxbits > 0u && qmaxbits < PSH_INF_BITS;
+        const float inv_s0 = ok ? 127.0f / xmax : 0.0f;
+        const double s0 = ok ? 1.0 / (double)inv_s0 : 0.0;
+        for (int q = tid; q < B; q += 1024) {
+            float xv[25];
+#pragma unroll
+            for (int j = 0; j < 25; ++j) xv[j] = j < W ? queries[(int64_t)q * W + j] : 0.0f;
+            double e2 = 0.0, nxq = 0.0;
+#pragma unroll
+            for (int j = 0; j < 25; ++j) {
+                const double r = (double)xv[j] - s0 * (double)mq8_quant(xv[j], inv_s0);
+                e2 += r * r;
+                nxq += (double)xv[j] * (double)xv[j];
+            }
+            float e2f = (float)e2, nxf = (float)nxq;
+            if ((double)e2f < e2) e2f = __uint_as_float(__float_as_uint(e2f) + 1u);          // rounded up (non-negative)
+            if ((double)nxf < nxq) nxf = __uint_as_float(__float_as_uint(nxf) + 1u);
+            if (ok && e2f == e2f) atomicMax(&s_e2, __float_as_uint(e2f));
+            if (ok && nxf == nxf) atomicMax(&s_nx, __float_as_uint(nxf));
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned* meta = reinterpret_cast<unsigned*>(base + PSH_MQ_META_OFF(B4));
+            meta[2] = ok ? s_e2 : 0u;
+            meta[3] = ok ? s_nx : 0u;
+            meta[4] = ok ? qmaxbits : 0u;
+        }
     }
 }
 

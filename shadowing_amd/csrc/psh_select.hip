@@ -179,7 +179,7 @@ __device__ inline void radix_select64(KeyFn key_of, LiveFn live, int n, int rank
 
 // bootstrap threshold: tau = k-th smallest of the sampled minima (+ margin).  The sample
 // is staged in LDS once; every selection pass then runs at LDS latency.
-__global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(ThresholdArgs a) {
+__global__ __launch_bounds__(PSH_SELECT_THREADS, 8) void threshold_kernel(ThresholdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned tkeys[];   // n_entries (or nothing)
     __shared__ SelectShared sm;
     const int b = (int)blockIdx.x;
@@ -187,19 +187,17 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
     const float* v = a.minbuf + (int64_t)b * a.min_stride;
     const int n = a.n_entries;
     __shared__ unsigned s_maxbits;                         // largest |value| among the sampled data and this query
-    __shared__ unsigned s_xmaxbits, s_e2bits, s_nxbits;    // 8-bit test: largest |x| of the batch, largest quantisation residue, largest ||x||^2
-    if (tid == 0) { prep_query(a.prep, b); s_maxbits = 0u; s_xmaxbits = 0u; s_e2bits = 0u; s_nxbits = 0u; sm.prefix_b = ~0ull; }   // ||x||, sum of squares, state reset
-    // 8-bit test (end of this kernel): what it reads from memory is requested HERE -- thread q keeps query q's samples, the
-    // block's own query goes to LDS --, so that the loads' round trips pass behind the selection instead of after it
-    static_assert(PSH_MAX_B_PER_LAUNCH <= PSH_SELECT_THREADS, "thread q prepares query q");
+    if (tid == 0) { prep_query(a.prep, b); s_maxbits = 0u; sm.prefix_b = ~0ull; }   // ||x||, sum of squares, state reset
+    // 8-bit test (end of this kernel): what it reads from memory is requested HERE -- this block's query and the batch's
+    // constants (mq_prep_kernel's meta words) go to LDS --, so that the round trips pass behind the selection, not after it
     __shared__ float s_xb[25];
+    __shared__ unsigned s_meta[3];                         // largest ||x - s0 x^||^2, largest ||x||^2, largest |x| of the batch (bits)
     __shared__ float s_sc;
-    float xv8[25];
     const bool i8prep = a.mq_frag && a.mq_i8;
     if (i8prep) {
-#pragma unroll
-        for (int j = 0; j < 25; ++j) xv8[j] = (tid < a.prep.B && j < a.prep.W) ? a.prep.queries[(int64_t)tid * a.prep.W + j] : 0.0f;
         if (tid < 25) s_xb[tid] = tid < a.prep.W ? a.prep.queries[(int64_t)b * a.prep.W + tid] : 0.0f;
+        if (tid >= 32 && tid < 35)
+            s_meta[tid - 32] = reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(a.mq_frag) + PSH_MQ_META_OFF((a.prep.B + 3) & ~3))[tid - 30];
         if (tid == 0) s_sc = 0.0f;
     }
     __syncthreads();                                       // (block-scope visibility of qstate[b] for thread 0 below)
@@ -209,12 +207,9 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
         // batched matrix-core scan: ONE scale for all queries (they share the f16 copy of the data)
         const int64_t xlo = a.mq_frag ? 0 : (int64_t)b * a.prep.W;
         const int64_t xhi = a.mq_frag ? (int64_t)a.prep.B * a.prep.W : xlo + a.prep.W;
-        unsigned xb = 0u;
         for (int64_t j = xlo + tid; j < xhi; j += PSH_SELECT_THREADS)
-            xb = max(xb, __float_as_uint(fabsf(a.prep.queries[j])));
-        mb = max(mb, xb);
+            mb = max(mb, __float_as_uint(fabsf(a.prep.queries[j])));
         if (mb) atomicMax(&s_maxbits, mb);
-        if (xb) atomicMax(&s_xmaxbits, xb);
         __syncthreads();
     }
     if (n < a.k) return;                                   // tau stays +inf (host avoids this)
@@ -329,42 +324,23 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void threshold_kernel(Threshold
         //     c <= s_x s_y sum x^ y^ + (s_x s_y / 2) ||x^||_1 + ||ex||_2 sqrt(ny),     2 E sqrt(ny) <= beta ny + E^2 / beta,
         // so a window the exact chain admits -- ny - 2 c < Theta := tau (1 + 2^-16) - nx -- satisfies, in units of 2 s_x s_y,
         //     (1 - beta) ny / (2 s_x s_y) - sum x^ y^  <  (Theta + E^2 / beta) / (2 s_x s_y) + ||x^||_1 / 2.
-        // E = the largest ||ex||_2 of the batch and beta = E / the largest ||x~||_2 (clamped) are the same in every block (maxima
-        // taken through integer atomics: no summation order), so the window side -- C_w, the MFMA's C operand -- is one
-        // for all queries.  Everything is evaluated in double and rounded towards "keep".
+        // E = the largest ||ex||_2 of the batch and beta = E / the largest ||x~||_2 (clamped) are the same for every query (one
+        // block of mq_prep_kernel takes the maxima, through integer atomics: no summation order), so the window side -- C_w, the
+        // MFMA's C operand -- is one for all queries.  Everything is evaluated in double and rounded towards "keep".
         __syncthreads();
         const float sc = s_sc;                             // thread 0 above; 0 = filter not armed
-        const float xm = __uint_as_float(s_xmaxbits) * sc;
-        const bool armed = sc > 0.0f && xm > 0.0f && xm < __uint_as_float(PSH_INF_BITS);
-        const float inv_sx = armed ? 127.0f / xm : 0.0f;
-        const double s_x = armed ? 1.0 / (double)inv_sx : 0.0;
+        // the batch's step and residues come UNSCALED from mq_prep_kernel (one block's work instead of every block's); the
+        // scale is a power of two: s_x = sc s0, E^2 = sc^2 E0^2, max ||x~||^2 = sc^2 max ||x||^2, exactly
+        const float xmax = __uint_as_float(s_meta[2]);
+        const bool armed = sc > 0.0f && s_meta[2] > 0u && s_meta[2] < PSH_INF_BITS && (xmax * sc) < __uint_as_float(PSH_INF_BITS);
+        const float inv_s0 = armed ? 127.0f / xmax : 0.0f;
+        const double s_x = armed ? (double)sc / (double)inv_s0 : 0.0;
         const int W = a.prep.W;
-        auto quant = [&](float xv) -> int {                // x^ of a scaled sample (the same expression wherever it is needed)
-            int q = (int)rintf((xv * sc) * inv_sx);
-            return q > 127 ? 127 : (q < -127 ? -127 : q);
-        };
-        if (armed) {
-            if (tid < a.prep.B) {                          // (B <= PSH_MAX_B_PER_LAUNCH = the block's threads: query tid)
-                double e2 = 0.0, nxq = 0.0;
-#pragma unroll
-                for (int j = 0; j < 25; ++j) {
-                    const double xs = (double)(xv8[j] * sc);
-                    const double r = xs - s_x * (double)quant(xv8[j]);
-                    e2 += r * r;
-                    nxq += xs * xs;
-                }
-                float e2f = (float)e2, nxf = (float)nxq;
-                if ((double)e2f < e2) e2f = __uint_as_float(__float_as_uint(e2f) + 1u);      // rounded up (non-negative)
-                if ((double)nxf < nxq) nxf = __uint_as_float(__float_as_uint(nxf) + 1u);
-                atomicMax(&s_e2bits, __float_as_uint(e2f));
-                atomicMax(&s_nxbits, __float_as_uint(nxf));
-            }
-        }
-        __syncthreads();
+        auto quant = [&](float xv) -> int { return mq8_quant(xv, inv_s0); };
         if (tid == 0) {
             QueryState* qs = a.qstate + b;
             const unsigned tb = qs->tau_bits;
-            const double E2 = (double)__uint_as_float(s_e2bits), NX = (double)__uint_as_float(s_nxbits);
+            const double E2 = (double)__uint_as_float(s_meta[0]) * (double)sc * (double)sc, NX = (double)__uint_as_float(s_meta[1]) * (double)sc * (double)sc;
             if (armed && tb < PSH_INF_BITS && NX > 0.0 && E2 < (double)__uint_as_float(PSH_INF_BITS)) {
                 double beta = sqrt(E2 / NX);
                 beta = beta < 1.0 / 4096.0 ? 1.0 / 4096.0 : (beta > 0.25 ? 0.25 : beta);
@@ -616,7 +592,7 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS) void rank_select_kernel(SelectA
     }
 }
 
-__global__ __launch_bounds__(PSH_SELECT_THREADS) void select_kernel(SelectArgs a) {
+__global__ __launch_bounds__(PSH_SELECT_THREADS, 8) void select_kernel(SelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t items[];   // kpad entries, then key_cap u32 keys
     __shared__ SelectShared sm;
     unsigned* keys = reinterpret_cast<unsigned*>(items + a.kpad);
@@ -1389,6 +1365,10 @@ hipError_t launch_select(const SelectArgs& a0, int B, hipStream_t s) {
     int64_t key_cap = items_bytes < lds_budget ? (int64_t)((lds_budget - items_bytes) / sizeof(unsigned)) : 0;
     const int64_t n_max = a.bcount ? (int64_t)a.nblk * a.slice : (int64_t)a.n_fixed;
     if (key_cap > n_max) key_cap = n_max;
+    // many queries (a block each): 8192 staged keys -- twice what a query of a large batch brings -- leave room for TWO
+    // blocks per compute unit (8 + 32 + 25 KB each): 512 queries are one round of blocks instead of two.  A query with
+    // more candidates than that selects from global memory (in_lds = false), as it does beyond the LDS anyway.
+    if (B > 256 && a.kpad <= 1024 && key_cap > 8192) key_cap = 8192;
     a.key_cap = (int)key_cap;
     // kpad > 1024: the ordering stage wants a second kpad-item buffer behind the items (merge sort by ranking)
     int64_t area = key_cap;
