@@ -24,6 +24,7 @@ the generic torch formulation on the host.
 from __future__ import annotations
 
 import contextlib
+import math
 import warnings
 import weakref
 from pathlib import Path
@@ -354,20 +355,35 @@ class PathShadowing:
                     return _native.scan_topk_embedded(rows, ker2, q, k, h=h, workspace=self._workspace,
                                                       exhaustive=exhaustive, flags=fl, keep_plan=True)
         else:
-            # a batch's rejection test puts every query on ONE 8-bit step (PSH_FLAG_MQ_F16, include/psh.h): queries that differ
-            # in amplitude by more than ~3x are better served by the f16 test (same results; decided here, where the
-            # queries are still host memory -- a few microseconds of numpy)
-            fl = 0
+            # a batch's rejection test puts every query of a call on ONE 8-bit step (include/psh.h, PSH_FLAG_MQ_F16): queries
+            # that differ in amplitude by more than ~3x go to the library as separate calls, one per amplitude class (a factor
+            # of 3 each) -- a call's time is proportional to its queries, so the classes cost what the batch would, plus a
+            # quarter of a millisecond of fixed work per class.  Decided here, where the queries are still host memory.
+            classes = None
             if x.shape[0] > 1 and x.device.type == "cpu":
                 amp = x[:, 0, :].abs().amax(dim=1)
-                lo = amp[amp > 0]
-                if lo.numel() and not (float(amp.max()) <= 3.0 * float(lo.min())):
-                    fl = _native.FLAG_MQ_F16
-            xq = x[:, 0, :].contiguous().to(dev)
+                top = float(amp[torch.isfinite(amp)].max()) if bool(torch.isfinite(amp).any()) else 0.0
+                if top > 0.0 and not (top <= 3.0 * float(amp.min())):
+                    cls = torch.floor(torch.log(torch.clamp(amp / top, min=1e-30)) / math.log(3.0) + 1e-6).to(torch.int64)
+                    cls = torch.where(torch.isfinite(amp) & (amp > 0), cls, torch.full_like(cls, -1000))   # zero / non-finite queries: a class of their own
+                    classes = [torch.nonzero(cls == c).flatten() for c in torch.unique(cls, sorted=True).tolist()[::-1]]
+            if classes is None or len(classes) == 1:
+                xq = x[:, 0, :].contiguous().to(dev)
+                if defer_status:
+                    d, idx, status = _native.scan_topk(rows, xq, k, h=h, workspace=self._workspace)
+                    return d, idx, ds, status
+                d, idx = _native.scan_topk_checked(rows, xq, k, h=h, workspace=self._workspace)
+                return d, idx, ds
+            B_ = x.shape[0]
+            d = torch.empty((B_, k), dtype=torch.float32, device=dev)
+            idx = torch.empty((B_, k, 2), dtype=torch.int32, device=dev)
+            for sel in classes:
+                dc, ic = _native.scan_topk_checked(rows, x[sel, 0, :].contiguous().to(dev), k, h=h, workspace=self._workspace)
+                sel_d = sel.to(dev)
+                d[sel_d] = dc
+                idx[sel_d] = ic
             if defer_status:
-                d, idx, status = _native.scan_topk(rows, xq, k, h=h, workspace=self._workspace, flags=fl)
-                return d, idx, ds, status
-            d, idx = _native.scan_topk_checked(rows, xq, k, h=h, workspace=self._workspace, flags=fl)
+                return d, idx, ds, torch.zeros(B_, dtype=torch.int32, device=dev)     # (every class was checked and resolved above)
             return d, idx, ds
         d, idx, status = scan(None, False)
         bad = torch.nonzero(status != _native.PSH_STATUS_OK).flatten()

@@ -208,24 +208,34 @@ def test_shadow_cuda_identity_matches_the_reference_with_paths(hip_device, oracl
         assert same.mean() > 0.99
 
 
-def test_shadow_cuda_picks_the_f16_test_for_a_batch_of_mixed_amplitudes(hip_device, oracle_mod, monkeypatch):
-    """PathShadowing looks at the host copy of a batch: queries more than ~3x apart in amplitude go to the f16 rejection test
-    (PSH_FLAG_MQ_F16), the others to the 8-bit one -- and either way the call returns the oracle's result."""
+def test_shadow_cuda_splits_a_batch_of_mixed_amplitudes_into_classes(hip_device, oracle_mod, monkeypatch):
+    """PathShadowing looks at the host copy of a batch: queries more than ~3x apart in amplitude reach the library as separate
+    calls, one per amplitude class (the 8-bit rejection test puts the queries of a CALL on one step), zero and non-finite
+    queries in a class of their own -- and the batch comes back as one, equal to the oracle."""
     import shadowing_amd as sa
     from shadowing_amd import _native
     ds = syn.dataset(2048, 1500, 2800)
     obj = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), ds, sa.PredictionContext(horizon=20))
     seen = []
-    real = _native.scan_topk                                      # (shadow() issues ONE raw call and reads its status with the results)
-    monkeypatch.setattr(_native, "scan_topk", lambda *a, **kw: (seen.append(kw.get("flags", 0)), real(*a, **kw))[1])
+    real = _native.scan_topk
+    monkeypatch.setattr(_native, "scan_topk", lambda *a, **kw: (seen.append(a[1].detach().cpu().numpy().copy()), real(*a, **kw))[1])
     q = syn.rolling_queries(24, 20, 2801)
-    for scale, want in ((np.ones((24, 1), np.float32), 0), (np.linspace(1.0, 40.0, 24, dtype=np.float32)[:, None], _native.FLAG_MQ_F16)):
+    for scale, many in ((np.ones((24, 1), np.float32), False), (np.geomspace(1.0, 3000.0, 24).astype(np.float32)[:, None], True)):
         x = (q * scale).astype(np.float32)
+        if many:
+            x[5] = 0.0
         n0 = len(seen)
-        d, _, idx = obj.shadow(x, k=100, cuda=True)
-        assert seen[n0] & _native.FLAG_MQ_F16 == want             # (the call's first launch; a query that overflows is rerun exhaustively)
+        d, paths, idx = obj.shadow(x, k=100, cuda=True)
+        calls = seen[n0:]
+        assert (len(calls) > 4) == many
+        for c in calls:                                            # within a call: amplitudes within a factor of 3 (or all zero)
+            a = np.abs(c).max(axis=1)
+            assert a.max() == 0 or a.max() <= 3.0 * a.min() * (1 + 1e-5)
         od, oidx = oracle_mod.scan_topk(ds, x, 100, h=20)
-        assert_exact(d, idx, od, oidx, f"flags {want}")
+        fin = np.isfinite(od).all(axis=1)
+        assert fin.sum() >= 23
+        assert_exact(d[fin], idx[fin], od[fin], oidx[fin], f"classes {many}")
+        assert np.array_equal(paths[fin][:, :, 0, :], oracle_mod.gather_paths(rows3(ds), idx[fin], 40))
 
 
 def test_resident_copy_follows_edits_of_the_ensemble(hip_device):
