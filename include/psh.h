@@ -116,7 +116,8 @@ extern "C" {
  * (PSH_STATUS_RETRY -> rerun with PSH_FLAG_NO_FUSE); one workspace per stream, armed by psh_workspace_init. */
 #define PSH_FLAG_OVERLAP      2048
 /* MQ_F16: psh_scan_topk with a batch of queries (W <= 25): the rejection test of the batched scan as the f16 banded product
- * of rounds 2-4 (two K = 16 steps per tile) instead of the 8-bit product (one K = 32 step; the default since round 4).  The
+ * of rounds 2-4 (two K = 16 steps per tile) instead of the 8-bit product (one K = 32 step; since round 4 the default for
+ * calls with 32 queries and more -- below that a segment's dearer set-up outweighs the halved matrix-core work).  The
  * 8-bit test puts every query of the batch on ONE quantisation step: a batch whose queries differ in amplitude by more than
  * ~4x is better served by f16 (a much smaller query keeps too many windows for its exact recheck -- slower, never wrong).
  * Same results either way (A/B tests; callers that know their batch). */

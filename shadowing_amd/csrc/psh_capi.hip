@@ -216,7 +216,7 @@ inline Tuning tuning() {
     Tuning t{1, 0, 0, PSH_EMB_WIDE_MIN_B, false, 0, 64, nullptr, nullptr, PSH_FUSED_XCD_SKEW, 2, 0, 2048, 2};
 #ifdef PSH_TUNING
     if (const char* e = getenv("PSH_DBG")) t.dbg = atoi(e);
-    if (const char* e = getenv("PSH_MQ_I8")) t.mq_i8 = atoi(e) != 0;                  // batched scan: 0 = the f16 rejection test (A/B)
+    if (const char* e = getenv("PSH_MQ_I8")) t.mq_i8 = atoi(e);                       // batched scan: 0 = the f16 rejection test (A/B), 2 = the 8-bit one whatever the batch
     if (const char* e = getenv("PSH_PX_R1")) { const int v = atoi(e); if (v >= 2) t.px_r1 = v; }   // prefix-sum scan: rows of the first phase (a large value: one phase)
     if (const char* e = getenv("PSH_EMBED_WIDE_MIN_B")) { const int v = atoi(e); if (v >= 1) t.wide_min = v; }
     t.narrow = getenv("PSH_EMBED_NARROW") != nullptr;
@@ -630,7 +630,10 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     bool use_mq = !p.ker && scan_mq_supported(p.W, p.B);      // batched queries: 4 queries x 8 shifts per MFMA
     if (flags_of(profile) & PSH_FLAG_FILTER_VALU) use_mx = use_mq = false;
     // the batched scan's rejection test: the 8-bit product (scan_mq8_kernel) unless the caller asks for f16
-    const bool mq_i8 = tuning().mq_i8 != 0 && !(flags_of(profile) & PSH_FLAG_MQ_F16);
+    // (from 32 queries on: a segment's set-up is ~1.5 k cycles dearer with the 8-bit test -- two passes over the staged values, the
+    //  energies turned into integers, the levels of every query -- and that is what a small batch pays for; 4 queries 230 against
+    //  179 us per call, 16: 303 / 279, 32: 373 / 395, 128: 778 / 1083)
+    const bool mq_i8 = tuning().mq_i8 != 0 && !(flags_of(profile) & PSH_FLAG_MQ_F16) && (p.B >= 32 || tuning().mq_i8 > 1);
     // (half-segment mode measured for the single-query scan: bootstrap 17.4 -> 12.3 us, but tau admits twice as
     // much and the scan's exact rechecks cost 4.3 us more -- 135.7 vs 134.3 us per step; left off)
     // (the matrix-core embedded scan samples one minimum per HALF segment; a sample too thin for that plan is taken by

@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_gpu_batched.py tests/test_gpu_overlap.py -q -m gpu 2>&1 | tail -15
+python tools/batch_sweep.py 2>/dev/null
+timeout 1500 python -m pytest tests/test_gpu_batched.py tests/test_gpu_overlap.py tests/test_gpu_parity.py -q -m gpu 2>&1 | tail -4
