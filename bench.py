@@ -639,7 +639,8 @@ def main():
             if pfile.exists():
                 try:
                     pj = json.loads(pfile.read_text())
-                    if pj.get("workload") == f"R={R},T={T},W={W},h={h},k={k},B={B}":
+                    if (pj.get("workload") == f"R={R},T={T},W={W},h={h},k={k},B={B}"
+                            and ("scan_mq8_kernel" in pj.get("kernel", "")) == (not args.mq_f16)):       # (the counters of THIS kernel only)
                         pmc = pj
                 except Exception:   # noqa: BLE001
                     pmc = None

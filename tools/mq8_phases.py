@@ -26,3 +26,5 @@ m = t.mean(0)
 print("s_memtime ticks per wave (mean): set-up %.0f  group loop %.0f  drain + hand-over %.0f  total %.0f" % (m[0], m[1], m[2], m.sum()))
 print("shares: set-up %.1f %%  group loop %.1f %%  drain + hand-over %.1f %%" % tuple(100 * m / m.sum()))
 print("per segment (64 per wave) and per group (128 per segment): set-up %.0f, loop %.0f = %.1f per group, drain %.0f ticks" % (m[0] / 64, m[1] / 64, m[1] / 64 / 128, m[2] / 64))
+tb = t.sum(1).reshape(-1, 8).max(1)                         # a block is done when its slowest wave is
+print("blocks' times (ticks, the slowest wave of each): min %.0f  mean %.0f  max %.0f  -> the launch waits %.1f %% beyond the mean block" % (tb.min(), tb.mean(), tb.max(), 100 * (tb.max() / tb.mean() - 1)))
