@@ -77,6 +77,8 @@ cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_q512 -o q -- python $R/bench.py --steps 10 --warmup 3 --queries 512 --no-cpu-baseline --no-parity > $OUT/bench_prof_q512.log 2>&1
 for f in $(find $OUT/prof_q512 -name "*kernel_stats.csv"); do grep "Name\|psh::" $f > $OUT/q512_kernel_stats.csv; done
 cd $R
+(for d in 0 4 8; do echo "PSH_DBG=$d"; PSH_DBG=$d python tools/mq8_phases.py 2>/dev/null; done) > $OUT/mq8_phases.txt
+timeout 300 python tools/batch_sweep.py 2>/dev/null > $OUT/batch_sweep.txt
 bash tools/mq_clock.sh > $OUT/mq_clock.txt 2>&1
 PSH_MQ_I8=0 bash tools/mq_clock.sh >> $OUT/mq_clock.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 -o /tmp/ubl tools/ubench_lds_unaligned.hip 2>/dev/null && /tmp/ubl > $OUT/ubench_lds_unaligned.txt 2>&1
