@@ -1,5 +1,5 @@
 // psh_scan.hip -- gfx950 (MI355X, CDNA4) kernels of the k-nearest-path scan: the Identity scans (scan_kernel,
-// scan_mx_kernel, scan_mq_kernel, boot_mq_kernel) and their launchers.  The embedded / one-window-row scans are in
+// scan_mx_kernel, scan_mq_kernel, scan_mq8_kernel, mq_prep_kernel, boot_mq_kernel) and their launchers.  The embedded / one-window-row scans are in
 // psh_embed.hip, thresholding / selection / merge / gather in psh_select.hip, shared device code in psh_device.h.
 //
 // What is computed (reference RudyMorel/shadowing, shadowing/path_shadowing/):
@@ -23,8 +23,10 @@
 //     8 TB/s -- so the scans are bound-then-verify: a cheap quantity with a RIGOROUS error
 //     bound rejects what cannot be admitted, the ~1e-4 survivors get the exact chain.  The
 //     cheap quantity is a banded f16 product on the matrix cores (scan_mx_kernel, one query;
-//     scan_mq_kernel / boot_mq_kernel, batches) or an fp32 correlation + prefix sums on the
-//     VALU (scan_kernel, every other window length; PSH_FILTER=valu).
+//     scan_mq_kernel / boot_mq_kernel, batches), the same band as an 8-BIT product with a
+//     quantisation bound per segment (scan_mq8_kernel: batches of 32 queries and more), or an
+//     fp32 correlation + prefix sums on the VALU (scan_kernel, every other window length;
+//     PSH_FLAG_FILTER_VALU).
 //   * an admission threshold tau (a provable upper bound of the k-th smallest acc: the k-th
 //     smallest over ANY subset of the windows bounds the global one) keeps all but ~1e4 of
 //     the 1e8 windows out of the candidate lists; it comes from a bootstrap pass over 1/16

@@ -1,12 +1,7 @@
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/round; mkdir -p $OUT
-cp $R/gpurun_out/round_q512_pmc.json $R/profiles/q512_pmc.json 2>/dev/null
-for i in 1 2 3; do timeout 300 python bench.py --steps 20 --warmup 3 --queries 512 --no-cpu-baseline > $OUT/bench_n1_q512_try$i.json 2>> $OUT/bench.err; done
-timeout 600 python tools/bench_foveal.py --steps 20 --generic --which tutorial testing wavelet 2>> $OUT/bench.err | grep "^{" > $OUT/bench_foveal.jsonl
-for i in 1 2 3; do python -c "
-import json; j=json.loads(open('$OUT/bench_n1_q512_try$i.json').read().strip().splitlines()[-1]); print(j['ms_per_step'], j['roofline']['avg_launch_ms'])"; done
-python -c "
-import json
-for ln in open('$OUT/bench_foveal.jsonl'):
-    j=json.loads(ln); print(j['workload'][:10], j['ms_per_call'], j['stages_ms']['scan_ms'])"
+O=$R/gpurun_out/final; mkdir -p $O
+timeout 3000 python -m pytest tests -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" | tail -8 > $O/tests.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
+timeout 300 python bench.py --steps 20 --warmup 5 > $O/bench_default20.json 2> $O/bench.err
+tail -n 4 $O/tests.txt; tail -n 1 $O/smoke.txt; cut -c1-330 $O/bench_default20.json
