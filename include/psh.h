@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PSH_VERSION 1
+#define PSH_VERSION 2      /* 2: psh_profile.tau_hint, psh_candidates_layout */
 
 #define PSH_OK                 0
 #define PSH_ERR_ARG           -1   /* NULL pointer / non-positive size / k > number of windows */
@@ -138,6 +138,16 @@ typedef struct psh_profile {
     int   n_sample_rows;
     int   grid_blocks;    /* blocks of the scan kernel */
     int   n_candidates;   /* PSH_PROFILE_STAGES: largest per-query candidate count the scan admitted */
+    /* in (version 2), optional: the caller's ADMISSION HINT -- device-addressable, B floats, or NULL.
+     * hint[b] is a level on acc = sum_j (x_j - y_{t+j})^2 = (d ||x||)^2 (behind an embedding: sum_i (hx_i - hy_i)^2): the call
+     * admits the windows of query b with acc < hint[b] and takes NO bootstrap sample (no sample launch; the fused launch skips
+     * its sample phase and its first grid barrier).  The results are the exact top-k whenever at least k windows lie below
+     * the hint; when fewer do -- or the hint is not a positive finite number, or it admits more than the candidate lists hold --
+     * the query's status says PSH_STATUS_OVERFLOW / PSH_STATUS_RETRY as for a sampled level that fell short, and the caller
+     * reruns the call WITHOUT the hint.  Meant for consecutive queries whose k-th distance is known roughly (rolling query
+     * dates: the previous call's out_d[b][k-1] -> hint = (d_k ||x||)^2 x margin), and for tests that pin the admitted set
+     * (psh_candidates_layout).  The small-problem / exhaustive paths ignore it. */
+    const float* tau_hint;
 } psh_profile;
 
 int         psh_version(void);
@@ -251,6 +261,22 @@ int psh_embedded_supported(int d, int K);   /* 1 when a d x K kernel fits the em
  * matrix -- four int32 {one_interval, ktop, merged_rows, d}: one_interval != 0 says the prefix-sum scan did the work
  * (tests and tools read it after synchronising the stream). */
 size_t psh_embed_plan_offset(void);
+/* Diagnostics (tests, tools): where a psh_scan_topk / psh_scan_topk_embedded call with these sizes on a workspace of
+ * `workspace_bytes` leaves the windows its scan ADMITTED (acc below the level), before the selection picks k of them:
+ *   out[0] byte offset of the per-query state (48 bytes a query: ||x||, the level's float bits, ...)
+ *   out[1] byte offset of bcount  (int32 [B][out[9]]: entries block i appended to the FRONT of its slice of query b)
+ *   out[2] byte offset of bcount2 (int32 [out[9]]: single-query matrix-core scan with two-class slices: entries at the BACK)
+ *   out[3] byte offset of cand_d  (float [B][cap]: distances; 0xffffffff = a back entry whose distance was not computed)
+ *   out[4] byte offset of cand_rt (int32 [B][cap][2]: (r_global, t))
+ *   out[5] cap (entries per query); block i's slice of query b starts at b * cap + i * (cap / grid_blocks) -- grid_blocks
+ *          from psh_profile after the call -- front entries upwards from its start, back entries downwards from its end
+ *   out[6] byte offset of the fused / overlap-friendly launches' candidate area (16-byte entries), out[7] of the fused
+ *          launch's per-block records (uint64 [out[10]]: low 31 bits = entries of block i, which start at entry i * out[11];
+ *          an entry = {d bits | r << 32, t}), out[8] of the overlap-friendly launches' per-query counts (uint32 [4]; query q's
+ *          entries {d bits, r, t, -} start at entry q * (out[10] * out[11] / B))
+ *   out[9] PSH_MAX_BLOCKS, out[10] blocks of the fused launch at most, out[11] entries a fused block may publish
+ * Nothing is launched; PSH_ERR_WORKSPACE when the workspace is too small for the sizes. */
+int psh_candidates_layout(int64_t R, int64_t T, int B, int W, int h, int k, size_t workspace_bytes, int64_t* out12);
 int psh_scan_topk_embedded(int device, void* stream,
                            const float* dataset, int64_t R, int64_t T, int64_t r_offset,
                            const float* kernel, int d, int K,

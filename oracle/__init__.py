@@ -6,5 +6,5 @@ reference lines each function restates and for the parity-pinning status.
 """
 from .oracle import (  # noqa: F401
     build, lib, qnorm, scan_topk, all_distances, gather_paths, shadow,
-    scan_topk_embedded, all_distances_embedded,
+    scan_topk_embedded, all_distances_embedded, all_acc, all_acc_embedded,
 )

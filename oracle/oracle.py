@@ -45,6 +45,10 @@ def lib() -> C.CDLL:
         L.psh_oracle_all_distances_embedded.restype = C.c_int
         L.psh_oracle_all_distances_embedded.argtypes = [f32p, C.c_int64, C.c_int64, f32p, C.c_int, C.c_int,
                                                         f32p, C.c_float, C.c_int, f32p]
+        L.psh_oracle_all_acc.restype = C.c_int
+        L.psh_oracle_all_acc.argtypes = [f32p, C.c_int64, C.c_int64, f32p, C.c_int, C.c_int, f32p]
+        L.psh_oracle_all_acc_embedded.restype = C.c_int
+        L.psh_oracle_all_acc_embedded.argtypes = [f32p, C.c_int64, C.c_int64, f32p, C.c_int, C.c_int, f32p, C.c_int, f32p]
         _lib = L
     return _lib
 
@@ -105,6 +109,36 @@ def all_distances(dataset, query, h: int = 0, qn=None) -> np.ndarray:
                                         _p(out, C.c_float))
     if rc != 0:
         raise RuntimeError("psh_oracle_all_distances failed")
+    return out
+
+
+def all_acc(dataset, query, h: int = 0) -> np.ndarray:
+    """(R, T') float32: every window's numerator acc = the sequential fp32 chain sum_j (x_j - y_{t+j})^2, before the
+    square root and the division by ||x|| -- what the scans compare with their admission level."""
+    ds = _rows(dataset)
+    x = _f32(query).reshape(-1)
+    R, T = ds.shape
+    W = x.shape[0]
+    out = np.empty((R, T - W - h + 1), np.float32)
+    if lib().psh_oracle_all_acc(_p(ds, C.c_float), R, T, _p(x, C.c_float), W, h, _p(out, C.c_float)) != 0:
+        raise RuntimeError("psh_oracle_all_acc failed")
+    return out
+
+
+def all_acc_embedded(dataset, kernel, hx, h: int = 0) -> np.ndarray:
+    """(R, T') float32: every window's embedded numerator sum_i (hx_i - hy_i)^2 in the oracle's order."""
+    ds = _rows(dataset)
+    ker = _f32(kernel)
+    if ker.ndim == 3:
+        ker = ker[:, 0, :]
+    ker = np.ascontiguousarray(ker)
+    d_, K = ker.shape
+    x = _f32(hx).reshape(-1)
+    R, T = ds.shape
+    out = np.empty((R, T - K - h + 1), np.float32)
+    if lib().psh_oracle_all_acc_embedded(_p(ds, C.c_float), R, T, _p(ker, C.c_float), d_, K, _p(x, C.c_float), h,
+                                         _p(out, C.c_float)) != 0:
+        raise RuntimeError("psh_oracle_all_acc_embedded failed")
     return out
 
 

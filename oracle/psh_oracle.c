@@ -428,6 +428,45 @@ int psh_oracle_all_distances(const float* dataset, int64_t R, int64_t T,
     return 0;
 }
 
+/* every window's NUMERATOR acc (the value the scans compare with their admission level) for one query: the sequential
+ * fp32 fma chain of path_distance.py:62-65 before the square root and the division -- tests/test_gpu_admitted_set.py
+ * builds {w : acc(w) < tau} from it.  Windows the reference's zero-padded conv makes NaN are NaN here too. */
+int psh_oracle_all_acc(const float* dataset, int64_t R, int64_t T, const float* x, int W, int h, float* out /* R x Tp */) {
+    const int64_t Tp = T - W - h + 1;
+    if (Tp <= 0) return -1;
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < R; ++r) {
+        int32_t* nf = (int32_t*)malloc(sizeof(int32_t) * (size_t)(T + 1));
+        const int dirty = nf && nonfinite_prefix(dataset + r * T, T, nf) != 0;
+        for (int64_t t = 0; t < Tp; ++t) {
+            float a = 0.0f;
+            if (Tp == 1) a = acc_single_window_row(dataset + r * T, x, W);
+            else for (int j = 0; j < W; ++j) { float D = x[j] - dataset[r * T + t + j]; a = fmaf(D, D, a); }
+            out[r * Tp + t] = (dirty && nf[t + W + h] != nf[t]) ? NAN : a;
+        }
+        free(nf);
+    }
+    return 0;
+}
+
+int psh_oracle_all_acc_embedded(const float* dataset, int64_t R, int64_t T, const float* ker, int d, int K,
+                                const float* hx, int h, float* out /* R x Tp */) {
+    const int64_t Tp = T - K - h + 1;
+    if (Tp <= 0) return -1;
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < R; ++r) {
+        int32_t* nf = (int32_t*)malloc(sizeof(int32_t) * (size_t)(T + 1));
+        const int dirty = nf && nonfinite_prefix(dataset + r * T, T, nf) != 0;
+        for (int64_t t = 0; t < Tp; ++t) {
+            out[r * Tp + t] = Tp == 1 ? embedded_acc_one_window(dataset + r * T, ker, d, K, hx)
+                                      : embedded_acc(dataset + r * T + t, ker, d, K, hx);
+            if (dirty && nf[t + K + h] != nf[t]) out[r * Tp + t] = NAN;
+        }
+        free(nf);
+    }
+    return 0;
+}
+
 /* path gather, path_shadowing.py:211-216 (single channel): out[b,i,:] =
  * dataset[r, t : t+len] for (r,t) = idx[b,i]; r is global (minus r_offset). */
 int psh_oracle_gather_paths(const float* dataset, int64_t R, int64_t T, int64_t r_offset,

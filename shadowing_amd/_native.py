@@ -14,6 +14,7 @@ import torch
 from . import _build
 
 PSH_OK = 0
+PSH_VERSION = 2          # include/psh.h: psh_profile.tau_hint, psh_candidates_layout
 PSH_STATUS_OK, PSH_STATUS_OVERFLOW, PSH_STATUS_RETRY = 0, 1, 2
 PSH_MAX_W, PSH_MAX_K, PSH_MAX_B_PER_LAUNCH = 256, 16384, 1024
 # psh_profile.flags (include/psh.h)
@@ -29,10 +30,10 @@ class PshProfile(C.Structure):
                 ("prep_ms", C.c_float), ("sample_ms", C.c_float), ("threshold_ms", C.c_float),
                 ("scan_ms", C.c_float), ("select_ms", C.c_float), ("total_ms", C.c_float),
                 ("path", C.c_int), ("n_sample_rows", C.c_int), ("grid_blocks", C.c_int),
-                ("n_candidates", C.c_int)]
+                ("n_candidates", C.c_int), ("tau_hint", C.c_void_p)]
 
     def as_dict(self) -> dict:
-        skip = ("mode", "flags", "ev_scan_begin", "ev_scan_end")
+        skip = ("mode", "flags", "ev_scan_begin", "ev_scan_end", "tau_hint")
         return {name: getattr(self, name) for name, _ in self._fields_ if name not in skip}
 
 
@@ -40,7 +41,7 @@ EXPORTS = ("psh_version", "psh_strerror", "psh_last_hip_error", "psh_workspace_b
            "psh_scan_topk", "psh_scan_topk_exhaustive", "psh_scan_topk_embedded",
            "psh_scan_topk_embedded_exhaustive", "psh_merge_workspace_bytes", "psh_merge_topk",
            "psh_merge_topk_gathered", "psh_merge_sorted_gathered", "psh_gather_paths", "psh_embed_rows",
-           "psh_embedded_supported", "psh_embed_plan_offset", "psh_workspace_init", "psh_last_comm_error", "psh_comm_unique_id", "psh_comm_create",
+           "psh_embedded_supported", "psh_embed_plan_offset", "psh_candidates_layout", "psh_workspace_init", "psh_last_comm_error", "psh_comm_unique_id", "psh_comm_create",
            "psh_comm_destroy", "psh_comm_world", "psh_exchange_merge", "psh_stream_create_reserving", "psh_stream_destroy",
            "psh_weighted_moments", "psh_realized_variance", "psh_count_nonfinite", "psh_smear_nonfinite")
 
@@ -121,6 +122,8 @@ def load() -> C.CDLL:
     L.psh_merge_sorted_gathered.argtypes = [i32, vp, vp, vp, i32, i64, i64, i32, i32, i32, vp, vp]
     L.psh_embed_plan_offset.restype = C.c_size_t
     L.psh_embed_plan_offset.argtypes = []
+    L.psh_candidates_layout.restype = i32
+    L.psh_candidates_layout.argtypes = [i64, i64, i32, i32, i32, i32, C.c_size_t, C.POINTER(C.c_int64)]
     L.psh_embedded_supported.restype = i32
     L.psh_embedded_supported.argtypes = [i32, i32]
     L.psh_embed_rows.restype = i32
@@ -135,6 +138,9 @@ def load() -> C.CDLL:
     L.psh_realized_variance.argtypes = [i32, vp, vp, i64, i64, i32, C.POINTER(C.c_int), i32, i32, vp]
     L.psh_gather_paths.restype = i32
     L.psh_gather_paths.argtypes = [i32, vp, vp, i64, i64, i64, i64, vp, i64, i32, vp]
+    if L.psh_version() != PSH_VERSION:
+        raise NativeLibraryError(f"{path} speaks version {L.psh_version()} of the C ABI, this binding version {PSH_VERSION} "
+                                 "(psh_profile differs): rebuild it with `python -m shadowing_amd._build`")
     _lib = L
     return L
 
@@ -212,7 +218,7 @@ def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, 
               qnorm: torch.Tensor | None = None, workspace: Workspace | None = None,
               exhaustive: bool = False, profile: bool = False, extra_workspace_factor: float = 1.0,
               scan_events: tuple | None = None, out: tuple | None = None, unsorted: bool = False, flags: int = 0,
-              info: dict | None = None):
+              info: dict | None = None, tau_hint: torch.Tensor | None = None):
     """Enqueue the scan on the current stream.
 
     dataset (R, T) float32 device, queries (B, W) float32 device.  Returns
@@ -226,6 +232,8 @@ def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, 
     merge afterwards).  `flags`: further PSH_FLAG_* bits (A/B switches of tests and tools).
     `info`: a dict that receives the launch plan's facts (path: 0 separate launches, 1 exhaustive, 2 fused, 3 the
     overlap-friendly launches; ...) without any synchronisation.
+    `tau_hint`: (B,) float32 device tensor, the caller's admission levels on acc = (d ||x||)^2 (psh_profile.tau_hint): no
+    bootstrap sample; a status other than OK then means "rerun without the hint".
     """
     ds = _dev_tensor(dataset, torch.float32, "dataset")
     q = _dev_tensor(queries, torch.float32, "queries")
@@ -243,7 +251,8 @@ def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, 
         parts = [scan_topk(ds, q[i:i + PSH_MAX_B_PER_LAUNCH].contiguous(), k, h=h, r_offset=r_offset,
                            qnorm=None if qnorm is None else qnorm[i:i + PSH_MAX_B_PER_LAUNCH].contiguous(),
                            workspace=workspace, exhaustive=exhaustive, extra_workspace_factor=extra_workspace_factor,
-                           unsorted=unsorted, flags=flags)
+                           unsorted=unsorted, flags=flags,
+                           tau_hint=None if tau_hint is None else tau_hint[i:i + PSH_MAX_B_PER_LAUNCH].contiguous())
                  for i in range(0, B, PSH_MAX_B_PER_LAUNCH)]
         return tuple(torch.cat([p[j] for p in parts], dim=0) for j in range(3))
     nbytes = int(workspace_bytes(R, T, B, W, h, k) * extra_workspace_factor)
@@ -274,11 +283,16 @@ def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, 
         prof.ev_scan_end = scan_events[1].cuda_event
     if unsorted and not exhaustive:
         flags |= FLAG_UNSORTED
-    if flags or info is not None:
+    if tau_hint is not None:
+        tau_hint = _dev_tensor(tau_hint, torch.float32, "tau_hint")
+        if tuple(tau_hint.shape) != (B,):
+            raise ValueError("tau_hint must be (B,) float32")
+    if flags or info is not None or tau_hint is not None:
         if prof is None:
             prof = PshProfile()
             prof.mode = 1                 # no events given: nothing is recorded, nothing is synchronised
         prof.flags = flags
+        prof.tau_hint = None if tau_hint is None else tau_hint.data_ptr()
     fn = load().psh_scan_topk_exhaustive if exhaustive else load().psh_scan_topk
     rc = fn(dev.index, _stream_ptr(dev), ds.data_ptr(), R, T, r_offset, q.data_ptr(),
             None if qnorm is None else qnorm.data_ptr(), B, W, h, k,
@@ -293,14 +307,23 @@ def scan_topk(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, 
 
 
 def scan_topk_checked(dataset: torch.Tensor, queries: torch.Tensor, k: int, h: int = 0, r_offset: int = 0,
-                      workspace: Workspace | None = None, out: tuple | None = None, unsorted: bool = False, flags: int = 0):
+                      workspace: Workspace | None = None, out: tuple | None = None, unsorted: bool = False, flags: int = 0,
+                      tau_hint: torch.Tensor | None = None):
     """scan_topk + the status protocol of include/psh.h, with ONE host synchronisation in the normal case:
+    a call with `tau_hint` whose status is not OK everywhere (the hint fell short of k windows, or was useless) -> the same
+    call without the hint, then as below;
     PSH_STATUS_RETRY (the fused launch gave up) -> the same call through the separate launches (PSH_FLAG_NO_FUSE);
     PSH_STATUS_OVERFLOW (candidate slices overflowed: ties en masse) -> those queries through the exhaustive path.
     Returns (d, idx) device tensors holding valid results for every query."""
     ws = workspace or Workspace(dataset.device)
-    d, idx, status = scan_topk(dataset, queries, k, h=h, r_offset=r_offset, workspace=ws, out=out, unsorted=unsorted, flags=flags)
+    d, idx, status = scan_topk(dataset, queries, k, h=h, r_offset=r_offset, workspace=ws, out=out, unsorted=unsorted, flags=flags,
+                               tau_hint=tau_hint)
     st = status.cpu()
+    if tau_hint is not None and bool((st != PSH_STATUS_OK).any()):
+        if bool((st == PSH_STATUS_RETRY).any()):
+            ws.arm()
+        d, idx, status = scan_topk(dataset, queries, k, h=h, r_offset=r_offset, workspace=ws, out=out, unsorted=unsorted, flags=flags)
+        st = status.cpu()
     if bool((st == PSH_STATUS_RETRY).any()):
         ws.arm()
         d, idx, status = scan_topk(dataset, queries, k, h=h, r_offset=r_offset, workspace=ws, out=out, unsorted=unsorted,
@@ -334,7 +357,7 @@ def embedding_supported(d: int, K: int) -> bool:
 def scan_topk_embedded(dataset: torch.Tensor, kernel: torch.Tensor, hx: torch.Tensor, k: int, h: int = 0,
                        r_offset: int = 0, hxnorm: torch.Tensor | None = None, workspace: Workspace | None = None,
                        exhaustive: bool = False, profile: bool = False, out: tuple | None = None, flags: int = 0,
-                       keep_plan: bool = False):
+                       keep_plan: bool = False, tau_hint: torch.Tensor | None = None, info: dict | None = None):
     """The scan behind a linear embedding: kernel (d, K) float32 device (unpadded), hx (B, d)
     embedded queries.  Same returns and conventions as scan_topk.
     keep_plan: the caller changes `kernel` only through torch (in-place edits bump its version): when the last sampled call
@@ -356,7 +379,8 @@ def scan_topk_embedded(dataset: torch.Tensor, kernel: torch.Tensor, hx: torch.Te
     if B > PSH_MAX_B_PER_LAUNCH and not profile:
         parts = [scan_topk_embedded(ds, ker, q[i:i + PSH_MAX_B_PER_LAUNCH].contiguous(), k, h=h, r_offset=r_offset,
                                     hxnorm=None if hxnorm is None else hxnorm[i:i + PSH_MAX_B_PER_LAUNCH].contiguous(),
-                                    workspace=workspace, exhaustive=exhaustive, flags=flags, keep_plan=keep_plan)
+                                    workspace=workspace, exhaustive=exhaustive, flags=flags, keep_plan=keep_plan,
+                                    tau_hint=None if tau_hint is None else tau_hint[i:i + PSH_MAX_B_PER_LAUNCH].contiguous())
                  for i in range(0, B, PSH_MAX_B_PER_LAUNCH)]
         return tuple(torch.cat([p[j] for p in parts], dim=0) for j in range(3))
     wsobj = workspace or Workspace(dev)
@@ -381,20 +405,37 @@ def scan_topk_embedded(dataset: torch.Tensor, kernel: torch.Tensor, hx: torch.Te
     if profile:
         prof = PshProfile()
         prof.mode = 0
-    if flags:
+    if tau_hint is not None:
+        tau_hint = _dev_tensor(tau_hint, torch.float32, "tau_hint")
+        if tuple(tau_hint.shape) != (B,):
+            raise ValueError("tau_hint must be (B,) float32")
+    if flags or tau_hint is not None or info is not None:
         if prof is None:
             prof = PshProfile()
             prof.mode = 1
         prof.flags = flags
+        prof.tau_hint = None if tau_hint is None else tau_hint.data_ptr()
     name = "psh_scan_topk_embedded_exhaustive" if exhaustive else "psh_scan_topk_embedded"
     rc = getattr(load(), name)(dev.index, _stream_ptr(dev), ds.data_ptr(), R, T, r_offset, ker.data_ptr(), d, K,
                                q.data_ptr(), None if hxnorm is None else hxnorm.data_ptr(), B, h, k,
                                out_d.data_ptr(), out_idx.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(),
                                C.byref(prof) if prof is not None else None)
     _check(rc, name)
+    if info is not None:
+        info.update(path=prof.path, n_sample_rows=prof.n_sample_rows, grid_blocks=prof.grid_blocks)
     if profile:
         return out_d, out_idx, status, prof.as_dict()
     return out_d, out_idx, status
+
+
+def candidates_layout(R: int, T: int, B: int, W: int, h: int, k: int, nbytes: int) -> dict:
+    """psh_candidates_layout: where a scan with these sizes on a workspace of `nbytes` leaves the windows it admitted
+    (diagnostics: tests/test_gpu_admitted_set.py reads the admitted SET back and compares it with the oracle's)."""
+    out = (C.c_int64 * 12)()
+    _check(load().psh_candidates_layout(R, T, B, W, h, k, nbytes, out), "psh_candidates_layout")
+    names = ("qstate", "bcount", "bcount2", "cand_d", "cand_rt", "cap", "hdr_cand", "hdr_blk", "hdr_stream_ncand", "max_blocks",
+             "fused_max_blocks", "fused_front")
+    return dict(zip(names, (int(v) for v in out)))
 
 
 def embed_rows(dataset: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:

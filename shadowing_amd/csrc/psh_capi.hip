@@ -3,6 +3,7 @@
 // carving, launch planning.  Everything is enqueued on the caller's stream; no
 // allocation, no global state (a thread-local string holds the last HIP error text).
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -670,10 +671,12 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
         if (rows_wave_min) bp.entries = chunks;
         use_mx = use_mq = false;
     }
+    // the caller's admission levels (psh_profile.tau_hint): no bootstrap sample anywhere below
+    const float* hint = profile ? profile->tau_hint : nullptr;
     const int64_t n_sample = bp.rows;
-    if (p.R * ((p.Tp + PSH_SEG - 1) / PSH_SEG) * PSH_SEG + k <= (int64_t)w.cap || (p.Tp == 1 && !rows_path) || n_sample == 0)
+    if (p.R * ((p.Tp + PSH_SEG - 1) / PSH_SEG) * PSH_SEG + k <= (int64_t)w.cap || (p.Tp == 1 && !rows_path) || (n_sample == 0 && !hint))
         return run_exhaustive(device, s, dataset, queries, qnorm, p, w, out_d, out_idx, out_status, profile);
-    const int64_t stride = p.R / n_sample;
+    const int64_t stride = n_sample > 0 ? p.R / n_sample : 1;
     const int64_t row0 = stride / 2;
     if (want_plan) p.eplan = w.eplan;
 
@@ -717,7 +720,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
             const int tile_fl = (logical + ((logical >> 6) << 2) + 4 + 3) & ~3;
             int tb = 0;
             while ((1ll << tb) < p.Tp) ++tb;
-            if (stream_scan_shmem_bytes_q(tile_fl, B) <= PSH_LDS_BYTES && units_p >= 256 && r2p <= units_p / 2 &&
+            if (stream_scan_shmem_bytes_q(tile_fl, B) <= PSH_LDS_BYTES && ((units_p >= 256 && r2p <= units_p / 2) || hint) &&
                 5 * (int64_t)k <= (int64_t)cand_cap && 5 * (int64_t)k * B <= grid_s * front * 2) {
                 Plan plan_s{(int)grid_s, 1, B, tile_fl, 0};
                 ScanArgs fa = make_scan_args(dataset, queries, p, w, plan_s, 0, 1, p.R);
@@ -741,6 +744,8 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
                 fu.units_stride = (int)((PSH_FUSED_MAX_UNITS / B) & ~3);
                 fu.cand_cap = cand_cap;
                 fu.k_out = k;
+                fu.tau_hint = hint;
+                if (hint) grid_p = 1;                  // nothing is sampled: one block derives scale, thresholds and the fragment table from the hints
                 if (!(tn.stream_skip & 1)) HIP_TRY(launch_stream_sample(fa, fu, p.aligned, (int)grid_p, tile_floats_for(p.W), s));
                 if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_begin, s));
                 if (!(tn.stream_skip & 4)) HIP_TRY(launch_stream_scan(fa, fu, p.aligned, (int)grid_s, s));
@@ -772,8 +777,9 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
         int64_t r2 = rows_f > 0 ? (2 * (int64_t)k * rows_f + p.R - 1) / p.R : 0;
         r2 += r2 < 64 ? r2 / 2 + 16 : 8;
         // (~2.5 k candidates are expected: they must fit the blocks' front lists with room to spare)
-        if (plan_f.grid <= PSH_FUSED_MAX_BLOCKS && rows_f >= 1 && units_f >= 256 && r2 <= units_f / 2 &&
+        if (plan_f.grid <= PSH_FUSED_MAX_BLOCKS && ((rows_f >= 1 && units_f >= 256 && r2 <= units_f / 2) || hint) &&
             5 * (int64_t)k <= (int64_t)plan_f.grid * PSH_FUSED_FRONT) {
+            if (rows_f < 1) rows_f = 1;
             const int64_t stride_f = p.R / rows_f, row0_f = stride_f / 2;
             ScanArgs fa = make_scan_args(dataset, queries, p, w, plan_f, 0, 1, p.R);
             const int logical = PSH_SEG + p.W + 3;
@@ -791,6 +797,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
                 fu.out_idx = out_idx;
                 fu.status = out_status;
                 fu.total = w.total;
+                fu.tau_hint = hint;
                 // give-up time of a poll at the 100 MHz wall clock: 2 ms (a block that is not resident); 20 ms when a
                 // collective shares the chip (its workgroups may hold a few CUs until the peers arrive)
                 fu.spin_ticks = (flags_of(profile) & PSH_FLAG_RESERVE_CUS) ? 2000000 : 200000;
@@ -821,8 +828,8 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     rc = tm.mark(); if (rc) return rc;                                       // 1
 
     Plan plan_s;
-    rc = plan_scan(device, p, n_sample, &plan_s); if (rc) return rc;
-    ScanArgs sa = make_scan_args(dataset, queries, p, w, plan_s, row0, stride, n_sample);
+    rc = plan_scan(device, p, n_sample > 0 ? n_sample : 1, &plan_s); if (rc) return rc;
+    ScanArgs sa = make_scan_args(dataset, queries, p, w, plan_s, row0, stride, n_sample > 0 ? n_sample : 1);
     sa.boot_per_wave = bp.per_wave;
     sa.emb_mx = boot_emx ? 1 : 0;
     sa.blockmax = (use_mx || use_mq) ? w.blockmax : nullptr;
@@ -832,7 +839,10 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     if (use_mq) HIP_TRY(launch_mq_prep(queries, B, p.W, w.mq_frag, s));
     // (a single query is better served by the exact bootstrap: 8192 segments are a latency-bound launch either
     // way -- 20.8 vs 18.7 us measured -- and the exact minima admit 9 % fewer candidates)
-    if (use_mq && bp.per_wave == 1 && boot_mq_supported(p.W)) {
+    if (hint) {
+        // the caller's levels: nothing is sampled (the threshold kernel takes tau = tau2 = hint[b])
+        n_blockmax = 0;
+    } else if (use_mq && bp.per_wave == 1 && boot_mq_supported(p.W)) {
         // segment minima as matrix-core upper bounds (boot_mq_kernel) instead of exact chains
         int ncu = 0;
         HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
@@ -864,7 +874,9 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     // smallest acc (the rank2-th smallest sampled minimum ~ 2k windows of the whole ensemble below it)
     int rank2 = 0;
     int k_thr = k;             // the rank the threshold kernel selects exactly
-    if (use_mx && mx_estimate) {
+    if (hint) {
+        // one class of candidates below the caller's level
+    } else if (use_mx && mx_estimate) {
         // the number of sampled minima below the ensemble's k-th smallest value is ~ Binomial(entries, k / windows): mean m = k x
         // the sampled fraction, deviation sqrt(m) -- the rank m + 4.5 sqrt(m) + 8 falls short of k windows once in ~10^5 calls
         // (-> status -> the exhaustive pass) and admits ~1.3 k candidates at k = 8192 instead of the 1.6 k of a flat 1.5 m
@@ -893,8 +905,8 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
         const int64_t r2 = ((p.ker ? 3 : (rows_path ? 6 : 4)) * (int64_t)k * n_sample + 2 * p.R - 1) / (2 * p.R) + (thin ? 8 : 16);
         if (r2 < k && r2 <= bp.entries) k_thr = (int)r2;
     }
-    ThresholdArgs ta{w.minbuf, w.min_stride, (int)bp.entries, w.qstate, k_thr, 0,
-                     (use_mx || use_mq) ? w.blockmax : nullptr, n_blockmax, use_mq ? w.mq_frag : nullptr, mq_i8 ? 1 : 0, rank2, pa};
+    ThresholdArgs ta{w.minbuf, w.min_stride, hint ? 0 : (int)bp.entries, w.qstate, k_thr, 0,
+                     ((use_mx || use_mq) && !hint) ? w.blockmax : nullptr, n_blockmax, use_mq ? w.mq_frag : nullptr, mq_i8 ? 1 : 0, rank2, pa, hint};
     HIP_TRY(launch_threshold(ta, B, s));
     rc = tm.mark(); if (rc) return rc;                                       // 3
 
@@ -966,8 +978,8 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
 
     if (profile) {
         profile->path = 0;
-        profile->n_sample_rows = (int)n_sample;
-        profile->grid_blocks = plan_f.grid;
+        profile->n_sample_rows = hint ? 0 : (int)n_sample;
+        profile->grid_blocks = nblk;           // the blocks whose slices the selection read (psh_candidates_layout)
     }
     if (stages) {
         HIP_TRY(hipStreamSynchronize(s));
@@ -1083,6 +1095,30 @@ int psh_merge_sorted_gathered(int device, void* stream, const float* d_gathered,
 }
 
 size_t psh_embed_plan_offset(void) { return PSH_FUSED_BYTES; }
+
+int psh_candidates_layout(int64_t R, int64_t T, int B, int W, int h, int k, size_t workspace_bytes, int64_t* out12) {
+    if (!out12 || R <= 0 || T <= 0 || B <= 0 || W <= 0 || h < 0 || k <= 0) return PSH_ERR_ARG;
+    if (W > PSH_MAX_W || k > PSH_MAX_K) return PSH_ERR_UNSUPPORTED;
+    const int64_t Tp = T - W - h + 1;
+    if (Tp <= 0) return PSH_ERR_ARG;
+    Workspace w;
+    char* const base = (char*)(uintptr_t)4096;             // (carve only does pointer arithmetic: any 256-byte aligned base)
+    const int rc = carve(base, workspace_bytes, B, k, boot_entries(R, Tp, k), &w);
+    if (rc) return rc;
+    out12[0] = (char*)w.qstate - base;
+    out12[1] = (char*)w.bcount - base;
+    out12[2] = (char*)w.bcount2 - base;
+    out12[3] = (char*)w.cand_d - base;
+    out12[4] = (char*)w.cand_rt - base;
+    out12[5] = w.cap;
+    out12[6] = (int64_t)offsetof(FusedHdr, cand);
+    out12[7] = (int64_t)offsetof(FusedHdr, blk);
+    out12[8] = (int64_t)(offsetof(FusedHdr, stream) + offsetof(StreamCtl, ncand));
+    out12[9] = PSH_MAX_BLOCKS;
+    out12[10] = PSH_FUSED_MAX_BLOCKS;
+    out12[11] = PSH_FUSED_FRONT;
+    return PSH_OK;
+}
 
 int psh_embedded_supported(int d, int K) {
     if (d <= 0 || K <= 0 || d > PSH_EMB_MAX_D || K > PSH_MAX_W || (int64_t)d * ((K + 3) & ~3) > PSH_EMB_MAX_TAPS) return 0;

@@ -71,7 +71,10 @@ __device__ __forceinline__ u64 g_load_b64(__amdgpu_buffer_rsrc_t r, unsigned byt
 enum { C_FRONT = 0, C_NEXT = 1, C_BAIL = 2, C_KMIN = 3, C_KMAX = 4, C_NFINITE = 5, C_EDGE = 6, C_NTOTAL = 7, C_ANYOVF = 8,
        C_TAU2 = 9, C_THR2 = 10, C_SCALE = 11, C_XN = 12, C_EPOCH = 13, C_MAGIC_OK = 14 };
 
-template <int WT, bool ALIGNED>
+// HINTED: the caller's admission level (psh_profile.tau_hint) instead of the sample: no phase A, no first barrier, phase B
+// only derives scale and threshold from the hint.  An instantiation of its own, so that the sampled launch compiles exactly
+// as it did without it (as a run-time flag it cost the W = 20 form nine VGPRs and the unaligned one a spill).
+template <int WT, bool ALIGNED, bool HINTED>
 __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_fused_kernel(ScanArgs a, FusedArgs f) {
     static_assert(WT >= 0 && WT <= 33, "the shifted-query band must fit K = 64 (WT = 0: run-time W <= 33)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -126,7 +129,8 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_fused_kernel(ScanArgs a
         const unsigned sg = uu - ri * (unsigned)a.nseg;
         stage_load<ALIGNED>(sx, a.dataset + (f.boot_row0 + (int64_t)ri * f.boot_row_stride) * a.T, a.T, (int)sg * PSH_SEG, nfloat, lane);
     };
-    const unsigned nbu = (unsigned)f.boot_units;
+    constexpr bool hinted = HINTED;
+    const unsigned nbu = hinted ? 0u : (unsigned)f.boot_units;
     Stage stb;
     unsigned ub = blockIdx.x * NW + (unsigned)wave;
     if (ub < nbu) boot_load(stb, ub);
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_fused_kernel(ScanArgs a
     const unsigned tagA = 2u * epoch, tagD = 2u * epoch + 1u;
 
     // ------------------------------------------------------------------ A: bootstrap sample
-    {
+    if constexpr (!hinted) {
         constexpr bool CHEAP = (WT >= 17) && (WT <= 32);
         const unsigned stride = gridDim.x * NW;
         unsigned u = ub;
@@ -195,9 +199,11 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_fused_kernel(ScanArgs a
         }
     }
     // publish: every storing wave drains its write-through stores, then ONE flag per block
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) g_store(&hdr->aflag[blockIdx.x], ((u64)tagA << 32) | 1ull);
+    if constexpr (!hinted) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) g_store(&hdr->aflag[blockIdx.x], ((u64)tagA << 32) | 1ull);
+    }
     stamp(1);
     // the first segment of the scan is requested now: its HBM latency runs under phase B
     auto grab = [&]() -> unsigned {
@@ -218,8 +224,55 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_fused_kernel(ScanArgs a
     unsigned u = grab();
     if (u < u_hi) load_unit(st, u);
 
+    // the admission level -> f16 scale and rejection threshold (one lane; phase B, sampled or hinted)
+    auto derive_levels = [&](const float tau0) {
+                bool armed = false;
+                const const_f32p xq = x;                  // scalar loads: the query sits in the scalar cache since phase A
+                const float s = sumsq8([&](int j) { return xq[j]; }, W);
+                const float xn = f.qnorm_in ? f.qnorm_in[0] : __builtin_sqrtf(s);
+                unsigned qmaxbits = 0u;
+                for (int j = 0; j < W; ++j) qmaxbits = max(qmaxbits, __float_as_uint(fabsf(xq[j])));
+                if (tau0 > 0.0f && tau0 < __uint_as_float(PSH_INF_BITS) && qmaxbits < PSH_INF_BITS) {
+                    // scale = 2^sexp: max|x| 2^sexp < 8 and tau0 4^sexp <= 4096 (exponents of the bit patterns: value in [2^(e-1), 2^e))
+                    const int et = (int)((__float_as_uint(tau0) >> 23) & 255u) - 126;
+                    int sexp = (12 - et) >= 0 ? (12 - et) / 2 : -((et - 12 + 1) / 2);
+                    if (qmaxbits >= 0x00800000u) {
+                        const int eq = (int)((qmaxbits >> 23) & 255u) - 126;
+                        sexp = sexp < 3 - eq ? sexp : 3 - eq;
+                    }
+                    if (sexp <= 60 && sexp >= -60 && __float_as_uint(tau0) >= 0x00800000u) {
+                        const float sc = __uint_as_float((unsigned)(127 + sexp) << 23);
+                        double nxs = 0.0;
+                        for (int j = 0; j < W; ++j) { const double vv = (double)xq[j] * (double)sc; nxs += vv * vv; }
+                        const double am = 1.0 / 512.0, bm = 1.0 / 262144.0;
+                        const double taus = (double)tau0 * (double)sc * (double)sc;
+                        const double T = taus * (1.0 + 1.0 / 131072.0) * (1.0 + 2.0 * am) - nxs * (1.0 - 3.0 * am) * (1.0 - 1e-12) + bm;
+                        float Tf = (float)T;
+                        if ((double)Tf < T) Tf = __uint_as_float(Tf >= 0.0f ? __float_as_uint(Tf) + 1u : __float_as_uint(Tf) - 1u);
+                        if (Tf == Tf && fabsf(Tf) < __uint_as_float(PSH_INF_BITS)) {
+                            ctl[C_TAU2] = (int)__float_as_uint(tau0);
+                            ctl[C_THR2] = (int)__float_as_uint(Tf);
+                            ctl[C_SCALE] = (int)__float_as_uint(sc);
+                            ctl[C_XN] = (int)__float_as_uint(xn);
+                            armed = true;
+                        }
+                    }
+                }
+                if (!armed) ctl[C_BAIL] = 2;         // absurd magnitudes / a zero estimate: the separate launches cope
+    };
     // ------------------------------------------------------------------ B: all minima -> tau2, scale, threshold
-    {
+    if constexpr (hinted) {
+        // (a hint that is not a positive finite number does not arm the launch: PSH_STATUS_RETRY, as for an absurd estimate)
+        if (tid == 0) derive_levels(f.tau_hint[0]);
+        __syncthreads();
+        if (ctl[C_BAIL] != 0) {
+            if (tid == 0) {
+                f.status[0] = PSH_STATUS_RETRY_;
+                if (blockIdx.x == 0) g_store(reinterpret_cast<u64*>(&hdr->epoch), (u64)(epoch + 1u));
+            }
+            return;
+        }
+    } else {
         const int nbu = f.boot_units;
         // first barrier: wave 0 sweeps the 256 block flags (2 KB; the other 15 waves do not add to the polling traffic)
         if (wave == 0) {
@@ -314,42 +367,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_fused_kernel(ScanArgs a
                 ctl[C_EDGE] = (int)(unsigned)edge;
             }
             wave_lds_fence();
-            if (lane == 0) {
-                bool armed = false;
-                const float tau0 = __uint_as_float((unsigned)ctl[C_EDGE]) * PSH_TAU_MARGIN;
-                const const_f32p xq = x;                  // scalar loads: the query sits in the scalar cache since phase A
-                const float s = sumsq8([&](int j) { return xq[j]; }, W);
-                const float xn = f.qnorm_in ? f.qnorm_in[0] : __builtin_sqrtf(s);
-                unsigned qmaxbits = 0u;
-                for (int j = 0; j < W; ++j) qmaxbits = max(qmaxbits, __float_as_uint(fabsf(xq[j])));
-                if (tau0 > 0.0f && tau0 < __uint_as_float(PSH_INF_BITS) && qmaxbits < PSH_INF_BITS) {
-                    // scale = 2^sexp: max|x| 2^sexp < 8 and tau0 4^sexp <= 4096 (exponents of the bit patterns: value in [2^(e-1), 2^e))
-                    const int et = (int)((__float_as_uint(tau0) >> 23) & 255u) - 126;
-                    int sexp = (12 - et) >= 0 ? (12 - et) / 2 : -((et - 12 + 1) / 2);
-                    if (qmaxbits >= 0x00800000u) {
-                        const int eq = (int)((qmaxbits >> 23) & 255u) - 126;
-                        sexp = sexp < 3 - eq ? sexp : 3 - eq;
-                    }
-                    if (sexp <= 60 && sexp >= -60 && __float_as_uint(tau0) >= 0x00800000u) {
-                        const float sc = __uint_as_float((unsigned)(127 + sexp) << 23);
-                        double nxs = 0.0;
-                        for (int j = 0; j < W; ++j) { const double vv = (double)xq[j] * (double)sc; nxs += vv * vv; }
-                        const double am = 1.0 / 512.0, bm = 1.0 / 262144.0;
-                        const double taus = (double)tau0 * (double)sc * (double)sc;
-                        const double T = taus * (1.0 + 1.0 / 131072.0) * (1.0 + 2.0 * am) - nxs * (1.0 - 3.0 * am) * (1.0 - 1e-12) + bm;
-                        float Tf = (float)T;
-                        if ((double)Tf < T) Tf = __uint_as_float(Tf >= 0.0f ? __float_as_uint(Tf) + 1u : __float_as_uint(Tf) - 1u);
-                        if (Tf == Tf && fabsf(Tf) < __uint_as_float(PSH_INF_BITS)) {
-                            ctl[C_TAU2] = (int)__float_as_uint(tau0);
-                            ctl[C_THR2] = (int)__float_as_uint(Tf);
-                            ctl[C_SCALE] = (int)__float_as_uint(sc);
-                            ctl[C_XN] = (int)__float_as_uint(xn);
-                            armed = true;
-                        }
-                    }
-                }
-                if (!armed) ctl[C_BAIL] = 2;         // absurd magnitudes / a zero estimate: the separate launches cope
-            }
+            if (lane == 0) derive_levels(__uint_as_float((unsigned)ctl[C_EDGE]) * PSH_TAU_MARGIN);
         }
         __syncthreads();
         if (ctl[C_BAIL] != 0) {                      // not armed: the same verdict in every block (same minima, same query)
@@ -700,11 +718,18 @@ static hipError_t launch_fused_k(K kernel, int grid, size_t shmem, hipStream_t s
 
 hipError_t launch_scan_fused(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, hipStream_t s) {
     const size_t shmem = scan_fused_shmem_bytes(a.tile_floats);
+    if (f.tau_hint) {
+        if (a.W == 20)
+            return aligned ? launch_fused_k(scan_fused_kernel<20, true, true>, grid, shmem, s, a, f)
+                           : launch_fused_k(scan_fused_kernel<20, false, true>, grid, shmem, s, a, f);
+        return aligned ? launch_fused_k(scan_fused_kernel<0, true, true>, grid, shmem, s, a, f)
+                       : launch_fused_k(scan_fused_kernel<0, false, true>, grid, shmem, s, a, f);
+    }
     if (a.W == 20)
-        return aligned ? launch_fused_k(scan_fused_kernel<20, true>, grid, shmem, s, a, f)
-                       : launch_fused_k(scan_fused_kernel<20, false>, grid, shmem, s, a, f);
-    return aligned ? launch_fused_k(scan_fused_kernel<0, true>, grid, shmem, s, a, f)
-                   : launch_fused_k(scan_fused_kernel<0, false>, grid, shmem, s, a, f);
+        return aligned ? launch_fused_k(scan_fused_kernel<20, true, false>, grid, shmem, s, a, f)
+                       : launch_fused_k(scan_fused_kernel<20, false, false>, grid, shmem, s, a, f);
+    return aligned ? launch_fused_k(scan_fused_kernel<0, true, false>, grid, shmem, s, a, f)
+                   : launch_fused_k(scan_fused_kernel<0, false, false>, grid, shmem, s, a, f);
 }
 
 }  // namespace psh

@@ -99,6 +99,7 @@ struct FusedArgs {
     int units_stride;                // stream launches: query q's sampled minima start at minima[q * units_stride]
     int cand_cap;                    // stream launches: entries of a query's region of `cand` (query q: cand + q * cand_cap entries)
     int k_out;                       // stream launches: row length of out_d / out_idx (= k)
+    const float* tau_hint;           // nullable: the caller's admission level per query (psh_profile.tau_hint) -- no sample, no first barrier
 };
 
 struct PrepArgs {
@@ -199,6 +200,7 @@ struct ThresholdArgs {
     int mq_i8;               // ... as the int8 table and per-query constants of scan_mq8_kernel instead
     int rank2;               // > 0: also estimate tau2 = the rank2-th smallest minimum (two-class candidate slices)
     PrepArgs prep;           // the per-query preparation runs here too (one launch less on the sampled path)
+    const float* tau_hint;   // nullable: B levels given by the caller (psh_profile.tau_hint): no minima, no selection -- tau = tau2 = hint
 };
 
 struct SelectArgs {

@@ -201,9 +201,13 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS, 8) void threshold_kernel(Thresh
         if (tid == 0) s_sc = 0.0f;
     }
     __syncthreads();                                       // (block-scope visibility of qstate[b] for thread 0 below)
-    if (a.blockmax) {
+    // a level given by the caller (psh_profile.tau_hint): no minima to select from -- tau = tau2 = hint[b]; the f16 scale then
+    // comes from the query and the level alone, the way the fused launch derives it (nothing is known about the data)
+    const bool hinted = a.tau_hint != nullptr;
+    if (a.blockmax || hinted) {
         unsigned mb = 0u;                                  // non-negative floats order as their bit patterns
-        for (int i = tid; i < a.n_blockmax; i += PSH_SELECT_THREADS) mb = max(mb, __float_as_uint(a.blockmax[i]));
+        if (a.blockmax)
+            for (int i = tid; i < a.n_blockmax; i += PSH_SELECT_THREADS) mb = max(mb, __float_as_uint(a.blockmax[i]));
         // batched matrix-core scan: ONE scale for all queries (they share the f16 copy of the data)
         const int64_t xlo = a.mq_frag ? 0 : (int64_t)b * a.prep.W;
         const int64_t xhi = a.mq_frag ? (int64_t)a.prep.B * a.prep.W : xlo + a.prep.W;
@@ -212,8 +216,8 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS, 8) void threshold_kernel(Thresh
         if (mb) atomicMax(&s_maxbits, mb);
         __syncthreads();
     }
-    if (n < a.k) return;                                   // tau stays +inf (host avoids this)
-    const bool in_lds = a.keys_in_lds != 0;
+    if (!hinted && n < a.k) return;                        // tau stays +inf (host avoids this)
+    const bool in_lds = a.keys_in_lds != 0 && !hinted;
     if (in_lds) {
         // the keys' min / max fall out of the staging pass (the selection would otherwise re-read all of them)
         unsigned kmin32 = 0xffffffffu, kmax32 = 0u;
@@ -239,19 +243,22 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS, 8) void threshold_kernel(Thresh
         __syncthreads();
     }
     const uint64_t kmin64 = in_lds ? sm.kmin : 0ull, kmax64 = in_lds ? sm.kmax : 0ull;
-    uint64_t prefix;
-    int sh, rem;
+    uint64_t prefix = 0;
+    int sh = 32, rem;
     bool exact;
     // tau only has to bound the k-th smallest minimum from above: once the digits examined pin it to
     // 2^15 ulps (0.4 %) the bucket's upper edge serves -- usually one pass instead of three
-    radix_select64([&](int i) { return (uint64_t)(in_lds ? tkeys[i] : __float_as_uint(v[i])) << 32; },
-                   [](int) { return true; }, n, a.k, 32, &sm, &prefix, &sh, &exact, &rem, in_lds, kmin64, kmax64, 32 + 15, a.rank2);
+    if (!hinted)
+        radix_select64([&](int i) { return (uint64_t)(in_lds ? tkeys[i] : __float_as_uint(v[i])) << 32; },
+                       [](int) { return true; }, n, a.k, 32, &sm, &prefix, &sh, &exact, &rem, in_lds, kmin64, kmax64, 32 + 15, a.rank2);
     if (tid == 0) {
         // every sampled value whose bits >> (sh-32) are <= the prefix's is among the k
         // smallest: the largest float with that truncated prefix bounds them all
-        const unsigned hi_bits = (unsigned)(prefix >> 32) | ((sh > 32) ? ((1u << (sh - 32)) - 1u) : 0u);
+        const unsigned hi_bits = hinted ? 0u : ((unsigned)(prefix >> 32) | ((sh > 32) ? ((1u << (sh - 32)) - 1u) : 0u));
         if (hi_bits < PSH_INF_BITS) {
-            const float tau0 = __uint_as_float(hi_bits) * PSH_TAU_MARGIN;   // strictly above the k-th value
+            // (a hint that is not a positive finite number leaves tau at +inf: everything is admitted, the slices overflow,
+            //  the selection says PSH_STATUS_OVERFLOW -- the documented answer to a useless hint)
+            const float tau0 = hinted ? a.tau_hint[b] : __uint_as_float(hi_bits) * PSH_TAU_MARGIN;   // strictly above the k-th value
             if (tau0 < __uint_as_float(PSH_INF_BITS) && tau0 > 0.0f) {
                 QueryState* qs = a.qstate + b;
                 qs->tau_bits = __float_as_uint(tau0);
@@ -267,14 +274,24 @@ __global__ __launch_bounds__(PSH_SELECT_THREADS, 8) void threshold_kernel(Thresh
                 float Af = (float)A;
                 if ((double)Af < A) Af = __uint_as_float(Af >= 0.0f ? __float_as_uint(Af) + 1u : __float_as_uint(Af) - 1u);
                 qs->thr_base = Af;
-                if (a.blockmax && s_maxbits < PSH_INF_BITS) {
+                if ((a.blockmax || hinted) && s_maxbits < PSH_INF_BITS) {
                     // matrix-core filter (scan_mx_kernel): scale = 2^s puts the largest sampled
                     // |value| into [4, 8) -- f16 keeps 11 bits down to 2^-14 and y~^2 stays below
                     // 65504 up to |y~| = 255 -- and mx_thr is the bound derived there, evaluated in
                     // double and rounded up (towards "keep")
                     int e = (int)((s_maxbits >> 23) & 255u) - 126;          // max in [2^(e-1), 2^e)
-                    const int sexp = 3 - e;
-                    const bool sane = sexp <= 60 && sexp >= -60 && s_maxbits >= 0x00800000u;   // normal, squares stay in fp32 range
+                    int sexp = 3 - e;
+                    if (hinted && !a.mq_frag) {
+                        // no sampled data behind the scale: the query's largest |x| 2^sexp < 8 AND tau 4^sexp <= 4096 (the fused
+                        // launch's conditions, psh_fused.hip phase B) -- a value the f16 conversion turns into +inf then sits in
+                        // windows whose acc is above the level anyway.  (Batches: the scans look at every segment's largest
+                        // value themselves and keep everything where it leaves the f16 range.)
+                        const int et = (int)((__float_as_uint(tau0) >> 23) & 255u) - 126;
+                        const int st = (12 - et) >= 0 ? (12 - et) / 2 : -((et - 12 + 1) / 2);
+                        sexp = sexp < st ? sexp : st;
+                    }
+                    const bool sane = sexp <= 60 && sexp >= -60 && s_maxbits >= 0x00800000u   // normal, squares stay in fp32 range
+                                      && (!hinted || __float_as_uint(tau0) >= 0x00800000u);
                     const float sc = __uint_as_float((unsigned)(127 + sexp) << 23);
                     const float* xq = a.prep.queries + (int64_t)b * a.prep.W;
                     double nxs = 0.0;

@@ -102,7 +102,10 @@ void stream_sample_kernel(ScanArgs a, FusedArgs f) {
     const int W = WT > 0 ? WT : a.W;
     const int nfloat = PSH_SEG + W - 1;
     const int nq = f.nq;
-    const unsigned nbu = (unsigned)f.boot_units;
+    // levels given by the caller (psh_profile.tau_hint; the launch is then ONE block): nothing is sampled, the last-block
+    // part below takes tau0 = hint[q]
+    const bool hinted = f.tau_hint != nullptr;
+    const unsigned nbu = hinted ? 0u : (unsigned)f.boot_units;
 
     auto boot_load = [&](Stage& sx, unsigned uu) {
         const unsigned ri = fast_div(uu, a.magic_nseg, (unsigned)a.nseg);
@@ -195,7 +198,9 @@ void stream_sample_kernel(ScanArgs a, FusedArgs f) {
             nfin += __shfl_xor(nfin, off, 64);
         }
         unsigned edge = 0u;
-        if (nfin >= f.rank) {
+        if (hinted) {
+            // (a hint that is not a positive finite number fails stream_sexp below: not armed -> PSH_STATUS_RETRY)
+        } else if (nfin >= f.rank) {
             const unsigned range = kmax - kmin;
             const int hb = range ? 32 - __builtin_clz(range) : 0;
             const int shift = hb > 10 ? hb - 10 : 0;                      // (range >> shift) < 1024
@@ -248,7 +253,7 @@ void stream_sample_kernel(ScanArgs a, FusedArgs f) {
         } else {
             armed = false;
         }
-        const float tau0 = __uint_as_float(edge) * PSH_TAU_MARGIN;
+        const float tau0 = hinted ? f.tau_hint[q] : __uint_as_float(edge) * PSH_TAU_MARGIN;
         int sx = 0;
         if (armed && !stream_sexp((const_f32p)a.queries + (size_t)q * W, W, tau0, &sx)) armed = false;   // (uniform: scalar inputs)
         if (lane == 0) { sh_tau0[q] = tau0; sh_sexp[q] = sx; sh_armed[q] = armed ? 1 : 0; }

@@ -35,7 +35,22 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version_and_strerror(lib):
-    assert lib.psh_version() == 1
+    from shadowing_amd import _native
+    assert lib.psh_version() == _native.PSH_VERSION == 2
+    # the header and the binding agree on the version and on the size of psh_profile (ctypes mirrors the C layout)
+    text = (REPO / "include" / "psh.h").read_text()
+    assert re.search(r"#define PSH_VERSION 2\b", text)
+    # ... as a C compiler lays the header's struct out
+    import subprocess, tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        src = Path(tmp) / "layout.c"
+        src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "psh.h"\n'
+                       'int main(void) { printf("%zu %zu %zu %zu\\n", sizeof(psh_profile), offsetof(psh_profile, tau_hint), '
+                       'offsetof(psh_profile, path), offsetof(psh_profile, prep_ms)); return 0; }\n')
+        subprocess.run(["gcc", f"-I{REPO / 'include'}", str(src), "-o", str(Path(tmp) / "layout")], check=True)
+        got = subprocess.run([str(Path(tmp) / "layout")], check=True, capture_output=True, text=True).stdout.split()
+    P = _native.PshProfile
+    assert [int(v) for v in got] == [C.sizeof(P), P.tau_hint.offset, P.path.offset, P.prep_ms.offset]
     assert lib.psh_strerror(0) == b"ok"
     for code in (-1, -2, -3, -4):
         assert len(lib.psh_strerror(code)) > 5
@@ -55,6 +70,24 @@ def test_workspace_bytes(lib):
     assert lib.psh_workspace_bytes(16, 4096, 1, 257, 0, 4, C.byref(out)) == -2         # W > PSH_MAX_W
     assert lib.psh_workspace_bytes(16, 4096, 1, 20, 0, 16385, C.byref(out)) == -2      # k > PSH_MAX_K
     assert lib.psh_merge_workspace_bytes(4, 1000, C.byref(out)) == 0 and out.value >= 4 * 1024 * 8
+
+
+def test_candidates_layout_is_host_only_and_consistent(lib):
+    """psh_candidates_layout (diagnostics of the admitted-set tests): pure arithmetic, runs without a device."""
+    from shadowing_amd import _native
+    nb = _native.workspace_bytes(4096, 4096, 4, 20, 20, 256)
+    lay = _native.candidates_layout(4096, 4096, 4, 20, 20, 256, nb)
+    assert lay["cap"] >= 64 * 256 and lay["cap"] % 64 == 0
+    assert 0 < lay["qstate"] < lay["bcount"] < lay["bcount2"] < lay["cand_d"] < lay["cand_rt"]
+    assert lay["cand_rt"] - lay["cand_d"] >= 4 * 4 * lay["cap"]
+    assert lay["cand_rt"] + 8 * 4 * lay["cap"] <= nb
+    assert lay["hdr_cand"] % 16 == 0 and lay["hdr_blk"] % 8 == 0 and lay["hdr_stream_ncand"] % 4 == 0
+    assert (lay["max_blocks"], lay["fused_max_blocks"], lay["fused_front"]) == (2048, 256, 64)
+    twice = _native.candidates_layout(4096, 4096, 4, 20, 20, 256, 2 * nb)
+    assert twice["cap"] > lay["cap"]                       # a larger workspace is a larger candidate buffer
+    out = (C.c_int64 * 12)()
+    assert lib.psh_candidates_layout(4096, 4096, 4, 20, 20, 256, 1024, out) == -3          # PSH_ERR_WORKSPACE
+    assert lib.psh_candidates_layout(4096, 4096, 4, 20, 20, 256, nb, None) == -1
 
 
 def test_null_arguments_are_rejected_not_crashing(lib):

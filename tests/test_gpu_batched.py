@@ -137,6 +137,25 @@ def test_8bit_rejection_test_on_adversarial_batches(hip_device, oracle_mod, case
         assert not np.isfinite(d[b]).any() and not np.isfinite(od[b]).any()
 
 
+@pytest.mark.parametrize("kind", ["spikes", "tiny_queries", "huge_queries", "scale_up", "scale_down", "planted_matches", "student_t",
+                                  "zero_constant_rows", "loud_rows", "quiet_one_loud", "spread_amplitudes", "quiet_stretches"])
+def test_promoted_stress_cut_of_the_8bit_scan(hip_device, oracle_mod, kind):
+    """One seed x twelve kinds of tests/stress/stress_mq8.py (the 4 x 36-case stress of round 4 runs outside pytest): the
+    8-bit batched scan against the oracle on tests/_adversarial.py's batches, every third kind also through the f16 test."""
+    from _adversarial import KINDS, make
+    from shadowing_amd import _native
+    i = KINDS.index(kind)
+    R, T = (2048, 3000, 4096)[i % 3], (768, 1024, 1500)[(i // 3) % 3]
+    W, h, k, B = (20, 8, 13, 25, 17, 20)[i % 6], (0, 7, 20, 29)[i % 4], (1, 32, 200, 1024)[i % 4], (32, 33, 48, 64, 100, 130)[i % 6]
+    ds, q = make(kind, R, T, B, W, h, 9000 + i)
+    od, oidx = oracle_mod.scan_topk(ds, q, k, h=h)
+    for flags in ((0, _native.FLAG_MQ_F16) if i % 3 == 0 else (0,)):
+        d, idx, status, prof = hip_scan(hip_device, ds, q, k, h, profile=True, flags=flags)
+        assert prof["path"] == 0
+        d, idx = resolve(hip_device, ds, q, k, h, d, idx, status)
+        assert_exact(d, idx, od, oidx, f"{kind} flags={flags}")
+
+
 def test_configs2_full_size_properties(hip_device, oracle_mod):
     """BASELINE configs[2] at its size: 512 rolling query dates x R = 32768 x T = 4096, k = 1024.  Size-independent
     properties for every query (rows sorted, indices admissible and distinct, each returned distance re-derived
