@@ -24,10 +24,16 @@ pytestmark = pytest.mark.gpu
 
 def _level(acc: np.ndarray, m: int) -> np.float32:
     """A level with ~m windows below it: just above the m-th smallest finite acc."""
-    a = acc[np.isfinite(acc)].ravel()
+    a = np.sort(acc[np.isfinite(acc)].ravel())
     m = min(m, a.size - 1)
-    v = np.partition(a, m)[m]
-    return np.nextafter(np.float32(v), np.float32(np.inf)) if v > 0 else np.float32(1e-30)
+    v = np.float32(a[m])
+    tau = np.nextafter(v, np.float32(np.inf))
+    if np.searchsorted(a, tau, "left") > 2 * m + 64:          # a plateau of exact ties at the m-th value (zero / constant rows):
+        tau = v                                               # the level sits AT it -- strictly-below excludes the plateau
+    if not tau > 0:                                           # (everything up to the m-th is zero: the first positive value)
+        pos = a[a > 0]
+        tau = np.float32(pos[0]) if pos.size else np.float32(1e-30)
+    return np.float32(tau)
 
 
 def _expected(acc: np.ndarray, tau: np.float32) -> np.ndarray:
@@ -187,13 +193,13 @@ def test_fused_and_overlap_launches_admit_exactly_the_windows_below_the_level(hi
 @pytest.mark.parametrize("test", ["i8", "f16"])
 def test_batched_scans_admit_exactly_the_windows_below_the_level(hip_device, oracle_mod, kind, test):
     """scan_mq8_kernel (the 8-bit product with its per-segment quantisation bound: P / s_y + L, the kC / 2^30 clamps, keep_all)
-    and scan_mq_kernel (f16), 40 queries, W = 8..25, levels 10^3 and 3 x 10^4 deep."""
+    and scan_mq_kernel (f16), 34 queries, W = 8..25, levels 10^3 .. 3 x 10^4 deep."""
     from shadowing_amd import _native
     flags = _native.FLAG_MQ_F16 if test == "f16" else 0
-    for i, (W, h, m) in enumerate([(20, 20, 1000), (25, 0, 30000), (8, 3, 30000), (13, 7, 3000)]):
-        if test == "f16" and i in (1, 3):
+    for i, (W, h, m) in enumerate([(20, 20, 1000), (25, 0, 30000), (8, 3, 10000)]):
+        if test == "f16" and i == 1:
             continue                                      # (GPU minutes: the f16 test is the older, longer-serving one)
-        ds, q = adversarial(kind, 1024, 2048, 40, W, h, 300 + 3 * i)
+        ds, q = adversarial(kind, 1024, 2048, 34, W, h, 300 + 3 * i)
         check_sets(hip_device, oracle_mod, ds, q, h, m, flags=flags, what=f"scan_mq {test} {kind} W={W} m={m}", expect_path=0)
 
 
@@ -252,11 +258,13 @@ def test_matrix_core_embedded_scan_admits_exactly_the_windows_below_the_level(hi
     BASELINE configs[4], K = 252, and a random user kernel), and embed_scan_kernel's dense chains as the control."""
     from shadowing_amd import _native
     rng = np.random.default_rng(7)
-    for i, (d, K, h, B, m, fl) in enumerate([(8, 252, 0, 4, 3000, _native.FLAG_EMBED_MX), (8, 252, 20, 16, 1000, _native.FLAG_EMBED_MX),
-                                             (5, 23, 7, 3, 30000, _native.FLAG_EMBED_MX), (8, 252, 0, 2, 3000, _native.FLAG_EMBED_MX | _native.FLAG_EMBED_MX_SPLIT),
-                                             (5, 23, 7, 3, 3000, _native.FLAG_EMBED_DENSE)]):
+    # (sizes: the oracle's d x K chains for every window of every query are what this test costs -- 2 x 10^9 fmas per case)
+    for i, (R, d, K, h, B, m, fl) in enumerate([(512, 8, 252, 0, 4, 3000, _native.FLAG_EMBED_MX), (384, 8, 252, 20, 9, 1000, _native.FLAG_EMBED_MX),
+                                                (1024, 5, 23, 7, 3, 30000, _native.FLAG_EMBED_MX),
+                                                (384, 8, 252, 0, 2, 3000, _native.FLAG_EMBED_MX | _native.FLAG_EMBED_MX_SPLIT),
+                                                (1024, 5, 23, 7, 3, 3000, _native.FLAG_EMBED_DENSE)]):
         ker = syn.wavelet_bank(d, K) if K == 252 else (rng.standard_normal((d, K)) / np.sqrt(K)).astype(np.float32)
-        ds, x = adversarial(kind, 1024, 2048, B, K, h, 600 + i)
+        ds, x = adversarial(kind, R, 2048, B, K, h, 600 + i)
         check_sets(hip_device, oracle_mod, ds, None, h, m, flags=fl, embedded=(np.ascontiguousarray(ker, dtype=np.float32), _embed(ker, x)),
                    what=f"embed_mx {kind} d={d} K={K} B={B} flags={fl}", expect_path=0)
 
@@ -280,9 +288,9 @@ def test_a_hint_that_falls_short_or_is_useless_reports_it_and_the_rerun_is_exact
         q = syn.rolling_queries(B, 20, 5).reshape(B, 20)
         q_t = torch.as_tensor(q).to(dev)
         od, oidx = oracle_mod.scan_topk(ds, q, 256, h=20)
-        acc = oracle_mod.all_acc(ds, q[0], h=20)
-        for hv in (float(_level(acc, 50)), 0.0, -1.0, float("nan"), float("inf")):
-            hint = torch.full((B,), hv, dtype=torch.float32, device=dev)
+        short = np.array([_level(oracle_mod.all_acc(ds, q[b], h=20), 50) for b in range(B)], np.float32)   # 50 windows below: < k
+        for hv in (None, 0.0, -1.0, float("nan"), float("inf")):
+            hint = torch.as_tensor(short).to(dev) if hv is None else torch.full((B,), hv, dtype=torch.float32, device=dev)
             ws = _native.Workspace(dev)
             d, idx, st = _native.scan_topk(ds_t, q_t, 256, h=20, workspace=ws, flags=flags, tau_hint=hint)
             torch.cuda.synchronize(dev)
@@ -294,7 +302,6 @@ def test_a_hint_that_falls_short_or_is_useless_reports_it_and_the_rerun_is_exact
         assert (st.cpu().numpy() == 0).all(), (B, flags)
         assert np.array_equal(d.cpu().numpy().view(np.uint32), od.view(np.uint32)) and np.array_equal(idx.cpu().numpy(), oidx)
         # the checked call: a hint that falls short costs a rerun, never the answer
-        short = torch.full((B,), float(_level(acc, 50)), dtype=torch.float32, device=dev)
-        d, idx = _native.scan_topk_checked(ds_t, q_t, 256, h=20, flags=flags, tau_hint=short)
+        d, idx = _native.scan_topk_checked(ds_t, q_t, 256, h=20, flags=flags, tau_hint=torch.as_tensor(short).to(dev))
         torch.cuda.synchronize(dev)
         assert np.array_equal(d.cpu().numpy().view(np.uint32), od.view(np.uint32)) and np.array_equal(idx.cpu().numpy(), oidx)
