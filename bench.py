@@ -98,11 +98,28 @@ def self_launch(n: int, argv: list[str]) -> int:
     """`python bench.py --gpus N` without a launcher: run the N ranks through torch.distributed.run (one process per
     GPU, RCCL over xGMI), exactly as the driver's own command line does.  Rank 0's JSON line passes through."""
     import subprocess
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), str(Path(__file__).resolve())] + argv
+    if "--cpu-oracle" not in argv:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            # ONE clear line instead of n tracebacks from the ranks
+            sys.stderr.write(f"bench.py: --gpus {n} needs {n} visible GPUs, this node shows {have} (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?)\n")
+            return 2
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.run(cmd, env=env).returncode
+    rc = 1
+    for attempt in range(3):
+        # the rendezvous port is picked by binding port 0 and closing it again: another process can take it in between --
+        # a rendezvous that dies of EADDRINUSE is started again on a fresh port (the ranks have not touched a GPU by then)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), str(Path(__file__).resolve())] + argv
+        res = subprocess.run(cmd, env=env, stderr=subprocess.PIPE, text=True)
+        sys.stderr.write(res.stderr)
+        rc = res.returncode
+        busy = rc != 0 and any(m in res.stderr for m in ("EADDRINUSE", "Address already in use", "address already in use"))
+        if not busy:
+            break
+        sys.stderr.write(f"bench.py: rendezvous port was taken (attempt {attempt + 1}); retrying on another one\n")
+    return rc
 
 
 def sweep(counts: list[int], argv: list[str]) -> int:
@@ -150,6 +167,25 @@ def sweep_report(lines: list[dict]) -> list[str]:
         rows.append(f"[sweep] n_gpus={j['n_gpus']} rccl_world_size={j.get('rccl_world_size')} ms_per_step={j['ms_per_step']:.4f} "
                     f"value={j['value']:.4g} {j['unit']} weak_scaling_efficiency={eff:.3f}" + ("".join(" " + m for m in marks)))
     return rows
+
+
+def workload_label(R: int, T: int, W: int, h: int, k: int, B: int, world: int) -> str:
+    """config.workload: which BASELINE.json configuration this run IS, derived from the sizes and the rank count actually
+    used -- never a fixed string (a run with other --rows-per-gpu / --gpus must not carry configs[1]'s name)."""
+    sizes = f"R={R} paths/GPU x T={T}, W={W}, horizon={h}, k={k}"
+    base = (T, W, h, k) == (4096, 20, 20, 1024)
+    if B == 1 and base and R == 32768:
+        if world == 1:
+            return "BASELINE.json configs[1]: single query, " + sizes + ", 1 GPU"
+        if world == 8:
+            return f"BASELINE.json configs[3]: R={world * R} paths sharded 8 ways (local top-k + one RCCL all-gather + merge), single query, " + sizes
+        return (f"BASELINE.json configs[3]'s layout at {world} of its 8 GPUs (weak-scaling point): R={world * R} paths sharded {world} ways, "
+                "single query, " + sizes)
+    if B == 512 and base and R == 32768 and world == 1:
+        return "BASELINE.json configs[2]: 512 batched query dates (rolling window), " + sizes + ", 1 GPU"
+    what = "single query" if B == 1 else f"batched queries B={B} (rolling window)"
+    return f"not a BASELINE.json configuration (non-default sizes): {what}, {sizes}, {world} GPU" + ("s" if world > 1 else "") + \
+           (f", R_total={world * R} sharded {world} ways" if world > 1 else "")
 
 
 def host_merge(d_all: np.ndarray, i_all: np.ndarray, k: int):
@@ -343,6 +379,7 @@ def main():
     status_ring = list(torch.zeros((args.steps + args.warmup + 8, B), dtype=torch.int32, device=dev).unbind(0))
     sync()
 
+    hints = [None] * NQ  # single query: per rotating query the caller-side admission level of the hinted one-stream comparison
     pending = []       # sharded path: (the step whose all-gather is still in flight, its query batch)
     from collections import deque
     finished = deque(maxlen=2)     # sharded path: the last merged results (they live in the ring: valid until 2 x streams further steps)
@@ -373,7 +410,8 @@ def main():
         # status words of ALL steps are kept: every one of them is looked at after the timed region
         out = (outs[si][0], outs[si][1], status_ring[c % len(status_ring)])
         if streams[si] is None or cfg["n_streams"] == 1:
-            d, idx, st = _native.scan_topk(ds[:, 0, :], q, k, h=h, workspace=wss[0], scan_events=ev, flags=step_flags[0], out=out)
+            d, idx, st = _native.scan_topk(ds[:, 0, :], q, k, h=h, workspace=wss[0], scan_events=ev, flags=step_flags[0], out=out,
+                                           tau_hint=hints[qi] if cfg.get("hint") else None)
         else:
             with torch.cuda.stream(streams[si]):
                 d, idx, st = _native.scan_topk(ds[:, 0, :], q, k, h=h, workspace=wss[si], scan_events=ev, flags=step_flags[0], out=out)
@@ -545,6 +583,7 @@ def main():
     scan_ms = [a.elapsed_time(b) for a, b in ev_pairs] if (sharded is None and on_gpu) else []
     end_gaps_ms = [ev_pairs[j][1].elapsed_time(ev_pairs[j + 1][1]) / EV_EVERY for j in range(len(ev_pairs) - 1)] if sharded is None else []
     overlap_mode = bool(flags & _native.FLAG_OVERLAP)
+    alg_bytes_const = R * T * 4 + B * W * 4 + B * k * 12    # SURVEY.md 8d (the roofline block below states it again)
     single_stream = None
     if overlap_mode and sharded is None:
         # beside the headline: the same K steps on ONE stream as the fused single launch (what an isolated caller gets)
@@ -554,6 +593,34 @@ def main():
         step_flags[0], cfg["n_streams"] = keep
         single_stream = {"ms_per_step": round(1e3 * el1 / args.steps, 5), "value": round(world * R * Tp * B * args.steps / el1, 1),
                          "unit": "windows/s", "launches": "psh::scan_fused_kernel, one stream" if bad1 == 0 else "fused launch gave up (status %d)" % bad1}
+        # ... and the same with the caller's ADMISSION HINT (psh_profile.tau_hint): what a caller that knows the k-th distance
+        # of its query roughly gets on one stream -- consecutive rolling dates: the previous date's d_k.  Here every rotating
+        # query's hint is its own exact k-th acc x HINT_MARGIN (known from an untimed call), i.e. a 5 % error in d_k: the fused
+        # launch then runs no sample phase and no first grid barrier.  Results are checked like the headline's.
+        HINT_MARGIN = 1.10
+        step_flags[0], cfg["n_streams"] = flags & ~_native.FLAG_OVERLAP, 1
+        for qi in range(NQ):
+            dq, _, stq = _native.scan_topk(ds[:, 0, :], qs[qi], k, h=h, workspace=wss[0], flags=step_flags[0])
+            xn = _native.query_norm(qs[qi])
+            torch.cuda.synchronize()
+            assert int(stq.max().item()) == 0
+            hints[qi] = ((dq[:, k - 1].double() * xn.double()) ** 2 * HINT_MARGIN).float().contiguous()
+        cfg["hint"] = True
+        el2, _, bad2 = timed_region()
+        cfg["hint"] = False
+        hinted_ok = None
+        if bad2 == 0 and not args.no_parity:
+            sync()
+            od, oi = expected_by_oracle(last_query[0])
+            hinted_ok = same_result(outs[0][0].cpu().numpy(), outs[0][1].cpu().numpy(), od, oi, tie_free_order=True)
+            if not hinted_ok:
+                raise SystemExit("PARITY FAILURE of the hinted one-stream steps against the oracle")
+        step_flags[0], cfg["n_streams"] = keep
+        single_stream["with_admission_hint"] = {
+            "ms_per_step": round(1e3 * el2 / args.steps, 5), "achieved_GBps": round(alg_bytes_const / (1e-3 * 1e3 * el2 / args.steps) / 1e9, 1),
+            "frac": round(alg_bytes_const / (el2 / args.steps) / 1e9 / HBM_PEAK_GBPS, 4), "status_max": bad2, "parity_vs_oracle": hinted_ok,
+            "hint": f"psh_profile.tau_hint = every query's exact k-th acc x {HINT_MARGIN} (a caller that knows d_k to 5 %: rolling dates)",
+            "launches": "psh::scan_fused_kernel<..,HINTED>: no sample phase, no first grid barrier"}
 
     windows_per_step = world * R * Tp * B
     value = windows_per_step * args.steps / elapsed
@@ -562,6 +629,9 @@ def main():
     # ---- roofline of the dominant kernel: algorithmic bytes / live-measured duration
     mx = (W <= (33 if B == 1 else 25) and args.filter != "valu")
     wt = "20" if W == 20 else "0"
+    # the batched scan's rejection test as the library chooses it (psh_capi.hip: the 8-bit product from 32 queries on, unless
+    # PSH_FLAG_MQ_F16; below that the f16 one) -- kernel name, MFMA count and peak below follow THIS, not the flag alone
+    f16_batch = args.mq_f16 or B < 32
     # which path serves the call (the launch plan's answer) -- and, for the sharded run, ONE bracketed launch of the
     # local scan outside the timed loop (per-GPU kernel time; the timed loop itself carries no events there)
     info = {}
@@ -581,8 +651,8 @@ def main():
                    "psh::stream_rank_kernel behind it run beside the scans of the other streams)" % wt if overlap_mode else
                    "psh::scan_fused_kernel<%s,true> (the WHOLE step in one launch: bootstrap, threshold, f16 matrix-core "
                    "rejection test + exact fp32 recheck over the ensemble, distributed selection)" % wt if fused else
-                   ("psh::scan_mx_kernel<%s,true>" if B == 1 else "psh::scan_mq_kernel<%s,true>" if args.mq_f16 else "psh::scan_mq8_kernel<%s,true>") % wt
-                   + (" (full scan: f16 matrix-core rejection test + exact fp32 recheck)" if (B == 1 or args.mq_f16) else
+                   ("psh::scan_mx_kernel<%s,true>" if B == 1 else "psh::scan_mq_kernel<%s,true>" if f16_batch else "psh::scan_mq8_kernel<%s,true>") % wt
+                   + (" (full scan: f16 matrix-core rejection test + exact fp32 recheck)" if (B == 1 or f16_batch) else
                       " (full scan: 8-bit matrix-core rejection test, one v_mfma_i32_32x32x32_i8 per tile, + exact fp32 recheck)") if mx
                    else "psh::scan_kernel<%s,true,1> (full scan, VALU rejection test)" % wt)
     alg_bytes = R * T * 4 + B * W * 4 + B * k * 12          # one read of the ensemble + query + result
@@ -610,13 +680,17 @@ def main():
                     traffic_source = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)"
             except Exception:   # noqa: BLE001
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+        # `achieved` / `frac`: algorithmic bytes over the WHOLE timed region's time per step (every launch of it, every gap --
+        # what the driver's clock sees); the figure from the bracketed launches (every EV_EVERY-th) rides beside it
+        whole = alg_bytes / (ms_per_step * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(whole, 1),
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(whole / HBM_PEAK_GBPS, 4),
+                    "achieved_bracketed_launches": round(achieved, 1), "frac_bracketed_launches": round(achieved / HBM_PEAK_GBPS, 4),
                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": alg_bytes,
                     "avg_launch_ms": round(avg_ms, 5), "min_launch_ms": round(float(np.min(scan_ms)), 5),
                     "launches_timed": len(scan_ms), "launches_timed_every": EV_EVERY,
-                    "frac_of_measured_copy_rate": round(achieved / HBM_COPY_GBPS, 4)}
-        if B > 1 and mx:
+                    "frac_of_measured_copy_rate": round(whole / HBM_COPY_GBPS, 4)}
+        if B > 1 and mx and not overlap_mode:
             # A batch is NOT bandwidth-bound: every ensemble byte is used by B queries (physical HBM traffic is one read of
             # the ensemble per launch: 0.5 GB in ~4 ms).  What bounds scan_mq_kernel is the matrix cores plus the vector ALUs
             # behind them ("report VALU utilisation + effective GB/s"): per 1024-window segment and group of four
@@ -629,23 +703,23 @@ def main():
             # --mq-f16 runs and prices the f16 kernel as before.
             nseg_b = (Tp + 1023) // 1024
             groups = (B + 3) // 4
-            per_group = 8 if args.mq_f16 else 4
+            per_group = 8 if f16_batch else 4
             mfma_per_launch = R * nseg_b * (groups * per_group + 8)         # + the 8 (f16) window-energy MFMAs of a segment
-            flops = R * nseg_b * (groups * per_group * 2 * 32 * 32 * (16 if args.mq_f16 else 32) + 8 * 2 * 32 * 32 * 16)
+            flops = R * nseg_b * (groups * per_group * 2 * 32 * 32 * (16 if f16_batch else 32) + 8 * 2 * 32 * 32 * 16)
             ach_tf = flops / (avg_ms * 1e-3) / 1e12
-            MFMA_F16_DENSE_TF = 2500.0 if args.mq_f16 else 5000.0            # MI355X_MICROARCH.md: ~2.5 PF dense bf16 / f16, 8-bit at twice that
+            MFMA_F16_DENSE_TF = 2500.0 if f16_batch else 5000.0            # MI355X_MICROARCH.md: ~2.5 PF dense bf16 / f16, 8-bit at twice that
             pmc = None
             pfile = REPO / "profiles" / "q512_pmc.json"
             if pfile.exists():
                 try:
                     pj = json.loads(pfile.read_text())
                     if (pj.get("workload") == f"R={R},T={T},W={W},h={h},k={k},B={B}"
-                            and ("scan_mq8_kernel" in pj.get("kernel", "")) == (not args.mq_f16)):       # (the counters of THIS kernel only)
+                            and ("scan_mq8_kernel" in pj.get("kernel", "")) == (not f16_batch)):       # (the counters of THIS kernel only)
                         pmc = pj
                 except Exception:   # noqa: BLE001
                     pmc = None
             roofline = {"bound": "mfma+valu", "kernel": kernel_name, "achieved": round(ach_tf, 1), "peak": MFMA_F16_DENSE_TF,
-                        "unit": "TFLOP/s" if args.mq_f16 else "TOP/s (8-bit)", "frac": round(ach_tf / MFMA_F16_DENSE_TF, 4),
+                        "unit": "TFLOP/s" if f16_batch else "TOP/s (8-bit)", "frac": round(ach_tf / MFMA_F16_DENSE_TF, 4),
                         "mfma_per_launch": mfma_per_launch, "issued_flops_per_launch": flops, "useful_mac_fraction": 0.625,
                         "matrix_core_busy_frac": pmc.get("matrix_core_busy_frac") if pmc else None,
                         "valu_busy_frac": pmc.get("valu_busy_frac") if pmc else None,
@@ -658,7 +732,8 @@ def main():
                         "launches_timed": len(scan_ms), "launches_timed_every": EV_EVERY}
         if interval_ms:
             roofline["avg_launch_interval_ms"] = round(interval_ms, 5)
-            roofline["note"] = ("overlap mode: `achieved` = algorithmic bytes / avg_launch_interval_ms (end-to-end interval of consecutive "
+            roofline["note"] = ("`achieved` / `frac` = algorithmic bytes / ms_per_step of the whole timed region; overlap mode: "
+                                "`achieved_bracketed_launches` = algorithmic bytes / avg_launch_interval_ms (end-to-end interval of consecutive "
                                 "scan launches, HIP events on the launches' own streams); avg_launch_ms is a launch's begin-to-end "
                                 "duration WHILE it shares the chip with the neighbouring scan (profiles/: the kernel trace gives both)")
     elif on_gpu:
@@ -683,13 +758,12 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "windows scanned/sec (k-nearest-path scan, Identity + RelativeMSE, W=20, k=1024)",
+            "metric": f"windows scanned/sec (k-nearest-path scan, Identity + RelativeMSE, W={W}, k={k})",
             "value": round(value, 1), "unit": "windows/s", "n_gpus": world,
             "rccl_world_size": dist.get_world_size() if (use_pg and on_gpu) else None, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: single query, R=32768 paths/GPU x T=4096, W=20, horizon=20, k=1024"
-                       if B == 1 else f"batched queries B={B} (rolling window), R={R}/GPU x T={T}, W={W}, horizon={h}, k={k}",
+            "config": {"workload": workload_label(R, T, W, h, k, B, world),
                        "R_per_gpu": R, "R_total": world * R, "T": T, "W": W, "horizon": h, "k": k, "queries": B,
                        "windows_per_step": windows_per_step,
                        "sharding": "rows (R) across ranks, local top-k + one all-gather + merge; consecutive steps "

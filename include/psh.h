@@ -405,6 +405,14 @@ int psh_gather_paths(int device, void* stream,
  *                        resident ensemble.
  */
 int psh_count_nonfinite(int device, void* stream, const float* x, int64_t n, unsigned long long* out_count);
+/*   psh_rows_nonfinite   out_flags[r] (device, R int32) = 1 if row r of dataset (device R x C x T) holds a non-finite sample in any
+ *                        channel, else 0.  For the EMBEDDED scans, whose rejection tests assume finite data (prefix sums and
+ *                        matrix-core tiles spread a NaN over clean windows): a caller scans the clean rows with
+ *                        psh_scan_topk_embedded, the dirty ones -- smeared with back = h, fwd = 0 -- with
+ *                        psh_scan_topk_embedded_exhaustive (dense chains over all K taps: 0 * NaN = NaN exactly where the
+ *                        reference's zero-padded conv has it), and merges the two lists (psh_merge_topk).
+ *                        shadowing_amd.PathShadowing does this. */
+int psh_rows_nonfinite(int device, void* stream, const float* dataset, int64_t R, int64_t C, int64_t T, int32_t* out_flags);
 int psh_smear_nonfinite(int device, void* stream, const float* dataset, int64_t R, int64_t C, int64_t T, int back, int fwd, float* out);
 
 /*

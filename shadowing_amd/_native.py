@@ -43,7 +43,7 @@ EXPORTS = ("psh_version", "psh_strerror", "psh_last_hip_error", "psh_workspace_b
            "psh_merge_topk_gathered", "psh_merge_sorted_gathered", "psh_gather_paths", "psh_embed_rows",
            "psh_embedded_supported", "psh_embed_plan_offset", "psh_candidates_layout", "psh_workspace_init", "psh_last_comm_error", "psh_comm_unique_id", "psh_comm_create",
            "psh_comm_destroy", "psh_comm_world", "psh_exchange_merge", "psh_stream_create_reserving", "psh_stream_destroy",
-           "psh_weighted_moments", "psh_realized_variance", "psh_count_nonfinite", "psh_smear_nonfinite")
+           "psh_weighted_moments", "psh_realized_variance", "psh_count_nonfinite", "psh_smear_nonfinite", "psh_rows_nonfinite")
 
 _lib = None
 
@@ -130,6 +130,8 @@ def load() -> C.CDLL:
     L.psh_embed_rows.argtypes = [i32, vp, vp, i64, i64, vp, i32, i32, vp]
     L.psh_count_nonfinite.restype = i32
     L.psh_count_nonfinite.argtypes = [i32, vp, vp, i64, vp]
+    L.psh_rows_nonfinite.restype = i32
+    L.psh_rows_nonfinite.argtypes = [i32, vp, vp, i64, i64, i64, vp]
     L.psh_smear_nonfinite.restype = i32
     L.psh_smear_nonfinite.argtypes = [i32, vp, vp, i64, i64, i64, i32, i32, vp]
     L.psh_weighted_moments.restype = i32
@@ -524,8 +526,12 @@ class PreparedShadow:
         dev = rows.device
         R, T = rows.shape
         C_ = ds3.shape[1]
-        self.q_pin = torch.empty((1, W), dtype=torch.float32, pin_memory=True)
-        self.q_dev = torch.empty((1, W), dtype=torch.float32, device=dev)
+        # the query and, behind it at a 16-byte boundary, the caller's admission hint (psh_profile.tau_hint: one float)
+        self._Wp = (W + 3) // 4 * 4
+        self._stage_pin = torch.zeros((self._Wp + 4,), dtype=torch.float32, pin_memory=True)
+        self._stage_dev = torch.zeros((self._Wp + 4,), dtype=torch.float32, device=dev)
+        self.q_pin = self._stage_pin[:W].view(1, W)
+        self.q_dev = self._stage_dev[:W].view(1, W)
         # results packed in ONE device buffer and one pinned host buffer (status | d | idx | paths): one D2H copy per call
         n_d, n_i, n_p = 4 * k, 8 * k, 4 * k * C_ * (W + h)
         o_d = 256
@@ -544,6 +550,8 @@ class PreparedShadow:
         self.d, self.paths, self.idx, self.status = self.host if host_direct else carve(self._res)
         if host_direct:
             self.q_dev = self.q_pin
+            self._stage_dev = self._stage_pin
+        self._hint_ptr = self._stage_dev.data_ptr() + 4 * self._Wp
         self.event = torch.cuda.Event()
         ws = workspace.get(workspace_bytes(R, T, 1, W, h, k))
         self._keep = (rows, ds3, ws, workspace)
@@ -578,13 +586,17 @@ class PreparedShadow:
             self._gather_args[7], self._gather_args[10] = self.idx.data_ptr(), self.paths.data_ptr()
         return out
 
-    def launch(self, stream: "torch.cuda.Stream", x_row: torch.Tensor) -> None:
-        """x_row: (1, W) float32 CPU tensor.  Everything is enqueued on `stream`, the D2H copies of the results included."""
+    def launch(self, stream: "torch.cuda.Stream", x_row: torch.Tensor, hint: float | None = None) -> None:
+        """x_row: (1, W) float32 CPU tensor.  Everything is enqueued on `stream`, the D2H copies of the results included.
+        `hint`: the caller's admission level on acc (psh_profile.tau_hint) -- a status other than OK then means "again without"."""
         self.q_pin.copy_(x_row)
+        if hint is not None:
+            self._stage_pin[self._Wp] = float(hint)
+        self.prof.tau_hint = self._hint_ptr if hint is not None else None
         sp = stream.cuda_stream
         with torch.cuda.stream(stream):
             if not self.host_direct:
-                self.q_dev.copy_(self.q_pin, non_blocking=True)
+                self._stage_dev.copy_(self._stage_pin, non_blocking=True)
             a = self._scan_args
             a[1] = sp
             rc = self._scan_fn(*a)
@@ -828,4 +840,16 @@ def smear_nonfinite(dataset: torch.Tensor, back: int, fwd: int = 0) -> torch.Ten
     out = torch.empty((R, T), dtype=torch.float32, device=ds.device)
     _check(load().psh_smear_nonfinite(ds.device.index, _stream_ptr(ds.device), ds.data_ptr(), R, Cc, T, int(back), int(fwd), out.data_ptr()),
            "psh_smear_nonfinite")
+    return out
+
+
+def rows_nonfinite(dataset: torch.Tensor) -> torch.Tensor:
+    """(R,) int32 flags: 1 where a row of the (R, C, T) ensemble holds a NaN / +-inf sample in any channel."""
+    ds = _dev_tensor(dataset, torch.float32, "dataset")
+    if ds.dim() != 3:
+        raise ValueError("dataset must be (R, C, T)")
+    R, Cc, T = ds.shape
+    out = torch.empty((R,), dtype=torch.int32, device=ds.device)
+    _check(load().psh_rows_nonfinite(ds.device.index, _stream_ptr(ds.device), ds.data_ptr(), R, Cc, T, out.data_ptr()),
+           "psh_rows_nonfinite")
     return out

@@ -1153,6 +1153,14 @@ int psh_count_nonfinite(int device, void* stream, const float* x, int64_t n, uns
     return PSH_OK;
 }
 
+int psh_rows_nonfinite(int device, void* stream, const float* dataset, int64_t R, int64_t C, int64_t T, int32_t* out_flags) {
+    if (!dataset || !out_flags || R < 0 || C <= 0 || T <= 0) return PSH_ERR_ARG;
+    DeviceGuard g(device);
+    if (!g.ok) { snprintf(g_hip_err, sizeof(g_hip_err), "hipSetDevice(%d) failed", device); return PSH_ERR_HIP; }
+    HIP_TRY(launch_rows_nonfinite(dataset, R, C * T, out_flags, (hipStream_t)stream));
+    return PSH_OK;
+}
+
 int psh_smear_nonfinite(int device, void* stream, const float* dataset, int64_t R, int64_t C, int64_t T, int back, int fwd, float* out) {
     if (!dataset || !out || R < 0 || C <= 0 || T <= 0 || back < 0 || fwd < 0) return PSH_ERR_ARG;
     if (R * T >= ((int64_t)1 << 31) * 256) return PSH_ERR_UNSUPPORTED;

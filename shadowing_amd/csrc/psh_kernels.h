@@ -333,6 +333,7 @@ struct RvArgs {
 };
 // psh_prep.hip: non-finite samples the way the reference's zero-padded conv treats them
 hipError_t launch_count_nonfinite(const float* x, int64_t n, unsigned long long* out, hipStream_t s);
+hipError_t launch_rows_nonfinite(const float* ds, int64_t R, int64_t row_len, int* flags, hipStream_t s);
 hipError_t launch_smear_nonfinite(const float* ds, int64_t R, int64_t C, int64_t T, int back, int fwd, float* out, hipStream_t s);
 hipError_t launch_moments(const MomentsArgs& a, hipStream_t s);
 hipError_t launch_realized_variance(const RvArgs& a, hipStream_t s);

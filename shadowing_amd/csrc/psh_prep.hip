@@ -49,6 +49,26 @@ hipError_t launch_count_nonfinite(const float* x, int64_t n, unsigned long long*
     return hipGetLastError();
 }
 
+// flags[r] = 1 if row r (any of its C channels) holds a non-finite sample, else 0: a wave per row.  What the embedded scans'
+// callers split a dirty ensemble by (psh.h: psh_rows_nonfinite) -- clean rows keep the sampled scan and its rejection tests,
+// the few dirty ones take the exhaustive dense chains, which meet a NaN the way the reference's conv does.
+__global__ __launch_bounds__(256) void rows_nonfinite_kernel(const float* __restrict__ ds, int64_t R, int64_t row_len, int* __restrict__ flags) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int lane = (int)(threadIdx.x & 63);
+    const float* row = ds + r * row_len;
+    bool bad = false;
+    for (int64_t p = lane; p < row_len; p += 64) bad = bad || nonfinite(row[p]);
+    const unsigned long long m = __ballot(bad);
+    if (lane == 0) flags[r] = m ? 1 : 0;
+}
+
+hipError_t launch_rows_nonfinite(const float* ds, int64_t R, int64_t row_len, int* flags, hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rows_nonfinite_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, ds, R, row_len, flags);
+    return hipGetLastError();
+}
+
 // out[r, q] = NaN if any channel holds a non-finite sample in [q - fwd, q + back] (clipped to the row), else dataset[r, 0, q].
 // A thread per output sample; the look-around stops at the first hit.  Only run for an ensemble that holds non-finite
 // samples at all (psh_count_nonfinite), once per resident copy.

@@ -162,10 +162,21 @@ class ShardedPathShadowing:
         # over the horizon, so that windows are NaN exactly where the reference's zero-padded conv makes them NaN
         # (PathShadowing._scan_rows_of, psh_prep.hip); paths are gathered from `dataset`
         self._rows = self.dataset[:, 0, :]
-        if local_topk is None and self.dataset.numel() and _native.count_nonfinite(self.dataset):
-            if self._linear:
-                raise ValueError("the sharded scan behind a linear embedding needs a finite ensemble (NaN / +-inf samples: "
-                                 "the reference's zero-padded conv spreads them over taps the native scan does not visit)")
+        dirty = bool(local_topk is None and self.dataset.numel() and _native.count_nonfinite(self.dataset))
+        if local_topk is None and self._linear:
+            # every rank takes the SAME decision: a rank that raised alone would leave the others waiting in the collectives
+            # that follow (communicator creation, the first all-gather)
+            anywhere = dirty
+            if self._emulate is None and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+                flag = torch.tensor([1 if dirty else 0], dtype=torch.int32, device=self.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+                anywhere = bool(int(flag.item()))
+            if anywhere:
+                raise ValueError("the sharded scan behind a linear embedding needs a finite ensemble on every rank (NaN / +-inf "
+                                 "samples: the embedded scans' rejection tests assume finite data; PathShadowing serves such an "
+                                 "ensemble on one GPU by scanning its dirty rows exhaustively -- INTEGRATION.md)"
+                                 + ("" if dirty else " -- another rank's shard holds such samples"))
+        if dirty:
             self._rows = _native.smear_nonfinite(self.dataset, int(self.context.get_out_times()), 0)
         self._scan_streams = None
         self._reserve = 0

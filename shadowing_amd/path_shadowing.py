@@ -98,7 +98,7 @@ class PathShadowing:
     """
 
     def __init__(self, embedding: PathEmbedding, distance: PathDistance,
-                 dataset, context: ContextManagerBase | None = None, cache: bool | str = "auto"):
+                 dataset, context: ContextManagerBase | None = None, cache: bool | str = "auto", hint: str | None = None):
         """`cache` governs the copy of the ensemble kept in HBM for cuda=True (the reference re-reads and
         re-uploads `dataset` on every call, ref :205, :154-155):
           "auto" (default)  kept only when staleness is detectable or impossible: a torch tensor (CUDA: used in
@@ -107,11 +107,26 @@ class PathShadowing:
                             as the reference does, so an in-place edit is never missed;
           True              kept for any dataset until `refresh()` -- the caller promises to call it after
                             editing the array in place (8.5 ms per call saved at R = 32768 x T = 4096);
-          False             never kept."""
+          False             never kept.
+        `hint` (cuda=True, one Identity query per call -- the blocking shadow() of a loop over query dates):
+          None (default)    every call samples the ensemble for its admission level;
+          "auto"            a call hands the library the level the PREVIOUS call's k-th distance predicts for this query
+                            (psh_profile.tau_hint = (d_k ||x||)^2 x 1.15): the fused launch then runs no sample phase and no first
+                            grid barrier.  A hint that falls short (fewer than k windows below it, or more than the candidate
+                            lists hold) costs one more launch without it and switches the hints off for a few calls
+                            (`last_hint` says what happened) -- results are the exact top-k either way.  Pays for rolling query
+                            dates whose k-th distance moves by a few per cent from date to date; not for unrelated queries."""
         if isinstance(dataset, Path) or hasattr(dataset, "load"):
             dataset = self._load_with_scatspectra(dataset)
         if cache not in (True, False, "auto"):
             raise ValueError('cache must be True, False or "auto"')
+        if hint not in (None, "auto"):
+            raise ValueError('hint must be None or "auto"')
+        self.hint = hint
+        self._hint_state = None     # {"dk": relative k-th distance of the last call, "k", "W", "skip": calls left without a hint, "fails"}
+        self.last_hint = None       # None: the last call gave no hint; "ok" / "short": what became of the one it gave
+        self._warned_reupload = False
+        self._predict_scope = None  # (dataset object, device copy) while predict() loops over its context splits
         self.dataset = dataset
         self.embedding = embedding
         self.distance = distance
@@ -120,6 +135,7 @@ class PathShadowing:
         self._resident = None       # (key, device tensor (R, C, T), weakref to the host tensor) -- the ensemble in HBM
         self._scan_rows = None      # (key, device tensor (R, T)): channel 0 of a multi-channel ensemble
         self._dirty = False         # the resident ensemble holds NaN / +-inf samples (set by _scan_rows_of)
+        self._dirty_split = None    # (back, clean rows' indices, their rows, dirty rows' indices, their smeared rows): _split_dirty_rows
         self._served_by = "hip"     # what the last _native_scan ran: "hip", or "torch" (a dirty ensemble behind a linear embedding)
         self._gen = 0               # bumped by refresh()
         self._workspace = None
@@ -164,7 +180,7 @@ class PathShadowing:
     def refresh(self) -> None:
         """Forget the copy of `dataset` resident in HBM: call after editing the array in place when the object
         was built with cache=True (with cache="auto" a writeable numpy array is re-read on every call anyway)."""
-        self._resident = self._scan_rows = None
+        self._resident = self._scan_rows = self._dirty_split = None
         self._gen += 1
 
     def _may_keep_resident(self) -> bool:
@@ -249,8 +265,26 @@ class PathShadowing:
         if y.is_cuda:
             return y.contiguous()
         if not self._may_keep_resident():
-            self._resident = self._scan_rows = None
-            return y.contiguous().to(device, non_blocking=False)
+            # a dataset that may change between calls without a trace (a writeable numpy array -- what the tutorial and
+            # TimeSeriesDataset.load() hand over) is uploaded on every call, as the reference does (ref :154-155).  Two things
+            # keep that from being paid silently: the calls of ONE predict() share one upload (the array cannot change between
+            # its context splits: ref :286-301 loops over them without returning to the caller), and the first upload warns,
+            # with the remedy.
+            scope = self._predict_scope
+            if scope is not None and scope[0] is self.dataset and scope[1] is not None and scope[1].device == device:
+                return scope[1]
+            self._resident = self._scan_rows = self._dirty_split = None
+            if not self._warned_reupload:
+                self._warned_reupload = True
+                mib = y.numel() * 4 / 2 ** 20
+                warnings.warn(f"PathShadowing(cuda=True): the dataset is a writeable numpy array, so it is uploaded to the GPU again on "
+                              f"every call ({mib:.0f} MiB each time, as the reference does) -- construct with cache=True (and call "
+                              "refresh() after editing the array in place), or pass a read-only array or a torch tensor, to keep it "
+                              "resident in HBM", RuntimeWarning, stacklevel=4)
+            up = y.contiguous().to(device, non_blocking=False)
+            if scope is not None and scope[0] is self.dataset:
+                self._predict_scope = (self.dataset, up)
+            return up
         # keyed on the host storage AND the identity of what owns it: for a torch dataset the tensor object itself
         # (a weak reference: an address the allocator reuses for another tensor is not a match), for a numpy
         # dataset the array object
@@ -276,15 +310,35 @@ class PathShadowing:
         their kernel rows span, which no rewriting of the data turns into the conv's rule for every kernel: a dirty ensemble
         behind a linear embedding takes the generic torch formulation, _native_scan.)"""
         back = int(self.context.get_out_times())
-        key = (ds.data_ptr(), tuple(ds.shape), ds._version, back)
-        if self._scan_rows is None or self._scan_rows[0] != key or self._scan_rows[2]() is not ds:
+        # keyed on the STORAGE (address, shape, version counter), not on the tensor object: _dim_array hands a fresh
+        # ds[:, None, :] view of a 2-D CUDA dataset on every call, and a key that wanted the same object recounted the whole
+        # ensemble -- a pass over it plus a host synchronisation -- on every shadow() call.  The cache keeps `ds` alive, so the
+        # address cannot be handed to another tensor while the entry exists.
+        key = (ds.data_ptr(), tuple(ds.shape), tuple(ds.stride()), ds._version, back, str(ds.device))
+        if self._scan_rows is None or self._scan_rows[0] != key:
             self._dirty = bool(_native.count_nonfinite(ds))
+            self._dirty_split = None
             if self._dirty:
                 rows = _native.smear_nonfinite(ds, back, 0)
             else:
                 rows = ds[:, 0, :] if ds.shape[1] == 1 else ds[:, 0, :].contiguous()
-            self._scan_rows = (key, rows, weakref.ref(ds))
+            self._scan_rows = (key, rows, ds)
         return self._scan_rows[1]
+
+    def _split_dirty_rows(self, ds: torch.Tensor, back: int):
+        """A dirty ensemble behind a linear embedding, once per resident copy: (clean row indices, their rows (Rc, T) as a
+        contiguous copy, dirty row indices, THEIR rows with every non-finite sample written back over the `back` samples before
+        it).  The embedded scans' rejection tests assume finite data (prefix sums and matrix-core tiles spread a NaN over clean
+        windows); the dense chains of the exhaustive path multiply all K taps, zeros included, and so meet a NaN exactly where
+        the reference's zero-padded conv does (ref path_embedding.py:48-51, :129-132) once the horizon is smeared in."""
+        if getattr(self, "_dirty_split", None) is None or self._dirty_split[0] != back:
+            flags = _native.rows_nonfinite(ds)
+            dirty_idx = torch.nonzero(flags).flatten()
+            clean_idx = torch.nonzero(flags == 0).flatten()
+            clean_rows = ds[clean_idx, 0, :].contiguous()
+            dirty_rows = _native.smear_nonfinite(ds[dirty_idx].contiguous(), back, 0) if dirty_idx.numel() else None
+            self._dirty_split = (back, clean_idx, clean_rows, dirty_idx, dirty_rows)
+        return self._dirty_split[1:]
 
     def _native_scan(self, x: torch.Tensor, y: torch.Tensor, k: int, defer_status: bool = False):
         """(d, idx, resident dataset) on the device.  `defer_status` (Identity scans only): ONE raw call, its status
@@ -303,18 +357,6 @@ class PathShadowing:
             # the reference fails inside torch.topk (ref :165) with the same exception type
             raise RuntimeError("selected index k out of range")
         kind = self._native_kind(x, y, k)
-        if kind in ("linear", "padded") and self._dirty:
-            # NaN / +-inf in the ensemble behind a linear embedding: the reference's conv1d makes a window NaN when ANY tap of
-            # its zero-padded kernel meets one (0 * NaN); the native scans only visit the taps their rows span.  Rare enough
-            # to be served by the reference's own formulation in torch ops on this device (memory-bounded splits).
-            R_, T_ = ds.shape[0], ds.shape[-1]
-            per_row = max(T_ - x.shape[-1] + 1, 1) * max(int(self.embedding.kernel.shape[0]), 1) * 4 * 3
-            n_splits = max(1, min(R_, -(-R_ * per_row // (1 << 30))))
-            while R_ // n_splits == 0:
-                n_splits -= 1
-            d, idx = self._generic_scan(x, ds, k, n_splits, True)
-            self._served_by = "torch"
-            return d.to(dev), idx.to(dev), ds
         if kind in ("linear", "padded"):
             # the (tiny) query embedding stays the module's own conv1d (ref :140); the scan
             # over the ensemble takes the unpadded kernel and the horizon as an integer --
@@ -323,6 +365,7 @@ class PathShadowing:
             with single_thread():
                 hx = self.embedding(x.to(ker.device))[:, 0, :].contiguous()
             hx = hx.to(dev)
+            back = h
             if kind == "padded":
                 h = 0
             # the scanning kernel on the device, kept while the module's kernel tensor is the same object at the same
@@ -335,63 +378,118 @@ class PathShadowing:
                     ker2 = ker[:, 0, :].contiguous().to(dev)
                 self._ker_dev = (kkey, ker2, ker)            # (ker: keeps the id alive)
             ker2 = self._ker_dev[1]
+            # a kernel without Foveal's suffix structure (a filter bank, a user kernel): the rejection test on the
+            # matrix cores (the library cannot look at the matrix without a synchronisation: the caller says which it is)
+            fl = 0 if isinstance(self.embedding, Foveal) else _native.FLAG_EMBED_MX
 
-            if rows.shape[-1] == ker2.shape[-1] + h:
-                # ONE window per row: the reference's embedded view (S, 1, d) is contiguous and its distance the
-                # 8-lane reduce over d (ref path_embedding.py:129-132, path_distance.py:65) -- embed every row once,
-                # then scan R pre-embedded points (rows one window long): psh_embed_rows + psh_scan_topk
-                points = _native.embed_rows(rows.contiguous(), ker2)
+            def embedded_topk(rows_t, kk, keep_plan):
+                """(d, idx) of the kk best windows of `rows_t` per query: the sampled scan, the exhaustive one for queries
+                whose status asks for it (candidate slices overflowed: massive ties / adversarial data)."""
+                d, idx, status = _native.scan_topk_embedded(rows_t, ker2, hx, kk, h=h, workspace=self._workspace, flags=fl,
+                                                            keep_plan=keep_plan)
+                bad = torch.nonzero(status != _native.PSH_STATUS_OK).flatten()
+                if bad.numel():
+                    d2, idx2, _ = _native.scan_topk_embedded(rows_t, ker2, hx[bad].contiguous(), kk, h=h, workspace=self._workspace,
+                                                             exhaustive=True, flags=fl)
+                    d[bad] = d2
+                    idx[bad] = idx2
+                return d, idx
 
-                d, idx = _native.scan_topk_checked(points, hx, k, h=0, workspace=self._workspace)
+            one_window = rows.shape[-1] == ker2.shape[-1] + h
+            if not self._dirty:
+                if one_window:
+                    # ONE window per row: the reference's embedded view (S, 1, d) is contiguous and its distance the
+                    # 8-lane reduce over d (ref path_embedding.py:129-132, path_distance.py:65) -- embed every row once,
+                    # then scan R pre-embedded points (rows one window long): psh_embed_rows + psh_scan_topk
+                    points = _native.embed_rows(rows.contiguous(), ker2)
+                    d, idx = _native.scan_topk_checked(points, hx, k, h=0, workspace=self._workspace)
+                    return d, idx, ds
+                # (keep_plan: ker2 is the cached device copy above -- same tensor, same version = same matrix)
+                d, idx = embedded_topk(rows, k, True)
                 return d, idx, ds
-            else:
-                # a kernel without Foveal's suffix structure (a filter bank, a user kernel): the rejection test on the
-                # matrix cores (the library cannot look at the matrix without a synchronisation: the caller says which it is)
-                fl = 0 if isinstance(self.embedding, Foveal) else _native.FLAG_EMBED_MX
-
-                def scan(sel, exhaustive):
-                    q = hx if sel is None else hx[sel].contiguous()
-                    # (keep_plan: ker2 is the cached device copy above -- same tensor, same version = same matrix)
-                    return _native.scan_topk_embedded(rows, ker2, q, k, h=h, workspace=self._workspace,
-                                                      exhaustive=exhaustive, flags=fl, keep_plan=True)
-        else:
-            # a batch's rejection test puts every query of a call on ONE 8-bit step (include/psh.h, PSH_FLAG_MQ_F16): queries
-            # that differ in amplitude by more than ~3x go to the library as separate calls, one per amplitude class (a factor
-            # of 3 each) -- a call's time is proportional to its queries, so the classes cost what the batch would, plus a
-            # quarter of a millisecond of fixed work per class.  Decided here, where the queries are still host memory.
-            classes = None
-            if x.shape[0] > 1 and x.device.type == "cpu":
-                amp = x[:, 0, :].abs().amax(dim=1)
-                top = float(amp[torch.isfinite(amp)].max()) if bool(torch.isfinite(amp).any()) else 0.0
-                if top > 0.0 and not (top <= 3.0 * float(amp.min())):
-                    cls = torch.floor(torch.log(torch.clamp(amp / top, min=1e-30)) / math.log(3.0) + 1e-6).to(torch.int64)
-                    cls = torch.where(torch.isfinite(amp) & (amp > 0), cls, torch.full_like(cls, -1000))   # zero / non-finite queries: a class of their own
-                    classes = [torch.nonzero(cls == c).flatten() for c in torch.unique(cls, sorted=True).tolist()[::-1]]
-            if classes is None or len(classes) == 1:
-                xq = x[:, 0, :].contiguous().to(dev)
-                if defer_status:
-                    d, idx, status = _native.scan_topk(rows, xq, k, h=h, workspace=self._workspace)
-                    return d, idx, ds, status
-                d, idx = _native.scan_topk_checked(rows, xq, k, h=h, workspace=self._workspace)
-                return d, idx, ds
-            B_ = x.shape[0]
-            d = torch.empty((B_, k), dtype=torch.float32, device=dev)
-            idx = torch.empty((B_, k, 2), dtype=torch.int32, device=dev)
-            for sel in classes:
-                dc, ic = _native.scan_topk_checked(rows, x[sel, 0, :].contiguous().to(dev), k, h=h, workspace=self._workspace)
-                sel_d = sel.to(dev)
-                d[sel_d] = dc
-                idx[sel_d] = ic
-            if defer_status:
-                return d, idx, ds, torch.zeros(B_, dtype=torch.int32, device=dev)     # (every class was checked and resolved above)
+            # ---- NaN / +-inf in the ensemble behind a linear embedding.  The reference's conv1d makes a window NaN when ANY tap
+            # of its zero-padded kernel meets one (0 * NaN); the native rejection tests assume finite data.  Rows without such a
+            # sample (almost all) are scanned as ever; the few that hold one go through the exhaustive dense chains on rows
+            # with the horizon smeared in (every tap multiplied: the conv's rule exactly); the two lists are merged by (d, r, t).
+            clean_idx, clean_rows, dirty_idx, dirty_rows = self._split_dirty_rows(ds, back if kind == "linear" else 0)
+            Tp = ds.shape[-1] - ker2.shape[-1] - h + 1
+            B_ = hx.shape[0]
+            parts_d, parts_i = [], []
+            n_clean, n_dirty = int(clean_idx.numel()) * Tp, int(dirty_idx.numel()) * Tp
+            if n_clean > 0:
+                kc = min(k, n_clean)
+                if one_window:
+                    points = _native.embed_rows(clean_rows, ker2)
+                    dc, ic = _native.scan_topk_checked(points, hx, kc, h=0, workspace=self._workspace)
+                elif kc == k:
+                    dc, ic = embedded_topk(clean_rows, kc, False)
+                else:
+                    dc, ic, _ = _native.scan_topk_embedded(clean_rows, ker2, hx, kc, h=h, workspace=self._workspace, exhaustive=True, flags=fl)
+                ic = ic.clone()
+                ic[..., 0] = clean_idx[ic[..., 0].long()].to(torch.int32)
+                parts_d.append(dc)
+                parts_i.append(ic)
+            if n_dirty > 0 and (n_clean < k or not one_window):
+                kd = min(k, n_dirty)
+                if one_window:
+                    # a dirty row IS its one window: NaN, ranked behind every clean one (ref :165)
+                    dd = torch.full((B_, kd), float("nan"), dtype=torch.float32, device=dev)
+                    idd = torch.zeros((B_, kd, 2), dtype=torch.int32, device=dev)
+                    idd[..., 0] = dirty_idx[:kd].to(torch.int32)[None, :]
+                else:
+                    dd, idd, _ = _native.scan_topk_embedded(dirty_rows, ker2, hx, kd, h=h, workspace=self._workspace, exhaustive=True, flags=fl)
+                    idd = idd.clone()
+                    idd[..., 0] = dirty_idx[idd[..., 0].long()].to(torch.int32)
+                parts_d.append(dd)
+                parts_i.append(idd)
+            if len(parts_d) == 1 and parts_d[0].shape[1] == k:
+                return parts_d[0], parts_i[0], ds
+            d, idx = _native.merge_topk(torch.cat(parts_d, dim=1).contiguous(), torch.cat(parts_i, dim=1).contiguous(), k)
             return d, idx, ds
-        d, idx, status = scan(None, False)
-        bad = torch.nonzero(status != _native.PSH_STATUS_OK).flatten()
-        if bad.numel():
-            # candidate buffer overflowed (massive ties / adversarial data): exact slow path
-            d2, idx2, _ = scan(bad, True)
-            d[bad] = d2
-            idx[bad] = idx2
+
+        # ---- Identity windows
+        # A batch's 8-bit rejection test (32 queries and more, W <= 25: psh_capi.hip) puts every query of a call on ONE
+        # quantisation step (include/psh.h, PSH_FLAG_MQ_F16): queries that differ in amplitude by more than ~3x go to the library
+        # as separate calls, one per amplitude class (a factor of 3 each) -- a call's time is proportional to its queries, so the
+        # classes cost what the batch would, plus a quarter of a millisecond of fixed work per class -- unless a class would fall
+        # below the 32 queries the 8-bit test wants: then ONE call with the f16 test serves the whole batch.  Smaller batches and
+        # longer windows never meet the 8-bit test: one call.  Decided here, where the queries are still host memory.
+        classes, flags = None, 0
+        if x.shape[0] >= 32 and x.shape[-1] <= 25 and x.device.type == "cpu":
+            amp = x[:, 0, :].abs().amax(dim=1)
+            top = float(amp[torch.isfinite(amp)].max()) if bool(torch.isfinite(amp).any()) else 0.0
+            if top > 0.0 and not (top <= 3.0 * float(amp.min())):
+                cls = torch.floor(torch.log(torch.clamp(amp / top, min=1e-30)) / math.log(3.0) + 1e-6).to(torch.int64)
+                cls = torch.where(torch.isfinite(amp) & (amp > 0), cls, torch.full_like(cls, -1000))   # zero / non-finite queries: a class of their own
+                classes = [torch.nonzero(cls == c).flatten() for c in torch.unique(cls, sorted=True).tolist()[::-1]]
+                if len(classes) == 1:
+                    classes = None
+                elif min(int(c.numel()) for c in classes) < 32:
+                    classes, flags = None, _native.FLAG_MQ_F16
+        if classes is None:
+            xq = x[:, 0, :].contiguous().to(dev)
+            if defer_status:
+                d, idx, status = _native.scan_topk(rows, xq, k, h=h, workspace=self._workspace, flags=flags)
+                return d, idx, ds, status
+            d, idx = _native.scan_topk_checked(rows, xq, k, h=h, workspace=self._workspace, flags=flags)
+            return d, idx, ds
+        B_ = x.shape[0]
+        d = torch.empty((B_, k), dtype=torch.float32, device=dev)
+        idx = torch.empty((B_, k, 2), dtype=torch.int32, device=dev)
+        status = torch.zeros(B_, dtype=torch.int32, device=dev)
+        for sel in classes:
+            xq = x[sel, 0, :].contiguous().to(dev)
+            sel_d = sel.to(dev)
+            if defer_status:
+                # (no synchronisation per class: the statuses travel with the results, the caller reads them once)
+                dc, ic, sc = _native.scan_topk(rows, xq, k, h=h, workspace=self._workspace)
+                status[sel_d] = sc
+            else:
+                dc, ic = _native.scan_topk_checked(rows, xq, k, h=h, workspace=self._workspace)
+            d[sel_d] = dc
+            idx[sel_d] = ic
+        if defer_status:
+            return d, idx, ds, status
         return d, idx, ds
 
     @staticmethod
@@ -523,15 +621,52 @@ class PathShadowing:
         if st is None or st[0] != key:
             st = self._sync_slot = (key, _native.PreparedShadow(rows, ds, W, k, h, self._workspace, 0, host_direct=True))
         slot = st[1]
-        slot.launch(torch.cuda.current_stream(dev), x[:, 0, :])
+        stream = torch.cuda.current_stream(dev)
+        hint = self._next_hint(x, k, W)
+        slot.launch(stream, x[:, 0, :], hint)
         slot.event.synchronize()
         self.last_path = "hip"
+        self.last_hint = None
+        if hint is not None and int(slot.host[3][0]) != _native.PSH_STATUS_OK:
+            # the hint fell short of k windows (or admitted more than the lists hold): the same call without it; no hints for
+            # a while (twice as long after every miss in a row)
+            self.last_hint = "short"
+            hstate = self._hint_state
+            hstate["fails"] = min(hstate["fails"] + 1, 5)
+            hstate["skip"] = 4 << hstate["fails"]
+            # (the fused launch says RETRY for "fewer than k found" with its header still armed; one a time-out disarmed says
+            #  RETRY again below and takes the general path)
+            slot.launch(stream, x[:, 0, :], None)
+            slot.event.synchronize()
+        elif hint is not None:
+            self.last_hint = "ok"
+            self._hint_state["fails"] = 0
         hd, hp, hi, hs = slot.take()
         if hs.any():
             if int(hs[0]) == _native.PSH_STATUS_RETRY:
                 self._workspace.arm()
             return None
+        if self.hint == "auto":
+            xn2 = float((x[:, 0, :].double() ** 2).sum())
+            hstate = self._hint_state if (self._hint_state and self._hint_state["key"] == (k, W, h)) else {"key": (k, W, h), "skip": 0, "fails": 0}
+            hstate["dk"] = float(hd[0, k - 1]) if xn2 > 0 else None
+            self._hint_state = hstate
         return hd, hp, hi
+
+    HINT_MARGIN = 1.15          # on acc: the k-th distance may come out 7 % above the previous call's before the hint falls short
+
+    def _next_hint(self, x: torch.Tensor, k: int, W: int):
+        """The admission level this call hands to the library (hint="auto"), or None: (d_k of the previous call x ||x||)^2 x
+        HINT_MARGIN -- the RELATIVE k-th distance moves far less from one query date to the next than acc itself."""
+        hstate = self._hint_state
+        if self.hint != "auto" or hstate is None or hstate.get("dk") is None or hstate["key"] != (k, W, self.context.get_out_times()):
+            return None
+        if hstate["skip"] > 0:
+            hstate["skip"] -= 1
+            return None
+        xn2 = float((x[:, 0, :].double() ** 2).sum())
+        level = hstate["dk"] ** 2 * xn2 * self.HINT_MARGIN
+        return level if (level > 0.0 and math.isfinite(level)) else None
 
     def shadow_async(self, x_context: ArrayType, k: int = 1, streams: int = 3) -> "PendingShadow":
         """shadow(cuda=True) without waiting for the result: the call only ENQUEUES the scan and the path gather and returns a
@@ -670,18 +805,25 @@ class PathShadowing:
         if device_predict is None:
             device_predict = bool(getattr(to_predict, "accepts_torch", False))
         means, stds = [], []
-        for rows in tqdm(torch.arange(n).split(n // n_context_splits)):
-            if cuda and device_predict:
-                y = self._dataset_tensor() if y is None else y
-                if self._native_ok(x[rows, ...], y, k):
-                    got = self._predict_on_device(x[rows, ...], y, k, to_predict, proba_name, eta)
-                    means.append(got[0])
-                    stds.append(got[1])
-                    continue
-            d, paths, _ = self.shadow(x[rows, ...], k, n_dataset_splits, cuda)
-            m, s = self.predict_from_paths(d, paths, to_predict, proba_name, eta)
-            means.append(m)
-            stds.append(s)
+        # (cuda=True: the context splits of this ONE call share one upload of a dataset that is otherwise re-read per call)
+        self._predict_scope = (self.dataset, None) if cuda else None
+        try:
+            for rows in tqdm(torch.arange(n).split(n // n_context_splits)):
+                if cuda and device_predict:
+                    y = self._dataset_tensor() if y is None else y
+                    if self._native_ok(x[rows, ...], y, k):
+                        got = self._predict_on_device(x[rows, ...], y, k, to_predict, proba_name, eta)
+                        means.append(got[0])
+                        stds.append(got[1])
+                        continue
+                d, paths, _ = self.shadow(x[rows, ...], k, n_dataset_splits, cuda)
+                m, s = self.predict_from_paths(d, paths, to_predict, proba_name, eta)
+                means.append(m)
+                stds.append(s)
+        finally:
+            if self._predict_scope is not None and self._predict_scope[1] is not None:
+                self._scan_rows = self._dirty_split = None          # (they keep the per-call upload alive)
+            self._predict_scope = None
         return np.concatenate(means), np.concatenate(stds)
 
 

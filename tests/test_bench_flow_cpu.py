@@ -111,3 +111,70 @@ def test_host_merge_and_same_result():
     wrong[0, 3, 1] += 1
     assert not bench.same_result(md, wrong, md, mi, tie_free_order=True)
     assert not bench.same_result(md, wrong, md[:, perm], mi[:, perm], tie_free_order=False)
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", REPO / "bench.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_workload_label_follows_the_sizes_and_the_rank_count():
+    """config.workload names the BASELINE.json configuration the run IS: configs[1] only at its sizes on one GPU, configs[3]
+    for the 8-way sharded run, configs[2] for 512 queries -- and says so when the sizes are not a BASELINE configuration
+    (r04's line for --rows-per-gpu 131072 carried configs[1]'s name)."""
+    wl = _bench_module().workload_label
+    assert wl(32768, 4096, 20, 20, 1024, 1, 1).startswith("BASELINE.json configs[1]:")
+    l8 = wl(32768, 4096, 20, 20, 1024, 1, 8)
+    assert l8.startswith("BASELINE.json configs[3]:") and "R=262144" in l8 and "8 ways" in l8
+    l2 = wl(32768, 4096, 20, 20, 1024, 1, 2)
+    assert "configs[3]" in l2 and "2 of its 8 GPUs" in l2 and "R=65536" in l2 and not l2.startswith("BASELINE.json configs[1]")
+    assert wl(32768, 4096, 20, 20, 1024, 512, 1).startswith("BASELINE.json configs[2]:")
+    for other in (wl(131072, 4096, 20, 20, 1024, 1, 1), wl(32768, 4096, 64, 20, 1024, 1, 1), wl(24, 160, 20, 20, 50, 1, 2),
+                  wl(32768, 4096, 20, 20, 1024, 40, 1)):
+        assert other.startswith("not a BASELINE.json configuration") and "configs[1]" not in other
+    assert "R=131072" in wl(131072, 4096, 20, 20, 1024, 1, 1)
+
+
+@pytest.mark.parametrize("nproc", [1, 2])
+def test_emitted_json_names_its_workload(oracle_mod, nproc):
+    res, lines = _run_bench(nproc, ["--steps", "2", "--warmup", "1", "--rows-per-gpu", "24", "--T", "160", "--k", "50"])
+    assert res.returncode == 0, res.stderr[-3000:]
+    j = json.loads(lines[0])
+    w = j["config"]["workload"]
+    assert w.startswith("not a BASELINE.json configuration") and "R=24 " in w and f"{nproc} GPU" in w
+    assert ("sharded 2 ways" in w) == (nproc == 2)
+    assert "W=20" in j["metric"] and "k=50" in j["metric"]
+
+
+def test_self_launch_refuses_more_ranks_than_gpus_with_one_line(monkeypatch, capsys):
+    """`python bench.py --gpus 8` on a node that shows fewer GPUs: one clear line and exit code 2, no rank is started."""
+    m = _bench_module()
+    import subprocess as sp
+    started = []
+    monkeypatch.setattr(sp, "run", lambda *a, **k: started.append(a) or (_ for _ in ()).throw(AssertionError("a rank was launched")))
+    monkeypatch.setattr(m.torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(m.torch.cuda, "device_count", lambda: 1)
+    assert m.self_launch(8, ["--gpus", "8"]) == 2
+    err = capsys.readouterr().err
+    assert err.count("\n") == 1 and "needs 8 visible GPUs" in err and "shows 1" in err and not started
+
+
+def test_self_launch_retries_a_taken_rendezvous_port(monkeypatch, capsys):
+    m = _bench_module()
+    import subprocess as sp
+    calls = []
+
+    class R:
+        def __init__(self, rc, err):
+            self.returncode, self.stderr = rc, err
+
+    def fake_run(cmd, **kw):
+        calls.append(cmd[cmd.index("--master-port") + 1])
+        return R(1, "RuntimeError: ... EADDRINUSE ...\n") if len(calls) == 1 else R(0, "")
+    monkeypatch.setattr(sp, "run", fake_run)
+    assert m.self_launch(2, ["--gpus", "2", "--cpu-oracle"]) == 0
+    assert len(calls) == 2
+    assert "retrying" in capsys.readouterr().err

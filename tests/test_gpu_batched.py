@@ -228,33 +228,49 @@ def test_shadow_cuda_identity_matches_the_reference_with_paths(hip_device, oracl
 
 
 def test_shadow_cuda_splits_a_batch_of_mixed_amplitudes_into_classes(hip_device, oracle_mod, monkeypatch):
-    """PathShadowing looks at the host copy of a batch: queries more than ~3x apart in amplitude reach the library as separate
-    calls, one per amplitude class (the 8-bit rejection test puts the queries of a CALL on one step), zero and non-finite
-    queries in a class of their own -- and the batch comes back as one, equal to the oracle."""
+    """PathShadowing looks at the host copy of a batch that will meet the 8-BIT rejection test (32 queries and more, W <= 25 --
+    it puts the queries of a CALL on one quantisation step): queries more than ~3x apart in amplitude reach the library as
+    separate calls, one per amplitude class of at least 32 queries; when a class would be smaller, ONE call with the f16 test
+    (PSH_FLAG_MQ_F16) serves the batch; batches below 32 queries are never split.  The batch comes back as one, equal to the
+    oracle, either way."""
     import shadowing_amd as sa
     from shadowing_amd import _native
     ds = syn.dataset(2048, 1500, 2800)
     obj = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), ds, sa.PredictionContext(horizon=20))
     seen = []
     real = _native.scan_topk
-    monkeypatch.setattr(_native, "scan_topk", lambda *a, **kw: (seen.append(a[1].detach().cpu().numpy().copy()), real(*a, **kw))[1])
-    q = syn.rolling_queries(24, 20, 2801)
-    for scale, many in ((np.ones((24, 1), np.float32), False), (np.geomspace(1.0, 3000.0, 24).astype(np.float32)[:, None], True)):
-        x = (q * scale).astype(np.float32)
-        if many:
-            x[5] = 0.0
+    monkeypatch.setattr(_native, "scan_topk", lambda *a, **kw: (seen.append((a[1].detach().cpu().numpy().copy(), kw.get("flags", 0))), real(*a, **kw))[1])
+    cases = {
+        "uniform 80":        (80, np.ones((80, 1), np.float32), 1, 0),
+        "two classes of 40": (80, np.repeat(np.array([1.0, 100.0], np.float32), 40)[:, None], 2, 0),
+        "spread 80":         (80, np.geomspace(1.0, 3000.0, 80).astype(np.float32)[:, None], 1, _native.FLAG_MQ_F16),   # 8 classes of ~10: one f16 call
+        "spread 24":         (24, np.geomspace(1.0, 3000.0, 24).astype(np.float32)[:, None], 1, 0),                     # below 32 queries: the f16 test anyway
+    }
+    for name, (B, scale, n_calls, flags) in cases.items():
+        x = (syn.rolling_queries(B, 20, 2801) * scale).astype(np.float32)
+        if name == "two classes of 40":
+            x[5] = 0.0                                             # (a zero query: a class of its own would be below 32 -> one f16 call)
+            n_calls, flags = 1, _native.FLAG_MQ_F16
         n0 = len(seen)
         d, paths, idx = obj.shadow(x, k=100, cuda=True)
         calls = seen[n0:]
-        assert (len(calls) > 4) == many
-        for c in calls:                                            # within a call: amplitudes within a factor of 3 (or all zero)
-            a = np.abs(c).max(axis=1)
-            assert a.max() == 0 or a.max() <= 3.0 * a.min() * (1 + 1e-5)
+        assert len(calls) == n_calls and all(f == flags for _, f in calls), (name, [(c.shape, f) for c, f in calls])
         od, oidx = oracle_mod.scan_topk(ds, x, 100, h=20)
         fin = np.isfinite(od).all(axis=1)
-        assert fin.sum() >= 23
-        assert_exact(d[fin], idx[fin], od[fin], oidx[fin], f"classes {many}")
+        assert fin.sum() >= B - 1
+        assert_exact(d[fin], idx[fin], od[fin], oidx[fin], name)
         assert np.array_equal(paths[fin][:, :, 0, :], oracle_mod.gather_paths(rows3(ds), idx[fin], 40))
+    # two clean classes of 40: two calls, each within a factor of 3
+    x = (syn.rolling_queries(80, 20, 2801) * np.repeat(np.array([1.0, 100.0], np.float32), 40)[:, None]).astype(np.float32)
+    n0 = len(seen)
+    d, paths, idx = obj.shadow(x, k=100, cuda=True)
+    calls = seen[n0:]
+    assert len(calls) == 2 and all(f == 0 and c.shape[0] == 40 for c, f in calls)
+    for c, _ in calls:
+        a = np.abs(c).max(axis=1)
+        assert a.max() <= 3.0 * a.min() * (1 + 1e-5) or a.max() / a.min() < 40      # (rolling queries: amplitudes within a class differ by what the path gives)
+    od, oidx = oracle_mod.scan_topk(ds, x, 100, h=20)
+    assert_exact(d, idx, od, oidx, "two classes")
 
 
 def test_resident_copy_follows_edits_of_the_ensemble(hip_device):

@@ -428,3 +428,70 @@ def test_blocking_shadow_prepared_slot(hip_device, oracle_mod):
         od, opaths, oidx = oracle_mod.shadow(flat, q[None, :], 300, 20)
         assert_exact(d, idx, od, oidx, "prepared shadow, ties")
         assert np.array_equal(paths, opaths)
+
+
+def test_blocking_shadow_with_admission_hints(hip_device, oracle_mod):
+    """PathShadowing(hint="auto"): consecutive rolling query dates hand the library the level the previous date's k-th distance
+    predicts (psh_profile.tau_hint -> the fused launch without its sample phase and first barrier).  Results are the exact
+    top-k whether a hint holds ("ok"), falls short ("short": one more launch without it, hints off for a few calls) or is
+    fooled on purpose."""
+    import shadowing_amd as sa
+    ds = syn.dataset(8192, 2048, 6400)
+    obj = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), torch.as_tensor(ds), sa.PredictionContext(horizon=20), hint="auto")
+    qs = syn.rolling_queries(24, 20, 6401)
+    seen = []
+    for i in range(24):
+        d, paths, idx = obj.shadow(qs[i], k=200, cuda=True)
+        assert obj.last_path == "hip"
+        od, opaths, oidx = oracle_mod.shadow(ds, qs[i][None, :], 200, 20)
+        assert_exact(d, idx, od, oidx, f"hinted call {i} ({obj.last_hint})")
+        assert np.array_equal(paths, opaths)
+        seen.append(obj.last_hint)
+    assert seen[0] is None and "ok" in seen                       # the first call has nothing to go by; some hints held
+    # a fooled hint (the previous k-th distance a tenth of what it was: far fewer than k windows below the level)
+    obj._hint_state["dk"] *= 0.1
+    obj._hint_state["skip"] = 0
+    d, paths, idx = obj.shadow(qs[5], k=200, cuda=True)
+    assert obj.last_hint == "short" and obj._hint_state["skip"] > 0
+    od, opaths, oidx = oracle_mod.shadow(ds, qs[5][None, :], 200, 20)
+    assert_exact(d, idx, od, oidx, "fooled hint (too low)")
+    # ... and one far too generous (more candidates than the blocks' lists hold): same recovery
+    obj._hint_state["dk"] *= 3.0
+    obj._hint_state["skip"] = 0
+    d, paths, idx = obj.shadow(qs[6], k=200, cuda=True)
+    assert obj.last_hint == "short"
+    od, opaths, oidx = oracle_mod.shadow(ds, qs[6][None, :], 200, 20)
+    assert_exact(d, idx, od, oidx, "fooled hint (too high)")
+    # without hint="auto" nothing is hinted
+    plain = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), torch.as_tensor(ds), sa.PredictionContext(horizon=20))
+    plain.shadow(qs[0], k=200, cuda=True); plain.shadow(qs[1], k=200, cuda=True)
+    assert plain.last_hint is None and plain._hint_state is None
+
+
+def test_cuda_dataset_is_scanned_for_nonfinite_samples_once(hip_device, oracle_mod, monkeypatch):
+    """A 2-D (R, T) CUDA tensor as the dataset: _dim_array hands a fresh (R, 1, T) view on every call -- the pass over the
+    ensemble that looks for NaN / inf (plus its host synchronisation) must still run once per storage and version, not once
+    per shadow() call (the cache keyed on the view object never hit)."""
+    import shadowing_amd as sa
+    from shadowing_amd import _native
+    ds = syn.dataset(4096, 1024, 6500)
+    dev_ds = torch.as_tensor(ds[:, 0, :]).to(hip_device)               # (R, T) on the device
+    counted = []
+    real = _native.count_nonfinite
+    monkeypatch.setattr(_native, "count_nonfinite", lambda t: (counted.append(1), real(t))[1])
+    obj = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), dev_ds, sa.PredictionContext(horizon=20))
+    for i in range(4):
+        q = syn.gbm_log_returns((20,), 6501 + i)
+        d, _, idx = obj.shadow(q, k=50, cuda=True)
+        od, _, oidx = oracle_mod.shadow(ds, q[None, :], 50, 20)
+        assert_exact(d, idx, od, oidx, f"call {i}")
+    obj.shadow(syn.rolling_queries(5, 20, 6510), k=50, cuda=True)      # (the batched path and shadow_async share the cache)
+    obj.shadow_async(syn.gbm_log_returns((20,), 6511), k=50).result()
+    assert len(counted) == 1
+    dev_ds[7, 100] = float("nan")                                       # an in-place edit bumps the version: looked at again
+    q = syn.gbm_log_returns((20,), 6512)
+    d, _, idx = obj.shadow(q, k=50, cuda=True)
+    assert len(counted) == 2 and obj._dirty
+    ds2 = ds.copy(); ds2[7, 0, 100] = np.nan
+    od, _, oidx = oracle_mod.shadow(ds2, q[None, :], 50, 20)
+    assert_exact(d, idx, od, oidx, "after the edit")

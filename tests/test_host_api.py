@@ -264,6 +264,63 @@ def test_resident_copy_policy():
     assert obj._dataset_tensor().data_ptr() == ro.__array_interface__["data"][0]     # read-only arrays are wrapped too
 
 
+def test_writeable_numpy_ensemble_warns_once_and_predict_shares_one_upload():
+    """The drop-in default (a writeable numpy array, what the tutorial passes): cuda=True re-uploads it per call like the
+    reference -- but says so ONCE, with the remedy, and the context splits of one predict() share one upload.  (The upload
+    itself is exercised here with the host standing in for the device: _resident_dataset only moves tensors.)"""
+    import warnings
+    ds = syn.dataset(8, 100, 5)
+    obj = sa.PathShadowing(sa.Identity(10), sa.RelativeMSE(), ds, sa.PredictionContext(5))
+    y = obj._dataset_tensor()
+    cpu = torch.device("cpu")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        a = obj._resident_dataset(y, cpu)
+        b = obj._resident_dataset(y, cpu)
+    assert len(w) == 1 and issubclass(w[0].category, RuntimeWarning)
+    assert "cache=True" in str(w[0].message) and "refresh()" in str(w[0].message) and "every call" in str(w[0].message)
+    assert a is not b or a.data_ptr() == y.data_ptr()                       # (per call: nothing is kept between calls)
+    assert obj._resident is None
+    # inside one predict(): the first call's upload serves the later context splits; afterwards nothing is kept
+    uploads = []
+    orig = torch.Tensor.to
+
+    def counting_to(self, *a_, **k_):
+        if self.shape == y.shape:
+            uploads.append(1)
+        return orig(self, *a_, **k_)
+    obj._predict_scope = (obj.dataset, None)
+    torch.Tensor.to = counting_to
+    try:
+        u1 = obj._resident_dataset(y, cpu)
+        u2 = obj._resident_dataset(y, cpu)
+        u3 = obj._resident_dataset(y, cpu)
+    finally:
+        torch.Tensor.to = orig
+        obj._predict_scope = None
+    assert len(uploads) == 1 and u1 is u2 is u3
+    # an edit of the array between two predict() calls is seen by the second (the scope ends with the call)
+    obj._predict_scope = (obj.dataset, None)
+    first = obj._resident_dataset(y, cpu).clone()
+    obj._predict_scope = None
+    ds[0, 0, 0] += 1.0
+    obj._predict_scope = (obj.dataset, None)
+    second = obj._resident_dataset(obj._dataset_tensor(), cpu)
+    obj._predict_scope = None
+    assert np.float32(second[0, 0, 0]) == np.float32(first[0, 0, 0]) + np.float32(1.0)
+    # predict() opens and closes the scope itself (host path: cuda=False leaves it alone)
+    mean, std = obj.predict(syn.gbm_log_returns((4, 10), 9), k=5, to_predict=lambda p: p.mean(-1), proba_name="uniform", n_context_splits=2)
+    assert obj._predict_scope is None and mean.shape[0] == 4
+    # cache=True / a tensor / a read-only array: no warning
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        sa.PathShadowing(sa.Identity(10), sa.RelativeMSE(), ds, sa.PredictionContext(5), cache=True)._resident_dataset(y, cpu)
+        sa.PathShadowing(sa.Identity(10), sa.RelativeMSE(), torch.tensor(ds), sa.PredictionContext(5))._resident_dataset(torch.tensor(ds), cpu)
+    assert not w
+    with pytest.raises(ValueError):
+        sa.PathShadowing(sa.Identity(10), sa.RelativeMSE(), ds, sa.PredictionContext(5), hint="always")
+
+
 def test_realized_variance_takes_torch_tensors():
     x = syn.gbm_log_returns((3, 4, 30), 5)
     for vol in (False, True):
