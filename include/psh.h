@@ -75,7 +75,7 @@ extern "C" {
 #define PSH_FLAG_UNSORTED 1
 /* A/B switches of the test-suite and the tools (results are identical either way):
  *   FILTER_VALU   the rejection test of the Identity scan on the vector ALUs instead of the matrix cores
- *   EMBED_DENSE   psh_scan_topk_embedded: dense fma chains even when the kernel has suffix rows
+ *   EMBED_DENSE   psh_scan_topk_embedded: dense fma chains over every tap even when the kernel has suffix rows / zero taps
  *   ROWS_GENERIC  one-window rows (T == W + h) through the generic exhaustive path instead of rows_kernel
  *   NO_FUSE       psh_scan_topk: the separate bootstrap / threshold / scan / select launches instead of the
  *                 single fused launch */
@@ -254,7 +254,8 @@ int psh_scan_topk_exhaustive(int device, void* stream,
  * scanned bound-then-verify over shared running sums -- same results, ~5x faster; when the
  * common support is one interval (Foveal itself) the running sums are differences of prefix sums
  * of the segment -- another ~2x (PSH_FLAG_EMBED_TAPS: the tap walk instead).
- * PSH_FLAG_EMBED_DENSE forces the dense chains (A/B tests).
+ * PSH_FLAG_EMBED_DENSE forces the dense chains over ALL K taps of every row, zero taps included (A/B tests; and the
+ * exhaustive pass over rows that hold non-finite samples: 0 * NaN = NaN as in the reference's conv -- psh_rows_nonfinite).
  */
 int psh_embedded_supported(int d, int K);   /* 1 when a d x K kernel fits the embedded scan (LDS), else 0 */
 /* Diagnostics: byte offset, inside the workspace, of what the last sampled psh_scan_topk_embedded call found in its kernel

@@ -243,6 +243,10 @@ __global__ __launch_bounds__(THREADS) void embed_scan_kernel(ScanArgs a) {
         for (int j = 0; j < K; ++j)
             if (row[j] != 0.0f) { lo = j < lo ? j : lo; hi = j + 1; }
         if (hi == 0) lo = 0;
+        // PSH_FLAG_EMBED_DENSE: EVERY tap is multiplied, the zeros in front of and behind a row's span included -- the same bits
+        // on finite data (fma(0, y, e) = e), and 0 * NaN = NaN exactly where the reference's zero-padded conv has it (what the
+        // callers' exhaustive pass over the dirty rows of an ensemble relies on: psh.h, psh_rows_nonfinite)
+        if (a.emb_dense) { lo = 0; hi = K; }
         lo &= ~3;
         rng[threadIdx.x] = make_int2(lo, hi - lo);
     }

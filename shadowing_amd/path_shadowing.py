@@ -437,7 +437,10 @@ class PathShadowing:
                     idd = torch.zeros((B_, kd, 2), dtype=torch.int32, device=dev)
                     idd[..., 0] = dirty_idx[:kd].to(torch.int32)[None, :]
                 else:
-                    dd, idd, _ = _native.scan_topk_embedded(dirty_rows, ker2, hx, kd, h=h, workspace=self._workspace, exhaustive=True, flags=fl)
+                    # (EMBED_DENSE: every one of the K taps is multiplied, zeros included -- the suffix-rows walk would skip the
+                    #  taps in front of Foveal's longest row, where the conv still meets a NaN)
+                    dd, idd, _ = _native.scan_topk_embedded(dirty_rows, ker2, hx, kd, h=h, workspace=self._workspace, exhaustive=True,
+                                                            flags=_native.FLAG_EMBED_DENSE)
                     idd = idd.clone()
                     idd[..., 0] = dirty_idx[idd[..., 0].long()].to(torch.int32)
                 parts_d.append(dd)
@@ -451,21 +454,30 @@ class PathShadowing:
         # A batch's 8-bit rejection test (32 queries and more, W <= 25: psh_capi.hip) puts every query of a call on ONE
         # quantisation step (include/psh.h, PSH_FLAG_MQ_F16): queries that differ in amplitude by more than ~3x go to the library
         # as separate calls, one per amplitude class (a factor of 3 each) -- a call's time is proportional to its queries, so the
-        # classes cost what the batch would, plus a quarter of a millisecond of fixed work per class -- unless a class would fall
-        # below the 32 queries the 8-bit test wants: then ONE call with the f16 test serves the whole batch.  Smaller batches and
-        # longer windows never meet the 8-bit test: one call.  Decided here, where the queries are still host memory.
+        # classes cost what the batch would, plus a quarter of a millisecond of fixed work per class -- as long as every class
+        # keeps the 32 queries the 8-bit test wants.  Otherwise (small classes, small batches, longer windows: the f16 test) the
+        # classes are a factor of 64 wide.  Decided here, where the queries are still host memory.
         classes, flags = None, 0
-        if x.shape[0] >= 32 and x.shape[-1] <= 25 and x.device.type == "cpu":
+        i8 = x.shape[0] >= 32 and x.shape[-1] <= 25            # the call would meet the 8-bit test
+        if x.shape[0] > 1 and x.device.type == "cpu":
             amp = x[:, 0, :].abs().amax(dim=1)
             top = float(amp[torch.isfinite(amp)].max()) if bool(torch.isfinite(amp).any()) else 0.0
             if top > 0.0 and not (top <= 3.0 * float(amp.min())):
-                cls = torch.floor(torch.log(torch.clamp(amp / top, min=1e-30)) / math.log(3.0) + 1e-6).to(torch.int64)
-                cls = torch.where(torch.isfinite(amp) & (amp > 0), cls, torch.full_like(cls, -1000))   # zero / non-finite queries: a class of their own
-                classes = [torch.nonzero(cls == c).flatten() for c in torch.unique(cls, sorted=True).tolist()[::-1]]
+                def by_factor(f):
+                    cls = torch.floor(torch.log(torch.clamp(amp / top, min=1e-30)) / math.log(f) + 1e-6).to(torch.int64)
+                    cls = torch.where(torch.isfinite(amp) & (amp > 0), cls, torch.full_like(cls, -1000))   # zero / non-finite queries: a class of their own
+                    return [torch.nonzero(cls == c).flatten() for c in torch.unique(cls, sorted=True).tolist()[::-1]]
+                fine = by_factor(3.0)
+                if i8 and min(int(c.numel()) for c in fine) >= 32:
+                    classes = fine                                # every class keeps the 8-bit test
+                else:
+                    # the f16 test copes with amplitudes a few dozen times apart on its one scale (beyond that a quiet query
+                    # keeps more windows than its slices hold and falls to the exhaustive pass): classes a factor of 64 wide,
+                    # each ONE call, on the f16 test where the 8-bit one would have met more than its factor of 3
+                    classes = by_factor(64.0)
+                    flags = _native.FLAG_MQ_F16 if i8 else 0
                 if len(classes) == 1:
                     classes = None
-                elif min(int(c.numel()) for c in classes) < 32:
-                    classes, flags = None, _native.FLAG_MQ_F16
         if classes is None:
             xq = x[:, 0, :].contiguous().to(dev)
             if defer_status:
@@ -482,10 +494,10 @@ class PathShadowing:
             sel_d = sel.to(dev)
             if defer_status:
                 # (no synchronisation per class: the statuses travel with the results, the caller reads them once)
-                dc, ic, sc = _native.scan_topk(rows, xq, k, h=h, workspace=self._workspace)
+                dc, ic, sc = _native.scan_topk(rows, xq, k, h=h, workspace=self._workspace, flags=flags)
                 status[sel_d] = sc
             else:
-                dc, ic = _native.scan_topk_checked(rows, xq, k, h=h, workspace=self._workspace)
+                dc, ic = _native.scan_topk_checked(rows, xq, k, h=h, workspace=self._workspace, flags=flags)
             d[sel_d] = dc
             idx[sel_d] = ic
         if defer_status:

@@ -228,49 +228,55 @@ def test_shadow_cuda_identity_matches_the_reference_with_paths(hip_device, oracl
 
 
 def test_shadow_cuda_splits_a_batch_of_mixed_amplitudes_into_classes(hip_device, oracle_mod, monkeypatch):
-    """PathShadowing looks at the host copy of a batch that will meet the 8-BIT rejection test (32 queries and more, W <= 25 --
-    it puts the queries of a CALL on one quantisation step): queries more than ~3x apart in amplitude reach the library as
-    separate calls, one per amplitude class of at least 32 queries; when a class would be smaller, ONE call with the f16 test
-    (PSH_FLAG_MQ_F16) serves the batch; batches below 32 queries are never split.  The batch comes back as one, equal to the
-    oracle, either way."""
+    """PathShadowing looks at the host copy of a batch.  One that will meet the 8-BIT rejection test (32 queries and more,
+    W <= 25 -- it puts the queries of a CALL on one quantisation step) and whose amplitudes differ by more than ~3x reaches the
+    library as one call per amplitude class of a factor 3, as long as every class keeps 32 queries; otherwise (small classes,
+    small batches) the classes are a factor of 64 wide -- what the f16 test's one scale copes with -- and on the f16 test.
+    The batch comes back as one, equal to the oracle, either way."""
     import shadowing_amd as sa
     from shadowing_amd import _native
     ds = syn.dataset(2048, 1500, 2800)
-    obj = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), ds, sa.PredictionContext(horizon=20))
+    obj = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), torch.as_tensor(ds), sa.PredictionContext(horizon=20))
     seen = []
     real = _native.scan_topk
     monkeypatch.setattr(_native, "scan_topk", lambda *a, **kw: (seen.append((a[1].detach().cpu().numpy().copy(), kw.get("flags", 0))), real(*a, **kw))[1])
-    cases = {
-        "uniform 80":        (80, np.ones((80, 1), np.float32), 1, 0),
-        "two classes of 40": (80, np.repeat(np.array([1.0, 100.0], np.float32), 40)[:, None], 2, 0),
-        "spread 80":         (80, np.geomspace(1.0, 3000.0, 80).astype(np.float32)[:, None], 1, _native.FLAG_MQ_F16),   # 8 classes of ~10: one f16 call
-        "spread 24":         (24, np.geomspace(1.0, 3000.0, 24).astype(np.float32)[:, None], 1, 0),                     # below 32 queries: the f16 test anyway
+    F16 = _native.FLAG_MQ_F16
+    two = np.repeat(np.array([1.0, 100.0], np.float32), 40)[:, None]
+    cases = {   # name: (B, per-query scale, a zero query?, calls expected (None: 2..4 wide classes), flags of every call)
+        "uniform 80":          (80, np.ones((80, 1), np.float32), False, 1, 0),
+        "two classes of 40":   (80, two, False, 2, 0),                                  # both keep the 8-bit test
+        "... and a zero query": (80, two, True, 3, F16),                                # a class of 39: wide classes on f16 (x1, x100, the zero one)
+        "spread 80":           (80, np.geomspace(1.0, 3000.0, 80).astype(np.float32)[:, None], False, None, F16),
+        "spread 24":           (24, np.geomspace(1.0, 3000.0, 24).astype(np.float32)[:, None], False, None, 0),
     }
-    for name, (B, scale, n_calls, flags) in cases.items():
-        x = (syn.rolling_queries(B, 20, 2801) * scale).astype(np.float32)
-        if name == "two classes of 40":
-            x[5] = 0.0                                             # (a zero query: a class of its own would be below 32 -> one f16 call)
-            n_calls, flags = 1, _native.FLAG_MQ_F16
+    for name, (B, scale, zero, n_calls, flags) in cases.items():
+        x = syn.rolling_queries(B, 20, 2801)
+        x = (x / np.abs(x).max(axis=1, keepdims=True) * 0.03 * scale).astype(np.float32)      # every query's largest |sample|: 0.03 x its scale
+        if zero:
+            x[5] = 0.0
         n0 = len(seen)
         d, paths, idx = obj.shadow(x, k=100, cuda=True)
         calls = seen[n0:]
-        assert len(calls) == n_calls and all(f == flags for _, f in calls), (name, [(c.shape, f) for c, f in calls])
+        shapes = [(c.shape[0], f) for c, f in calls]
+        assert all(f & ~_native.FLAG_NO_FUSE == flags for _, f in calls[:1]), (name, shapes)
+        if n_calls is not None:
+            # the policy's calls come first and partition the batch (whatever follows is the status protocol: an estimate that
+            # fell short on this small ensemble -> the checked rerun / the exhaustive pass of those queries)
+            assert len(calls) >= n_calls and all(f == flags for _, f in calls[:n_calls]), (name, shapes)
+            assert sum(c.shape[0] for c, _ in calls[:n_calls]) == B, (name, shapes)
+        else:
+            # 2..4 wide classes (plus, at worst, a quiet class's trip through the status protocol)
+            first = [c for c, f in calls if f == flags]
+            assert 2 <= len(calls) <= 8 and sum(c.shape[0] for c in first[:4]) >= B, (name, shapes)
+        if name == "two classes of 40":
+            for c, _ in calls[:2]:                                  # within a call: amplitudes within a factor of 3
+                a = np.abs(c).max(axis=1)
+                assert c.shape[0] == 40 and a.max() <= 3.0 * a.min() * (1 + 1e-5)
         od, oidx = oracle_mod.scan_topk(ds, x, 100, h=20)
         fin = np.isfinite(od).all(axis=1)
         assert fin.sum() >= B - 1
         assert_exact(d[fin], idx[fin], od[fin], oidx[fin], name)
         assert np.array_equal(paths[fin][:, :, 0, :], oracle_mod.gather_paths(rows3(ds), idx[fin], 40))
-    # two clean classes of 40: two calls, each within a factor of 3
-    x = (syn.rolling_queries(80, 20, 2801) * np.repeat(np.array([1.0, 100.0], np.float32), 40)[:, None]).astype(np.float32)
-    n0 = len(seen)
-    d, paths, idx = obj.shadow(x, k=100, cuda=True)
-    calls = seen[n0:]
-    assert len(calls) == 2 and all(f == 0 and c.shape[0] == 40 for c, f in calls)
-    for c, _ in calls:
-        a = np.abs(c).max(axis=1)
-        assert a.max() <= 3.0 * a.min() * (1 + 1e-5) or a.max() / a.min() < 40      # (rolling queries: amplitudes within a class differ by what the path gives)
-    od, oidx = oracle_mod.scan_topk(ds, x, 100, h=20)
-    assert_exact(d, idx, od, oidx, "two classes")
 
 
 def test_resident_copy_follows_edits_of_the_ensemble(hip_device):
