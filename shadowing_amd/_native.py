@@ -552,6 +552,9 @@ class PreparedShadow:
             self.q_dev = self.q_pin
             self._stage_dev = self._stage_pin
         self._hint_ptr = self._stage_dev.data_ptr() + 4 * self._Wp
+        self._stage_np = self._stage_pin.numpy()             # (numpy views: element stores / reads without a torch dispatch)
+        self._q_np = self._stage_np[:W]
+        self._refresh_status_view()
         self.event = torch.cuda.Event()
         ws = workspace.get(workspace_bytes(R, T, 1, W, h, k))
         self._keep = (rows, ds3, ws, workspace)
@@ -564,6 +567,9 @@ class PreparedShadow:
                            self.idx.data_ptr(), self.status.data_ptr(), ws.data_ptr(), ws.numel(), C.byref(self.prof)]
         self._gather_args = [dev.index, None, ds3.data_ptr(), ds3.shape[0], C_, ds3.shape[2], 0, self.idx.data_ptr(), k, W + h,
                              self.paths.data_ptr()]
+
+    def _refresh_status_view(self):
+        self.status_np = self.host[3].numpy()                # the call's status word as the host sees it (after the event)
 
     # results of this size and more are HANDED to the caller instead of copied out of the slot's pinned buffer (host_direct
     # slots): at k = 8192 the four numpy copies were 100 us of a 340 us shadow() call
@@ -579,6 +585,7 @@ class PreparedShadow:
         out = tuple(t.numpy() for t in self.host)
         self._res_host = torch.empty(self._res_host.numel(), dtype=torch.uint8, pin_memory=True)
         self.host = self._carve(self._res_host)
+        self._refresh_status_view()
         if self.host_direct:                                 # the kernels write the pinned buffer themselves: new addresses
             self.host[3].zero_()
             self.d, self.paths, self.idx, self.status = self.host
@@ -589,14 +596,14 @@ class PreparedShadow:
     def launch(self, stream: "torch.cuda.Stream", x_row: torch.Tensor, hint: float | None = None) -> None:
         """x_row: (1, W) float32 CPU tensor.  Everything is enqueued on `stream`, the D2H copies of the results included.
         `hint`: the caller's admission level on acc (psh_profile.tau_hint) -- a status other than OK then means "again without"."""
-        self.q_pin.copy_(x_row)
+        self._q_np[:] = x_row.numpy().reshape(-1) if isinstance(x_row, torch.Tensor) else x_row
         if hint is not None:
-            self._stage_pin[self._Wp] = float(hint)
+            self._stage_np[self._Wp] = hint
         self.prof.tau_hint = self._hint_ptr if hint is not None else None
         sp = stream.cuda_stream
-        with torch.cuda.stream(stream):
-            if not self.host_direct:
-                self._stage_dev.copy_(self._stage_pin, non_blocking=True)
+        if self.host_direct:
+            # nothing here is a torch operation: the kernels read the pinned staging buffer and write the pinned result buffer
+            # themselves -- two library calls and the event, no stream context to enter and leave (5 us of a blocking call)
             a = self._scan_args
             a[1] = sp
             rc = self._scan_fn(*a)
@@ -607,8 +614,21 @@ class PreparedShadow:
             rc = self._gather_fn(*g)
             if rc:
                 _check(rc, "psh_gather_paths")
-            if not self.host_direct:
-                self._res_host.copy_(self._res, non_blocking=True)
+            self.event.record(stream)
+            return
+        with torch.cuda.stream(stream):
+            self._stage_dev.copy_(self._stage_pin, non_blocking=True)
+            a = self._scan_args
+            a[1] = sp
+            rc = self._scan_fn(*a)
+            if rc:
+                _check(rc, "psh_scan_topk")
+            g = self._gather_args
+            g[1] = sp
+            rc = self._gather_fn(*g)
+            if rc:
+                _check(rc, "psh_gather_paths")
+            self._res_host.copy_(self._res, non_blocking=True)
             self.event.record()
 
 

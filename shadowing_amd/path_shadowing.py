@@ -634,12 +634,16 @@ class PathShadowing:
             st = self._sync_slot = (key, _native.PreparedShadow(rows, ds, W, k, h, self._workspace, 0, host_direct=True))
         slot = st[1]
         stream = torch.cuda.current_stream(dev)
-        hint = self._next_hint(x, k, W)
+        xn2 = None
+        if self.hint == "auto":
+            xl = x[0, 0, :].tolist()
+            xn2 = math.fsum(v * v for v in xl)
+        hint = self._next_hint(xn2, k, W)
         slot.launch(stream, x[:, 0, :], hint)
         slot.event.synchronize()
         self.last_path = "hip"
         self.last_hint = None
-        if hint is not None and int(slot.host[3][0]) != _native.PSH_STATUS_OK:
+        if hint is not None and int(slot.status_np[0]) != _native.PSH_STATUS_OK:
             # the hint fell short of k windows (or admitted more than the lists hold): the same call without it; no hints for
             # a while (twice as long after every miss in a row)
             self.last_hint = "short"
@@ -659,7 +663,6 @@ class PathShadowing:
                 self._workspace.arm()
             return None
         if self.hint == "auto":
-            xn2 = float((x[:, 0, :].double() ** 2).sum())
             hstate = self._hint_state if (self._hint_state and self._hint_state["key"] == (k, W, h)) else {"key": (k, W, h), "skip": 0, "fails": 0}
             hstate["dk"] = float(hd[0, k - 1]) if xn2 > 0 else None
             self._hint_state = hstate
@@ -667,7 +670,7 @@ class PathShadowing:
 
     HINT_MARGIN = 1.15          # on acc: the k-th distance may come out 7 % above the previous call's before the hint falls short
 
-    def _next_hint(self, x: torch.Tensor, k: int, W: int):
+    def _next_hint(self, xn2: float | None, k: int, W: int):
         """The admission level this call hands to the library (hint="auto"), or None: (d_k of the previous call x ||x||)^2 x
         HINT_MARGIN -- the RELATIVE k-th distance moves far less from one query date to the next than acc itself."""
         hstate = self._hint_state
@@ -676,7 +679,6 @@ class PathShadowing:
         if hstate["skip"] > 0:
             hstate["skip"] -= 1
             return None
-        xn2 = float((x[:, 0, :].double() ** 2).sum())
         level = hstate["dk"] ** 2 * xn2 * self.HINT_MARGIN
         return level if (level > 0.0 and math.isfinite(level)) else None
 

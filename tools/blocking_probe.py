@@ -30,3 +30,46 @@ t0 = time.perf_counter()
 for q in qs: obj.shadow(q, k=1024, cuda=True)
 T[4] = time.perf_counter() - t0
 print("us per call: arguments %.1f, enqueue %.1f, wait %.1f, copy out %.1f; shadow() itself %.1f" % tuple(1e6 * T / len(qs)))
+
+# ---- the same loop with admission hints (PathShadowing(hint="auto"), psh_profile.tau_hint): ROLLING query dates -- what the
+#      hint is for -- and unrelated queries (where it mostly falls short and backs off), each against the same object without
+def loop(o, queries):
+    for q in queries[:20]:
+        o.shadow(q, k=1024, cuda=True)
+    seen = {"ok": 0, "short": 0, None: 0}
+    t0 = time.perf_counter()
+    for q in queries:
+        o.shadow(q, k=1024, cuda=True)
+        seen[o.last_hint] += 1
+    return 1e6 * (time.perf_counter() - t0) / len(queries), seen
+hinted = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), ds, sa.PredictionContext(horizon=20), hint="auto")
+rolling = list(syn.rolling_queries(300, 20, 7))
+for name, queries in (("rolling dates", rolling), ("unrelated queries", qs)):
+    us_plain, _ = loop(obj, queries)
+    us_hint, seen = loop(hinted, queries)
+    print("%s: shadow() %.1f us per call without hints, %.1f with hint=\"auto\" (hints held %d, fell short %d, calls without one %d)"
+          % (name, us_plain, us_hint, seen["ok"], seen["short"], seen[None]))
+
+# ---- where a hinted call's time goes: the slot API directly, the same query, hint None vs its own k-th acc x 1.1
+q = qs[0]
+x = _torch(_dim_array(q))
+d0, _, _ = obj.shadow(q, k=1024, cuda=True)
+xn2 = float(np.asarray(q, np.float64) @ np.asarray(q, np.float64))
+good = float(d0[0, -1]) ** 2 * xn2 * 1.1
+slot = obj._sync_slot[1]
+for name, hv in (("no hint", None), ("hint", good), ("no hint", None), ("hint", good)):
+    te = tw = 0.0
+    for _ in range(200):
+        t0 = time.perf_counter(); slot.launch(cur, x[:, 0, :], hv); t1 = time.perf_counter(); slot.event.synchronize(); t2 = time.perf_counter()
+        te += t1 - t0; tw += t2 - t1
+    print("%-8s enqueue %.1f us, wait %.1f us, status %d" % (name, 1e6 * te / 200, 1e6 * tw / 200, int(slot.host[3][0])))
+
+# ---- per-call times of the hinted object over the 300 rolling dates
+times = []
+for q in rolling:
+    t0 = time.perf_counter(); hinted.shadow(q, k=1024, cuda=True); t = time.perf_counter() - t0
+    times.append((1e6 * t, hinted.last_hint, hinted.last_path))
+ts = np.array([t for t, _, _ in times])
+print("per call: median %.1f, mean %.1f, p90 %.1f, max %.1f us" % (np.median(ts), ts.mean(), np.percentile(ts, 90), ts.max()))
+for i in np.argsort(-ts)[:12]:
+    print("  call %d: %.0f us, hint %s, path %s" % (i, times[i][0], times[i][1], times[i][2]))
