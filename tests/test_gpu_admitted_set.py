@@ -147,7 +147,7 @@ def check_sets(dev, oracle_mod, ds, q, h, m, flags=0, what="", embedded=None, k=
         a = accs[b][exp[:, 0], exp[:, 1]]
         dref = (np.sqrt(a, dtype=np.float32) / xn).astype(np.float32)
         assert np.array_equal(dbits, dref.view(np.uint32)), f"{what}: query {b}: an admitted window's distance differs from the oracle's"
-        if len(exp) >= k and status[b] == 0:
+        if len(exp) >= k and status[b] == 0 and b < 2:         # (the first two queries: every other test of the suite is about top-k)
             # ... and with at least k windows below the level the call's answer is the exact top-k
             od, oidx = (oracle_mod.scan_topk(ds, q[b:b + 1], k, h=h) if embedded is None
                         else oracle_mod.scan_topk_embedded(ds, ker, hx[b:b + 1], k, h=h))
@@ -196,9 +196,12 @@ def test_batched_scans_admit_exactly_the_windows_below_the_level(hip_device, ora
     and scan_mq_kernel (f16), 34 queries, W = 8..25, levels 10^3 .. 3 x 10^4 deep."""
     from shadowing_amd import _native
     flags = _native.FLAG_MQ_F16 if test == "f16" else 0
+    heavy = kind in ("plain", "spikes", "planted_matches", "scale_down", "quiet_stretches")
     for i, (W, h, m) in enumerate([(20, 20, 1000), (25, 0, 30000), (8, 3, 10000)]):
-        if test == "f16" and i == 1:
-            continue                                      # (GPU minutes: the f16 test is the older, longer-serving one)
+        # (GPU minutes: every kind meets the 8-bit test at W = 20 and W = 25; the third window length and the f16 test -- the
+        #  older, longer-serving one -- on five kinds)
+        if (test == "f16" and (i == 1 or not heavy)) or (i == 2 and not heavy):
+            continue
         ds, q = adversarial(kind, 1024, 2048, 34, W, h, 300 + 3 * i)
         check_sets(hip_device, oracle_mod, ds, q, h, m, flags=flags, what=f"scan_mq {test} {kind} W={W} m={m}", expect_path=0)
 
@@ -235,7 +238,7 @@ def _embed(ker, x):
     return out
 
 
-EMBEDDED_KINDS = ["plain", "spikes", "planted_matches", "scale_down", "scale_up", "quiet_stretches", "loud_rows", "student_t"]
+EMBEDDED_KINDS = ["plain", "spikes", "planted_matches", "scale_down", "quiet_stretches", "loud_rows"]
 
 
 @pytest.mark.parametrize("kind", EMBEDDED_KINDS)
