@@ -690,7 +690,11 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     {
         const bool small_batch = !p.ker && !rows_path && B >= 2 && B <= PSH_STREAM_MAX_Q && !(flags_of(profile) & PSH_FLAG_FILTER_VALU);
         const bool one_overlap = use_mx && B == 1 && (flags_of(profile) & PSH_FLAG_OVERLAP);
-        if ((small_batch || one_overlap) && !rows_path && !stages && !(flags_of(profile) & PSH_FLAG_NO_FUSE) && scan_fused_supported(p.W)) {
+        // ONE query with a long window (34 <= W <= 256): the same three launches, flag or no flag, with the scan's banded product
+        // as a K-loop (stream_scan_long_kernel) -- otherwise such a call has only the vector-ALU filter of scan_kernel
+        const bool one_long = !p.ker && !rows_path && B == 1 && stream_long_supported(p.W) && !(flags_of(profile) & PSH_FLAG_FILTER_VALU);
+        if ((small_batch || one_overlap || one_long) && !rows_path && !stages && !(flags_of(profile) & PSH_FLAG_NO_FUSE) &&
+            (scan_fused_supported(p.W) || one_long)) {
             int ncu = 0;
             HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
             const Tuning tn = tuning();
@@ -700,6 +704,9 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
             // smallest minimum: the k best windows of the ensemble put 2k/2 x fraction = 16 expected minima below their level,
             // P(Poisson(16) >= 40) = 3e-7 that fewer than k windows lie below the estimate (-> PSH_STATUS_RETRY)
             int64_t units_cap = tn.stream_units < 2048 ? tn.stream_units : 2048;     // (the sample kernel keeps a query's minima in registers: <= 2048)
+            // (a long window's exact sample chains cost W / 20 of the benchmark's: half the units -- the level's rank stays at its
+            //  floor of 24 with 8 minima expected below the k-th distance)
+            if (one_long && units_cap > 1024) units_cap = 1024;
             if (units_cap > PSH_FUSED_MAX_UNITS / B) units_cap = PSH_FUSED_MAX_UNITS / B;
             int64_t rows_p = units_cap / nseg;
             if (rows_p > p.R / 4) rows_p = p.R / 4;
@@ -720,7 +727,8 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
             const int tile_fl = (logical + ((logical >> 6) << 2) + 4 + 3) & ~3;
             int tb = 0;
             while ((1ll << tb) < p.Tp) ++tb;
-            if (stream_scan_shmem_bytes_q(tile_fl, B) <= PSH_LDS_BYTES && ((units_p >= 256 && r2p <= units_p / 2) || hint) &&
+            if ((one_long ? stream_scan_long_shmem_bytes(p.W) : stream_scan_shmem_bytes_q(tile_fl, B)) <= PSH_LDS_BYTES &&
+                ((units_p >= 256 && r2p <= units_p / 2) || hint) &&
                 5 * (int64_t)k <= (int64_t)cand_cap && 5 * (int64_t)k * B <= grid_s * front * 2) {
                 Plan plan_s{(int)grid_s, 1, B, tile_fl, 0};
                 ScanArgs fa = make_scan_args(dataset, queries, p, w, plan_s, 0, 1, p.R);
@@ -748,7 +756,8 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
                 if (hint) grid_p = 1;                  // nothing is sampled: one block derives scale, thresholds and the fragment table from the hints
                 if (!(tn.stream_skip & 1)) HIP_TRY(launch_stream_sample(fa, fu, p.aligned, (int)grid_p, tile_floats_for(p.W), s));
                 if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_begin, s));
-                if (!(tn.stream_skip & 4)) HIP_TRY(launch_stream_scan(fa, fu, p.aligned, (int)grid_s, s));
+                if (!(tn.stream_skip & 4)) HIP_TRY(one_long ? launch_stream_scan_long(fa, fu, p.aligned, (int)grid_s, s)
+                                                            : launch_stream_scan(fa, fu, p.aligned, (int)grid_s, s));
                 if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_end, s));
                 // (~2.5 k candidates per query: <= 8 own ones per wave, ONE pass over all of them)
                 if (!(tn.stream_skip & 2)) HIP_TRY(launch_stream_rank(fa, fu, tn.stream_rgrid_per_cu * ncu, s));

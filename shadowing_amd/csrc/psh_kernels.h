@@ -56,6 +56,8 @@ static_assert(sizeof(QueryState) == 48, "QueryState is 48 bytes (the host side m
 // the overlap-friendly three-launch step (psh_stream.hip): what its launches hand to each other.  Kernel boundaries on the
 // caller's stream are the synchronisation; the two counters are device-scope atomics.
 #define PSH_STREAM_MAX_Q 3           // queries one overlap-friendly step serves (their B fragments sit in LDS beside the scan's tiles)
+#define PSH_STREAM_LONG_KS 18        // K-steps of 16 the shifted-query band of a long window takes at most: ceil((256 + 31) / 16)
+static_assert(PSH_STREAM_LONG_KS >= PSH_STREAM_MAX_Q * 4, "bxtab holds the fragment tables of the 2-3 query step as well");
 struct StreamCtl {
     unsigned ticket;                 // sample kernel: blocks that have arrived (the last one derives the levels); left at 0
     unsigned ovf;                    // scan kernel: a block met more candidates than its list holds
@@ -77,7 +79,8 @@ struct FusedHdr {
     unsigned long long cand[PSH_FUSED_MAX_BLOCKS * PSH_FUSED_FRONT * 2];   // {r << 32 | d bits, t}
     // psh_stream.hip: the B fragments of the shifted query the sample kernel prepares for the scan (whose candidates go to
     // `cand` as ONE compact list of {d bits, r, t, -} entries, StreamCtl::ncand of them)
-    unsigned short bxtab[PSH_STREAM_MAX_Q * 4 * 64 * 8];     // [query][K-step][lane][8 halves]: -2 x~ shifted by the lane's column
+    // (one query with a LONG window, 34 <= W <= 256: [K-step][lane][8 halves] for up to PSH_STREAM_LONG_KS steps of the band)
+    unsigned short bxtab[PSH_STREAM_LONG_KS * 64 * 8];       // [query][K-step][lane][8 halves]: -2 x~ shifted by the lane's column
 };
 #define PSH_FUSED_BYTES ((sizeof(psh::FusedHdr) + 255) / 256 * 256)
 
@@ -314,6 +317,9 @@ hipError_t launch_stream_sample(const ScanArgs& a, const FusedArgs& f, bool alig
 hipError_t launch_stream_scan(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, hipStream_t s);
 hipError_t launch_stream_rank(const ScanArgs& a, const FusedArgs& f, int grid, hipStream_t s);
 size_t stream_scan_shmem_bytes_q(int tile_floats, int nq);
+bool stream_long_supported(int W);              // one query, 34 <= W <= 256: the scan of the step as a K-loop over the band (stream_scan_long_kernel)
+size_t stream_scan_long_shmem_bytes(int W);
+hipError_t launch_stream_scan_long(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, hipStream_t s);
 hipError_t launch_embed_rows(const float* dataset, int64_t R, int64_t T, const float* ker, int d, int K, float* out, hipStream_t s);
 // psh_predict.hip: the reductions of predict_from_paths() on the device
 struct MomentsArgs {

@@ -71,7 +71,9 @@ __device__ inline bool stream_threshold(const_f32p xq, int W, float tau0, float 
     double nxs = 0.0;
 #pragma unroll 1
     for (int j = 0; j < W; ++j) { const double vv = (double)xq[j] * (double)sc; nxs += vv * vv; }
-    const double am = 1.0 / 512.0, bm = 1.0 / 262144.0;
+    // (b: the absolute part of the bound -- f16 subnormals, one unit of 2^-24 per product -- grows with the taps: 2^-18 covers the
+    //  2 W + 1 = 41 .. 67 terms of W <= 33; a long window takes (2 W + 2) / 64 of it)
+    const double am = 1.0 / 512.0, bm = (1.0 / 262144.0) * (W > 31 ? (double)(2 * W + 2) / 64.0 : 1.0);
     const double taus = (double)tau0 * (double)sc * (double)sc;
     const double T = taus * (1.0 + 1.0 / 131072.0) * (1.0 + 2.0 * am) - nxs * (1.0 - 3.0 * am) * (1.0 - 1e-12) + bm;
     float Tf = (float)T;
@@ -80,6 +82,9 @@ __device__ inline bool stream_threshold(const_f32p xq, int W, float tau0, float 
     *thr_out = Tf;
     return true;
 }
+// K-steps of 16 the banded product of a window of W samples takes: the band of column n (the query shifted down by n, n < 32)
+// ends at tap W + 30 -- four steps up to W = 33 (the kernels with the band in registers), ceil((W + 31) / 16) beyond
+__host__ __device__ inline int stream_ksteps(int W) { return W <= 33 ? 4 : (W + 31 + 15) / 16; }
 
 // NWP waves per block: 1 when the launch has to fit beside another step's scan blocks (one query, PSH_FLAG_OVERLAP); 4 for the
 // two- and three-query step, whose last block then works on its queries side by side (a wave per query: the tail of the
@@ -280,8 +285,9 @@ void stream_sample_kernel(ScanArgs a, FusedArgs f) {
         // the scan's B fragments of the shifted query (column n of K-step s holds -2 x~[16 s + 8 hk + i - n]): prepared ONCE
         // here, a 4 KB table every scan block fetches with four 16-byte loads per lane instead of 32 scattered ones
         const int n = lane & 31, hk = lane >> 5;
+        const int nks = stream_ksteps(W);                    // (more than four: one query with a long window, stream_scan_long_kernel)
 #pragma unroll 1
-        for (int s = 0; s < 4; ++s) {                        // (once per launch: compact code, not speed)
+        for (int s = 0; s < nks; ++s) {                      // (once per launch: compact code, not speed)
             f16x8 b;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -521,6 +527,186 @@ __device__ __forceinline__ void stream_scan_body(const ScanArgs& a, const FusedA
     stamp(3);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// S for ONE query with a LONG window (34 <= W <= 256; the reference takes any Identity(dimension): path_embedding.py:135-139,
+// the tutorial's context is 126 samples).  The same rejection test -- t^ = sum y~^2 - 2 sum x~ y~ on f16 copies, same bound,
+// same exact recheck -- with the band split over ceil((W + 31) / 16) K-steps that accumulate into the one 32 x 32 tile of a row
+// group: 2 MFMAs per K-step (energies: the band of ones; correlation: the shifted query) instead of 8 per segment.  What changes
+// around it: the shifted-query fragments and the boundary fragments of the band of ones are block-shared tables in LDS (18
+// steps do not fit registers; the INTERIOR steps of the ones band are one constant register set), and there is no fp32 tile --
+// the f16 arrays grow with W and the tables take its place -- so a survivor's exact chain reads its window from memory (the
+// segment was streamed a microsecond ago: L2 / MALL).  Candidates, status protocol and the launches around it (sample + levels,
+// ranking) are stream_scan_kernel's.
+__host__ __device__ inline int stream_long_nhalf(int W) { return ((992 + 16 * stream_ksteps(W) + 127) / 128) * 128; }
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(ScanArgs a, FusedArgs f) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NW = PSH_SCAN_THREADS / 64;
+    constexpr int NFL = PSH_STREAM_FL(1);
+    const int lane = lane_id();
+    const int tid = (int)threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int W = a.W;
+    const int nks = stream_ksteps(W), nhalf = stream_long_nhalf(W);
+    int* ctl = reinterpret_cast<int*>(smem);                                 // 64 control words
+    u32x4* fl = reinterpret_cast<u32x4*>(ctl + 64);                           // NFL entries {acc bits, r, t, query}
+    _Float16* bxl = reinterpret_cast<_Float16*>(fl + NFL);                    // [K-step][lane][8]: -2 x~ shifted by the lane's column
+    _Float16* bol = bxl + (size_t)nks * 64 * 8;                               // [K-step][lane][8]: the band of ones
+    _Float16* ah0 = bol + (size_t)nks * 64 * 8;
+    _Float16* a1 = ah0 + (size_t)wave * 2 * nhalf;                            // y^
+    _Float16* a2 = a1 + nhalf;                                                // (y~^2)^
+    FusedHdr* hdr = f.hdr;
+    const StreamCtl* sc = &hdr->stream;
+
+    const int nfloat = PSH_SEG + W - 1;
+    const unsigned n_rs = (unsigned)a.n_rows * (unsigned)a.nseg;
+    const unsigned u_lo = (unsigned)(((u64)n_rs * blockIdx.x) / gridDim.x);
+    const unsigned u_hi = (unsigned)(((u64)n_rs * (blockIdx.x + 1u)) / gridDim.x);
+    auto decode = [&](unsigned uu, unsigned& ri, unsigned& sg) {
+        ri = fast_div(uu, a.magic_nseg, (unsigned)a.nseg);
+        sg = uu - ri * (unsigned)a.nseg;
+    };
+    auto load_unit = [&](Stage& sx, unsigned uu) {
+        unsigned ri, sg;
+        decode(uu, ri, sg);
+        stage_load<ALIGNED>(sx, a.dataset + (a.row0 + (int64_t)ri * a.row_stride) * a.T, a.T, (int)sg * PSH_SEG, nfloat, lane);
+    };
+    Stage st;
+    unsigned u = u_lo + (unsigned)wave;
+    if (u < u_hi) load_unit(st, u);
+    // the tables: the sample kernel's fragments of the shifted query (plain loads: an earlier launch on this stream), the band of
+    // ones by arithmetic
+    for (int i = tid; i < nks * 64; i += PSH_SCAN_THREADS) {
+        *reinterpret_cast<f16x8*>(bxl + (size_t)i * 8) = *reinterpret_cast<const f16x8*>(hdr->bxtab + (size_t)i * 8);
+        const int s = i >> 6, l = i & 63, n = l & 31, hk = l >> 5;
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int j = 16 * s + 8 * hk + e - n;
+            o[e] = (_Float16)((j >= 0 && j < W) ? 1.0f : 0.0f);
+        }
+        *reinterpret_cast<f16x8*>(bol + (size_t)i * 8) = o;
+    }
+    const unsigned armed_w = sc->armed;
+    const float scale = __uint_as_float(sc->scale_bits);
+    const float tau2 = __uint_as_float(sc->tau2_bits[0]), thr2 = __uint_as_float(sc->thr2_bits[0]), xn = __uint_as_float(sc->xn_bits[0]);
+    if (tid == 0) { ctl[S_FRONT] = 0; ctl[S_NEXT] = NW; }
+    {   // every slot of the f16 arrays a segment does not write must be finite (0 * NaN poisons a row)
+        unsigned* z = reinterpret_cast<unsigned*>(a1);
+        for (int i = lane; i < nhalf; i += 64) z[i] = 0u;                     // 2 arrays x nhalf halves = nhalf dwords
+    }
+    __syncthreads();
+    if (armed_w == 0u) return;                                                // uniform: the ranking reports PSH_STATUS_RETRY
+    // K-steps whose band of ones is all ones in every lane: column n <= 31 starts its band at tap n, so from step 2 on; it ends
+    // at tap n + W - 1 >= W - 1, so up to the step that ends at tap W - 1 at the latest: 16 s + 15 <= W - 1
+    const int ones_lo = 2, ones_hi = (W - 16) / 16;                           // interior steps: ones_lo <= s <= ones_hi
+    f16x8 ones8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones8[e] = (_Float16)1.0f;
+    const const_f32p x = (const_f32p)a.queries;
+    auto grab = [&]() -> unsigned {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(&ctl[S_NEXT], 1);
+        return u_lo + (unsigned)__builtin_amdgcn_readfirstlane(v);
+    };
+    while (u < u_hi) {
+        unsigned ri, sg;
+        decode(u, ri, sg);
+        const int64_t row = a.row0 + (int64_t)ri * a.row_stride;
+        const int seg_start = (int)sg * PSH_SEG;
+        const int r_global = (int)(row + a.r_offset);
+        {
+            const int nq4 = (nfloat + 3) >> 2;
+#pragma unroll
+            for (int q = 0; q < PSH_NSTAGE; ++q) {
+                const int m = lane + 64 * q;
+                if (q < PSH_NSTAGE - 1 || m < nq4) {
+                    const f32x4 v = st.v[q] * scale;
+                    const f32x4 v2 = v * v;
+                    *reinterpret_cast<f16x4*>(a1 + mx_half(4 * m)) = __builtin_convertvector(v, f16x4);
+                    *reinterpret_cast<f16x4*>(a2 + mx_half(4 * m)) = __builtin_convertvector(v2, f16x4);
+                }
+            }
+        }
+        wave_lds_fence();
+        const unsigned un = grab();
+        if (un < u_hi) load_unit(st, un);
+
+        const int m = lane & 31, hk = lane >> 5;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll 2
+        for (int s = 0; s < nks; ++s) {
+            const int ai = mx_half(32 * m + 16 * s + 8 * hk);
+            const f16x8 e2 = *reinterpret_cast<const f16x8*>(a2 + ai);
+            const f16x8 e1 = *reinterpret_cast<const f16x8*>(a1 + ai);
+            const f16x8 bx = *reinterpret_cast<const f16x8*>(bxl + ((size_t)s * 64 + lane) * 8);
+            f16x8 bo = ones8;
+            if (s < ones_lo || s > ones_hi) bo = *reinterpret_cast<const f16x8*>(bol + ((size_t)s * 64 + lane) * 8);   // (uniform)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e2, bo, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, bx, acc, 0, 0, 0);
+        }
+        bool keep = false;                                                    // NaN-safe: !(t^ > thr)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) keep = keep || !(acc[r] > thr2);
+        if (__any(keep)) {
+            // the survivors: exact chain from memory (the reference's order: D = fl(x_j - y_j), acc = fma(D, D, acc)), admitted
+            // below the level
+            const float* yseg = a.dataset + row * a.T + seg_start;
+            unsigned hm = 0u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hm |= !(acc[r] > thr2) ? (1u << r) : 0u;
+#pragma unroll 1
+            for (int r = 0; r < 16; ++r) {
+                const int p = 32 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + m;     // C layout: row -> window
+                bool hit = (((hm >> r) & 1u) != 0u) && (seg_start + p < a.Tp);
+                if (!__ballot(hit)) continue;
+                float v = 0.0f;
+                if (hit) {
+                    const float* y = yseg + p;
+#pragma unroll 4
+                    for (int j = 0; j < W; ++j) { const float D = __fsub_rn(x[j], y[j]); v = __builtin_fmaf(D, D, v); }
+                }
+                hit = hit && (v < tau2);
+                const unsigned long long mask = __ballot(hit);
+                if (!mask) continue;
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&ctl[S_FRONT], __popcll(mask));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (hit) {
+                    const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    if (slot < NFL) fl[slot] = u32x4{__float_as_uint(v), (unsigned)r_global, (unsigned)(seg_start + p), 0u};
+                }
+            }
+        }
+        wave_lds_fence();  // all lanes done with the arrays before they are overwritten
+        u = un;
+    }
+    __syncthreads();
+    if (wave == 0) {                                                          // (stream_scan_body's publication, one query)
+        const int nfront = ctl[S_FRONT];
+        const int mown = nfront < NFL ? nfront : NFL;
+        const bool have = lane < mown;
+        const unsigned long long mask = __ballot(have);
+        if (mask) {
+            unsigned base = 0u;
+            if (lane == 0) base = __hip_atomic_fetch_add((gu32*)&hdr->stream.ncand[0], (unsigned)__popcll(mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            if (have) {
+                const unsigned slot = base + (unsigned)lane;
+                if (slot < (unsigned)f.cand_cap) {
+                    u32x4 o = fl[lane];
+                    o[0] = __float_as_uint(dist_from_acc(__uint_as_float(o[0]), xn));
+                    reinterpret_cast<u32x4*>(hdr->cand)[slot] = o;
+                }
+            }
+        }
+        if (lane == 0 && nfront > NFL) __hip_atomic_store((gu32*)&hdr->stream.ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // one query: 112 registers (56 arch + 56 acc of the unified file), so that a sample or ranking wave of another stream's step fits
 // beside four of these on a SIMD; two or three queries: the whole file (their steps are rarely run beside others)
 template <int WT, bool ALIGNED>
@@ -627,6 +813,11 @@ size_t stream_scan_shmem_bytes_q(int tile_floats, int nq) {
            + (nq > 1 ? (size_t)nq * 4 * 64 * 8 * sizeof(_Float16) : 0);
 }
 size_t stream_scan_shmem_bytes(int tile_floats) { return stream_scan_shmem_bytes_q(tile_floats, 1); }
+bool stream_long_supported(int W) { return W >= 34 && W <= 256; }
+size_t stream_scan_long_shmem_bytes(int W) {
+    return (size_t)PSH_STREAM_FIXED_BYTES + (size_t)PSH_FUSED_FRONT * 16 + (size_t)2 * stream_ksteps(W) * 64 * 8 * sizeof(_Float16)
+           + (size_t)(PSH_SCAN_THREADS / 64) * 2 * stream_long_nhalf(W) * sizeof(_Float16);
+}
 size_t stream_sample_shmem_bytes(int tile_floats) {
     const size_t t = (size_t)tile_floats * sizeof(float), h = (size_t)PSH_STREAM_HIST * sizeof(unsigned);
     return t > h ? t : h;
@@ -677,6 +868,12 @@ hipError_t launch_stream_scan(const ScanArgs& a, const FusedArgs& f, bool aligne
                        : launch_k(stream_scan_kernel<20, false>, dim3(grid), PSH_SCAN_THREADS, shmem, s, a, f);
     return aligned ? launch_k(stream_scan_kernel<0, true>, dim3(grid), PSH_SCAN_THREADS, shmem, s, a, f)
                    : launch_k(stream_scan_kernel<0, false>, dim3(grid), PSH_SCAN_THREADS, shmem, s, a, f);
+}
+
+hipError_t launch_stream_scan_long(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, hipStream_t s) {
+    const size_t shmem = stream_scan_long_shmem_bytes(a.W);
+    return aligned ? launch_k(stream_scan_long_kernel<true>, dim3(grid), PSH_SCAN_THREADS, shmem, s, a, f)
+                   : launch_k(stream_scan_long_kernel<false>, dim3(grid), PSH_SCAN_THREADS, shmem, s, a, f);
 }
 
 hipError_t launch_stream_rank(const ScanArgs& a, const FusedArgs& f, int grid, hipStream_t s) {

@@ -363,8 +363,9 @@ def test_batched_scan_with_more_survivors_than_the_queue_holds(hip_device, oracl
 
 @pytest.mark.parametrize("W,B", [(1, 1), (8, 1), (17, 1), (24, 1), (33, 1), (34, 1), (8, 3), (24, 5), (25, 6), (26, 2)])
 def test_matrix_core_kernels_at_run_time_window_lengths(hip_device, oracle_mod, W, B):
-    """W <= 33 (one query) and W <= 25 (batches) take the matrix-core kernels compiled for a run-time W;
-    W = 34 / (26, batch) are the first lengths that fall back to the VALU test."""
+    """W <= 33 (one query) and W <= 25 (batches) take the matrix-core kernels compiled for a run-time W; with per-stage
+    profiling (the separate launches) W = 34 / (26, batch) are the first lengths on the VALU test -- one query with a longer
+    window otherwise runs stream_scan_long_kernel (test_long_identity_windows_on_the_matrix_cores)."""
     R, T, h, k = 5000, 1100, 7, 200
     ds = syn.dataset(R, T, 1200 + W)
     q = syn.gbm_log_returns((B, W), 1300 + W)
@@ -372,6 +373,55 @@ def test_matrix_core_kernels_at_run_time_window_lengths(hip_device, oracle_mod, 
     assert prof["path"] == 0 and not status.any()
     od, oidx = oracle_mod.scan_topk(ds, q, k, h=h)
     assert_exact(d, idx, od, oidx, f"W={W} B={B}")
+
+
+@pytest.mark.parametrize("W,R,T,h,k", [(34, 4096, 2048, 7, 200), (50, 4096, 2048, 0, 300), (64, 8192, 2048, 20, 1024), (126, 4096, 2048, 20, 256),
+                                       (126, 3000, 2051, 60, 300), (252, 4096, 2048, 20, 200), (256, 2048, 3000, 0, 100), (100, 6000, 1500, 11, 64)])
+def test_long_identity_windows_on_the_matrix_cores(hip_device, oracle_mod, W, R, T, h, k):
+    """One query with a window of 34 .. 256 samples (the reference takes any Identity(dimension), path_embedding.py:135-139; the
+    tutorial's context is 126): the overlap-friendly launches with the scan's banded product as a K-loop over ceil((W + 31) / 16)
+    steps (stream_scan_long_kernel) -- path 3 with or without PSH_FLAG_OVERLAP, status protocol as for short windows, results
+    bit for bit the oracle's.  (Rounds 1-4 had only the vector-ALU filter for these lengths.)"""
+    from shadowing_amd import _native
+    ds = syn.dataset(R, T, 1600 + W)
+    q = syn.gbm_log_returns((1, W), 1700 + W)
+    ds_t = torch.as_tensor(np.ascontiguousarray(ds[:, 0, :])).to(hip_device)
+    q_t = torch.as_tensor(q).to(hip_device)
+    od, oidx = oracle_mod.scan_topk(ds, q, k, h=h)
+    for flags in (0, _native.FLAG_OVERLAP):
+        info = {}
+        ws = _native.Workspace(hip_device)
+        d, idx, st = _native.scan_topk(ds_t, q_t, k, h=h, workspace=ws, flags=flags, info=info)
+        torch.cuda.synchronize()
+        assert info["path"] == 3, info
+        assert int(st[0]) == 0, f"W={W}: status {int(st[0])}"
+        assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, f"long window W={W} flags={flags}")
+    # the checked call (what PathShadowing uses) and the vector-ALU filter on the same inputs
+    d, idx = _native.scan_topk_checked(ds_t, q_t, k, h=h)
+    assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, f"long window W={W} checked")
+    d, idx = _native.scan_topk_checked(ds_t, q_t, k, h=h, flags=_native.FLAG_FILTER_VALU)
+    assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, f"long window W={W} VALU filter")
+
+
+def test_long_window_shadow_with_paths_and_adversarial_data(hip_device, oracle_mod):
+    """shadow(cuda=True) with Identity(126) (paths included), and the long-window scan on spikes / planted matches / a quiet
+    ensemble through the status protocol."""
+    import shadowing_amd as sa
+    from _adversarial import make
+    W, h = 126, 60
+    ds = syn.dataset(4096, 2048, 1800)
+    obj = sa.PathShadowing(sa.Identity(W), sa.RelativeMSE(), torch.as_tensor(ds), sa.PredictionContext(horizon=h))
+    q = syn.gbm_log_returns((W,), 1801)
+    d, paths, idx = obj.shadow(q, k=300, cuda=True)
+    od, opaths, oidx = oracle_mod.shadow(ds, q[None, :], 300, h)
+    assert_exact(d, idx, od, oidx, "Identity(126) shadow")
+    assert np.array_equal(paths, opaths) and obj.last_path == "hip"
+    from shadowing_amd import _native
+    for kind in ("spikes", "planted_matches", "scale_down", "quiet_stretches", "zero_constant_rows", "huge_queries"):
+        dsa, qa = make(kind, 2048, 2048, 1, 64, 5, 1900)
+        d, idx = _native.scan_topk_checked(torch.as_tensor(dsa).to(hip_device), torch.as_tensor(qa).to(hip_device), 200, h=5)
+        od, oidx = oracle_mod.scan_topk(dsa, qa, 200, h=5)
+        assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, f"long window, {kind}")
 
 
 def test_unsorted_flag_returns_the_same_set(hip_device, oracle_mod):
