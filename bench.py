@@ -646,7 +646,10 @@ def main():
         one_ms = one[0].elapsed_time(one[1])
     fused = info.get("path") == 2
     overlap_mode = info.get("path") == 3
-    kernel_name = ("psh::stream_scan_kernel<%s,true> (the scan of the three overlap-friendly launches: f16 matrix-core rejection "
+    kernel_name = ("psh::stream_scan_long_kernel<true> (the scan of the three overlap-friendly launches for a LONG window: the f16 "
+                   "banded product as a K-loop over %d steps of 16 taps, 2 MFMAs each, + exact fp32 recheck from memory)" % ((W + 31 + 15) // 16)
+                   if (overlap_mode and W > 33) else
+                   "psh::stream_scan_kernel<%s,true> (the scan of the three overlap-friendly launches: f16 matrix-core rejection "
                    "test + exact fp32 recheck over the whole ensemble, no barrier; psh::stream_sample_kernel before it and "
                    "psh::stream_rank_kernel behind it run beside the scans of the other streams)" % wt if overlap_mode else
                    "psh::scan_fused_kernel<%s,true> (the WHOLE step in one launch: bootstrap, threshold, f16 matrix-core "
