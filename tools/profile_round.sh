@@ -83,3 +83,14 @@ bash tools/mq_clock.sh > $OUT/mq_clock.txt 2>&1
 PSH_MQ_I8=0 bash tools/mq_clock.sh >> $OUT/mq_clock.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 -o /tmp/ubl tools/ubench_lds_unaligned.hip 2>/dev/null && /tmp/ubl > $OUT/ubench_lds_unaligned.txt 2>&1
 tail -c 600 $OUT/pmc_summary.txt; head -8 $OUT/kernel_stats.csv; cat $OUT/bench_n1.json
+# round 5: long Identity windows on the matrix cores (stream_scan_long_kernel) beside the vector-ALU filter they replaced, the
+# blocking shadow() with and without admission hints, matrix-core cover of vector work (why configs[2] is where it is)
+cd $R
+for W in 64 126 252; do timeout 300 python bench.py --W $W --steps 300 --warmup 20 --no-cpu-baseline > $OUT/bench_n1_W$W.json 2>> $OUT/bench.err; done
+timeout 300 python bench.py --W 126 --steps 100 --warmup 10 --no-cpu-baseline --filter valu > $OUT/bench_n1_W126_valu_filter.json 2>> $OUT/bench.err
+timeout 300 python tools/blocking_probe.py 2>> $OUT/bench.err | grep -v amdgpu.ids > $OUT/blocking_probe.txt
+hipcc --offload-arch=gfx950 -O3 -o /tmp/ucover tools/ubench_mfma_cover2.hip 2>/dev/null && /tmp/ucover > $OUT/ubench_mfma_cover.txt 2>&1
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_W126 -o w -- python $R/bench.py --W 126 --steps 200 --warmup 20 --no-cpu-baseline --no-parity > $OUT/bench_prof_W126.log 2>&1
+for f in $(find $OUT/prof_W126 -name "*kernel_stats.csv"); do grep "Name\|psh::" $f > $OUT/W126_kernel_stats.csv; done
+cd $R
