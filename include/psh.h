@@ -209,7 +209,15 @@ int psh_query_norm(int device, void* stream, const float* queries, int B, int W,
  *                        of k, when a block's candidate list overflows, or on a workspace psh_workspace_init never armed:
  *                        results of EVERY query of the call are INVALID (stale) -> the same call with PSH_FLAG_NO_FUSE
  *                        (the separate launches: a provable bound, per-query OVERFLOW as above).
+ *   A call with psh_profile.tau_hint whose status is not OK for some query: the hint fell short (or was useless) -> the
+ *                        same call WITHOUT the hint, then as above.
  * shadowing_amd/_native.py: scan_topk_checked is this protocol in 20 lines.
+ *
+ * WINDOW LENGTHS.  The rejection test of a scan runs on the matrix cores for ONE query with W <= 256 (W <= 33: the fused
+ * launch / the three overlap-friendly launches with the shifted-query band in registers; 34 <= W <= 256: the three launches
+ * with the band as a K-loop over ceil((W + 31) / 16) steps, flag or no flag -- stream_scan_long_kernel), for two or three
+ * queries with W <= 33, and for larger batches with W <= 25; every other shape uses the vector-ALU filter (17 <= W <= 32) or
+ * the exact chains.  Results do not depend on which.
  */
 int psh_scan_topk(int device, void* stream,
                   const float* dataset, int64_t R, int64_t T, int64_t r_offset,
