@@ -37,18 +37,20 @@ def loop(o, queries):
     for q in queries[:20]:
         o.shadow(q, k=1024, cuda=True)
     seen = {"ok": 0, "short": 0, None: 0}
-    t0 = time.perf_counter()
+    ts = []
     for q in queries:
+        t0 = time.perf_counter()
         o.shadow(q, k=1024, cuda=True)
+        ts.append(1e6 * (time.perf_counter() - t0))
         seen[o.last_hint] += 1
-    return 1e6 * (time.perf_counter() - t0) / len(queries), seen
+    return (float(np.median(ts)), float(np.mean(ts))), seen
 hinted = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), ds, sa.PredictionContext(horizon=20), hint="auto")
 rolling = list(syn.rolling_queries(300, 20, 7))
 for name, queries in (("rolling dates", rolling), ("unrelated queries", qs)):
     us_plain, _ = loop(obj, queries)
     us_hint, seen = loop(hinted, queries)
-    print("%s: shadow() %.1f us per call without hints, %.1f with hint=\"auto\" (hints held %d, fell short %d, calls without one %d)"
-          % (name, us_plain, us_hint, seen["ok"], seen["short"], seen[None]))
+    print("%s: shadow() median %.1f / mean %.1f us per call without hints, median %.1f / mean %.1f with hint=\"auto\" (hints held %d, fell short %d, calls without one %d)"
+          % (name, us_plain[0], us_plain[1], us_hint[0], us_hint[1], seen["ok"], seen["short"], seen[None]))
 
 # ---- where a hinted call's time goes: the slot API directly, the same query, hint None vs its own k-th acc x 1.1
 q = qs[0]
