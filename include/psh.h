@@ -207,7 +207,8 @@ int psh_query_norm(int device, void* stream, const float* queries, int B, int W,
  *                        the three overlap-friendly launches for one query under PSH_FLAG_OVERLAP and for EVERY call with
  *                        B = 2 or 3, flag or no flag -- admit below a statistical estimate and give up when it falls short
  *                        of k, when a block's candidate list overflows, or on a workspace psh_workspace_init never armed:
- *                        results of EVERY query of the call are INVALID (stale) -> the same call with PSH_FLAG_NO_FUSE
+ *                        results of EVERY query of the call are INVALID -- since version 2 the launches overwrite them with NaN
+ *                        distances and (-1, -1) indices instead of leaving an earlier call's numbers -> the same call with PSH_FLAG_NO_FUSE
  *                        (the separate launches: a provable bound, per-query OVERFLOW as above).
  *   A call with psh_profile.tau_hint whose status is not OK for some query: the hint fell short (or was useless) -> the
  *                        same call WITHOUT the hint, then as above.

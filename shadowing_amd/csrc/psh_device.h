@@ -447,6 +447,16 @@ __device__ __forceinline__ int mx_half(int idx) {
     return (((slot & ~15) | ((slot + (slot >> 4)) & 15)) << 3) | (idx & 7);
 }
 
+// A call that reports PSH_STATUS_RETRY leaves NO plausible numbers behind: NaN distances and (-1, -1) indices instead of an
+// earlier call's results (the protocol says "invalid"; a caller that forgot to look at the status sees it at once).
+__device__ __forceinline__ void poison_results(float* out_d, int32_t* out_idx, int k, int tid, int nthreads) {
+    for (int i = tid; i < k; i += nthreads) {
+        out_d[i] = __uint_as_float(0x7fc00000u);
+        out_idx[2 * i + 0] = -1;
+        out_idx[2 * i + 1] = -1;
+    }
+}
+
 // ---- deferred candidate append -----------------------------------------------------
 // vmcnt retires in order: a global store issued by the (rare) admission path would be
 // YOUNGER than the prefetch of the next segment, so anything that later waits for that

@@ -151,6 +151,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_fused_kernel(ScanArgs a
     __syncthreads();
     if (!ctl[C_MAGIC_OK]) {            // a workspace psh_workspace_init never saw (or a run that gave up): separate launches
         if (blockIdx.x == 0 && tid == 0) f.status[0] = PSH_STATUS_RETRY_;
+        if (blockIdx.x == 0) poison_results(f.out_d, f.out_idx, a.k, tid, PSH_SCAN_THREADS);
         return;
     }
     const unsigned epoch = (unsigned)ctl[C_EPOCH];
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_fused_kernel(ScanArgs a
                 f.status[0] = PSH_STATUS_RETRY_;
                 if (blockIdx.x == 0) g_store(reinterpret_cast<u64*>(&hdr->epoch), (u64)(epoch + 1u));
             }
+            if (blockIdx.x == 0) poison_results(f.out_d, f.out_idx, a.k, tid, PSH_SCAN_THREADS);
             return;
         }
     } else {
@@ -333,6 +335,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_fused_kernel(ScanArgs a
                 if (ctl[C_BAIL]) g_store(&hdr->magic, 0ull);
                 else if (blockIdx.x == 0) g_store(reinterpret_cast<u64*>(&hdr->epoch), (u64)(epoch + 1u));
             }
+            if (blockIdx.x == 0) poison_results(f.out_d, f.out_idx, a.k, tid, PSH_SCAN_THREADS);
             return;
         }
         kmin = (unsigned)ctl[C_KMIN];
@@ -380,6 +383,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_fused_kernel(ScanArgs a
                 f.status[0] = PSH_STATUS_RETRY_;
                 if (blockIdx.x == 0) g_store(reinterpret_cast<u64*>(&hdr->epoch), (u64)(epoch + 1u));
             }
+            if (blockIdx.x == 0) poison_results(f.out_d, f.out_idx, a.k, tid, PSH_SCAN_THREADS);
             return;
         }
     }
@@ -569,6 +573,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_fused_kernel(ScanArgs a
     stamp(6);
     if (ctl[C_BAIL] != 0) {
         if (tid == 0) { f.status[0] = PSH_STATUS_RETRY_; g_store(&hdr->magic, 0ull); }
+        if (blockIdx.x == 0) poison_results(f.out_d, f.out_idx, a.k, tid, PSH_SCAN_THREADS);
         return;
     }
     const int ntotal = ctl[C_NTOTAL];
@@ -671,6 +676,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_fused_kernel(ScanArgs a
         }
     }
     stamp(7);
+    if (blockIdx.x == 0 && !good) poison_results(f.out_d, f.out_idx, a.k, tid, PSH_SCAN_THREADS);   // (`good` is the same in every block: none wrote a rank)
     if (blockIdx.x == 0 && tid == 0) {
         // RETRY is sticky: a block that gave up at the second barrier (its deadline passed while THIS block, dispatched
         // late, had not published yet) wrote RETRY, returned without its out[rank] rows and disarmed the header BEFORE

@@ -743,7 +743,10 @@ void stream_rank_kernel(ScanArgs a, FusedArgs f) {
             a.qstate[q] = qs;
         }
     }
-    if (!good) return;
+    if (!good) {                                             // (uniform over the launch: no block writes a rank then)
+        if (blockIdx.x == 0) poison_results(f.out_d + (size_t)q * f.k_out, f.out_idx + (size_t)q * f.k_out * 2, a.k, lane, 64);
+        return;
+    }
     const u32x4v* cand = reinterpret_cast<const u32x4v*>(hdr->cand) + (size_t)q * f.cand_cap;
     float* out_d = f.out_d + (size_t)q * f.k_out;
     int32_t* out_idx = f.out_idx + (size_t)q * f.k_out * 2;

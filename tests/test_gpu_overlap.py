@@ -335,6 +335,20 @@ def test_plain_small_batch_call_reports_retry_and_the_protocol_recovers(hip_devi
         stat = st.cpu().numpy()
         if name == "constant rows":
             assert (stat == _native.PSH_STATUS_RETRY).all(), f"{name}: status {stat}"
+            # a call that says RETRY leaves no plausible numbers behind (ABI version 2): NaN distances, (-1, -1) indices
+            assert np.isnan(rd.cpu().numpy()).all() and (ri.cpu().numpy() == -1).all()
+            # ... and so does the fused single launch (one query of the same ensemble), through results a good call left there
+            good_ds = torch.as_tensor(np.ascontiguousarray(ds[:, 0, :512])).to(hip_device)
+            o_d = torch.empty((1, k), dtype=torch.float32, device=hip_device); o_i = torch.empty((1, k, 2), dtype=torch.int32, device=hip_device)
+            ws1 = _native.Workspace(hip_device)
+            _, _, st1 = _native.scan_topk(good_ds, q_t[:1].contiguous(), k, h=h, workspace=ws1, out=(o_d, o_i))
+            torch.cuda.synchronize()
+            assert int(st1[0]) == 0 and torch.isfinite(o_d).all()
+            inf1 = {}
+            _, _, st1 = _native.scan_topk(ds_t, q_t[:1].contiguous(), k, h=h, workspace=ws1, out=(o_d, o_i), info=inf1)
+            torch.cuda.synchronize()
+            assert inf1["path"] == 2 and int(st1[0]) == _native.PSH_STATUS_RETRY
+            assert torch.isnan(o_d).all() and bool((o_i == -1).all())
         else:
             assert (stat == _native.PSH_STATUS_RETRY).all() or (stat == _native.PSH_STATUS_OK).all(), f"{name}: status {stat}"
             if (stat == _native.PSH_STATUS_OK).all():
