@@ -534,8 +534,8 @@ __device__ __forceinline__ void stream_scan_body(const ScanArgs& a, const FusedA
 // group: 2 MFMAs per K-step (energies: the band of ones; correlation: the shifted query) instead of 8 per segment.  What changes
 // around it: the shifted-query fragments and the boundary fragments of the band of ones are block-shared tables in LDS (18
 // steps do not fit registers; the INTERIOR steps of the ones band are one constant register set), and there is no fp32 tile --
-// the f16 arrays grow with W and the tables take its place -- so a survivor's exact chain reads its window from memory (the
-// segment was streamed a microsecond ago: L2 / MALL).  Candidates, status protocol and the launches around it (sample + levels,
+// the f16 arrays grow with W and the tables take its place -- so a segment that holds survivors fetches its fp32 values again (one
+// coalesced round trip: the segment was streamed a microsecond ago, L2 / MALL) into the f16 arrays' LDS for the exact chains.  Candidates, status protocol and the launches around it (sample + levels,
 // ranking) are stream_scan_kernel's.
 __host__ __device__ inline int stream_long_nhalf(int W) { return ((992 + 16 * stream_ksteps(W) + 127) / 128) * 128; }
 
@@ -652,9 +652,19 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
 #pragma unroll
         for (int r = 0; r < 16; ++r) keep = keep || !(acc[r] > thr2);
         if (__any(keep)) {
-            // the survivors: exact chain from memory (the reference's order: D = fl(x_j - y_j), acc = fma(D, D, acc)), admitted
-            // below the level
-            const float* yseg = a.dataset + row * a.T + seg_start;
+            // the survivors (about one segment in four holds any): the segment's fp32 values come back from memory in ONE
+            // coalesced round trip (streamed a microsecond ago: L2 / MALL) into the wave's f16 arrays -- their fragments are
+            // consumed -- and the exact chains (the reference's order: D = fl(x_j - y_j), acc = fma(D, D, acc)) read them there.
+            // (Each survivor reading its W samples from memory itself was W / 4 dependent round trips: W = 64 at +25 % of the
+            // W = 20 step.)
+            float* tile = reinterpret_cast<float*>(a1);                       // nfloat floats <= 4 nhalf bytes (both arrays)
+            {
+                Stage sv;
+                stage_load<ALIGNED>(sv, a.dataset + row * a.T, a.T, seg_start, nfloat, lane);
+                wave_lds_fence();                                             // every lane has read its fragments
+                stage_store<false>(sv, tile, nfloat, lane);
+                wave_lds_fence();
+            }
             unsigned hm = 0u;
 #pragma unroll
             for (int r = 0; r < 16; ++r) hm |= !(acc[r] > thr2) ? (1u << r) : 0u;
@@ -665,7 +675,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
                 if (!__ballot(hit)) continue;
                 float v = 0.0f;
                 if (hit) {
-                    const float* y = yseg + p;
+                    const float* y = tile + p;
 #pragma unroll 4
                     for (int j = 0; j < W; ++j) { const float D = __fsub_rn(x[j], y[j]); v = __builtin_fmaf(D, D, v); }
                 }
@@ -679,6 +689,12 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
                     const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                     if (slot < NFL) fl[slot] = u32x4{__float_as_uint(v), (unsigned)r_global, (unsigned)(seg_start + p), 0u};
                 }
+            }
+            // the arrays' tails past what a segment's conversion writes hold fp32 bits now: zeros again (0 * NaN poisons a row)
+            wave_lds_fence();
+            for (int idx = 4 * ((nfloat + 3) >> 2) + 4 * lane; idx < nhalf; idx += 256) {
+                *reinterpret_cast<f16x4*>(a1 + mx_half(idx)) = f16x4{0, 0, 0, 0};
+                *reinterpret_cast<f16x4*>(a2 + mx_half(idx)) = f16x4{0, 0, 0, 0};
             }
         }
         wave_lds_fence();  // all lanes done with the arrays before they are overwritten
