@@ -183,6 +183,38 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
         }
     }
     __syncthreads();
+    // ---- leading zero taps (round 5).  A bank of localised filters anchored at the window's end (wavelets at dyadic scales:
+    // configs[4]'s 28 / 55 / 110 / 220 / 252-tap rows) leaves whole 32-tap steps of a row's band empty: row i first meets a
+    // non-zero tap at step f_i / 32 (f_i = its first non-zero tap; the band of step ks covers taps 32 ks - 15 .. 32 ks + 31).
+    // The accumulator slots take the rows SORTED by that step, latest first, so that the three 4-row groups of the product
+    // loop start at steps gs[0] >= gs[1] >= gs[2] and the loop runs its MFMAs only where a group has anything to multiply
+    // (configs[4]: 20 of 27 group-steps).  perm[slot] = the kernel row in accumulator slot `slot` (>= d: an all-zero slot).
+    int* permL = ctl + 8;                                                               // 12 ints (the 64 bytes behind the control words)
+    {
+        int* stL = reinterpret_cast<int*>(bh);                                          // scratch: the B copies are built below
+        constexpr int NS = 4 * NG;                                                      // accumulator slots this instantiation computes (>= d)
+        if (tid < PSH_EMX_MAX_D) {
+            int f = K;
+            if (tid < d) for (int j = K - 1; j >= 0; --j) f = kerF[tid * Kst + j] != 0.0f ? j : f;
+            stL[tid] = (tid < d && f < K) ? f / 32 : dm.KS;                             // (an all-zero row, a slot past d: never active)
+            permL[tid] = PSH_EMX_MAX_D;                                                 // (slots past NS: no row)
+        }
+        __syncthreads();
+        if (tid < NS) {                                                                 // rank among the NS slots by (start, latest first; row index)
+            const int mine = stL[tid];
+            int rank = 0;
+            for (int j = 0; j < NS; ++j) rank += (stL[j] > mine || (stL[j] == mine && j < tid)) ? 1 : 0;
+            permL[rank] = tid;
+        }
+        __syncthreads();
+        if (tid < 3) {
+            int m = dm.KS;
+            if (tid < NG)
+                for (int r4 = 0; r4 < 4; ++r4) { const int v = stL[permL[4 * tid + r4]]; m = v < m ? v : m; }
+            ctl[5 + tid] = m;
+        }
+        __syncthreads();
+    }
     const unsigned kmb = (unsigned)ctl[1];
     const int ek = kmb >= 0x00800000u ? 9 - ((int)((kmb >> 23) & 255u) - 126) : 0;      // max|ker| 2^ek in [256, 512)
     const int ekc = ek > 100 ? 100 : (ek < -100 ? -100 : ek);
@@ -192,7 +224,8 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
             // copy c of row i:  copy[x] = L_i[x + c],  L_i[x] = ker_i[x - PADL] (zero outside [0, K))
             const int i = e / (4 * dm.CS), rem = e - i * 4 * dm.CS, c = rem / dm.CS, x2 = rem - c * dm.CS;
             const int j = x2 + c - PSH_EMX_PADL;
-            float v = (i < d && j >= 0 && j < K) ? kerF[i * Kst + j] * sk : 0.0f;
+            const int ir = permL[i];                                                    // the kernel row in accumulator slot i
+            float v = (ir < d && j >= 0 && j < K) ? kerF[ir * Kst + j] * sk : 0.0f;
             const _Float16 hi = (_Float16)v;
             const _Float16 lo = (_Float16)(v - (float)hi);
             bh[e] = hi;
@@ -206,7 +239,8 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
 #pragma unroll
             for (int cc = 0; cc < 8; ++cc) c = ((dm.pos8 >> (4 * cc)) & 15u) == (unsigned)ps ? cc : c;
             const int j = x2 + c - PSH_EMX_PADL;
-            const float v = (i < d && j >= 0 && j < K) ? kerF[i * Kst + j] * sk : 0.0f;
+            const int ir = permL[i];
+            const float v = (ir < d && j >= 0 && j < K) ? kerF[ir * Kst + j] * sk : 0.0f;
             bh[e] = (_Float16)v;
         }
     }
@@ -241,7 +275,8 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
             float hq[16], nxq = 0.0f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                hq[i] = (q < a.B && i < d) ? a.hx[(int64_t)q * d + i] : 0.0f;
+                const int ir = i < PSH_EMX_MAX_D ? permL[i] : d;                        // slot i holds kernel row ir
+                hq[i] = (q < a.B && ir < d) ? a.hx[(int64_t)q * d + ir] : 0.0f;
                 nxq = __builtin_fmaf(hq[i], hq[i], nxq);
             }
 #pragma unroll
@@ -261,6 +296,11 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
     typedef const __attribute__((address_space(4))) QueryState* const_qsp;
     const const_qsp qstate_k = (const_qsp)a.qstate;
     const int scol = lane & 15, kq = lane >> 4;                                         // column = shift s (and A row), K quarter
+    int perm_s[PSH_EMX_MAX_D];                                                          // the slots' kernel rows, wave-uniform
+#pragma unroll
+    for (int i = 0; i < PSH_EMX_MAX_D; ++i) perm_s[i] = __builtin_amdgcn_readfirstlane(permL[i]);
+    // first steps of the product loop's groups (slots 0-3 / 4-7 / 8-11), latest first; NG < 3: the plain loop runs every step
+    const int gs0 = __builtin_amdgcn_readfirstlane(ctl[5]), gs1 = __builtin_amdgcn_readfirstlane(ctl[6]), gs2 = __builtin_amdgcn_readfirstlane(ctl[7]);
 
     // exact verification of the queued survivors: lane (e, i) runs row i of survivor e (4 per pass), the oracle's order:
     // hy_i = fma chain over all K taps, D_i = hx_i - hy_i, acc = fma chain over i.
@@ -509,9 +549,7 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                 };
                 if constexpr (NG == 3) {
                     f16x8 F0[4], F1[4], F2[4];
-                    f16x8 a0 = *reinterpret_cast<const f16x8*>(ap), a1 = *reinterpret_cast<const f16x8*>(ap + 256), b0, b1;
-                    ldB(F0, 0, 0);
-                    ldB(F1, 1, 0);
+                    f16x8 a0, a1, b0, b1;
                     // One read BETWEEN two MFMAs, into the buffer whose MFMAs were issued a group earlier: a block of 4 - 6 reads
                     // behind 8 MFMAs holds the wave's next MFMA back by ~50 cycles per read (tools/ubench_emx_loop.hip: 1141 cycles
                     // per step for one wave in the loop -- and the partner wave is in its epilogue more often than not -- against
@@ -528,10 +566,48 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                         C[1][4 * (gm) + r4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1, FM[r4], C[1][4 * (gm) + r4], 0, 0, 0);       \
                         __builtin_amdgcn_sched_barrier(0);                                                                             \
                     }
-                    const _Float16* bpk = bp;
-                    const _Float16* apk = ap;
+                    // Phases by the groups' first steps (rows sorted above): [gs2, gs1) slots 8-11 alone, [gs1, gs0) slots 4-11,
+                    // [gs0, KS) all twelve -- the ring below.  The first two keep the ring's rule (one read between two MFMAs, a
+                    // group's fragments requested a group of MFMAs ahead) with two buffers; a step's A fragments move between
+                    // two register sets (8 moves a step: these phases are short).
+                    int ks0 = gs2 < dm.KS ? gs2 : dm.KS;
+                    const _Float16* bpk = bp + 32 * ks0;
+                    const _Float16* apk = ap + 32 * ks0;
+                    a0 = *reinterpret_cast<const f16x8*>(apk); a1 = *reinterpret_cast<const f16x8*>(apk + 256);
+                    if (ks0 < gs1) {
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) F2[r4] = *reinterpret_cast<const f16x8*>(bpk + (size_t)(8 + r4) * rstride);
 #pragma unroll 1
-                    for (int ks = 0; ks < dm.KS; ks += 2) {
+                        for (; ks0 < gs1 && ks0 < dm.KS; ++ks0) {
+                            PSH_EMX_STEP(a0, a1, F2, 2, F0, 2, 32, b0 = *reinterpret_cast<const f16x8*>(apk + 32),
+                                         b1 = *reinterpret_cast<const f16x8*>(apk + 256 + 32))
+#pragma unroll
+                            for (int r4 = 0; r4 < 4; ++r4) F2[r4] = F0[r4];
+                            a0 = b0; a1 = b1;
+                            bpk += 32; apk += 32;
+                        }
+                    }
+                    if (ks0 < gs0 && ks0 < dm.KS) {
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) F1[r4] = *reinterpret_cast<const f16x8*>(bpk + (size_t)(4 + r4) * rstride);
+#pragma unroll 1
+                        for (; ks0 < gs0 && ks0 < dm.KS; ++ks0) {
+                            PSH_EMX_STEP(a0, a1, F1, 1, F2, 2, 0, (void)0, (void)0)
+                            PSH_EMX_STEP(a0, a1, F2, 2, F1, 1, 32, b0 = *reinterpret_cast<const f16x8*>(apk + 32),
+                                         b1 = *reinterpret_cast<const f16x8*>(apk + 256 + 32))
+                            a0 = b0; a1 = b1;
+                            bpk += 32; apk += 32;
+                        }
+                    } else if (ks0 < dm.KS) {
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) F1[r4] = *reinterpret_cast<const f16x8*>(bpk + (size_t)(4 + r4) * rstride);
+                    }
+                    if (ks0 < dm.KS) {
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) F0[r4] = *reinterpret_cast<const f16x8*>(bpk + (size_t)r4 * rstride);
+                    }
+#pragma unroll 1
+                    for (int ks = ks0; ks < dm.KS; ks += 2) {
                         // (the reads of step KS -- past the copies and the segment's tail, inside the block's LDS -- feed nothing)
                         PSH_EMX_STEP(a0, a1, F0, 0, F2, 2, 0, (void)0, (void)0)
                         PSH_EMX_STEP(a0, a1, F1, 1, F0, 0, 32, b0 = *reinterpret_cast<const f16x8*>(apk + 32),
@@ -767,7 +843,7 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
             unsigned taunx = 0u;
             auto fetch_query = [&](int bq) {
 #pragma unroll
-                for (int i = 0; i < 4 * NG; ++i) hnx[i] = hxk[(int64_t)bq * d + (i < d ? i : 0)];
+                for (int i = 0; i < 4 * NG; ++i) hnx[i] = hxk[(int64_t)bq * d + (perm_s[i] < d ? perm_s[i] : 0)];
                 if (MODE == PSH_MODE_FILTER) taunx = qstate_k[bq].tau2_bits;
             };
             if (q_begin < q_end) fetch_query(q_begin);
@@ -777,7 +853,7 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                 float nx = 0.0f;
 #pragma unroll
                 for (int i = 0; i < 4 * NG; ++i) {
-                    hxs[i] = i < d ? hnx[i] : 0.0f;
+                    hxs[i] = perm_s[i] < d ? hnx[i] : 0.0f;
                     asm volatile("" : "+v"(hxs[i]));                                    // a VGPR copy: an fma with an SGPR operand issues at ~0.6 of the rate (ubench_dot2)
                     nx = __builtin_fmaf(hxs[i], hxs[i], nx);
                 }
