@@ -217,7 +217,9 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
     }
     const unsigned kmb = (unsigned)ctl[1];
     const int ek = kmb >= 0x00800000u ? 9 - ((int)((kmb >> 23) & 255u) - 126) : 0;      // max|ker| 2^ek in [256, 512)
-    const int ekc = ek > 100 ? 100 : (ek < -100 ? -100 : ek);
+    // (wave-uniform constants through readfirstlane: scalar registers -- as vector registers three of them were spilled once
+    //  the product loop's phases took theirs)
+    const int ekc = __builtin_amdgcn_readfirstlane(ek > 100 ? 100 : (ek < -100 ? -100 : ek));
     const float sk = __uint_as_float((unsigned)(127 + ekc) << 23);
     if (NP == 3) {
         for (int e = tid; e < PSH_EMX_MAX_D * 4 * dm.CS; e += PSH_EMX_THREADS) {
@@ -248,8 +250,8 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
     // eps: splits and the dropped lo.lo term (3 * 2^-22) + fp32 accumulation of 3 K' products (3 * 32 KS * 2^-24), doubled
     const float eps = NP == 3 ? PSH_EMX_EPS_REL + 2.0f * (float)(3 * 32 * dm.KS) / 16777216.0f
                               : 1.001f * (1.0f / 1024.0f + 1.0f / 4194304.0f) + 2.0f * (float)(32 * dm.KS) / 16777216.0f;
-    const float cerr = eps * __builtin_sqrtf(__uint_as_float((unsigned)ctl[2])) * 1.001f;
-    const float kl1max = __uint_as_float((unsigned)ctl[3]);
+    const float cerr = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(eps * __builtin_sqrtf(__uint_as_float((unsigned)ctl[2])) * 1.001f)));
+    const float kl1max = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(ctl[3]));
     constexpr float eps2 = 1.001f * (1.0f / 1024.0f + 1.0f / 4194304.0f) + 64.0f / 16777216.0f;
     float sqc = 1.0f, thrG = 0.0f;
     int eqc = 0;
