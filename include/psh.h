@@ -282,11 +282,14 @@ size_t psh_embed_plan_offset(void);
  *          from psh_profile after the call -- front entries upwards from its start, back entries downwards from its end
  *   out[6] byte offset of the fused / overlap-friendly launches' candidate area (16-byte entries), out[7] of the fused
  *          launch's per-block records (uint64 [out[10]]: low 31 bits = entries of block i, which start at entry i * out[11];
- *          an entry = {d bits | r << 32, t}), out[8] of the overlap-friendly launches' per-query counts (uint32 [4]; query q's
- *          entries {d bits, r, t, -} start at entry q * (out[10] * out[11] / B))
+ *          an entry = {d bits | r << 32, t}), out[8] of the overlap-friendly launches' per-query counts (uint32 [4])
  *   out[9] PSH_MAX_BLOCKS, out[10] blocks of the fused launch at most, out[11] entries a fused block may publish
+ *   out[12] byte offset of the overlap-friendly launches' lists (16-byte entries {d bits, r, t, q}; query q's list starts at
+ *          entry q * out[13]), out[13] entries a query's list holds: the region of cand_d / cand_rt taken as one array, at
+ *          most 65536 per query (a block whose own 64-entry list is full appends there directly: clustered matches in a
+ *          smooth ensemble), or out[6] with out[10] * out[11] / B entries on a workspace too small for more
  * Nothing is launched; PSH_ERR_WORKSPACE when the workspace is too small for the sizes. */
-int psh_candidates_layout(int64_t R, int64_t T, int B, int W, int h, int k, size_t workspace_bytes, int64_t* out12);
+int psh_candidates_layout(int64_t R, int64_t T, int B, int W, int h, int k, size_t workspace_bytes, int64_t* out14);
 int psh_scan_topk_embedded(int device, void* stream,
                            const float* dataset, int64_t R, int64_t T, int64_t r_offset,
                            const float* kernel, int d, int K,

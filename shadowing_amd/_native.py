@@ -433,10 +433,10 @@ def scan_topk_embedded(dataset: torch.Tensor, kernel: torch.Tensor, hx: torch.Te
 def candidates_layout(R: int, T: int, B: int, W: int, h: int, k: int, nbytes: int) -> dict:
     """psh_candidates_layout: where a scan with these sizes on a workspace of `nbytes` leaves the windows it admitted
     (diagnostics: tests/test_gpu_admitted_set.py reads the admitted SET back and compares it with the oracle's)."""
-    out = (C.c_int64 * 12)()
+    out = (C.c_int64 * 14)()
     _check(load().psh_candidates_layout(R, T, B, W, h, k, nbytes, out), "psh_candidates_layout")
     names = ("qstate", "bcount", "bcount2", "cand_d", "cand_rt", "cap", "hdr_cand", "hdr_blk", "hdr_stream_ncand", "max_blocks",
-             "fused_max_blocks", "fused_front")
+             "fused_max_blocks", "fused_front", "stream_list", "stream_cap")
     return dict(zip(names, (int(v) for v in out)))
 
 

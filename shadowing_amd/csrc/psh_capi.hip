@@ -153,6 +153,19 @@ int carve(void* ws, size_t bytes, int B, int k, int64_t min_stride, Workspace* o
     return PSH_OK;
 }
 
+// The overlap-friendly launches' lists of admitted windows (psh_stream.hip): 16-byte entries, one compact list per query.
+// The workspace's two candidate arrays (4 + 8 bytes per entry of `cap`, adjacent) are taken as ONE region -- up to 65536
+// entries per query (the ranking compares every pair: 64 k entries are ~0.3 ms, still a fraction of the separate launches a
+// PSH_STATUS_RETRY costs) -- and FusedHdr::cand (16384 entries for the call) serves a workspace too small for more.
+#define PSH_STREAM_LIST_MAX 65536
+static void stream_cand_list(const Workspace& w, int B, void** list, int* cap_per_query) {
+    const int64_t region = (int64_t)((char*)w.cand_rt - (char*)w.cand_d) + (int64_t)sizeof(int2) * B * (int64_t)w.cap;
+    int64_t per = region / 16 / B;
+    if (per > PSH_STREAM_LIST_MAX) per = PSH_STREAM_LIST_MAX;
+    if (per > PSH_STREAM_CAND_CAP / B) { *list = (void*)w.cand_d; *cap_per_query = (int)per; }
+    else { *list = (void*)w.fused->cand; *cap_per_query = PSH_STREAM_CAND_CAP / B; }
+}
+
 // candidate capacity per query: the scan writes one slice per block (up to
 // PSH_MAX_BLOCKS of them), the exhaustive path one slot per window of a row chunk
 int recommended_cap(int64_t Tp, int k) {
@@ -600,6 +613,24 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     int rc = check_problem(dataset, R, T, r_offset, queries, B, W, h, k, out_d, out_idx, &p, ker, emb_d);
     if (rc) return rc;
     if (!out_status) return PSH_ERR_ARG;
+    // Several queries with a LONG Identity window (34 <= W <= 256): a loop of one-query steps, each the three launches with
+    // the matrix-core long-window scan (psh_stream.hip).  The batched kernels' bands stop at W = 25 and the vector-ALU filter
+    // costs W fma per window and query: R = 32768, T = 4096, W = 126 -- 2 / 4 / 16 / 64 queries 1.34 / 2.48 / 8.9 / 34 ms in
+    // one pass, 0.37 / 0.73 / 2.9 / 11.6 ms as a loop (tools/long_batch_probe.py).  Status words stay per query; a RETRY of any
+    // step sends the caller's WHOLE call to PSH_FLAG_NO_FUSE, as the protocol says.
+    if (!ker && B > 1 && p.Tp > 1 && stream_long_supported(W) && !(profile && profile->mode == PSH_PROFILE_STAGES) &&
+        !(flags_of(profile) & (PSH_FLAG_FILTER_VALU | PSH_FLAG_NO_FUSE))) {
+        psh_profile sub;
+        for (int b = 0; b < B; ++b) {
+            if (profile) { sub = *profile; if (profile->tau_hint) sub.tau_hint = profile->tau_hint + b; }
+            rc = scan_topk_impl(device, stream, dataset, R, T, r_offset, queries + (size_t)b * W, qnorm ? qnorm + b : nullptr, 1, W, h, k,
+                                nullptr, 0, out_d + (size_t)b * k, out_idx + (size_t)b * k * 2, out_status + b, workspace, workspace_bytes,
+                                profile ? &sub : nullptr);
+            if (rc) return rc;
+        }
+        if (profile) { const float* hint0 = profile->tau_hint; *profile = sub; profile->tau_hint = hint0; }
+        return PSH_OK;
+    }
     p.emb_dense = (flags_of(profile) & PSH_FLAG_EMBED_DENSE) != 0;
     p.rows_generic = (flags_of(profile) & PSH_FLAG_ROWS_GENERIC) != 0;
     p.emb_taps = (flags_of(profile) & PSH_FLAG_EMBED_TAPS) != 0;
@@ -722,7 +753,9 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
             const int64_t n_rs = p.R * nseg;
             if (grid_s * (PSH_SCAN_THREADS / 64) > n_rs) grid_s = (n_rs + (PSH_SCAN_THREADS / 64) - 1) / (PSH_SCAN_THREADS / 64);
             const int front = B == 1 ? PSH_FUSED_FRONT : 2 * PSH_FUSED_FRONT;
-            const int cand_cap = PSH_STREAM_CAND_CAP / B;
+            int cand_cap = 0;
+            void* cand_list = nullptr;
+            stream_cand_list(w, B, &cand_list, &cand_cap);
             const int logical = PSH_SEG + p.W + 3;
             const int tile_fl = (logical + ((logical >> 6) << 2) + 4 + 3) & ~3;
             int tb = 0;
@@ -751,6 +784,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
                 fu.nq = B;
                 fu.units_stride = (int)((PSH_FUSED_MAX_UNITS / B) & ~3);
                 fu.cand_cap = cand_cap;
+                fu.cand_list = cand_list;
                 fu.k_out = k;
                 fu.tau_hint = hint;
                 if (hint) grid_p = 1;                  // nothing is sampled: one block derives scale, thresholds and the fragment table from the hints
@@ -1105,7 +1139,8 @@ int psh_merge_sorted_gathered(int device, void* stream, const float* d_gathered,
 
 size_t psh_embed_plan_offset(void) { return PSH_FUSED_BYTES; }
 
-int psh_candidates_layout(int64_t R, int64_t T, int B, int W, int h, int k, size_t workspace_bytes, int64_t* out12) {
+int psh_candidates_layout(int64_t R, int64_t T, int B, int W, int h, int k, size_t workspace_bytes, int64_t* out14) {
+    int64_t* out12 = out14;
     if (!out12 || R <= 0 || T <= 0 || B <= 0 || W <= 0 || h < 0 || k <= 0) return PSH_ERR_ARG;
     if (W > PSH_MAX_W || k > PSH_MAX_K) return PSH_ERR_UNSUPPORTED;
     const int64_t Tp = T - W - h + 1;
@@ -1126,6 +1161,13 @@ int psh_candidates_layout(int64_t R, int64_t T, int B, int W, int h, int k, size
     out12[9] = PSH_MAX_BLOCKS;
     out12[10] = PSH_FUSED_MAX_BLOCKS;
     out12[11] = PSH_FUSED_FRONT;
+    {   // the overlap-friendly launches' lists (w.fused sits at the base)
+        void* list = nullptr;
+        int per = 0;
+        stream_cand_list(w, B, &list, &per);
+        out14[12] = (char*)list - base;
+        out14[13] = per;
+    }
     return PSH_OK;
 }
 

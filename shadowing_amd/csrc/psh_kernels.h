@@ -100,7 +100,9 @@ struct FusedArgs {
     int front;                       // stream scan: candidates a block may hold (all its queries together)
     int nq;                          // stream launches: queries of the step (<= PSH_STREAM_MAX_Q)
     int units_stride;                // stream launches: query q's sampled minima start at minima[q * units_stride]
-    int cand_cap;                    // stream launches: entries of a query's region of `cand` (query q: cand + q * cand_cap entries)
+    int cand_cap;                    // stream launches: entries of a query's region of `cand_list` (query q: cand_list + q * cand_cap entries)
+    void* cand_list;                 // stream launches: the queries' compact lists of admitted windows, 16-byte {d bits, r, t, q} entries
+                                     // (the workspace's candidate arrays taken as one region; FusedHdr::cand on a minimal workspace)
     int k_out;                       // stream launches: row length of out_d / out_idx (= k)
     const float* tau_hint;           // nullable: the caller's admission level per query (psh_profile.tau_hint) -- no sample, no first barrier
 };

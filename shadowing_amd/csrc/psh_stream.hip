@@ -313,6 +313,14 @@ void stream_sample_kernel(ScanArgs a, FusedArgs f) {
 // S: the scan
 // ------------------------------------------------------------------------------------------------------------------
 #define PSH_STREAM_FIXED_BYTES 256    // control words; the block's candidate list follows
+// A block's list of admitted windows is full (clustered matches: a smooth ensemble -- price levels, not returns -- puts a
+// window's neighbours in t next to it in distance too): the entry goes straight to the query's compact list in memory, one
+// device-scope atomic per entry (r05; until then such a step gave up -- PSH_STATUS_RETRY -- and the caller ran the separate launches)
+__device__ __forceinline__ void spill_candidate(FusedHdr* hdr, void* cand_list, int cand_cap, int q, float xn, float acc, int r_global, int t) {
+    const unsigned slot = __hip_atomic_fetch_add((gu32*)&hdr->stream.ncand[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (slot < (unsigned)cand_cap)
+        reinterpret_cast<u32x4*>(cand_list)[(size_t)q * cand_cap + slot] = u32x4{__float_as_uint(dist_from_acc(acc, xn)), (unsigned)r_global, (unsigned)t, (unsigned)q};
+}
 #define PSH_STREAM_FL(NQ) ((NQ) == 1 ? PSH_FUSED_FRONT : 2 * PSH_FUSED_FRONT)
 enum { S_FRONT = 0, S_NEXT = 1 };
 
@@ -426,6 +434,7 @@ __device__ __forceinline__ void stream_scan_body(const ScanArgs& a, const FusedA
             if (hit) {
                 const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                 if (slot < NFL) fl[slot] = u32x4{__float_as_uint(v), (unsigned)r_global, (unsigned)(seg_start + p), (unsigned)q};
+                else spill_candidate(hdr, f.cand_list, f.cand_cap, q, __uint_as_float(sc->xn_bits[q]), v, r_global, seg_start + p);
             }
         }
     };
@@ -517,12 +526,11 @@ __device__ __forceinline__ void stream_scan_body(const ScanArgs& a, const FusedA
                     if (slot < (unsigned)f.cand_cap) {
                         u32x4 o = e;
                         o[0] = __float_as_uint(dist_from_acc(__uint_as_float(e[0]), xn[q]));
-                        reinterpret_cast<u32x4*>(hdr->cand)[(size_t)q * f.cand_cap + slot] = o;
+                        reinterpret_cast<u32x4*>(f.cand_list)[(size_t)q * f.cand_cap + slot] = o;
                     }
                 }
             }
         }
-        if (lane == 0 && nfront > NFL) __hip_atomic_store((gu32*)&hdr->stream.ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     stamp(3);
 }
@@ -688,6 +696,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
                 if (hit) {
                     const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                     if (slot < NFL) fl[slot] = u32x4{__float_as_uint(v), (unsigned)r_global, (unsigned)(seg_start + p), 0u};
+                    else spill_candidate(hdr, f.cand_list, f.cand_cap, 0, xn, v, r_global, seg_start + p);
                 }
             }
             // the arrays' tails past what a segment's conversion writes hold fp32 bits now: zeros again (0 * NaN poisons a row)
@@ -715,11 +724,10 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
                 if (slot < (unsigned)f.cand_cap) {
                     u32x4 o = fl[lane];
                     o[0] = __float_as_uint(dist_from_acc(__uint_as_float(o[0]), xn));
-                    reinterpret_cast<u32x4*>(hdr->cand)[slot] = o;
+                    reinterpret_cast<u32x4*>(f.cand_list)[slot] = o;
                 }
             }
         }
-        if (lane == 0 && nfront > NFL) __hip_atomic_store((gu32*)&hdr->stream.ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -763,7 +771,7 @@ void stream_rank_kernel(ScanArgs a, FusedArgs f) {
         if (blockIdx.x == 0) poison_results(f.out_d + (size_t)q * f.k_out, f.out_idx + (size_t)q * f.k_out * 2, a.k, lane, 64);
         return;
     }
-    const u32x4v* cand = reinterpret_cast<const u32x4v*>(hdr->cand) + (size_t)q * f.cand_cap;
+    const u32x4v* cand = reinterpret_cast<const u32x4v*>(f.cand_list) + (size_t)q * f.cand_cap;
     float* out_d = f.out_d + (size_t)q * f.k_out;
     int32_t* out_idx = f.out_idx + (size_t)q * f.k_out * 2;
     const int per = (ncand + (int)gridDim.x - 1) / (int)gridDim.x;

@@ -83,9 +83,12 @@ def test_candidates_layout_is_host_only_and_consistent(lib):
     assert lay["cand_rt"] + 8 * 4 * lay["cap"] <= nb
     assert lay["hdr_cand"] % 16 == 0 and lay["hdr_blk"] % 8 == 0 and lay["hdr_stream_ncand"] % 4 == 0
     assert (lay["max_blocks"], lay["fused_max_blocks"], lay["fused_front"]) == (2048, 256, 64)
+    # the overlap-friendly launches' lists: inside the candidate arrays' region, a list per query, 16-byte entries
+    assert lay["stream_list"] == lay["cand_d"] and 4096 < lay["stream_cap"] <= 65536
+    assert lay["stream_list"] + 16 * 4 * lay["stream_cap"] <= lay["cand_rt"] + 8 * 4 * lay["cap"]
     twice = _native.candidates_layout(4096, 4096, 4, 20, 20, 256, 2 * nb)
     assert twice["cap"] > lay["cap"]                       # a larger workspace is a larger candidate buffer
-    out = (C.c_int64 * 12)()
+    out = (C.c_int64 * 14)()
     assert lib.psh_candidates_layout(4096, 4096, 4, 20, 20, 256, 1024, out) == -3          # PSH_ERR_WORKSPACE
     assert lib.psh_candidates_layout(4096, 4096, 4, 20, 20, 256, nb, None) == -1
 

@@ -79,14 +79,15 @@ def read_admitted(ws, lay, info, B):
         return [(rt, (e[:, 0] & np.uint64(0xffffffff)).astype(np.uint32))]
     assert info["path"] == 3, info                                      # the overlap-friendly launches: one compact list per query
     ncand = buf[lay["hdr_stream_ncand"]: lay["hdr_stream_ncand"] + 16].view(torch.int32).cpu().numpy()
-    ccap = lay["fused_max_blocks"] * lay["fused_front"] // B
-    ent = buf[lay["hdr_cand"]: lay["hdr_cand"] + 16 * ccap * B].view(torch.int32).view(B, ccap, 4).cpu().numpy()
+    ccap = lay["stream_cap"]
     for b in range(B):
         n = int(ncand[b])
         if n > ccap:
             out.append(None)
             continue
-        out.append((ent[b, :n, 1:3].astype(np.int64), ent[b, :n, 0].view(np.uint32).copy()))
+        o = lay["stream_list"] + 16 * ccap * b
+        ent = buf[o: o + 16 * n].view(torch.int32).view(n, 4).cpu().numpy()
+        out.append((ent[:, 1:3].astype(np.int64), ent[:, 0].view(np.uint32).copy()))
     return out
 
 

@@ -424,6 +424,75 @@ def test_long_window_shadow_with_paths_and_adversarial_data(hip_device, oracle_m
         assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, f"long window, {kind}")
 
 
+@pytest.mark.parametrize("W,flags", [(20, "overlap"), (33, "overlap"), (40, 0), (64, 0), (126, 0), (126, "overlap"), (250, 0)])
+def test_smooth_ensembles_fill_block_lists_without_giving_up(hip_device, oracle_mod, W, flags):
+    """A smooth ensemble (price LEVELS: random walks, not returns) puts a match's neighbours in t next to it in distance and
+    makes the f16 test's slack -- proportional to ||x|| ||y|| -- large beside the admission level: thousands of admitted
+    windows in a few blocks.  A block's 64-entry list then overflows into the query's list in memory (spill_candidate) instead
+    of failing the step: status OK on the three launches, results the oracle's.  (Until round 5 such a step answered
+    PSH_STATUS_RETRY -- correct through the protocol, but three passes over the ensemble.)"""
+    from shadowing_amd import _native
+    R, T, h, k = 8192, 2048, 0, 1024
+    rng = np.random.default_rng(2100 + W)
+    ds = (0.05 * np.cumsum(rng.standard_normal((R, T)), axis=1)).astype(np.float32)
+    q = (0.05 * np.cumsum(rng.standard_normal((1, W)))).astype(np.float32).reshape(1, W)
+    ds_t, q_t = torch.as_tensor(ds).to(hip_device), torch.as_tensor(q).to(hip_device)
+    info = {}
+    d, idx, st = _native.scan_topk(ds_t, q_t, k, h=h, flags=_native.FLAG_OVERLAP if flags else 0, info=info)
+    torch.cuda.synchronize()
+    assert info["path"] == 3 and int(st[0]) == 0, (info, st.tolist())
+    od, oidx = oracle_mod.scan_topk(ds[:, None, :], q, k, h=h)
+    assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, f"smooth ensemble W={W}")
+    # two and three queries ride the same launches (W <= 33)
+    if W <= 33:
+        q3 = np.concatenate([q, q[:, ::-1], 0.5 * q + 0.01], axis=0).astype(np.float32)
+        d, idx, st = _native.scan_topk(ds_t, torch.as_tensor(q3).to(hip_device), k, h=h, info=info)
+        torch.cuda.synchronize()
+        assert info["path"] == 3 and not st.cpu().numpy().any(), (info, st.tolist())
+        od, oidx = oracle_mod.scan_topk(ds[:, None, :], q3, k, h=h)
+        assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, f"smooth ensemble W={W}, three queries")
+
+
+@pytest.mark.parametrize("W,B,h,k", [(34, 2, 3, 100), (64, 5, 20, 300), (126, 4, 60, 256), (126, 17, 0, 64), (252, 3, 20, 128)])
+def test_long_window_batches_loop_over_the_one_query_step(hip_device, oracle_mod, W, B, h, k):
+    """Several queries with a window of 34 .. 256 samples: psh_scan_topk serves them as B one-query steps (path 3, the
+    matrix-core long-window scan) -- the batched kernels' bands stop at W = 25 -- with per-query status words, a hint per
+    query, and the same results as the one-pass vector-ALU scan (PSH_FLAG_FILTER_VALU) and the oracle."""
+    from shadowing_amd import _native
+    R, T = 4096, 2048
+    ds = syn.dataset(R, T, 2200 + W)
+    q = syn.gbm_log_returns((B, W), 2300 + W + B)
+    ds_t = torch.as_tensor(np.ascontiguousarray(ds[:, 0, :])).to(hip_device)
+    q_t = torch.as_tensor(q).to(hip_device)
+    od, oidx = oracle_mod.scan_topk(ds, q, k, h=h)
+    info = {}
+    d, idx, st = _native.scan_topk(ds_t, q_t, k, h=h, info=info)
+    torch.cuda.synchronize()
+    assert info["path"] == 3 and not st.cpu().numpy().any(), (info, st.tolist())
+    assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, f"long-window batch W={W} B={B}")
+    info = {}
+    _native.scan_topk(ds_t, q_t, k, h=h, info=info, flags=_native.FLAG_FILTER_VALU)
+    assert info["path"] == 0, info
+    d, idx = _native.scan_topk_checked(ds_t, q_t, k, h=h, flags=_native.FLAG_FILTER_VALU)      # (its per-query OVERFLOW is part of the protocol)
+    assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, f"long-window batch W={W} B={B}, one pass")
+    # a level per query: acc of the k-th window x 1.1 (OK), and one query's hint far too low (that query alone reports it)
+    xn2 = (q.astype(np.float64) ** 2).sum(axis=1)
+    lev = ((od[:, k - 1].astype(np.float64) ** 2) * xn2 * 1.1).astype(np.float32)
+    d, idx, st = _native.scan_topk(ds_t, q_t, k, h=h, tau_hint=torch.as_tensor(lev).to(hip_device))
+    torch.cuda.synchronize()
+    assert not st.cpu().numpy().any()
+    assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, f"long-window batch W={W} B={B}, hints")
+    lev[B - 1] *= 1e-3
+    d, idx, st = _native.scan_topk(ds_t, q_t, k, h=h, tau_hint=torch.as_tensor(lev).to(hip_device))
+    torch.cuda.synchronize()
+    stn = st.cpu().numpy()
+    assert stn[B - 1] != 0 and not stn[: B - 1].any(), stn
+    assert np.isnan(d[B - 1].cpu().numpy()).all()
+    assert_exact(d[: B - 1].cpu().numpy(), idx[: B - 1].cpu().numpy(), od[: B - 1], oidx[: B - 1], "the other queries of the call")
+    d, idx = _native.scan_topk_checked(ds_t, q_t, k, h=h, tau_hint=torch.as_tensor(lev).to(hip_device))
+    assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, f"long-window batch W={W} B={B}, checked with a short hint")
+
+
 def test_unsorted_flag_returns_the_same_set(hip_device, oracle_mod):
     """PSH_FLAG_UNSORTED (what the sharded scan asks of its local selection): the k best, any order."""
     ds = syn.dataset(4096, 2048, 1400)
