@@ -206,7 +206,9 @@ int psh_query_norm(int device, void* stream, const float* queries, int B, int W,
  *   PSH_STATUS_RETRY     the launches that serve 1, 2 or 3 queries (W <= 33) -- the fused single launch for one query,
  *                        the three overlap-friendly launches for one query under PSH_FLAG_OVERLAP and for EVERY call with
  *                        B = 2 or 3, flag or no flag -- admit below a statistical estimate and give up when it falls short
- *                        of k, when a block's candidate list overflows, or on a workspace psh_workspace_init never armed:
+ *                        of k, when the candidate lists overflow (the fused launch: 64 entries per block; the three
+ *                        launches: a query's list in the workspace, out[13] of psh_candidates_layout), or on a workspace
+ *                        psh_workspace_init never armed:
  *                        results of EVERY query of the call are INVALID -- since version 2 the launches overwrite them with NaN
  *                        distances and (-1, -1) indices instead of leaving an earlier call's numbers -> the same call with PSH_FLAG_NO_FUSE
  *                        (the separate launches: a provable bound, per-query OVERFLOW as above).
@@ -217,8 +219,10 @@ int psh_query_norm(int device, void* stream, const float* queries, int B, int W,
  * WINDOW LENGTHS.  The rejection test of a scan runs on the matrix cores for ONE query with W <= 256 (W <= 33: the fused
  * launch / the three overlap-friendly launches with the shifted-query band in registers; 34 <= W <= 256: the three launches
  * with the band as a K-loop over ceil((W + 31) / 16) steps, flag or no flag -- stream_scan_long_kernel), for two or three
- * queries with W <= 33, and for larger batches with W <= 25; every other shape uses the vector-ALU filter (17 <= W <= 32) or
- * the exact chains.  Results do not depend on which.
+ * queries with W <= 33, for larger batches with W <= 25, and for ANY number of queries with 34 <= W <= 256 -- served as a
+ * loop of one-query steps inside the call (status words per query as always); every other shape (batches with
+ * 26 <= W <= 33, PSH_FLAG_FILTER_VALU / PSH_FLAG_NO_FUSE calls) uses the vector-ALU filter or the exact chains.  Results
+ * do not depend on which.
  */
 int psh_scan_topk(int device, void* stream,
                   const float* dataset, int64_t R, int64_t T, int64_t r_offset,
