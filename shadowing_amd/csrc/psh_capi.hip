@@ -613,17 +613,21 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     int rc = check_problem(dataset, R, T, r_offset, queries, B, W, h, k, out_d, out_idx, &p, ker, emb_d);
     if (rc) return rc;
     if (!out_status) return PSH_ERR_ARG;
-    // Several queries with a LONG Identity window (34 <= W <= 256): a loop of one-query steps, each the three launches with
-    // the matrix-core long-window scan (psh_stream.hip).  The batched kernels' bands stop at W = 25 and the vector-ALU filter
-    // costs W fma per window and query: R = 32768, T = 4096, W = 126 -- 2 / 4 / 16 / 64 queries 1.34 / 2.48 / 8.9 / 34 ms in
-    // one pass, 0.37 / 0.73 / 2.9 / 11.6 ms as a loop (tools/long_batch_probe.py).  Status words stay per query; a RETRY of any
-    // step sends the caller's WHOLE call to PSH_FLAG_NO_FUSE, as the protocol says.
-    if (!ker && B > 1 && p.Tp > 1 && stream_long_supported(W) && !(profile && profile->mode == PSH_PROFILE_STAGES) &&
-        !(flags_of(profile) & (PSH_FLAG_FILTER_VALU | PSH_FLAG_NO_FUSE))) {
+    // Several queries with a window the batched kernels' bands do not reach (they stop at W = 25): a LOOP of the steps that do
+    // have a matrix-core rejection test, inside the call --
+    //   34 <= W <= 256: one query per step (the three launches with the long-window scan, psh_stream.hip);
+    //   26 <= W <= 33, four queries and more: three queries per step (the three launches' 2-3 query form).
+    // The one-pass vector-ALU filter costs W fma per window and query: R = 32768, T = 4096, W = 126 -- 2 / 4 / 16 / 64 queries
+    // 1.14 / 2.19 / 8.6 / 33.6 ms in one pass, 0.34 / 0.65 / 2.6 / 10.6 ms as a loop; W = 252: 2.2 .. 67 against 0.50 .. 16.2 ms
+    // (tools/long_batch_probe.py).  Status words stay per query; a RETRY of any step sends the caller's WHOLE call to
+    // PSH_FLAG_NO_FUSE, as the protocol says.
+    const int per_step = !ker && p.Tp > 1 ? (stream_long_supported(W) && B > 1 ? 1 : (W >= 26 && W <= 33 && B > PSH_STREAM_MAX_Q ? PSH_STREAM_MAX_Q : 0)) : 0;
+    if (per_step && !(profile && profile->mode == PSH_PROFILE_STAGES) && !(flags_of(profile) & (PSH_FLAG_FILTER_VALU | PSH_FLAG_NO_FUSE))) {
         psh_profile sub;
-        for (int b = 0; b < B; ++b) {
+        for (int b = 0; b < B; b += per_step) {
+            const int nb = B - b < per_step ? B - b : per_step;
             if (profile) { sub = *profile; if (profile->tau_hint) sub.tau_hint = profile->tau_hint + b; }
-            rc = scan_topk_impl(device, stream, dataset, R, T, r_offset, queries + (size_t)b * W, qnorm ? qnorm + b : nullptr, 1, W, h, k,
+            rc = scan_topk_impl(device, stream, dataset, R, T, r_offset, queries + (size_t)b * W, qnorm ? qnorm + b : nullptr, nb, W, h, k,
                                 nullptr, 0, out_d + (size_t)b * k, out_idx + (size_t)b * k * 2, out_status + b, workspace, workspace_bytes,
                                 profile ? &sub : nullptr);
             if (rc) return rc;
