@@ -208,15 +208,27 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
         }
         __syncthreads();
         if (tid < 3) {
+            // (the last slot of the last group -- the row with the longest support: a bank's low-pass -- runs ALONE from its
+            //  own first step, ctl[20], to the first step of the group's three other rows)
             int m = dm.KS;
             if (tid < NG)
-                for (int r4 = 0; r4 < 4; ++r4) { const int v = stL[permL[4 * tid + r4]]; m = v < m ? v : m; }
+                for (int r4 = 0; r4 < (NG == 3 && tid == 2 ? 3 : 4); ++r4) { const int v = stL[permL[4 * tid + r4]]; m = v < m ? v : m; }
             ctl[5 + tid] = m;
+            if (tid == 2) ctl[20] = NG == 3 ? stL[permL[11]] : dm.KS;
         }
         __syncthreads();
     }
     const unsigned kmb = (unsigned)ctl[1];
-    const int ek = kmb >= 0x00800000u ? 9 - ((int)((kmb >> 23) & 255u) - 126) : 0;      // max|ker| 2^ek in [256, 512)
+    int ek = kmb >= 0x00800000u ? 9 - ((int)((kmb >> 23) & 255u) - 126) : 0;            // max|ker| 2^ek in [256, 512)
+    if constexpr (QM) {
+        // The per-query pass takes the accumulators AS THEY ARE for its f16 A fragments (round 5: scaling them first was 48
+        // packed multiplies per half segment): |acc| <= (ymax 2^ey < 512) (max_i ||ker_i||_1 2^ek) must stay inside f16, and as
+        // far up as the scale of rounds 3-4 put it ([8192, 16384) exactly; now [8192, 32768) by the two factors' binades):
+        // max_i ||ker_i||_1 2^ek in [32, 64).  The copies' taps are then at most 64 -- a tap below 2^-14 / 2^ek is a subnormal
+        // f16, absolute error 2^-25 instead of 2^-11 relative: sqrt(12) K 2^-25 / 32 < 2^-20 of max ||ker||_1 on the radius (eps).
+        const unsigned lb = (unsigned)ctl[3];
+        ek = lb >= 0x00800000u ? 6 - ((int)((lb >> 23) & 255u) - 126) : 0;
+    }
     // (wave-uniform constants through readfirstlane: scalar registers -- as vector registers three of them were spilled once
     //  the product loop's phases took theirs)
     const int ekc = __builtin_amdgcn_readfirstlane(ek > 100 ? 100 : (ek < -100 ? -100 : ek));
@@ -249,7 +261,7 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
     __syncthreads();
     // eps: splits and the dropped lo.lo term (3 * 2^-22) + fp32 accumulation of 3 K' products (3 * 32 KS * 2^-24), doubled
     const float eps = NP == 3 ? PSH_EMX_EPS_REL + 2.0f * (float)(3 * 32 * dm.KS) / 16777216.0f
-                              : 1.001f * (1.0f / 1024.0f + 1.0f / 4194304.0f) + 2.0f * (float)(32 * dm.KS) / 16777216.0f;
+                              : 1.001f * (1.0f / 1024.0f + 1.0f / 4194304.0f) + 2.0f * (float)(32 * dm.KS) / 16777216.0f + (QM ? 1.0f / 524288.0f : 0.0f);
     const float cerr = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(eps * __builtin_sqrtf(__uint_as_float((unsigned)ctl[2])) * 1.001f)));
     const float kl1max = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(ctl[3]));
     constexpr float eps2 = 1.001f * (1.0f / 1024.0f + 1.0f / 4194304.0f) + 64.0f / 16777216.0f;
@@ -303,6 +315,7 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
     for (int i = 0; i < PSH_EMX_MAX_D; ++i) perm_s[i] = __builtin_amdgcn_readfirstlane(permL[i]);
     // first steps of the product loop's groups (slots 0-3 / 4-7 / 8-11), latest first; NG < 3: the plain loop runs every step
     const int gs0 = __builtin_amdgcn_readfirstlane(ctl[5]), gs1 = __builtin_amdgcn_readfirstlane(ctl[6]), gs2 = __builtin_amdgcn_readfirstlane(ctl[7]);
+    const int gs3 = __builtin_amdgcn_readfirstlane(ctl[20]);                            // slot 11 alone: steps [gs3, gs2)
 
     // exact verification of the queued survivors: lane (e, i) runs row i of survivor e (4 per pass), the oracle's order:
     // hy_i = fma chain over all K taps, D_i = hx_i - hy_i, acc = fma chain over i.
@@ -572,10 +585,30 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                     // [gs0, KS) all twelve -- the ring below.  The first two keep the ring's rule (one read between two MFMAs, a
                     // group's fragments requested a group of MFMAs ahead) with two buffers; a step's A fragments move between
                     // two register sets (8 moves a step: these phases are short).
-                    int ks0 = gs2 < dm.KS ? gs2 : dm.KS;
+                    int ks0 = gs3 < gs2 ? gs3 : gs2;
+                    ks0 = ks0 < dm.KS ? ks0 : dm.KS;
                     const _Float16* bpk = bp + 32 * ks0;
                     const _Float16* apk = ap + 32 * ks0;
                     a0 = *reinterpret_cast<const f16x8*>(apk); a1 = *reinterpret_cast<const f16x8*>(apk + 256);
+                    if (ks0 < gs2) {
+                        // slot 11 alone (configs[4]: the 252-tap low-pass beside 220- and 110-tap rows -- three steps of 2 MFMAs
+                        // instead of 8): its fragments two steps ahead (two MFMAs do not cover an LDS read)
+                        f16x8 fa = *reinterpret_cast<const f16x8*>(bpk + (size_t)11 * rstride);
+                        f16x8 fb = *reinterpret_cast<const f16x8*>(bpk + (size_t)11 * rstride + 32);
+                        b0 = *reinterpret_cast<const f16x8*>(apk + 32); b1 = *reinterpret_cast<const f16x8*>(apk + 256 + 32);
+#pragma unroll 1
+                        for (; ks0 < gs2 && ks0 < dm.KS; ++ks0) {
+                            // (reads past step KS -- inside the block's LDS -- feed nothing)
+                            const f16x8 fc = *reinterpret_cast<const f16x8*>(bpk + (size_t)11 * rstride + 64);
+                            const f16x8 c0 = *reinterpret_cast<const f16x8*>(apk + 64), c1 = *reinterpret_cast<const f16x8*>(apk + 256 + 64);
+                            __builtin_amdgcn_sched_barrier(0);
+                            C[0][11] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, fa, C[0][11], 0, 0, 0);
+                            C[1][11] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, fa, C[1][11], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            fa = fb; fb = fc; a0 = b0; a1 = b1; b0 = c0; b1 = c1;
+                            bpk += 32; apk += 32;
+                        }
+                    }
                     if (ks0 < gs1) {
 #pragma unroll
                         for (int r4 = 0; r4 < 4; ++r4) F2[r4] = *reinterpret_cast<const f16x8*>(bpk + (size_t)(8 + r4) * rstride);
@@ -739,9 +772,10 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
             }
             if constexpr (QM) {
                 // ---- the per-query pass on the matrix cores
-                // the scale of the accumulators: |H_i| <= ymax max_i ||ker_i||_1 -> [8192, 16384) (f16 keeps 11 bits down to 6e-5)
-                const unsigned bb = __float_as_uint(ymax * kl1max);
-                int ec = bb >= 0x00800000u ? 14 - ((int)((bb >> 23) & 255u) - 126) : 0;
+                // the scale of the accumulators: |H_i| <= ymax max_i ||ker_i||_1 -> [8192, 32768) in the product's units (f16 keeps 11 bits down to 6e-5)
+                // (sc = 1 / inv: the accumulators are the A fragments' values already)
+                int ec = ey + ekc;
+                const bool clamped = ec > 100 || ec < -100;                             // (fp32's ends: such a half segment keeps every window)
                 ec = ec > 100 ? 100 : (ec < -100 ? -100 : ec);
                 const float sc = __uint_as_float((unsigned)(127 + ec) << 23);
                 wave_lds_fence();                                                       // the half before this one has read nhL
@@ -754,20 +788,8 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                 // the C operand of the slot's first MFMA;  v > thr  <=>  D' < thr / kk, the smallest v the largest D'.  (The MFMA adds
                 // nt / kk in fp32 like any partial sum: the (1 - 2^-20) on the energies covers 16 such roundings.)
                 const float inv_kk = (-0.5f * sqc) * sc;
-                const bool badC = __any(bad0) || eqc + ec > 120 || eqc + ec < -120;
+                const bool badC = __any(bad0) || clamped || eqc + ec > 120 || eqc + ec < -120;
                 f16x8 A2[8][(4 * NG > 8) ? 2 : 1];
-                {
-                    // product units -> the A fragments' scale in one (power-of-two) factor, again pair-wise in place
-                    const float k2 = inv * sc;
-                    const f32x2v k22 = f32x2v{k2, k2};
-#pragma unroll
-                    for (int i = 0; i < 4 * NG; ++i)
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) {
-                            const f32x2v lo2 = __builtin_shufflevector(C[mt][i], C[mt][i], 0, 1) * k22, hi2 = __builtin_shufflevector(C[mt][i], C[mt][i], 2, 3) * k22;
-                            C[mt][i] = __builtin_shufflevector(lo2, hi2, 0, 1, 2, 3);
-                        }
-                }
                 {
                     const float nf = ((1.0f - eps2 - 1.0f / 4096.0f) * (1.0f - 1.0f / 1048576.0f)) * inv_kk;
 #pragma unroll
@@ -799,7 +821,7 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                     for (int sl = 0; sl < 8; ++sl) D[sl] = *reinterpret_cast<const f32x4*>(nhL + sl * 64 + kqp * 16 + 4 * gq);
                     const float st2 = qcv[0] + Rad;
                     const float thr = qv ? (st2 * st2 * (1.0f + 1.0f / 16384.0f) - qcv[1]) + thrG : -__uint_as_float(PSH_INF_BITS);
-                    const float thrp = thr * inv_kk;                                    // (a query that is not there: +inf -- nothing is above it)
+                    const float thrp = clamped ? -__uint_as_float(PSH_INF_BITS) : thr * inv_kk;   // (a query that is not there: +inf -- nothing is above it)
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int sl = 0; sl < 8; ++sl) D[sl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[sl][0], B2[0], D[sl], 0, 0, 0);
