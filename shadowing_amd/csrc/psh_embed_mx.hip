@@ -590,48 +590,67 @@ __global__ __launch_bounds__(PSH_EMX_THREADS) void embed_mx_kernel(ScanArgs a) {
                     const _Float16* bpk = bp + 32 * ks0;
                     const _Float16* apk = ap + 32 * ks0;
                     a0 = *reinterpret_cast<const f16x8*>(apk); a1 = *reinterpret_cast<const f16x8*>(apk + 256);
+                    // (In all three phases the register sets ROTATE BY NAME -- two or three steps per turn, the set the next phase
+                    //  expects restored once at the exit: as "next = current" moves inside the loops they were 24 v_mov per step,
+                    //  96 cycles beside a step's 32 - 128 cycles of MFMAs.)
                     if (ks0 < gs2) {
                         // slot 11 alone (configs[4]: the 252-tap low-pass beside 220- and 110-tap rows -- three steps of 2 MFMAs
-                        // instead of 8): its fragments two steps ahead (two MFMAs do not cover an LDS read)
+                        // instead of 8): its fragments two steps ahead (two MFMAs do not cover an LDS read); reads past step KS --
+                        // inside the block's LDS -- feed nothing
+                        const int lim0 = gs2 < dm.KS ? gs2 : dm.KS;
                         f16x8 fa = *reinterpret_cast<const f16x8*>(bpk + (size_t)11 * rstride);
-                        f16x8 fb = *reinterpret_cast<const f16x8*>(bpk + (size_t)11 * rstride + 32);
+                        f16x8 fb = *reinterpret_cast<const f16x8*>(bpk + (size_t)11 * rstride + 32), fc;
+                        f16x8 c0, c1;
                         b0 = *reinterpret_cast<const f16x8*>(apk + 32); b1 = *reinterpret_cast<const f16x8*>(apk + 256 + 32);
-#pragma unroll 1
-                        for (; ks0 < gs2 && ks0 < dm.KS; ++ks0) {
-                            // (reads past step KS -- inside the block's LDS -- feed nothing)
-                            const f16x8 fc = *reinterpret_cast<const f16x8*>(bpk + (size_t)11 * rstride + 64);
-                            const f16x8 c0 = *reinterpret_cast<const f16x8*>(apk + 64), c1 = *reinterpret_cast<const f16x8*>(apk + 256 + 64);
-                            __builtin_amdgcn_sched_barrier(0);
-                            C[0][11] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, fa, C[0][11], 0, 0, 0);
-                            C[1][11] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, fa, C[1][11], 0, 0, 0);
-                            __builtin_amdgcn_sched_barrier(0);
-                            fa = fb; fb = fc; a0 = b0; a1 = b1; b0 = c0; b1 = c1;
-                            bpk += 32; apk += 32;
+#define PSH_EMX_ONE(FU, U0, U1, FL, L0, L1)                                                                                            \
+                        FL = *reinterpret_cast<const f16x8*>(bpk + (size_t)11 * rstride + 64);                                         \
+                        L0 = *reinterpret_cast<const f16x8*>(apk + 64); L1 = *reinterpret_cast<const f16x8*>(apk + 256 + 64);          \
+                        __builtin_amdgcn_sched_barrier(0);                                                                             \
+                        C[0][11] = __builtin_amdgcn_mfma_f32_16x16x32_f16(U0, FU, C[0][11], 0, 0, 0);                                  \
+                        C[1][11] = __builtin_amdgcn_mfma_f32_16x16x32_f16(U1, FU, C[1][11], 0, 0, 0);                                  \
+                        __builtin_amdgcn_sched_barrier(0);                                                                             \
+                        bpk += 32; apk += 32; ++ks0;
+                        for (;;) {
+                            PSH_EMX_ONE(fa, a0, a1, fc, c0, c1)
+                            if (ks0 >= lim0) { a0 = b0; a1 = b1; break; }
+                            PSH_EMX_ONE(fb, b0, b1, fa, a0, a1)
+                            if (ks0 >= lim0) { a0 = c0; a1 = c1; break; }
+                            PSH_EMX_ONE(fc, c0, c1, fb, b0, b1)
+                            if (ks0 >= lim0) break;
                         }
+#undef PSH_EMX_ONE
                     }
-                    if (ks0 < gs1) {
+                    if (ks0 < gs1 && ks0 < dm.KS) {
+                        const int lim1 = gs1 < dm.KS ? gs1 : dm.KS;
 #pragma unroll
                         for (int r4 = 0; r4 < 4; ++r4) F2[r4] = *reinterpret_cast<const f16x8*>(bpk + (size_t)(8 + r4) * rstride);
-#pragma unroll 1
-                        for (; ks0 < gs1 && ks0 < dm.KS; ++ks0) {
+                        for (;;) {
                             PSH_EMX_STEP(a0, a1, F2, 2, F0, 2, 32, b0 = *reinterpret_cast<const f16x8*>(apk + 32),
                                          b1 = *reinterpret_cast<const f16x8*>(apk + 256 + 32))
-#pragma unroll
-                            for (int r4 = 0; r4 < 4; ++r4) F2[r4] = F0[r4];
-                            a0 = b0; a1 = b1;
-                            bpk += 32; apk += 32;
+                            bpk += 32; apk += 32; ++ks0;
+                            if (ks0 >= lim1) { a0 = b0; a1 = b1; break; }
+                            PSH_EMX_STEP(b0, b1, F0, 2, F2, 2, 32, a0 = *reinterpret_cast<const f16x8*>(apk + 32),
+                                         a1 = *reinterpret_cast<const f16x8*>(apk + 256 + 32))
+                            bpk += 32; apk += 32; ++ks0;
+                            if (ks0 >= lim1) break;
                         }
+                        // (the next phase fetches group 2's fragments of its first step itself)
                     }
                     if (ks0 < gs0 && ks0 < dm.KS) {
+                        const int lim2 = gs0 < dm.KS ? gs0 : dm.KS;
 #pragma unroll
                         for (int r4 = 0; r4 < 4; ++r4) F1[r4] = *reinterpret_cast<const f16x8*>(bpk + (size_t)(4 + r4) * rstride);
-#pragma unroll 1
-                        for (; ks0 < gs0 && ks0 < dm.KS; ++ks0) {
+                        for (;;) {
                             PSH_EMX_STEP(a0, a1, F1, 1, F2, 2, 0, (void)0, (void)0)
                             PSH_EMX_STEP(a0, a1, F2, 2, F1, 1, 32, b0 = *reinterpret_cast<const f16x8*>(apk + 32),
                                          b1 = *reinterpret_cast<const f16x8*>(apk + 256 + 32))
-                            a0 = b0; a1 = b1;
-                            bpk += 32; apk += 32;
+                            bpk += 32; apk += 32; ++ks0;
+                            if (ks0 >= lim2) { a0 = b0; a1 = b1; break; }
+                            PSH_EMX_STEP(b0, b1, F1, 1, F2, 2, 0, (void)0, (void)0)
+                            PSH_EMX_STEP(b0, b1, F2, 2, F1, 1, 32, a0 = *reinterpret_cast<const f16x8*>(apk + 32),
+                                         a1 = *reinterpret_cast<const f16x8*>(apk + 256 + 32))
+                            bpk += 32; apk += 32; ++ks0;
+                            if (ks0 >= lim2) break;
                         }
                     } else if (ks0 < dm.KS) {
 #pragma unroll
