@@ -645,8 +645,13 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#ifdef PSH_TUNING
+        const int nks_run = (a.dbg & 8) ? 1 : nks;                            // ablation: one K-step (results invalid)
+#else
+        const int nks_run = nks;
+#endif
 #pragma unroll 2
-        for (int s = 0; s < nks; ++s) {
+        for (int s = 0; s < nks_run; ++s) {
             const int ai = mx_half(32 * m + 16 * s + 8 * hk);
             const f16x8 e2 = *reinterpret_cast<const f16x8*>(a2 + ai);
             const f16x8 e1 = *reinterpret_cast<const f16x8*>(a1 + ai);
@@ -659,6 +664,9 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
         bool keep = false;                                                    // NaN-safe: !(t^ > thr)
 #pragma unroll
         for (int r = 0; r < 16; ++r) keep = keep || !(acc[r] > thr2);
+#ifdef PSH_TUNING
+        if (a.dbg & 4) keep = false;                                          // ablation: no survivor handling (results invalid)
+#endif
         if (__any(keep)) {
             // the survivors (about one segment in four holds any): the segment's fp32 values come back from memory in ONE
             // coalesced round trip (streamed a microsecond ago: L2 / MALL) into the wave's f16 arrays -- their fragments are
