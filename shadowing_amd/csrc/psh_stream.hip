@@ -545,7 +545,16 @@ __device__ __forceinline__ void stream_scan_body(const ScanArgs& a, const FusedA
 // the f16 arrays grow with W and the tables take its place -- so a segment that holds survivors fetches its fp32 values again (one
 // coalesced round trip: the segment was streamed a microsecond ago, L2 / MALL) into the f16 arrays' LDS for the exact chains.  Candidates, status protocol and the launches around it (sample + levels,
 // ranking) are stream_scan_kernel's.
-__host__ __device__ inline int stream_long_nhalf(int W) { return ((992 + 16 * stream_ksteps(W) + 127) / 128) * 128; }
+// The long-window scan's f16 arrays (round 5, second layout): ROWS of 32 samples, a row of y^ followed by the same row of
+// (y~^2)^ and 8 halves of padding -- 72 halves = 144 bytes = 36 dwords a row: the 16 lanes of a ds_read_b128 group (rows m
+// with all 16 residues mod 16, 4 dwords each) fall on 36 m mod 64 = 16 different multiples of 4.  The fragment of row m,
+// K-step s lies at row m + (s >> 1), halves 16 (s & 1) + 8 hk .. + 7 of it: per PAIR of K-steps one pointer moves by one row
+// and every other offset is an immediate -- the slot-rotation layout of the short kernels (mx_half) cost the K-loop 7 vector
+// instructions per step for the address alone, and on this part vector instructions ADD to the matrix cores' time (A.5).
+#define PSH_LONG_ROW 72
+__host__ __device__ inline int stream_long_rows(int W) { return 31 + (stream_ksteps(W) + 1) / 2; }                 // rows the band of row 31 reaches
+__host__ __device__ inline int stream_long_nhalf(int W) { return stream_long_rows(W) * PSH_LONG_ROW; }             // halves per wave (both arrays)
+__device__ __forceinline__ int long_half(int idx) { return (idx >> 5) * PSH_LONG_ROW + (idx & 31); }                // logical sample -> its y^ half ((y~^2)^: + 32)
 
 template <bool ALIGNED>
 __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(ScanArgs a, FusedArgs f) {
@@ -559,11 +568,9 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
     const int nks = stream_ksteps(W), nhalf = stream_long_nhalf(W);
     int* ctl = reinterpret_cast<int*>(smem);                                 // 64 control words
     u32x4* fl = reinterpret_cast<u32x4*>(ctl + 64);                           // NFL entries {acc bits, r, t, query}
-    _Float16* bxl = reinterpret_cast<_Float16*>(fl + NFL);                    // [K-step][lane][8]: -2 x~ shifted by the lane's column
-    _Float16* bol = bxl + (size_t)nks * 64 * 8;                               // [K-step][lane][8]: the band of ones
-    _Float16* ah0 = bol + (size_t)nks * 64 * 8;
-    _Float16* a1 = ah0 + (size_t)wave * 2 * nhalf;                            // y^
-    _Float16* a2 = a1 + nhalf;                                                // (y~^2)^
+    _Float16* bxl = reinterpret_cast<_Float16*>(fl + NFL);                    // [K-step]{[lane][8]: -2 x~ shifted by the lane's column; [lane][8]: the band of ones}
+    _Float16* ah0 = bxl + (size_t)nks * 2 * 64 * 8;
+    _Float16* a1 = ah0 + (size_t)wave * nhalf;                                // rows of {y^ [32], (y~^2)^ [32], pad [8]}
     FusedHdr* hdr = f.hdr;
     const StreamCtl* sc = &hdr->stream;
 
@@ -586,15 +593,15 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
     // the tables: the sample kernel's fragments of the shifted query (plain loads: an earlier launch on this stream), the band of
     // ones by arithmetic
     for (int i = tid; i < nks * 64; i += PSH_SCAN_THREADS) {
-        *reinterpret_cast<f16x8*>(bxl + (size_t)i * 8) = *reinterpret_cast<const f16x8*>(hdr->bxtab + (size_t)i * 8);
         const int s = i >> 6, l = i & 63, n = l & 31, hk = l >> 5;
+        *reinterpret_cast<f16x8*>(bxl + ((size_t)s * 128 + l) * 8) = *reinterpret_cast<const f16x8*>(hdr->bxtab + (size_t)i * 8);
         f16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int j = 16 * s + 8 * hk + e - n;
             o[e] = (_Float16)((j >= 0 && j < W) ? 1.0f : 0.0f);
         }
-        *reinterpret_cast<f16x8*>(bol + (size_t)i * 8) = o;
+        *reinterpret_cast<f16x8*>(bxl + ((size_t)s * 128 + 64 + l) * 8) = o;
     }
     const unsigned armed_w = sc->armed;
     const float scale = __uint_as_float(sc->scale_bits);
@@ -602,16 +609,10 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
     if (tid == 0) { ctl[S_FRONT] = 0; ctl[S_NEXT] = NW; }
     {   // every slot of the f16 arrays a segment does not write must be finite (0 * NaN poisons a row)
         unsigned* z = reinterpret_cast<unsigned*>(a1);
-        for (int i = lane; i < nhalf; i += 64) z[i] = 0u;                     // 2 arrays x nhalf halves = nhalf dwords
+        for (int i = lane; i < nhalf / 2; i += 64) z[i] = 0u;
     }
     __syncthreads();
     if (armed_w == 0u) return;                                                // uniform: the ranking reports PSH_STATUS_RETRY
-    // K-steps whose band of ones is all ones in every lane: column n <= 31 starts its band at tap n, so from step 2 on; it ends
-    // at tap n + W - 1 >= W - 1, so up to the step that ends at tap W - 1 at the latest: 16 s + 15 <= W - 1
-    const int ones_lo = 2, ones_hi = (W - 16) / 16;                           // interior steps: ones_lo <= s <= ones_hi
-    f16x8 ones8;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones8[e] = (_Float16)1.0f;
     const const_f32p x = (const_f32p)a.queries;
     auto grab = [&]() -> unsigned {
         int v = 0;
@@ -632,8 +633,9 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
                 if (q < PSH_NSTAGE - 1 || m < nq4) {
                     const f32x4 v = st.v[q] * scale;
                     const f32x4 v2 = v * v;
-                    *reinterpret_cast<f16x4*>(a1 + mx_half(4 * m)) = __builtin_convertvector(v, f16x4);
-                    *reinterpret_cast<f16x4*>(a2 + mx_half(4 * m)) = __builtin_convertvector(v2, f16x4);
+                    _Float16* dst = a1 + (m >> 3) * PSH_LONG_ROW + 4 * (m & 7);   // (= long_half(4 m))
+                    *reinterpret_cast<f16x4*>(dst) = __builtin_convertvector(v, f16x4);
+                    *reinterpret_cast<f16x4*>(dst + 32) = __builtin_convertvector(v2, f16x4);
                 }
             }
         }
@@ -642,7 +644,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
         if (un < u_hi) load_unit(st, un);
 
         const int m = lane & 31, hk = lane >> 5;
-        f32x16 acc;
+        f32x16 acc;                                                           // (ONE chain: energies and correlation into two tiles, summed at the end, was 4 % slower)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 #ifdef PSH_TUNING
@@ -650,16 +652,31 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
 #else
         const int nks_run = nks;
 #endif
-#pragma unroll 2
-        for (int s = 0; s < nks_run; ++s) {
-            const int ai = mx_half(32 * m + 16 * s + 8 * hk);
-            const f16x8 e2 = *reinterpret_cast<const f16x8*>(a2 + ai);
-            const f16x8 e1 = *reinterpret_cast<const f16x8*>(a1 + ai);
-            const f16x8 bx = *reinterpret_cast<const f16x8*>(bxl + ((size_t)s * 64 + lane) * 8);
-            f16x8 bo = ones8;
-            if (s < ones_lo || s > ones_hi) bo = *reinterpret_cast<const f16x8*>(bol + ((size_t)s * 64 + lane) * 8);   // (uniform)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e2, bo, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, bx, acc, 0, 0, 0);
+        {
+            // two K-steps per turn: 8 fragment reads off two pointers with immediate offsets, 4 MFMAs, 2 pointer moves (the band
+            // of ones comes from its table in every step: a read costs the vector ALUs nothing, a constant kept in registers was
+            // rebuilt with 4 moves per step)
+            const _Float16* pa = a1 + m * PSH_LONG_ROW + 8 * hk;
+            const _Float16* pb = bxl + lane * 8;
+#define PSH_LONG_STEP(AOFF, BOFF)                                                                                                      \
+            {                                                                                                                          \
+                const f16x8 e1 = *reinterpret_cast<const f16x8*>(pa + (AOFF));                                                         \
+                const f16x8 e2 = *reinterpret_cast<const f16x8*>(pa + (AOFF) + 32);                                                    \
+                const f16x8 bx = *reinterpret_cast<const f16x8*>(pb + (BOFF));                                                         \
+                const f16x8 bo = *reinterpret_cast<const f16x8*>(pb + (BOFF) + 64 * 8);                                                \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e2, bo, acc, 0, 0, 0);                                                    \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, bx, acc, 0, 0, 0);                                                    \
+            }
+            int s = 0;
+#pragma unroll 1
+            for (; s + 1 < nks_run; s += 2) {
+                PSH_LONG_STEP(0, 0)
+                PSH_LONG_STEP(16, 128 * 8)
+                pa += PSH_LONG_ROW;
+                pb += 2 * 128 * 8;
+            }
+            if (s < nks_run) PSH_LONG_STEP(0, 0)
+#undef PSH_LONG_STEP
         }
         bool keep = false;                                                    // NaN-safe: !(t^ > thr)
 #pragma unroll
@@ -673,7 +690,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
             // consumed -- and the exact chains (the reference's order: D = fl(x_j - y_j), acc = fma(D, D, acc)) read them there.
             // (Each survivor reading its W samples from memory itself was W / 4 dependent round trips: W = 64 at +25 % of the
             // W = 20 step.)
-            float* tile = reinterpret_cast<float*>(a1);                       // nfloat floats <= 4 nhalf bytes (both arrays)
+            float* tile = reinterpret_cast<float*>(a1);                       // nfloat floats <= 2 nhalf bytes (the wave's rows)
             {
                 Stage sv;
                 stage_load<ALIGNED>(sv, a.dataset + row * a.T, a.T, seg_start, nfloat, lane);
@@ -709,9 +726,9 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
             }
             // the arrays' tails past what a segment's conversion writes hold fp32 bits now: zeros again (0 * NaN poisons a row)
             wave_lds_fence();
-            for (int idx = 4 * ((nfloat + 3) >> 2) + 4 * lane; idx < nhalf; idx += 256) {
-                *reinterpret_cast<f16x4*>(a1 + mx_half(idx)) = f16x4{0, 0, 0, 0};
-                *reinterpret_cast<f16x4*>(a2 + mx_half(idx)) = f16x4{0, 0, 0, 0};
+            for (int idx = 4 * ((nfloat + 3) >> 2) + 4 * lane; idx < 32 * stream_long_rows(W); idx += 256) {
+                *reinterpret_cast<f16x4*>(a1 + long_half(idx)) = f16x4{0, 0, 0, 0};
+                *reinterpret_cast<f16x4*>(a1 + long_half(idx) + 32) = f16x4{0, 0, 0, 0};
             }
         }
         wave_lds_fence();  // all lanes done with the arrays before they are overwritten
@@ -851,7 +868,7 @@ size_t stream_scan_shmem_bytes(int tile_floats) { return stream_scan_shmem_bytes
 bool stream_long_supported(int W) { return W >= 34 && W <= 256; }
 size_t stream_scan_long_shmem_bytes(int W) {
     return (size_t)PSH_STREAM_FIXED_BYTES + (size_t)PSH_FUSED_FRONT * 16 + (size_t)2 * stream_ksteps(W) * 64 * 8 * sizeof(_Float16)
-           + (size_t)(PSH_SCAN_THREADS / 64) * 2 * stream_long_nhalf(W) * sizeof(_Float16);
+           + (size_t)(PSH_SCAN_THREADS / 64) * stream_long_nhalf(W) * sizeof(_Float16);
 }
 size_t stream_sample_shmem_bytes(int tile_floats) {
     const size_t t = (size_t)tile_floats * sizeof(float), h = (size_t)PSH_STREAM_HIST * sizeof(unsigned);
