@@ -3,7 +3,11 @@ matrix-core steps inside the call), the same call with PSH_FLAG_FILTER_VALU (one
 loop of one-query calls, on configs[1]'s ensemble (--walk: price levels, the bounds' worst case).  One JSON line per (W, B)."""
 import argparse
 import json
+import sys
 import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 
 import torch
 
