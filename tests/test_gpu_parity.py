@@ -496,6 +496,20 @@ def test_long_window_batches_loop_over_the_one_query_step(hip_device, oracle_mod
     assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, f"long-window batch W={W} B={B}, checked with a short hint")
 
 
+def test_shape_fuzz_cut(hip_device):
+    """A cut of tests/stress/stress_shapes.py (the whole script: 1300 cases on an MI355X in round 5, no mismatch): random window
+    lengths 1 .. 256, 1 .. 20 queries, ragged rows, adversarial and smooth ensembles, both flag settings, good and short
+    hints, through the status protocol -- whatever launch structure the library picks -- against the oracle, bit for bit."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("stress_shapes", Path(__file__).parent / "stress" / "stress_shapes.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad, seen = mod.run(11, 70, verbose=False)
+    assert bad == 0
+    assert {0, 2, 3} <= set(seen), seen                     # separate launches, the fused launch, the three launches: all taken
+
+
 def test_unsorted_flag_returns_the_same_set(hip_device, oracle_mod):
     """PSH_FLAG_UNSORTED (what the sharded scan asks of its local selection): the k best, any order."""
     ds = syn.dataset(4096, 2048, 1400)
