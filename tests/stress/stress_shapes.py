@@ -17,7 +17,7 @@ from shadowing_amd import _native
 def run(seed: int, n_cases: int, verbose: bool = True):
     """(mismatches, {path: cases}) of `n_cases` random cases."""
     dev = torch.device("cuda", 0)
-    rng = np.random.default_rng(cseed)
+    rng = np.random.default_rng(seed)
     bad = 0
     paths_seen = {}
     t_all = time.time()
