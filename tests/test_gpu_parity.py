@@ -416,6 +416,12 @@ def test_long_window_shadow_with_paths_and_adversarial_data(hip_device, oracle_m
     od, opaths, oidx = oracle_mod.shadow(ds, q[None, :], 300, h)
     assert_exact(d, idx, od, oidx, "Identity(126) shadow")
     assert np.array_equal(paths, opaths) and obj.last_path == "hip"
+    # several query dates with the long context in ONE call (the loop of one-query steps inside psh_scan_topk)
+    qb = syn.rolling_queries(5, W, 1802)
+    d, paths, idx = obj.shadow(qb, k=200, cuda=True)
+    od, opaths, oidx = oracle_mod.shadow(ds, qb, 200, h)
+    assert_exact(d, idx, od, oidx, "Identity(126) shadow, 5 queries")
+    assert np.array_equal(paths, opaths) and obj.last_path == "hip"
     from shadowing_amd import _native
     for kind in ("spikes", "planted_matches", "scale_down", "quiet_stretches", "zero_constant_rows", "huge_queries"):
         dsa, qa = make(kind, 2048, 2048, 1, 64, 5, 1900)
