@@ -502,6 +502,35 @@ def test_long_window_batches_loop_over_the_one_query_step(hip_device, oracle_mod
     assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, f"long-window batch W={W} B={B}, checked with a short hint")
 
 
+@pytest.mark.parametrize("B,W,r_offset,dup", [(1, 20, 0, False), (3, 20, 0, False), (1, 64, 0, False), (1, 20, 1 << 22, False), (2, 24, 0, True)])
+def test_many_admitted_windows_are_ranked_below_a_level(hip_device, oracle_mod, B, W, r_offset, dup):
+    """Tens of thousands of admitted windows per query (a generous hint here; a smooth ensemble in practice) through the ranking
+    launch of the three launches: lists far beyond a block's 64 entries and the header's 16384, the k best in (d, r, t) order,
+    packed and unpacked keys, ties everywhere (duplicated rows).  (A ranking that first finds a level holding the k best and
+    ranks only the candidates below it -- three counting passes on the distance bits -- was built for this case in round 5 and
+    was no faster: a pass by one wave is bound by the latency of its loads, not by the entries it moves; DESIGN_APPENDIX A.5.)"""
+    from shadowing_amd import _native
+    R, T, h, k, m = 6000, 2048, 5, 1024, 30000
+    ds = syn.dataset(R, T, 2500 + W + B)
+    if dup:
+        ds[1::2] = ds[0::2]                                    # every distance twice: ties everywhere, also at the level's edge
+    q = syn.gbm_log_returns((B, W), 2600 + W + B)
+    od, oidx = oracle_mod.scan_topk(ds, q, m, h=h, r_offset=r_offset) if r_offset else oracle_mod.scan_topk(ds, q, m, h=h)
+    lev = ((od[:, m - 1].astype(np.float64) ** 2) * (q.astype(np.float64) ** 2).sum(axis=1) * (1.0 + 1e-6)).astype(np.float32)
+    ds_t = torch.as_tensor(np.ascontiguousarray(ds[:, 0, :])).to(hip_device)
+    q_t = torch.as_tensor(q).to(hip_device)
+    ws = _native.Workspace(hip_device)
+    info = {}
+    d, idx, st = _native.scan_topk(ds_t, q_t, k, h=h, r_offset=r_offset, workspace=ws, flags=_native.FLAG_OVERLAP, info=info,
+                                   tau_hint=torch.as_tensor(lev).to(hip_device))
+    torch.cuda.synchronize()
+    assert info["path"] == 3 and not st.cpu().numpy().any(), (info, st.tolist())
+    lay = _native.candidates_layout(R, T, B, W, h, k, ws.buf.numel())
+    ncand = ws.buf[lay["hdr_stream_ncand"]: lay["hdr_stream_ncand"] + 4 * B].view(torch.int32).cpu().numpy()
+    assert (ncand > 8192).all() and (ncand >= m - 64).all(), ncand       # the mode under test; ~m windows lie below the level
+    assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od[:, :k], oidx[:, :k], f"many candidates B={B} W={W} r_offset={r_offset}")
+
+
 def test_shape_fuzz_cut(hip_device):
     """A cut of tests/stress/stress_shapes.py (the whole script: 1300 cases on an MI355X in round 5, no mismatch): random window
     lengths 1 .. 256, 1 .. 20 queries, ragged rows, adversarial and smooth ensembles, both flag settings, good and short
