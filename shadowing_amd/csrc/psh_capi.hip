@@ -604,6 +604,15 @@ int psh_scan_topk_embedded_exhaustive(int device, void* stream, const float* dat
                                 out_d, out_idx, out_status, workspace, workspace_bytes, profile);
 }
 
+// queries one step of the long-window scan serves (34 <= W <= 256): up to three -- as many as put their fragment tables in LDS beside
+// the waves' rows (W <= ~230: three; up to 256: two); 0 = not a long window
+static int long_queries_per_step(int W) {
+    if (!stream_long_supported(W)) return 0;
+    for (int nq = PSH_STREAM_MAX_Q; nq > 1; --nq)
+        if (stream_scan_long_shmem_bytes(W, nq) <= PSH_LDS_BYTES) return nq;
+    return 1;
+}
+
 static int scan_topk_impl(int device, void* stream, const float* dataset, int64_t R, int64_t T, int64_t r_offset,
                           const float* queries, const float* qnorm, int B, int W, int h, int k,
                           const float* ker, int emb_d,
@@ -615,13 +624,15 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     if (!out_status) return PSH_ERR_ARG;
     // Several queries with a window the batched kernels' bands do not reach (they stop at W = 25): a LOOP of the steps that do
     // have a matrix-core rejection test, inside the call --
-    //   34 <= W <= 256: one query per step (the three launches with the long-window scan, psh_stream.hip);
+    //   34 <= W <= 256: up to three queries per step (the three launches with the long-window scan, psh_stream.hip: the
+    //                   queries share the pass, the conversion and the energies' MFMAs);
     //   26 <= W <= 33, four queries and more: three queries per step (the three launches' 2-3 query form).
     // The one-pass vector-ALU filter costs W fma per window and query: R = 32768, T = 4096, W = 126 -- 2 / 4 / 16 / 64 queries
     // 1.14 / 2.19 / 8.6 / 33.6 ms in one pass, 0.34 / 0.65 / 2.6 / 10.6 ms as a loop; W = 252: 2.2 .. 67 against 0.50 .. 16.2 ms
     // (tools/long_batch_probe.py).  Status words stay per query; a RETRY of any step sends the caller's WHOLE call to
     // PSH_FLAG_NO_FUSE, as the protocol says.
-    const int per_step = !ker && p.Tp > 1 ? (stream_long_supported(W) && B > 1 ? 1 : (W >= 26 && W <= 33 && B > PSH_STREAM_MAX_Q ? PSH_STREAM_MAX_Q : 0)) : 0;
+    const int long_q = long_queries_per_step(W);
+    const int per_step = !ker && p.Tp > 1 ? (long_q > 0 && B > long_q ? long_q : (W >= 26 && W <= 33 && B > PSH_STREAM_MAX_Q ? PSH_STREAM_MAX_Q : 0)) : 0;
     if (per_step && !(profile && profile->mode == PSH_PROFILE_STAGES) && !(flags_of(profile) & (PSH_FLAG_FILTER_VALU | PSH_FLAG_NO_FUSE))) {
         psh_profile sub;
         for (int b = 0; b < B; b += per_step) {
@@ -727,7 +738,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
         const bool one_overlap = use_mx && B == 1 && (flags_of(profile) & PSH_FLAG_OVERLAP);
         // ONE query with a long window (34 <= W <= 256): the same three launches, flag or no flag, with the scan's banded product
         // as a K-loop (stream_scan_long_kernel) -- otherwise such a call has only the vector-ALU filter of scan_kernel
-        const bool one_long = !p.ker && !rows_path && B == 1 && stream_long_supported(p.W) && !(flags_of(profile) & PSH_FLAG_FILTER_VALU);
+        const bool one_long = !p.ker && !rows_path && long_q > 0 && B <= long_q && !(flags_of(profile) & PSH_FLAG_FILTER_VALU);
         if ((small_batch || one_overlap || one_long) && !rows_path && !stages && !(flags_of(profile) & PSH_FLAG_NO_FUSE) &&
             (scan_fused_supported(p.W) || one_long)) {
             int ncu = 0;
@@ -764,7 +775,7 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
             const int tile_fl = (logical + ((logical >> 6) << 2) + 4 + 3) & ~3;
             int tb = 0;
             while ((1ll << tb) < p.Tp) ++tb;
-            if ((one_long ? stream_scan_long_shmem_bytes(p.W) : stream_scan_shmem_bytes_q(tile_fl, B)) <= PSH_LDS_BYTES &&
+            if ((one_long ? stream_scan_long_shmem_bytes(p.W, B) : stream_scan_shmem_bytes_q(tile_fl, B)) <= PSH_LDS_BYTES &&
                 ((units_p >= 256 && r2p <= units_p / 2) || hint) &&
                 5 * (int64_t)k <= (int64_t)cand_cap && 5 * (int64_t)k * B <= grid_s * front * 2) {
                 Plan plan_s{(int)grid_s, 1, B, tile_fl, 0};

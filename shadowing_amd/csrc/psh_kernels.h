@@ -80,7 +80,8 @@ struct FusedHdr {
     // psh_stream.hip: the B fragments of the shifted query the sample kernel prepares for the scan (whose candidates go to
     // `cand` as ONE compact list of {d bits, r, t, -} entries, StreamCtl::ncand of them)
     // (one query with a LONG window, 34 <= W <= 256: [K-step][lane][8 halves] for up to PSH_STREAM_LONG_KS steps of the band)
-    unsigned short bxtab[PSH_STREAM_LONG_KS * 64 * 8];       // [query][K-step][lane][8 halves]: -2 x~ shifted by the lane's column
+    unsigned short bxtab[PSH_STREAM_MAX_Q * PSH_STREAM_LONG_KS * 64 * 8];   // [query][K-step][lane][8 halves]: -2 x~ shifted by the lane's column
+                                                             // (a query's K-steps: 4 up to W = 33, stream_ksteps(W) for a long window)
 };
 #define PSH_FUSED_BYTES ((sizeof(psh::FusedHdr) + 255) / 256 * 256)
 
@@ -319,8 +320,8 @@ hipError_t launch_stream_sample(const ScanArgs& a, const FusedArgs& f, bool alig
 hipError_t launch_stream_scan(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, hipStream_t s);
 hipError_t launch_stream_rank(const ScanArgs& a, const FusedArgs& f, int grid, hipStream_t s);
 size_t stream_scan_shmem_bytes_q(int tile_floats, int nq);
-bool stream_long_supported(int W);              // one query, 34 <= W <= 256: the scan of the step as a K-loop over the band (stream_scan_long_kernel)
-size_t stream_scan_long_shmem_bytes(int W);
+bool stream_long_supported(int W);              // one to three queries, 34 <= W <= 256: the scan of the step as a K-loop over the band (stream_scan_long_kernel)
+size_t stream_scan_long_shmem_bytes(int W, int nq);
 hipError_t launch_stream_scan_long(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, hipStream_t s);
 hipError_t launch_embed_rows(const float* dataset, int64_t R, int64_t T, const float* ker, int d, int K, float* out, hipStream_t s);
 // psh_predict.hip: the reductions of predict_from_paths() on the device

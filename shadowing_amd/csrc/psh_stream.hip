@@ -296,7 +296,7 @@ void stream_sample_kernel(ScanArgs a, FusedArgs f) {
                 const float xv = a.queries[(size_t)q * W + (in ? j : 0)];
                 b[i] = (_Float16)(in ? -2.0f * (xv * scale) : 0.0f);
             }
-            *reinterpret_cast<f16x8*>(hdr->bxtab + ((size_t)q * 4 * 64 + (size_t)(s * 64 + lane)) * 8) = b;
+            *reinterpret_cast<f16x8*>(hdr->bxtab + ((size_t)q * nks * 64 + (size_t)(s * 64 + lane)) * 8) = b;    // (nks = 4 up to W = 33)
         }
     }
     if (NWP > 1) __syncthreads(); else wave_lds_fence();
@@ -556,11 +556,14 @@ __host__ __device__ inline int stream_long_rows(int W) { return 31 + (stream_kst
 __host__ __device__ inline int stream_long_nhalf(int W) { return stream_long_rows(W) * PSH_LONG_ROW; }             // halves per wave (both arrays)
 __device__ __forceinline__ int long_half(int idx) { return (idx >> 5) * PSH_LONG_ROW + (idx & 31); }                // logical sample -> its y^ half ((y~^2)^: + 32)
 
-template <bool ALIGNED>
+// NQ: one, two or three queries ride one pass (round 5): the window energies' MFMA of a K-step is shared, a query adds one
+// MFMA with its own fragment -- 1 + NQ per step where NQ one-query steps issue 2 NQ -- and the segment is staged and converted
+// once (three queries with W = 126: one pass where the loop of one-query steps made three).
+template <bool ALIGNED, int NQ>
 __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(ScanArgs a, FusedArgs f) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NW = PSH_SCAN_THREADS / 64;
-    constexpr int NFL = PSH_STREAM_FL(1);
+    constexpr int NFL = PSH_STREAM_FL(NQ);
     const int lane = lane_id();
     const int tid = (int)threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -568,8 +571,9 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
     const int nks = stream_ksteps(W), nhalf = stream_long_nhalf(W);
     int* ctl = reinterpret_cast<int*>(smem);                                 // 64 control words
     u32x4* fl = reinterpret_cast<u32x4*>(ctl + 64);                           // NFL entries {acc bits, r, t, query}
-    _Float16* bxl = reinterpret_cast<_Float16*>(fl + NFL);                    // [K-step]{[lane][8]: -2 x~ shifted by the lane's column; [lane][8]: the band of ones}
-    _Float16* ah0 = bxl + (size_t)nks * 2 * 64 * 8;
+    _Float16* bxl = reinterpret_cast<_Float16*>(fl + NFL);                    // [K-step]{NQ x [lane][8]: -2 x~_q shifted by the lane's column; [lane][8]: the band of ones}
+    constexpr int TS = (NQ + 1) * 64 * 8;                                     // halves of a K-step's tables
+    _Float16* ah0 = bxl + (size_t)nks * TS;
     _Float16* a1 = ah0 + (size_t)wave * nhalf;                                // rows of {y^ [32], (y~^2)^ [32], pad [8]}
     FusedHdr* hdr = f.hdr;
     const StreamCtl* sc = &hdr->stream;
@@ -594,18 +598,24 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
     // ones by arithmetic
     for (int i = tid; i < nks * 64; i += PSH_SCAN_THREADS) {
         const int s = i >> 6, l = i & 63, n = l & 31, hk = l >> 5;
-        *reinterpret_cast<f16x8*>(bxl + ((size_t)s * 128 + l) * 8) = *reinterpret_cast<const f16x8*>(hdr->bxtab + (size_t)i * 8);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            *reinterpret_cast<f16x8*>(bxl + (size_t)s * TS + ((size_t)q * 64 + l) * 8) = *reinterpret_cast<const f16x8*>(hdr->bxtab + ((size_t)q * nks * 64 + i) * 8);
         f16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int j = 16 * s + 8 * hk + e - n;
             o[e] = (_Float16)((j >= 0 && j < W) ? 1.0f : 0.0f);
         }
-        *reinterpret_cast<f16x8*>(bxl + ((size_t)s * 128 + 64 + l) * 8) = o;
+        *reinterpret_cast<f16x8*>(bxl + (size_t)s * TS + ((size_t)NQ * 64 + l) * 8) = o;
     }
     const unsigned armed_w = sc->armed;
     const float scale = __uint_as_float(sc->scale_bits);
-    const float tau2 = __uint_as_float(sc->tau2_bits[0]), thr2 = __uint_as_float(sc->thr2_bits[0]), xn = __uint_as_float(sc->xn_bits[0]);
+    float tau2[NQ], thr2[NQ], xn[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        tau2[q] = __uint_as_float(sc->tau2_bits[q]); thr2[q] = __uint_as_float(sc->thr2_bits[q]); xn[q] = __uint_as_float(sc->xn_bits[q]);
+    }
     if (tid == 0) { ctl[S_FRONT] = 0; ctl[S_NEXT] = NW; }
     {   // every slot of the f16 arrays a segment does not write must be finite (0 * NaN poisons a row)
         unsigned* z = reinterpret_cast<unsigned*>(a1);
@@ -613,7 +623,6 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
     }
     __syncthreads();
     if (armed_w == 0u) return;                                                // uniform: the ranking reports PSH_STATUS_RETRY
-    const const_f32p x = (const_f32p)a.queries;
     auto grab = [&]() -> unsigned {
         int v = 0;
         if (lane == 0) v = atomicAdd(&ctl[S_NEXT], 1);
@@ -644,20 +653,23 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
         if (un < u_hi) load_unit(st, un);
 
         const int m = lane & 31, hk = lane >> 5;
-        f32x16 acc;                                                           // (ONE chain: energies and correlation into two tiles, summed at the end, was 4 % slower)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 #ifdef PSH_TUNING
         const int nks_run = (a.dbg & 8) ? 1 : nks;                            // ablation: one K-step (results invalid)
 #else
         const int nks_run = nks;
 #endif
-        {
+        unsigned hmq[NQ];                                                     // per query: bit r = accumulator r's window survives the test
+        const _Float16* pa0 = a1 + m * PSH_LONG_ROW + 8 * hk;
+        const _Float16* pb0 = bxl + lane * 8;
+        if constexpr (NQ == 1) {
+            f32x16 acc;                                                       // (ONE chain: energies and correlation into two tiles, summed at the end, was 4 % slower)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
             // two K-steps per turn: 8 fragment reads off two pointers with immediate offsets, 4 MFMAs, 2 pointer moves (the band
             // of ones comes from its table in every step: a read costs the vector ALUs nothing, a constant kept in registers was
             // rebuilt with 4 moves per step)
-            const _Float16* pa = a1 + m * PSH_LONG_ROW + 8 * hk;
-            const _Float16* pb = bxl + lane * 8;
+            const _Float16* pa = pa0;
+            const _Float16* pb = pb0;
 #define PSH_LONG_STEP(AOFF, BOFF)                                                                                                      \
             {                                                                                                                          \
                 const f16x8 e1 = *reinterpret_cast<const f16x8*>(pa + (AOFF));                                                         \
@@ -671,20 +683,48 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
 #pragma unroll 1
             for (; s + 1 < nks_run; s += 2) {
                 PSH_LONG_STEP(0, 0)
-                PSH_LONG_STEP(16, 128 * 8)
+                PSH_LONG_STEP(16, TS)
                 pa += PSH_LONG_ROW;
-                pb += 2 * 128 * 8;
+                pb += 2 * TS;
             }
             if (s < nks_run) PSH_LONG_STEP(0, 0)
 #undef PSH_LONG_STEP
-        }
-        bool keep = false;                                                    // NaN-safe: !(t^ > thr)
+            unsigned hm = 0u;                                                 // NaN-safe: !(t^ > thr)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) keep = keep || !(acc[r] > thr2);
+            for (int r = 0; r < 16; ++r) hm |= !(acc[r] > thr2[0]) ? (1u << r) : 0u;
+            hmq[0] = hm;
+        } else {
+            // the window energies first (one chain over the band of ones), then every query's banded product on top of them
+            // (the energies are the C operand of its first MFMA: no copy); a query's tile is tested and dropped before the next
+            // one's chain starts -- only the 16-bit masks stay
+            auto chain = [&](const f32x16& c0, int aoff, int boff) -> f32x16 {
+                f32x16 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(pa0 + aoff), *reinterpret_cast<const f16x8*>(pb0 + boff), c0, 0, 0, 0);
+#pragma unroll 2
+                for (int s = 1; s < nks_run; ++s)
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(pa0 + (s >> 1) * PSH_LONG_ROW + 16 * (s & 1) + aoff),
+                                                               *reinterpret_cast<const f16x8*>(pb0 + (size_t)s * TS + boff), c, 0, 0, 0);
+                return c;
+            };
+            f32x16 zero16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) zero16[i] = 0.0f;
+            const f32x16 accE = chain(zero16, 32, NQ * 64 * 8);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const f32x16 aq = chain(accE, 0, q * 64 * 8);
+                unsigned hm = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hm |= !(aq[r] > thr2[q]) ? (1u << r) : 0u;
+                hmq[q] = hm;
+            }
+        }
+        unsigned hany = 0u;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) hany |= hmq[q];
 #ifdef PSH_TUNING
-        if (a.dbg & 4) keep = false;                                          // ablation: no survivor handling (results invalid)
+        if (a.dbg & 4) hany = 0u;                                             // ablation: no survivor handling (results invalid)
 #endif
-        if (__any(keep)) {
+        if (__any(hany != 0u)) {
             // the survivors (about one segment in four holds any): the segment's fp32 values come back from memory in ONE
             // coalesced round trip (streamed a microsecond ago: L2 / MALL) into the wave's f16 arrays -- their fragments are
             // consumed -- and the exact chains (the reference's order: D = fl(x_j - y_j), acc = fma(D, D, acc)) read them there.
@@ -698,30 +738,33 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
                 stage_store<false>(sv, tile, nfloat, lane);
                 wave_lds_fence();
             }
-            unsigned hm = 0u;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hm |= !(acc[r] > thr2) ? (1u << r) : 0u;
+            for (int q = 0; q < NQ; ++q) {
+                const unsigned hm = hmq[q];
+                if (!__any(hm != 0u)) continue;
+                const const_f32p x = (const_f32p)a.queries + (size_t)q * W;
 #pragma unroll 1
-            for (int r = 0; r < 16; ++r) {
-                const int p = 32 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + m;     // C layout: row -> window
-                bool hit = (((hm >> r) & 1u) != 0u) && (seg_start + p < a.Tp);
-                if (!__ballot(hit)) continue;
-                float v = 0.0f;
-                if (hit) {
-                    const float* y = tile + p;
+                for (int r = 0; r < 16; ++r) {
+                    const int p = 32 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + m; // C layout: row -> window
+                    bool hit = (((hm >> r) & 1u) != 0u) && (seg_start + p < a.Tp);
+                    if (!__ballot(hit)) continue;
+                    float v = 0.0f;
+                    if (hit) {
+                        const float* y = tile + p;
 #pragma unroll 4
-                    for (int j = 0; j < W; ++j) { const float D = __fsub_rn(x[j], y[j]); v = __builtin_fmaf(D, D, v); }
-                }
-                hit = hit && (v < tau2);
-                const unsigned long long mask = __ballot(hit);
-                if (!mask) continue;
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&ctl[S_FRONT], __popcll(mask));
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (hit) {
-                    const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                    if (slot < NFL) fl[slot] = u32x4{__float_as_uint(v), (unsigned)r_global, (unsigned)(seg_start + p), 0u};
-                    else spill_candidate(hdr, f.cand_list, f.cand_cap, 0, xn, v, r_global, seg_start + p);
+                        for (int j = 0; j < W; ++j) { const float D = __fsub_rn(x[j], y[j]); v = __builtin_fmaf(D, D, v); }
+                    }
+                    hit = hit && (v < tau2[q]);
+                    const unsigned long long mask = __ballot(hit);
+                    if (!mask) continue;
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&ctl[S_FRONT], __popcll(mask));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (hit) {
+                        const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                        if (slot < NFL) fl[slot] = u32x4{__float_as_uint(v), (unsigned)r_global, (unsigned)(seg_start + p), (unsigned)q};
+                        else spill_candidate(hdr, f.cand_list, f.cand_cap, q, xn[q], v, r_global, seg_start + p);
+                    }
                 }
             }
             // the arrays' tails past what a segment's conversion writes hold fp32 bits now: zeros again (0 * NaN poisons a row)
@@ -735,21 +778,29 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
         u = un;
     }
     __syncthreads();
-    if (wave == 0) {                                                          // (stream_scan_body's publication, one query)
+    if (wave == 0) {                                                          // (stream_scan_body's publication)
         const int nfront = ctl[S_FRONT];
         const int mown = nfront < NFL ? nfront : NFL;
-        const bool have = lane < mown;
-        const unsigned long long mask = __ballot(have);
-        if (mask) {
-            unsigned base = 0u;
-            if (lane == 0) base = __hip_atomic_fetch_add((gu32*)&hdr->stream.ncand[0], (unsigned)__popcll(mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-            if (have) {
-                const unsigned slot = base + (unsigned)lane;
-                if (slot < (unsigned)f.cand_cap) {
-                    u32x4 o = fl[lane];
-                    o[0] = __float_as_uint(dist_from_acc(__uint_as_float(o[0]), xn));
-                    reinterpret_cast<u32x4*>(f.cand_list)[slot] = o;
+#pragma unroll
+        for (int c0 = 0; c0 < NFL; c0 += 64) {
+            if (c0 >= mown) break;
+            const bool have = c0 + lane < mown;
+            u32x4 e = have ? fl[c0 + lane] : u32x4{0u, 0u, 0u, 0xffffffffu};
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const bool mine = have && (int)e[3] == q;
+                const unsigned long long mask = __ballot(mine);
+                if (!mask) continue;
+                unsigned base = 0u;
+                if (lane == 0) base = __hip_atomic_fetch_add((gu32*)&hdr->stream.ncand[q], (unsigned)__popcll(mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                if (mine) {
+                    const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    if (slot < (unsigned)f.cand_cap) {
+                        u32x4 o = e;
+                        o[0] = __float_as_uint(dist_from_acc(__uint_as_float(e[0]), xn[q]));
+                        reinterpret_cast<u32x4*>(f.cand_list)[(size_t)q * f.cand_cap + slot] = o;
+                    }
                 }
             }
         }
@@ -866,8 +917,9 @@ size_t stream_scan_shmem_bytes_q(int tile_floats, int nq) {
 }
 size_t stream_scan_shmem_bytes(int tile_floats) { return stream_scan_shmem_bytes_q(tile_floats, 1); }
 bool stream_long_supported(int W) { return W >= 34 && W <= 256; }
-size_t stream_scan_long_shmem_bytes(int W) {
-    return (size_t)PSH_STREAM_FIXED_BYTES + (size_t)PSH_FUSED_FRONT * 16 + (size_t)2 * stream_ksteps(W) * 64 * 8 * sizeof(_Float16)
+size_t stream_scan_long_shmem_bytes(int W, int nq) {
+    return (size_t)PSH_STREAM_FIXED_BYTES + (size_t)(nq == 1 ? PSH_FUSED_FRONT : 2 * PSH_FUSED_FRONT) * 16
+           + (size_t)(nq + 1) * stream_ksteps(W) * 64 * 8 * sizeof(_Float16)
            + (size_t)(PSH_SCAN_THREADS / 64) * stream_long_nhalf(W) * sizeof(_Float16);
 }
 size_t stream_sample_shmem_bytes(int tile_floats) {
@@ -922,10 +974,15 @@ hipError_t launch_stream_scan(const ScanArgs& a, const FusedArgs& f, bool aligne
                    : launch_k(stream_scan_kernel<0, false>, dim3(grid), PSH_SCAN_THREADS, shmem, s, a, f);
 }
 
+template <int NQ>
+static hipError_t launch_stream_scan_long_q(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, hipStream_t s) {
+    const size_t shmem = stream_scan_long_shmem_bytes(a.W, NQ);
+    return aligned ? launch_k(stream_scan_long_kernel<true, NQ>, dim3(grid), PSH_SCAN_THREADS, shmem, s, a, f)
+                   : launch_k(stream_scan_long_kernel<false, NQ>, dim3(grid), PSH_SCAN_THREADS, shmem, s, a, f);
+}
 hipError_t launch_stream_scan_long(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, hipStream_t s) {
-    const size_t shmem = stream_scan_long_shmem_bytes(a.W);
-    return aligned ? launch_k(stream_scan_long_kernel<true>, dim3(grid), PSH_SCAN_THREADS, shmem, s, a, f)
-                   : launch_k(stream_scan_long_kernel<false>, dim3(grid), PSH_SCAN_THREADS, shmem, s, a, f);
+    return f.nq == 1 ? launch_stream_scan_long_q<1>(a, f, aligned, grid, s)
+         : f.nq == 2 ? launch_stream_scan_long_q<2>(a, f, aligned, grid, s) : launch_stream_scan_long_q<3>(a, f, aligned, grid, s);
 }
 
 hipError_t launch_stream_rank(const ScanArgs& a, const FusedArgs& f, int grid, hipStream_t s) {

@@ -176,12 +176,13 @@ def test_single_query_matrix_core_scan_admits_exactly_the_windows_below_the_leve
 @pytest.mark.parametrize("kind", ADVERSARIAL)
 def test_fused_and_overlap_launches_admit_exactly_the_windows_below_the_level(hip_device, oracle_mod, kind):
     """scan_fused_kernel<.., HINTED>, the three overlap-friendly launches (one query, and two / three riding one pass) and the
-    long-window scan (stream_scan_long_kernel, W = 64 / 126 / 250): the same f16 test with the scale taken from the level and the
+    long-window scan (stream_scan_long_kernel, W = 40 .. 256, one to three queries a pass): the same f16 test with the scale taken from the level and the
     query alone; <= 64 candidates per block, so a level ~2000 deep."""
     from shadowing_amd import _native
     for i, (W, h, B, flags, path) in enumerate([(20, 20, 1, 0, 2), (13, 0, 1, 0, 2), (20, 20, 1, _native.FLAG_OVERLAP, 3),
                                                 (20, 5, 2, 0, 3), (25, 0, 3, 0, 3),
-                                                (64, 5, 1, 0, 3), (126, 20, 1, 0, 3), (250, 0, 1, 0, 3)]):    # long windows: the K-loop scan
+                                                (64, 5, 1, 0, 3), (126, 20, 1, 0, 3), (250, 0, 1, 0, 3),      # long windows: the K-loop scan
+                                                (40, 3, 3, 0, 3), (126, 0, 2, 0, 3), (200, 7, 3, 0, 3), (256, 0, 2, 0, 3)]):   # ... two / three queries a pass
         ds, q = adversarial(kind, 4096, 2048, B, W, h, 200 + 5 * i)
         for m in (2000, 500, 100):                       # (planted matches crowd single blocks: a shallower level then)
             try:
