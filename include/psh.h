@@ -218,9 +218,10 @@ int psh_query_norm(int device, void* stream, const float* queries, int B, int W,
  *
  * WINDOW LENGTHS.  The rejection test of a scan runs on the matrix cores for ONE query with W <= 256 (W <= 33: the fused
  * launch / the three overlap-friendly launches with the shifted-query band in registers; 34 <= W <= 256: the three launches
- * with the band as a K-loop over ceil((W + 31) / 16) steps, flag or no flag -- stream_scan_long_kernel), for two or three
- * queries with W <= 33, for larger batches with W <= 25, and for ANY number of queries with 26 <= W <= 256 -- served as a
- * loop of steps inside the call (three queries per step up to W = 33, one beyond; status words per query as always);
+ * with the band as a K-loop over ceil((W + 46) / 16) steps, flag or no flag -- stream_scan_long_kernel), for two or three
+ * queries with W <= 33 or 34 <= W <= 256 (they ride one pass of the three launches; W > ~230: two), for larger batches with
+ * W <= 25, and for ANY number of queries with 26 <= W <= 256 -- served as a loop of such steps inside the call (three
+ * queries per step; status words per query as always);
  * PSH_FLAG_FILTER_VALU / PSH_FLAG_NO_FUSE calls use the vector-ALU filter or the exact chains.  Results do not depend on
  * which.
  */
