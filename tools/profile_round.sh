@@ -98,5 +98,5 @@ cd $R
 # loop of matrix-core steps inside the call beside the one-pass vector-ALU filter; --walk: price levels, the bounds' worst case),
 # the long-window scan with parts switched off
 PSH_LIB=$R/shadowing_amd/lib/libpsh_hip_tuning.so timeout 300 python tools/emx_phases.py 2>/dev/null | grep -v amdgpu.ids > $OUT/emx_phases.txt
-(timeout 600 python tools/long_batch_probe.py --W 30 64 126 252 --B 1 2 4 16 64 2>/dev/null | grep "^{"; timeout 300 python tools/long_batch_probe.py --walk --W 20 64 126 --B 1 4 2>/dev/null | grep "^{") > $OUT/long_batch_probe.jsonl
+(timeout 600 python tools/long_batch_probe.py --W 30 64 126 252 --B 1 2 3 4 16 64 2>/dev/null | grep "^{"; timeout 300 python tools/long_batch_probe.py --walk --W 20 64 126 --B 1 4 2>/dev/null | grep "^{") > $OUT/long_batch_probe.jsonl
 (for W in 64 126 252; do for d in 0 4 12; do PSH_DBG=$d PSH_LIB=$R/shadowing_amd/lib/libpsh_hip_tuning.so python tools/long_ablate.py $W 2>/dev/null | tail -1; done; done) > $OUT/long_ablate.txt
