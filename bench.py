@@ -646,8 +646,9 @@ def main():
         one_ms = one[0].elapsed_time(one[1])
     fused = info.get("path") == 2
     overlap_mode = info.get("path") == 3
-    kernel_name = ("psh::stream_scan_long_kernel<true> (the scan of the three overlap-friendly launches for a LONG window: the f16 "
-                   "banded product as a K-loop over %d steps of 16 taps, 2 MFMAs each, + exact fp32 recheck from memory)" % ((W + 31 + 15) // 16)
+    kernel_name = ("psh::stream_scan_long_kernel<true,%d> (the scan of the three overlap-friendly launches for a LONG window, up to three "
+                   "queries a pass: the f16 banded product as a K-loop over %d steps of 16 taps, 1 + queries MFMAs each, + exact fp32 "
+                   "recheck from memory)" % (min(B, 3), (W + 31 + 15) // 16)
                    if (overlap_mode and W > 33) else
                    "psh::stream_scan_kernel<%s,true> (the scan of the three overlap-friendly launches: f16 matrix-core rejection "
                    "test + exact fp32 recheck over the whole ensemble, no barrier; psh::stream_sample_kernel before it and "
