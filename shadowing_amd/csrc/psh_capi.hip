@@ -761,6 +761,10 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
             int64_t r2p = (2 * (int64_t)k * rows_p + p.R - 1) / p.R + 8;
             if (r2p < 24) r2p = 24;
             int64_t grid_p = (int64_t)tn.stream_pgrid_per_cu * ncu;
+            // (a long window's sample is its exact chains -- 1024 windows x W taps per unit, 11 us at W = 126 -- not its bytes:
+            //  one unit per wave instead of two, unless the caller says other steps' scans share the chip: three streams measured
+            //  +2 % with it, a lone stream's call 3 - 10 % less -- 3 queries with W = 126: 317 -> 284 us)
+            if (one_long && !(flags_of(profile) & PSH_FLAG_OVERLAP)) grid_p *= 2;
             if (grid_p > units_p) grid_p = units_p;
             int64_t grid_s = ncu;
             // a stream made by psh_stream_create_reserving: one block per compute unit the stream may use
