@@ -91,6 +91,25 @@ def test_every_identity_path_with_nonfinite_samples(hip_device, oracle_mod):
     assert not np.array_equal(ii.cpu().numpy(), oidx)
 
 
+@pytest.mark.parametrize("W,h", [(64, 20), (126, 0), (250, 7), (30, 5)])
+def test_long_windows_with_nonfinite_samples(hip_device, oracle_mod, W, h):
+    """The long-window scan (one, two / three queries a pass, the loop of steps for more) and the 26 .. 33-tap batches on a
+    dirty ensemble: a NaN or an infinity in a segment poisons the f16 tiles of its rows (kept, never rejected), the exact chains
+    give NaN for the windows that hold it, and the smeared horizon follows the reference's rule -- all equal the oracle."""
+    import shadowing_amd as sa
+    R, T, k = 4096, 2048, 200
+    ds = _dirty(R, T, 7400 + W, n_nan=1500, n_inf=300)
+    ds[5, 0, :] = np.nan
+    obj = sa.PathShadowing(sa.Identity(W), sa.RelativeMSE(), torch.as_tensor(ds), sa.PredictionContext(h))
+    for B in (1, 2, 3, 7):
+        q = syn.rolling_queries(B, W, 7500 + B)
+        d, paths, idx = obj.shadow(q, k=k, cuda=True)
+        assert obj.last_path == "hip"
+        od, opaths, oidx = oracle_mod.shadow(ds, q, k, h)
+        assert_exact(d, idx, od, oidx, f"dirty ensemble, W={W}, {B} queries")
+        assert np.array_equal(paths, opaths, equal_nan=True)
+
+
 @pytest.mark.parametrize("kind", ["foveal", "wavelet", "foveal_one_window", "imputation"])
 def test_embedded_scans_with_nonfinite_samples(hip_device, oracle_mod, kind):
     """A dirty ensemble behind a linear embedding stays on the NATIVE path (round 5; rounds 3-4 handed it to torch ops): the
