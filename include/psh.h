@@ -146,7 +146,9 @@ typedef struct psh_profile {
      * the query's status says PSH_STATUS_OVERFLOW / PSH_STATUS_RETRY as for a sampled level that fell short, and the caller
      * reruns the call WITHOUT the hint.  Meant for consecutive queries whose k-th distance is known roughly (rolling query
      * dates: the previous call's out_d[b][k-1] -> hint = (d_k ||x||)^2 x margin), and for tests that pin the admitted set
-     * (psh_candidates_layout).  The small-problem / exhaustive paths ignore it. */
+     * (psh_candidates_layout).  The small-problem / exhaustive paths ignore it.  Mind the window length: the number of windows
+     * below a level grows like level^(W / 2), so a margin of 10 % on acc admits ~2.6 k windows for k = 1024 at W = 20 and
+     * hundreds of thousands at W = 126 (-> slow, or PSH_STATUS_RETRY beyond the lists' 65536 entries): margin ~ 2.6^(2 / W). */
     const float* tau_hint;
 } psh_profile;
 

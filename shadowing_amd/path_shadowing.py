@@ -679,7 +679,9 @@ class PathShadowing:
         if hstate["skip"] > 0:
             hstate["skip"] -= 1
             return None
-        level = hstate["dk"] ** 2 * xn2 * self.HINT_MARGIN
+        # (windows below a level: ~ level^(W / 2).  The margin that triples the admitted count at any window length, capped at
+        #  HINT_MARGIN: 1.15 up to W = 15, 1.017 at W = 126 -- a long window's hint holds only if d_k moves by less than 1 %)
+        level = hstate["dk"] ** 2 * xn2 * min(self.HINT_MARGIN, 3.0 ** (2.0 / W))
         return level if (level > 0.0 and math.isfinite(level)) else None
 
     def shadow_async(self, x_context: ArrayType, k: int = 1, streams: int = 3) -> "PendingShadow":
