@@ -698,11 +698,21 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
             // (the energies are the C operand of its first MFMA: no copy); a query's tile is tested and dropped before the next
             // one's chain starts -- only the 16-bit masks stay
             auto chain = [&](const f32x16& c0, int aoff, int boff) -> f32x16 {
-                f32x16 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(pa0 + aoff), *reinterpret_cast<const f16x8*>(pb0 + boff), c0, 0, 0, 0);
-#pragma unroll 2
-                for (int s = 1; s < nks_run; ++s)
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(pa0 + (s >> 1) * PSH_LONG_ROW + 16 * (s & 1) + aoff),
-                                                               *reinterpret_cast<const f16x8*>(pb0 + (size_t)s * TS + boff), c, 0, 0, 0);
+                // (two K-steps per turn off two pointers, every other offset an immediate -- as the one-query loop)
+                const _Float16* pa = pa0 + aoff;
+                const _Float16* pb = pb0 + boff;
+                auto ld = [](const _Float16* p) { return *reinterpret_cast<const f16x8*>(p); };
+                f32x16 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ld(pa), ld(pb), c0, 0, 0, 0);
+                if (nks_run > 1) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ld(pa + 16), ld(pb + TS), c, 0, 0, 0);
+                int s = 2;
+#pragma unroll 1
+                for (; s + 1 < nks_run; s += 2) {
+                    pa += PSH_LONG_ROW;
+                    pb += 2 * TS;
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ld(pa), ld(pb), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ld(pa + 16), ld(pb + TS), c, 0, 0, 0);
+                }
+                if (s < nks_run) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ld(pa + PSH_LONG_ROW), ld(pb + 2 * TS), c, 0, 0, 0);
                 return c;
             };
             f32x16 zero16;
