@@ -81,6 +81,12 @@ def parse():
                          "timed_region, the parity checks, the JSON line) on CPU tensors over gloo, with the CPU oracle standing in "
                          "for the HIP scan -- tests/test_bench_flow_cpu.py runs it with two ranks so that a Python-level bug "
                          "cannot burn a multi-GPU lease")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region (warm-up + K steps) is run this many times: `value` / `ms_per_step` are the FIRST region's (the "
+                         "contract's K steps), `ms_per_step_repeats` carries median / min / max over all of them")
+    ap.add_argument("--no-blocking-api", action="store_true",
+                    help="skip the `blocking_shadow_api` block (N = 1, one query): the reference's own call -- one blocking "
+                         "PathShadowing.shadow(x, k, cuda=True), README.md:47-57 -- timed call by call outside the headline's region")
     ap.add_argument("--sweep", type=str, default=None,
                     help="comma-separated GPU counts: run each in turn, print one JSON line per N (stdout) and the "
                          "weak-scaling efficiency against the first (stderr)")
@@ -264,6 +270,83 @@ def torch_cpu_baseline(ds: np.ndarray, q: np.ndarray, k: int, h: int) -> dict:
     return {"value": round(rows * (T - W - h + 1) / med, 1), "unit": "windows/s", "threads": torch.get_num_threads(),
             "sample": f"{rows} of {R} rows x 1 query, 16 splits, {len(times)} passes, median {med:.3f} s; "
                       f"shadowing_amd.PathShadowing._generic_scan (the reference's formulation in torch ops), cuda=False"}
+
+
+def blocking_shadow_api(sa, syn, ds, ds_host, q_hosts, W, h, k, expected_by_oracle):
+    """The reference's OWN call, timed call by call: one blocking `PathShadowing.shadow(x, k, cuda=True)` on a resident
+    ensemble, numpy query in, numpy (distances, paths, indices) out (reference README.md:47-57, path_shadowing.py:181-218).
+    Outside the headline's timed region; wall clock of the caller (time.perf_counter around every call)."""
+    obj = sa.PathShadowing(sa.Identity(W), sa.RelativeMSE(), ds, sa.PredictionContext(h))
+    unrelated = [syn.single_query(W, 5000 + j) for j in range(64)]
+    WARM, CALLS = 300, 500
+
+    def loop(o, queries, n):
+        ts = []
+        for i in range(n):
+            q = queries[i % len(queries)]
+            t0 = time.perf_counter()
+            o.shadow(q, k=k, cuda=True)
+            ts.append(1e6 * (time.perf_counter() - t0))
+        return np.asarray(ts)
+
+    loop(obj, unrelated, WARM)
+    ts = loop(obj, unrelated, CALLS)
+    # parity: the rotating queries of the headline through the SAME call, paths included (the oracle's distances and
+    # indices; the paths are the ensemble's own samples at those indices)
+    parity = None
+    if expected_by_oracle is not None:
+        parity = True
+        for qi, qh in enumerate(q_hosts):
+            d, paths, idx = obj.shadow(qh[0], k=k, cuda=True)
+            od, oi = expected_by_oracle(qi)
+            want = np.stack([ds_host[r, :, t:t + W + h] for r, t in oi[0]])[None]
+            parity = parity and same_result(d, idx, od, oi, tie_free_order=True) and bool(np.array_equal(paths, want))
+        if not parity:
+            raise SystemExit("PARITY FAILURE of the blocking shadow() calls against the oracle")
+    served = "psh_shadow_blocking: " + ("psh::scan_fused_kernel<..,BLK> (scan + selection + path gather in one launch, results written "
+                                        "to pinned host memory by the kernel, completion words polled)" if getattr(obj, "_sync_slot", None) and obj._sync_slot[1].last_fused
+                                        else "psh_scan_topk's launches + the gather launch, stream synchronised")
+    out = {"what": "one blocking PathShadowing.shadow(x, k, cuda=True) per call on a resident ensemble -- the reference's own call "
+                   "(README.md:47-57) -- numpy in, numpy (d, paths, idx) out; caller's wall clock per call, unrelated queries",
+           "median_us": round(float(np.median(ts)), 1), "p90_us": round(float(np.percentile(ts, 90)), 1),
+           "min_us": round(float(ts.min()), 1), "max_us": round(float(ts.max()), 1), "calls": CALLS, "warmup_calls": WARM,
+           "parity_vs_oracle": parity, "served_by": served}
+    # rolling query dates (what predict() loops over, ref :286-301): without hints and with hint="auto" -- the previous date's
+    # k-th distance as this date's admission level, a hint a caller CAN have
+    rolling = list(syn.rolling_queries(CALLS, W, 7))
+    loop(obj, rolling, 50)
+    t_plain = loop(obj, rolling, CALLS)
+    hinted = sa.PathShadowing(sa.Identity(W), sa.RelativeMSE(), ds, sa.PredictionContext(h), hint="auto")
+    loop(hinted, rolling, 50)
+    seen = {"ok": 0, "short": 0, None: 0}
+    t_hint = []
+    for q in rolling:
+        t0 = time.perf_counter()
+        hinted.shadow(q, k=k, cuda=True)
+        t_hint.append(1e6 * (time.perf_counter() - t0))
+        seen[hinted.last_hint] += 1
+    out["rolling_dates"] = {"no_hint_median_us": round(float(np.median(t_plain)), 1), "hint_auto_median_us": round(float(np.median(t_hint)), 1),
+                            "no_hint_mean_us": round(float(np.mean(t_plain)), 1), "hint_auto_mean_us": round(float(np.mean(t_hint)), 1),
+                            "hints_held": seen["ok"], "hints_fell_short": seen["short"], "calls_without_hint": seen[None], "calls": CALLS,
+                            "policy": "PathShadowing(hint=\"auto\"): level = (previous date's d_k x ||x||)^2 x min(1.15, 3^(2/W)); a hint "
+                                      "that falls short costs one more launch and switches hints off for a few calls"}
+    if k != 8192:
+        big = 8192
+        for q in unrelated[:20]:
+            obj.shadow(q, k=big, cuda=True)
+        tb = loop_k(obj, unrelated, 100, big)
+        out["k8192_median_us"] = round(float(np.median(tb)), 1)
+    return out
+
+
+def loop_k(o, queries, n, k):
+    ts = []
+    for i in range(n):
+        q = queries[i % len(queries)]
+        t0 = time.perf_counter()
+        o.shadow(q, k=k, cuda=True)
+        ts.append(1e6 * (time.perf_counter() - t0))
+    return np.asarray(ts)
 
 
 def main():
@@ -553,6 +636,13 @@ def main():
         elapsed, host_enqueue, bad = timed_region()
     if bad != 0:
         raise SystemExit("candidate buffer overflow during the timed steps (unexpected)")
+    # the same region again (the driver's K = 20 steps are 1.7 ms of device time: one region says little about the spread)
+    region_ms = [1e3 * elapsed / args.steps]
+    for _ in range(max(0, args.repeats - 1)):
+        el_r, _, bad_r = timed_region()
+        if bad_r != 0:
+            raise SystemExit("a repeated timed region reported status %d (unexpected)" % bad_r)
+        region_ms.append(1e3 * el_r / args.steps)
 
     # ---- what the timed steps LEFT BEHIND, against the checker: the last result of every stream (unsharded) / the last two
     #      merged results (sharded) must be what their own query batch gives
@@ -622,8 +712,11 @@ def main():
         single_stream["with_admission_hint"] = {
             "ms_per_step": round(1e3 * el2 / args.steps, 5), "achieved_GBps": round(alg_bytes_const / (1e-3 * 1e3 * el2 / args.steps) / 1e9, 1),
             "frac": round(alg_bytes_const / (el2 / args.steps) / 1e9 / HBM_PEAK_GBPS, 4), "status_max": bad2, "parity_vs_oracle": hinted_ok,
-            "hint": f"psh_profile.tau_hint = every query's exact k-th acc x {HINT_MARGIN} (a caller that knows d_k to {50 * (HINT_MARGIN - 1):.1f} %: "
-                    "rolling dates; ~2.6 k windows below it at any W)",
+            "label": "UPPER BOUND of what a hint can buy: an oracle-grade hint (the query's own exact k-th acc, known from an untimed call) -- "
+                     "no caller has it; the hint a caller CAN have (the previous query date's d_k, PathShadowing(hint=\"auto\")) is "
+                     "timed at the API in blocking_shadow_api.rolling_dates, with held / fell-short counts",
+            "hint": f"psh_profile.tau_hint = every query's exact k-th acc x {HINT_MARGIN} (d_k known to {50 * (HINT_MARGIN - 1):.1f} %; "
+                    "~2.6 k windows below it at any W)",
             "launches": ("psh::scan_fused_kernel<..,HINTED>: no sample phase, no first grid barrier" if W <= 33 else
                          "the three launches, the sample launch as one block that derives the level's constants")}
 
@@ -765,6 +858,10 @@ def main():
             cpu = cpu_baseline(ds_host, q_host, k, h)
             cpu["value"] = round(cpu["value"], 1)
 
+    blocking = None
+    if rank == 0 and world == 1 and on_gpu and B == 1 and sharded is None and not args.no_blocking_api:
+        blocking = blocking_shadow_api(sa, syn, ds, ds_host, q_hosts, W, h, k, None if args.no_parity else expected_by_oracle)
+
     if rank == 0:
         out = {
             "metric": f"windows scanned/sec (k-nearest-path scan, Identity + RelativeMSE, W={W}, k={k})",
@@ -785,7 +882,11 @@ def main():
             "cpu_baseline": cpu,
             "achieved_hbm_GBps_whole_step": round(world * alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
             "streams": n_streams,
+            "ms_per_step_repeats": {"n": len(region_ms), "median": round(float(np.median(region_ms)), 5), "min": round(min(region_ms), 5),
+                                    "max": round(max(region_ms), 5), "what": f"the timed region (warm-up {args.warmup} + {args.steps} steps) run "
+                                    f"{len(region_ms)} times; `value` / `ms_per_step` are the first region's"},
             "single_stream_fused": single_stream,
+            "blocking_shadow_api": blocking,
             "host_enqueue_ms_per_step": round(1e3 * host_enqueue / args.steps, 5),
             "stages_ms_separate_launches": stages,
             "parity_vs_reference_golden": parity,

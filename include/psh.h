@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PSH_VERSION 2      /* 2: psh_profile.tau_hint, psh_candidates_layout */
+#define PSH_VERSION 3      /* 2: psh_profile.tau_hint, psh_candidates_layout; 3: psh_shadow_blocking, psh_shadow_block_layout */
 
 #define PSH_OK                 0
 #define PSH_ERR_ARG           -1   /* NULL pointer / non-positive size / k > number of windows */
@@ -408,6 +408,48 @@ int psh_stream_destroy(int device, void* stream);
 int psh_gather_paths(int device, void* stream,
                      const float* dataset, int64_t R, int64_t C, int64_t T, int64_t r_offset,
                      const int32_t* idx, int64_t n, int len, float* out);
+
+/*
+ * ONE BLOCKING shadow() OF ONE Identity QUERY -- the reference's own call (README.md:47-57; path_shadowing.py:181-218:
+ * normalise, batched_distance, the path gather, .cpu().numpy()) as ONE library call that returns when the results ARE in the
+ * caller's host memory.  The only entry point that waits: it is the latency of this call that a caller of the reference's
+ * API sees, and it is dominated by what lies around the ~100 us scan -- a second launch for the gather, the copies out, the
+ * runtime's end-of-kernel notification.  Here
+ *   - the query (and the optional admission hint) are read by the kernels from `host_block`, and the k distances, indices
+ *     and gathered paths are WRITTEN BY THE KERNELS straight into it (write-through stores over PCIe: 172 KB at k = 1024);
+ *   - when the fused single launch serves the call (W <= 33, the sizes psh_scan_topk takes it for), the ranking phase of that
+ *     launch gathers the winners' paths itself -- no psh_gather_paths launch -- and its last blocks set completion words in the
+ *     block which this function polls: it returns ~1 us after the last result byte has landed instead of after the
+ *     runtime has noticed the kernel's end;
+ *   - otherwise (long windows, large k, small ensembles): psh_scan_topk's launches + the gather launch, then
+ *     hipStreamSynchronize.
+ *   host_block        pinned host memory the device can address (hipHostMalloc / torch pin_memory; fine-grained, the HIP
+ *                     default), >= out7[0] bytes of psh_shadow_block_layout; the CALLER writes the W query samples at byte
+ *                     PSH_SHADOW_OFF_QUERY (and, with_hint != 0, the admission level -- psh_profile.tau_hint's meaning -- at
+ *                     PSH_SHADOW_OFF_HINT) before the call and reads after it: int32 status at out7[1] (PSH_STATUS_*, the
+ *                     STATUS PROTOCOL of psh_scan_topk: anything but OK -> the results are invalid, rerun through
+ *                     psh_scan_topk with PSH_FLAG_NO_FUSE / without the hint), float32 d[k] at out7[4], int32 idx[k][2] at
+ *                     out7[5], float32 paths[k][C][W + h] at out7[6].  The words in between belong to the library.
+ *   rows              device, R x T: what the scan reads (channel 0; the smeared rows of an ensemble with non-finite samples)
+ *   dataset3          device, R x C x T: what the paths are gathered from (== rows when C == 1)
+ *   workspace         as psh_scan_topk's (B = 1), armed by psh_workspace_init; one workspace and one host block per stream
+ *   profile           optional: flags in, path / grid_blocks out (path 2 = the fused launch served the call); its tau_hint and
+ *                     events are ignored (with_hint selects the hint in the block)
+ * Returns PSH_OK when the call has COMPLETED on the device (whatever the status word says), else a PSH_ERR_*.
+ */
+#define PSH_SHADOW_OFF_STATUS 0
+#define PSH_SHADOW_OFF_DONE   64     /* 8 completion words + the call counter at 96: the library's */
+#define PSH_SHADOW_OFF_SEQ    96
+#define PSH_SHADOW_OFF_TIMES  16     /* diagnostics, 4 floats: us the last call spent enqueueing / waiting / until its launch had started / until the first completion word (fused launch) */
+#define PSH_SHADOW_OFF_STARTED 60     /* diagnostics: the launch's first block sets it to the call counter when it starts */
+#define PSH_SHADOW_OFF_HINT   112
+#define PSH_SHADOW_OFF_QUERY  128    /* PSH_MAX_W floats */
+int psh_shadow_block_layout(int W, int h, int k, int64_t C, size_t* out7);   /* {bytes, status, query, hint, d, idx, paths} */
+int psh_shadow_blocking(int device, void* stream,
+                        const float* rows, int64_t R, int64_t T, int64_t r_offset,
+                        const float* dataset3, int64_t C, int W, int h, int k,
+                        void* host_block, size_t host_block_bytes, int with_hint,
+                        void* workspace, size_t workspace_bytes, psh_profile* profile);
 
 /*
  * NON-FINITE SAMPLES.  The scans above judge a window by its own samples -- psh_scan_topk by all W of them,

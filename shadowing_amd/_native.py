@@ -14,7 +14,7 @@ import torch
 from . import _build
 
 PSH_OK = 0
-PSH_VERSION = 2          # include/psh.h: psh_profile.tau_hint, psh_candidates_layout
+PSH_VERSION = 3          # include/psh.h: 2: psh_profile.tau_hint, psh_candidates_layout; 3: psh_shadow_blocking
 PSH_STATUS_OK, PSH_STATUS_OVERFLOW, PSH_STATUS_RETRY = 0, 1, 2
 PSH_MAX_W, PSH_MAX_K, PSH_MAX_B_PER_LAUNCH = 256, 16384, 1024
 # psh_profile.flags (include/psh.h)
@@ -43,7 +43,8 @@ EXPORTS = ("psh_version", "psh_strerror", "psh_last_hip_error", "psh_workspace_b
            "psh_merge_topk_gathered", "psh_merge_sorted_gathered", "psh_gather_paths", "psh_embed_rows",
            "psh_embedded_supported", "psh_embed_plan_offset", "psh_candidates_layout", "psh_workspace_init", "psh_last_comm_error", "psh_comm_unique_id", "psh_comm_create",
            "psh_comm_destroy", "psh_comm_world", "psh_exchange_merge", "psh_stream_create_reserving", "psh_stream_destroy",
-           "psh_weighted_moments", "psh_realized_variance", "psh_count_nonfinite", "psh_smear_nonfinite", "psh_rows_nonfinite")
+           "psh_weighted_moments", "psh_realized_variance", "psh_count_nonfinite", "psh_smear_nonfinite", "psh_rows_nonfinite",
+           "psh_shadow_block_layout", "psh_shadow_blocking")
 
 _lib = None
 
@@ -130,6 +131,11 @@ def load() -> C.CDLL:
     L.psh_embed_rows.argtypes = [i32, vp, vp, i64, i64, vp, i32, i32, vp]
     L.psh_count_nonfinite.restype = i32
     L.psh_count_nonfinite.argtypes = [i32, vp, vp, i64, vp]
+    L.psh_shadow_block_layout.restype = i32
+    L.psh_shadow_block_layout.argtypes = [i32, i32, i32, i64, C.POINTER(C.c_size_t)]
+    L.psh_shadow_blocking.restype = i32
+    L.psh_shadow_blocking.argtypes = [i32, vp, vp, i64, i64, i64, vp, i64, i32, i32, i32, vp, C.c_size_t, i32, vp, C.c_size_t,
+                                      C.POINTER(PshProfile)]
     L.psh_rows_nonfinite.restype = i32
     L.psh_rows_nonfinite.argtypes = [i32, vp, vp, i64, i64, i64, vp]
     L.psh_smear_nonfinite.restype = i32
@@ -596,7 +602,8 @@ class PreparedShadow:
     def launch(self, stream: "torch.cuda.Stream", x_row: torch.Tensor, hint: float | None = None) -> None:
         """x_row: (1, W) float32 CPU tensor.  Everything is enqueued on `stream`, the D2H copies of the results included.
         `hint`: the caller's admission level on acc (psh_profile.tau_hint) -- a status other than OK then means "again without"."""
-        self._q_np[:] = x_row.numpy().reshape(-1) if isinstance(x_row, torch.Tensor) else x_row
+        # (a CUDA query, or one that requires grad -- the reference's `_torch` passes tensors through as they are: a detached host copy)
+        self._q_np[:] = x_row.detach().cpu().numpy().reshape(-1) if isinstance(x_row, torch.Tensor) else x_row
         if hint is not None:
             self._stage_np[self._Wp] = hint
         self.prof.tau_hint = self._hint_ptr if hint is not None else None
@@ -630,6 +637,101 @@ class PreparedShadow:
                 _check(rc, "psh_gather_paths")
             self._res_host.copy_(self._res, non_blocking=True)
             self.event.record()
+
+
+class _HostBlock:
+    """One pinned block of psh_shadow_blocking (query in, status / d / idx / paths out).  `root` is the numpy view every array
+    handed to a caller is based on: while the caller keeps one of them, root's reference count says so and the block is not
+    written again."""
+
+    def __init__(self, owner: "BlockingShadow"):
+        import sys
+        import numpy as np
+        self.t = torch.zeros(owner.nbytes, dtype=torch.uint8, pin_memory=True)
+        self.root = self.t.numpy()
+        W = owner.W
+        self.q = self.root[owner.o_query:owner.o_query + 4 * W].view(np.float32)
+        self.hint = self.root[owner.o_hint:owner.o_hint + 4].view(np.float32)
+        self.status = self.root[owner.o_status:owner.o_status + 4].view(np.int32)
+        self.times = self.root[16:32].view(np.float32)        # PSH_SHADOW_OFF_TIMES: us enqueueing / waiting / until the launch started, last call
+        self.prof = PshProfile()
+        self.prof.flags = owner.flags
+        rows, ds3 = owner.rows, owner.ds3
+        self.args = [rows.device.index, None, rows.data_ptr(), rows.shape[0], rows.shape[1], 0, ds3.data_ptr(), ds3.shape[1],
+                     W, owner.h, owner.k, self.t.data_ptr(), owner.nbytes, 0, owner.ws.data_ptr(), owner.ws.numel(), C.byref(self.prof)]
+        self._getrc = sys.getrefcount
+        self.rc0 = self._getrc(self.root)
+
+    def busy(self) -> bool:
+        return self._getrc(self.root) != self.rc0
+
+
+class BlockingShadow:
+    """shadow() of ONE Identity query as ONE blocking library call (psh_shadow_blocking): the fused launch reads the query
+    from a pinned block and writes distances, indices AND the gathered paths into it, the call returns when the launch's
+    completion words have landed there.  Results are handed to the caller as numpy arrays that VIEW the block (no copy out:
+    11 us at k = 1024); a block is written again only once the caller has dropped every array of it -- callers that keep
+    their results get a fresh block per call, up to POOL of them, after which results are copied out of a scratch block."""
+
+    POOL = 8
+
+    def __init__(self, rows: torch.Tensor, ds3: torch.Tensor, W: int, k: int, h: int, workspace: "Workspace", flags: int = 0):
+        import numpy as np
+        self._np = np
+        self.rows = _dev_tensor(rows, torch.float32, "rows")
+        self.ds3 = _dev_tensor(ds3, torch.float32, "dataset")
+        self.W, self.k, self.h, self.flags = W, k, h, flags
+        self.C = ds3.shape[1]
+        L = load()
+        lay = (C.c_size_t * 7)()
+        _check(L.psh_shadow_block_layout(W, h, k, self.C, lay), "psh_shadow_block_layout")
+        self.nbytes, self.o_status, self.o_query, self.o_hint, self.o_d, self.o_i, self.o_p = (int(v) for v in lay)
+        R, T = self.rows.shape
+        self.ws = workspace.get(workspace_bytes(R, T, 1, W, h, k))
+        self._keep = workspace
+        self._fn = L.psh_shadow_blocking
+        self.blocks = [_HostBlock(self)]
+        self.scratch = None
+        self.last_fused = False
+
+    def _block(self):
+        for b in self.blocks:
+            if not b.busy():
+                return b, False
+        if len(self.blocks) < self.POOL:
+            b = _HostBlock(self)
+            self.blocks.append(b)
+            return b, False
+        if self.scratch is None:
+            self.scratch = _HostBlock(self)
+        return self.scratch, True
+
+    def call(self, stream_ptr: int, x, hint: float | None = None):
+        """x: W float32 values (numpy).  Returns (status, None) or (0, (d (1,k), paths (1,k,C,W+h), idx (1,k,2)))."""
+        np = self._np
+        b, copy = self._block()
+        b.q[:] = x
+        a = b.args
+        a[1] = stream_ptr
+        if hint is not None:
+            b.hint[0] = hint
+            a[13] = 1
+        else:
+            a[13] = 0
+        rc = self._fn(*a)
+        if rc:
+            _check(rc, "psh_shadow_blocking")
+        self.last_fused = b.prof.path == 2
+        st = int(b.status[0])
+        if st != PSH_STATUS_OK:
+            return st, None
+        k, W, h, Cc = self.k, self.W, self.h, self.C
+        d = np.ndarray((1, k), np.float32, b.root, self.o_d)
+        idx = np.ndarray((1, k, 2), np.int32, b.root, self.o_i)
+        paths = np.ndarray((1, k, Cc, W + h), np.float32, b.root, self.o_p)
+        if copy:
+            return 0, (d.copy(), paths.copy(), idx.copy())
+        return 0, (d, paths, idx)
 
 
 class PreparedStep:

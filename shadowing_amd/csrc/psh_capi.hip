@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "psh.h"
 #include "psh_kernels.h"
@@ -613,11 +614,21 @@ static int long_queries_per_step(int W) {
     return 1;
 }
 
+// what psh_shadow_blocking adds to a one-query call: the fused launch gathers the winners' paths itself and sets completion
+// words the host polls; `taken` says whether the call was served that way (else: the caller enqueues the gather and waits
+// for the stream)
+struct BlockingExtras {
+    const float* g_ds; float* g_out; int64_t g_T; int g_C, g_len;
+    unsigned* done; unsigned done_val;
+    bool taken; int shards;
+    const float* q_host; const float* hint_host;      // the query (W floats) and, nullable, the admission level as the HOST reads them
+};
+
 static int scan_topk_impl(int device, void* stream, const float* dataset, int64_t R, int64_t T, int64_t r_offset,
                           const float* queries, const float* qnorm, int B, int W, int h, int k,
                           const float* ker, int emb_d,
                           float* out_d, int32_t* out_idx, int32_t* out_status,
-                          void* workspace, size_t workspace_bytes, psh_profile* profile) {
+                          void* workspace, size_t workspace_bytes, psh_profile* profile, BlockingExtras* bx = nullptr) {
     Problem p;
     int rc = check_problem(dataset, R, T, r_offset, queries, B, W, h, k, out_d, out_idx, &p, ker, emb_d);
     if (rc) return rc;
@@ -874,6 +885,14 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
                 //  launch's blocks all at once -- a CU mask, other scans in flight: where they do not apply, the separate
                 //  launches serve the call, never the fused one)
                 if (!(flags_of(profile) & PSH_FLAG_OVERLAP)) {
+                if (bx) {
+                    fu.g_ds = bx->g_ds; fu.g_out = bx->g_out; fu.g_T = bx->g_T; fu.g_C = bx->g_C; fu.g_len = bx->g_len;
+                    fu.done = bx->done; fu.done_val = bx->done_val;
+                    memcpy(fu.qv, bx->q_host, sizeof(float) * (size_t)p.W);              // (W <= 33: scan_fused_supported)
+                    if (bx->hint_host) fu.hint_v = *bx->hint_host;
+                    fu.done_shards = plan_f.grid < PSH_FUSED_DONE_SHARDS ? plan_f.grid : PSH_FUSED_DONE_SHARDS;
+                    bx->taken = true; bx->shards = fu.done_shards;
+                }
                 if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_begin, s));
                 HIP_TRY(launch_scan_fused(fa, fu, p.aligned, plan_f.grid, s));
                 if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_end, s));
@@ -1212,6 +1231,95 @@ int psh_gather_paths(int device, void* stream, const float* dataset, int64_t R, 
     if (!g.ok) { snprintf(g_hip_err, sizeof(g_hip_err), "hipSetDevice(%d) failed", device); return PSH_ERR_HIP; }
     GatherArgs a{dataset, R, C, T, r_offset, idx, n, (int64_t)len, out};
     HIP_TRY(launch_gather(a, (hipStream_t)stream));
+    return PSH_OK;
+}
+
+// ---- one BLOCKING shadow() of one Identity query (reference path_shadowing.py:181-218) --------------------------------
+int psh_shadow_block_layout(int W, int h, int k, int64_t C, size_t* out7) {
+    if (!out7 || W <= 0 || W > PSH_MAX_W || h < 0 || k <= 0 || k > PSH_MAX_K || C <= 0) return PSH_ERR_ARG;
+    const size_t n_d = (size_t)4 * k, n_i = (size_t)8 * k, n_p = (size_t)4 * k * (size_t)C * (size_t)(W + h);
+    const size_t o_d = PSH_SHADOW_OFF_QUERY + (size_t)4 * PSH_MAX_W;
+    const size_t o_i = align_up(o_d + n_d, 256), o_p = align_up(o_i + n_i, 256);
+    out7[0] = align_up(o_p + n_p, 256);
+    out7[1] = PSH_SHADOW_OFF_STATUS; out7[2] = PSH_SHADOW_OFF_QUERY; out7[3] = PSH_SHADOW_OFF_HINT;
+    out7[4] = o_d; out7[5] = o_i; out7[6] = o_p;
+    return PSH_OK;
+}
+
+static inline double now_s() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int psh_shadow_blocking(int device, void* stream, const float* rows, int64_t R, int64_t T, int64_t r_offset,
+                        const float* dataset3, int64_t C, int W, int h, int k,
+                        void* host_block, size_t host_block_bytes, int with_hint,
+                        void* workspace, size_t workspace_bytes, psh_profile* profile) {
+    size_t lay[7];
+    int rc = psh_shadow_block_layout(W, h, k, C, lay);
+    if (rc) return rc;
+    if (!host_block || host_block_bytes < lay[0] || !dataset3 || !rows) return PSH_ERR_ARG;
+    char* hb = static_cast<char*>(host_block);
+    volatile unsigned* done = reinterpret_cast<volatile unsigned*>(hb + PSH_SHADOW_OFF_DONE);
+    unsigned* seqp = reinterpret_cast<unsigned*>(hb + PSH_SHADOW_OFF_SEQ);
+    const unsigned seq = (*seqp = *seqp + 1u == 0u ? 1u : *seqp + 1u);       // never 0: a fresh block's words
+    int32_t* status = reinterpret_cast<int32_t*>(hb + PSH_SHADOW_OFF_STATUS);
+    *status = -1;                                                              // (a call that never ran leaves no OK behind)
+    psh_profile pf;
+    if (profile) pf = *profile; else memset(&pf, 0, sizeof(pf));
+    pf.mode = PSH_PROFILE_EVENTS;
+    pf.ev_scan_begin = pf.ev_scan_end = nullptr;
+    pf.tau_hint = with_hint ? reinterpret_cast<const float*>(hb + PSH_SHADOW_OFF_HINT) : nullptr;
+    const double t_begin = now_s();
+    BlockingExtras bx{dataset3, reinterpret_cast<float*>(hb + lay[6]), T, (int)C, W + h,
+                      const_cast<unsigned*>(done), seq, false, 0,
+                      reinterpret_cast<const float*>(hb + PSH_SHADOW_OFF_QUERY), with_hint ? reinterpret_cast<const float*>(hb + PSH_SHADOW_OFF_HINT) : nullptr};
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);                                   // query, hint, status: in memory before the doorbell
+    rc = scan_topk_impl(device, stream, rows, R, T, r_offset, reinterpret_cast<const float*>(hb + PSH_SHADOW_OFF_QUERY), nullptr,
+                        1, W, h, k, nullptr, 0, reinterpret_cast<float*>(hb + lay[4]), reinterpret_cast<int32_t*>(hb + lay[5]), status,
+                        workspace, workspace_bytes, &pf, &bx);
+    if (profile) { const float* th = profile->tau_hint; const int md = profile->mode; void* e0 = profile->ev_scan_begin; void* e1 = profile->ev_scan_end;
+                   *profile = pf; profile->tau_hint = th; profile->mode = md; profile->ev_scan_begin = e0; profile->ev_scan_end = e1; }
+    if (rc) return rc;
+    DeviceGuard g(device);
+    if (!g.ok) { snprintf(g_hip_err, sizeof(g_hip_err), "hipSetDevice(%d) failed", device); return PSH_ERR_HIP; }
+    hipStream_t s = (hipStream_t)stream;
+    if (!bx.taken) {
+        // not the fused launch (a window or a k it does not serve, a small ensemble): the gather as its own launch, and the
+        // stream's end is the call's end
+        GatherArgs a{dataset3, R, C, T, r_offset, reinterpret_cast<const int32_t*>(hb + lay[5]), (int64_t)k, (int64_t)(W + h),
+                     reinterpret_cast<float*>(hb + lay[6])};
+        HIP_TRY(launch_gather(a, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return PSH_OK;
+    }
+    // the launch's completion words (one per shard of its blocks) land in this block as the last thing it writes; a launch
+    // that returned early (RETRY before its scan) sets none -- the stream says so
+    const double t0 = now_s();
+    reinterpret_cast<float*>(hb + PSH_SHADOW_OFF_TIMES)[0] = (float)(1e6 * (t0 - t_begin));     // diagnostics: us spent enqueueing
+    double t_query = t0 + 60e-6;
+    volatile unsigned* started = reinterpret_cast<volatile unsigned*>(hb + PSH_SHADOW_OFF_STARTED);
+    bool seen_start = false, seen_first = false;
+    for (unsigned spin = 1;; ++spin) {
+        if (!seen_start && *started == seq) { seen_start = true; reinterpret_cast<float*>(hb + PSH_SHADOW_OFF_TIMES)[2] = (float)(1e6 * (now_s() - t0)); }
+        bool all = true, any = false;
+        for (int i = 0; i < bx.shards; ++i) { const bool d = done[i] == seq; all = all && d; any = any || d; }
+        if (any && !seen_first) { seen_first = true; reinterpret_cast<float*>(hb + PSH_SHADOW_OFF_TIMES)[3] = (float)(1e6 * (now_s() - t0)); }
+        if (all) break;
+        __builtin_ia32_pause();
+        if ((spin & 63u) == 0u) {
+            const double t = now_s();
+            if (t >= t_query) {
+                const hipError_t q = hipStreamQuery(s);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) { snprintf(g_hip_err, sizeof(g_hip_err), "hipStreamQuery -> %s", hipGetErrorString(q)); return PSH_ERR_HIP; }
+                t_query = now_s() + 15e-6;
+            }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    reinterpret_cast<float*>(hb + PSH_SHADOW_OFF_TIMES)[1] = (float)(1e6 * (now_s() - t0));          // ... and waiting
     return PSH_OK;
 }
 

@@ -46,6 +46,10 @@ __device__ __forceinline__ void g_store(u64* p, u64 v) {
 __device__ __forceinline__ void g_store32(unsigned* p, unsigned v) {
     __hip_atomic_store((gu32*)(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// a word the HOST reads (a blocking caller's pinned block): write-through to system scope
+__device__ __forceinline__ void sys_store32(unsigned* p, unsigned v) {
+    __hip_atomic_store((gu32*)(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ u64 g_load(const u64* p) {
     return __hip_atomic_load((gu64*)(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -74,7 +78,9 @@ enum { C_FRONT = 0, C_NEXT = 1, C_BAIL = 2, C_KMIN = 3, C_KMAX = 4, C_NFINITE = 
 // HINTED: the caller's admission level (psh_profile.tau_hint) instead of the sample: no phase A, no first barrier, phase B
 // only derives scale and threshold from the hint.  An instantiation of its own, so that the sampled launch compiles exactly
 // as it did without it (as a run-time flag it cost the W = 20 form nine VGPRs and the unaligned one a spill).
-template <int WT, bool ALIGNED, bool HINTED>
+// BLK: a blocking caller's launch (psh_shadow_blocking: FusedArgs::g_ds / done) -- the ranking gathers the winners' paths and the
+// last blocks set the completion words; an instantiation of its own for the same reason.
+template <int WT, bool ALIGNED, bool HINTED, bool BLK>
 __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_fused_kernel(ScanArgs a, FusedArgs f) {
     static_assert(WT >= 0 && WT <= 33, "the shifted-query band must fit K = 64 (WT = 0: run-time W <= 33)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -101,12 +107,17 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_fused_kernel(ScanArgs a
     // tuning aid (tools/fused_times.py, -DPSH_TUNING build only sets the pointer): phase boundaries of every wave 0
     auto stamp = [&](int i) { if (a.dbg_times && tid == 0) a.dbg_times[(size_t)blockIdx.x * 8 + i] = (unsigned long long)wall_clock64(); };
     stamp(0);
+    if constexpr (BLK) { if (blockIdx.x == 0 && tid == 0 && f.done) sys_store32(f.done - 1, f.done_val); }   // diagnostics: "started" (psh.h PSH_SHADOW_OFF_STARTED)
     const long long t_start = wall_clock64();
     auto give_up = [&]() -> bool { return wall_clock64() - t_start > f.spin_ticks; };
 
     const int W = WT > 0 ? WT : a.W;
     const int nfloat = PSH_SEG + W - 1;
-    const const_f32p x = (const_f32p)a.queries;
+    // a blocking caller's query travels in the kernel arguments (FusedArgs::qv): read where they lie, in the kernarg segment --
+    // explicit arguments start at its offset 0, `f` follows `a` at its own alignment
+    constexpr size_t qv_off = (sizeof(ScanArgs) + alignof(FusedArgs) - 1) / alignof(FusedArgs) * alignof(FusedArgs) + offsetof(FusedArgs, qv);
+    typedef const __attribute__((address_space(4))) char* const_i8p;
+    const const_f32p x = BLK ? (const_f32p)((const_i8p)__builtin_amdgcn_kernarg_segment_ptr() + qv_off) : (const_f32p)a.queries;
     const unsigned n_rs = (unsigned)a.n_rows * (unsigned)a.nseg;
     // a block's share of the units.  Blocks are dealt to the XCDs round-robin (MI355X_MICROARCH.md: workgroup dispatch),
     // and the odd XCDs stream ~4 % slower than the even ones on every box measured (tools/fused_times.py: they end their
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_fused_kernel(ScanArgs a
     if (tid < PSH_FUSED_FRONT) rankc[tid] = 0;
     // HINTED: the query may sit in host memory (a blocking caller's pinned buffer, psh.h) -- one parallel fetch of its taps
     // here instead of 3 W dependent scalar loads over PCIe in the level derivation below (measured: +130 us per call)
-    if constexpr (HINTED) { if (tid < (WT > 0 ? WT : a.W)) xs[tid] = a.queries[tid]; }
+    if constexpr (HINTED) { if (tid < (WT > 0 ? WT : a.W)) xs[tid] = BLK ? x[tid] : a.queries[tid]; }
     __syncthreads();
     if (!ctl[C_MAGIC_OK]) {            // a workspace psh_workspace_init never saw (or a run that gave up): separate launches
         if (blockIdx.x == 0 && tid == 0) f.status[0] = PSH_STATUS_RETRY_;
@@ -269,7 +280,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_fused_kernel(ScanArgs a
     // ------------------------------------------------------------------ B: all minima -> tau2, scale, threshold
     if constexpr (hinted) {
         // (a hint that is not a positive finite number does not arm the launch: PSH_STATUS_RETRY, as for an absurd estimate)
-        if (tid == 0) derive_levels(f.tau_hint[0]);
+        if (tid == 0) derive_levels(BLK ? f.hint_v : f.tau_hint[0]);
         __syncthreads();
         if (ctl[C_BAIL] != 0) {
             if (tid == 0) {
@@ -665,7 +676,21 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_fused_kernel(ScanArgs a
             if (lane == 0 && c) atomicAdd(&rankc[i2], c);
         }
         __syncthreads();
-        if (tid < mown) {
+        if constexpr (BLK) {
+            // a blocking caller: every winner of this block leaves with its path (shadow()'s gather, reference
+            // path_shadowing.py:211-216: C x (W + h) samples from the ensemble) -- a wave per winner, everything as write-through
+            // system-scope stores into the caller's pinned block (no gather launch, no copy, nothing left in an L2)
+            for (int j = wave; j < mown; j += NW) {
+                const int rk = rankc[j];
+                if (rk >= a.k) continue;
+                const u32x4 o = fl[j];
+                if (lane < 3) sys_store32(lane == 0 ? reinterpret_cast<unsigned*>(f.out_d + rk) : reinterpret_cast<unsigned*>(f.out_idx + 2 * rk + (lane - 1)), o[lane]);
+                const float* src = f.g_ds + ((int64_t)o[1] - a.r_offset) * f.g_C * f.g_T + (int64_t)o[2];
+                unsigned* dst = reinterpret_cast<unsigned*>(f.g_out + (int64_t)rk * f.g_C * f.g_len);
+                for (int c = 0; c < f.g_C; ++c)
+                    for (int e = lane; e < f.g_len; e += 64) sys_store32(dst + c * f.g_len + e, __float_as_uint(src[(int64_t)c * f.g_T + e]));
+            }
+        } else if (tid < mown) {
             const int rk = rankc[tid];
             if (rk < a.k) {
                 const u32x4 o = fl[tid];
@@ -684,7 +709,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_fused_kernel(ScanArgs a
         // publication by the candidate loads and the ranking (several round trips).  OK is only declared over a header
         // that is still armed.
         const bool armed = g_load(&hdr->magic) == PSH_FUSED_MAGIC;
-        f.status[0] = (good && armed) ? PSH_STATUS_OK_ : PSH_STATUS_RETRY_;
+        sys_store32(reinterpret_cast<unsigned*>(f.status), (good && armed) ? PSH_STATUS_OK_ : PSH_STATUS_RETRY_);   // (a blocking caller's word sits in host memory)
         if (f.total) f.total[0] = ntotal;
         if (a.qstate) {                                     // diagnostics / the separate launches' state, kept coherent
             QueryState q;
@@ -695,6 +720,25 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void scan_fused_kernel(ScanArgs a
         }
         // every block has read the epoch long ago (they all passed the first barrier): the next launch's tags
         g_store(reinterpret_cast<u64*>(&hdr->epoch), (u64)(epoch + 1u));
+    }
+    if constexpr (BLK) {
+        // completion words of a blocking call: every wave's stores have been acknowledged (vmcnt) before its block takes a
+        // ticket of its shard; the block that takes the shard's last ticket resets the counter for the next launch (launches on
+        // a workspace are serialised) and tells the host.  The launches that return early (RETRY before the scan) set no word:
+        // the host's wait falls back on the stream (psh_capi.hip).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned shard = blockIdx.x % (unsigned)f.done_shards;
+            const unsigned in_shard = (gridDim.x - shard + (unsigned)f.done_shards - 1u) / (unsigned)f.done_shards;
+            unsigned* cnt = &hdr->pad[4 + shard];
+            const unsigned old = __hip_atomic_fetch_add((gu32*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old + 1u == in_shard) {
+                g_store32(cnt, 0u);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                sys_store32(f.done + shard, f.done_val);
+            }
+        }
     }
 }
 
@@ -727,20 +771,20 @@ static hipError_t launch_fused_k(K kernel, int grid, size_t shmem, hipStream_t s
     return hipGetLastError();
 }
 
+template <bool HINTED, bool BLK>
+static hipError_t launch_fused_hb(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, size_t shmem, hipStream_t s) {
+    if (a.W == 20)
+        return aligned ? launch_fused_k(scan_fused_kernel<20, true, HINTED, BLK>, grid, shmem, s, a, f)
+                       : launch_fused_k(scan_fused_kernel<20, false, HINTED, BLK>, grid, shmem, s, a, f);
+    return aligned ? launch_fused_k(scan_fused_kernel<0, true, HINTED, BLK>, grid, shmem, s, a, f)
+                   : launch_fused_k(scan_fused_kernel<0, false, HINTED, BLK>, grid, shmem, s, a, f);
+}
+
 hipError_t launch_scan_fused(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, hipStream_t s) {
     const size_t shmem = scan_fused_shmem_bytes(a.tile_floats);
-    if (f.tau_hint) {
-        if (a.W == 20)
-            return aligned ? launch_fused_k(scan_fused_kernel<20, true, true>, grid, shmem, s, a, f)
-                           : launch_fused_k(scan_fused_kernel<20, false, true>, grid, shmem, s, a, f);
-        return aligned ? launch_fused_k(scan_fused_kernel<0, true, true>, grid, shmem, s, a, f)
-                       : launch_fused_k(scan_fused_kernel<0, false, true>, grid, shmem, s, a, f);
-    }
-    if (a.W == 20)
-        return aligned ? launch_fused_k(scan_fused_kernel<20, true, false>, grid, shmem, s, a, f)
-                       : launch_fused_k(scan_fused_kernel<20, false, false>, grid, shmem, s, a, f);
-    return aligned ? launch_fused_k(scan_fused_kernel<0, true, false>, grid, shmem, s, a, f)
-                   : launch_fused_k(scan_fused_kernel<0, false, false>, grid, shmem, s, a, f);
+    const bool blk = f.g_ds != nullptr && f.done != nullptr;
+    if (f.tau_hint) return blk ? launch_fused_hb<true, true>(a, f, aligned, grid, shmem, s) : launch_fused_hb<true, false>(a, f, aligned, grid, shmem, s);
+    return blk ? launch_fused_hb<false, true>(a, f, aligned, grid, shmem, s) : launch_fused_hb<false, false>(a, f, aligned, grid, shmem, s);
 }
 
 }  // namespace psh

@@ -106,7 +106,20 @@ struct FusedArgs {
                                      // (the workspace's candidate arrays taken as one region; FusedHdr::cand on a minimal workspace)
     int k_out;                       // stream launches: row length of out_d / out_idx (= k)
     const float* tau_hint;           // nullable: the caller's admission level per query (psh_profile.tau_hint) -- no sample, no first barrier
+    // a BLOCKING caller's extras (psh_shadow_blocking; the fused launch only): shadow()'s path gather (reference
+    // path_shadowing.py:211-216) done by the ranking itself, and completion words the host polls instead of waiting for the
+    // end of the kernel -- results and words leave as write-through system-scope stores
+    const float* g_ds;               // nullable: (R, C, T) ensemble the paths of the k winners are gathered from
+    float* g_out;                    //   (k, C, g_len) float32, device-ADDRESSABLE (the caller's pinned block)
+    int64_t g_T;
+    int g_C, g_len;
+    float qv[36];                    //   the query BY VALUE (W <= 33): the launch reads it from its kernel arguments, not over PCIe
+    float hint_v;                    //   with tau_hint != nullptr: the admission level by value
+    unsigned* done;                  // nullable: done_shards device-addressable words; shard i's last block stores done_val there
+    unsigned done_val;
+    int done_shards;                 //   blocks are dealt to the shards round-robin (blockIdx % done_shards): one counter each in FusedHdr::pad
 };
+#define PSH_FUSED_DONE_SHARDS 8      // completion counters of a blocking call: FusedHdr::pad[4 .. 11]
 
 struct PrepArgs {
     const float* queries;

@@ -139,6 +139,7 @@ class PathShadowing:
         self._served_by = "hip"     # what the last _native_scan ran: "hip", or "torch" (a dirty ensemble behind a linear embedding)
         self._gen = 0               # bumped by refresh()
         self._workspace = None
+        self._fast = None           # what the last blocking one-query shadow(cuda=True) was prepared for (_shadow_prepared)
         self.last_profile = None
         self.last_path = None       # "hip" / "torch": which implementation served the last shadow() / predict()
         self.last_predict_reduction = None   # device_predict: "device" (psh_weighted_moments) / "host" (the class's own avg / std)
@@ -573,6 +574,10 @@ class PathShadowing:
         ksize = self.embedding.kernel.shape[-1]
         if ksize != 0 and ksize != x_context.shape[-1]:
             raise Exception("The embedding kernel should be of the same size as the context.")
+        if cuda and self._fast is not None:
+            got = self._shadow_fast(self._fast, x_context, k)
+            if got is not None:
+                return got
         x = _torch(_dim_array(x_context))
         y = self._dataset_tensor()
         length = x.shape[-1] + self.context.get_out_times()
@@ -612,8 +617,11 @@ class PathShadowing:
         return _numpy(d), _numpy(paths.permute(0, 1, 3, 2).contiguous()), _numpy(idx)
 
     def _shadow_prepared(self, x: torch.Tensor, y: torch.Tensor, k: int):
-        """shadow() for ONE Identity query through a _native.PreparedShadow slot on the current stream (fused launch); None when
-        the status says the general path has to serve the call."""
+        """shadow() for ONE Identity query as one blocking library call (_native.BlockingShadow -> psh_shadow_blocking: the fused
+        launch gathers the paths itself and writes everything into a pinned block the results are handed out of); None when the
+        status says the general path has to serve the call.  Leaves `self._fast`: what the next call checks -- a dozen identity
+        comparisons -- to come straight back here without the general argument handling (ref :181-218 re-reads the dataset
+        on every call; here the question is only whether anything a call depends on has been replaced)."""
         if not (y.is_cuda or self._may_keep_resident()):
             return None                                               # (an ensemble re-uploaded per call: no slot to keep)
         dev = self._hip_device()
@@ -631,19 +639,53 @@ class PathShadowing:
         key = (ds.data_ptr(), tuple(ds.shape), ds._version, W, k, h, str(dev), wsb.data_ptr())
         st = getattr(self, "_sync_slot", None)
         if st is None or st[0] != key:
-            st = self._sync_slot = (key, _native.PreparedShadow(rows, ds, W, k, h, self._workspace, 0, host_direct=True))
-        slot = st[1]
-        stream = torch.cuda.current_stream(dev)
+            st = self._sync_slot = (key, _native.BlockingShadow(rows, ds, W, k, h, self._workspace, 0))
+        owner = self.dataset
+        self._fast = {"slot": st[1], "owner": owner, "version": owner._version if isinstance(owner, torch.Tensor) else None,
+                      "numpy_ro": isinstance(owner, np.ndarray) and self.cache is not True,
+                      "emb": self.embedding, "kernel": self.embedding.kernel, "dist": self.distance, "ctx": self.context, "h": h,
+                      "k": k, "W": W, "dev": dev.index, "gen": self._gen, "wsbuf": wsb, "cache": self.cache, "hint": self.hint,
+                      "ds": ds, "rows": rows}
+        xq = x[0, 0, :].detach()
+        return self._shadow_blocking_call(self._fast, xq.cpu().numpy() if xq.is_cuda else xq.numpy())
+
+    def _shadow_fast(self, fs: dict, x_context, k: int):
+        """The blocking call again when NOTHING it depends on has changed since `_shadow_prepared` built `fs` (same dataset
+        object and version, same plugin objects, horizon, k, device, workspace buffer, no refresh()); else None."""
+        owner = self.dataset
+        if not (k == fs["k"] and owner is fs["owner"] and self.embedding is fs["emb"] and self.embedding.kernel is fs["kernel"]
+                and self.distance is fs["dist"] and self.context is fs["ctx"] and self._gen == fs["gen"] and self.cache == fs["cache"]
+                and self.hint == fs["hint"] and self._workspace is not None and self._workspace.buf is fs["wsbuf"]
+                and self.context.get_out_times() == fs["h"] and torch.cuda.current_device() == fs["dev"]):
+            return None
+        if fs["version"] is not None:
+            if owner._version != fs["version"]:
+                return None
+        elif fs["numpy_ro"] and owner.flags.writeable:
+            return None
+        if isinstance(x_context, np.ndarray):
+            xq = x_context
+        elif isinstance(x_context, torch.Tensor) and not x_context.is_cuda and not x_context.requires_grad:
+            xq = x_context.numpy()
+        else:
+            return None
+        W = fs["W"]
+        if xq.size != W or xq.shape[-1] != W or xq.ndim > 3:
+            return None                                               # (several queries, another length: the general path says what is wrong)
+        return self._shadow_blocking_call(fs, xq.reshape(W))
+
+    def _shadow_blocking_call(self, fs: dict, xq: np.ndarray):
+        slot, k, W = fs["slot"], fs["k"], fs["W"]
+        stream = torch._C._cuda_getCurrentRawStream(fs["dev"])
         xn2 = None
         if self.hint == "auto":
-            xl = x[0, 0, :].tolist()
-            xn2 = math.fsum(v * v for v in xl)
+            x64 = np.asarray(xq, dtype=np.float32).astype(np.float64)
+            xn2 = float(x64 @ x64)
         hint = self._next_hint(xn2, k, W)
-        slot.launch(stream, x[:, 0, :], hint)
-        slot.event.synchronize()
+        status, res = slot.call(stream, xq, hint)
         self.last_path = "hip"
         self.last_hint = None
-        if hint is not None and int(slot.status_np[0]) != _native.PSH_STATUS_OK:
+        if hint is not None and status != _native.PSH_STATUS_OK:
             # the hint fell short of k windows (or admitted more than the lists hold): the same call without it; no hints for
             # a while (twice as long after every miss in a row)
             self.last_hint = "short"
@@ -652,21 +694,20 @@ class PathShadowing:
             hstate["skip"] = 4 << hstate["fails"]
             # (the fused launch says RETRY for "fewer than k found" with its header still armed; one a time-out disarmed says
             #  RETRY again below and takes the general path)
-            slot.launch(stream, x[:, 0, :], None)
-            slot.event.synchronize()
+            status, res = slot.call(stream, xq, None)
         elif hint is not None:
             self.last_hint = "ok"
             self._hint_state["fails"] = 0
-        hd, hp, hi, hs = slot.take()
-        if hs.any():
-            if int(hs[0]) == _native.PSH_STATUS_RETRY:
+        if status != _native.PSH_STATUS_OK:
+            if status == _native.PSH_STATUS_RETRY:
                 self._workspace.arm()
             return None
         if self.hint == "auto":
+            h = fs["h"]
             hstate = self._hint_state if (self._hint_state and self._hint_state["key"] == (k, W, h)) else {"key": (k, W, h), "skip": 0, "fails": 0}
-            hstate["dk"] = float(hd[0, k - 1]) if xn2 > 0 else None
+            hstate["dk"] = float(res[0][0, k - 1]) if xn2 > 0 else None
             self._hint_state = hstate
-        return hd, hp, hi
+        return res
 
     HINT_MARGIN = 1.15          # on acc: the k-th distance may come out 7 % above the previous call's before the hint falls short
 

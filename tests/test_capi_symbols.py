@@ -36,10 +36,10 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_version_and_strerror(lib):
     from shadowing_amd import _native
-    assert lib.psh_version() == _native.PSH_VERSION == 2
+    assert lib.psh_version() == _native.PSH_VERSION == 3
     # the header and the binding agree on the version and on the size of psh_profile (ctypes mirrors the C layout)
     text = (REPO / "include" / "psh.h").read_text()
-    assert re.search(r"#define PSH_VERSION 2\b", text)
+    assert re.search(r"#define PSH_VERSION 3\b", text)
     # ... as a C compiler lays the header's struct out
     import subprocess, tempfile
     with tempfile.TemporaryDirectory() as tmp:
