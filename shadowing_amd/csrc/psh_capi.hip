@@ -749,7 +749,8 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
         const bool one_overlap = use_mx && B == 1 && (flags_of(profile) & PSH_FLAG_OVERLAP);
         // ONE query with a long window (34 <= W <= 256): the same three launches, flag or no flag, with the scan's banded product
         // as a K-loop (stream_scan_long_kernel) -- otherwise such a call has only the vector-ALU filter of scan_kernel
-        const bool one_long = !p.ker && !rows_path && long_q > 0 && B <= long_q && !(flags_of(profile) & PSH_FLAG_FILTER_VALU);
+        // (the long-window scan's deferred survivors pack t into 30 bits)
+        const bool one_long = !p.ker && !rows_path && long_q > 0 && B <= long_q && !(flags_of(profile) & PSH_FLAG_FILTER_VALU) && p.T < (1ll << 30);
         if ((small_batch || one_overlap || one_long) && !rows_path && !stages && !(flags_of(profile) & PSH_FLAG_NO_FUSE) &&
             (scan_fused_supported(p.W) || one_long)) {
             int ncu = 0;

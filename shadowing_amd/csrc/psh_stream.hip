@@ -551,16 +551,50 @@ __device__ __forceinline__ void stream_scan_body(const ScanArgs& a, const FusedA
 // K-step s lies at row m + (s >> 1), halves 16 (s & 1) + 8 hk .. + 7 of it: per PAIR of K-steps one pointer moves by one row
 // and every other offset is an immediate -- the slot-rotation layout of the short kernels (mx_half) cost the K-loop 7 vector
 // instructions per step for the address alone, and on this part vector instructions ADD to the matrix cores' time (A.5).
-#define PSH_LONG_ROW 72
+// inc += (inc of the lane CTRL names, 0 where there is none): one step of a wave scan, a v_add_f32 with a DPP operand
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_addf(float inc) {
+    return inc + __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(inc), CTRL, ROW_MASK, 0xf, true));
+}
+#define PSH_LONG_ROW 40
+#define PSH_LONG_SFLOATS 1280         // fp32 prefix sums of a segment's squares: entries 0 .. SEG + W - 1 <= 1279; the survivors' scratch afterwards
+#define PSH_LONG_QCAP 64              // deferred survivors a wave keeps before it verifies them (8-byte entries)
+#define PSH_LONG_GAMMA 7.62939453125e-06f   // 2^-17: what the energies' prefix sums may be off by, per unit of the prefix S[p + W] (see below)
 __host__ __device__ inline int stream_long_rows(int W) { return 31 + (stream_ksteps(W) + 1) / 2; }                 // rows the band of row 31 reaches
 __host__ __device__ inline int stream_long_nhalf(int W) { return stream_long_rows(W) * PSH_LONG_ROW; }             // halves per wave (both arrays)
 __device__ __forceinline__ int long_half(int idx) { return (idx >> 5) * PSH_LONG_ROW + (idx & 31); }                // logical sample -> its y^ half ((y~^2)^: + 32)
+
+// The band's K-steps of one query: the fragment of K-step s lies at pa0 + (s >> 1) rows + 16 (s & 1) halves, its table at
+// pb + s ts -- every offset an immediate off two registers for all 18 steps a window of 256 takes; one exit.
+__device__ __forceinline__ f32x16 long_chain(const _Float16* pa0, const _Float16* pb, const int ts, const f32x16& c0, const int nks) {
+    auto ld = [](const _Float16* p) { return *reinterpret_cast<const f16x8*>(p); };
+    f32x16 c = c0;
+    f16x8 a0 = ld(pa0), b0 = ld(pb), a1, b1;
+    // step S multiplies set CUR and requests step S + 1 into set NXT (spelled out: an unrolled loop with a break became a real
+    // loop that picked its register set with v_cndmask).  (The compiler sinks a pair of reads down to the step that uses it, so a
+    // step is still read - wait - multiply; reads as inline assembly with hand-placed wait counts kept them ahead but cost the
+    // allocator 200 spills over the chain's eighteen exits -- four waves per SIMD hide the round trip well enough.)
+#define PSH_LONG_STEP(S, CA, CB, NA, NB)                                                        \
+    if ((S) >= nks) goto done;                                                                  \
+    NA = ld(pa0 + (((S) + 1) >> 1) * PSH_LONG_ROW + 16 * (((S) + 1) & 1));                      \
+    NB = ld(pb + ((S) + 1) * ts);                                                               \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(CA, CB, c, 0, 0, 0);
+    PSH_LONG_STEP(0, a0, b0, a1, b1) PSH_LONG_STEP(1, a1, b1, a0, b0) PSH_LONG_STEP(2, a0, b0, a1, b1) PSH_LONG_STEP(3, a1, b1, a0, b0)
+    PSH_LONG_STEP(4, a0, b0, a1, b1) PSH_LONG_STEP(5, a1, b1, a0, b0) PSH_LONG_STEP(6, a0, b0, a1, b1) PSH_LONG_STEP(7, a1, b1, a0, b0)
+    PSH_LONG_STEP(8, a0, b0, a1, b1) PSH_LONG_STEP(9, a1, b1, a0, b0) PSH_LONG_STEP(10, a0, b0, a1, b1) PSH_LONG_STEP(11, a1, b1, a0, b0)
+    PSH_LONG_STEP(12, a0, b0, a1, b1) PSH_LONG_STEP(13, a1, b1, a0, b0) PSH_LONG_STEP(14, a0, b0, a1, b1) PSH_LONG_STEP(15, a1, b1, a0, b0)
+    PSH_LONG_STEP(16, a0, b0, a1, b1) PSH_LONG_STEP(17, a1, b1, a0, b0)
+#undef PSH_LONG_STEP
+    static_assert(PSH_STREAM_LONG_KS == 18, "the chain is spelled out for 18 steps");
+done:
+    return c;
+}
 
 // NQ: one, two or three queries ride one pass (round 5): the window energies' MFMA of a K-step is shared, a query adds one
 // MFMA with its own fragment -- 1 + NQ per step where NQ one-query steps issue 2 NQ -- and the segment is staged and converted
 // once (three queries with W = 126: one pass where the loop of one-query steps made three).
 template <bool ALIGNED, int NQ>
-__global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(ScanArgs a, FusedArgs f) {
+__device__ __forceinline__ void stream_scan_long_body(const ScanArgs& a, const FusedArgs& f) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NW = PSH_SCAN_THREADS / 64;
     constexpr int NFL = PSH_STREAM_FL(NQ);
@@ -571,10 +605,12 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
     const int nks = stream_ksteps(W), nhalf = stream_long_nhalf(W);
     int* ctl = reinterpret_cast<int*>(smem);                                 // 64 control words
     u32x4* fl = reinterpret_cast<u32x4*>(ctl + 64);                           // NFL entries {acc bits, r, t, query}
-    _Float16* bxl = reinterpret_cast<_Float16*>(fl + NFL);                    // [K-step]{NQ x [lane][8]: -2 x~_q shifted by the lane's column; [lane][8]: the band of ones}
-    constexpr int TS = (NQ + 1) * 64 * 8;                                     // halves of a K-step's tables
-    _Float16* ah0 = bxl + (size_t)nks * TS;
-    _Float16* a1 = ah0 + (size_t)wave * nhalf;                                // rows of {y^ [32], (y~^2)^ [32], pad [8]}
+    _Float16* bxl = reinterpret_cast<_Float16*>(fl + NFL);                    // [K-step][query][lane][8]: -2 x~_q shifted by the lane's column
+    constexpr int TS = NQ * 64 * 8;                                           // halves of a K-step's tables
+    float* sp0 = reinterpret_cast<float*>(bxl + (size_t)nks * TS);            // per wave: PSH_LONG_SFLOATS prefix sums, then the queue, then the rows
+    float* sp = sp0 + (size_t)wave * (PSH_LONG_SFLOATS + 2 * PSH_LONG_QCAP + nhalf / 2);
+    u64* sq = reinterpret_cast<u64*>(sp + PSH_LONG_SFLOATS);                  // deferred survivors: row | t << 32 | query << 62
+    _Float16* a1 = reinterpret_cast<_Float16*>(sq + PSH_LONG_QCAP);           // rows of {y^ [32], pad [8]}
     FusedHdr* hdr = f.hdr;
     const StreamCtl* sc = &hdr->stream;
 
@@ -586,28 +622,37 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
         ri = fast_div(uu, a.magic_nseg, (unsigned)a.nseg);
         sg = uu - ri * (unsigned)a.nseg;
     };
+    // A segment is staged by BUFFER loads (round 6): the row is the resource (base = its first float, records = its bytes), a lane's
+    // five 16-byte pieces sit at one constant VGPR offset + immediates, the segment's start is the scalar offset -- no address
+    // arithmetic on the vector ALUs, and what lies beyond the row reads as zero (it only feeds inadmissible windows).  Rows need
+    // 4-byte alignment only: one code path for aligned and unaligned ensembles.
+    const int lane16 = lane * 16;
+    auto stage_row = [&](Stage& sx, int64_t row, int seg_start) {
+        const int64_t bytes = a.T * 4;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dataset + row * a.T), 0,
+                                                                             (int)(bytes > 0x7ffffffc ? 0x7ffffffc : bytes), 0x00020000);
+        const int nq4 = (nfloat + 3) >> 2;
+#pragma unroll
+        for (int q = 0; q < PSH_NSTAGE; ++q)
+            if (q < PSH_NSTAGE - 1 || lane + 64 * q < nq4) {
+                const u32x4v w = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + 1024 * q, seg_start * 4, 2 /* nt */);
+                sx.v[q] = f32x4{__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])};
+            }
+    };
     auto load_unit = [&](Stage& sx, unsigned uu) {
         unsigned ri, sg;
         decode(uu, ri, sg);
-        stage_load<ALIGNED>(sx, a.dataset + (a.row0 + (int64_t)ri * a.row_stride) * a.T, a.T, (int)sg * PSH_SEG, nfloat, lane);
+        stage_row(sx, a.row0 + (int64_t)ri * a.row_stride, (int)sg * PSH_SEG);
     };
     Stage st;
     unsigned u = u_lo + (unsigned)wave;
     if (u < u_hi) load_unit(st, u);
-    // the tables: the sample kernel's fragments of the shifted query (plain loads: an earlier launch on this stream), the band of
-    // ones by arithmetic
+    // the tables: the sample kernel's fragments of the shifted query (plain loads: an earlier launch on this stream)
     for (int i = tid; i < nks * 64; i += PSH_SCAN_THREADS) {
-        const int s = i >> 6, l = i & 63, n = l & 31, hk = l >> 5;
+        const int s = i >> 6, l = i & 63;
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
             *reinterpret_cast<f16x8*>(bxl + (size_t)s * TS + ((size_t)q * 64 + l) * 8) = *reinterpret_cast<const f16x8*>(hdr->bxtab + ((size_t)q * nks * 64 + i) * 8);
-        f16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int j = 16 * s + 8 * hk + e - n;
-            o[e] = (_Float16)((j >= 0 && j < W) ? 1.0f : 0.0f);
-        }
-        *reinterpret_cast<f16x8*>(bxl + (size_t)s * TS + ((size_t)NQ * 64 + l) * 8) = o;
     }
     const unsigned armed_w = sc->armed;
     const float scale = __uint_as_float(sc->scale_bits);
@@ -617,7 +662,7 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
         tau2[q] = __uint_as_float(sc->tau2_bits[q]); thr2[q] = __uint_as_float(sc->thr2_bits[q]); xn[q] = __uint_as_float(sc->xn_bits[q]);
     }
     if (tid == 0) { ctl[S_FRONT] = 0; ctl[S_NEXT] = NW; }
-    {   // every slot of the f16 arrays a segment does not write must be finite (0 * NaN poisons a row)
+    {   // every slot of the rows a segment does not write must be finite (0 * NaN poisons a row)
         unsigned* z = reinterpret_cast<unsigned*>(a1);
         for (int i = lane; i < nhalf / 2; i += 64) z[i] = 0u;
     }
@@ -628,105 +673,153 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
         if (lane == 0) v = atomicAdd(&ctl[S_NEXT], 1);
         return u_lo + (unsigned)__builtin_amdgcn_readfirstlane(v);
     };
+    // ---- deferred survivors (round 6).  A window that survives the test goes to the wave's queue -- row, t, query: 8 bytes --
+    // and the queue is verified when it is full (64 entries) and when the wave has no unit left: about ten survivors in a wave's
+    // whole life on ordinary data, so ONE batch at its end instead of a stall in one segment out of four (re-fetching the segment
+    // and running the chains in place was 20 of the scan's 125 us at W = 126).
+    int qn = 0;                                                               // entries in the queue (uniform)
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));     // a window starts at any float
+    auto verify_queue = [&]() {
+        // a lane per queued window: its W samples straight from memory, 16 bytes a load (64 scattered requests an instruction,
+        // all of them L2 / MALL hits: the segment was streamed microseconds ago), the chain in the reference's order
+        const bool have = lane < qn;
+        const u64 mine = have ? sq[lane] : 0ull;
+        const int q = (int)(mine >> 62);
+        const unsigned t = (unsigned)(mine >> 32) & 0x3fffffffu;
+        const float* y = a.dataset + (int64_t)(unsigned)mine * a.T + t;
+        const const_f32p x = (const_f32p)a.queries + (size_t)(NQ == 1 ? 0 : q) * W;
+        float v = 0.0f;
+        if (have) {
+            int j = 0;
+#pragma unroll 2
+            for (; j + 4 <= W; j += 4) {
+                const f32x4u yy = *reinterpret_cast<const f32x4u*>(y + j);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const float D = __fsub_rn(x[j + c], yy[c]); v = __builtin_fmaf(D, D, v); }
+            }
+            for (; j < W; ++j) { const float D = __fsub_rn(x[j], y[j]); v = __builtin_fmaf(D, D, v); }
+        }
+        float tq = tau2[0], xq = xn[0];
+#pragma unroll
+        for (int qq = 1; qq < NQ; ++qq) { tq = q == qq ? tau2[qq] : tq; xq = q == qq ? xn[qq] : xq; }
+        const bool hit = have && (v < tq);
+        const unsigned long long mask = __ballot(hit);
+        if (mask) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&ctl[S_FRONT], __popcll(mask));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (hit) {
+                const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                const int r_global = (int)((int64_t)(unsigned)mine + a.r_offset);
+                if (slot < NFL) fl[slot] = u32x4{__float_as_uint(v), (unsigned)r_global, t, (unsigned)q};
+                else spill_candidate(hdr, f.cand_list, f.cand_cap, q, xq, v, r_global, (int)t);
+            }
+        }
+        wave_lds_fence();                                                     // (the queue is read: it may be written again)
+        qn = 0;
+    };
+    const int m = lane & 31, hk = lane >> 5;
+    const _Float16* pa0 = a1 + m * PSH_LONG_ROW + 8 * hk;
+    const _Float16* pb0 = bxl + lane * 8;
+    const float* ps_lo = sp + m + 128 * hk;                                   // S[p] of the lane's 16 windows: p = m + 128 hk + 32 (r & 3) + 256 (r >> 2)
+    const float* ps_hi = ps_lo + W;
     while (u < u_hi) {
         unsigned ri, sg;
         decode(u, ri, sg);
         const int64_t row = a.row0 + (int64_t)ri * a.row_stride;
         const int seg_start = (int)sg * PSH_SEG;
-        const int r_global = (int)(row + a.r_offset);
         {
+            // the segment's f16 copy y^ (rows of 32 samples), and -- round 6 -- the WINDOW ENERGIES from fp32 prefix sums of the
+            // squares instead of a second banded product: S[i] = sum of y~_j^2, j < i, 3 adds inside a lane, six DPP adds across
+            // the wave, the carry from one 256-sample group to the next (embed_px_kernel's scan, psh_embed_px.hip).  All terms are
+            // >= 0, every S[i] is a sum of them in SOME order with at most 17 roundings on a term's way:
+            //     |S^[i] - S[i]| <= 17 u S[i] (1 + ...)   (u = 2^-24)    =>    |(S^[p + W] - S^[p]) - E(p)| <= 35 u S[p + W]
+            // which the test below takes off the energy as PSH_LONG_GAMMA S^[p + W] = 128 u S[p + W] (3.6x the bound: room for the
+            // C operand's own rounding and its share of the product's accumulation).  The correlation keeps the f16 bound of
+            // stream_threshold unchanged -- its error model had the energies' f16 roundings in it, which are gone.  The K-loop
+            // is ONE MFMA and TWO fragment reads per step instead of two and four (the energies' MFMAs were what made a long
+            // window's K-loop ADD to the streaming time: W = 126 105 -> 87 us, W = 252 155 -> 113 us for the scan without them).
+            // A NaN / inf sample makes every LATER prefix of the segment NaN / inf: those windows survive the test (NaN-safe
+            // compare) and the exact chains sort them out -- slow on such a segment, never wrong.
             const int nq4 = (nfloat + 3) >> 2;
+            // (the five groups' scans step by step side by side: a DPP operand written by the instruction before costs two wait
+            //  states, five independent chains fill them)
+            float d0[PSH_NSTAGE], d1[PSH_NSTAGE], d2[PSH_NSTAGE], d3[PSH_NSTAGE], inc[PSH_NSTAGE];
 #pragma unroll
             for (int q = 0; q < PSH_NSTAGE; ++q) {
-                const int m = lane + 64 * q;
-                if (q < PSH_NSTAGE - 1 || m < nq4) {
-                    const f32x4 v = st.v[q] * scale;
-                    const f32x4 v2 = v * v;
-                    _Float16* dst = a1 + (m >> 3) * PSH_LONG_ROW + 4 * (m & 7);   // (= long_half(4 m))
-                    *reinterpret_cast<f16x4*>(dst) = __builtin_convertvector(v, f16x4);
-                    *reinterpret_cast<f16x4*>(dst + 32) = __builtin_convertvector(v2, f16x4);
-                }
+                const int mm = lane + 64 * q;
+                const bool on = q < PSH_NSTAGE - 1 || mm < nq4;
+                const f32x4 v = on ? st.v[q] * scale : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                const f32x4 z = v * v;
+                if (on) *reinterpret_cast<f16x4*>(a1 + (mm >> 3) * PSH_LONG_ROW + 4 * (mm & 7)) = __builtin_convertvector(v, f16x4);
+                d0[q] = z[0]; d1[q] = d0[q] + z[1]; d2[q] = d1[q] + z[2]; d3[q] = d2[q] + z[3];
+                inc[q] = d3[q];
+            }
+#ifdef PSH_TUNING
+            if (!(a.dbg & 64))                                                // ablation: no scan, no sums stored (results invalid)
+#endif
+            {
+#pragma unroll
+            for (int q = 0; q < PSH_NSTAGE; ++q) inc[q] = dpp_addf<0x111, 0xf>(inc[q]);
+#pragma unroll
+            for (int q = 0; q < PSH_NSTAGE; ++q) inc[q] = dpp_addf<0x112, 0xf>(inc[q]);
+#pragma unroll
+            for (int q = 0; q < PSH_NSTAGE; ++q) inc[q] = dpp_addf<0x114, 0xf>(inc[q]);
+#pragma unroll
+            for (int q = 0; q < PSH_NSTAGE; ++q) inc[q] = dpp_addf<0x118, 0xf>(inc[q]);
+#pragma unroll
+            for (int q = 0; q < PSH_NSTAGE; ++q) inc[q] = dpp_addf<0x142, 0xa>(inc[q]);
+#pragma unroll
+            for (int q = 0; q < PSH_NSTAGE; ++q) inc[q] = dpp_addf<0x143, 0xc>(inc[q]);
+            float carry = 0.0f;
+#pragma unroll
+            for (int q = 0; q < PSH_NSTAGE; ++q) {
+                const int mm = lane + 64 * q;
+                const float x0 = carry + (inc[q] - d3[q]);                    // exclusive: the lane's own total taken off again
+                carry += __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(inc[q]), 63));
+                if (q < PSH_NSTAGE - 1 || mm <= nq4) *reinterpret_cast<f32x4*>(sp + 4 * mm) = f32x4{x0, x0 + d0[q], x0 + d1[q], x0 + d2[q]};
+            }
             }
         }
         wave_lds_fence();
         const unsigned un = grab();
         if (un < u_hi) load_unit(st, un);
-
-        const int m = lane & 31, hk = lane >> 5;
 #ifdef PSH_TUNING
         const int nks_run = (a.dbg & 8) ? 1 : nks;                            // ablation: one K-step (results invalid)
 #else
         const int nks_run = nks;
 #endif
+        // the tile's C operand: what the prefix sums say about the 16 windows of this lane, E^(p) - gamma S^[p + W]
+        f32x16 ce;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int off = 32 * (r & 3) + 256 * (r >> 2);
+            ce[r] = __builtin_fmaf(ps_hi[off], 1.0f - PSH_LONG_GAMMA, -ps_lo[off]);
+        }
+#ifdef PSH_TUNING
+        if (a.dbg & 32) {                                                     // ablation: no energies read back (results invalid)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ce[r] = 0.0f;
+        }
+#endif
+        // The band's K-steps as ONE unrolled chain: the fragment of K-step s lies at pa0 + (s >> 1) rows + 16 (s & 1) halves, its
+        // table at pb0 + s TS -- every offset an immediate off TWO registers for all 18 steps a window of 256 takes, a uniform
+        // branch per step.  The test that follows is 16 compares into scalar masks OR-ed on the scalar unit; only a segment that
+        // holds a survivor builds per-lane masks.
+        auto ld = [](const _Float16* p) { return *reinterpret_cast<const f16x8*>(p); };
         unsigned hmq[NQ];                                                     // per query: bit r = accumulator r's window survives the test
-        const _Float16* pa0 = a1 + m * PSH_LONG_ROW + 8 * hk;
-        const _Float16* pb0 = bxl + lane * 8;
-        if constexpr (NQ == 1) {
-            f32x16 acc;                                                       // (ONE chain: energies and correlation into two tiles, summed at the end, was 4 % slower)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-            // two K-steps per turn: 8 fragment reads off two pointers with immediate offsets, 4 MFMAs, 2 pointer moves (the band
-            // of ones comes from its table in every step: a read costs the vector ALUs nothing, a constant kept in registers was
-            // rebuilt with 4 moves per step)
-            const _Float16* pa = pa0;
-            const _Float16* pb = pb0;
-#define PSH_LONG_STEP(AOFF, BOFF)                                                                                                      \
-            {                                                                                                                          \
-                const f16x8 e1 = *reinterpret_cast<const f16x8*>(pa + (AOFF));                                                         \
-                const f16x8 e2 = *reinterpret_cast<const f16x8*>(pa + (AOFF) + 32);                                                    \
-                const f16x8 bx = *reinterpret_cast<const f16x8*>(pb + (BOFF));                                                         \
-                const f16x8 bo = *reinterpret_cast<const f16x8*>(pb + (BOFF) + 64 * 8);                                                \
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e2, bo, acc, 0, 0, 0);                                                    \
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, bx, acc, 0, 0, 0);                                                    \
+        for (int q = 0; q < NQ; ++q) {
+            const f32x16 c = long_chain(pa0, pb0 + q * 64 * 8, TS, ce, nks_run);
+            unsigned long long any = 0ull;                                    // NaN-safe: !(t^ > thr)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) any |= __ballot(!(c[r] > thr2[q]));
+            unsigned hm = 0u;
+            if (any) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hm |= !(c[r] > thr2[q]) ? (1u << r) : 0u;
             }
-            int s = 0;
-#pragma unroll 1
-            for (; s + 1 < nks_run; s += 2) {
-                PSH_LONG_STEP(0, 0)
-                PSH_LONG_STEP(16, TS)
-                pa += PSH_LONG_ROW;
-                pb += 2 * TS;
-            }
-            if (s < nks_run) PSH_LONG_STEP(0, 0)
-#undef PSH_LONG_STEP
-            unsigned hm = 0u;                                                 // NaN-safe: !(t^ > thr)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) hm |= !(acc[r] > thr2[0]) ? (1u << r) : 0u;
-            hmq[0] = hm;
-        } else {
-            // the window energies first (one chain over the band of ones), then every query's banded product on top of them
-            // (the energies are the C operand of its first MFMA: no copy); a query's tile is tested and dropped before the next
-            // one's chain starts -- only the 16-bit masks stay
-            auto chain = [&](const f32x16& c0, int aoff, int boff) -> f32x16 {
-                // (two K-steps per turn off two pointers, every other offset an immediate -- as the one-query loop)
-                const _Float16* pa = pa0 + aoff;
-                const _Float16* pb = pb0 + boff;
-                auto ld = [](const _Float16* p) { return *reinterpret_cast<const f16x8*>(p); };
-                f32x16 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ld(pa), ld(pb), c0, 0, 0, 0);
-                if (nks_run > 1) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ld(pa + 16), ld(pb + TS), c, 0, 0, 0);
-                int s = 2;
-#pragma unroll 1
-                for (; s + 1 < nks_run; s += 2) {
-                    pa += PSH_LONG_ROW;
-                    pb += 2 * TS;
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ld(pa), ld(pb), c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ld(pa + 16), ld(pb + TS), c, 0, 0, 0);
-                }
-                if (s < nks_run) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ld(pa + PSH_LONG_ROW), ld(pb + 2 * TS), c, 0, 0, 0);
-                return c;
-            };
-            f32x16 zero16;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) zero16[i] = 0.0f;
-            const f32x16 accE = chain(zero16, 32, NQ * 64 * 8);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const f32x16 aq = chain(accE, 0, q * 64 * 8);
-                unsigned hm = 0u;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) hm |= !(aq[r] > thr2[q]) ? (1u << r) : 0u;
-                hmq[q] = hm;
-            }
+            hmq[q] = hm;
         }
         unsigned hany = 0u;
 #pragma unroll
@@ -735,58 +828,30 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
         if (a.dbg & 4) hany = 0u;                                             // ablation: no survivor handling (results invalid)
 #endif
         if (__any(hany != 0u)) {
-            // the survivors (about one segment in four holds any): the segment's fp32 values come back from memory in ONE
-            // coalesced round trip (streamed a microsecond ago: L2 / MALL) into the wave's f16 arrays -- their fragments are
-            // consumed -- and the exact chains (the reference's order: D = fl(x_j - y_j), acc = fma(D, D, acc)) read them there.
-            // (Each survivor reading its W samples from memory itself was W / 4 dependent round trips: W = 64 at +25 % of the
-            // W = 20 step.)
-            float* tile = reinterpret_cast<float*>(a1);                       // nfloat floats <= 2 nhalf bytes (the wave's rows)
-            {
-                Stage sv;
-                stage_load<ALIGNED>(sv, a.dataset + row * a.T, a.T, seg_start, nfloat, lane);
-                wave_lds_fence();                                             // every lane has read its fragments
-                stage_store<false>(sv, tile, nfloat, lane);
-                wave_lds_fence();
-            }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const unsigned hm = hmq[q];
                 if (!__any(hm != 0u)) continue;
-                const const_f32p x = (const_f32p)a.queries + (size_t)q * W;
 #pragma unroll 1
                 for (int r = 0; r < 16; ++r) {
                     const int p = 32 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + m; // C layout: row -> window
-                    bool hit = (((hm >> r) & 1u) != 0u) && (seg_start + p < a.Tp);
-                    if (!__ballot(hit)) continue;
-                    float v = 0.0f;
-                    if (hit) {
-                        const float* y = tile + p;
-#pragma unroll 4
-                        for (int j = 0; j < W; ++j) { const float D = __fsub_rn(x[j], y[j]); v = __builtin_fmaf(D, D, v); }
-                    }
-                    hit = hit && (v < tau2[q]);
+                    const bool hit = (((hm >> r) & 1u) != 0u) && (seg_start + p < a.Tp);
                     const unsigned long long mask = __ballot(hit);
                     if (!mask) continue;
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(&ctl[S_FRONT], __popcll(mask));
-                    base = __builtin_amdgcn_readfirstlane(base);
+                    const int n = (int)__popcll(mask);
+                    if (qn + n > PSH_LONG_QCAP) verify_queue();               // (uniform; the prefix sums are dead by now: its scratch)
                     if (hit) {
-                        const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                        if (slot < NFL) fl[slot] = u32x4{__float_as_uint(v), (unsigned)r_global, (unsigned)(seg_start + p), (unsigned)q};
-                        else spill_candidate(hdr, f.cand_list, f.cand_cap, q, xn[q], v, r_global, seg_start + p);
+                        const int slot = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                        sq[slot] = (u64)(unsigned)row | ((u64)(unsigned)(seg_start + p) << 32) | ((u64)(unsigned)q << 62);
                     }
+                    qn += n;
                 }
-            }
-            // the arrays' tails past what a segment's conversion writes hold fp32 bits now: zeros again (0 * NaN poisons a row)
-            wave_lds_fence();
-            for (int idx = 4 * ((nfloat + 3) >> 2) + 4 * lane; idx < 32 * stream_long_rows(W); idx += 256) {
-                *reinterpret_cast<f16x4*>(a1 + long_half(idx)) = f16x4{0, 0, 0, 0};
-                *reinterpret_cast<f16x4*>(a1 + long_half(idx) + 32) = f16x4{0, 0, 0, 0};
             }
         }
         wave_lds_fence();  // all lanes done with the arrays before they are overwritten
         u = un;
     }
+    if (qn > 0) verify_queue();
     __syncthreads();
     if (wave == 0) {                                                          // (stream_scan_body's publication)
         const int nfront = ctl[S_FRONT];
@@ -816,6 +881,10 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(Scan
         }
     }
 }
+template <bool ALIGNED, int NQ>
+__global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_long_kernel(ScanArgs a, FusedArgs f) {
+    stream_scan_long_body<ALIGNED, NQ>(a, f);
+}
 
 // one query: 112 registers (56 arch + 56 acc of the unified file), so that a sample or ranking wave of another stream's step fits
 // beside four of these on a SIMD; two or three queries: the whole file (their steps are rarely run beside others)
@@ -827,6 +896,7 @@ template <int WT, bool ALIGNED, int NQ>
 __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_q_kernel(ScanArgs a, FusedArgs f) {
     stream_scan_body<WT, ALIGNED, NQ>(a, f);
 }
+
 
 // ------------------------------------------------------------------------------------------------------------------
 // R: ranking by counting (grid.y = query)
@@ -928,9 +998,10 @@ size_t stream_scan_shmem_bytes_q(int tile_floats, int nq) {
 size_t stream_scan_shmem_bytes(int tile_floats) { return stream_scan_shmem_bytes_q(tile_floats, 1); }
 bool stream_long_supported(int W) { return W >= 34 && W <= 256; }
 size_t stream_scan_long_shmem_bytes(int W, int nq) {
+    // control words, the block's list, the queries' fragment tables; per wave: the prefix sums, the survivors' queue, the f16 rows
     return (size_t)PSH_STREAM_FIXED_BYTES + (size_t)(nq == 1 ? PSH_FUSED_FRONT : 2 * PSH_FUSED_FRONT) * 16
-           + (size_t)(nq + 1) * stream_ksteps(W) * 64 * 8 * sizeof(_Float16)
-           + (size_t)(PSH_SCAN_THREADS / 64) * stream_long_nhalf(W) * sizeof(_Float16);
+           + (size_t)nq * stream_ksteps(W) * 64 * 8 * sizeof(_Float16)
+           + (size_t)(PSH_SCAN_THREADS / 64) * ((size_t)(PSH_LONG_SFLOATS + 2 * PSH_LONG_QCAP) * sizeof(float) + (size_t)stream_long_nhalf(W) * sizeof(_Float16));
 }
 size_t stream_sample_shmem_bytes(int tile_floats) {
     const size_t t = (size_t)tile_floats * sizeof(float), h = (size_t)PSH_STREAM_HIST * sizeof(unsigned);

@@ -182,7 +182,7 @@ def test_fused_and_overlap_launches_admit_exactly_the_windows_below_the_level(hi
     for i, (W, h, B, flags, path) in enumerate([(20, 20, 1, 0, 2), (13, 0, 1, 0, 2), (20, 20, 1, _native.FLAG_OVERLAP, 3),
                                                 (20, 5, 2, 0, 3), (25, 0, 3, 0, 3),
                                                 (64, 5, 1, 0, 3), (126, 20, 1, 0, 3), (250, 0, 1, 0, 3),      # long windows: the K-loop scan
-                                                (40, 3, 3, 0, 3), (126, 0, 2, 0, 3), (200, 7, 3, 0, 3), (256, 0, 2, 0, 3)]):   # ... two / three queries a pass
+                                                (40, 3, 3, 0, 3), (126, 0, 2, 0, 3), (96, 7, 3, 0, 3), (140, 0, 2, 0, 3)]):   # ... two / three queries a pass (three up to W = 97, two up to 145: what fits LDS)
         ds, q = adversarial(kind, 4096, 2048, B, W, h, 200 + 5 * i)
         for m in (2000, 500, 100):                       # (planted matches crowd single blocks: a shallower level then)
             try:
