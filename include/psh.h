@@ -122,6 +122,10 @@ extern "C" {
  * ~4x is better served by f16 (a much smaller query keeps too many windows for its exact recheck -- slower, never wrong).
  * Same results either way (A/B tests; callers that know their batch). */
 #define PSH_FLAG_MQ_F16       4096
+/* LONG_LOOP: psh_scan_topk with four queries and more and a window of 34 .. 256 samples: the loop of one- to three-query steps of
+ * rounds 5 (a pass over the ensemble per step) instead of the batched long-window scan (round 6: one pass per chunk of queries,
+ * the queries' fragment tables in LDS, a segment's fragments in registers for all of them).  Same results (A/B tests, timing). */
+#define PSH_FLAG_LONG_LOOP    8192
 typedef struct psh_profile {
     int   mode;           /* in */
     int   flags;          /* in: PSH_FLAG_* */

@@ -11,7 +11,7 @@ CSRC = PKG / "csrc"
 LIBDIR = PKG / "lib"
 LIB = LIBDIR / "libpsh_hip.so"
 INCLUDE = PKG.parent / "include"
-SOURCES = [CSRC / "psh_scan.hip", CSRC / "psh_fused.hip", CSRC / "psh_stream.hip", CSRC / "psh_embed.hip", CSRC / "psh_embed_px.hip", CSRC / "psh_embed_mx.hip", CSRC / "psh_select.hip",
+SOURCES = [CSRC / "psh_scan.hip", CSRC / "psh_fused.hip", CSRC / "psh_stream.hip", CSRC / "psh_lq.hip", CSRC / "psh_embed.hip", CSRC / "psh_embed_px.hip", CSRC / "psh_embed_mx.hip", CSRC / "psh_select.hip",
            CSRC / "psh_capi.hip", CSRC / "psh_comm.hip", CSRC / "psh_predict.hip", CSRC / "psh_prep.hip"]
 DEPS = SOURCES + [CSRC / "psh_kernels.h", CSRC / "psh_device.h", INCLUDE / "psh.h"]
 

@@ -18,7 +18,7 @@ PSH_VERSION = 3          # include/psh.h: 2: psh_profile.tau_hint, psh_candidate
 PSH_STATUS_OK, PSH_STATUS_OVERFLOW, PSH_STATUS_RETRY = 0, 1, 2
 PSH_MAX_W, PSH_MAX_K, PSH_MAX_B_PER_LAUNCH = 256, 16384, 1024
 # psh_profile.flags (include/psh.h)
-FLAG_UNSORTED, FLAG_FILTER_VALU, FLAG_EMBED_DENSE, FLAG_ROWS_GENERIC, FLAG_NO_FUSE, FLAG_RESERVE_CUS, FLAG_EMBED_MX, FLAG_EMBED_TAPS, FLAG_EMBED_PLAN_KEEP, FLAG_EMBED_MX_SPLIT, FLAG_SELECT_ONE_BLOCK, FLAG_OVERLAP, FLAG_MQ_F16 = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096
+FLAG_UNSORTED, FLAG_FILTER_VALU, FLAG_EMBED_DENSE, FLAG_ROWS_GENERIC, FLAG_NO_FUSE, FLAG_RESERVE_CUS, FLAG_EMBED_MX, FLAG_EMBED_TAPS, FLAG_EMBED_PLAN_KEEP, FLAG_EMBED_MX_SPLIT, FLAG_SELECT_ONE_BLOCK, FLAG_OVERLAP, FLAG_MQ_F16, FLAG_LONG_LOOP = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192
 
 
 class NativeLibraryError(RuntimeError):

@@ -643,8 +643,11 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     // (tools/long_batch_probe.py).  Status words stay per query; a RETRY of any step sends the caller's WHOLE call to
     // PSH_FLAG_NO_FUSE, as the protocol says.
     const int long_q = long_queries_per_step(W);
+    // four queries and more with a long window: ONE pass per chunk of queries of the batched long-window scan (psh_lq.hip) through
+    // the separate launches' pipeline, instead of the loop of steps below
+    const bool use_lq = !ker && p.Tp > 1 && B >= 4 && scan_lq_supported(W, B, T) && !(flags_of(profile) & (PSH_FLAG_FILTER_VALU | PSH_FLAG_NO_FUSE | PSH_FLAG_LONG_LOOP));
     const int per_step = !ker && p.Tp > 1 ? (long_q > 0 && B > long_q ? long_q : (W >= 26 && W <= 33 && B > PSH_STREAM_MAX_Q ? PSH_STREAM_MAX_Q : 0)) : 0;
-    if (per_step && !(profile && profile->mode == PSH_PROFILE_STAGES) && !(flags_of(profile) & (PSH_FLAG_FILTER_VALU | PSH_FLAG_NO_FUSE))) {
+    if (per_step && !use_lq && !(profile && profile->mode == PSH_PROFILE_STAGES) && !(flags_of(profile) & (PSH_FLAG_FILTER_VALU | PSH_FLAG_NO_FUSE))) {
         psh_profile sub;
         for (int b = 0; b < B; b += per_step) {
             const int nb = B - b < per_step ? B - b : per_step;
@@ -940,6 +943,16 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
             sa.boot_estimate = (r2e < k && r2e <= bp.entries) ? 1 : 0;
         }
         HIP_TRY(launch_boot_mq(sa, p.aligned, (int)gx, s));
+    } else if (use_lq && bp.per_wave == 1) {
+        // upper bounds of the segment minima of every query from the batched long-window kernel (one pass over the sampled rows)
+        int ncu = 0;
+        HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+        sa.q_per_group = scan_lq_chunk(p.W, B);
+        sa.n_qgroups = (B + sa.q_per_group - 1) / sa.q_per_group;
+        int64_t gx = (n_sample * sa.nseg + 7) / 8;
+        if (gx > ncu) gx = ncu;
+        if (gx < 1) gx = 1;
+        HIP_TRY(launch_scan_lq(sa, PSH_MODE_BOOT, (int)gx, s));
     } else if (rows_path) {
         int ncu = 0;
         HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
@@ -1028,6 +1041,19 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
         fa.mq_i8 = mq_i8 ? 1 : 0;
         fa.slice = w.cap / nblk;
         HIP_TRY(launch_scan_mq(fa, p.aligned, (int)gx, s));
+    } else if (use_lq) {
+        int ncu = 0;
+        HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+        fa.q_per_group = scan_lq_chunk(p.W, B);
+        fa.n_qgroups = (B + fa.q_per_group - 1) / fa.q_per_group;
+        const int64_t n_rs = p.R * ((p.Tp + PSH_SEG - 1) / PSH_SEG);
+        int64_t gx = (n_rs + 7) / 8;
+        if (gx > ncu) gx = ncu;
+        if (gx > PSH_MAX_BLOCKS) gx = PSH_MAX_BLOCKS;
+        if (gx < 1) gx = 1;
+        nblk = (int)gx;
+        fa.slice = w.cap / nblk;
+        HIP_TRY(launch_scan_lq(fa, PSH_MODE_FILTER, nblk, s));
     } else if (rows_path) {
         int ncu = 0;
         HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));

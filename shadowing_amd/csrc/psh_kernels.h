@@ -336,6 +336,11 @@ size_t stream_scan_shmem_bytes_q(int tile_floats, int nq);
 bool stream_long_supported(int W);              // one to three queries, 34 <= W <= 256: the scan of the step as a K-loop over the band (stream_scan_long_kernel)
 size_t stream_scan_long_shmem_bytes(int W, int nq);
 hipError_t launch_stream_scan_long(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, hipStream_t s);
+// psh_lq.hip: batched queries with a long window (B >= 4, 34 <= W <= 256): BOOT / FILTER of the separate launches' pipeline
+bool scan_lq_supported(int W, int B, int64_t T);
+int scan_lq_chunk(int W, int B);                 // queries a block's chunk takes (ScanArgs::q_per_group; grid.y = ceil(B / chunk))
+size_t scan_lq_shmem_bytes(int W, int B, int q_per_group);
+hipError_t launch_scan_lq(const ScanArgs& a, int mode, int grid_x, hipStream_t s);
 hipError_t launch_embed_rows(const float* dataset, int64_t R, int64_t T, const float* ker, int d, int K, float* out, hipStream_t s);
 // psh_predict.hip: the reductions of predict_from_paths() on the device
 struct MomentsArgs {

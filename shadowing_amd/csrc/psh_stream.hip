@@ -73,7 +73,11 @@ __device__ inline bool stream_threshold(const_f32p xq, int W, float tau0, float 
     for (int j = 0; j < W; ++j) { const double vv = (double)xq[j] * (double)sc; nxs += vv * vv; }
     // (b: the absolute part of the bound -- f16 subnormals, one unit of 2^-24 per product -- grows with the taps: 2^-18 covers the
     //  2 W + 1 = 41 .. 67 terms of W <= 33; a long window takes (2 W + 2) / 64 of it)
-    const double am = 1.0 / 512.0, bm = (1.0 / 262144.0) * (W > 31 ? (double)(2 * W + 2) / 64.0 : 1.0);
+    // a: the relative part.  W <= 33: 2^-9 covers the f16 roundings of x~, y~ AND (y~^2)^ plus the fp32 accumulation of both banded
+    // products.  A long window's energies are fp32 prefix sums whose error the tile's C operand takes off separately (round 6:
+    // ce <= E by construction), so only the correlation is left:  |c^ - c| <= (2^-10 (1 + 2^-12) + 2 x 288 x 2^-24)(nx~ + E) / 2 x 2,
+    // and with E <= 2 (nx~ + acc~):  t^ <= acc~ (1 + 2 a') - nx~ (1 - 3 a'),  a' = 1.012e-3 -> 1 / 900 with a tenth to spare.
+    const double am = W > 33 ? 1.0 / 900.0 : 1.0 / 512.0, bm = (1.0 / 262144.0) * (W > 31 ? (double)(2 * W + 2) / 64.0 : 1.0);
     const double taus = (double)tau0 * (double)sc * (double)sc;
     const double T = taus * (1.0 + 1.0 / 131072.0) * (1.0 + 2.0 * am) - nxs * (1.0 - 3.0 * am) * (1.0 - 1e-12) + bm;
     float Tf = (float)T;

@@ -476,9 +476,28 @@ def test_long_window_batches_loop_over_the_one_query_step(hip_device, oracle_mod
     info = {}
     d, idx, st = _native.scan_topk(ds_t, q_t, k, h=h, info=info)
     torch.cuda.synchronize()
-    # (the path of the LAST step: the three launches, or -- one query left over with W <= 33 -- the fused launch)
-    assert info["path"] == (3 if W > 33 or B % 3 != 1 else 2) and not st.cpu().numpy().any(), (info, st.tolist())
+    # round 6: four queries and more with W >= 34 are ONE pass per chunk of queries of the batched long-window scan (psh_lq.hip,
+    # through the separate launches: path 0); fewer queries, 26 <= W <= 33 and PSH_FLAG_LONG_LOOP keep the loop of steps
+    # (the path of its LAST step: the three launches, or -- one query left over with W <= 33 -- the fused launch)
+    batched = W > 33 and B >= 4
+    assert info["path"] == (0 if batched else (3 if W > 33 or B % 3 != 1 else 2)), info
+    stn = st.cpu().numpy()
+    if batched:
+        # (the separate launches admit below a sampled estimate per query: on an ensemble this small a query's estimate may fall
+        #  short of k windows -- its status says so, PSH_STATUS_OVERFLOW, and the checked call reruns that query: the protocol)
+        ok = stn == 0
+        assert ok.sum() >= (B + 1) // 2, stn
+        assert_exact(d.cpu().numpy()[ok], idx.cpu().numpy()[ok], od[ok], oidx[ok], f"long-window batch W={W} B={B}: the queries that report OK")
+        d, idx = _native.scan_topk_checked(ds_t, q_t, k, h=h)
+    else:
+        assert not stn.any(), (info, stn)
     assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, f"long-window batch W={W} B={B}")
+    if batched:
+        info = {}
+        d, idx, st = _native.scan_topk(ds_t, q_t, k, h=h, info=info, flags=_native.FLAG_LONG_LOOP)
+        torch.cuda.synchronize()
+        assert info["path"] == 3 and not st.cpu().numpy().any(), (info, st.tolist())
+        assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, f"long-window batch W={W} B={B}, the loop of steps")
     info = {}
     _native.scan_topk(ds_t, q_t, k, h=h, info=info, flags=_native.FLAG_FILTER_VALU)
     assert info["path"] == 0, info
@@ -496,7 +515,8 @@ def test_long_window_batches_loop_over_the_one_query_step(hip_device, oracle_mod
     torch.cuda.synchronize()
     stn = st.cpu().numpy()
     assert stn[B - 1] != 0 and not stn[: B - 1].any(), stn
-    assert np.isnan(d[B - 1].cpu().numpy()).all()
+    if not batched:                                    # (the three launches poison a query's invalid results; the separate launches' status says it)
+        assert np.isnan(d[B - 1].cpu().numpy()).all()
     assert_exact(d[: B - 1].cpu().numpy(), idx[: B - 1].cpu().numpy(), od[: B - 1], oidx[: B - 1], "the other queries of the call")
     d, idx = _native.scan_topk_checked(ds_t, q_t, k, h=h, tau_hint=torch.as_tensor(lev).to(hip_device))
     assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, f"long-window batch W={W} B={B}, checked with a short hint")

@@ -33,8 +33,8 @@ def _kernels(txt: str) -> dict:
 @pytest.fixture(scope="module")
 def asm(tmp_path_factory):
     tmp = tmp_path_factory.mktemp("isa")
-    names = ["psh_stream", "psh_fused", "psh_embed_px", "psh_embed_mx"]
-    with ThreadPoolExecutor(max_workers=4) as pool:
+    names = ["psh_stream", "psh_fused", "psh_embed_px", "psh_embed_mx", "psh_lq"]
+    with ThreadPoolExecutor(max_workers=5) as pool:
         return dict(zip(names, pool.map(lambda n: _asm(n, tmp), names)))
 
 
@@ -114,3 +114,15 @@ def test_wavelet_scan_on_the_matrix_cores_does_not_spill_and_keeps_its_product_l
         assert sum(o.startswith("v_mfma") for o in ops) == 48 and sum(o == "ds_read_b128" for o in ops) == 28, ops
         assert not [o for o in ops if o.startswith("v_") and not o.startswith("v_mfma") and o not in ("v_add_u32_e32",)], ops
         assert sum(o == "v_add_u32_e32" for o in ops) <= 2, ops
+
+
+def test_long_window_scans_do_not_spill(asm):
+    """stream_scan_long_kernel (one to three queries: at most 128 registers, four waves a SIMD) and scan_lq_kernel (the batched
+    long-window scan: eight waves a CU, 256 registers a lane) keep everything in registers; a scan_lq segment's MFMAs come in
+    groups of four independent tiles."""
+    k = _kernels(asm["psh_stream"])
+    long_k = {n: m for n, m in k.items() if "stream_scan_long_kernel" in n}
+    assert len(long_k) == 6 and all(m["spill"] == 0 and m["scratch"] == 0 and m["vgpr"] <= 128 for m in long_k.values()), long_k
+    assert all(m["vgpr"] <= 112 for n, m in long_k.items() if "ELi1EEEv" in n), long_k      # one query: room for a sample / ranking wave beside four of these
+    lq = {n: m for n, m in _kernels(asm["psh_lq"]).items() if "scan_lq_kernel" in n}
+    assert len(lq) == 8 and all(m["spill"] == 0 and m["scratch"] == 0 and m["vgpr"] <= 256 for m in lq.values()), lq
