@@ -163,19 +163,21 @@ class ShardedPathShadowing:
         # (PathShadowing._scan_rows_of, psh_prep.hip); paths are gathered from `dataset`
         self._rows = self.dataset[:, 0, :]
         dirty = bool(local_topk is None and self.dataset.numel() and _native.count_nonfinite(self.dataset))
-        if local_topk is None and self._linear:
-            # every rank takes the SAME decision: a rank that raised alone would leave the others waiting in the collectives
-            # that follow (communicator creation, the first all-gather)
-            anywhere = dirty
-            if self._emulate is None and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-                flag = torch.tensor([1 if dirty else 0], dtype=torch.int32, device=self.device)
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
-                anywhere = bool(int(flag.item()))
-            if anywhere:
-                raise ValueError("the sharded scan behind a linear embedding needs a finite ensemble on every rank (NaN / +-inf "
-                                 "samples: the embedded scans' rejection tests assume finite data; PathShadowing serves such an "
-                                 "ensemble on one GPU by scanning its dirty rows exhaustively -- INTEGRATION.md)"
-                                 + ("" if dirty else " -- another rank's shard holds such samples"))
+        self._dirty_split = None
+        if dirty and self._linear:
+            # NaN / +-inf samples behind a linear embedding (round 6: served, no longer refused): the embedded scans' rejection
+            # tests assume finite data (prefix sums and matrix-core tiles spread a NaN over clean windows), so THIS rank scans its
+            # clean rows as ever and its dirty rows -- the horizon smeared in -- with the exhaustive dense chains, which meet a NaN
+            # exactly where the reference's zero-padded conv does (ref path_embedding.py:48-51, :129-132), and merges the two
+            # lists before the exchange: PathShadowing._split_dirty_rows per shard.  No rank has to know about another's shard.
+            back = int(self.context.get_out_times())
+            flags_ = _native.rows_nonfinite(self.dataset)
+            dirty_idx = torch.nonzero(flags_).flatten()
+            clean_idx = torch.nonzero(flags_ == 0).flatten()
+            clean_rows = self.dataset[clean_idx, 0, :].contiguous()
+            dirty_rows = _native.smear_nonfinite(self.dataset[dirty_idx].contiguous(), back, 0)
+            self._dirty_split = (clean_idx, clean_rows, dirty_idx, dirty_rows)
+            dirty = False                               # (self._rows is not used by the split scan)
         if dirty:
             self._rows = _native.smear_nonfinite(self.dataset, int(self.context.get_out_times()), 0)
         self._scan_streams = None
@@ -285,6 +287,13 @@ class ShardedPathShadowing:
         if self._local_topk is not None:            # CPU test path (oracle injected)
             d, idx = self._local_topk(self.dataset[:, 0, :], q, k_local, h, self.row_offset)
             status = None
+        elif self._dirty_split is not None:
+            d, idx = self._split_local_topk(q, k_local, h, workspace or self._workspace, flags)
+            status = torch.zeros((q.shape[0],), dtype=torch.int32, device=self.device)
+            if out is not None and k_local == k:
+                out[0].copy_(d)
+                out[1].copy_(idx)
+                d, idx = out
         else:
             d, idx, status = _native_local_topk(self._rows, q, k_local, h, self.row_offset, workspace or self._workspace,
                                                 out=out if k_local == k else None, check=check, ker=self._ker,
@@ -294,6 +303,33 @@ class ShardedPathShadowing:
             d = torch.cat([d, d.new_full((B, k - k_local), float("inf"))], dim=1)
             idx = torch.cat([idx, idx.new_full((B, k - k_local, 2), -1)], dim=1)
         return d.contiguous(), idx.contiguous(), status
+
+    def _split_local_topk(self, hx: torch.Tensor, k_local: int, h: int, workspace, flags: int):
+        """This rank's k_local best behind a linear embedding when its shard holds non-finite samples: the clean rows through the
+        embedded scan (status protocol: a query whose slices overflow is redone exactly), the dirty rows -- smeared -- through the
+        exhaustive dense chains, the two lists merged by (d, r, t); row numbers global.  One host synchronisation (rare path)."""
+        clean_idx, clean_rows, dirty_idx, dirty_rows = self._dirty_split
+        Tp = self.dataset.shape[-1] - self._ker.shape[-1] - h + 1
+        n_clean, n_dirty = int(clean_idx.numel()) * Tp, int(dirty_idx.numel()) * Tp
+        parts_d, parts_i = [], []
+        if n_clean > 0:
+            kc = min(k_local, n_clean)
+            dc, ic, _ = _native_local_topk(clean_rows, hx, kc, h, 0, workspace, check=True, ker=self._ker, flags=flags)
+            ic = ic.clone()
+            ic[..., 0] = (clean_idx[ic[..., 0].long()] + self.row_offset).to(torch.int32)
+            parts_d.append(dc)
+            parts_i.append(ic)
+        if n_dirty > 0:
+            kd = min(k_local, n_dirty)
+            dd, idd, _ = _native.scan_topk_embedded(dirty_rows, self._ker, hx, kd, h=h, workspace=workspace, exhaustive=True,
+                                                    flags=_native.FLAG_EMBED_DENSE)
+            idd = idd.clone()
+            idd[..., 0] = (dirty_idx[idd[..., 0].long()] + self.row_offset).to(torch.int32)
+            parts_d.append(dd)
+            parts_i.append(idd)
+        if len(parts_d) == 1 and parts_d[0].shape[1] == k_local:
+            return parts_d[0].contiguous(), parts_i[0].contiguous()
+        return _native.merge_topk(torch.cat(parts_d, dim=1).contiguous(), torch.cat(parts_i, dim=1).contiguous(), k_local)
 
     def scan(self, queries: torch.Tensor, k: int, check: bool = True):
         """Collective.  queries (B, W) float32 (same on every rank).  Returns device

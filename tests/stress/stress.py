@@ -14,7 +14,7 @@ cases = [  # fixed, then random
     (70000, 128, 20, 20, 500, 3), (9000, 1000, 24, 12, 300, 5), (9000, 1000, 17, 3, 300, 2), (9000, 1000, 32, 0, 300, 2),
     (5000, 1501, 20, 20, 200, 2), (513, 4099, 20, 1, 1024, 1), (20000, 60, 20, 20, 100, 2), (1200, 900, 16, 4, 64, 1100),
 ]
-for _ in range(25):
+for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 25):
     W = int(rng.choice([3, 8, 15, 16, 17, 20, 20, 20, 21, 31, 32, 33, 64, 100, 256]))
     h = int(rng.integers(0, 30))
     T = int(rng.integers(W + h + 1, 3000))
@@ -42,3 +42,4 @@ for (R, T, W, h, k, B) in cases:
     bad += not (okd and oki)
     print(f"R={R} T={T} W={W} h={h} k={k} B={B} overflowed={badq.numel()} d={okd} idx={oki}{flag}", flush=True)
 print("mismatches:", bad, "time", round(time.time() - t_all, 1))
+sys.exit(1 if bad else 0)

@@ -53,6 +53,27 @@ def test_two_rank_gloo_run_with_a_batch_and_a_short_shard(oracle_mod):
     assert j["parity_rotating_queries"]["ok"] is True
 
 
+def test_four_rank_gloo_run_with_odd_shards(oracle_mod):
+    # four ranks (the driver's N = 4 line), an odd number of rows per rank and a row length that is no multiple of anything,
+    # k above a shard's window count: every rank pads, four lists meet in the merge
+    res, lines = _run_bench(4, ["--steps", "5", "--warmup", "2", "--rows-per-gpu", "7", "--T", "131", "--k", "600"])
+    assert res.returncode == 0, res.stderr[-3000:]
+    assert len(lines) == 1, res.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 4 and j["config"]["R_total"] == 28 and j["scaling"] == "weak"
+    assert j["parity_vs_golden"] is True and j["parity_rotating_queries"]["ok"] is True
+    assert "4 ways" in j["config"]["workload"] or "not a BASELINE" in j["config"]["workload"]
+
+
+def test_two_rank_gloo_run_with_512_query_dates(oracle_mod):
+    # configs[2]'s batch size through the sharded flow (B*k*12 bytes per rank in the one all-gather: 6 MiB at k = 1024; here small)
+    res, lines = _run_bench(2, ["--steps", "2", "--warmup", "1", "--rows-per-gpu", "6", "--T", "120", "--k", "24", "--queries", "512"])
+    assert res.returncode == 0, res.stderr[-3000:]
+    j = json.loads(lines[0])
+    assert j["config"]["queries"] == 512 and j["parity_rotating_queries"]["ok"] is True
+    assert j["config"]["windows_per_step"] == 2 * 6 * (120 - 20 - 20 + 1) * 512
+
+
 def test_one_rank_hook_and_launcher_mismatch(oracle_mod):
     res, lines = _run_bench(1, ["--steps", "2", "--warmup", "1", "--rows-per-gpu", "8", "--T", "100", "--k", "16"])
     assert res.returncode == 0, res.stderr[-3000:]

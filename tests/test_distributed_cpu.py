@@ -136,6 +136,65 @@ def test_two_rank_gloo_linear_embedding_matches_single_process(tmp_path, oracle_
         assert np.array_equal(z["paths"], paths)
 
 
+def _worker_embedded_dirty(rank, world, port, R, T, h, k, B, tmp):
+    sys.path.insert(0, str(REPO))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        import shadowing_amd as sa
+        from shadowing_amd import synthetic as syn
+        from shadowing_amd.distributed import ShardedPathShadowing, shard_rows
+        emb = sa.Foveal(alpha=1.4, beta=0.9, max_context=40)
+        ker = emb.kernel[:, 0, :].numpy().copy()
+
+        def local(ds2d, hx, k_, h_, r_offset):
+            d, idx = oracle.scan_topk_embedded(ds2d.numpy(), ker, hx.numpy(), k_, h=h_, r_offset=r_offset, nthreads=2)
+            return torch.from_numpy(d), torch.from_numpy(idx)
+
+        lo, hi = shard_rows(R, world, rank)
+        rows = _dirty_rows(R, T)[lo:hi]
+        obj = ShardedPathShadowing(emb, sa.RelativeMSE(), rows, lo, sa.PredictionContext(h), local_topk=local, merge=_torch_merge)
+        d, paths, idx = obj.shadow(syn.rolling_queries(B, 40, 16), k)
+        np.savez(os.path.join(tmp, f"rank{rank}.npz"), d=d, paths=paths, idx=idx)
+    finally:
+        dist.destroy_process_group()
+
+
+def _dirty_rows(R, T):
+    from shadowing_amd import synthetic as syn
+    ds = syn.dataset(R, T, 15).copy()
+    ds[R - 3, 0, 100] = np.nan                 # the LAST rank's shard holds the non-finite samples; the first one is clean
+    ds[R - 6, 0, 17] = np.inf
+    ds[R - 6, 0, 250] = -np.inf
+    return ds
+
+
+def test_two_rank_gloo_dirty_shard_behind_a_linear_embedding(tmp_path, oracle_mod):
+    """One rank's shard holds NaN / +-inf samples, the other's is clean, a Foveal embedding in front: every rank returns the
+    single-process oracle's answer (the reference's rule: a window is NaN when any tap of the zero-padded kernel meets such a
+    sample) -- no rank refuses, none has to know about the other's shard (round 6)."""
+    R, T, h, k, B = 21, 320, 7, 60, 2
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_worker_embedded_dirty, args=(2, port, R, T, h, k, B, str(tmp_path)), nprocs=2, join=True)
+    import shadowing_amd as sa
+    from shadowing_amd import synthetic as syn
+    ds = _dirty_rows(R, T)
+    emb = sa.Foveal(alpha=1.4, beta=0.9, max_context=40)
+    ker = emb.kernel[:, 0, :].numpy().copy()
+    x = syn.rolling_queries(B, 40, 16)
+    hx = emb(torch.tensor(x)[:, None, :])[:, 0, :].numpy()
+    d, idx = oracle_mod.scan_topk_embedded(ds, ker, hx, k, h=h)
+    assert np.isfinite(d).all()
+    paths = oracle_mod.gather_paths(ds, idx, 40 + h)[:, :, None, :]
+    for rank in range(2):
+        z = np.load(tmp_path / f"rank{rank}.npz")
+        assert np.array_equal(z["d"].view(np.uint32), d.view(np.uint32))
+        assert np.array_equal(z["idx"], idx)
+        assert np.array_equal(z["paths"], paths, equal_nan=True)
+
+
 def test_shard_rows_partition():
     from shadowing_amd.distributed import shard_rows
     for R in (1, 7, 8, 262144, 1000003):

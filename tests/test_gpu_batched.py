@@ -195,7 +195,7 @@ def test_batched_distance_cuda_matches_the_reference(hip_device, name):
     import shadowing_amd as sa
     g = load_golden(name)
     ds = rows3(g["dataset"])
-    obj = sa.PathShadowing(sa.Identity(g["W"]), sa.RelativeMSE(), ds, sa.PredictionContext(horizon=g["h"]))
+    obj = sa.PathShadowing(sa.Identity(g["W"]), sa.RelativeMSE(), ds, sa.PredictionContext(horizon=g["h"]), cache=True)
     x = torch.tensor(g["queries"])[:, None, :]
     d, idx = obj.batched_distance(x, torch.tensor(ds), g["k"], g["n_splits"], cuda=True)
     assert isinstance(d, torch.Tensor) and not d.is_cuda and d.dtype == torch.float32 and tuple(d.shape) == g["d"].shape
@@ -210,7 +210,7 @@ def test_shadow_cuda_identity_matches_the_reference_with_paths(hip_device, oracl
     import shadowing_amd as sa
     g = load_golden(name)
     ds = g["dataset"]
-    obj = sa.PathShadowing(sa.Identity(g["W"]), sa.RelativeMSE(), ds, sa.PredictionContext(horizon=g["h"]))
+    obj = sa.PathShadowing(sa.Identity(g["W"]), sa.RelativeMSE(), ds, sa.PredictionContext(horizon=g["h"]), cache=True)
     d, paths, idx = obj.shadow(g["queries"] if g["queries"].shape[0] > 1 else g["queries"][0], k=g["k"],
                                n_splits=g["n_splits"], cuda=True)
     assert obj.last_path == "hip"
@@ -310,7 +310,7 @@ def test_shadow_cuda_reads_the_status_with_the_results_and_recovers(hip_device, 
     base = syn.dataset(1, 2048, 2100)
     ds = np.ascontiguousarray(np.tile(base, (3000, 1, 1)))
     q = syn.single_query(20, 2101)
-    obj = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), ds, sa.PredictionContext(horizon=20))
+    obj = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), ds, sa.PredictionContext(horizon=20), cache=True)
     d, paths, idx = obj.shadow(q, k=500, cuda=True)
     assert obj.last_path == "hip"
     od, oidx = oracle_mod.scan_topk(rows3(ds), q[None, :], 500, h=20)
@@ -318,7 +318,7 @@ def test_shadow_cuda_reads_the_status_with_the_results_and_recovers(hip_device, 
     assert np.array_equal(paths[:, :, 0, :], oracle_mod.gather_paths(rows3(ds), idx, 40))
     # and an ordinary ensemble right after, on the same object's workspace
     ds2 = syn.dataset(4096, 2048, 2102)
-    obj2 = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), ds2, sa.PredictionContext(horizon=20))
+    obj2 = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), ds2, sa.PredictionContext(horizon=20), cache=True)
     d2, paths2, idx2 = obj2.shadow(q, k=500, cuda=True)
     od2, oidx2 = oracle_mod.scan_topk(rows3(ds2), q[None, :], 500, h=20)
     assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32)) and np.array_equal(idx2, oidx2)

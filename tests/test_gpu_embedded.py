@@ -330,7 +330,7 @@ def test_one_window_rows_behind_a_linear_embedding(hip_device, oracle_mod, name)
     od, oidx = oracle_mod.scan_topk_embedded(ds, g["kernel"], g["hx"], g["k"], h=h)
     assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, name + " vs oracle")
     obj = sa.PathShadowing(sa.PathEmbedding(torch.tensor(g["kernel"])[:, None, :]), sa.RelativeMSE(), g["dataset"],
-                           sa.PredictionContext(horizon=g["h"]))
+                           sa.PredictionContext(horizon=g["h"]), cache=True)
     d2, paths, idx2 = obj.shadow(g["queries"], k=g["k"], cuda=True)
     assert obj.last_path == "hip"
     assert_exact(d2, idx2, od, oidx, name + " through PathShadowing")
@@ -349,7 +349,7 @@ def test_kernel_matrix_larger_than_sixteen_tiles_allow(hip_device, oracle_mod):
     assert tuple(fov.kernel.shape) == (39, 1, 252)
     ds = syn.dataset(1024, 2048, 88)
     x = syn.gbm_log_returns((2, 252), 89)
-    obj = sa.PathShadowing(fov, sa.RelativeMSE(), ds, sa.PredictionContext(horizon=20))
+    obj = sa.PathShadowing(fov, sa.RelativeMSE(), ds, sa.PredictionContext(horizon=20), cache=True)
     d, _, idx = obj.shadow(x, k=300, cuda=True)
     assert obj.last_path == "hip"
     hx = fov(torch.tensor(x)[:, None, :])[:, 0, :].numpy()
@@ -728,7 +728,7 @@ def test_reference_test_cell_2_shadow_self_consistency_on_the_device(hip_device)
     ctx = sa.PredictionContext(horizon=252)
     ds = torch.randn(32, 1, 4096).numpy()
     x = torch.randn(8, 1, 126).numpy()
-    obj = sa.PathShadowing(emb, sa.RelativeMSE(), ds, ctx)
+    obj = sa.PathShadowing(emb, sa.RelativeMSE(), ds, ctx, cache=True)
     d, paths, idx = obj.shadow(x, k=1024, cuda=True)
     assert obj.last_path == "hip" and paths.shape == (8, 1024, 1, 378) and idx.shape == (8, 1024, 2)
     hx = emb(torch.tensor(x))[:, 0, :]

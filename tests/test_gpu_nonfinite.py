@@ -187,3 +187,30 @@ def test_sharded_class_with_nonfinite_samples(hip_device, oracle_mod):
     torch.cuda.synchronize()
     od, oidx = oracle_mod.scan_topk(ds, q, k, h=h, r_offset=5000)
     assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, "dirty shard")
+
+
+@pytest.mark.parametrize("kind", ["foveal", "wavelet"])
+def test_sharded_class_serves_a_dirty_shard_behind_a_linear_embedding(hip_device, oracle_mod, kind):
+    """Round 6: ShardedPathShadowing no longer refuses NaN / +-inf samples behind a linear embedding -- the rank's clean rows keep
+    the embedded scan, its dirty rows (horizon smeared in) the exhaustive dense chains, the two lists are merged before the
+    exchange (PathShadowing's split, per shard): the oracle's answer, global row numbers, through the all-gather and the merge."""
+    import shadowing_amd as sa
+    from shadowing_amd.distributed import ShardedPathShadowing
+    R, T, h, k = 1024, 1500, 30, 200
+    emb = sa.Foveal(alpha=1.3, beta=0.9, max_context=60) if kind == "foveal" else sa.PathEmbedding(torch.tensor(syn.wavelet_bank(3, 64))[:, None, :])
+    ds = _dirty(R, T, 7700, n_nan=300, n_inf=60)
+    K = emb.kernel.shape[-1]
+    x = syn.gbm_log_returns((3, K), 7701)
+    hx = emb(torch.tensor(x)[:, None, :])[:, 0, :].numpy()
+    obj = ShardedPathShadowing(emb, sa.RelativeMSE(), torch.as_tensor(ds), 3000, sa.PredictionContext(h), device=hip_device,
+                               always_exchange=True)
+    for _ in range(2):
+        d, idx = obj.scan(torch.as_tensor(x), k)
+        torch.cuda.synchronize()
+        od, oidx = oracle_mod.scan_topk_embedded(ds, emb.kernel[:, 0, :].numpy(), hx, k, h=h, r_offset=3000)
+        assert np.isfinite(od).all()
+        assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, f"dirty shard behind {kind}")
+    dn, paths, idn = obj.shadow(x, k=k)
+    assert_exact(dn, idn, od, oidx, "shadow() on the dirty shard")
+    assert np.array_equal(paths[:, :, 0, :], oracle_mod.gather_paths(ds, idn - np.array([3000, 0], np.int32), paths.shape[-1]))
+    obj.close()

@@ -302,7 +302,7 @@ def test_small_batch_status_protocol_and_reference_golden(hip_device, oracle_mod
     assert np.array_equal(got_d[[0, 2]].view(np.uint32), od[[0, 2]].view(np.uint32)) and np.array_equal(got_i[[0, 2]], oidx[[0, 2]])
     assert np.isinf(got_d[1]).all()
     g = load_golden("cfg3_rolling_R2048")
-    obj = sa.PathShadowing(sa.Identity(g["W"]), sa.RelativeMSE(), g["dataset"], sa.PredictionContext(g["h"]))
+    obj = sa.PathShadowing(sa.Identity(g["W"]), sa.RelativeMSE(), g["dataset"], sa.PredictionContext(g["h"]), cache=True)
     dd, paths, ii = obj.shadow(g["queries"][:3], k=g["k"], cuda=True)
     assert_matches_reference(dd, ii, {**g, "d": g["d"][:3], "idx": g["idx"][:3]}, None, what="3 queries of cfg3_rolling_R2048")
 

@@ -109,7 +109,7 @@ def test_massive_ties_overflow_is_reported_and_exhaustive_is_exact(hip_device, o
     assert_exact(d2, idx2, od, oidx, "ties, exhaustive")
     # and the host wrapper resolves it transparently
     import shadowing_amd as sa
-    obj = sa.PathShadowing(sa.Identity(W), sa.RelativeMSE(), ds, sa.PredictionContext(h))
+    obj = sa.PathShadowing(sa.Identity(W), sa.RelativeMSE(), ds, sa.PredictionContext(h), cache=True)
     d3, _, idx3 = obj.shadow(q, k=k, cuda=True)
     assert_exact(d3, idx3, od, oidx, "ties, PathShadowing")
 
@@ -781,3 +781,18 @@ def test_selection_by_ranking_leaves_what_it_cannot_take(hip_device, oracle_mod)
     od2, oidx2 = oracle_mod.scan_topk(ds2, q, k, h=20)
     oidx2 = oidx2.copy(); oidx2[..., 0] += off
     assert_exact(d2, idx2, od2, oidx2, "row offset beyond the packed key")
+
+
+@pytest.mark.parametrize("script,seed,cases", [("stress_mx.py", 3, 25), ("stress_emx.py", 5, 25), ("stress.py", 7, 20)])
+def test_promoted_cuts_of_the_remaining_stress_scripts(hip_device, script, seed, cases):
+    """tests/stress/stress_mx.py (the single-query matrix-core scan on adversarial data), stress_emx.py (the dense embedded scan's
+    matrix-core rejection test against the vector-ALU one and the oracle) and stress.py (the separate launches) used to run outside
+    pytest only (round 5's verdict): 70 cases of them here -- each script is its own process, as on the command line, and says
+    `mismatches: 0`."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    res = subprocess.run([sys.executable, str(Path(__file__).parent / "stress" / script), str(seed), str(cases)],
+                         capture_output=True, text=True, timeout=1500)
+    tail = res.stdout[-2500:]
+    assert res.returncode == 0 and "MISMATCH" not in res.stdout and "mismatches: 0" in res.stdout, tail + res.stderr[-1500:]

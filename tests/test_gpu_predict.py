@@ -76,7 +76,7 @@ def test_predict_reduces_on_the_device_and_hands_other_classes_the_statistic(hip
     import shadowing_amd as sa
     ds = syn.dataset(2048, 1024, 81)
     x = syn.gbm_log_returns((4, 20), 82)
-    obj = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), ds, sa.PredictionContext(horizon=40))
+    obj = sa.PathShadowing(sa.Identity(20), sa.RelativeMSE(), ds, sa.PredictionContext(horizon=40), cache=True)
     Ts = [5, 20, 40]
 
     def stat(p):
