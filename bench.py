@@ -118,14 +118,39 @@ def self_launch(n: int, argv: list[str]) -> int:
         # a rendezvous that dies of EADDRINUSE is started again on a fresh port (the ranks have not touched a GPU by then)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
                "--master-port", str(free_port()), str(Path(__file__).resolve())] + argv
-        res = subprocess.run(cmd, env=env, stderr=subprocess.PIPE, text=True)
-        sys.stderr.write(res.stderr)
-        rc = res.returncode
-        busy = rc != 0 and any(m in res.stderr for m in ("EADDRINUSE", "Address already in use", "address already in use"))
+        rc, head, seconds = _run_streaming(cmd, env)
+        # only a rendezvous that died EARLY of a taken port is started again: a run that got as far as its GPUs is not repeated
+        busy = rc != 0 and seconds < 60.0 and any(m in head for m in ("EADDRINUSE", "Address already in use", "address already in use"))
         if not busy:
             break
         sys.stderr.write(f"bench.py: rendezvous port was taken (attempt {attempt + 1}); retrying on another one\n")
     return rc
+
+
+def _run_streaming(cmd: list[str], env: dict) -> tuple[int, str, float]:
+    """Run `cmd`, passing its stderr through LINE BY LINE as it comes (progress, RCCL / HIP errors of the ranks are seen while the
+    run is alive, nothing is held back in memory) and keeping the first 64 KB of it for the caller to look at.  Returns
+    (return code, that head of stderr, wall seconds)."""
+    import subprocess
+    import threading
+    t0 = time.perf_counter()
+    proc = subprocess.Popen(cmd, env=env, stderr=subprocess.PIPE, text=True)
+    head: list[str] = []
+    kept = [0]
+
+    def pump():
+        for line in proc.stderr:
+            sys.stderr.write(line)
+            sys.stderr.flush()
+            if kept[0] < 65536:
+                head.append(line)
+                kept[0] += len(line)
+
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    rc = proc.wait()
+    th.join(timeout=10)
+    return rc, "".join(head), time.perf_counter() - t0
 
 
 def sweep(counts: list[int], argv: list[str]) -> int:

@@ -647,7 +647,11 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     // the separate launches' pipeline, instead of the loop of steps below
     const bool use_lq = !ker && p.Tp > 1 && B >= 4 && scan_lq_supported(W, B, T) && !(flags_of(profile) & (PSH_FLAG_FILTER_VALU | PSH_FLAG_NO_FUSE | PSH_FLAG_LONG_LOOP));
     const int per_step = !ker && p.Tp > 1 ? (long_q > 0 && B > long_q ? long_q : (W >= 26 && W <= 33 && B > PSH_STREAM_MAX_Q ? PSH_STREAM_MAX_Q : 0)) : 0;
-    if (per_step && !use_lq && !(profile && profile->mode == PSH_PROFILE_STAGES) && !(flags_of(profile) & (PSH_FLAG_FILTER_VALU | PSH_FLAG_NO_FUSE))) {
+    // (the loop pays only when its sub-calls get the three launches: 5 k candidates in a query's list of 65536, a sample of 256
+    //  units and more -- a call outside that would be B / 3 passes with the vector-ALU filter instead of one; psh_profile then
+    //  describes the LAST step of the loop: path, grid, and in PSH_PROFILE_EVENTS mode the bracket of that step's scan)
+    const bool step_fits = 5 * (int64_t)k <= 65536 && p.R * ((p.Tp + PSH_SEG - 1) / PSH_SEG) >= 1024;
+    if (per_step && step_fits && !use_lq && !(profile && profile->mode == PSH_PROFILE_STAGES) && !(flags_of(profile) & (PSH_FLAG_FILTER_VALU | PSH_FLAG_NO_FUSE))) {
         psh_profile sub;
         for (int b = 0; b < B; b += per_step) {
             const int nb = B - b < per_step ? B - b : per_step;

@@ -260,6 +260,17 @@ class PathShadowing:
                 "there is no CPU fallback on this path -- use cuda=False for the host path")
         return torch.device("cuda", torch.cuda.current_device())
 
+    @staticmethod
+    def _caller_stacklevel() -> int:
+        """`stacklevel` that makes a warning point at the first frame OUTSIDE this module (shadow(), predict() and the device-side
+        predict reach the warning through different depths)."""
+        import sys
+        level, f = 1, sys._getframe(1)
+        while f is not None and f.f_globals.get("__name__") == __name__:
+            f = f.f_back
+            level += 1
+        return level
+
     def _resident_dataset(self, y: torch.Tensor, device: torch.device) -> torch.Tensor:
         """The (R, C, T) ensemble in HBM, uploaded once and kept while `y` is the same
         host storage (the reference re-uploads every split on every call, ref :154-155)."""
@@ -281,7 +292,7 @@ class PathShadowing:
                 warnings.warn(f"PathShadowing(cuda=True): the dataset is a writeable numpy array, so it is uploaded to the GPU again on "
                               f"every call ({mib:.0f} MiB each time, as the reference does) -- construct with cache=True (and call "
                               "refresh() after editing the array in place), or pass a read-only array or a torch tensor, to keep it "
-                              "resident in HBM", RuntimeWarning, stacklevel=4)
+                              "resident in HBM", RuntimeWarning, stacklevel=self._caller_stacklevel())
             up = y.contiguous().to(device, non_blocking=False)
             if scope is not None and scope[0] is self.dataset:
                 self._predict_scope = (self.dataset, up)
@@ -301,7 +312,7 @@ class PathShadowing:
             self._scan_rows = None
         return self._resident[1]
 
-    def _scan_rows_of(self, ds: torch.Tensor) -> torch.Tensor:
+    def _scan_rows_of(self, ds: torch.Tensor, smear: bool = True) -> torch.Tensor:
         """(R, T) rows the scan reads: the ensemble itself, or -- several channels, CrossChannelContext -- a
         contiguous copy of channel 0 kept beside it.  An ensemble that holds NaN / +-inf samples (looked for ONCE per
         resident copy: psh_count_nonfinite; `self._dirty` afterwards) is scanned by the Identity scan through rows in which
@@ -315,11 +326,14 @@ class PathShadowing:
         # ds[:, None, :] view of a 2-D CUDA dataset on every call, and a key that wanted the same object recounted the whole
         # ensemble -- a pass over it plus a host synchronisation -- on every shadow() call.  The cache keeps `ds` alive, so the
         # address cannot be handed to another tensor while the entry exists.
-        key = (ds.data_ptr(), tuple(ds.shape), tuple(ds.stride()), ds._version, back, str(ds.device))
+        # (`smear` False: a linear embedding's scan never reads the smeared copy -- its dirty rows go through _split_dirty_rows --
+        #  so a dirty ensemble does not pay for a second R x T array it would not use)
+        key = (ds.data_ptr(), tuple(ds.shape), tuple(ds.stride()), ds._version, back, str(ds.device), bool(smear))
         if self._scan_rows is None or self._scan_rows[0] != key:
-            self._dirty = bool(_native.count_nonfinite(ds))
-            self._dirty_split = None
-            if self._dirty:
+            if self._scan_rows is None or self._scan_rows[0][:6] != key[:6]:
+                self._dirty = bool(_native.count_nonfinite(ds))
+                self._dirty_split = None
+            if self._dirty and smear:
                 rows = _native.smear_nonfinite(ds, back, 0)
             else:
                 rows = ds[:, 0, :] if ds.shape[1] == 1 else ds[:, 0, :].contiguous()
@@ -349,7 +363,7 @@ class PathShadowing:
         _native.load()
         self._served_by = "hip"
         ds = self._resident_dataset(y, dev)
-        rows = self._scan_rows_of(ds)
+        rows = self._scan_rows_of(ds, smear=self._native_kind(x, y, k) not in ("linear", "padded"))
         h = self.context.get_out_times()
         if self._workspace is None or self._workspace.device != dev:
             self._workspace = _native.Workspace(dev)

@@ -175,7 +175,7 @@ def test_self_launch_refuses_more_ranks_than_gpus_with_one_line(monkeypatch, cap
     m = _bench_module()
     import subprocess as sp
     started = []
-    monkeypatch.setattr(sp, "run", lambda *a, **k: started.append(a) or (_ for _ in ()).throw(AssertionError("a rank was launched")))
+    monkeypatch.setattr(m, "_run_streaming", lambda *a, **k: started.append(a) or (_ for _ in ()).throw(AssertionError("a rank was launched")))
     monkeypatch.setattr(m.torch.cuda, "is_available", lambda: True)
     monkeypatch.setattr(m.torch.cuda, "device_count", lambda: 1)
     assert m.self_launch(8, ["--gpus", "8"]) == 2
@@ -188,14 +188,14 @@ def test_self_launch_retries_a_taken_rendezvous_port(monkeypatch, capsys):
     import subprocess as sp
     calls = []
 
-    class R:
-        def __init__(self, rc, err):
-            self.returncode, self.stderr = rc, err
-
-    def fake_run(cmd, **kw):
+    def fake_run(cmd, env):
         calls.append(cmd[cmd.index("--master-port") + 1])
-        return R(1, "RuntimeError: ... EADDRINUSE ...\n") if len(calls) == 1 else R(0, "")
-    monkeypatch.setattr(sp, "run", fake_run)
+        return (1, "RuntimeError: ... EADDRINUSE ...\n", 2.0) if len(calls) == 1 else (0, "", 5.0)
+    monkeypatch.setattr(m, "_run_streaming", fake_run)
     assert m.self_launch(2, ["--gpus", "2", "--cpu-oracle"]) == 0
     assert len(calls) == 2
     assert "retrying" in capsys.readouterr().err
+    # the same text from a run that died LATE (its ranks had their GPUs for minutes) is not a reason to run it again
+    calls.clear()
+    monkeypatch.setattr(m, "_run_streaming", lambda cmd, env: (calls.append(1) or (1, "... Address already in use ...\n", 300.0)))
+    assert m.self_launch(2, ["--gpus", "2", "--cpu-oracle"]) == 1 and len(calls) == 1
