@@ -693,8 +693,8 @@ class PathShadowing:
         stream = torch._C._cuda_getCurrentRawStream(fs["dev"])
         xn2 = None
         if self.hint == "auto":
-            x64 = np.asarray(xq, dtype=np.float32).astype(np.float64)
-            xn2 = float(x64 @ x64)
+            x32 = xq if xq.dtype == np.float32 else xq.astype(np.float32)      # (a hint: fp32 is plenty, and one numpy call)
+            xn2 = float(np.dot(x32, x32))
         hint = self._next_hint(xn2, k, W)
         status, res = slot.call(stream, xq, hint)
         self.last_path = "hip"

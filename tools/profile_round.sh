@@ -99,4 +99,10 @@ cd $R
 # the long-window scan with parts switched off
 PSH_LIB=$R/shadowing_amd/lib/libpsh_hip_tuning.so timeout 300 python tools/emx_phases.py 2>/dev/null | grep -v amdgpu.ids > $OUT/emx_phases.txt
 (timeout 600 python tools/long_batch_probe.py --W 30 64 126 252 --B 1 2 3 4 16 64 2>/dev/null | grep "^{"; timeout 300 python tools/long_batch_probe.py --walk --W 20 64 126 --B 1 4 2>/dev/null | grep "^{") > $OUT/long_batch_probe.jsonl
-(for W in 64 126 252; do for d in 0 4 12; do PSH_DBG=$d PSH_LIB=$R/shadowing_amd/lib/libpsh_hip_tuning.so python tools/long_ablate.py $W 2>/dev/null | tail -1; done; done) > $OUT/long_ablate.txt
+(for W in 64 126 252; do for d in 0 4 68 12; do PSH_DBG=$d PSH_LIB=$R/shadowing_amd/lib/libpsh_hip_tuning.so python tools/long_ablate.py $W 2>/dev/null | tail -1; done; done) > $OUT/long_ablate.txt
+# round 6: the blocking shadow() call as one library call (psh_shadow_blocking: the library's own split of a call), the batched
+# long-window scan (stage times, ablations: PSH_DBG 1 no MFMAs, 2 no tests, 4 no survivor handling), the long-window scan's counters
+timeout 300 python tools/blocking_times.py 2>> $OUT/bench.err | grep -v amdgpu.ids > $OUT/blocking_times.txt
+timeout 600 python tools/lq_stages.py 64,126,252 2>> $OUT/bench.err | grep "^{" > $OUT/lq_stages.jsonl
+(for d in 0 1 2 3 4; do PSH_DBG=$d PSH_LIB=$R/shadowing_amd/lib/libpsh_hip_tuning.so python tools/lq_ablate.py 126 64 2>/dev/null | tail -1; done; PSH_DBG=16 PSH_LIB=$R/shadowing_amd/lib/libpsh_hip_tuning.so python tools/lq_ablate.py 126 64 2>/dev/null | tail -1) > $OUT/lq_ablate.txt
+bash tools/pmc_long.sh > /dev/null 2>&1; cp $R/gpurun_out/longpmc/long_pmc_summary.txt $OUT/long_pmc_summary.txt 2>/dev/null
