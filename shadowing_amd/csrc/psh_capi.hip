@@ -664,6 +664,30 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
         if (profile) { const float* hint0 = profile->tau_hint; *profile = sub; profile->tau_hint = hint0; }
         return PSH_OK;
     }
+    // A dense embedding's batch beyond what the matrix-core scan takes in one call (its per-query pass runs on the matrix cores
+    // for up to 256 queries -- PSH_EMX_QM_MAX_B -- and the queries' constants sit in LDS): chunks of the largest supported size inside the call instead of the vector-ALU
+    // scan for all of them (configs[4] with 512 query dates: 46 -> 10 ms per GPU).  Status words stay per query.
+    if (ker && (flags_of(profile) & PSH_FLAG_EMBED_MX) && !(flags_of(profile) & PSH_FLAG_EMBED_DENSE) && p.Tp > 1 && B > 3 &&
+        (B > 256 || !embed_mx_supported(emb_d, W, B, tile_floats_for(W))) && !(profile && profile->mode == PSH_PROFILE_STAGES)) {
+        int chunk = 0;
+        for (int c = B < 256 ? B : 256; c >= 3; c = c > 32 ? c - 32 : c - 1)
+            if (embed_mx_supported(emb_d, W, c, tile_floats_for(W))) { chunk = c; break; }
+        if (chunk >= 3) {
+            const int n_chunks = (B + chunk - 1) / chunk;
+            const int per = (B + n_chunks - 1) / n_chunks;                    // even chunks
+            psh_profile sub;
+            for (int b = 0; b < B; b += per) {
+                const int nb = B - b < per ? B - b : per;
+                if (profile) { sub = *profile; if (profile->tau_hint) sub.tau_hint = profile->tau_hint + b; }
+                rc = scan_topk_impl(device, stream, dataset, R, T, r_offset, queries + (size_t)b * emb_d, qnorm ? qnorm + b : nullptr, nb, W, h, k,
+                                    ker, emb_d, out_d + (size_t)b * k, out_idx + (size_t)b * k * 2, out_status + b, workspace, workspace_bytes,
+                                    profile ? &sub : nullptr);
+                if (rc) return rc;
+            }
+            if (profile) { const float* hint0 = profile->tau_hint; *profile = sub; profile->tau_hint = hint0; }
+            return PSH_OK;
+        }
+    }
     p.emb_dense = (flags_of(profile) & PSH_FLAG_EMBED_DENSE) != 0;
     p.rows_generic = (flags_of(profile) & PSH_FLAG_ROWS_GENERIC) != 0;
     p.emb_taps = (flags_of(profile) & PSH_FLAG_EMBED_TAPS) != 0;

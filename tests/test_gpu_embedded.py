@@ -569,6 +569,36 @@ def test_configs4_wavelet_scan_at_its_per_gpu_size_equals_the_oracle(hip_device,
     assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, "configs[4] per-GPU size")
 
 
+def test_wavelet_batches_beyond_one_call_of_the_matrix_core_scan_are_chunked(hip_device, oracle_mod):
+    """configs[4] with MANY query dates: 300 / 515 queries are more than embed_mx_kernel's tables take in LDS (256 at d = 11,
+    K = 252) -- round 6: psh_scan_topk_embedded serves them as even chunks inside the call (150 + 150, 172 + 172 + 171) instead of
+    the vector-ALU scan for all of them (46 -> 10 ms per GPU at 512 queries); per-query status words, the oracle's answer."""
+    from shadowing_amd import _native
+    R, T, K, h, k = 1024, 2048, 252, 20, 64
+    ker = syn.wavelet_bank(5, K)
+    ds = syn.dataset(R, T, 81)
+    dt = torch.as_tensor(ds[:, 0, :].copy()).to(hip_device)
+    kd = torch.tensor(ker).to(hip_device)
+    ws = _native.Workspace(hip_device)
+    for B in (300, 515):
+        x = syn.rolling_queries(B, K, 82 + B)
+        hx = torch.nn.functional.conv1d(torch.tensor(x)[:, None, :], torch.tensor(ker)[:, None, :])[:, :, 0].contiguous()
+        hd = hx.to(hip_device)
+        d, idx, st = _native.scan_topk_embedded(dt, kd, hd, k, h=h, workspace=ws, flags=_native.FLAG_EMBED_MX)[:3]
+        torch.cuda.synchronize()
+        bad = torch.nonzero(st != 0).flatten()
+        assert bad.numel() <= B // 4, st.tolist()
+        if bad.numel():
+            d2, i2, _ = _native.scan_topk_embedded(dt, kd, hd[bad].contiguous(), k, h=h, workspace=ws, exhaustive=True,
+                                                   flags=_native.FLAG_EMBED_MX)[:3]
+            d[bad], idx[bad] = d2, i2
+            torch.cuda.synchronize()
+        sel = sorted({0, 1, B // 3, B // 2 - 1, B // 2, B // 2 + 1, B - 2, B - 1, 149, 150, 171, 172})
+        sel = [q for q in sel if q < B]
+        od, oidx = oracle_mod.scan_topk_embedded(ds, ker, hx.numpy()[sel], k, h=h)
+        assert_exact(d.cpu().numpy()[sel], idx.cpu().numpy()[sel], od, oidx, f"wavelet batch of {B}: queries around the chunk boundaries")
+
+
 @pytest.mark.parametrize("name", IMPUTATION_GOLDENS)
 def test_path_shadowing_with_an_imputation_context_runs_native(hip_device, name):
     """PathShadowing(embedding, RelativeMSE, ds, ImputationContext((l, c, r))).shadow(cuda=True) through the
