@@ -4,13 +4,13 @@
 // scan (psh_stream.hip): W = 126, 64 queries = 32 passes over the ensemble, 6.4 ms.  Here ONE pass per chunk of queries:
 //
 //   * a block of 8 waves (two per SIMD: 256 registers a lane) owns a share of the (row, segment) units and a CHUNK of the
-//     queries -- as many as put their shifted-query fragment tables ([query][K-step][lane][8 halves]: a KB per query and K-step) in
-//     LDS beside the waves' buffers: 9 at W = 126, 5 at W = 252, 15 at W = 64; grid.y = the chunks;
+//     queries -- as many as put their fragment tables (eight shifted copies of -2 x~ per query, lq_copy_chunks below: 4.6 KB a
+//     query at W = 126) in LDS beside the waves' buffers: 20 at W = 126, 13 at W = 252, 32 at W = 64; grid.y = the chunks;
 //   * a wave stages a segment (buffer loads), converts it to f16 rows and takes the WINDOW ENERGIES from fp32 prefix sums of the
 //     squares (stream_scan_long_kernel's construction: the tile's C operand is E^ - gamma S, shared by every query);
-//   * the segment's A fragments -- all K-steps of the band -- are read into REGISTERS once (4 a step: 40 at W = 126, 72 at 256) and
-//     every query of the chunk runs its chain of MFMAs over them, ONE 16-byte LDS read (its B fragment) per MFMA: 128 B/clk a CU,
-//     half the LDS rate.  The kernel is bound by the matrix cores: B x (W + 31 rounded up to K-steps of 16) x 2 flop a window;
+//   * the chunk's queries in groups of FOUR, K-step by K-step: a step's A fragment multiplies four queries' B fragments into four
+//     independent tiles, ONE aligned 16-byte LDS read per MFMA (128 B/clk a CU, half the LDS rate).  The matrix cores' share:
+//     B x (W + 31 rounded up to K-steps of 16) x 2 flop a window;
 //   * FILTER: windows whose t^ = E^ - 2 c^ does not exceed the query's rejection threshold (stream_threshold's bound) go to the
 //     wave's queue and are verified with the reference's exact chain straight from memory (a lane a window), the admitted ones
 //     (acc < tau) to the query's slice of this block -- the layout select_kernel reads (psh_select.hip);
@@ -38,6 +38,14 @@ __host__ __device__ inline int lq_ksteps(int W) { return (W + 31 + 15) / 16; }
 // the K-steps are compiled in as 6 / 10 / 14 / 18 (a band that ends earlier multiplies zero tables)
 __host__ __device__ inline int lq_bucket(int W) { const int n = lq_ksteps(W); return n <= 6 ? 6 : (n <= 10 ? 10 : (n <= 14 ? 14 : 18)); }
 __host__ __device__ inline int lq_rows(int nks) { return 31 + (nks + 1) / 2; }
+// A query's B fragments as EIGHT SHIFTED COPIES of -2 x~ (round 6, second form) instead of one fragment per (K-step, lane): the
+// fragment of lane (n = 8 a + c, hk), K-step s is -2 x~[16 s + 8 hk + i - n], i < 8 = the 16-byte chunk 2 s + hk - a + 3 of copy
+// c, where copy c holds Z_c[m] = -2 x~[m - 24 - c] (zero outside the window): an ALIGNED 16-byte read at a per-lane base plus
+// 32 s bytes.  A copy takes 2 NKS + 4 chunks, padded to CP = 4 mod 16 chunks so that the 16 lanes of a ds_read_b128 group
+// (4 c - a takes 16 different values mod 16 for the groups' (c, a) pairs) fall on 16 different bank quads: 4.6 KB a query at
+// W = 126 where the per-step fragments took 10 -- twice the queries in a chunk, half the passes over the ensemble.
+__host__ __device__ constexpr int lq_copy_chunks(int nks) { return 2 * nks + 4 <= 20 ? 20 : (2 * nks + 4 <= 36 ? 36 : 52); }
+__host__ __device__ constexpr int lq_query_bytes(int nks) { return 8 * lq_copy_chunks(nks) * 16; }
 __host__ __device__ inline size_t lq_wave_bytes(int nks) {
     return (size_t)PSH_LQ_SFLOATS * 4 + (size_t)PSH_LQ_QCAP * 8 + (size_t)lq_rows(nks) * PSH_LQ_ROW * 2;
 }
@@ -62,8 +70,9 @@ __global__ __launch_bounds__(PSH_LQ_THREADS) void scan_lq_kernel(ScanArgs a) {
     int* ctl = reinterpret_cast<int*>(smem);
     float* qc = smem + 16;                                                    // 4 floats a query
     int* lcount = reinterpret_cast<int*>(smem + 16 + 4 * PSH_LQ_MAXQ);        // this block's cursor in the slice of every query of its chunk
-    _Float16* tab = reinterpret_cast<_Float16*>(smem + PSH_LQ_FIXED / 4);     // [query][K-step][lane][8]
-    char* wbase = reinterpret_cast<char*>(tab + (size_t)a.q_per_group * NKS * 512) + (size_t)wave * lq_wave_bytes(NKS);
+    _Float16* tab = reinterpret_cast<_Float16*>(smem + PSH_LQ_FIXED / 4);     // [query][copy c < 8][chunk < CP][8 halves]
+    constexpr int CP = lq_copy_chunks(NKS), QS = lq_query_bytes(NKS) / 2;     // chunks a copy, HALVES a query
+    char* wbase = reinterpret_cast<char*>(tab + (size_t)a.q_per_group * QS) + (size_t)wave * lq_wave_bytes(NKS);
     float* sp = reinterpret_cast<float*>(wbase);                              // prefix sums
     unsigned* sq_row = reinterpret_cast<unsigned*>(sp + PSH_LQ_SFLOATS);      // deferred survivors: row, t | query << 27
     unsigned* sq_tq = sq_row + PSH_LQ_QCAP;
@@ -157,20 +166,19 @@ __global__ __launch_bounds__(PSH_LQ_THREADS) void scan_lq_kernel(ScanArgs a) {
         }
         qc[4 * tid + 0] = out;
     }
-    // the tables: column n of K-step s holds -2 x~[16 s + 8 hk + i - n]; zero outside the window (and in the K-steps past the band)
-    for (int e = tid; e < nq * NKS * 64; e += PSH_LQ_THREADS) {
-        const int l = e & 63, s = (e >> 6) % NKS, ql = (e >> 6) / NKS;
-        const int n = l & 31, hk = l >> 5;
+    // the tables: copy c, chunk v, half i holds -2 x~[8 (v - 3) + i - c]; zero outside the window
+    for (int e = tid; e < nq * 8 * CP; e += PSH_LQ_THREADS) {
+        const int v = e % CP, c = (e / CP) & 7, ql = e / (8 * CP);
         const float* xq = a.queries + (size_t)(q0 + ql) * W;
         f16x8 b;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int j = 16 * s + 8 * hk + i - n;
+            const int j = 8 * (v - 3) + i - c;
             const bool in = j >= 0 && j < W;
             const float xv = xq[in ? j : 0];
             b[i] = (_Float16)(in ? -2.0f * (xv * scale) : 0.0f);
         }
-        *reinterpret_cast<f16x8*>(tab + (size_t)e * 8) = b;
+        *reinterpret_cast<f16x8*>(tab + (size_t)ql * QS + ((size_t)c * CP + v) * 8) = b;
     }
     {   // every slot of the rows a segment does not write must be finite (0 * NaN poisons a row)
         unsigned* z = reinterpret_cast<unsigned*>(a1);
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(PSH_LQ_THREADS) void scan_lq_kernel(ScanArgs a) {
 
     const int m = lane & 31, hk = lane >> 5;
     const _Float16* pa0 = a1 + m * PSH_LQ_ROW + 8 * hk;
-    const _Float16* pb0 = tab + lane * 8;
+    const _Float16* pb0 = tab + ((size_t)(m & 7) * CP + (hk - (m >> 3) + 3)) * 8;       // copy n & 7, chunk hk - (n >> 3) + 3 (+ 2 s a K-step)
     const float* ps_lo = sp + m + 128 * hk;
     const float* ps_hi = ps_lo + W;
     while (u < u_hi) {
@@ -232,6 +240,7 @@ __global__ __launch_bounds__(PSH_LQ_THREADS) void scan_lq_kernel(ScanArgs a) {
         decode(u, ri, sg);
         const int64_t row = a.row0 + (int64_t)ri * a.row_stride;
         const int seg_start = (int)sg * PSH_SEG;
+        bool clean;                                                           // the segment holds no NaN / inf and nothing the f16 rows overflow on
         {
             // f16 rows and the fp32 prefix sums of the squares (psh_stream.hip, stream_scan_long_kernel: the bound is there)
             const int nq4 = (nfloat + 3) >> 2;
@@ -266,6 +275,9 @@ __global__ __launch_bounds__(PSH_LQ_THREADS) void scan_lq_kernel(ScanArgs a) {
                 carry += __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(inc[q]), 63));
                 if (q < PSH_NSTAGE - 1 || mm <= nq4) *reinterpret_cast<f32x4*>(sp + 4 * mm) = f32x4{x0, x0 + d0[q], x0 + d1[q], x0 + d2[q]};
             }
+            // the segment's total of squares says whether any tile value can be NaN: a NaN / inf sample makes it NaN / inf, a sample
+            // beyond the f16 range (|y~| > 65504: the rows hold inf, 0 x inf = NaN in its row's tiles) makes it > 4.29e9
+            clean = carry < 4.0e9f;
         }
         wave_lds_fence();
         const unsigned un = grab();
@@ -312,8 +324,23 @@ __global__ __launch_bounds__(PSH_LQ_THREADS) void scan_lq_kernel(ScanArgs a) {
             // nothing more, and one with survivors walks its non-empty masks on the scalar unit (building per-lane bit masks and
             // sixteen ballots over them was 300 instructions a tile, a quarter of the (segment, query) pairs)
             unsigned long long mk[16], any = 0ull;
+            if (clean) {
+                // no NaN can sit in the tile: its smallest value decides -- 8 instructions (v_min3) and one compare instead of 16
+                // compares and as many scalar ORs; the masks are made for the tiles that hold a survivor only
+                float mn = fminf(fminf(c[0], c[1]), c[2]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { mk[r] = __ballot(!(c[r] > thr)); any |= mk[r]; }
+                for (int r = 3; r + 1 < 16; r += 2) mn = fminf(fminf(mn, c[r]), c[r + 1]);
+                mn = fminf(mn, c[15]);
+                any = __ballot(!(mn > thr));
+                if (any) {
+                    any = 0ull;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { mk[r] = __ballot(!(c[r] > thr)); any |= mk[r]; }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { mk[r] = __ballot(!(c[r] > thr)); any |= mk[r]; }
+            }
 #ifdef PSH_TUNING
             if (a.dbg & 4) any = 0ull;                                        // ablation: no survivor handling (results invalid)
 #endif
@@ -370,13 +397,13 @@ __global__ __launch_bounds__(PSH_LQ_THREADS) void scan_lq_kernel(ScanArgs a) {
             f32x16 acc[NG];
 #pragma unroll
             for (int j = 0; j < NG; ++j) acc[j] = ce;
-            const _Float16* pbg = pb0 + (size_t)g0 * NKS * 512;
+            const _Float16* pbg = pb0 + (size_t)g0 * QS;
             auto ld = [](const _Float16* p) { return *reinterpret_cast<const f16x8*>(p); };
             // two sets of fragments take turns: the next step's A fragment and NG B fragments are requested before this step's MFMAs
             f16x8 fa[2], fb[2][NG];
             fa[0] = ld(pa0);
 #pragma unroll
-            for (int j = 0; j < NG; ++j) fb[0][j] = ld(pbg + (size_t)(j * NKS) * 512);
+            for (int j = 0; j < NG; ++j) fb[0][j] = ld(pbg + (size_t)j * QS);
 #ifdef PSH_TUNING
             if (!(a.dbg & 1))                                                 // ablation: no MFMAs (results invalid)
 #endif
@@ -385,7 +412,7 @@ __global__ __launch_bounds__(PSH_LQ_THREADS) void scan_lq_kernel(ScanArgs a) {
                 if (s + 1 < NKS) {
                     fa[(s + 1) & 1] = ld(pa0 + ((s + 1) >> 1) * PSH_LQ_ROW + 16 * ((s + 1) & 1));
 #pragma unroll
-                    for (int j = 0; j < NG; ++j) fb[(s + 1) & 1][j] = ld(pbg + (size_t)(j * NKS + s + 1) * 512);
+                    for (int j = 0; j < NG; ++j) fb[(s + 1) & 1][j] = ld(pbg + (size_t)j * QS + 16 * (s + 1));
                 }
 #pragma unroll
                 for (int j = 0; j < NG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s & 1], fb[s & 1][j], acc[j], 0, 0, 0);
@@ -422,7 +449,7 @@ int scan_lq_chunk(int W, int B) {
     const int nks = lq_bucket(W);
     const size_t fixed = (size_t)PSH_LQ_FIXED;
     const size_t room = (size_t)PSH_LDS_BYTES - fixed - (size_t)(PSH_LQ_THREADS / 64) * lq_wave_bytes(nks);
-    int qc = (int)(room / ((size_t)nks * 1024));
+    int qc = (int)(room / (size_t)lq_query_bytes(nks));
     if (qc > PSH_LQ_MAXQ) qc = PSH_LQ_MAXQ;
     if (qc < 1) qc = 1;
     const int chunks = (B + qc - 1) / qc;
@@ -430,7 +457,7 @@ int scan_lq_chunk(int W, int B) {
 }
 size_t scan_lq_shmem_bytes(int W, int B, int q_per_group) {
     const int nks = lq_bucket(W);
-    return (size_t)PSH_LQ_FIXED + (size_t)q_per_group * nks * 1024 + (size_t)(PSH_LQ_THREADS / 64) * lq_wave_bytes(nks);
+    return (size_t)PSH_LQ_FIXED + (size_t)q_per_group * lq_query_bytes(nks) + (size_t)(PSH_LQ_THREADS / 64) * lq_wave_bytes(nks);
 }
 
 template <int MODE>
