@@ -198,6 +198,9 @@ __global__ __launch_bounds__(PSH_LQ_THREADS) void scan_lq_kernel(ScanArgs a) {
 #ifdef PSH_TUNING
         if ((a.dbg & 16) && lane == 0) atomicAdd(&a.bcount[PSH_MAX_BLOCKS - 1], qn);   // probe: survivors verified (tools/lq_ablate.py)
 #endif
+#ifdef PSH_TUNING
+        if (a.dbg & 8) { qn = 0; return; }                                   // ablation: queued survivors dropped unverified (results invalid)
+#endif
         const bool have = lane < qn;
         const unsigned row = have ? sq_row[lane] : 0u, tq = have ? sq_tq[lane] : 0u;
         const int ql = (int)(tq >> 27);
@@ -277,7 +280,9 @@ __global__ __launch_bounds__(PSH_LQ_THREADS) void scan_lq_kernel(ScanArgs a) {
             }
             // the segment's total of squares says whether any tile value can be NaN: a NaN / inf sample makes it NaN / inf, a sample
             // beyond the f16 range (|y~| > 65504: the rows hold inf, 0 x inf = NaN in its row's tiles) makes it > 4.29e9
-            clean = carry < 4.0e9f;
+            // (a wave-uniform value, but a vector compare's mask: without the readfirstlane the compiler treats every branch on it
+            //  as divergent and carries the test's sixteen scalar masks through vector registers)
+            clean = __builtin_amdgcn_readfirstlane(carry < 4.0e9f ? 1 : 0) != 0;
         }
         wave_lds_fence();
         const unsigned un = grab();
@@ -290,11 +295,8 @@ __global__ __launch_bounds__(PSH_LQ_THREADS) void scan_lq_kernel(ScanArgs a) {
             ce[r] = __builtin_fmaf(ps_hi[off], MODE == PSH_MODE_FILTER ? 1.0f - PSH_LQ_GAMMA : 1.0f + PSH_LQ_GAMMA, -ps_lo[off]);
         }
         const int nvalid = a.Tp - seg_start;                                  // windows of this segment that exist (>= 1024: all)
-        auto finish = [&](const f32x16& c, const int ql) __attribute__((always_inline)) {
-#ifdef PSH_TUNING
-            if (a.dbg & 2) { if (c[0] == 12345.678f) a.minbuf[0] = c[1]; return; }   // ablation: no test (results invalid)
-#endif
-            if (MODE == PSH_MODE_BOOT) {
+        // BOOT: the minimum of an upper bound of acc per (unit, query)
+        auto boot_finish = [&](const f32x16& c, const int ql) __attribute__((always_inline)) {
             float mn = __uint_as_float(PSH_INF_BITS);
             if (nvalid >= PSH_SEG) {
 #pragma unroll
@@ -318,73 +320,57 @@ __global__ __launch_bounds__(PSH_LQ_THREADS) void scan_lq_kernel(ScanArgs a) {
                 if (!(ub == ub)) ub = __uint_as_float(PSH_INF_BITS);      // NaN data: the unit carries no information
                 a.minbuf[(int64_t)(q0 + ql) * a.min_stride + (int64_t)u] = ub;
             }
-        } else {
-            const float thr = qc[4 * ql + 0];
-            // sixteen compares into sixteen scalar masks (NaN-safe: !(t^ > thr)); a tile without a survivor -- most of them -- costs
-            // nothing more, and one with survivors walks its non-empty masks on the scalar unit (building per-lane bit masks and
-            // sixteen ballots over them was 300 instructions a tile, a quarter of the (segment, query) pairs)
-            unsigned long long mk[16], any = 0ull;
-            if (clean) {
-                // no NaN can sit in the tile: its smallest value decides -- 8 instructions (v_min3) and one compare instead of 16
-                // compares and as many scalar ORs; the masks are made for the tiles that hold a survivor only
-                float mn = fminf(fminf(c[0], c[1]), c[2]);
-#pragma unroll
-                for (int r = 3; r + 1 < 16; r += 2) mn = fminf(fminf(mn, c[r]), c[r + 1]);
-                mn = fminf(mn, c[15]);
-                any = __ballot(!(mn > thr));
-                if (any) {
-                    any = 0ull;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { mk[r] = __ballot(!(c[r] > thr)); any |= mk[r]; }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { mk[r] = __ballot(!(c[r] > thr)); any |= mk[r]; }
-            }
+        };
+        // FILTER, the test of a tile: does it hold a window with t^ <= thr (NaN-safe: !(t^ > thr))?  On a clean segment no NaN can
+        // sit in the tile and its smallest value decides: 8 v_min3 and one compare; the tile that holds none -- 19 in 20 -- is
+        // done.  What follows for the others is ONE piece of code per kernel, behind the group (tile_survivors below): inlined into
+        // every tile's test the survivors' code made the kernel 70 KB of instructions and every visit of it -- a tile in twenty --
+        // a string of instruction-cache misses: 1.3 of the scan's 3.9 ms at W = 126, 64 queries.
+        auto tile_hit = [&](const f32x16& c, const int ql) __attribute__((always_inline)) -> bool {
 #ifdef PSH_TUNING
-            if (a.dbg & 4) any = 0ull;                                        // ablation: no survivor handling (results invalid)
+            if (a.dbg & 2) { if (c[0] == 12345.678f) a.minbuf[0] = c[1]; return false; }   // ablation: no test (results invalid)
 #endif
-            if (any) {
-                int tot = 0;
+            if (!clean) return true;
+            const float thr = qc[4 * ql + 0];
+            float mn = fminf(fminf(c[0], c[1]), c[2]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) tot += (int)__popcll(mk[r]);
-                if (tot <= PSH_LQ_QCAP && nvalid >= PSH_SEG) {
-                    // (room for the whole tile is made BEFORE the walk: one place where the queue is verified, not sixteen)
-                    if (qn + tot > PSH_LQ_QCAP) verify_queue();
+            for (int r = 3; r + 1 < 16; r += 2) mn = fminf(fminf(mn, c[r]), c[r + 1]);
+            mn = fminf(mn, c[15]);
+            return __ballot(!(mn > thr)) != 0ull;
+        };
+        // the windows of a tile that pass the test go to the wave's queue (the accumulators' layout: slot r of lane (m, hk) is
+        // window 32 ((r & 3) + 8 (r >> 2) + 4 hk) + m); a loop over the slots that hold one, compact code
+        auto tile_survivors = [&](const f32x16& c, const int ql) __attribute__((always_inline)) {
+            const float thr = qc[4 * ql + 0];
+            unsigned hm = 0u;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        if (!mk[r]) continue;
-                        if ((mk[r] >> lane) & 1ull) {
-                            const int p = 32 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + m;   // C layout: row -> window
-                            const int slot = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk[r] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk[r], 0u));
-                            sq_row[slot] = (unsigned)row;
-                            sq_tq[slot] = (unsigned)(seg_start + p) | ((unsigned)ql << 27);
-                        }
-                        qn += (int)__popcll(mk[r]);
-                    }
-                } else {
-                    // a row's last segment (windows that do not exist are masked) or a tile with more survivors than the queue holds
-                    unsigned hm = 0u;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) hm |= ((mk[r] >> lane) & 1ull) ? (1u << r) : 0u;
-#pragma unroll 1
-                    for (int r = 0; r < 16; ++r) {
-                        const int p = 32 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + m;
-                        const bool hit = (((hm >> r) & 1u) != 0u) && (p < nvalid);
-                        const unsigned long long mask = __ballot(hit);
-                        if (!mask) continue;
-                        const int n = (int)__popcll(mask);
-                        if (qn + n > PSH_LQ_QCAP) verify_queue();
-                        if (hit) {
-                            const int slot = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                            sq_row[slot] = (unsigned)row;
-                            sq_tq[slot] = (unsigned)(seg_start + p) | ((unsigned)ql << 27);
-                        }
-                        qn += n;
-                    }
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int p = 32 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + m;
+                hm |= (!(c[r] > thr) && p < nvalid) ? (1u << r) : 0u;
             }
-        }
+            unsigned any16 = hm;                                              // the slots that hold a survivor in some lane
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) any16 |= (unsigned)__shfl_xor((int)any16, off, 64);
+            any16 = (unsigned)__builtin_amdgcn_readfirstlane((int)any16);
+#ifdef PSH_TUNING
+            if (a.dbg & 4) any16 = 0u;                                        // ablation: no survivor handling (results invalid)
+#endif
+#pragma unroll 1
+            while (any16) {
+                const int r = __builtin_ctz(any16);
+                any16 &= any16 - 1u;
+                const bool hit = ((hm >> r) & 1u) != 0u;
+                const unsigned long long mask = __ballot(hit);
+                const int n = (int)__popcll(mask);
+                if (qn + n > PSH_LQ_QCAP) verify_queue();
+                if (hit) {
+                    const int p = 32 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + m;
+                    const int slot = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    sq_row[slot] = (unsigned)row;
+                    sq_tq[slot] = (unsigned)(seg_start + p) | ((unsigned)ql << 27);
+                }
+                qn += n;
+            }
         };
         // The chunk's queries in GROUPS of up to four, K-step by K-step (round 6, second form): a step's A fragment is read once and
         // multiplies the fragments of the group's queries into FOUR independent tiles -- no MFMA waits for the one before it, and
@@ -392,11 +378,12 @@ __global__ __launch_bounds__(PSH_LQ_THREADS) void scan_lq_kernel(ScanArgs a) {
         // left no registers to request fragments ahead: every other MFMA waited for an LDS read issued just before it).
         // (Query by query -- the segment's A fragments in registers, one dependent chain of MFMAs per query -- every chain ended
         // in a drain and a test with nothing to overlap them: 1460 cycles a query and wave where the chain itself is 320.)
-        auto run_group = [&](auto ng_tag, const int g0) __attribute__((always_inline)) {
+        f32x16 acc[4];
+        // returns a bit per tile of the group that holds a survivor (FILTER)
+        auto run_group = [&](auto ng_tag, const int g0) __attribute__((always_inline)) -> unsigned {
             constexpr int NG = decltype(ng_tag)::value;
-            f32x16 acc[NG];
 #pragma unroll
-            for (int j = 0; j < NG; ++j) acc[j] = ce;
+            for (int j = 0; j < 4; ++j) acc[j] = ce;
             const _Float16* pbg = pb0 + (size_t)g0 * QS;
             auto ld = [](const _Float16* p) { return *reinterpret_cast<const f16x8*>(p); };
             // two sets of fragments take turns: the next step's A fragment and NG B fragments are requested before this step's MFMAs
@@ -404,6 +391,9 @@ __global__ __launch_bounds__(PSH_LQ_THREADS) void scan_lq_kernel(ScanArgs a) {
             fa[0] = ld(pa0);
 #pragma unroll
             for (int j = 0; j < NG; ++j) fb[0][j] = ld(pbg + (size_t)j * QS);
+            // (the first step's reads are a group of the pipeline too: without it every group below takes the reads of the step
+            //  before its own and the LAST step's five are left to the default scheduler, which sinks each in front of its MFMA)
+            __builtin_amdgcn_sched_group_barrier(0x100, NG + 1, 0);
 #ifdef PSH_TUNING
             if (!(a.dbg & 1))                                                 // ablation: no MFMAs (results invalid)
 #endif
@@ -421,15 +411,33 @@ __global__ __launch_bounds__(PSH_LQ_THREADS) void scan_lq_kernel(ScanArgs a) {
                 if (s + 1 < NKS) __builtin_amdgcn_sched_group_barrier(0x100, NG + 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, NG, 0);
             }
+            unsigned hitm = 0u;
+            if (MODE == PSH_MODE_BOOT) {
 #pragma unroll
-            for (int j = 0; j < NG; ++j) finish(acc[j], g0 + j);
+                for (int j = 0; j < NG; ++j) boot_finish(acc[j], g0 + j);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NG; ++j) hitm |= tile_hit(acc[j], g0 + j) ? (1u << j) : 0u;
+            }
+            return (unsigned)__builtin_amdgcn_readfirstlane((int)hitm);       // (uniform: said so, the compiler keeps it in a vector register otherwise)
         };
         for (int g0 = 0; g0 < nq; g0 += 4) {
+            unsigned hitm;
             switch (nq - g0 < 4 ? nq - g0 : 4) {
-                case 1: run_group(std::integral_constant<int, 1>{}, g0); break;
-                case 2: run_group(std::integral_constant<int, 2>{}, g0); break;
-                case 3: run_group(std::integral_constant<int, 3>{}, g0); break;
-                default: run_group(std::integral_constant<int, 4>{}, g0); break;
+                case 1: hitm = run_group(std::integral_constant<int, 1>{}, g0); break;
+                case 2: hitm = run_group(std::integral_constant<int, 2>{}, g0); break;
+                case 3: hitm = run_group(std::integral_constant<int, 3>{}, g0); break;
+                default: hitm = run_group(std::integral_constant<int, 4>{}, g0); break;
+            }
+            if (MODE == PSH_MODE_FILTER && hitm) {
+#ifdef PSH_TUNING
+                if (a.dbg & 32) hitm = 0u;                                    // ablation: the tiles' min trees alone (results invalid)
+#endif
+#pragma unroll 1
+                for (int j = 0; j < 4; ++j) {
+                    if (!((hitm >> j) & 1u)) continue;
+                    tile_survivors(j == 0 ? acc[0] : (j == 1 ? acc[1] : (j == 2 ? acc[2] : acc[3])), g0 + j);
+                }
             }
         }
         wave_lds_fence();  // all lanes done with the arrays before they are overwritten

@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+mkdir -p gpurun_out
+export PSH_LIB=$PWD/shadowing_amd/lib/libpsh_hip_tuning.so
+timeout 600 python tools/lq_ablate2.py 126:64:0,1,2,3,4,8,32 64:64:0,2,4,8,32 252:64:0,2,4,8,32 126:16:0 126:512:0 2>&1 | grep -v amdgpu.ids > gpurun_out/lq_ablate_4.txt
+unset PSH_LIB
+timeout 900 python -m pytest tests -m gpu -x -q -k "long or admitted" 2>&1 | grep -E "passed|failed|error" > gpurun_out/gputests_4.log
+bash tools/pmc_lq.sh > gpurun_out/lq_pmc_4.txt 2>&1
