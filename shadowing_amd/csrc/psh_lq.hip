@@ -295,6 +295,15 @@ __global__ __launch_bounds__(PSH_LQ_THREADS) void scan_lq_kernel(ScanArgs a) {
             ce[r] = __builtin_fmaf(ps_hi[off], MODE == PSH_MODE_FILTER ? 1.0f - PSH_LQ_GAMMA : 1.0f + PSH_LQ_GAMMA, -ps_lo[off]);
         }
         const int nvalid = a.Tp - seg_start;                                  // windows of this segment that exist (>= 1024: all)
+        if (nvalid < PSH_SEG) {
+            // A row's last segment: the windows past the last admissible one never pass the test (+inf in their slots of the C
+            // operand).  Left alone they pass it in most tiles: what lies beyond the row reads as zero, a window of zeros is at
+            // acc = ||x||^2, and for a long window that IS about where the admission level sits (the k-th smallest of 10^8 sums of
+            // W squared differences) -- a quarter of all tiles went through the survivors' code for windows that do not exist.
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (32 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + m >= nvalid) ce[r] = __uint_as_float(PSH_INF_BITS);
+        }
         // BOOT: the minimum of an upper bound of acc per (unit, query)
         auto boot_finish = [&](const f32x16& c, const int ql) __attribute__((always_inline)) {
             float mn = __uint_as_float(PSH_INF_BITS);
@@ -338,36 +347,41 @@ __global__ __launch_bounds__(PSH_LQ_THREADS) void scan_lq_kernel(ScanArgs a) {
             mn = fminf(mn, c[15]);
             return __ballot(!(mn > thr)) != 0ull;
         };
-        // the windows of a tile that pass the test go to the wave's queue (the accumulators' layout: slot r of lane (m, hk) is
-        // window 32 ((r & 3) + 8 (r >> 2) + 4 hk) + m); a loop over the slots that hold one, compact code
-        auto tile_survivors = [&](const f32x16& c, const int ql) __attribute__((always_inline)) {
+        // the windows of a tile that pass the test, a bit per accumulator slot (slot r of lane (m, hk) is window
+        // 32 ((r & 3) + 8 (r >> 2) + 4 hk) + m)
+        auto tile_bits = [&](const f32x16& c, const int ql) __attribute__((always_inline)) -> unsigned {
             const float thr = qc[4 * ql + 0];
             unsigned hm = 0u;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int p = 32 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + m;
-                hm |= (!(c[r] > thr) && p < nvalid) ? (1u << r) : 0u;
-            }
-            unsigned any16 = hm;                                              // the slots that hold a survivor in some lane
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) any16 |= (unsigned)__shfl_xor((int)any16, off, 64);
-            any16 = (unsigned)__builtin_amdgcn_readfirstlane((int)any16);
-#ifdef PSH_TUNING
-            if (a.dbg & 4) any16 = 0u;                                        // ablation: no survivor handling (results invalid)
-#endif
+            for (int r = 0; r < 16; ++r) hm |= !(c[r] > thr) ? (1u << r) : 0u;
+            return hm;
+        };
+        // ... go to the wave's queue: a loop over the LANES that hold one (one or two in a tile that holds any)
+        auto queue_bits = [&](unsigned hm, const int ql) __attribute__((always_inline)) {
+            if (nvalid < PSH_SEG) {                                           // a row's last segment: windows that do not exist
 #pragma unroll 1
-            while (any16) {
-                const int r = __builtin_ctz(any16);
-                any16 &= any16 - 1u;
-                const bool hit = ((hm >> r) & 1u) != 0u;
-                const unsigned long long mask = __ballot(hit);
-                const int n = (int)__popcll(mask);
+                for (int r = 0; r < 16; ++r)
+                    if (32 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + m >= nvalid) hm &= ~(1u << r);
+            }
+#ifdef PSH_TUNING
+            if (a.dbg & 4) hm = 0u;                                           // ablation: no survivor handling (results invalid)
+#endif
+            unsigned long long lanes = __ballot(hm != 0u);
+#pragma unroll 1
+            while (lanes) {
+                const int l = (int)__builtin_ctzll(lanes);
+                lanes &= lanes - 1ull;
+                unsigned h = (unsigned)__builtin_amdgcn_readlane((int)hm, l);
+                const int n = (int)__popc(h);
                 if (qn + n > PSH_LQ_QCAP) verify_queue();
-                if (hit) {
-                    const int p = 32 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + m;
-                    const int slot = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                    sq_row[slot] = (unsigned)row;
-                    sq_tq[slot] = (unsigned)(seg_start + p) | ((unsigned)ql << 27);
+                if (lane == l) {
+                    int slot = qn;
+#pragma unroll 1
+                    for (; h; h &= h - 1u, ++slot) {
+                        const int r = __builtin_ctz(h);
+                        sq_row[slot] = (unsigned)row;
+                        sq_tq[slot] = (unsigned)(seg_start + 32 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + m) | ((unsigned)ql << 27);
+                    }
                 }
                 qn += n;
             }
@@ -433,10 +447,13 @@ __global__ __launch_bounds__(PSH_LQ_THREADS) void scan_lq_kernel(ScanArgs a) {
 #ifdef PSH_TUNING
                 if (a.dbg & 32) hitm = 0u;                                    // ablation: the tiles' min trees alone (results invalid)
 #endif
+                unsigned hmj[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hmj[j] = ((hitm >> j) & 1u) ? tile_bits(acc[j], g0 + j) : 0u;
 #pragma unroll 1
                 for (int j = 0; j < 4; ++j) {
                     if (!((hitm >> j) & 1u)) continue;
-                    tile_survivors(j == 0 ? acc[0] : (j == 1 ? acc[1] : (j == 2 ? acc[2] : acc[3])), g0 + j);
+                    queue_bits(j == 0 ? hmj[0] : (j == 1 ? hmj[1] : (j == 2 ? hmj[2] : hmj[3])), g0 + j);
                 }
             }
         }

@@ -800,6 +800,15 @@ __device__ __forceinline__ void stream_scan_long_body(const ScanArgs& a, const F
             const int off = 32 * (r & 3) + 256 * (r >> 2);
             ce[r] = __builtin_fmaf(ps_hi[off], 1.0f - PSH_LONG_GAMMA, -ps_lo[off]);
         }
+        if (a.Tp - seg_start < PSH_SEG) {
+            // A row's last segment: the windows past the last admissible one never pass the test (+inf in their slots of the C
+            // operand).  Left alone they often do: what lies beyond the row reads as zero, a window of zeros is at acc = ||x||^2,
+            // and for a long window that is about where the admission level sits -- the survivors' walk below then ran in most
+            // last segments for windows that do not exist.
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (seg_start + 32 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + m >= a.Tp) ce[r] = __uint_as_float(PSH_INF_BITS);
+        }
 #ifdef PSH_TUNING
         if (a.dbg & 32) {                                                     // ablation: no energies read back (results invalid)
 #pragma unroll

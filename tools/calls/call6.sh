@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+mkdir -p gpurun_out
+export PSH_LIB=$PWD/shadowing_amd/lib/libpsh_hip_tuning.so
+timeout 600 python tools/lq_ablate2.py 126:64:0,2,4,8,32 64:64:0,2 252:64:0,2 126:16:0 126:512:0 2>&1 | grep -v amdgpu.ids > gpurun_out/lq_ablate_6.txt
+for w in 64 126 252; do PSH_DBG=0 timeout 100 python tools/long_ablate.py $w; done 2>&1 | grep -v amdgpu.ids >> gpurun_out/lq_ablate_6.txt
+unset PSH_LIB
+timeout 900 python -m pytest tests -m gpu -x -q -k "long or admitted" 2>&1 | grep -E "passed|failed|error" > gpurun_out/gputests_6.log
+for w in 64 126 252; do timeout 200 python bench.py --W $w --steps 200 --no-cpu-baseline --no-blocking-api 2>/dev/null | tail -1 > gpurun_out/bench_W$w.json; done

@@ -9,7 +9,7 @@ import os
 import sys
 
 out = sys.argv[1]
-KEEP = ("stream_scan_kernel", "stream_scan_long_kernel", "stream_sample_kernel", "stream_rank_kernel", "scan_fused_kernel", "scan_kernel", "scan_mx_kernel", "scan_mq_kernel", "scan_mq8_kernel", "boot_mq_kernel", "embed_scan_kernel", "embed_px_kernel", "embed_mx_kernel", "rank_sort", "select", "threshold")
+KEEP = ("stream_scan_kernel", "stream_scan_long_kernel", "stream_sample_kernel", "stream_rank_kernel", "scan_fused_kernel", "scan_kernel", "scan_mx_kernel", "scan_mq_kernel", "scan_mq8_kernel", "scan_lq_kernel", "boot_mq_kernel", "embed_scan_kernel", "embed_px_kernel", "embed_mx_kernel", "rank_sort", "select", "threshold")
 means = {}
 for path in sorted(glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
     acc = collections.defaultdict(list)
