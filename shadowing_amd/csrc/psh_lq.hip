@@ -113,11 +113,16 @@ __global__ __launch_bounds__(PSH_LQ_THREADS) void scan_lq_kernel(ScanArgs a) {
     // ---- the chunk's scale and per-query constants.  One f16 scale 2^sexp for the chunk: max|x_q| 2^sexp < 8 for every query,
     //      and (FILTER) tau_q 4^sexp <= 4096 -- the fused launch's rule (psh_fused.hip, derive_levels).  A query whose level or
     //      samples are not finite positive numbers is not armed: its threshold is +inf, every window is verified exactly.
+    //      The chunk's queries are staged in LDS first (the waves' buffers, not in use yet): the sums and the tables below read
+    //      every sample dozens of times, and from memory a block's set-up was 126 dependent round trips per query -- 35 us a
+    //      block, once per chunk and launch.
+    float* xs = reinterpret_cast<float*>(tab + (size_t)a.q_per_group * QS);   // [query][W]
+    for (int e = tid; e < nq * W; e += PSH_LQ_THREADS) xs[e] = a.queries[(size_t)q0 * W + e];
     if (tid == 0) { ctl[0] = 60; ctl[1] = NW; }                              // ctl[0]: the chunk's exponent (minimum); ctl[1]: the next unit
     if (tid < PSH_LQ_MAXQ) lcount[tid] = 0;
     __syncthreads();
     for (int ql = wave; ql < nq; ql += NW) {
-        const float* xq = a.queries + (size_t)(q0 + ql) * W;
+        const float* xq = xs + (size_t)ql * W;
         unsigned mb = 0u;
         for (int j = lane; j < W; j += 64) mb = max(mb, __float_as_uint(fabsf(xq[j])));
 #pragma unroll
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(PSH_LQ_THREADS) void scan_lq_kernel(ScanArgs a) {
     if (tid < nq) {
         // the query's constant under the chunk's scale: FILTER the rejection threshold (stream_threshold, psh_stream.hip: a = 2^-9
         // relative, b absolute growing with the taps), BOOT nx~ = sum x~^2
-        const float* xq = a.queries + (size_t)(q0 + tid) * W;
+        const float* xq = xs + (size_t)tid * W;
         double nxs = 0.0;
         for (int j = 0; j < W; ++j) { const double vv = (double)xq[j] * (double)scale; nxs += vv * vv; }
         float out = __uint_as_float(PSH_INF_BITS);
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(PSH_LQ_THREADS) void scan_lq_kernel(ScanArgs a) {
     // the tables: copy c, chunk v, half i holds -2 x~[8 (v - 3) + i - c]; zero outside the window
     for (int e = tid; e < nq * 8 * CP; e += PSH_LQ_THREADS) {
         const int v = e % CP, c = (e / CP) & 7, ql = e / (8 * CP);
-        const float* xq = a.queries + (size_t)(q0 + ql) * W;
+        const float* xq = xs + (size_t)ql * W;
         f16x8 b;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -180,11 +185,12 @@ __global__ __launch_bounds__(PSH_LQ_THREADS) void scan_lq_kernel(ScanArgs a) {
         }
         *reinterpret_cast<f16x8*>(tab + (size_t)ql * QS + ((size_t)c * CP + v) * 8) = b;
     }
+    __syncthreads();                                                          // (the staged queries are dead: the waves' buffers)
     {   // every slot of the rows a segment does not write must be finite (0 * NaN poisons a row)
         unsigned* z = reinterpret_cast<unsigned*>(a1);
         for (int i = lane; i < lq_rows(NKS) * PSH_LQ_ROW / 2; i += 64) z[i] = 0u;
     }
-    __syncthreads();
+    wave_lds_fence();
     auto grab = [&]() -> unsigned {
         int v = 0;
         if (lane == 0) v = atomicAdd(&ctl[1], 1);
