@@ -795,7 +795,11 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
             int64_t units_cap = tn.stream_units < 2048 ? tn.stream_units : 2048;     // (the sample kernel keeps a query's minima in registers: <= 2048)
             // (a long window's exact sample chains cost W / 20 of the benchmark's: half the units -- the level's rank stays at its
             //  floor of 24 with 8 minima expected below the k-th distance)
-            if (one_long && units_cap > 1024) units_cap = 1024;
+            // (round 6: without a hint a long window's sample runs on the matrix cores -- stream_sample_long_kernel, upper bounds of the
+            //  minima -- and takes the full 2048 units; PSH_STREAM_SKIP bit 3 of the tuning build: the exact chains, for A/B runs)
+            const bool long_mx_sample = one_long && !hint && !(tn.stream_skip & 8) &&
+                                        stream_sample_long_shmem_bytes(p.W, B) <= (size_t)PSH_LDS_BYTES;
+            if (one_long && !long_mx_sample && units_cap > 1024) units_cap = 1024;
             if (units_cap > PSH_FUSED_MAX_UNITS / B) units_cap = PSH_FUSED_MAX_UNITS / B;
             int64_t rows_p = units_cap / nseg;
             if (rows_p > p.R / 4) rows_p = p.R / 4;
@@ -850,7 +854,8 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
                 fu.k_out = k;
                 fu.tau_hint = hint;
                 if (hint) grid_p = 1;                  // nothing is sampled: one block derives scale, thresholds and the fragment table from the hints
-                if (!(tn.stream_skip & 1)) HIP_TRY(launch_stream_sample(fa, fu, p.aligned, (int)grid_p, tile_floats_for(p.W), s));
+                if (!(tn.stream_skip & 1)) HIP_TRY(long_mx_sample ? launch_stream_sample_long(fa, fu, (int)grid_p, s)
+                                                                  : launch_stream_sample(fa, fu, p.aligned, (int)grid_p, tile_floats_for(p.W), s));
                 if (events) HIP_TRY(hipEventRecord((hipEvent_t)profile->ev_scan_begin, s));
                 if (!(tn.stream_skip & 4)) HIP_TRY(one_long ? launch_stream_scan_long(fa, fu, p.aligned, (int)grid_s, s)
                                                             : launch_stream_scan(fa, fu, p.aligned, (int)grid_s, s));

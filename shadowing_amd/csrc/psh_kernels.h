@@ -330,6 +330,8 @@ hipError_t launch_fused_init(FusedHdr* hdr, hipStream_t s);
 // psh_stream.hip: the same step as three launches that can share the chip with another stream's (PSH_FLAG_OVERLAP)
 size_t stream_scan_shmem_bytes(int tile_floats);
 hipError_t launch_stream_sample(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, int sample_tile_floats, hipStream_t s);
+hipError_t launch_stream_sample_long(const ScanArgs& a, const FusedArgs& f, int grid, hipStream_t s);   // long windows, no hint: the sample on the matrix cores
+size_t stream_sample_long_shmem_bytes(int W, int nq);
 hipError_t launch_stream_scan(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, hipStream_t s);
 hipError_t launch_stream_rank(const ScanArgs& a, const FusedArgs& f, int grid, hipStream_t s);
 size_t stream_scan_shmem_bytes_q(int tile_floats, int nq);
@@ -337,6 +339,19 @@ bool stream_long_supported(int W);              // one to three queries, 34 <= W
 size_t stream_scan_long_shmem_bytes(int W, int nq);
 hipError_t launch_stream_scan_long(const ScanArgs& a, const FusedArgs& f, bool aligned, int grid, hipStream_t s);
 // psh_lq.hip: batched queries with a long window (B >= 4, 34 <= W <= 256): BOOT / FILTER of the separate launches' pipeline
+// the batched long-window scan's layout of a query's B fragments (psh_lq.hip), shared with the long-window sample (psh_stream.hip)
+__host__ __device__ inline int lq_ksteps(int W) { return (W + 31 + 15) / 16; }
+// the K-steps are compiled in as 6 / 10 / 14 / 18 (a band that ends earlier multiplies zero tables)
+__host__ __device__ inline int lq_bucket(int W) { const int n = lq_ksteps(W); return n <= 6 ? 6 : (n <= 10 ? 10 : (n <= 14 ? 14 : 18)); }
+__host__ __device__ constexpr int lq_rows(int nks) { return 31 + (nks + 1) / 2; }
+// A query's B fragments as EIGHT SHIFTED COPIES of -2 x~ (round 6, second form) instead of one fragment per (K-step, lane): the
+// fragment of lane (n = 8 a + c, hk), K-step s is -2 x~[16 s + 8 hk + i - n], i < 8 = the 16-byte chunk 2 s + hk - a + 3 of copy
+// c, where copy c holds Z_c[m] = -2 x~[m - 24 - c] (zero outside the window): an ALIGNED 16-byte read at a per-lane base plus
+// 32 s bytes.  A copy takes 2 NKS + 4 chunks, padded to CP = 4 mod 16 chunks so that the 16 lanes of a ds_read_b128 group
+// (4 c - a takes 16 different values mod 16 for the groups' (c, a) pairs) fall on 16 different bank quads: 4.6 KB a query at
+// W = 126 where the per-step fragments took 10 -- twice the queries in a chunk, half the passes over the ensemble.
+__host__ __device__ constexpr int lq_copy_chunks(int nks) { return 2 * nks + 4 <= 20 ? 20 : (2 * nks + 4 <= 36 ? 36 : 52); }
+__host__ __device__ constexpr int lq_query_bytes(int nks) { return 8 * lq_copy_chunks(nks) * 16; }
 bool scan_lq_supported(int W, int B, int64_t T);
 int scan_lq_chunk(int W, int B);                 // queries a block's chunk takes (ScanArgs::q_per_group; grid.y = ceil(B / chunk))
 size_t scan_lq_shmem_bytes(int W, int B, int q_per_group);

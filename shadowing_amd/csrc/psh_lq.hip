@@ -34,18 +34,8 @@ typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 #define PSH_LQ_FIXED 2048             // control words, per-query constants and counters
 #define PSH_LQ_MAXQ 32                // queries a chunk holds at most
 
-__host__ __device__ inline int lq_ksteps(int W) { return (W + 31 + 15) / 16; }
-// the K-steps are compiled in as 6 / 10 / 14 / 18 (a band that ends earlier multiplies zero tables)
-__host__ __device__ inline int lq_bucket(int W) { const int n = lq_ksteps(W); return n <= 6 ? 6 : (n <= 10 ? 10 : (n <= 14 ? 14 : 18)); }
-__host__ __device__ inline int lq_rows(int nks) { return 31 + (nks + 1) / 2; }
-// A query's B fragments as EIGHT SHIFTED COPIES of -2 x~ (round 6, second form) instead of one fragment per (K-step, lane): the
-// fragment of lane (n = 8 a + c, hk), K-step s is -2 x~[16 s + 8 hk + i - n], i < 8 = the 16-byte chunk 2 s + hk - a + 3 of copy
-// c, where copy c holds Z_c[m] = -2 x~[m - 24 - c] (zero outside the window): an ALIGNED 16-byte read at a per-lane base plus
-// 32 s bytes.  A copy takes 2 NKS + 4 chunks, padded to CP = 4 mod 16 chunks so that the 16 lanes of a ds_read_b128 group
-// (4 c - a takes 16 different values mod 16 for the groups' (c, a) pairs) fall on 16 different bank quads: 4.6 KB a query at
-// W = 126 where the per-step fragments took 10 -- twice the queries in a chunk, half the passes over the ensemble.
-__host__ __device__ constexpr int lq_copy_chunks(int nks) { return 2 * nks + 4 <= 20 ? 20 : (2 * nks + 4 <= 36 ? 36 : 52); }
-__host__ __device__ constexpr int lq_query_bytes(int nks) { return 8 * lq_copy_chunks(nks) * 16; }
+// (lq_ksteps, lq_bucket, lq_rows, lq_copy_chunks, lq_query_bytes: psh_kernels.h -- the long-window sample of the three launches,
+//  psh_stream.hip, lays its tables out the same way)
 __host__ __device__ inline size_t lq_wave_bytes(int nks) {
     return (size_t)PSH_LQ_SFLOATS * 4 + (size_t)PSH_LQ_QCAP * 8 + (size_t)lq_rows(nks) * PSH_LQ_ROW * 2;
 }

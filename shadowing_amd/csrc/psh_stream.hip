@@ -90,77 +90,17 @@ __device__ inline bool stream_threshold(const_f32p xq, int W, float tau0, float 
 // ends at tap W + 30 -- four steps up to W = 33 (the kernels with the band in registers), ceil((W + 31) / 16) beyond
 __host__ __device__ inline int stream_ksteps(int W) { return W <= 33 ? 4 : (W + 31 + 15) / 16; }
 
-// NWP waves per block: 1 when the launch has to fit beside another step's scan blocks (one query, PSH_FLAG_OVERLAP); 4 for the
-// two- and three-query step, whose last block then works on its queries side by side (a wave per query: the tail of the
-// launch -- selection, threshold, fragment table -- is 12 us per query when one wave does them in turn)
-template <int WT, bool ALIGNED, int NWP>
-__global__ __launch_bounds__(64 * NWP) __attribute__((amdgpu_waves_per_eu(8, 8)))
-void stream_sample_kernel(ScanArgs a, FusedArgs f) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    // This wave shares its SIMD with four scan waves of another step, all OLDER than it: the arbiter serves the oldest
-    // first, and at the default priority a sample / ranking launch took 70 us beside a scan (10-35 us alone) -- long enough
-    // to gate the next scan of its own stream.  Its work is a few per cent of a scan's: it goes first.
-    __builtin_amdgcn_s_setprio(3);
-    const int lane = lane_id();
-    const int wave = NWP == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    float* tile = smem + (size_t)wave * a.tile_floats;       // a tile per wave; the last block's histograms live there too
+// What follows the sample in the block that arrives LAST (one device-scope ticket): per query the admission level tau2 from the
+// rank-th smallest minimum (or the caller's hint), then ONE f16 scale for the step, every query's rejection threshold and the
+// scan's B fragments of the shifted query (scan_fused_kernel's phase B).  Shared by stream_sample_kernel (exact minima) and
+// stream_sample_long_kernel (matrix-core upper bounds of the minima, long windows): `tile` is the wave's scratch (>= 1024 words).
+template <int NWP>
+__device__ __forceinline__ void stream_sample_finish(const ScanArgs& a, const FusedArgs& f, float* tile, const int W, const int nq,
+                                                     const unsigned nbu, const bool hinted, const int lane, const int wave) {
     __shared__ int sh_last, sh_sexp[4], sh_armed[4];
     __shared__ float sh_tau0[4];
     FusedHdr* hdr = f.hdr;
     StreamCtl* ctl = &hdr->stream;
-    const int W = WT > 0 ? WT : a.W;
-    const int nfloat = PSH_SEG + W - 1;
-    const int nq = f.nq;
-    // levels given by the caller (psh_profile.tau_hint; the launch is then ONE block): nothing is sampled, the last-block
-    // part below takes tau0 = hint[q]
-    const bool hinted = f.tau_hint != nullptr;
-    const unsigned nbu = hinted ? 0u : (unsigned)f.boot_units;
-
-    auto boot_load = [&](Stage& sx, unsigned uu) {
-        const unsigned ri = fast_div(uu, a.magic_nseg, (unsigned)a.nseg);
-        const unsigned sg = uu - ri * (unsigned)a.nseg;
-        stage_load<ALIGNED>(sx, a.dataset + (f.boot_row0 + (int64_t)ri * f.boot_row_stride) * a.T, a.T, (int)sg * PSH_SEG, nfloat, lane);
-    };
-    unsigned u = blockIdx.x * NWP + (unsigned)wave;
-    for (int p = lane; p < a.tile_floats; p += 64) tile[p] = 0.0f;           // no slot is ever read uninitialised
-    // a header psh_workspace_init never saw: no ticket can be trusted -- block 0 says so, the scan and the ranking return
-    const bool armed_hdr = hdr->magic == PSH_FUSED_MAGIC;
-    if (!armed_hdr) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->armed = 0u; ctl->ovf = 0u; for (int q = 0; q < 4; ++q) ctl->ncand[q] = 0u; }
-        return;
-    }
-    while (u < nbu) {
-        const unsigned ri = fast_div(u, a.magic_nseg, (unsigned)a.nseg);
-        const unsigned sg = u - ri * (unsigned)a.nseg;
-        const int seg_start = (int)sg * PSH_SEG;
-        {   // (no register prefetch of the next unit: 20 VGPRs this wave does not have; the other sample waves of the chip
-            //  cover the latency)
-            Stage st;
-            boot_load(st, u);
-            stage_store<false>(st, tile, nfloat, lane);
-        }
-        wave_lds_fence();
-        const unsigned un = u + gridDim.x * NWP;
-        const int t_lane = seg_start + PSH_L * lane;
-        int nvalid = a.Tp - t_lane;
-        nvalid = nvalid < 0 ? 0 : (nvalid > PSH_L ? PSH_L : nvalid);
-        // the exact chains of the lane's 16 windows, taps from the scalar cache (few registers: this wave lives in the 64
-        // VGPRs four scan waves leave on a SIMD; the sample is ~3 % of a scan's arithmetic); the unit serves every query
-#pragma unroll 1
-        for (int q = 0; q < nq; ++q) {
-            float acc[PSH_L];
-            accumulate16<WT, false>(tile, lane, (const_f32p)a.queries + (size_t)q * W, W, acc);
-            float m = __uint_as_float(PSH_INF_BITS);
-#pragma unroll
-            for (int i = 0; i < PSH_L; ++i) m = (i < nvalid) ? fminf(m, acc[i]) : m;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
-            if (!(m == m)) m = __uint_as_float(PSH_INF_BITS);              // NaN data: the segment carries no information
-            if (lane == 0) st_sc1(&hdr->minima[(size_t)q * f.units_stride + u], __float_as_uint(m));   // write-through
-        }
-        wave_lds_fence();
-        u = un;
-    }
     // arrive: the minima have left this CU (drain), then ONE device-scope ticket per block; the last arriver goes on
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (NWP > 1) __syncthreads();
@@ -311,6 +251,78 @@ void stream_sample_kernel(ScanArgs a, FusedArgs f) {
         ctl->ovf = 0u;
         ctl->ticket = 0u;                                                 // the next launch on this workspace counts from zero
     }
+}
+
+// NWP waves per block: 1 when the launch has to fit beside another step's scan blocks (one query, PSH_FLAG_OVERLAP); 4 for the
+// two- and three-query step, whose last block then works on its queries side by side (a wave per query: the tail of the
+// launch -- selection, threshold, fragment table -- is 12 us per query when one wave does them in turn)
+template <int WT, bool ALIGNED, int NWP>
+__global__ __launch_bounds__(64 * NWP) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void stream_sample_kernel(ScanArgs a, FusedArgs f) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // This wave shares its SIMD with four scan waves of another step, all OLDER than it: the arbiter serves the oldest
+    // first, and at the default priority a sample / ranking launch took 70 us beside a scan (10-35 us alone) -- long enough
+    // to gate the next scan of its own stream.  Its work is a few per cent of a scan's: it goes first.
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = lane_id();
+    const int wave = NWP == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float* tile = smem + (size_t)wave * a.tile_floats;       // a tile per wave; the last block's histograms live there too
+    FusedHdr* hdr = f.hdr;
+    StreamCtl* ctl = &hdr->stream;
+    const int W = WT > 0 ? WT : a.W;
+    const int nfloat = PSH_SEG + W - 1;
+    const int nq = f.nq;
+    // levels given by the caller (psh_profile.tau_hint; the launch is then ONE block): nothing is sampled, the last-block
+    // part below takes tau0 = hint[q]
+    const bool hinted = f.tau_hint != nullptr;
+    const unsigned nbu = hinted ? 0u : (unsigned)f.boot_units;
+
+    auto boot_load = [&](Stage& sx, unsigned uu) {
+        const unsigned ri = fast_div(uu, a.magic_nseg, (unsigned)a.nseg);
+        const unsigned sg = uu - ri * (unsigned)a.nseg;
+        stage_load<ALIGNED>(sx, a.dataset + (f.boot_row0 + (int64_t)ri * f.boot_row_stride) * a.T, a.T, (int)sg * PSH_SEG, nfloat, lane);
+    };
+    unsigned u = blockIdx.x * NWP + (unsigned)wave;
+    for (int p = lane; p < a.tile_floats; p += 64) tile[p] = 0.0f;           // no slot is ever read uninitialised
+    // a header psh_workspace_init never saw: no ticket can be trusted -- block 0 says so, the scan and the ranking return
+    const bool armed_hdr = hdr->magic == PSH_FUSED_MAGIC;
+    if (!armed_hdr) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->armed = 0u; ctl->ovf = 0u; for (int q = 0; q < 4; ++q) ctl->ncand[q] = 0u; }
+        return;
+    }
+    while (u < nbu) {
+        const unsigned ri = fast_div(u, a.magic_nseg, (unsigned)a.nseg);
+        const unsigned sg = u - ri * (unsigned)a.nseg;
+        const int seg_start = (int)sg * PSH_SEG;
+        {   // (no register prefetch of the next unit: 20 VGPRs this wave does not have; the other sample waves of the chip
+            //  cover the latency)
+            Stage st;
+            boot_load(st, u);
+            stage_store<false>(st, tile, nfloat, lane);
+        }
+        wave_lds_fence();
+        const unsigned un = u + gridDim.x * NWP;
+        const int t_lane = seg_start + PSH_L * lane;
+        int nvalid = a.Tp - t_lane;
+        nvalid = nvalid < 0 ? 0 : (nvalid > PSH_L ? PSH_L : nvalid);
+        // the exact chains of the lane's 16 windows, taps from the scalar cache (few registers: this wave lives in the 64
+        // VGPRs four scan waves leave on a SIMD; the sample is ~3 % of a scan's arithmetic); the unit serves every query
+#pragma unroll 1
+        for (int q = 0; q < nq; ++q) {
+            float acc[PSH_L];
+            accumulate16<WT, false>(tile, lane, (const_f32p)a.queries + (size_t)q * W, W, acc);
+            float m = __uint_as_float(PSH_INF_BITS);
+#pragma unroll
+            for (int i = 0; i < PSH_L; ++i) m = (i < nvalid) ? fminf(m, acc[i]) : m;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+            if (!(m == m)) m = __uint_as_float(PSH_INF_BITS);              // NaN data: the segment carries no information
+            if (lane == 0) st_sc1(&hdr->minima[(size_t)q * f.units_stride + u], __float_as_uint(m));   // write-through
+        }
+        wave_lds_fence();
+        u = un;
+    }
+    stream_sample_finish<NWP>(a, f, tile, W, nq, nbu, hinted, lane, wave);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -912,6 +924,206 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_q_kernel(ScanArg
 
 
 // ------------------------------------------------------------------------------------------------------------------
+// P for long windows (round 6): the sample on the matrix cores
+// ------------------------------------------------------------------------------------------------------------------
+// stream_sample_kernel's exact chains cost a sampled unit 1024 x W x 2 vector instructions -- 8 us of a wave at W = 126, 51 us a
+// launch beside the scans, and at W = 252 (where no sample block fits in the LDS a long-window scan block leaves) 25 us in front of
+// every scan.  Here a sampled unit takes the long-window scan's own road: f16 rows, window energies from fp32 prefix sums, the
+// banded product with the shifted query on the matrix cores -- and gives an UPPER bound of its smallest acc per query, exactly
+// scan_lq_kernel's BOOT construction (psh_lq.hip: the C operand is E^ + gamma S, the bound (t^ + nx~)(1 + 3 a + 6 gamma) + b, the
+// query's fragments eight shifted copies of -2 x~ under a scale that needs the query alone: max|x| 2^s < 8).  The rank-th smallest
+// upper bound is a level with at least `rank` windows below it, as the rank-th smallest exact minimum is; it sits a few per mille
+// higher (1 + 3 a) and admits ~20 % more candidates at W = 126.  The tail is stream_sample_finish.
+// NWP: 1 (one query: 13-15 KB of LDS and <= 128 VGPRs, beside a scan block up to W ~ 200) or 4 (two / three queries).
+template <int NKS, int NWP>
+__device__ __forceinline__ void stream_sample_long_body(const ScanArgs& a, const FusedArgs& f) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __builtin_amdgcn_s_setprio(3);                                            // (see stream_sample_kernel)
+    const int lane = lane_id();
+    const int tid = (int)threadIdx.x;
+    const int wave = NWP == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int W = a.W, nq = f.nq;
+    constexpr int CP = lq_copy_chunks(NKS), QS = lq_query_bytes(NKS) / 2;     // chunks a copy, HALVES a query
+    constexpr int NROWS = lq_rows(NKS);
+    int* ctlw = reinterpret_cast<int*>(smem);                                 // [0]: the step's sample exponent
+    float* nxq = smem + 4;                                                    // nx~ (1 + 1e-6) per query
+    _Float16* tab = reinterpret_cast<_Float16*>(smem + 16);                   // [query][copy c < 8][chunk < CP][8 halves]
+    float* sp = reinterpret_cast<float*>(tab + (size_t)nq * QS) + (size_t)wave * (PSH_LONG_SFLOATS + NROWS * PSH_LONG_ROW / 2);
+    _Float16* a1 = reinterpret_cast<_Float16*>(sp + PSH_LONG_SFLOATS);        // rows of {y^ [32], pad [8]}
+    FusedHdr* hdr = f.hdr;
+    StreamCtl* ctl = &hdr->stream;
+    const unsigned nbu = (unsigned)f.boot_units;
+    const int nfloat = PSH_SEG + W - 1;
+    const bool armed_hdr = hdr->magic == PSH_FUSED_MAGIC;                     // (stream_sample_kernel: a header psh_workspace_init never saw)
+    if (!armed_hdr) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->armed = 0u; ctl->ovf = 0u; for (int q = 0; q < 4; ++q) ctl->ncand[q] = 0u; }
+        return;
+    }
+    const int lane16 = lane * 16;
+    auto load_unit = [&](Stage& sx, unsigned uu) {
+        const unsigned ri = fast_div(uu, a.magic_nseg, (unsigned)a.nseg);
+        const unsigned sg = uu - ri * (unsigned)a.nseg;
+        const int64_t row = f.boot_row0 + (int64_t)ri * f.boot_row_stride;
+        const int64_t bytes = a.T * 4;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dataset + row * a.T), 0,
+                                                                             (int)(bytes > 0x7ffffffc ? 0x7ffffffc : bytes), 0x00020000);
+        const int nq4 = (nfloat + 3) >> 2;
+#pragma unroll
+        for (int q = 0; q < PSH_NSTAGE; ++q)
+            if (q < PSH_NSTAGE - 1 || lane + 64 * q < nq4) {
+                const u32x4v w = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + 1024 * q, (int)sg * PSH_SEG * 4, 0);
+                sx.v[q] = f32x4{__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])};
+            }
+    };
+    Stage st;
+    unsigned u = blockIdx.x * NWP + (unsigned)wave;
+    if (u < nbu) load_unit(st, u);
+    // ---- the sample's scale (every query: max|x| 2^sexp < 8), nx~, the tables
+    if (tid == 0) ctlw[0] = 60;
+    if (NWP > 1) __syncthreads(); else wave_lds_fence();
+    for (int q = wave; q < nq; q += NWP) {
+        const const_f32p xq = (const_f32p)a.queries + (size_t)q * W;
+        unsigned mb = 0u;
+        for (int j = lane; j < W; j += 64) mb = max(mb, __float_as_uint(fabsf(xq[j])));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, off, 64));
+        // (a query with a NaN / inf sample does not bound the scale: its tables hold NaN, its upper bounds come out +inf and the
+        //  finish finds fewer finite minima than its rank -> not armed -> PSH_STATUS_RETRY)
+        if (lane == 0 && mb >= 0x00800000u && mb < PSH_INF_BITS) atomicMin(&ctlw[0], 3 - ((int)((mb >> 23) & 255u) - 126));
+    }
+    if (NWP > 1) __syncthreads(); else wave_lds_fence();
+    const int sexp = ctlw[0] < -60 ? -60 : ctlw[0];
+    const float scale = __uint_as_float((unsigned)(127 + sexp) << 23);
+    for (int q = wave; q < nq; q += NWP) {
+        const const_f32p xq = (const_f32p)a.queries + (size_t)q * W;
+        double part = 0.0;
+        for (int j = lane; j < W; j += 64) { const double vv = (double)xq[j] * (double)scale; part += vv * vv; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        if (lane == 0) nxq[q] = (float)(part * (1.0 + 1e-6));
+    }
+    for (int e = tid; e < nq * 8 * CP; e += 64 * NWP) {                       // copy c, chunk v, half i: -2 x~[8 (v - 3) + i - c]
+        const int v = e % CP, c = (e / CP) & 7, q = e / (8 * CP);
+        const const_f32p xq = (const_f32p)a.queries + (size_t)q * W;
+        f16x8 b;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = 8 * (v - 3) + i - c;
+            const bool in = j >= 0 && j < W;
+            const float xv = xq[in ? j : 0];
+            b[i] = (_Float16)(in ? -2.0f * (xv * scale) : 0.0f);
+        }
+        *reinterpret_cast<f16x8*>(tab + (size_t)q * QS + ((size_t)c * CP + v) * 8) = b;
+    }
+    {   // every slot of the rows a segment does not write must be finite (0 * NaN poisons a row)
+        unsigned* z = reinterpret_cast<unsigned*>(a1);
+        for (int i = lane; i < NROWS * PSH_LONG_ROW / 2; i += 64) z[i] = 0u;
+    }
+    if (NWP > 1) __syncthreads(); else wave_lds_fence();
+
+    const int m = lane & 31, hk = lane >> 5;
+    const _Float16* pa0 = a1 + m * PSH_LONG_ROW + 8 * hk;
+    const _Float16* pb0 = tab + ((size_t)(m & 7) * CP + (hk - (m >> 3) + 3)) * 8;   // copy n & 7, chunk hk - (n >> 3) + 3 (+ 2 s a K-step)
+    const float* ps_lo = sp + m + 128 * hk;
+    const float* ps_hi = ps_lo + W;
+    while (u < nbu) {
+        const unsigned ri = fast_div(u, a.magic_nseg, (unsigned)a.nseg);
+        const int seg_start = (int)(u - ri * (unsigned)a.nseg) * PSH_SEG;
+        {   // f16 rows and the fp32 prefix sums of the squares (stream_scan_long_body: the construction and its bound are there)
+            const int nq4 = (nfloat + 3) >> 2;
+            float d0[PSH_NSTAGE], d1[PSH_NSTAGE], d2[PSH_NSTAGE], d3[PSH_NSTAGE], inc[PSH_NSTAGE];
+#pragma unroll
+            for (int q = 0; q < PSH_NSTAGE; ++q) {
+                const int mm = lane + 64 * q;
+                const bool on = q < PSH_NSTAGE - 1 || mm < nq4;
+                const f32x4 v = on ? st.v[q] * scale : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                const f32x4 z = v * v;
+                if (on) *reinterpret_cast<f16x4*>(a1 + (mm >> 3) * PSH_LONG_ROW + 4 * (mm & 7)) = __builtin_convertvector(v, f16x4);
+                d0[q] = z[0]; d1[q] = d0[q] + z[1]; d2[q] = d1[q] + z[2]; d3[q] = d2[q] + z[3];
+                inc[q] = d3[q];
+            }
+#pragma unroll
+            for (int q = 0; q < PSH_NSTAGE; ++q) inc[q] = dpp_addf<0x111, 0xf>(inc[q]);
+#pragma unroll
+            for (int q = 0; q < PSH_NSTAGE; ++q) inc[q] = dpp_addf<0x112, 0xf>(inc[q]);
+#pragma unroll
+            for (int q = 0; q < PSH_NSTAGE; ++q) inc[q] = dpp_addf<0x114, 0xf>(inc[q]);
+#pragma unroll
+            for (int q = 0; q < PSH_NSTAGE; ++q) inc[q] = dpp_addf<0x118, 0xf>(inc[q]);
+#pragma unroll
+            for (int q = 0; q < PSH_NSTAGE; ++q) inc[q] = dpp_addf<0x142, 0xa>(inc[q]);
+#pragma unroll
+            for (int q = 0; q < PSH_NSTAGE; ++q) inc[q] = dpp_addf<0x143, 0xc>(inc[q]);
+            float carry = 0.0f;
+#pragma unroll
+            for (int q = 0; q < PSH_NSTAGE; ++q) {
+                const int mm = lane + 64 * q;
+                const float x0 = carry + (inc[q] - d3[q]);
+                carry += __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(inc[q]), 63));
+                if (q < PSH_NSTAGE - 1 || mm <= nq4) *reinterpret_cast<f32x4*>(sp + 4 * mm) = f32x4{x0, x0 + d0[q], x0 + d1[q], x0 + d2[q]};
+            }
+        }
+        wave_lds_fence();
+        const unsigned un = u + gridDim.x * NWP;
+        if (un < nbu) load_unit(st, un);
+        // the tile's C operand: an UPPER bound of the 16 windows' energies, E^(p) + gamma S^[p + W]
+        f32x16 ce;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int off = 32 * (r & 3) + 256 * (r >> 2);
+            ce[r] = __builtin_fmaf(ps_hi[off], 1.0f + PSH_LONG_GAMMA, -ps_lo[off]);
+        }
+        const int nvalid = a.Tp - seg_start;
+        auto ld = [](const _Float16* p) { return *reinterpret_cast<const f16x8*>(p); };
+#pragma unroll 1
+        for (int q = 0; q < nq; ++q) {
+            f32x16 c = ce;
+            const _Float16* pb = pb0 + (size_t)q * QS;
+#pragma unroll
+            for (int s2 = 0; s2 < NKS; ++s2)
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ld(pa0 + (s2 >> 1) * PSH_LONG_ROW + 16 * (s2 & 1)), ld(pb + 16 * s2), c, 0, 0, 0);
+            float mn = __uint_as_float(PSH_INF_BITS);
+            if (nvalid >= PSH_SEG) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mn = fminf(mn, c[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = 32 * ((r & 3) + 8 * (r >> 2) + 4 * hk) + m;
+                    mn = p < nvalid ? fminf(mn, c[r]) : mn;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off, 64));
+            // an upper bound of the smallest acc of the unit: acc~ <= (t^ + nx~)(1 + 3 a + 6 gamma) + b, back to the data's scale
+            // (scan_lq_kernel's BOOT; t^ + nx~ < 0 cannot be a true value: the bound is then b alone)
+            float ub = (fmaxf(mn + nxq[q], 0.0f) * (1.0f + 3.0f / 900.0f + 6.0f * PSH_LONG_GAMMA) + (float)(2 * W + 2) / 64.0f / 262144.0f) * (1.0f + 1e-6f);
+            const float inv = __uint_as_float((unsigned)(127 - sexp) << 23);
+            ub = ub * inv * inv;
+            if (!(ub == ub)) ub = __uint_as_float(PSH_INF_BITS);              // NaN data: the unit carries no information
+            if (lane == 0) st_sc1(&hdr->minima[(size_t)q * f.units_stride + u], __float_as_uint(ub));   // write-through
+        }
+        wave_lds_fence();                                                     // all lanes done with the arrays before they are overwritten
+        u = un;
+    }
+    stream_sample_finish<NWP>(a, f, sp, W, nq, nbu, false, lane, wave);
+}
+// one query: 128 registers, so that the wave fits beside the four scan waves (96 registers each) of another step on its SIMD
+template <int NKS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void stream_sample_long_kernel1(ScanArgs a, FusedArgs f) {
+    stream_sample_long_body<NKS, 1>(a, f);
+}
+// (W > 161: no sample block fits in the LDS a scan block leaves, whatever its registers -- and the cap would spill the longer chains)
+template <int NKS>
+__global__ __launch_bounds__(64) void stream_sample_long_kernel1u(ScanArgs a, FusedArgs f) {
+    stream_sample_long_body<NKS, 1>(a, f);
+}
+template <int NKS>
+__global__ __launch_bounds__(256) void stream_sample_long_kernel4(ScanArgs a, FusedArgs f) {
+    stream_sample_long_body<NKS, 4>(a, f);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // R: ranking by counting (grid.y = query)
 // ------------------------------------------------------------------------------------------------------------------
 template <bool PACKED>
@@ -1046,6 +1258,33 @@ hipError_t launch_stream_sample(const ScanArgs& a, const FusedArgs& f, bool alig
     b.tile_floats = sample_tile_floats;
     if (f.nq == 1) return launch_stream_sample_w<1>(b, f, aligned, grid, stream_sample_shmem_bytes(sample_tile_floats), s);
     return launch_stream_sample_w<4>(b, f, aligned, (grid + 3) / 4, 4 * stream_sample_shmem_bytes(sample_tile_floats), s);
+}
+
+size_t stream_sample_long_shmem_bytes(int W, int nq) {
+    const int nks = lq_bucket(W), nwp = nq == 1 ? 1 : 4;
+    return 64 + (size_t)nq * lq_query_bytes(nks) + (size_t)nwp * ((size_t)PSH_LONG_SFLOATS * 4 + (size_t)lq_rows(nks) * PSH_LONG_ROW * 2);
+}
+static hipError_t launch_stream_sample_long_1(const ScanArgs& a, const FusedArgs& f, int grid, hipStream_t s) {
+    const int nks = lq_bucket(a.W);
+    const size_t shmem = stream_sample_long_shmem_bytes(a.W, f.nq);
+    if (nks == 6) return launch_k(stream_sample_long_kernel1<6>, dim3(grid), 64, shmem, s, a, f);
+    if (nks == 10) return launch_k(stream_sample_long_kernel1<10>, dim3(grid), 64, shmem, s, a, f);
+    if (nks == 14) return launch_k(stream_sample_long_kernel1u<14>, dim3(grid), 64, shmem, s, a, f);
+    return launch_k(stream_sample_long_kernel1u<18>, dim3(grid), 64, shmem, s, a, f);
+}
+static hipError_t launch_stream_sample_long_4(const ScanArgs& a, const FusedArgs& f, int grid, hipStream_t s) {
+    const int nks = lq_bucket(a.W);
+    const size_t shmem = stream_sample_long_shmem_bytes(a.W, f.nq);
+    if (nks == 6) return launch_k(stream_sample_long_kernel4<6>, dim3(grid), 256, shmem, s, a, f);
+    if (nks == 10) return launch_k(stream_sample_long_kernel4<10>, dim3(grid), 256, shmem, s, a, f);
+    if (nks == 14) return launch_k(stream_sample_long_kernel4<14>, dim3(grid), 256, shmem, s, a, f);
+    return launch_k(stream_sample_long_kernel4<18>, dim3(grid), 256, shmem, s, a, f);
+}
+// the long-window step's sample (34 <= W <= 256, no hint): one-wave blocks for one query, a quarter as many four-wave blocks for
+// two or three (launch_stream_sample's rule)
+hipError_t launch_stream_sample_long(const ScanArgs& a, const FusedArgs& f, int grid, hipStream_t s) {
+    if (f.nq == 1) return launch_stream_sample_long_1(a, f, grid, s);
+    return launch_stream_sample_long_4(a, f, (grid + 3) / 4, s);
 }
 
 template <int NQ>
