@@ -486,17 +486,17 @@ static hipError_t launch_lq_m(const ScanArgs& a, int grid_x, hipStream_t s) {
     const int nks = lq_bucket(a.W);
     const size_t shmem = scan_lq_shmem_bytes(a.W, a.B, a.q_per_group);
     const dim3 grid((unsigned)grid_x, (unsigned)a.n_qgroups);
-#define PSH_LQ_LAUNCH(N)                                                                                                             \
+#define PSH_LQ_LAUNCH(KERNEL)                                                                                                        \
     {                                                                                                                                \
-        hipError_t e = hipFuncSetAttribute((const void*)scan_lq_kernel<MODE, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+        hipError_t e = hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);             \
         if (e != hipSuccess) return e;                                                                                               \
-        hipLaunchKernelGGL((scan_lq_kernel<MODE, N>), grid, dim3(PSH_LQ_THREADS), shmem, s, a);                                      \
+        hipLaunchKernelGGL(KERNEL, grid, dim3(PSH_LQ_THREADS), shmem, s, a);                                                         \
         return hipGetLastError();                                                                                                    \
     }
-    if (nks == 6) PSH_LQ_LAUNCH(6)
-    if (nks == 10) PSH_LQ_LAUNCH(10)
-    if (nks == 14) PSH_LQ_LAUNCH(14)
-    PSH_LQ_LAUNCH(18)
+    if (nks == 6) PSH_LQ_LAUNCH((scan_lq_kernel<MODE, 6>))
+    if (nks == 10) PSH_LQ_LAUNCH((scan_lq_kernel<MODE, 10>))
+    if (nks == 14) PSH_LQ_LAUNCH((scan_lq_kernel<MODE, 14>))
+    PSH_LQ_LAUNCH((scan_lq_kernel<MODE, 18>))
 #undef PSH_LQ_LAUNCH
 }
 
