@@ -104,5 +104,9 @@ PSH_LIB=$R/shadowing_amd/lib/libpsh_hip_tuning.so timeout 300 python tools/emx_p
 # long-window scan (stage times, ablations: PSH_DBG 1 no MFMAs, 2 no tests, 4 no survivor handling), the long-window scan's counters
 timeout 300 python tools/blocking_times.py 2>> $OUT/bench.err | grep -v amdgpu.ids > $OUT/blocking_times.txt
 timeout 600 python tools/lq_stages.py 64,126,252 2>> $OUT/bench.err | grep "^{" > $OUT/lq_stages.jsonl
-(for d in 0 1 2 3 4; do PSH_DBG=$d PSH_LIB=$R/shadowing_amd/lib/libpsh_hip_tuning.so python tools/lq_ablate.py 126 64 2>/dev/null | tail -1; done; PSH_DBG=16 PSH_LIB=$R/shadowing_amd/lib/libpsh_hip_tuning.so python tools/lq_ablate.py 126 64 2>/dev/null | tail -1) > $OUT/lq_ablate.txt
+# (PSH_DBG: 1 no MFMA chains, 2 no tests, 3 neither, 4 no survivor handling, 8 survivors queued but not verified, 32 the min trees alone, 16 counts the survivors)
+PSH_LIB=$R/shadowing_amd/lib/libpsh_hip_tuning.so timeout 600 python tools/lq_ablate2.py 126:64:0,1,2,3,4,8,32,16 64:64:0,2,3 252:64:0,2,3 126:4:0 126:16:0 126:512:0 64:512:0 252:512:0 2>/dev/null | grep "^W=" > $OUT/lq_ablate.txt
+bash tools/pmc_lq.sh > /dev/null 2>&1; cp $R/gpurun_out/lqpmc/lq_pmc_summary.txt $OUT/lq_pmc_summary.txt 2>/dev/null
+# the long-window step with its sample as exact chains (PSH_STREAM_SKIP=8, tuning build) and on the matrix cores, same box
+(for W in 64 126 252; do for skip in 8 0; do echo "W=$W PSH_STREAM_SKIP=$skip (8: the exact-chain sample; 0: stream_sample_long_kernel)"; PSH_LIB=$R/shadowing_amd/lib/libpsh_hip_tuning.so PSH_STREAM_SKIP=$skip timeout 200 python bench.py --W $W --steps 200 --warmup 20 --no-cpu-baseline --no-blocking-api 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('  ms_per_step', d['ms_per_step'], 'repeats', d.get('ms_per_step_repeats',{}).get('median'), d.get('ms_per_step_repeats',{}).get('min'), 'parity', d.get('parity_rotating_queries',{}).get('ok'))"; done; done) > $OUT/long_sample_ab.txt 2>&1
 bash tools/pmc_long.sh > /dev/null 2>&1; cp $R/gpurun_out/longpmc/long_pmc_summary.txt $OUT/long_pmc_summary.txt 2>/dev/null

@@ -18,7 +18,7 @@ for f in bench_n1_20steps.json bench_n1_fused_one_stream.json kernel_stats_fused
          bench_n1_R131072.json fused_skeleton.json mq_ablations.txt ubench_lds_unaligned.txt \
          bench_n1_q512_f16_test.json ubench_mfma_i8.txt q512_kernel_stats.csv mq_clock.txt mq8_phases.txt batch_sweep.txt \
          bench_n1_W64.json bench_n1_W126.json bench_n1_W252.json bench_n1_W126_valu_filter.json blocking_probe.txt ubench_mfma_cover.txt W126_kernel_stats.csv emx_phases.txt long_batch_probe.jsonl long_ablate.txt \
-         blocking_times.txt lq_stages.jsonl lq_ablate.txt long_pmc_summary.txt; do
+         blocking_times.txt lq_stages.jsonl lq_ablate.txt long_pmc_summary.txt lq_pmc_summary.txt long_sample_ab.txt; do
   [ -s $S/$f ] && cp $S/$f $R/profiles/${TAG}_$f
 done
 ls -la $R/profiles
