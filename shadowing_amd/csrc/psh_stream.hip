@@ -978,11 +978,15 @@ __device__ __forceinline__ void stream_sample_long_body(const ScanArgs& a, const
     Stage st;
     unsigned u = blockIdx.x * NWP + (unsigned)wave;
     if (u < nbu) load_unit(st, u);
-    // ---- the sample's scale (every query: max|x| 2^sexp < 8), nx~, the tables
+    // ---- the sample's scale (every query: max|x| 2^sexp < 8), nx~, the tables.  The queries are staged in LDS first (the first
+    //      wave's prefix-sum scratch: <= 3 x 256 floats): the tables read every sample a dozen times, and from memory a block's
+    //      set-up was five dependent round trips -- half the life of a block that samples two units.
+    float* xs = reinterpret_cast<float*>(tab + (size_t)nq * QS);             // [query][W]
+    for (int e = tid; e < nq * W; e += 64 * NWP) xs[e] = a.queries[e];
     if (tid == 0) ctlw[0] = 60;
     if (NWP > 1) __syncthreads(); else wave_lds_fence();
     for (int q = wave; q < nq; q += NWP) {
-        const const_f32p xq = (const_f32p)a.queries + (size_t)q * W;
+        const float* xq = xs + (size_t)q * W;
         unsigned mb = 0u;
         for (int j = lane; j < W; j += 64) mb = max(mb, __float_as_uint(fabsf(xq[j])));
 #pragma unroll
@@ -995,7 +999,7 @@ __device__ __forceinline__ void stream_sample_long_body(const ScanArgs& a, const
     const int sexp = ctlw[0] < -60 ? -60 : ctlw[0];
     const float scale = __uint_as_float((unsigned)(127 + sexp) << 23);
     for (int q = wave; q < nq; q += NWP) {
-        const const_f32p xq = (const_f32p)a.queries + (size_t)q * W;
+        const float* xq = xs + (size_t)q * W;
         double part = 0.0;
         for (int j = lane; j < W; j += 64) { const double vv = (double)xq[j] * (double)scale; part += vv * vv; }
 #pragma unroll
@@ -1004,7 +1008,7 @@ __device__ __forceinline__ void stream_sample_long_body(const ScanArgs& a, const
     }
     for (int e = tid; e < nq * 8 * CP; e += 64 * NWP) {                       // copy c, chunk v, half i: -2 x~[8 (v - 3) + i - c]
         const int v = e % CP, c = (e / CP) & 7, q = e / (8 * CP);
-        const const_f32p xq = (const_f32p)a.queries + (size_t)q * W;
+        const float* xq = xs + (size_t)q * W;
         f16x8 b;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -1015,6 +1019,7 @@ __device__ __forceinline__ void stream_sample_long_body(const ScanArgs& a, const
         }
         *reinterpret_cast<f16x8*>(tab + (size_t)q * QS + ((size_t)c * CP + v) * 8) = b;
     }
+    if (NWP > 1) __syncthreads(); else wave_lds_fence();                     // (the staged queries are dead: the first wave's scratch)
     {   // every slot of the rows a segment does not write must be finite (0 * NaN poisons a row)
         unsigned* z = reinterpret_cast<unsigned*>(a1);
         for (int i = lane; i < NROWS * PSH_LONG_ROW / 2; i += 64) z[i] = 0u;

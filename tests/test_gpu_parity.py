@@ -430,6 +430,39 @@ def test_long_window_shadow_with_paths_and_adversarial_data(hip_device, oracle_m
         assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, f"long window, {kind}")
 
 
+@pytest.mark.parametrize("W", [40, 66, 97, 129, 145, 161, 162, 200, 256])
+@pytest.mark.parametrize("B", [1, 2, 3])
+def test_long_window_sample_on_the_matrix_cores(hip_device, oracle_mod, W, B):
+    """The long-window step's sample as matrix-core UPPER bounds of the unit minima (stream_sample_long_kernel, round 6): every
+    K-step bucket (6 / 10 / 14 / 18), one query (one-wave blocks) and two / three (four-wave blocks; beyond what rides one pass a
+    loop of steps), a T that leaves a ragged last segment, a horizon -- status OK from the three launches themselves (the level
+    held: at least k windows below it) and the oracle's results; then the same ensemble with NaN / inf samples through
+    shadow(cuda=True)."""
+    from shadowing_amd import _native
+    R, T, h, k = 3072, 2300, 9, 150
+    ds = syn.dataset(R, T, 4100 + W)
+    q = syn.gbm_log_returns((B, W), 4200 + W + B)
+    ds_t = torch.as_tensor(np.ascontiguousarray(ds[:, 0, :])).to(hip_device)
+    q_t = torch.as_tensor(q).to(hip_device)
+    od, oidx = oracle_mod.scan_topk(ds, q, k, h=h)
+    info = {}
+    d, idx, st = _native.scan_topk(ds_t, q_t, k, h=h, info=info)
+    torch.cuda.synchronize()
+    assert info["path"] == 3 and not st.cpu().numpy().any(), (W, B, info, st.tolist())
+    assert_exact(d.cpu().numpy(), idx.cpu().numpy(), od, oidx, f"long-window sample W={W} B={B}")
+    import shadowing_amd as sa
+    dirty = ds.copy()
+    rng = np.random.default_rng(4300 + W)
+    for r in rng.integers(0, R, 40):
+        dirty[r, 0, rng.integers(0, T)] = [np.nan, np.inf, -np.inf][int(rng.integers(0, 3))]
+    obj = sa.PathShadowing(sa.Identity(W), sa.RelativeMSE(), torch.as_tensor(dirty), sa.PredictionContext(h), cache=True)
+    d, paths, idx = obj.shadow(q, k=k, cuda=True)
+    assert obj.last_path == "hip"
+    od, opaths, oidx = oracle_mod.shadow(dirty, q, k, h)
+    assert_exact(d, idx, od, oidx, f"long-window sample, dirty ensemble W={W} B={B}")
+    assert np.array_equal(paths, opaths, equal_nan=True)
+
+
 @pytest.mark.parametrize("W,flags", [(20, "overlap"), (33, "overlap"), (40, 0), (64, 0), (126, 0), (126, "overlap"), (250, 0)])
 def test_smooth_ensembles_fill_block_lists_without_giving_up(hip_device, oracle_mod, W, flags):
     """A smooth ensemble (price LEVELS: random walks, not returns) puts a match's neighbours in t next to it in distance and
