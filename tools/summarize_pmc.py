@@ -41,7 +41,7 @@ if "--traffic" in sys.argv:
             for (k2, c2) in means:
                 if other in k2 and c2 == "FETCH_SIZE":
                     extra[other + "_hbm_bytes_per_launch"] = int(2 * means[(k2, "FETCH_SIZE")] * 1024 + means.get((k2, "WRITE_SIZE"), 0.0) * 1024)
-        j = {"workload": f"R={R},T={T},W={W},h={h},k={k},B={B}", "kernel": kn, "round": 5, **extra,
+        j = {"workload": f"R={R},T={T},W={W},h={h},k={k},B={B}", "kernel": kn, "round": 6, **extra,
              "FETCH_SIZE_KiB_per_launch": round(fetch, 1), "WRITE_SIZE_KiB_per_launch": round(write, 1),
              "correction": "gfx950 rocprofv3 FETCH_SIZE counts 64 B per 128-B request on wide coalesced streams: read bytes = "
                            "2 x FETCH_SIZE x 1024 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE taken as is",
@@ -65,7 +65,7 @@ if "--mq" in sys.argv:
         valu = means.get((kn, "SQ_ACTIVE_INST_VALU"))              # quad-cycles (MI355X_MICROARCH.md)
         fetch, write = means.get((kn, "FETCH_SIZE")), means.get((kn, "WRITE_SIZE"), 0.0)
         R, T, W, h, k, B = 32768, 4096, 20, 20, 1024, 512
-        j = {"workload": f"R={R},T={T},W={W},h={h},k={k},B={B}", "kernel": kn, "round": 5, "launch_cycles": round(cyc),
+        j = {"workload": f"R={R},T={T},W={W},h={h},k={k},B={B}", "kernel": kn, "round": 6, "launch_cycles": round(cyc),
              "matrix_core_busy_frac": round(mfma / (nsimd * cyc), 4) if mfma else None,
              "valu_busy_frac": round(4.0 * valu / (nsimd * cyc), 4) if valu else None,
              "SQ_INSTS_MFMA": means.get((kn, "SQ_INSTS_MFMA")), "SQ_INSTS_VALU": means.get((kn, "SQ_INSTS_VALU")),
