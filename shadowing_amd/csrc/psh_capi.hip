@@ -805,7 +805,12 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
             if (rows_p > p.R / 4) rows_p = p.R / 4;
             if (rows_p < 1) rows_p = 1;
             const int64_t units_p = rows_p * nseg;
-            int64_t r2p = (2 * (int64_t)k * rows_p + p.R - 1) / p.R + 8;
+            // the level's rank among the sampled minima: the k best windows of the ensemble put at most kf = k x sampled fraction
+            // minima below their level (Poisson), so the (kf + 5 sqrt(kf) + 4)-th smallest lies above it but for five sigma -- 40 at
+            // the benchmark's kf = 16 (what 2 kf + 8 gave until round 6: the same there, but twelve sigma at kf = 128, where it
+            // admitted twice the windows a smooth ensemble's lists hold)
+            const double kf = (double)k * (double)rows_p / (double)p.R;
+            int64_t r2p = (int64_t)ceil(kf + 5.0 * sqrt(kf)) + 4;
             if (r2p < 24) r2p = 24;
             int64_t grid_p = (int64_t)tn.stream_pgrid_per_cu * ncu;
             // (a long window's sample is its exact chains -- 1024 windows x W taps per unit, 11 us at W = 126 -- not its bytes:

@@ -316,10 +316,18 @@ __global__ __launch_bounds__(PSH_LQ_THREADS) void scan_lq_kernel(ScanArgs a) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off, 64));
             if (lane == 0) {
-                // an upper bound of the smallest acc of the unit: acc~ <= (t^ + nx~)(1 + 3 a) + b, back to the data's scale.
-                // (t^ + nx~ < 0 cannot be a true value: rounding below zero -- the bound is then b alone)
+                // An upper bound of the smallest acc of the unit, back in the data's scale.  With 2 |c^ - c| <= a (nx~ + E) and
+                // E <= 2 (nx~ + acc~) (stream_threshold's model, read the other way round):
+                //     acc~ (1 - 2 a) <= t^ + nx~ (1 + 3 a) + b.
+                // A unit whose estimate t^ + nx~ is below nx~ / 6 -- a near-match: smooth ensembles -- would get a bound made of the
+                // 3 a nx~ term alone, several times its value; the ESTIMATE (1 + 3 a)(t^ + nx~) stands in there.  Nothing rests on
+                // either being a proof: the level is checked by what it admits (select_kernel: at least k, or the fallback).
                 const float nx = qc[4 * ql + 0];
-                float ub = (fmaxf(mn + nx, 0.0f) * (1.0f + 3.0f / 900.0f + 6.0f * PSH_LQ_GAMMA) + (float)(2 * W + 2) / 64.0f / 262144.0f) * (1.0f + 1e-6f);
+                const float est = fmaxf(mn + nx, 0.0f);
+                const float bb = (float)(2 * W + 2) / 64.0f / 262144.0f;
+                float ub = est < nx * (1.0f / 6.0f)
+                               ? (est * (1.0f + 3.0f / 900.0f + 6.0f * PSH_LQ_GAMMA) + bb) * (1.0f + 1e-6f)
+                               : (est + nx * (3.0f / 900.0f) + bb) * (1.0f + 2.0f / 900.0f + 1.0e-5f + 6.0f * PSH_LQ_GAMMA) * (1.0f + 1e-6f);
                 const float inv = __uint_as_float((unsigned)(127 - sexp) << 23);
                 ub = ub * inv * inv;
                 if (!(ub == ub)) ub = __uint_as_float(PSH_INF_BITS);      // NaN data: the unit carries no information

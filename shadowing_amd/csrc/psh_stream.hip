@@ -932,8 +932,10 @@ __global__ __launch_bounds__(PSH_SCAN_THREADS) void stream_scan_q_kernel(ScanArg
 // banded product with the shifted query on the matrix cores -- and gives an UPPER bound of its smallest acc per query, exactly
 // scan_lq_kernel's BOOT construction (psh_lq.hip: the C operand is E^ + gamma S, the bound (t^ + nx~)(1 + 3 a + 6 gamma) + b, the
 // query's fragments eight shifted copies of -2 x~ under a scale that needs the query alone: max|x| 2^s < 8).  The rank-th smallest
-// upper bound is a level with at least `rank` windows below it, as the rank-th smallest exact minimum is; it sits a few per mille
-// higher (1 + 3 a) and admits ~20 % more candidates at W = 126.  The tail is stream_sample_finish.
+// upper bound is a level with at least `rank` windows below it, as the rank-th smallest exact minimum is; it sits half a per cent
+// higher and admits ~30 % more candidates at W = 126.  A unit that holds a near-match (its estimate below nx~ / 6: smooth
+// ensembles, where the bound would be the correlation's error term alone) is sampled with the exact chains instead.  The tail is
+// stream_sample_finish.
 // NWP: 1 (one query: 13-15 KB of LDS and <= 128 VGPRs, beside a scan block up to W ~ 200) or 4 (two / three queries).
 template <int NKS, int NWP>
 __device__ __forceinline__ void stream_sample_long_body(const ScanArgs& a, const FusedArgs& f) {
@@ -1080,6 +1082,7 @@ __device__ __forceinline__ void stream_sample_long_body(const ScanArgs& a, const
         }
         const int nvalid = a.Tp - seg_start;
         auto ld = [](const _Float16* p) { return *reinterpret_cast<const f16x8*>(p); };
+        bool loose = false;                                                   // (uniform)
 #pragma unroll 1
         for (int q = 0; q < nq; ++q) {
             f32x16 c = ce;
@@ -1100,15 +1103,52 @@ __device__ __forceinline__ void stream_sample_long_body(const ScanArgs& a, const
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off, 64));
-            // an upper bound of the smallest acc of the unit: acc~ <= (t^ + nx~)(1 + 3 a + 6 gamma) + b, back to the data's scale
-            // (scan_lq_kernel's BOOT; t^ + nx~ < 0 cannot be a true value: the bound is then b alone)
-            float ub = (fmaxf(mn + nxq[q], 0.0f) * (1.0f + 3.0f / 900.0f + 6.0f * PSH_LONG_GAMMA) + (float)(2 * W + 2) / 64.0f / 262144.0f) * (1.0f + 1e-6f);
+            // An upper bound of the smallest acc of the unit (scan_lq_kernel's BOOT has the derivation):
+            //     acc~ (1 - 2 a) <= t^ + nx~ (1 + 3 a) + b,   back to the data's scale.
+            // A unit whose estimate t^ + nx~ is below nx~ / 6 -- a near-match: smooth ensembles -- would get a bound made of the
+            // 3 a nx~ term alone: such a unit is sampled with the exact chains below instead.
+            const float nx = nxq[q];
+            const float est = fmaxf(mn + nx, 0.0f);
+            if (est < nx * (1.0f / 6.0f)) loose = true;                       // (NaN: not loose -- the bound comes out NaN -> +inf)
+            float ub = (est + nx * (3.0f / 900.0f) + (float)(2 * W + 2) / 64.0f / 262144.0f)
+                       * (1.0f + 2.0f / 900.0f + 1.0e-5f + 6.0f * PSH_LONG_GAMMA) * (1.0f + 1e-6f);
             const float inv = __uint_as_float((unsigned)(127 - sexp) << 23);
             ub = ub * inv * inv;
             if (!(ub == ub)) ub = __uint_as_float(PSH_INF_BITS);              // NaN data: the unit carries no information
             if (lane == 0) st_sc1(&hdr->minima[(size_t)q * f.units_stride + u], __float_as_uint(ub));   // write-through
         }
         wave_lds_fence();                                                     // all lanes done with the arrays before they are overwritten
+        if (__builtin_amdgcn_readfirstlane(loose ? 1 : 0)) {
+            // the unit again, as stream_sample_kernel samples it: its fp32 samples (an L2 hit) into the scratch -- prefix sums and
+            // rows are dead --, the exact chains of the lane's 16 windows, the exact minimum over the unit
+            {
+                Stage s2;
+                stage_load<false>(s2, a.dataset + (f.boot_row0 + (int64_t)ri * f.boot_row_stride) * a.T, a.T, seg_start, nfloat, lane);
+                stage_store<false>(s2, sp, nfloat, lane);
+            }
+            wave_lds_fence();
+            const int t_lane = seg_start + PSH_L * lane;
+            int nv = a.Tp - t_lane;
+            nv = nv < 0 ? 0 : (nv > PSH_L ? PSH_L : nv);
+#pragma unroll 1
+            for (int q = 0; q < nq; ++q) {
+                float acc[PSH_L];
+                accumulate16<0, false>(sp, lane, (const_f32p)a.queries + (size_t)q * W, W, acc);
+                float mq = __uint_as_float(PSH_INF_BITS);
+#pragma unroll
+                for (int i = 0; i < PSH_L; ++i) mq = (i < nv) ? fminf(mq, acc[i]) : mq;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) mq = fminf(mq, __shfl_xor(mq, off, 64));
+                if (!(mq == mq)) mq = __uint_as_float(PSH_INF_BITS);
+                if (lane == 0) st_sc1(&hdr->minima[(size_t)q * f.units_stride + u], __float_as_uint(mq));
+            }
+            wave_lds_fence();
+            {   // (the rows held fp32 samples: every slot a segment does not write must be finite again)
+                unsigned* z = reinterpret_cast<unsigned*>(a1);
+                for (int i = lane; i < NROWS * PSH_LONG_ROW / 2; i += 64) z[i] = 0u;
+            }
+            wave_lds_fence();
+        }
         u = un;
     }
     stream_sample_finish<NWP>(a, f, sp, W, nq, nbu, false, lane, wave);
