@@ -789,9 +789,9 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
             const Tuning tn = tuning();
             const int64_t nseg = (p.Tp + PSH_SEG - 1) / PSH_SEG;
             // a thinner sample than the fused launch's: its megabytes are HBM traffic beside ANOTHER step's scan here.  2048
-            // units (what the exchange area holds, split between the queries); the level is the (2k x sampled fraction + 8)-th
-            // smallest minimum: the k best windows of the ensemble put 2k/2 x fraction = 16 expected minima below their level,
-            // P(Poisson(16) >= 40) = 3e-7 that fewer than k windows lie below the estimate (-> PSH_STATUS_RETRY)
+            // units (what the exchange area holds, split between the queries); the level is the r2p-th smallest minimum (below): the
+            // k best windows of the ensemble put kf = k x sampled fraction = 16 expected minima below their level at the benchmark's
+            // sizes, P(Poisson(16) >= 40) = 3e-7 that fewer than k windows lie below the estimate (-> PSH_STATUS_RETRY)
             int64_t units_cap = tn.stream_units < 2048 ? tn.stream_units : 2048;     // (the sample kernel keeps a query's minima in registers: <= 2048)
             // (a long window's exact sample chains cost W / 20 of the benchmark's: half the units -- the level's rank stays at its
             //  floor of 24 with 8 minima expected below the k-th distance)
