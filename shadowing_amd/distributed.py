@@ -221,11 +221,46 @@ class ShardedPathShadowing:
         if self._comm is None:
             G = self.world_size
             rank = dist.get_rank(self.group) if dist.is_initialized() else 0
-            box = [_native.comm_unique_id() if rank == 0 else None]
+            err = None
+            box = [None]
+            if rank == 0:
+                try:
+                    box[0] = _native.comm_unique_id()
+                except Exception as e:                               # noqa: BLE001 -- (RCCL could not be opened: the ranks hear of it below)
+                    err = e
             if G > 1:
                 dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
                                            group=self.group)
-            self._comm = _native.Comm(self.device, G, rank, box[0])
+            # Created collectively, and agreed on collectively: a rank whose library cannot open RCCL or whose ncclCommInitRank
+            # fails (first contact with a node's links) must not leave the others inside the next all-gather.  Every rank reports
+            # through the torch.distributed group that is there anyway; one failure -> every rank drops its communicator and the
+            # object serves the exchange with torch.distributed.all_gather (exchange="torch") from here on, with ONE warning.
+            if box[0] is None:
+                err = err or _native.NativeLibraryError("rank 0 could not make an RCCL unique id")
+            else:
+                try:
+                    self._comm = _native.Comm(self.device, G, rank, box[0])
+                except Exception as e:                               # noqa: BLE001 -- whatever the library raised: agree first
+                    err = e
+            if G > 1:
+                flag = torch.tensor([0 if err is None else 1], dtype=torch.int32,
+                                    device=self.device if dist.get_backend(self.group) == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+                failed = bool(int(flag.item()))
+            else:
+                failed = err is not None
+            if failed:
+                if self._comm is not None:
+                    _close_comm(self._comm, self.device)
+                    self._comm = None
+                if self.exchange == "library":
+                    raise _native.NativeLibraryError(f'exchange="library": psh_comm_create failed on a rank ({err!r})')
+                import warnings
+                warnings.warn("ShardedPathShadowing: the library's RCCL communicator could not be created on every rank "
+                              f"({err!r} on this one); the exchange runs through torch.distributed.all_gather instead",
+                              RuntimeWarning, stacklevel=3)
+                self.exchange = "torch"
+                return None
             # the communicator belongs to libpsh_hip.so: it goes away with this object (or at interpreter exit)
             self._comm_finalizer = weakref.finalize(self, _close_comm, self._comm, self.device)
             # not at interpreter exit: a synchronize / ncclCommDestroy there hangs when a peer rank is already gone with a
@@ -386,6 +421,8 @@ class ShardedPathShadowing:
         ring = self._fast.get(key)
         if ring is None:
             comm = self._library_exchange()
+            if comm is None:                                 # (no communicator on some rank: the general path, torch's all-gather)
+                return None
             n = len(self._scan_streams)
             sorted_merge = _native.merge_sorted_supported(G, k)
             ring = [_native.PreparedStep(comm, self._rows, self.row_offset, B, W, k, h, self._scan_ws[j % n], self._side,
@@ -441,6 +478,8 @@ class ShardedPathShadowing:
             sorted_merge = _native.merge_sorted_supported(G, k)
             library = exchange and self._use_library(B, k)
             comm = self._library_exchange() if library else None
+            if library and comm is None:                     # (no communicator on some rank: torch's all-gather, every rank alike)
+                library = False
             # private scan streams: nothing in the scan needs co-residency, so no compute unit is reserved for the collective
             mode = ((_native.FLAG_OVERLAP | (_native.FLAG_RESERVE_CUS if self._reserve else 0)) if ws is not None
                     else (_native.FLAG_RESERVE_CUS if library else 0))

@@ -197,6 +197,56 @@ def test_sharded_class_on_private_streams(hip_device, oracle_mod, tmp_path):
         dist.destroy_process_group()
 
 
+def test_sharded_class_falls_back_when_the_communicator_cannot_be_created(hip_device, oracle_mod, tmp_path, monkeypatch):
+    """A rank whose library cannot create its RCCL communicator (RCCL not to be opened, ncclCommInitRank failing on first contact
+    with a node's links): the ranks agree through the torch.distributed group, every one drops to torch's all-gather with ONE
+    warning, and the results are the oracle's -- pipelined device queries (the lean ring must NOT be used) and a checked batch.
+    exchange="library" raises instead."""
+    import warnings
+    import torch.distributed as dist
+    import shadowing_amd as sa
+    from shadowing_amd import _native
+    from shadowing_amd.distributed import ShardedPathShadowing
+
+    class Broken:
+        def __init__(self, *a, **kw):
+            raise _native.NativeLibraryError("psh_comm_create: simulated failure")
+    monkeypatch.setattr(_native, "Comm", Broken)
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/pg", rank=0, world_size=1, device_id=hip_device)
+    objs = []
+    try:
+        big = syn.dataset(8192, 2048, 5650)
+        obj = ShardedPathShadowing(sa.Identity(20), sa.RelativeMSE(), big, 0, sa.PredictionContext(20), device=hip_device,
+                                   always_exchange=True, streams=3)
+        objs.append(obj)
+        qs = [torch.tensor(syn.gbm_log_returns((1, 20), 5651 + i)).to(hip_device) for i in range(5)]
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            outs = []
+            for qi in qs:
+                dd, ii = obj.scan_begin(qi, 200, check=False).finish()
+                outs.append((dd.clone(), ii.clone()))
+            torch.cuda.synchronize()
+        assert sum("communicator could not be created" in str(w.message) for w in rec) == 1, [str(w.message) for w in rec]
+        assert obj.exchange == "torch" and not obj._fast
+        for qi, (dd, ii) in zip(qs, outs):
+            od, oi = oracle_mod.scan_topk(big, qi.cpu().numpy(), 200, h=20)
+            assert_exact(dd.cpu().numpy(), ii.cpu().numpy(), od, oi, "fallback exchange")
+        d, paths, idx = obj.shadow(syn.rolling_queries(3, 20, 5660), 128)
+        od, opaths, oidx = oracle_mod.shadow(big, syn.rolling_queries(3, 20, 5660), 128, 20)
+        assert_exact(d, idx, od, oidx, "fallback exchange, batch")
+        assert np.array_equal(paths, opaths)
+        strict = ShardedPathShadowing(sa.Identity(20), sa.RelativeMSE(), big, 0, sa.PredictionContext(20), device=hip_device,
+                                      always_exchange=True, exchange="library")
+        objs.append(strict)
+        with pytest.raises(_native.NativeLibraryError):
+            strict.shadow(syn.rolling_queries(1, 20, 5661), 64)
+    finally:
+        for o in objs:
+            o.close()
+        dist.destroy_process_group()
+
+
 def test_sharded_class_lean_steps(hip_device, oracle_mod, tmp_path):
     """The lean form of a step (ShardedPathShadowing._fast_step: prepared argument lists, a ring of buffers, two ctypes
     calls): device queries, check=False, library exchange -- 20 single queries pipelined three deep, then a batch of 4."""
