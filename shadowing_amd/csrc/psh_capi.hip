@@ -643,9 +643,11 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     // (tools/long_batch_probe.py).  Status words stay per query; a RETRY of any step sends the caller's WHOLE call to
     // PSH_FLAG_NO_FUSE, as the protocol says.
     const int long_q = long_queries_per_step(W);
-    // four queries and more with a long window: ONE pass per chunk of queries of the batched long-window scan (psh_lq.hip) through
-    // the separate launches' pipeline, instead of the loop of steps below
-    const bool use_lq = !ker && p.Tp > 1 && B >= 4 && scan_lq_supported(W, B, T) && !(flags_of(profile) & (PSH_FLAG_FILTER_VALU | PSH_FLAG_NO_FUSE | PSH_FLAG_LONG_LOOP));
+    // four queries and more with a long window -- or two / three that do not ride one pass of the three launches (W > 97 / 145:
+    // their tables do not fit beside the scan's rows) --: ONE pass per chunk of queries of the batched long-window scan (psh_lq.hip)
+    // through the separate launches' pipeline, instead of the loop of steps below
+    const bool use_lq = !ker && p.Tp > 1 && (B >= 4 || (long_q > 0 && B > long_q)) && scan_lq_supported(W, B, T) &&
+                        !(flags_of(profile) & (PSH_FLAG_FILTER_VALU | PSH_FLAG_NO_FUSE | PSH_FLAG_LONG_LOOP));
     const int per_step = !ker && p.Tp > 1 ? (long_q > 0 && B > long_q ? long_q : (W >= 26 && W <= 33 && B > PSH_STREAM_MAX_Q ? PSH_STREAM_MAX_Q : 0)) : 0;
     // (the loop pays only when its sub-calls get the three launches: 5 k candidates in a query's list of 65536, a sample of 256
     //  units and more -- a call outside that would be B / 3 passes with the vector-ALU filter instead of one; psh_profile then
