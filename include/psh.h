@@ -227,10 +227,9 @@ int psh_query_norm(int device, void* stream, const float* queries, int B, int W,
  * with the band as a K-loop over ceil((W + 46) / 16) steps, flag or no flag -- stream_scan_long_kernel; round 6: the window
  * energies from fp32 prefix sums, one MFMA a step), for two or three queries with W <= 33 or a long window (they ride one pass
  * of the three launches: three up to W = 97, two up to W = 145 -- what fits LDS), for
- * larger batches with W <= 25, for four queries and more with 34 <= W <= 256 and for two or three beyond what rides one pass --
+ * larger batches with W <= 25, for four queries and more with 26 <= W <= 256 and for two or three beyond what rides one pass --
  * round 6: the batched long-window scan (psh_lq.hip) through the separate launches, one pass per chunk of queries;
- * PSH_FLAG_LONG_LOOP: round 5's loop of steps --
- * and for batches with 26 <= W <= 33 as a loop of three-query steps inside the call (status words per query as always);
+ * PSH_FLAG_LONG_LOOP: round 5's loop of two- or three-query steps inside the call -- (status words per query as always);
  * PSH_FLAG_FILTER_VALU / PSH_FLAG_NO_FUSE calls use the vector-ALU filter or the exact chains.  Results do not depend on
  * which.
  */

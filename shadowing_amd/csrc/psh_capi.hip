@@ -638,6 +638,8 @@ static int scan_topk_impl(int device, void* stream, const float* dataset, int64_
     //   34 <= W <= 256: up to three queries per step (the three launches with the long-window scan, psh_stream.hip: the
     //                   queries share the pass, the conversion and the energies' MFMAs);
     //   26 <= W <= 33, four queries and more: three queries per step (the three launches' 2-3 query form).
+    // Round 6: what is left to the loop is PSH_FLAG_LONG_LOOP and shapes the batched long-window scan does not take (use_lq below
+    // serves four queries and more with 26 <= W <= 256 and two / three that do not ride one pass).
     // The one-pass vector-ALU filter costs W fma per window and query: R = 32768, T = 4096, W = 126 -- 2 / 4 / 16 / 64 queries
     // 1.14 / 2.19 / 8.6 / 33.6 ms in one pass, 0.34 / 0.65 / 2.6 / 10.6 ms as a loop; W = 252: 2.2 .. 67 against 0.50 .. 16.2 ms
     // (tools/long_batch_probe.py).  Status words stay per query; a RETRY of any step sends the caller's WHOLE call to

@@ -471,7 +471,9 @@ __global__ __launch_bounds__(PSH_LQ_THREADS) void scan_lq_kernel(ScanArgs a) {
     }
 }
 
-bool scan_lq_supported(int W, int B, int64_t T) { return W >= 34 && W <= 256 && B >= 2 && B <= PSH_MAX_B_PER_LAUNCH && T < (1ll << 27); }
+// (W >= 26: nothing in the kernel needs a window longer than the batched 8-bit / f16 scans' bands reach -- W <= 25 is theirs --;
+//  batches with 26 <= W <= 33 were a loop of three-query steps until late in round 6)
+bool scan_lq_supported(int W, int B, int64_t T) { return W >= 26 && W <= 256 && B >= 2 && B <= PSH_MAX_B_PER_LAUNCH && T < (1ll << 27); }
 
 // queries a chunk takes: what puts its tables in LDS beside the eight waves' buffers
 int scan_lq_chunk(int W, int B) {

@@ -213,10 +213,10 @@ def test_batched_scans_admit_exactly_the_windows_below_the_level(hip_device, ora
 @pytest.mark.parametrize("kind", ADVERSARIAL)
 def test_batched_long_window_scan_admits_exactly_the_windows_below_the_level(hip_device, oracle_mod, kind):
     """scan_lq_kernel (round 6, psh_lq.hip): 34 queries -- more than one chunk of queries at every length -- with windows of 64,
-    126 and 252 samples; the energies from fp32 prefix sums (the gamma S[p + W] term), the correlation's f16 bound with a = 1 / 900,
+    126, 252 and (batches with 26 <= W <= 33 take this kernel too) 30 samples; the energies from fp32 prefix sums (the gamma S[p + W] term), the correlation's f16 bound with a = 1 / 900,
     one scale per chunk of queries, survivors verified from the wave's queue."""
     heavy = kind in ("plain", "spikes", "planted_matches", "scale_down", "quiet_stretches")
-    for i, (W, h, m) in enumerate([(126, 20, 3000), (64, 0, 10000), (252, 5, 1000)]):
+    for i, (W, h, m) in enumerate([(126, 20, 3000), (64, 0, 10000), (252, 5, 1000), (30, 3, 10000)]):
         if i > 0 and not heavy:
             continue
         ds, q = adversarial(kind, 1024, 2048, 34, W, h, 500 + 3 * i)
