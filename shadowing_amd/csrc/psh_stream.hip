@@ -51,10 +51,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t st_rsrc(const void* base, unsi
 // scan_fused_kernel's phase B in two steps (same formulas, same roundings towards "keep"): the largest scale exponent a
 // query allows -- scale = 2^sexp with max|x| 2^sexp < 8 and tau0 4^sexp <= 4096 -- then, under the step's common scale,
 // the query's rejection threshold.
+__device__ inline bool stream_sexp_of(unsigned qmaxbits, float tau0, int* sexp_out);
 __device__ inline bool stream_sexp(const_f32p xq, int W, float tau0, int* sexp_out) {
     unsigned qmaxbits = 0u;
 #pragma unroll 1
     for (int j = 0; j < W; ++j) qmaxbits = max(qmaxbits, __float_as_uint(fabsf(xq[j])));
+    return stream_sexp_of(qmaxbits, tau0, sexp_out);
+}
+// (qmaxbits: the bit pattern of the query's largest |x|)
+__device__ inline bool stream_sexp_of(unsigned qmaxbits, float tau0, int* sexp_out) {
     if (!(tau0 > 0.0f && tau0 < __uint_as_float(PSH_INF_BITS) && qmaxbits < PSH_INF_BITS)) return false;
     // (exponents of the bit patterns: value in [2^(e-1), 2^e))
     const int et = (int)((__float_as_uint(tau0) >> 23) & 255u) - 126;
@@ -67,10 +72,15 @@ __device__ inline bool stream_sexp(const_f32p xq, int W, float tau0, int* sexp_o
     *sexp_out = sexp;
     return true;
 }
+__device__ inline bool stream_threshold_of(double nxs, int W, float tau0, float sc, float* thr_out);
 __device__ inline bool stream_threshold(const_f32p xq, int W, float tau0, float sc, float* thr_out) {
     double nxs = 0.0;
 #pragma unroll 1
     for (int j = 0; j < W; ++j) { const double vv = (double)xq[j] * (double)sc; nxs += vv * vv; }
+    return stream_threshold_of(nxs, W, tau0, sc, thr_out);
+}
+// (nxs: the sum of (x_j sc)^2 in double)
+__device__ inline bool stream_threshold_of(double nxs, int W, float tau0, float sc, float* thr_out) {
     // (b: the absolute part of the bound -- f16 subnormals, one unit of 2^-24 per product -- grows with the taps: 2^-18 covers the
     //  2 W + 1 = 41 .. 67 terms of W <= 33; a long window takes (2 W + 2) / 64 of it)
     // a: the relative part.  W <= 33: 2^-9 covers the f16 roundings of x~, y~ AND (y~^2)^ plus the fp32 accumulation of both banded
@@ -94,9 +104,13 @@ __host__ __device__ inline int stream_ksteps(int W) { return W <= 33 ? 4 : (W + 
 // rank-th smallest minimum (or the caller's hint), then ONE f16 scale for the step, every query's rejection threshold and the
 // scan's B fragments of the shifted query (scan_fused_kernel's phase B).  Shared by stream_sample_kernel (exact minima) and
 // stream_sample_long_kernel (matrix-core upper bounds of the minima, long windows): `tile` is the wave's scratch (>= 1024 words).
+// `xs` (nullable; a long window's launch passes nq x W floats of LDS that are dead by now): the last block stages the queries
+// there and runs the per-query work -- max|x|, nx~, the scan's fragment table -- a lane a sample instead of a serial loop over the
+// window by lane 0 with every sample fetched from memory: 10 us of a 25 us launch at W = 126, twice that at 252.
 template <int NWP>
 __device__ __forceinline__ void stream_sample_finish(const ScanArgs& a, const FusedArgs& f, float* tile, const int W, const int nq,
-                                                     const unsigned nbu, const bool hinted, const int lane, const int wave) {
+                                                     const unsigned nbu, const bool hinted, const int lane, const int wave,
+                                                     float* xs = nullptr) {
     __shared__ int sh_last, sh_sexp[4], sh_armed[4];
     __shared__ float sh_tau0[4];
     FusedHdr* hdr = f.hdr;
@@ -110,6 +124,10 @@ __device__ __forceinline__ void stream_sample_finish(const ScanArgs& a, const Fu
     }
     if (NWP > 1) __syncthreads(); else wave_lds_fence();
     if (!sh_last) return;
+    if (xs) {
+        for (int e = (int)threadIdx.x; e < nq * W; e += 64 * NWP) xs[e] = a.queries[e];
+        if (NWP > 1) __syncthreads(); else wave_lds_fence();
+    }
 
     // ---- the last block, per query: rank-th smallest minimum -> tau0 (its bucket's upper edge) and the scale it allows
     unsigned* hist = reinterpret_cast<unsigned*>(tile);
@@ -204,7 +222,14 @@ __device__ __forceinline__ void stream_sample_finish(const ScanArgs& a, const Fu
         }
         const float tau0 = hinted ? f.tau_hint[q] : __uint_as_float(edge) * PSH_TAU_MARGIN;
         int sx = 0;
-        if (armed && !stream_sexp((const_f32p)a.queries + (size_t)q * W, W, tau0, &sx)) armed = false;   // (uniform: scalar inputs)
+        if (armed && xs) {
+            // (stream_sexp with the query's largest |x| taken a lane a sample: a maximum does not depend on the order)
+            unsigned mb = 0u;
+            for (int j = lane; j < W; j += 64) mb = max(mb, __float_as_uint(fabsf(xs[(size_t)q * W + j])));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, off, 64));
+            if (!stream_sexp_of(mb, tau0, &sx)) armed = false;
+        } else if (armed && !stream_sexp((const_f32p)a.queries + (size_t)q * W, W, tau0, &sx)) armed = false;   // (uniform: scalar inputs)
         if (lane == 0) { sh_tau0[q] = tau0; sh_sexp[q] = sx; sh_armed[q] = armed ? 1 : 0; }
     }
     if (NWP > 1) __syncthreads(); else wave_lds_fence();
@@ -218,9 +243,18 @@ __device__ __forceinline__ void stream_sample_finish(const ScanArgs& a, const Fu
         const const_f32p xq = (const_f32p)a.queries + (size_t)q * W;
         const float tau0q_ = sh_tau0[q];
         float thr = 0.0f;
-        if (armed && !stream_threshold(xq, W, tau0q_, scale, &thr)) sh_armed[q] = 0;
+        if (armed && xs) {
+            // (stream_threshold with nx~ summed a lane a sample, in double: whatever the order, its rounding is 10^-16 of the sum
+            //  where the formula keeps 10^-12 in hand)
+            double part = 0.0;
+            for (int j = lane; j < W; j += 64) { const double vv = (double)xs[(size_t)q * W + j] * (double)scale; part += vv * vv; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+            if (!stream_threshold_of(part, W, tau0q_, scale, &thr)) sh_armed[q] = 0;
+        } else if (armed && !stream_threshold(xq, W, tau0q_, scale, &thr)) sh_armed[q] = 0;
         if (lane == 0) {
-            const float s2 = sumsq8([&](int j) { return xq[j]; }, W);
+            // (||x||: the reference's order -- sumsq8 --, from the staged copy when there is one)
+            const float s2 = xs ? sumsq8([&](int j) { return xs[(size_t)q * W + j]; }, W) : sumsq8([&](int j) { return xq[j]; }, W);
             ctl->tau2_bits[q] = __float_as_uint(tau0q_);
             ctl->thr2_bits[q] = __float_as_uint(thr);
             ctl->xn_bits[q] = __float_as_uint(f.qnorm_in ? f.qnorm_in[q] : __builtin_sqrtf(s2));
@@ -237,7 +271,7 @@ __device__ __forceinline__ void stream_sample_finish(const ScanArgs& a, const Fu
             for (int i = 0; i < 8; ++i) {
                 const int j = 16 * s + 8 * hk + i - n;
                 const bool in = j >= 0 && j < W;
-                const float xv = a.queries[(size_t)q * W + (in ? j : 0)];
+                const float xv = xs ? xs[(size_t)q * W + (in ? j : 0)] : a.queries[(size_t)q * W + (in ? j : 0)];
                 b[i] = (_Float16)(in ? -2.0f * (xv * scale) : 0.0f);
             }
             *reinterpret_cast<f16x8*>(hdr->bxtab + ((size_t)q * nks * 64 + (size_t)(s * 64 + lane)) * 8) = b;    // (nks = 4 up to W = 33)
@@ -1151,7 +1185,10 @@ __device__ __forceinline__ void stream_sample_long_body(const ScanArgs& a, const
         }
         u = un;
     }
-    stream_sample_finish<NWP>(a, f, sp, W, nq, nbu, false, lane, wave);
+    // (the rows of the block's first wave -- 620 floats and more, >= 3 W -- take the staged queries of the launch's tail; with four
+    //  waves the others may still be sampling: the barrier in front of the finish's ticket is their last use of anything here)
+    stream_sample_finish<NWP>(a, f, sp, W, nq, nbu, false, lane, wave,
+                              reinterpret_cast<float*>(reinterpret_cast<_Float16*>(reinterpret_cast<float*>(tab + (size_t)nq * QS) + PSH_LONG_SFLOATS)));
 }
 // one query: 128 registers, so that the wave fits beside the four scan waves (96 registers each) of another step on its SIMD
 template <int NKS>
