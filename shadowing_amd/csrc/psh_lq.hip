@@ -1,4 +1,5 @@
-// psh_lq.hip -- BATCHED queries with a LONG window (gfx950): B >= 4 queries, 34 <= W <= 256, Identity + RelativeMSE (reference
+// psh_lq.hip -- BATCHED queries with a LONG window (gfx950): B >= 4 queries with 26 <= W <= 256 (two / three when their tables do
+// not ride one pass of the three launches, psh_stream.hip: W > 97 / 145), Identity + RelativeMSE (reference
 // path_embedding.py:135-139 takes any Identity(dimension); predict() loops over many query dates, path_shadowing.py:286-301).
 // Part of libpsh_hip.so.  Until round 6 such a call was a loop of two- or three-query passes of the single-query long-window
 // scan (psh_stream.hip): W = 126, 64 queries = 32 passes over the ensemble, 6.4 ms.  Here ONE pass per chunk of queries:
